@@ -1,0 +1,153 @@
+#!/usr/bin/env python
+"""bench.py — VampNet `vamp()` hot path on N MI355X (contract: see the task statement / DESIGN.md §Measurement).
+
+A "step" = one full Interface.vamp() (coarse 12 sampling steps + coarse-to-fine 4 chunks x 2 steps) over a batch of
+synthetic 10 s clips (T = 575 tokens, 14 codebooks) that is already resident in HBM.  Workload = BASELINE.json
+configs[2] ("coarse + c2f full vamp(), batch=8, 10 s clips, typical_filtering=True, 1xMI355X"); with --gpus N each
+GPU keeps 8 clips (weak scaling; N = 8 is configs[3], batch 64 sharded 8-way with one all-gather of the tokens).
+Random-init weights of the real architecture (no checkpoints in this image), device Philox RNG, exact-fp32 MFMA.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TOKENS_PER_CLIP = 14 * 575
+PEAK_F32_MFMA_TF = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
+
+
+def cpu_baseline(threads=None):
+    """The oracle (a port of the reference's torch-CPU path, bitwise-pinned to it) timed on the host cores on a
+    bounded sample: 2 coarse sampling steps (B=1, T=575) + 2 c2f steps (B=1, T=173), extrapolated to the 12 + 8
+    steps of one clip (every step costs the same: one forward + sampling)."""
+    from oracle import vampnet_oracle as O, weights as W
+    if threads:
+        torch.set_num_threads(threads)
+    cores = torch.get_num_threads()
+    cb = W.synth_codebooks()
+    out = {}
+    for name, dims, T, seed in (("coarse", W.COARSE_DIMS, 575, 0), ("c2f", W.C2F_DIMS, 173, 1)):
+        sd = W.synth_state_dict(dims, seed)
+        z = W.synth_codes(1, dims["n_codebooks"], T, seed=2)
+        mask = torch.ones_like(z)
+        mask[:, :dims["n_cond"]] = 0
+        O.generate(sd, dims, cb, z, mask, sampling_steps=1, seed=0)            # warm-up
+        t0 = time.perf_counter()
+        O.generate(sd, dims, cb, z, mask, sampling_steps=2, seed=0)
+        out[name] = (time.perf_counter() - t0) / 2
+        del sd
+    clip_s = 12 * out["coarse"] + 8 * out["c2f"]
+    return {"value": TOKENS_PER_CLIP / clip_s, "unit": "codec-tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle.generate: 2 coarse steps (B=1,T=575, {out['coarse']:.3f} s/step) + 2 c2f steps "
+                      f"(B=1,T=173, {out['c2f']:.3f} s/step), extrapolated to 12+8 steps = {clip_s:.2f} s/clip"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-per-gpu", type=int, default=8)
+    ap.add_argument("--coarse-steps", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(device))
+        pg = dist.group.WORLD
+
+    from oracle import weights as W            # synthetic weights/inputs only (no oracle compute on this path)
+    from vampnet_amd.interface import Interface
+    from tests.gpu_common import SynthCodec, model_kwargs
+
+    cb = W.synth_codebooks()
+    itf = Interface.from_state_dicts(SynthCodec(cb), W.synth_state_dict(W.COARSE_DIMS, 0), model_kwargs(W.COARSE_DIMS),
+                                     W.synth_state_dict(W.C2F_DIMS, 1), model_kwargs(W.C2F_DIMS), device=device,
+                                     max_batch=args.batch_per_gpu, rng="device", process_group=pg)
+    B = args.batch_per_gpu * world
+    codes = W.synth_codes(B, 14, 575, seed=2).to(device)
+    torch.manual_seed(0)
+    mask = itf.build_mask(codes)                # periodic_prompt=7, upper_codebook_mask=3 (hello.py / BASELINE cfg)
+    kw = dict(batch_size=B, _sampling_steps=args.coarse_steps, typical_filtering=True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        itf.vamp(codes, mask, device_seed=100 + i, **kw)
+    barrier()
+    if not args.no_kernel_events:
+        itf.engine.profile_begin(4000 * max(args.steps, 1))
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = itf.vamp(codes, mask, device_seed=i, **kw)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = itf.engine.profile_end() if not args.no_kernel_events else None
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert out.shape == (B, 14, 575)
+
+    if rank == 0:
+        tokens = B * TOKENS_PER_CLIP * args.steps
+        res = {
+            "metric": "codec-tokens/s, coarse+c2f vamp(), 10 s clips", "value": tokens / elapsed,
+            "unit": "codec-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (random-init weights of the real architecture, "
+            "random codes, periodic-7 prompt mask)",
+            "config": {"workload": "BASELINE configs[2]: Interface.vamp() coarse(12 steps)+c2f(4x2 steps), "
+                                   f"batch {args.batch_per_gpu}/GPU x 10 s @ 44.1 kHz (T=575, 14 codebooks), "
+                                   "typical_filtering=True, device RNG",
+                       "global_batch": B, "coarse_steps": args.coarse_steps,
+                       "parallelism": f"batch-shard x{world}" if world > 1 else "single GPU",
+                       "s_per_clip": elapsed / args.steps / B * world},
+        }
+        if prof is not None:
+            n, ms, fl = prof["gemm"]
+            an, ams, afl = prof["attention"]
+            res["roofline"] = {"bound": "mfma", "kernel": "vn_gemm_f32_kernel", "achieved": fl / (ms * 1e-3) / 1e12 if ms else None,
+                               "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+                               "frac": (fl / (ms * 1e-3) / 1e12) / PEAK_F32_MFMA_TF if ms else None,
+                               "traffic": None, "launches": int(n), "avg_launch_us": 1e3 * ms / n if n else None,
+                               "gemm_time_frac": ms / (1e3 * elapsed) if elapsed else None,
+                               "attention": {"launches": int(an), "avg_launch_us": 1e3 * ams / an if an else None,
+                                             "achieved": afl / (ams * 1e-3) / 1e12 if ams else None}}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

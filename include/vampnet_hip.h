@@ -1,0 +1,172 @@
+/*
+ * vampnet_hip.h — C ABI of libvampnet_hip.so, the MI355X (gfx950) engine for the VampNet
+ * `Interface.vamp()` hot path.
+ *
+ * The reference (hugofloresgarcia/vampnet) is pure Python/PyTorch and has NO FFI seam; the
+ * path sits behind the Python class `Interface` (vampnet/interface.py:54-575).  This header
+ * is the seam a maintainer would bind instead of the torch ops (see INTEGRATION.md for the
+ * ctypes stub).  Each entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *   - every pointer marked "dev" is a DEVICE pointer owned by the caller (e.g. tensor.data_ptr()
+ *     of a torch-ROCm tensor); the library never frees or retains it past the call, except the
+ *     weight blob of vn_model_create which must outlive the model.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all
+ *     work is enqueued asynchronously on it; nothing synchronises the device.
+ *   - every function returns VN_OK (0) or a negative vn_status; vn_last_error(ctx) gives text.
+ *     No C++ exception crosses the ABI.  No allocation happens after *_create (workspace is sized
+ *     at vn_model_create from dims.max_batch/max_T), so calls are hipGraph-capturable.
+ *   - a vn_ctx and the models created from it may be used by ONE host thread at a time.
+ *   - all arithmetic is fp32 (exact-f32 MFMA v_mfma_f32_32x32x2_f32 / 16x16x4_f32) — the parity
+ *     mode of the CPU reference.
+ *   - tokens are int64 at the boundary like the reference's LongTensors; MASK == dims.vocab.
+ */
+#ifndef VAMPNET_HIP_H
+#define VAMPNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vn_ctx vn_ctx;
+typedef struct vn_model vn_model;
+
+typedef enum {
+    VN_OK = 0,
+    VN_ERR_INVALID = -1,     /* bad argument / unsupported shape */
+    VN_ERR_HIP = -2,         /* a HIP runtime call failed */
+    VN_ERR_OOM = -3,
+    VN_ERR_UNSUPPORTED = -4
+} vn_status;
+
+/* Model hyper-parameters = VampNet.__init__ kwargs (vampnet/modules/transformer.py:535-552). */
+typedef struct {
+    int32_t n_layers;      /* 20 coarse / 16 c2f                    */
+    int32_t n_heads;       /* 20; d_model / n_heads must be 64      */
+    int32_t d_model;       /* 1280                                  */
+    int32_t n_codebooks;   /* 4 coarse / 14 c2f                     */
+    int32_t n_cond;        /* n_conditioning_codebooks: 0 / 4       */
+    int32_t vocab;         /* 1024 (MASK token id == vocab)         */
+    int32_t latent_dim;    /* 8                                     */
+    int32_t num_buckets;   /* 32  (transformer.py:96)               */
+    int32_t max_distance;  /* 128 (transformer.py:97)               */
+    float   eps;           /* 1e-6 RMSNorm (transformer.py:38)      */
+    int32_t max_batch;     /* workspace sizing                      */
+    int32_t max_T;         /* workspace sizing (575 / 173)          */
+} vn_dims;
+
+/* Packed fp32 weight blob.  The library defines the layout; the host packer asks for offsets.
+ * tensor ids (layer = -1 for non-layer tensors):                                              */
+enum {
+    VN_W_EMB_TABLES = 0,  /* [C][vocab+1][latent]   codec codebook rows + MASK row (layers.py:134-150) */
+    VN_W_EMB_WT     = 1,  /* [C*latent][D]          embedding.out_proj.weight TRANSPOSED (layers.py:132) */
+    VN_W_EMB_B      = 2,  /* [D]                                                                  */
+    VN_W_REL_BIAS   = 3,  /* [num_buckets][H]       layers.0.self_attn.relative_attention_bias    */
+    VN_W_FINAL_NORM = 4,  /* [D]                    transformer.norm.weight                       */
+    VN_W_CLS_W      = 5,  /* [Cp*vocab][D]  weight-norm folded, rows re-ordered to (c, p)  (transformer.py:596-604,634) */
+    VN_W_CLS_B      = 6,  /* [Cp*vocab]     same row order                                        */
+    VN_W_NORM1      = 7,  /* per layer [D]          norm_1.weight                                 */
+    VN_W_QKV        = 8,  /* per layer [3D][D]      rows: w_qs | w_ks | w_vs  (transformer.py:109-111) */
+    VN_W_WO         = 9,  /* per layer [D][D]       self_attn.fc.weight                           */
+    VN_W_NORM3      = 10, /* per layer [D]          norm_3.weight                                 */
+    VN_W_W1         = 11, /* per layer [4D][D]      feed_forward.w_1.weight, rows interleaved in 32-blocks:
+                             packed row 64*g + i      (i < 32) = original row 32*g + i        (value half p1)
+                             packed row 64*g + 32 + i (i < 32) = original row 2D + 32*g + i   (gate half p2)
+                             so one wave tile holds matching value/gate columns (activations.py:33-35) */
+    VN_W_W2         = 12, /* per layer [D][2D]      feed_forward.w_2.weight                       */
+    VN_W__COUNT     = 13
+};
+
+/* Sampling parameters = VampNet.generate kwargs (transformer.py:687-710). */
+typedef struct {
+    int32_t steps;               /* _sampling_steps                                             */
+    float   temperature;         /* <= 0 behaves as 1.0 (transformer.py:1019-1023)              */
+    float   mask_temperature;    /* 10.5                                                        */
+    double  sample_cutoff;       /* sample iff (i/steps) <= sample_cutoff, compared in double like
+                                    the reference's Python floats (transformer.py:852)          */
+    float   top_p;               /* <= 0 or >= 1: disabled (transformer.py:1001-1016)           */
+    int64_t n0_override;         /* < 0: N0 = masked count over THIS batch (transformer.py:766);
+                                    >= 0: the global batch's N0 when this call sees a shard     */
+    uint64_t seed;               /* device-RNG seed (used only where a noise pointer is NULL)   */
+    int64_t batch_offset;        /* index of this call's first item inside the GLOBAL batch: the
+                                    device-RNG stream is indexed by global item, so a batch sharded
+                                    over GPUs draws the same noise as the unsharded batch         */
+} vn_sample_params;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int  vn_ctx_create(int device, vn_ctx** out);
+void vn_ctx_destroy(vn_ctx* ctx);
+const char* vn_last_error(const vn_ctx* ctx);
+/* library build info, e.g. "vampnet_hip 0.1 gfx950 f32-mfma" */
+const char* vn_version(void);
+
+/* ---- kernel timing (bench.py's roofline leg) ------------------------------------------------
+ * While enabled, every launch of the two MFMA kernels (vn_gemm_f32_kernel, vn_attention_kernel) made
+ * through this ctx is bracketed by hipEvents on the launch stream.  vn_profile_end synchronises the
+ * recorded events and returns, per class c in {0: gemm, 1: attention}:
+ *   stats[3c+0] = launches, stats[3c+1] = total kernel time in ms, stats[3c+2] = algorithmic FLOPs
+ * (2*M*N*K per GEMM launch; 4*T*T*64 per (b,h) for attention).                                   */
+int vn_profile_begin(vn_ctx* ctx, int max_launches);
+int vn_profile_end(vn_ctx* ctx, double* stats6);
+
+/* ---- weights ------------------------------------------------------------------------------ */
+/* total number of floats in the packed blob */
+int vn_weights_size(const vn_dims* dims, int64_t* n_floats);
+/* offset (in floats) and element count of one tensor inside the blob */
+int vn_weights_offset(const vn_dims* dims, int tensor_id, int layer, int64_t* offset, int64_t* count);
+
+/* ---- model -------------------------------------------------------------------------------- */
+/* replaces VampNet.__init__ + load_state_dict (transformer.py:535-615; interface.py:27-50).
+ * `blob_dev`: packed weights (layout above) in device memory, must outlive the model.        */
+int  vn_model_create(vn_ctx* ctx, const vn_dims* dims, const float* blob_dev, vn_model** out);
+void vn_model_destroy(vn_model* model);
+
+/* replaces embedding.from_codes + VampNet.forward (layers.py:134-163; transformer.py:617-639).
+ * codes  dev int64 [B][C][T] (MASK = vocab allowed in any codebook)
+ * logits dev f32   [B][T][Cp][vocab]  (== reference logits[b, p, t*Cp + c] transposed so each
+ *                                         (t, c) owns `vocab` contiguous values)              */
+int vn_forward(vn_model* model, const int64_t* codes, int B, int T, float* logits, void* stream);
+
+/* replaces VampNet.generate (transformer.py:686-946; spec SURVEY.md App. A), return_signal=False,
+ * ctrls=None, cfg_guidance=None.
+ * start_tokens dev int64 [B][C][T]; mask dev int64 [B][C][T] in {0,1};
+ * num_to_mask_sched host int64 [steps] or NULL: floor(gamma((i+1)/steps) * N0) per step
+ *     (transformer.py:903) as the caller computed it (bit-exact torch fp32); NULL = computed here;
+ * exp_noise  dev f32 [steps][B*T*Cp][vocab] Exp(1) draws (multinomial replay) or NULL
+ *     = device Philox stream;  unif_noise dev f32 [steps][B][T*Cp] U(1e-20,1) or NULL likewise;
+ * out_tokens dev int64 [B][C][T].                                                              */
+int vn_generate(vn_model* model, const int64_t* start_tokens, const int64_t* mask, int B, int T,
+                const vn_sample_params* params, const int64_t* num_to_mask_sched,
+                const float* exp_noise, const float* unif_noise, int64_t* out_tokens, void* stream);
+
+/* One sampling step on caller-provided logits (teacher-forced parity tests):
+ * sample_from_logits + the where()/inf bookkeeping + mask_by_random_topk + re-mask
+ * (transformer.py:852-927, 952-1074).
+ * z_masked dev int64 [B][C][T] in/out; logits dev f32 [B][T][Cp][vocab];
+ * exp_noise dev f32 [B*T*Cp][vocab] or NULL; unif_noise dev f32 [B][T*Cp] or NULL;
+ * sampled_out dev int64 [B][C][T] (tokens before re-masking; conditioning codebooks copied).   */
+int vn_sample_step(vn_model* model, int64_t* z_masked, const float* logits, int B, int T,
+                   int step, const vn_sample_params* params, int64_t num_to_mask_sched,
+                   const float* exp_noise, const float* unif_noise, int64_t* sampled_out, void* stream);
+
+/* ---- single kernels (unit tests / profiling; same kernels the model uses) ------------------ */
+/* RMSNorm (transformer.py:55-58): y[r][:] = w * (x[r][:] * rsqrt(mean(x^2) + eps))             */
+int vn_rmsnorm_f32(vn_ctx* ctx, const float* x, const float* w, float* y, int rows, int D, float eps, void* stream);
+
+/* C[M][N] (op)= A[M][K] * W[N][K]^T  (torch F.linear).  epilogue:
+ *   0 store; 1 store + bias[N]; 2 C += (residual, transformer.py:347,367);
+ *   3 GEGLU: W rows interleaved as VN_W_W1, C is [M][N/2] (activations.py:16-35)                */
+int vn_gemm_f32(vn_ctx* ctx, const float* A, const float* W, const float* bias, float* C,
+                int M, int N, int K, int epilogue, void* stream);
+
+/* Self-attention core (transformer.py:229-254): q,k,v dev f32 [B][H][T][64];
+ * rel_bias dev f32 [num_buckets][H]; out dev f32 [B][T][H*64].                                */
+int vn_attention_f32(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                     float* out, int B, int H, int T, int num_buckets, int max_distance, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAMPNET_HIP_H */

@@ -27,10 +27,11 @@ COARSE_DIMS = dict(n_heads=20, n_layers=20, n_codebooks=4, n_cond=0, latent_dim=
 C2F_DIMS = dict(n_heads=20, n_layers=16, n_codebooks=14, n_cond=4, latent_dim=8,
                 d_model=1280, vocab=1024)
 # small shapes the CPU oracle finishes in milliseconds (unit tests, golden fixtures)
+# (d_model / n_heads = 64 like the shipped configs: the HIP attention kernel is specialised for d_head 64)
 TINY_COARSE_DIMS = dict(n_heads=4, n_layers=2, n_codebooks=4, n_cond=0, latent_dim=8,
-                        d_model=128, vocab=1024)
+                        d_model=256, vocab=1024)
 TINY_C2F_DIMS = dict(n_heads=4, n_layers=2, n_codebooks=14, n_cond=4, latent_dim=8,
-                     d_model=128, vocab=1024)
+                     d_model=256, vocab=1024)
 
 
 def _uniform(rng, shape, bound):

@@ -1,0 +1,105 @@
+"""-m gpu: each HIP kernel through the C ABI vs the CPU oracle (fp32, seeded)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vampnet_oracle as O, weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from vampnet_amd.engine import Engine
+    return Engine("cuda:0")
+
+
+def _rand(shape, seed, scale=1.0):
+    g = np.random.default_rng(seed)
+    return torch.from_numpy((g.standard_normal(shape) * scale).astype(np.float32))
+
+
+@pytest.mark.parametrize("rows,D", [(4600, 1280), (575, 1280), (7, 256), (3, 1000), (1, 1280)])
+def test_rmsnorm(eng, rows, D):
+    x, w = _rand((rows, D), 1, 3.0), 1 + _rand((D,), 2, 0.1)
+    got = eng.rmsnorm(x.cuda(), w.cuda()).cpu()
+    ref = O.rmsnorm(x, w)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-6, atol=1e-6)
+
+
+GEMM_SHAPES = [(575, 1280, 1280), (4600, 3840, 1280), (4600, 1280, 2560), (1384, 10240, 1280),
+               (50, 256, 256), (1, 128, 64), (129, 192, 96), (64, 64, 32), (700, 4096, 256)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_store_bias_residual(eng, M, N, K):
+    from vampnet_amd import _lib
+    a, w, b = _rand((M, K), 3), _rand((N, K), 4, 1.0 / np.sqrt(K)), _rand((N,), 5)
+    ref64 = a.double() @ w.double().t()
+    absdot = a.abs().double() @ w.abs().double().t()
+    tol = (2e-6 * absdot + 1e-6).numpy()       # fp32 accumulation-order class (guide: ~1e-7 * sum|a b| at K<=1024)
+    A, Wd = a.cuda(), w.cuda()
+    got = eng.gemm(A, Wd).cpu().double()
+    assert np.all(np.abs((got - ref64).numpy()) <= tol)
+    got = eng.gemm(A, Wd, bias=b.cuda(), epilogue=_lib.EPI_BIAS).cpu().double()
+    assert np.all(np.abs((got - (ref64 + b.double())).numpy()) <= tol)
+    c0 = _rand((M, N), 6)
+    out = c0.cuda().clone()
+    eng.gemm(A, Wd, epilogue=_lib.EPI_RESIDUAL, out=out)
+    assert np.all(np.abs((out.cpu().double() - (ref64 + c0.double())).numpy()) <= tol)
+
+
+def test_gemm_identity_asymmetric(eng):
+    """A = I catches a transposed C write (guide §3: always check with asymmetric B)."""
+    K = N = 256
+    a = torch.eye(K)[:200]
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K) * 1e-3
+    got = eng.gemm(a.cuda(), w.cuda()).cpu()
+    assert torch.equal(got, w.t()[:200])
+
+
+@pytest.mark.parametrize("M,D", [(575, 1280), (4600, 1280), (33, 256)])
+def test_gemm_geglu(eng, M, D):
+    from vampnet_amd import _lib
+    x, w1 = _rand((M, D), 7), _rand((4 * D, D), 8, 1.0 / np.sqrt(D))
+    ref = O.gated_gelu(torch.nn.functional.linear(x, w1))
+    val, gate = w1[:2 * D].reshape(2 * D // 32, 32, D), w1[2 * D:].reshape(2 * D // 32, 32, D)
+    w1p = torch.stack([val, gate], dim=1).reshape(4 * D, D)
+    got = eng.gemm(x.cuda(), w1p.cuda(), epilogue=_lib.EPI_GEGLU).cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+
+
+def _attention_ref(q, k, v, table):
+    B, H, T, _ = q.shape
+    bias = O.compute_bias(table, T)                      # (H,1,T,T)
+    qh, kh, vh = (t.permute(1, 0, 2, 3) for t in (q, k, v))
+    attn = torch.einsum("hblk,hbtk->hblt", qh, kh) / np.sqrt(64)
+    attn = torch.softmax(attn + bias, dim=3)
+    out = torch.einsum("hblt,hbtv->hblv", attn, vh)
+    return out.permute(1, 2, 0, 3).reshape(B, T, H * 64)
+
+
+@pytest.mark.parametrize("B,H,T", [(1, 20, 575), (2, 20, 173), (3, 4, 64), (2, 2, 1), (1, 3, 65), (1, 2, 130), (2, 1, 600)])
+def test_attention(eng, B, H, T):
+    q, k, v = _rand((B, H, T, 64), 10), _rand((B, H, T, 64), 11), _rand((B, H, T, 64), 12)
+    table = _rand((32, H), 13)
+    ref = _attention_ref(q, k, v, table)
+    got = eng.attention(q.cuda(), k.cuda(), v.cuda(), table.cuda()).cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-5, atol=3e-6)
+
+
+def test_attention_bias_buckets_exact(eng):
+    """q = 0 -> scores are the bias alone; v = one-hot(position) -> output row = softmax(bias) itself,
+    which pins every bucket boundary (rel = -574..574) against the oracle table."""
+    T, H = 575, 2
+    q = torch.zeros(1, H, T, 64)
+    k = _rand((1, H, T, 64), 14)
+    table = _rand((32, H), 15, 3.0)
+    ref_soft = torch.softmax(O.compute_bias(table, T)[:, 0], dim=-1)      # (H, T, T)
+    for blk in range(0, T, 64):
+        v = torch.zeros(1, H, T, 64)
+        n = min(64, T - blk)
+        v[0, :, blk:blk + n, :n] = torch.eye(n)
+        got = eng.attention(q.cuda(), k.cuda(), v.cuda(), table.cuda()).cpu().reshape(T, H, 64)
+        want = ref_soft[:, :, blk:blk + n].permute(1, 0, 2)
+        np.testing.assert_allclose(got[:, :, :n].numpy(), want.numpy(), rtol=1e-5, atol=1e-7)

@@ -1,0 +1,159 @@
+"""CPU tests of the product's host logic (no GPU): mask builders, RNG replay, schedule, weight packing,
+C-ABI surface, Interface orchestration (with an oracle-backed stand-in for the device model)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vampnet_oracle as O, weights as W
+from vampnet_amd import _lib, masks
+from vampnet_amd.engine import draw_noise_host, pack_weights, VampNetModel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    """The shared library loads on a GPU-less host and exports exactly what include/vampnet_hip.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "vampnet_hip.h")).read()
+    declared = set(re.findall(r"\b(vn_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert b"gfx950" in lib.vn_version()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.VnError):
+        _lib.load()
+
+
+def test_engine_refuses_cpu():
+    from vampnet_amd.engine import Engine
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.VnError):
+        Engine("cuda:0")
+
+
+def test_weight_layout_and_packing():
+    lib = _lib.load()
+    d = W.TINY_COARSE_DIMS
+    dims = _lib.vn_dims(d["n_layers"], d["n_heads"], d["d_model"], d["n_codebooks"], d["n_cond"], d["vocab"],
+                        d["latent_dim"], 32, 128, 1e-6, 2, 64)
+    n = C.c_int64()
+    assert lib.vn_weights_size(C.byref(dims), C.byref(n)) == 0
+    spans = []
+    for tid in range(13):
+        for layer in (range(d["n_layers"]) if tid >= _lib.W_NORM1 else [0]):
+            off, cnt = C.c_int64(), C.c_int64()
+            assert lib.vn_weights_offset(C.byref(dims), tid, layer, C.byref(off), C.byref(cnt)) == 0
+            assert off.value % 64 == 0
+            spans.append((off.value, off.value + cnt.value))
+    spans.sort()
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] <= n.value
+    sd, cb = W.synth_state_dict(d, 0), W.synth_codebooks()
+    blob = pack_weights(lib, dims, sd, cb)
+    D, V, Cp = d["d_model"], d["vocab"], d["n_codebooks"] - d["n_cond"]
+    off, cnt = C.c_int64(), C.c_int64()
+    # classifier rows re-ordered (p c) -> (c p), weight-norm folded
+    lib.vn_weights_offset(C.byref(dims), _lib.W_CLS_W, 0, C.byref(off), C.byref(cnt))
+    wc = blob[off.value:off.value + cnt.value].view(Cp, V, D)
+    ref = O.classifier_weight(sd).squeeze(-1)
+    assert torch.equal(wc[2, 17], ref[17 * Cp + 2])
+    # W1 interleave: packed row 64g+i = value row 32g+i ; 64g+32+i = gate row 2D+32g+i
+    lib.vn_weights_offset(C.byref(dims), _lib.W_W1, 1, C.byref(off), C.byref(cnt))
+    w1p = blob[off.value:off.value + cnt.value].view(4 * D, D)
+    w1 = sd["transformer.layers.1.feed_forward.w_1.weight"]
+    assert torch.equal(w1p[64 * 3 + 5], w1[32 * 3 + 5]) and torch.equal(w1p[64 * 3 + 32 + 5], w1[2 * D + 32 * 3 + 5])
+    # LoRA merge: W + (B A) / 8
+    sd2 = dict(sd)
+    A, Bm = torch.randn(8, D), torch.randn(D, 8)
+    sd2["transformer.layers.0.self_attn.fc.lora_A"], sd2["transformer.layers.0.self_attn.fc.lora_B"] = A, Bm
+    blob2 = pack_weights(lib, dims, sd2, cb)
+    lib.vn_weights_offset(C.byref(dims), _lib.W_WO, 0, C.byref(off), C.byref(cnt))
+    got = blob2[off.value:off.value + cnt.value].view(D, D)
+    assert torch.allclose(got, sd["transformer.layers.0.self_attn.fc.weight"] + (Bm @ A) / 8.0)
+    bad = _lib.vn_dims(2, 4, 128, 4, 0, 1024, 8, 32, 128, 1e-6, 1, 8)       # d_head 32
+    assert lib.vn_weights_size(C.byref(bad), C.byref(n)) != 0
+
+
+# ------------------------------------------------------------------------------------------ masks
+@pytest.mark.parametrize("kw", [dict(), dict(periodic_prompt=5, upper_codebook_mask=2, _dropout=0.1),
+                                dict(rand_mask_intensity=0.8, prefix_s=0.2, suffix_s=0.1, periodic_prompt=0),
+                                dict(periodic_prompt=13, periodic_prompt_width=3, ncc=1),
+                                dict(periodic_prompt=4, periodic_prompt_width=5, upper_codebook_mask=14)])
+@pytest.mark.parametrize("B,T", [(1, 575), (2, 120), (3, 7)])
+def test_build_mask_matches_oracle_and_rng_stream(kw, B, T):
+    z = W.synth_codes(B, 14, T, seed=4)
+    for seed in (0, 1, 2):
+        torch.manual_seed(seed)
+        ref = O.build_mask(z, **kw)
+        tail_ref = torch.rand(3)
+        torch.manual_seed(seed)
+        got = masks.build_mask(z, rand_mask_intensity=kw.get("rand_mask_intensity", 1.0),
+                               n_prefix=O.s2t(kw.get("prefix_s", 0.0)), n_suffix=O.s2t(kw.get("suffix_s", 0.0)),
+                               periodic_prompt=kw.get("periodic_prompt", 7),
+                               periodic_prompt_width=kw.get("periodic_prompt_width", 1),
+                               dropout=kw.get("_dropout", 0.0), upper_codebook_mask=kw.get("upper_codebook_mask", 3),
+                               ncc=kw.get("ncc", 0))
+        assert torch.equal(ref, got)
+        assert torch.equal(tail_ref, torch.rand(3))          # generator left in the same state
+
+
+def test_apply_mask_and_asserts():
+    z = W.synth_codes(2, 4, 9)
+    m = (torch.arange(9) % 2).expand(2, 4, 9).long()
+    out, _ = masks.apply_mask(z, m, 1024)
+    ref, _ = O.apply_mask(z, m, 1024)
+    assert torch.equal(out, ref)
+    with pytest.raises(AssertionError):
+        masks.apply_mask(z, m.int(), 1024)
+    with pytest.raises(AssertionError):
+        masks.apply_mask(z, m * 2, 1024)
+    with pytest.raises(AssertionError):
+        masks.apply_mask(z, m[:, :2], 1024)
+
+
+# ------------------------------------------------------------------------------------------ RNG replay + schedule
+@pytest.mark.parametrize("cutoff", [1.0, 0.5, -1.0])
+def test_noise_ledger_matches_reference_stream(cutoff):
+    dims, B, T, steps = W.TINY_COARSE_DIMS, 3, 21, 4
+    sd, cb = W.synth_state_dict(dims, 0), W.synth_codebooks()
+    z = W.synth_codes(B, 4, T, seed=1)
+    mask = torch.ones_like(z)
+    trace = []
+    torch.manual_seed(5)
+    O.generate(sd, dims, cb, z, mask, sampling_steps=steps, sample_cutoff=cutoff, trace=trace)
+    tail = torch.rand(2)
+    N, V = T * 4, 1024
+    torch.manual_seed(5)
+    exp, unif = draw_noise_host(B, N, V, steps, cutoff)
+    assert torch.equal(tail, torch.rand(2))
+    for i, t in enumerate(trace):
+        if t["exp"] is not None:
+            assert torch.equal(exp[i], t["exp"])
+        else:
+            assert not exp[i].any()
+        assert torch.equal(unif[i], t["unif"])
+    # shard view: rows of items [1, 3) of the same global stream
+    torch.manual_seed(5)
+    exp_s, unif_s = draw_noise_host(B, N, V, steps, cutoff, b0=1, nb=2)
+    assert torch.equal(exp_s, exp[:, N:3 * N]) and torch.equal(unif_s, unif[:, 1:3])
+
+
+def test_mask_schedule_matches_reference_arithmetic():
+    for steps in (1, 2, 6, 12, 36):
+        for n0 in (1, 43, 2049, 2300, 16392, 64 * 2049):
+            got = VampNetModel.mask_schedule(steps, n0)
+            for i in range(steps):
+                r = torch.tensor((i + 1) / steps).repeat(2)
+                want = torch.floor(O.gamma(r) * torch.tensor(n0)).long()[0].item()
+                assert got[i] == want
+            assert got[-1] == 0

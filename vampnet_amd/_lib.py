@@ -1,0 +1,84 @@
+"""ctypes binding of libvampnet_hip.so (include/vampnet_hip.h).  No CPU fallback: if the HIP library is
+missing or fails to load, importing/using the engine raises — the product path never degrades to torch."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvampnet_hip.so")
+
+
+class VnError(RuntimeError):
+    pass
+
+
+class vn_dims(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("n_heads", C.c_int32), ("d_model", C.c_int32),
+                ("n_codebooks", C.c_int32), ("n_cond", C.c_int32), ("vocab", C.c_int32),
+                ("latent_dim", C.c_int32), ("num_buckets", C.c_int32), ("max_distance", C.c_int32),
+                ("eps", C.c_float), ("max_batch", C.c_int32), ("max_T", C.c_int32)]
+
+
+class vn_sample_params(C.Structure):
+    _fields_ = [("steps", C.c_int32), ("temperature", C.c_float), ("mask_temperature", C.c_float),
+                ("sample_cutoff", C.c_double), ("top_p", C.c_float), ("n0_override", C.c_int64),
+                ("seed", C.c_uint64), ("batch_offset", C.c_int64)]
+
+
+# tensor ids of the packed weight blob (enum in vampnet_hip.h)
+(W_EMB_TABLES, W_EMB_WT, W_EMB_B, W_REL_BIAS, W_FINAL_NORM, W_CLS_W, W_CLS_B,
+ W_NORM1, W_QKV, W_WO, W_NORM3, W_W1, W_W2) = range(13)
+
+EPI_STORE, EPI_BIAS, EPI_RESIDUAL, EPI_GEGLU = range(4)
+
+# every symbol include/vampnet_hip.h declares: (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "vn_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "vn_ctx_destroy": (None, [_P]),
+    "vn_last_error": (C.c_char_p, [_P]),
+    "vn_version": (C.c_char_p, []),
+    "vn_profile_begin": (C.c_int, [_P, C.c_int]),
+    "vn_profile_end": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "vn_weights_size": (C.c_int, [C.POINTER(vn_dims), C.POINTER(C.c_int64)]),
+    "vn_weights_offset": (C.c_int, [C.POINTER(vn_dims), C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "vn_model_create": (C.c_int, [_P, C.POINTER(vn_dims), _P, C.POINTER(_P)]),
+    "vn_model_destroy": (None, [_P]),
+    "vn_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    "vn_generate": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(vn_sample_params), C.POINTER(C.c_int64),
+                              _P, _P, _P, _P]),
+    "vn_sample_step": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(vn_sample_params), C.c_int64,
+                                 _P, _P, _P, _P]),
+    "vn_rmsnorm_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
+    "vn_gemm_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "vn_attention_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the engine; raises VnError (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VnError(f"{LIB_PATH} not found: build it with `python -m vampnet_amd.build` "
+                      "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise VnError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise VnError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, ctx=None, what=""):
+    if rc != 0:
+        msg = load().vn_last_error(ctx).decode() if ctx else ""
+        raise VnError(f"{what} failed with status {rc}: {msg}")

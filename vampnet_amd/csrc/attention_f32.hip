@@ -1,0 +1,201 @@
+// Fused fp32 self-attention with the shared T5 relative-position bias, for gfx950.
+//
+// Replaces MultiHeadRelativeAttention.forward's core (vampnet/modules/transformer.py:234-254):
+//   attn = einsum(q,k)/sqrt(64) + bias[h, bucket(k - q)] ; softmax(dim=keys) ; einsum(attn, v)
+// (mask is all-ones at inference, transformer.py:619; dropout is eval-mode identity.)
+//
+// The (H,B,T,T) score tensor (26.5 MB per layer per item in the reference) is never materialised:
+// flash-style online softmax, exact fp32 throughout (v_mfma_f32_16x16x4_f32 = bitwise fmaf chains).
+//
+// Work decomposition: grid = (ceil(T/64) q-blocks, H, B); block = 4 waves; wave w owns 16 query rows.
+// Both products are computed TRANSPOSED so that every softmax quantity is lane-local
+// (cdna_hip_programming.md App. B "swapped QK^T"):
+//   S^T[key][q]  = K[key][:] . Q[q][:]    A = K tile (LDS),  B = Q (registers)   -> lane (j=lane&15, g=lane>>4)
+//                                          holds S for its query j and keys 16u + 4g + r  (u,r = 0..3)
+//   O^T[d][q]    = V^T[d][key] . P^T[key][q]   A = V tile (LDS, read as float4 over d), B = P (the very
+//                                          registers the softmax produced) -> no data movement between the GEMMs.
+// Row max needs two xor-shuffles (lanes j, j+16, j+32, j+48 share a query); row sum is reduced once at the end.
+// The bias is a 2T-1 entry per-head table in LDS indexed by key - query (see vn_bias_expand_kernel).
+// K/V tiles (64 keys x 64 d) are register-prefetched one tile ahead (issue-early / write-late, guide T14).
+// LDS rows are padded to 68 floats so the float4 fragment reads are (almost) bank-conflict free.
+//
+// Algorithmic FLOPs: 4*T*T*64 per (b,h)  (2 GEMMs); HBM bytes: Q,K,V read + O written = 4*T*64*4 per (b,h)
+// (K/V are re-read by the ceil(T/64) q-blocks of a head, from L2).
+#include "vn_common.h"
+
+#define ATT_KT 64        // keys per tile
+#define ATT_LD 68        // padded LDS row (floats)
+
+__global__ __launch_bounds__(256) void vn_attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                           const float* __restrict__ v,
+                                                           const float* __restrict__ bias_full,  // [H][2T-1]
+                                                           float* __restrict__ out, int B, int H, int T) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;
+    float* Vs = Ks + ATT_KT * ATT_LD;
+    float* bt = Vs + ATT_KT * ATT_LD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const size_t headoff = ((size_t)b * H + h) * (size_t)T * VN_DHEAD;
+    const float* Q = q + headoff;
+    const float* K = k + headoff;
+    const float* V = v + headoff;
+
+    const int qrow = qb * 64 + wave * 16 + j;
+    const int qrow_c = qrow < T ? qrow : T - 1;
+
+    // bias table for this head -> LDS
+    const int nb = 2 * T - 1;
+    for (int i = tid; i < nb; i += 256) bt[i] = bias_full[(size_t)h * nb + i];
+
+    // Q fragment: lane (j,g) holds Q[q_j][16s + 4g + e]
+    f32x4 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const f32x4*)(Q + (size_t)qrow_c * VN_DHEAD + 16 * s + 4 * g);
+
+    // tile staging: thread handles float4 idx = tid + 256*i  (row = idx>>4, c4 = idx&15)
+    f32x4 kreg[4], vreg[4];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 4, c4 = idx & 15;
+            const int key = kt * ATT_KT + row;
+            if (key < T) {
+                kreg[i] = *(const f32x4*)(K + (size_t)key * VN_DHEAD + c4 * 4);
+                vreg[i] = *(const f32x4*)(V + (size_t)key * VN_DHEAD + c4 * 4);
+            } else {
+                kreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                vreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto write_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 4, c4 = idx & 15;
+            *(f32x4*)(Ks + row * ATT_LD + c4 * 4) = kreg[i];
+            *(f32x4*)(Vs + row * ATT_LD + c4 * 4) = vreg[i];
+        }
+    };
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = (T + ATT_KT - 1) / ATT_KT;
+    load_tile(0);
+    write_tile();
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) load_tile(kt + 1);
+
+        // ---- S^T = K . Q^T  (4 key sub-tiles u, contraction over d in 16 steps of 4)
+        f32x4 sacc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sacc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f32x4 kf[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kf[u] = *(const f32x4*)(Ks + (u * 16 + j) * ATT_LD + 16 * s + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    sacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u][e], qf[s][e], sacc[u], 0, 0, 0);
+        }
+
+        // ---- online softmax over this tile's 64 keys; lane holds keys kt*64 + 16u + 4g + r for query j
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * ATT_KT + u * 16 + 4 * g + r;
+                const int key_c = key < T ? key : T - 1;
+                float x = sacc[u][r] * 0.125f + bt[key_c - qrow_c + (T - 1)];   // /sqrt(64) exact; += bias
+                x = key < T ? x : -INFINITY;
+                sacc[u][r] = x;
+                mx = fmaxf(mx, x);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);          // finite: every tile has >= 1 valid key
+        const float alpha = expf(m_run - m_new);       // first tile: exp(-inf) = 0
+        float lsum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pexp = expf(sacc[u][r] - m_new);
+                sacc[u][r] = pexp;
+                lsum += pexp;
+            }
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e][0] *= alpha; o[e][1] *= alpha; o[e][2] *= alpha; o[e][3] *= alpha;
+        }
+
+        // ---- O^T += V^T . P^T : lane (j,g) reads V[key(u,g,r)][4j .. 4j+3]; tile e covers d = 4i + e
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x4 vf = *(const f32x4*)(Vs + (u * 16 + 4 * g + r) * ATT_LD + 4 * j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[e], sacc[u][r], o[e], 0, 0, 0);
+            }
+
+        __syncthreads();                       // every wave finished reading Ks/Vs
+        if (kt + 1 < nkt) {
+            write_tile();
+            __syncthreads();
+        }
+    }
+
+    // ---- finish: row sum across the 4 lanes of a query, normalise, store.
+    // accumulator o[e][r] = O[q_j][d = 16g + 4r + e]  (C/D map of 16x16 MFMA: row i = 4*(lane>>4) + r, d = 4i + e)
+    float l_tot = l_run;
+    l_tot += __shfl_xor(l_tot, 16);
+    l_tot += __shfl_xor(l_tot, 32);
+    if (qrow < T) {
+        float* orow = out + ((size_t)b * T + qrow) * ((size_t)H * VN_DHEAD) + h * VN_DHEAD + 16 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            f32x4 ov;
+            ov[0] = o[0][r] / l_tot;
+            ov[1] = o[1][r] / l_tot;
+            ov[2] = o[2][r] / l_tot;
+            ov[3] = o[3][r] / l_tot;
+            *(f32x4*)(orow + 4 * r) = ov;
+        }
+    }
+}
+
+int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* relbias_full,
+                        float* out, int B, int H, int T, hipStream_t s) {
+    if (B <= 0 || T <= 0) return VN_OK;
+    const size_t lds = (size_t)(2 * ATT_KT * ATT_LD + 2 * T - 1 + 3) * sizeof(float);
+    if (lds > 160 * 1024) return vn_fail(ctx, VN_ERR_INVALID, "attention: T=%s%ld too long for the LDS bias table", "", T);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_kernel,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s);
+    hipLaunchKernelGGL(vn_attention_kernel, dim3(vn_cdiv(T, 64), H, B), dim3(256), lds, s, q, k, v, relbias_full, out,
+                       B, H, T);
+    vn_prof_post(ctx, pi, s);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}

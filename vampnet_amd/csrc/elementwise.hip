@@ -1,0 +1,229 @@
+// HBM-bound row kernels of the hot path: codebook-embedding sum, RMSNorm, dtype/layout glue.
+#include "vn_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// RMSNorm (vampnet/modules/transformer.py:55-58):  y = w * (x * rsqrt(mean(x^2) + eps)), fp32.
+// One 64-lane wave per row, float4 loads (coalesced 1 KiB per wave instruction), shuffle reduce.
+// Algorithmic bytes: 8*D per row (read x, write y) + D*4 weights (L2 resident).
+// ---------------------------------------------------------------------------------------------
+template <int VEC>   // VEC = float4 per lane = D / 256
+__global__ __launch_bounds__(256) void vn_rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         float* __restrict__ y, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const f32x4* xr = (const f32x4*)(x + (size_t)row * D);
+    f32x4 v[VEC];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        v[i] = xr[lane + 64 * i];
+        ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float rstd = 1.0f / sqrtf(ss / (float)D + eps);   // exact div+sqrt == torch.rsqrt on CPU
+    f32x4* yr = (f32x4*)(y + (size_t)row * D);
+    const f32x4* wr = (const f32x4*)w;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        const f32x4 ww = wr[lane + 64 * i];
+        f32x4 o;
+        o[0] = ww[0] * (v[i][0] * rstd);
+        o[1] = ww[1] * (v[i][1] * rstd);
+        o[2] = ww[2] * (v[i][2] * rstd);
+        o[3] = ww[3] * (v[i][3] * rstd);
+        yr[lane + 64 * i] = o;
+    }
+}
+
+// generic fallback (any D multiple of 4): strided loop, two passes over the row (second from L1/L2)
+__global__ __launch_bounds__(256) void vn_rmsnorm_generic_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ w,
+                                                                 float* __restrict__ y, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const f32x4* xr = (const f32x4*)(x + (size_t)row * D);
+    const int nv = D >> 2;
+    float ss = 0.f;
+    for (int i = lane; i < nv; i += 64) {
+        const f32x4 v = xr[i];
+        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float rstd = 1.0f / sqrtf(ss / (float)D + eps);
+    f32x4* yr = (f32x4*)(y + (size_t)row * D);
+    const f32x4* wr = (const f32x4*)w;
+    for (int i = lane; i < nv; i += 64) {
+        const f32x4 v = xr[i], ww = wr[i];
+        f32x4 o;
+        o[0] = ww[0] * (v[0] * rstd);
+        o[1] = ww[1] * (v[1] * rstd);
+        o[2] = ww[2] * (v[2] * rstd);
+        o[3] = ww[3] * (v[3] * rstd);
+        yr[i] = o;
+    }
+}
+
+int vn_launch_rmsnorm(vn_ctx* ctx, const float* x, const float* w, float* y, int rows, int D, float eps,
+                      hipStream_t s) {
+    if (rows <= 0) return VN_OK;
+    if (D % 4) return vn_fail(ctx, VN_ERR_INVALID, "rmsnorm: D=%s%ld must be a multiple of 4", "", D);
+    const dim3 grid(vn_cdiv(rows, 4)), block(256);
+    if (D == 1280) hipLaunchKernelGGL(vn_rmsnorm_kernel<5>, grid, block, 0, s, x, w, y, rows, D, eps);
+    else if (D == 256) hipLaunchKernelGGL(vn_rmsnorm_kernel<1>, grid, block, 0, s, x, w, y, rows, D, eps);
+    else hipLaunchKernelGGL(vn_rmsnorm_generic_kernel, grid, block, 0, s, x, w, y, rows, D, eps);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Codebook embedding (vampnet/modules/layers.py:134-163): per codebook c gather the latent row
+// tables[c][code] (row `vocab` = MASK special), concatenate (8C values) and apply the 1x1 conv
+//   x[m][d] = b[d] + sum_j Wt[j][d] * lat[m][j]            (Wt = out_proj.weight transposed, [8C][D])
+// The sum runs j = 0..8C-1 in order (one fmaf chain per output).  Block = 256 threads handles
+// ROWS rows; thread t owns columns d = t, t+256, ... ; latents staged in LDS (broadcast reads).
+// Algorithmic bytes: 4*D per row written + (8C*4 gathered) ; Wt (<= 573 KB) stays in L2.
+// ---------------------------------------------------------------------------------------------
+#define EMB_ROWS 8
+__global__ __launch_bounds__(256) void vn_embed_kernel(const int32_t* __restrict__ codes,
+                                                       const float* __restrict__ tables,
+                                                       const float* __restrict__ wt, const float* __restrict__ b,
+                                                       float* __restrict__ x, int B, int C, int T, int V1,
+                                                       int latent, int D) {
+    extern __shared__ __attribute__((aligned(16))) float lat[];   // [EMB_ROWS][C*latent]
+    const int J = C * latent;
+    const int m0 = blockIdx.x * EMB_ROWS;
+    const int M = B * T;
+    for (int i = threadIdx.x; i < EMB_ROWS * J; i += 256) {
+        const int r = i / J, j = i - r * J;
+        const int m = m0 + r;
+        float val = 0.f;
+        if (m < M) {
+            const int bb = m / T, t = m - bb * T;
+            const int c = j / latent, e = j - c * latent;
+            const int code = codes[((size_t)bb * C + c) * T + t];
+            val = tables[((size_t)c * V1 + code) * latent + e];
+        }
+        lat[i] = val;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float acc[EMB_ROWS];
+        const float bias = b[d];
+#pragma unroll
+        for (int r = 0; r < EMB_ROWS; ++r) acc[r] = bias;
+        for (int j = 0; j < J; ++j) {
+            const float wv = wt[(size_t)j * D + d];
+#pragma unroll
+            for (int r = 0; r < EMB_ROWS; ++r) acc[r] = fmaf(wv, lat[r * J + j], acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < EMB_ROWS; ++r)
+            if (m0 + r < M) x[(size_t)(m0 + r) * D + d] = acc[r];
+    }
+}
+
+int vn_launch_embed(vn_ctx* ctx, const int32_t* codes, const float* tables, const float* wt, const float* b,
+                    float* x, int B, int C, int T, int V1, int latent, int D, hipStream_t s) {
+    const int M = B * T;
+    if (M <= 0) return VN_OK;
+    const size_t lds = (size_t)EMB_ROWS * C * latent * sizeof(float);
+    hipLaunchKernelGGL(vn_embed_kernel, dim3(vn_cdiv(M, EMB_ROWS)), dim3(256), lds, s, codes, tables, wt, b, x, B,
+                       C, T, V1, latent, D);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// T5 relative-position bias expansion (transformer.py:123-209): the bias depends only on
+// rel = key - query, so one table per head over rel in [-(T-1), T-1] replaces the (H,1,T,T) tensor:
+//   out[h][rel + T - 1] = rel_bias[bucket(rel)][h]
+// bucket(): bidirectional, num_buckets/2 per side, half exact, half log-spaced up to max_distance.
+// The bucket LUT is computed on the HOST in double precision: the reference truncates an fp32
+// expression that is an exact integer at |rel| = max_exact * 2^n (16, 32, 64 for the shipped config;
+// v = (nb - max_exact) * log(a/max_exact) / log(max_distance/max_exact)), where a 1-ulp logf
+// difference would flip the bucket; between those points v is >= 1e-3 away from an integer, so
+// floor(v + 1e-9) in double reproduces the reference table (pinned for |rel| <= 600 by
+// tests/golden/misc.npz and tests/test_gpu_kernels.py).
+// ---------------------------------------------------------------------------------------------
+void vn_bucket_lut_host(int T, int num_buckets, int max_distance, int32_t* lut /* [2T-1] */) {
+    const int nb = num_buckets / 2, max_exact = nb / 2;
+    for (int i = 0; i < 2 * T - 1; ++i) {
+        const int rel = i - (T - 1);
+        int bucket = rel > 0 ? nb : 0;
+        const int a = rel < 0 ? -rel : rel;
+        if (a < max_exact) {
+            bucket += a;
+        } else {
+            const double v = log((double)a / max_exact) / log((double)max_distance / max_exact) * (nb - max_exact);
+            int large = max_exact + (int)floor(v + 1e-9);
+            bucket += large < nb - 1 ? large : nb - 1;
+        }
+        lut[i] = bucket;
+    }
+}
+
+__global__ void vn_bias_expand_kernel(const float* __restrict__ rel_bias, const int32_t* __restrict__ lut,
+                                      float* __restrict__ out, int H, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int bucket = lut[i];
+    for (int h = 0; h < H; ++h) out[(size_t)h * n + i] = rel_bias[(size_t)bucket * H + h];
+}
+
+int vn_launch_bias_expand(vn_ctx* ctx, const float* rel_bias, const int32_t* lut_dev, float* out, int H, int T,
+                          hipStream_t s) {
+    const int n = 2 * T - 1;
+    hipLaunchKernelGGL(vn_bias_expand_kernel, dim3(vn_cdiv(n, 256)), dim3(256), 0, s, rel_bias, lut_dev, out, H, n);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// token dtype glue: the boundary speaks int64 like the reference's LongTensors, kernels use int32.
+// ---------------------------------------------------------------------------------------------
+__global__ void vn_i64_to_i32_kernel(const int64_t* __restrict__ in, int32_t* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)in[i];
+}
+__global__ void vn_i32_to_i64_kernel(const int32_t* __restrict__ in, int64_t* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int64_t)in[i];
+}
+// z = mask ? V : tokens (transformer.py:762 masked_fill) ; count += #(z == V) (transformer.py:766)
+__global__ void vn_apply_mask_kernel(const int64_t* __restrict__ tokens, const int64_t* __restrict__ mask,
+                                     int32_t* __restrict__ z, int32_t* __restrict__ count, long n, int V) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int is_masked = 0;
+    if (i < n) {
+        const int32_t v = mask[i] != 0 ? V : (int32_t)tokens[i];
+        z[i] = v;
+        is_masked = (v == V);
+    }
+    const unsigned long long bal = __ballot(is_masked);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(count, (int)__popcll(bal));
+}
+
+int vn_launch_i64_to_i32(vn_ctx* ctx, const int64_t* in, int32_t* out, long n, hipStream_t s) {
+    if (n <= 0) return VN_OK;
+    hipLaunchKernelGGL(vn_i64_to_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+int vn_launch_i32_to_i64(vn_ctx* ctx, const int32_t* in, int64_t* out, long n, hipStream_t s) {
+    if (n <= 0) return VN_OK;
+    hipLaunchKernelGGL(vn_i32_to_i64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+int vn_launch_apply_mask(vn_ctx* ctx, const int64_t* tokens, const int64_t* mask, int32_t* z, int32_t* count,
+                         long n, int V, hipStream_t s) {
+    if (n <= 0) return VN_OK;
+    hipLaunchKernelGGL(vn_apply_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tokens, mask, z,
+                       count, n, V);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}

@@ -1,0 +1,406 @@
+// Host side of libvampnet_hip.so: context, packed-weight layout, model workspace, the per-step
+// kernel schedule of VampNet.forward / VampNet.generate, and the extern "C" entry points declared in
+// include/vampnet_hip.h.  Everything is enqueued asynchronously on the caller's stream; there is no
+// host<->device synchronisation on the generate path when the caller supplies the mask schedule.
+#include <new>
+#include <vector>
+#include "vn_common.h"
+
+struct vn_model {
+    vn_ctx* ctx;
+    vn_dims d;
+    const float* blob;
+    int Cp, D, H, L;
+    // workspace (device)
+    float *x, *y, *qkv, *g, *logits, *bias_full, *psel;
+    int32_t *z, *z_sampled, *sampled, *count, *lut;
+    int bias_T;              // T the expanded bias table is currently built for (-1 = none)
+    long max_rows;
+};
+
+static int dims_check(vn_ctx* ctx, const vn_dims* d) {
+    if (!d) return vn_fail(ctx, VN_ERR_INVALID, "dims is NULL%s", "");
+    if (d->n_heads <= 0 || d->d_model != d->n_heads * VN_DHEAD)
+        return vn_fail(ctx, VN_ERR_UNSUPPORTED, "d_model / n_heads must be 64 (got d_model=%s%ld, heads=%ld)", "",
+                       d->d_model, d->n_heads);
+    if (d->d_model % 128) return vn_fail(ctx, VN_ERR_UNSUPPORTED, "d_model=%s%ld must be a multiple of 128", "", d->d_model);
+    if (d->n_codebooks <= d->n_cond || d->n_cond < 0)
+        return vn_fail(ctx, VN_ERR_INVALID, "need n_codebooks > n_cond >= 0%s", "");
+    if (d->vocab != 1024 && d->vocab != 256)
+        return vn_fail(ctx, VN_ERR_UNSUPPORTED, "vocab=%s%ld unsupported (1024 or 256)", "", d->vocab);
+    if (d->n_layers <= 0 || d->latent_dim <= 0) return vn_fail(ctx, VN_ERR_INVALID, "bad n_layers/latent_dim%s", "");
+    return VN_OK;
+}
+
+// ---- weight blob layout ----------------------------------------------------------------------
+static long tensor_count(const vn_dims* d, int id) {
+    const long D = d->d_model, C = d->n_codebooks, Cp = C - d->n_cond, V = d->vocab, ld = d->latent_dim;
+    switch (id) {
+        case VN_W_EMB_TABLES: return C * (V + 1) * ld;
+        case VN_W_EMB_WT: return C * ld * D;
+        case VN_W_EMB_B: return D;
+        case VN_W_REL_BIAS: return (long)d->num_buckets * d->n_heads;
+        case VN_W_FINAL_NORM: return D;
+        case VN_W_CLS_W: return Cp * V * D;
+        case VN_W_CLS_B: return Cp * V;
+        case VN_W_NORM1: return D;
+        case VN_W_QKV: return 3 * D * D;
+        case VN_W_WO: return D * D;
+        case VN_W_NORM3: return D;
+        case VN_W_W1: return 4 * D * D;
+        case VN_W_W2: return 2 * D * D;
+    }
+    return -1;
+}
+static long align64(long n) { return (n + 63) & ~63L; }   // 256-byte aligned tensors
+
+static long tensor_offset(const vn_dims* d, int id, int layer) {
+    long off = 0;
+    for (int t = VN_W_EMB_TABLES; t <= VN_W_CLS_B; ++t) {
+        if (t == id) return off;
+        off += align64(tensor_count(d, t));
+    }
+    long per_layer = 0;
+    for (int t = VN_W_NORM1; t <= VN_W_W2; ++t) per_layer += align64(tensor_count(d, t));
+    off += per_layer * layer;
+    for (int t = VN_W_NORM1; t <= VN_W_W2; ++t) {
+        if (t == id) return off;
+        off += align64(tensor_count(d, t));
+    }
+    return -1;
+}
+
+extern "C" int vn_weights_size(const vn_dims* dims, int64_t* n_floats) {
+    if (!dims || !n_floats) return VN_ERR_INVALID;
+    if (dims_check(nullptr, dims) != VN_OK) return VN_ERR_INVALID;
+    *n_floats = tensor_offset(dims, VN_W_NORM1, dims->n_layers);
+    return VN_OK;
+}
+
+extern "C" int vn_weights_offset(const vn_dims* dims, int tensor_id, int layer, int64_t* offset, int64_t* count) {
+    if (!dims || !offset || !count || tensor_id < 0 || tensor_id >= VN_W__COUNT) return VN_ERR_INVALID;
+    if (dims_check(nullptr, dims) != VN_OK) return VN_ERR_INVALID;
+    const bool per_layer = tensor_id >= VN_W_NORM1;
+    if (per_layer && (layer < 0 || layer >= dims->n_layers)) return VN_ERR_INVALID;
+    *offset = tensor_offset(dims, tensor_id, per_layer ? layer : 0);
+    *count = tensor_count(dims, tensor_id);
+    return VN_OK;
+}
+
+static const float* W(const vn_model* m, int id, int layer = 0) { return m->blob + tensor_offset(&m->d, id, layer); }
+
+// ---- context ---------------------------------------------------------------------------------
+extern "C" const char* vn_version(void) { return "vampnet_hip 0.1 gfx950 f32-mfma"; }
+
+extern "C" int vn_ctx_create(int device, vn_ctx** out) {
+    if (!out) return VN_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return VN_ERR_HIP;
+    vn_ctx* c = new (std::nothrow) vn_ctx();
+    if (!c) return VN_ERR_OOM;
+    c->device = device;
+    c->err[0] = 0;
+    c->prof = vn_prof();
+    if (hipSetDevice(device) != hipSuccess) { delete c; return VN_ERR_HIP; }
+    *out = c;
+    return VN_OK;
+}
+static void prof_free(vn_ctx* ctx) {
+    vn_prof& p = ctx->prof;
+    for (int i = 0; i < 2 * p.cap; ++i) (void)hipEventDestroy(p.ev[i]);
+    delete[] p.ev; delete[] p.cls; delete[] p.flops;
+    p = vn_prof();
+}
+extern "C" void vn_ctx_destroy(vn_ctx* ctx) {
+    if (!ctx) return;
+    prof_free(ctx);
+    delete ctx;
+}
+
+extern "C" int vn_profile_begin(vn_ctx* ctx, int max_launches) {
+    if (!ctx || max_launches <= 0) return VN_ERR_INVALID;
+    vn_prof& p = ctx->prof;
+    if (p.cap < max_launches) {
+        prof_free(ctx);
+        p.ev = new (std::nothrow) hipEvent_t[2 * (size_t)max_launches];
+        p.cls = new (std::nothrow) int[max_launches];
+        p.flops = new (std::nothrow) double[max_launches];
+        if (!p.ev || !p.cls || !p.flops) return VN_ERR_OOM;
+        for (int i = 0; i < 2 * max_launches; ++i) VN_HIP_CHECK(ctx, hipEventCreate(&p.ev[i]));
+        p.cap = max_launches;
+    }
+    p.n = 0;
+    p.on = true;
+    return VN_OK;
+}
+
+extern "C" int vn_profile_end(vn_ctx* ctx, double* st) {
+    if (!ctx || !st) return VN_ERR_INVALID;
+    vn_prof& p = ctx->prof;
+    for (int i = 0; i < 6; ++i) st[i] = 0.0;
+    p.on = false;
+    for (int i = 0; i < p.n; ++i) {
+        VN_HIP_CHECK(ctx, hipEventSynchronize(p.ev[2 * i + 1]));
+        float ms = 0.f;
+        VN_HIP_CHECK(ctx, hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]));
+        const int c = p.cls[i];
+        st[3 * c + 0] += 1.0;
+        st[3 * c + 1] += ms;
+        st[3 * c + 2] += p.flops[i];
+    }
+    p.n = 0;
+    return VN_OK;
+}
+extern "C" const char* vn_last_error(const vn_ctx* ctx) { return ctx ? ctx->err : "null ctx"; }
+
+// ---- model -----------------------------------------------------------------------------------
+template <typename T>
+static int dev_alloc(vn_ctx* ctx, T** p, size_t n) {
+    void* q = nullptr;
+    if (hipMalloc(&q, n * sizeof(T) + 256) != hipSuccess) {
+        vn_fail(ctx, VN_ERR_OOM, "hipMalloc of %s%ld bytes failed", "", (long)(n * sizeof(T)));
+        return VN_ERR_OOM;
+    }
+    *p = (T*)q;
+    return VN_OK;
+}
+
+extern "C" void vn_model_destroy(vn_model* m) {
+    if (!m) return;
+    float* fb[] = {m->x, m->y, m->qkv, m->g, m->logits, m->bias_full, m->psel};
+    for (float* p : fb) (void)hipFree(p);
+    int32_t* ib[] = {m->z, m->z_sampled, m->sampled, m->count, m->lut};
+    for (int32_t* p : ib) (void)hipFree(p);
+    delete m;
+}
+
+extern "C" int vn_model_create(vn_ctx* ctx, const vn_dims* dims, const float* blob_dev, vn_model** out) {
+    if (!ctx || !out) return VN_ERR_INVALID;
+    *out = nullptr;
+    int rc = dims_check(ctx, dims);
+    if (rc != VN_OK) return rc;
+    if (!blob_dev) return vn_fail(ctx, VN_ERR_INVALID, "weight blob is NULL%s", "");
+    if (dims->max_batch <= 0 || dims->max_T <= 0) return vn_fail(ctx, VN_ERR_INVALID, "max_batch/max_T must be > 0%s", "");
+    VN_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    vn_model* m = new (std::nothrow) vn_model();
+    if (!m) return VN_ERR_OOM;
+    memset(m, 0, sizeof(*m));
+    m->ctx = ctx; m->d = *dims; m->blob = blob_dev;
+    m->D = dims->d_model; m->H = dims->n_heads; m->L = dims->n_layers; m->Cp = dims->n_codebooks - dims->n_cond;
+    m->bias_T = -1;
+    const size_t rows = (size_t)dims->max_batch * dims->max_T;
+    m->max_rows = (long)rows;
+    const size_t D = m->D, N = (size_t)dims->max_T * m->Cp, B = dims->max_batch;
+    const size_t ztot = B * dims->n_codebooks * dims->max_T;
+    if ((rc = dev_alloc(ctx, &m->x, rows * D)) || (rc = dev_alloc(ctx, &m->y, rows * D)) ||
+        (rc = dev_alloc(ctx, &m->qkv, 3 * rows * D)) || (rc = dev_alloc(ctx, &m->g, rows * 2 * D)) ||
+        (rc = dev_alloc(ctx, &m->logits, B * N * dims->vocab)) ||
+        (rc = dev_alloc(ctx, &m->bias_full, (size_t)m->H * (2 * dims->max_T - 1))) ||
+        (rc = dev_alloc(ctx, &m->psel, B * N)) || (rc = dev_alloc(ctx, &m->z, ztot)) ||
+        (rc = dev_alloc(ctx, &m->z_sampled, ztot)) || (rc = dev_alloc(ctx, &m->sampled, B * N)) ||
+        (rc = dev_alloc(ctx, &m->count, (size_t)16)) || (rc = dev_alloc(ctx, &m->lut, (size_t)2 * dims->max_T))) {
+        vn_model_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return VN_OK;
+}
+
+static int ensure_bias(vn_model* m, int T, hipStream_t s) {
+    if (m->bias_T == T) return VN_OK;
+    std::vector<int32_t> lut(2 * T - 1);
+    vn_bucket_lut_host(T, m->d.num_buckets, m->d.max_distance, lut.data());
+    // pageable-host async copy: the runtime stages the source before returning
+    VN_HIP_CHECK(m->ctx, hipMemcpyAsync(m->lut, lut.data(), lut.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    VN_HIP_CHECK(m->ctx, hipStreamSynchronize(s));
+    int rc = vn_launch_bias_expand(m->ctx, W(m, VN_W_REL_BIAS), m->lut, m->bias_full, m->H, T, s);
+    if (rc == VN_OK) m->bias_T = T;
+    return rc;
+}
+
+// forward on the int32 token buffer m->z -> m->logits   (layers.py:134-163 + transformer.py:617-639)
+static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logits, hipStream_t s) {
+    vn_ctx* ctx = m->ctx;
+    const int D = m->D, H = m->H, M = B * T;
+    int rc;
+    if ((rc = ensure_bias(m, T, s))) return rc;
+    if ((rc = vn_launch_embed(ctx, z, W(m, VN_W_EMB_TABLES), W(m, VN_W_EMB_WT), W(m, VN_W_EMB_B), m->x, B,
+                              m->d.n_codebooks, T, m->d.vocab + 1, m->d.latent_dim, D, s)))
+        return rc;
+    const long plane = (long)B * H * T * VN_DHEAD;
+    for (int l = 0; l < m->L; ++l) {
+        // y = RMSNorm(x) ; FiLM = identity (d_cond = 0, transformer.py:554)
+        if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM1, l), m->y, M, D, m->d.eps, s))) return rc;
+        vn_gemm_args a{};
+        a.A = m->y; a.W = W(m, VN_W_QKV, l); a.C = m->qkv; a.M = M; a.N = 3 * D; a.K = D; a.ldc = 3 * D;
+        a.T = T; a.H = H; a.qkv_plane = plane;
+        if ((rc = vn_launch_gemm_f32(ctx, a, VN_EPI_QKV, s))) return rc;
+        if ((rc = vn_launch_attention(ctx, m->qkv, m->qkv + plane, m->qkv + 2 * plane, m->bias_full, m->y, B, H, T, s)))
+            return rc;
+        vn_gemm_args o{};
+        o.A = m->y; o.W = W(m, VN_W_WO, l); o.C = m->x; o.M = M; o.N = D; o.K = D; o.ldc = D;
+        if ((rc = vn_launch_gemm_f32(ctx, o, VN_EPI_RESIDUAL, s))) return rc;           // x = x + attn
+        if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM3, l), m->y, M, D, m->d.eps, s))) return rc;
+        vn_gemm_args f1{};
+        f1.A = m->y; f1.W = W(m, VN_W_W1, l); f1.C = m->g; f1.M = M; f1.N = 4 * D; f1.K = D; f1.ldc = 2 * D;
+        if ((rc = vn_launch_gemm_f32(ctx, f1, VN_EPI_GEGLU, s))) return rc;             // g = p1 * gelu(p2)
+        vn_gemm_args f2{};
+        f2.A = m->g; f2.W = W(m, VN_W_W2, l); f2.C = m->x; f2.M = M; f2.N = D; f2.K = 2 * D; f2.ldc = D;
+        if ((rc = vn_launch_gemm_f32(ctx, f2, VN_EPI_RESIDUAL, s))) return rc;          // x = x + ffn
+    }
+    if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_FINAL_NORM), m->y, M, D, m->d.eps, s))) return rc;
+    vn_gemm_args c{};
+    c.A = m->y; c.W = W(m, VN_W_CLS_W); c.bias = W(m, VN_W_CLS_B); c.C = logits; c.M = M;
+    c.N = m->Cp * m->d.vocab; c.K = D; c.ldc = c.N;
+    return vn_launch_gemm_f32(ctx, c, VN_EPI_BIAS, s);
+}
+
+static int shape_check(vn_model* m, int B, int T) {
+    if (!m) return VN_ERR_INVALID;
+    if (B <= 0 || T <= 0 || B > m->d.max_batch || T > m->d.max_T)
+        return vn_fail(m->ctx, VN_ERR_INVALID, "batch/T out of the workspace bounds given at vn_model_create (B=%s%ld, T=%ld)",
+                       "", B, T);
+    return VN_OK;
+}
+
+extern "C" int vn_forward(vn_model* m, const int64_t* codes, int B, int T, float* logits, void* stream) {
+    int rc = shape_check(m, B, T);
+    if (rc) return rc;
+    if (!codes || !logits) return vn_fail(m->ctx, VN_ERR_INVALID, "NULL codes/logits%s", "");
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)B * m->d.n_codebooks * T;
+    if ((rc = vn_launch_i64_to_i32(m->ctx, codes, m->z, n, s))) return rc;
+    return forward_i32(m, m->z, B, T, logits, s);
+}
+
+// gamma schedule on the host (mask.py:8-9, transformer.py:903) — used only when the caller passes no schedule
+static long host_k_sched(int i, int steps, long n0) {
+    const float r = (float)((double)(i + 1) / (double)steps);
+    float gm = cosf(r * 3.14159265358979323846f / 2.0f);
+    gm = gm < 1e-10f ? 1e-10f : (gm > 1.0f ? 1.0f : gm);
+    return (long)floorf(gm * (float)n0);
+}
+
+static int sample_step(vn_model* m, int B, int T, int step, const vn_sample_params* p, long k_sched,
+                       const float* logits, const float* exp_noise, const float* unif_noise, bool want_sampled,
+                       hipStream_t s) {
+    vn_sample_args sa{};
+    sa.logits = logits; sa.z = m->z; sa.exp_noise = exp_noise; sa.sampled = m->sampled; sa.psel = m->psel;
+    sa.B = B; sa.T = T; sa.C = m->d.n_codebooks; sa.n_cond = m->d.n_cond; sa.V = m->d.vocab;
+    sa.temperature = p->temperature > 0.f ? p->temperature : 1.0f;                  // transformer.py:1019-1023
+    sa.do_sample = ((double)step / (double)p->steps) <= p->sample_cutoff ? 1 : 0;  // transformer.py:852-855 (Python doubles)
+    sa.seed = p->seed; sa.step = (uint32_t)step; sa.batch_offset = (long)p->batch_offset;
+    int rc = vn_launch_sample(m->ctx, sa, s);
+    if (rc) return rc;
+    const float r = (float)((double)(step + 1) / (double)p->steps);   // torch.tensor(python float) -> f32 (util.py:6-7)
+    vn_remask_args ra{};
+    ra.sampled = m->sampled; ra.psel = m->psel; ra.unif_noise = unif_noise; ra.z = m->z;
+    ra.out_sampled = want_sampled ? m->z_sampled : nullptr;
+    ra.B = B; ra.T = T; ra.C = m->d.n_codebooks; ra.n_cond = m->d.n_cond; ra.V = m->d.vocab;
+    ra.mask_temp = p->mask_temperature * (1.0f - r);                               // transformer.py:917-919
+    ra.k_sched = k_sched; ra.last_step = (step == p->steps - 1);
+    ra.seed = p->seed; ra.step = (uint32_t)step; ra.batch_offset = (long)p->batch_offset;
+    return vn_launch_remask(m->ctx, ra, s);
+}
+
+static int params_check(vn_model* m, const vn_sample_params* p) {
+    if (!p) return vn_fail(m->ctx, VN_ERR_INVALID, "params is NULL%s", "");
+    if (p->steps <= 0) return vn_fail(m->ctx, VN_ERR_INVALID, "steps must be > 0%s", "");
+    if (p->top_p > 0.f && p->top_p < 1.f)
+        return vn_fail(m->ctx, VN_ERR_UNSUPPORTED, "top_p in (0,1) is not implemented on the device yet%s", "");
+    return VN_OK;
+}
+
+extern "C" int vn_sample_step(vn_model* m, int64_t* z_masked, const float* logits, int B, int T, int step,
+                              const vn_sample_params* params, int64_t num_to_mask_sched, const float* exp_noise,
+                              const float* unif_noise, int64_t* sampled_out, void* stream) {
+    int rc = shape_check(m, B, T);
+    if (rc) return rc;
+    if ((rc = params_check(m, params))) return rc;
+    if (!z_masked || !logits) return vn_fail(m->ctx, VN_ERR_INVALID, "NULL z_masked/logits%s", "");
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)B * m->d.n_codebooks * T;
+    if ((rc = vn_launch_i64_to_i32(m->ctx, z_masked, m->z, n, s))) return rc;
+    if ((rc = sample_step(m, B, T, step, params, (long)num_to_mask_sched, logits, exp_noise, unif_noise,
+                          sampled_out != nullptr, s)))
+        return rc;
+    if ((rc = vn_launch_i32_to_i64(m->ctx, m->z, z_masked, n, s))) return rc;
+    if (sampled_out) rc = vn_launch_i32_to_i64(m->ctx, m->z_sampled, sampled_out, n, s);
+    return rc;
+}
+
+extern "C" int vn_generate(vn_model* m, const int64_t* start_tokens, const int64_t* mask, int B, int T,
+                           const vn_sample_params* p, const int64_t* sched, const float* exp_noise,
+                           const float* unif_noise, int64_t* out_tokens, void* stream) {
+    int rc = shape_check(m, B, T);
+    if (rc) return rc;
+    if ((rc = params_check(m, p))) return rc;
+    if (!start_tokens || !mask || !out_tokens) return vn_fail(m->ctx, VN_ERR_INVALID, "NULL tokens/mask/out%s", "");
+    hipStream_t s = (hipStream_t)stream;
+    vn_ctx* ctx = m->ctx;
+    const long n = (long)B * m->d.n_codebooks * T;
+    const long N = (long)T * m->Cp, V = m->d.vocab;
+    VN_HIP_CHECK(ctx, hipMemsetAsync(m->count, 0, sizeof(int32_t), s));
+    if ((rc = vn_launch_apply_mask(ctx, start_tokens, mask, m->z, m->count, n, (int)V, s))) return rc;   // :762-766
+    long n0 = p->n0_override;
+    std::vector<long> ks(p->steps);
+    if (sched) {
+        for (int i = 0; i < p->steps; ++i) ks[i] = (long)sched[i];
+    } else {
+        if (n0 < 0) {   // one blocking read of the batch-wide masked count (transformer.py:766)
+            int32_t c = 0;
+            VN_HIP_CHECK(ctx, hipMemcpyAsync(&c, m->count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            VN_HIP_CHECK(ctx, hipStreamSynchronize(s));
+            n0 = c;
+        }
+        for (int i = 0; i < p->steps; ++i) ks[i] = host_k_sched(i, p->steps, n0);
+    }
+    for (int i = 0; i < p->steps; ++i) {
+        if ((rc = forward_i32(m, m->z, B, T, m->logits, s))) return rc;
+        const float* en = exp_noise ? exp_noise + (size_t)i * B * N * V : nullptr;
+        const float* un = unif_noise ? unif_noise + (size_t)i * B * N : nullptr;
+        if ((rc = sample_step(m, B, T, i, p, ks[i], m->logits, en, un, i == p->steps - 1, s))) return rc;
+    }
+    return vn_launch_i32_to_i64(ctx, m->z_sampled, out_tokens, n, s);                   // transformer.py:935-946
+}
+
+// ---- single-kernel entry points ---------------------------------------------------------------
+extern "C" int vn_rmsnorm_f32(vn_ctx* ctx, const float* x, const float* w, float* y, int rows, int D, float eps,
+                              void* stream) {
+    if (!ctx || !x || !w || !y) return VN_ERR_INVALID;
+    return vn_launch_rmsnorm(ctx, x, w, y, rows, D, eps, (hipStream_t)stream);
+}
+
+extern "C" int vn_gemm_f32(vn_ctx* ctx, const float* A, const float* Wt, const float* bias, float* C, int M, int N,
+                           int K, int epilogue, void* stream) {
+    if (!ctx || !A || !Wt || !C) return VN_ERR_INVALID;
+    if (epilogue < VN_EPI_STORE || epilogue > VN_EPI_GEGLU) return vn_fail(ctx, VN_ERR_INVALID, "bad epilogue%s", "");
+    if (epilogue == VN_EPI_BIAS && !bias) return vn_fail(ctx, VN_ERR_INVALID, "bias epilogue needs bias%s", "");
+    vn_gemm_args a{};
+    a.A = A; a.W = Wt; a.bias = bias; a.C = C; a.M = M; a.N = N; a.K = K;
+    a.ldc = epilogue == VN_EPI_GEGLU ? N / 2 : N;
+    return vn_launch_gemm_f32(ctx, a, epilogue, (hipStream_t)stream);
+}
+
+extern "C" int vn_attention_f32(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                                float* out, int B, int H, int T, int num_buckets, int max_distance, void* stream) {
+    if (!ctx || !q || !k || !v || !rel_bias || !out || T <= 0 || H <= 0) return VN_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    // unit-test path: scratch for the expanded table is allocated per call (the model path pre-allocates)
+    float* full = nullptr;
+    int32_t* lut_d = nullptr;
+    const int n = 2 * T - 1;
+    VN_HIP_CHECK(ctx, hipMalloc((void**)&full, (size_t)H * n * sizeof(float)));
+    VN_HIP_CHECK(ctx, hipMalloc((void**)&lut_d, (size_t)n * sizeof(int32_t)));
+    std::vector<int32_t> lut(n);
+    vn_bucket_lut_host(T, num_buckets, max_distance, lut.data());
+    int rc = VN_OK;
+    if (hipMemcpy(lut_d, lut.data(), n * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) rc = VN_ERR_HIP;
+    if (rc == VN_OK) rc = vn_launch_bias_expand(ctx, rel_bias, lut_d, full, H, T, s);
+    if (rc == VN_OK) rc = vn_launch_attention(ctx, q, k, v, full, out, B, H, T, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(full);
+    (void)hipFree(lut_d);
+    return rc;
+}

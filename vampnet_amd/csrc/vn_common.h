@@ -1,0 +1,124 @@
+// Internal helpers shared by the gfx950 kernels of libvampnet_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include "../../include/vampnet_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define VN_WAVE 64
+#define VN_DHEAD 64
+
+struct vn_prof {
+    bool on = false;
+    int cap = 0, n = 0;
+    hipEvent_t* ev = nullptr;      // 2 events per launch
+    int* cls = nullptr;            // class per launch (0 gemm, 1 attention)
+    double* flops = nullptr;
+};
+
+struct vn_ctx {
+    int device;
+    char err[512];
+    vn_prof prof;
+};
+
+// bracket a launch with events when profiling is on (no-ops otherwise)
+static inline int vn_prof_pre(vn_ctx* ctx, int cls, double flops, hipStream_t s) {
+    vn_prof& p = ctx->prof;
+    if (!p.on || p.n >= p.cap) return -1;
+    const int i = p.n++;
+    p.cls[i] = cls;
+    p.flops[i] = flops;
+    (void)hipEventRecord(p.ev[2 * i], s);
+    return i;
+}
+static inline void vn_prof_post(vn_ctx* ctx, int i, hipStream_t s) {
+    if (i >= 0) (void)hipEventRecord(ctx->prof.ev[2 * i + 1], s);
+}
+
+static inline int vn_fail(vn_ctx* ctx, int code, const char* fmt, const char* a = "", long b = 0, long c = 0) {
+    if (ctx) snprintf(ctx->err, sizeof(ctx->err), fmt, a, b, c);
+    return code;
+}
+
+#define VN_HIP_CHECK(ctx, expr)                                                            \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            if (ctx) snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s (%s:%d)", #expr, \
+                              hipGetErrorString(_e), __FILE__, __LINE__);                  \
+            return VN_ERR_HIP;                                                             \
+        }                                                                                  \
+    } while (0)
+
+#define VN_LAUNCH_CHECK(ctx) VN_HIP_CHECK(ctx, hipGetLastError())
+
+static inline int vn_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- launchers implemented in the .hip files ------------------------------------------------
+enum { VN_EPI_STORE = 0, VN_EPI_BIAS = 1, VN_EPI_RESIDUAL = 2, VN_EPI_GEGLU = 3, VN_EPI_QKV = 4 };
+
+struct vn_gemm_args {
+    const float* A;      // [M][K] row-major, lda = K
+    const float* W;      // [N][K] row-major
+    const float* bias;   // [N] or null
+    float* C;            // epilogue dependent
+    int M, N, K;
+    int ldc;             // row stride of C (floats)
+    // QKV scatter: C = qkv base [3][B][H][T][64]; row m = b*T + t
+    int T, H;
+    long qkv_plane;      // B*H*T*64
+};
+int vn_launch_gemm_f32(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);
+
+int vn_launch_rmsnorm(vn_ctx* ctx, const float* x, const float* w, float* y, int rows, int D, float eps, hipStream_t s);
+int vn_launch_embed(vn_ctx* ctx, const int32_t* codes, const float* tables, const float* wt, const float* b,
+                    float* x, int B, int C, int T, int V1, int latent, int D, hipStream_t s);
+int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* relbias_full,
+                        float* out, int B, int H, int T, hipStream_t s);
+// expands [num_buckets][H] into per-head tables over rel = key - query in [-(T-1), T-1]: out[h][rel + T - 1]
+void vn_bucket_lut_host(int T, int num_buckets, int max_distance, int32_t* lut /* [2T-1] */);
+int vn_launch_bias_expand(vn_ctx* ctx, const float* rel_bias, const int32_t* lut_dev, float* out, int H, int T,
+                          hipStream_t s);
+
+struct vn_sample_args {
+    const float* logits;      // [B][N][V]   N = T*Cp
+    const int32_t* z;         // [B][C][T] current tokens (MASK = V)
+    const float* exp_noise;   // [B*N][V] or null
+    int32_t* sampled;         // [B][N]
+    float* psel;              // [B][N]  (+inf where not masked)
+    int B, T, C, n_cond, V;
+    float temperature;        // already resolved (>0)
+    int do_sample;
+    uint64_t seed;
+    uint32_t step;
+    long batch_offset;        // global index of item 0 (device RNG only)
+};
+int vn_launch_sample(vn_ctx* ctx, const vn_sample_args& a, hipStream_t s);
+
+struct vn_remask_args {
+    const int32_t* sampled;   // [B][N]
+    const float* psel;        // [B][N]
+    const float* unif_noise;  // [B][N] or null
+    int32_t* z;               // [B][C][T] in/out (only codebooks >= n_cond rewritten)
+    int32_t* out_sampled;     // [B][C][T] or null: sampled tokens unflattened (+ cond codebooks from z)
+    int B, T, C, n_cond, V;
+    float mask_temp;          // mask_temperature * (1 - r)
+    long k_sched;             // floor(gamma(r) * N0)
+    int last_step;
+    uint64_t seed;
+    uint32_t step;
+    long batch_offset;
+};
+int vn_launch_remask(vn_ctx* ctx, const vn_remask_args& a, hipStream_t s);
+
+int vn_launch_i64_to_i32(vn_ctx* ctx, const int64_t* in, int32_t* out, long n, hipStream_t s);
+int vn_launch_i32_to_i64(vn_ctx* ctx, const int32_t* in, int64_t* out, long n, hipStream_t s);
+// z = mask ? V : tokens ; also counts masked tokens into *count (device int32, pre-zeroed)
+int vn_launch_apply_mask(vn_ctx* ctx, const int64_t* tokens, const int64_t* mask, int32_t* z, int32_t* count,
+                         long n, int V, hipStream_t s);

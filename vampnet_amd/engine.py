@@ -1,0 +1,338 @@
+"""Host-side mirror of the reference `VampNet` inference API over libvampnet_hip.so.
+
+`VampNetModel` offers what `Interface` needs from `vampnet.modules.transformer.VampNet`
+(reference transformer.py:535-946): `n_codebooks`, `n_conditioning_codebooks`, `mask_token`,
+`chunk_size_s`, `generate(...)` with the same keyword names and defaults, plus `forward_codes`
+(= embedding.from_codes + forward) for parity tests.  All arithmetic happens in the HIP library;
+torch only owns device memory and the stream.  Nothing here imports `oracle/`.
+"""
+import ctypes as C
+import math
+import random
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import VnError, vn_dims, vn_sample_params
+
+LORA_SCALING = 1.0 / 8.0      # loralib: lora_alpha / r = 1 / 8 (transformer.py:22 LORA_R)
+
+
+def seed_all(seed: int):
+    """audiotools.util.seed as the reference calls it at transformer.py:711-712: reseeds the GLOBAL RNGs."""
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+class Engine:
+    """One vn_ctx per device."""
+
+    def __init__(self, device="cuda:0"):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise VnError("no GPU visible: the vampnet_amd engine has no CPU path")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise VnError(f"device must be a ROCm GPU, got {device}")
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        h = C.c_void_p()
+        rc = self.lib.vn_ctx_create(idx, C.byref(h))
+        if rc != 0:
+            raise VnError(f"vn_ctx_create({idx}) failed with status {rc}")
+        self.handle = h
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def check(self, rc, what):
+        _lib.check(rc, self.handle, what)
+
+    def version(self):
+        return self.lib.vn_version().decode()
+
+    def profile_begin(self, max_launches=20000):
+        self.check(self.lib.vn_profile_begin(self.handle, max_launches), "vn_profile_begin")
+
+    def profile_end(self):
+        """{'gemm': (launches, ms, flops), 'attention': (...)} for the launches since profile_begin."""
+        st = (C.c_double * 6)()
+        self.check(self.lib.vn_profile_end(self.handle, st), "vn_profile_end")
+        return {"gemm": tuple(st[0:3]), "attention": tuple(st[3:6])}
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.vn_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ---- single kernels (tests / profiling) ---------------------------------------------------
+    def rmsnorm(self, x, w, eps=1e-6):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        rows = x.numel() // x.shape[-1]
+        self.check(self.lib.vn_rmsnorm_f32(self.handle, x.data_ptr(), w.data_ptr(), y.data_ptr(), rows,
+                                           x.shape[-1], eps, self.stream()), "vn_rmsnorm_f32")
+        return y
+
+    def gemm(self, a, w, bias=None, epilogue=_lib.EPI_STORE, out=None):
+        """out (op)= a @ w.T ; a [M,K], w [N,K] (torch F.linear)."""
+        M, K = a.shape
+        N = w.shape[0]
+        if out is None:
+            out = torch.empty(M, N // 2 if epilogue == _lib.EPI_GEGLU else N, device=a.device, dtype=torch.float32)
+        self.check(self.lib.vn_gemm_f32(self.handle, a.data_ptr(), w.data_ptr(),
+                                        bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                        M, N, K, epilogue, self.stream()), "vn_gemm_f32")
+        return out
+
+    def attention(self, q, k, v, rel_bias, num_buckets=32, max_distance=128):
+        """q,k,v [B,H,T,64]; rel_bias [num_buckets,H] -> [B,T,H*64]."""
+        B, H, T, dh = q.shape
+        out = torch.empty(B, T, H * dh, device=q.device, dtype=torch.float32)
+        self.check(self.lib.vn_attention_f32(self.handle, q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                             rel_bias.data_ptr(), out.data_ptr(), B, H, T, num_buckets,
+                                             max_distance, self.stream()), "vn_attention_f32")
+        return out
+
+
+def _merge_lora(sd, key):
+    """W_eff = W + (lora_B @ lora_A) * alpha / r for a lora.Linear in eval mode."""
+    w = sd[key + ".weight"].float()
+    a, b = sd.get(key + ".lora_A"), sd.get(key + ".lora_B")
+    if a is not None and b is not None:
+        w = w + (b.float() @ a.float()) * LORA_SCALING
+    return w
+
+
+def pack_weights(lib, dims: vn_dims, sd: dict, codebooks: torch.Tensor) -> torch.Tensor:
+    """Builds the packed fp32 blob (layout: include/vampnet_hip.h) on the host from a reference-format
+    state_dict (key names: SURVEY.md App. B) and the codec codebooks [>=C, vocab, latent]."""
+    n = C.c_int64()
+    if lib.vn_weights_size(C.byref(dims), C.byref(n)) != 0:
+        raise VnError("vn_weights_size rejected the dims (need d_model == 64 * n_heads, vocab 1024)")
+    blob = torch.zeros(n.value, dtype=torch.float32)
+
+    def put(tid, layer, t):
+        off, cnt = C.c_int64(), C.c_int64()
+        if lib.vn_weights_offset(C.byref(dims), tid, layer, C.byref(off), C.byref(cnt)) != 0:
+            raise VnError(f"vn_weights_offset({tid},{layer}) failed")
+        t = t.contiguous().float().reshape(-1)
+        if t.numel() != cnt.value:
+            raise VnError(f"tensor {tid} layer {layer}: expected {cnt.value} values, got {t.numel()}")
+        blob[off.value:off.value + cnt.value] = t
+
+    Cn, nc, V, D = dims.n_codebooks, dims.n_cond, dims.vocab, dims.d_model
+    Cp = Cn - nc
+    mask_rows = sd["embedding.special.MASK"].float()                       # [C, latent]
+    tables = torch.cat([codebooks[:Cn].float(), mask_rows[:, None, :]], dim=1)   # [C, V+1, latent]
+    put(_lib.W_EMB_TABLES, 0, tables)
+    put(_lib.W_EMB_WT, 0, sd["embedding.out_proj.weight"].float().squeeze(-1).t())
+    put(_lib.W_EMB_B, 0, sd["embedding.out_proj.bias"])
+    put(_lib.W_REL_BIAS, 0, sd["transformer.layers.0.self_attn.relative_attention_bias.weight"])
+    put(_lib.W_FINAL_NORM, 0, sd["transformer.norm.weight"])
+    # classifier: fold old-style weight_norm (w = g * v / ||v||), reorder rows (p c) -> (c p)
+    if "classifier.layers.0.weight_v" in sd:
+        wc = torch._weight_norm(sd["classifier.layers.0.weight_v"].float(), sd["classifier.layers.0.weight_g"].float(), 0)
+    else:   # new-style parametrization or already-folded weight
+        wc = sd["classifier.layers.0.weight"].float()
+    wc = wc.reshape(V, Cp, D).permute(1, 0, 2)
+    put(_lib.W_CLS_W, 0, wc)
+    put(_lib.W_CLS_B, 0, sd["classifier.layers.0.bias"].float().reshape(V, Cp).t())
+    for l in range(dims.n_layers):
+        p = f"transformer.layers.{l}."
+        put(_lib.W_NORM1, l, sd[p + "norm_1.weight"])
+        put(_lib.W_QKV, l, torch.cat([_merge_lora(sd, p + "self_attn.w_qs"), sd[p + "self_attn.w_ks.weight"].float(),
+                                      _merge_lora(sd, p + "self_attn.w_vs")], dim=0))
+        put(_lib.W_WO, l, _merge_lora(sd, p + "self_attn.fc"))
+        put(_lib.W_NORM3, l, sd[p + "norm_3.weight"])
+        w1 = _merge_lora(sd, p + "feed_forward.w_1")
+        val, gate = w1[:2 * D].reshape(2 * D // 32, 32, D), w1[2 * D:].reshape(2 * D // 32, 32, D)
+        put(_lib.W_W1, l, torch.stack([val, gate], dim=1))
+        put(_lib.W_W2, l, _merge_lora(sd, p + "feed_forward.w_2"))
+    return blob
+
+
+def draw_noise_host(B, N, V, steps, sample_cutoff, b0=0, nb=None, pin=False):
+    """torch-CPU noise ledger of one generate() call for a global batch B; returns the rows of items
+    [b0, b0+nb): exp [steps, nb*N, V] (zeros on non-sampling steps), unif [steps, nb, N]."""
+    nb = B if nb is None else nb
+    exp = torch.zeros(steps, nb * N, V, dtype=torch.float32)
+    unif = torch.empty(steps, nb, N, dtype=torch.float32)
+    if pin:
+        exp, unif = exp.pin_memory(), unif.pin_memory()
+    whole = (b0 == 0 and nb == B)
+    for i in range(steps):
+        if (i / steps) <= sample_cutoff:                      # transformer.py:852-855
+            if whole:
+                exp[i].exponential_(1)
+            else:
+                exp[i].copy_(torch.empty(B * N, V).exponential_(1)[b0 * N:(b0 + nb) * N])
+        if whole:
+            unif[i].uniform_(1e-20, 1)
+        else:
+            unif[i].copy_(torch.zeros(B, N).uniform_(1e-20, 1)[b0:b0 + nb])
+    return exp, unif
+
+
+class VampNetModel:
+    """Device-resident VampNet (one of coarse / c2f)."""
+
+    def __init__(self, engine: Engine, sd: dict, codebooks: torch.Tensor, *, n_heads, n_layers, n_codebooks,
+                 n_conditioning_codebooks=0, latent_dim=8, embedding_dim=1280, vocab_size=1024,
+                 max_batch=8, max_T=575, chunk_size_s=10, **_ignored):
+        self.engine = engine
+        self.lib = engine.lib
+        self.n_heads, self.n_layers = n_heads, n_layers
+        self.n_codebooks = n_codebooks
+        self.n_conditioning_codebooks = n_conditioning_codebooks
+        self.n_predict_codebooks = n_codebooks - n_conditioning_codebooks
+        self.latent_dim, self.embedding_dim, self.vocab_size = latent_dim, embedding_dim, vocab_size
+        self.mask_token = vocab_size                     # transformer.py:576
+        self.chunk_size_s = chunk_size_s
+        self.dims = vn_dims(n_layers, n_heads, embedding_dim, n_codebooks, n_conditioning_codebooks, vocab_size,
+                            latent_dim, 32, 128, 1e-6, max_batch, max_T)
+        blob = pack_weights(self.lib, self.dims, sd, codebooks)
+        self.blob = blob.to(engine.device)               # must outlive the vn_model
+        h = C.c_void_p()
+        engine.check(self.lib.vn_model_create(engine.handle, C.byref(self.dims), self.blob.data_ptr(), C.byref(h)),
+                     "vn_model_create")
+        self.handle = h
+
+    @property
+    def device(self):
+        return self.engine.device
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.vn_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ---- forward ------------------------------------------------------------------------------
+    def forward_codes(self, codes: torch.Tensor, layout="reference"):
+        """embedding.from_codes + forward.  codes int64 [B, C, T] (MASK = vocab).
+        layout="native": [B, T, Cp, V]; "reference": [B, V, T*Cp] (transformer.py:634)."""
+        B, Cn, T = codes.shape
+        assert Cn == self.n_codebooks
+        codes = codes.to(self.device, torch.int64).contiguous()
+        logits = torch.empty(B, T, self.n_predict_codebooks, self.vocab_size, device=self.device, dtype=torch.float32)
+        self.engine.check(self.lib.vn_forward(self.handle, codes.data_ptr(), B, T, logits.data_ptr(),
+                                              self.engine.stream()), "vn_forward")
+        if layout == "native":
+            return logits
+        return logits.reshape(B, T * self.n_predict_codebooks, self.vocab_size).permute(0, 2, 1)
+
+    # ---- sampling ------------------------------------------------------------------------------
+    def _params(self, steps, temperature, mask_temperature, sample_cutoff, top_p, n0_override, seed, batch_offset=0):
+        return vn_sample_params(int(steps), float(temperature), float(mask_temperature), float(sample_cutoff),
+                                float(top_p) if top_p is not None else 0.0,
+                                int(n0_override) if n0_override is not None else -1,
+                                int(seed) & 0xFFFFFFFFFFFFFFFF, int(batch_offset))
+
+    @staticmethod
+    def mask_schedule(steps: int, n0: int):
+        """floor(gamma((i+1)/steps) * N0) per step with torch's own fp32 ops (mask.py:8-9, transformer.py:831-834,903)
+        so the integer schedule is bit-identical to the reference's."""
+        n0_t = torch.tensor(int(n0))
+        out = []
+        for i in range(steps):
+            r = torch.tensor((i + 1) / steps)
+            g = (r * torch.pi / 2).cos().clamp(1e-10, 1.0)
+            out.append(int(torch.floor(g * n0_t).long()))
+        return out
+
+    def draw_noise(self, B, T, steps, sample_cutoff, batch_offset=0, local_batch=None, pin=True):
+        """Replays the reference's torch-CPU draw order: per step an Exp(1) tensor of shape
+        (B*T*Cp, V) iff that step samples (multinomial), then U(1e-20, 1) of shape (B, T*Cp).  B is the GLOBAL
+        batch; when this rank owns items [batch_offset, batch_offset + local_batch) only those rows are kept
+        (every rank draws the identical global stream)."""
+        N = T * self.n_predict_codebooks
+        V = self.vocab_size
+        nb = B if local_batch is None else local_batch
+        b0 = batch_offset
+        return draw_noise_host(B, N, V, steps, sample_cutoff, b0, nb, pin)
+
+    @torch.inference_mode()
+    def generate(self, codec=None, time_steps: int = 300, _sampling_steps: int = 12, start_tokens=None,
+                 temperature: float = 1.0, mask=None, mask_temperature: float = 10.5, ctrls=None, ctrl_masks=None,
+                 typical_filtering=True, typical_mass=0.15, typical_min_tokens=64, top_p=None, seed: int = None,
+                 sample_cutoff: float = 1.0, return_signal=False, debug=False, causal_weight: float = 0.0,
+                 cfg_scale: float = 3.0, cfg_guidance: float = None, cond=None,
+                 rng: str = "torch", n0_override: int = None, device_seed: int = None,
+                 global_batch: int = None, batch_offset: int = 0):
+        """Drop-in for VampNet.generate (transformer.py:686-946).  Extra keywords (not in the reference):
+          rng="torch"  : parity mode — noise is drawn from torch's CPU generator in the reference's order;
+          rng="device" : fast mode — Philox stream on the GPU (seeded by `device_seed` or the torch generator);
+          n0_override  : the global batch's masked-token count when this call sees a shard;
+          global_batch / batch_offset : size of the global batch and index of this shard's first item, so that
+                         both RNG modes draw the noise the unsharded call would.
+        `typical_filtering/typical_mass/typical_min_tokens` are accepted and have no effect, exactly like the
+        reference (transformer.py:989-993 discards the filter's result)."""
+        if ctrls is not None or cfg_guidance is not None:
+            raise NotImplementedError("ctrls / cfg_guidance are never used by Interface (SURVEY.md App. A.3)")
+        if return_signal:
+            raise NotImplementedError("return_signal=True: decode through Interface.decode")
+        if seed is not None:
+            seed_all(seed)
+        z = start_tokens
+        if z is None:
+            raise ValueError("start_tokens is required (the reference crashes on None too: transformer.py:731)")
+        z = z.to(self.device, torch.int64).contiguous()
+        B, Cn, T = z.shape
+        if mask is None:
+            mask = torch.ones_like(z)
+            mask[:, :self.n_conditioning_codebooks, :] = 0
+        mask = mask.to(self.device)
+        if mask.ndim == 2:
+            mask = mask[:, None, :].repeat(1, Cn, 1)
+        mask = (mask != 0).to(torch.int64).contiguous()
+        steps = int(_sampling_steps)
+        if n0_override is None:
+            n0 = int(((mask != 0) | (z == self.mask_token)).sum().item())   # transformer.py:762-766, batch-wide
+        else:
+            n0 = int(n0_override)
+        sched = (C.c_int64 * steps)(*self.mask_schedule(steps, n0))
+        if rng == "torch":
+            exp, unif = self.draw_noise(global_batch or B, T, steps, sample_cutoff, batch_offset, B)
+            exp = exp.to(self.device, non_blocking=True)
+            unif = unif.to(self.device, non_blocking=True)
+            exp_p, unif_p = exp.data_ptr(), unif.data_ptr()
+            dseed = 0
+        elif rng == "device":
+            exp = unif = None
+            exp_p = unif_p = None
+            dseed = device_seed if device_seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
+        else:
+            raise ValueError("rng must be 'torch' or 'device'")
+        params = self._params(steps, temperature, mask_temperature, sample_cutoff, top_p, n0, dseed, batch_offset)
+        out = torch.empty_like(z)
+        self.engine.check(self.lib.vn_generate(self.handle, z.data_ptr(), mask.data_ptr(), B, T, C.byref(params),
+                                               sched, exp_p, unif_p, out.data_ptr(), self.engine.stream()),
+                          "vn_generate")
+        if exp is not None:      # keep the noise alive until the enqueued work has consumed it
+            torch.cuda.current_stream(self.device).synchronize()
+        return out
+
+    @torch.inference_mode()
+    def sample_step(self, z_masked, logits_native, step, steps, n0, *, temperature=1.0, mask_temperature=10.5,
+                    sample_cutoff=1.0, top_p=None, exp_noise=None, unif_noise=None, device_seed=0):
+        """One step of the sampling logic on given logits (teacher-forced parity tests).
+        Returns (z_masked_next, sampled)."""
+        z = z_masked.to(self.device, torch.int64).contiguous().clone()
+        B, Cn, T = z.shape
+        sampled = torch.empty_like(z)
+        params = self._params(steps, temperature, mask_temperature, sample_cutoff, top_p, n0, device_seed)
+        k = self.mask_schedule(steps, n0)[step]
+        self.engine.check(self.lib.vn_sample_step(
+            self.handle, z.data_ptr(), logits_native.contiguous().data_ptr(), B, T, step, C.byref(params), k,
+            exp_noise.data_ptr() if exp_noise is not None else None,
+            unif_noise.data_ptr() if unif_noise is not None else None, sampled.data_ptr(), self.engine.stream()),
+            "vn_sample_step")
+        return z, sampled

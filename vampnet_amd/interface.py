@@ -1,0 +1,312 @@
+"""`Interface` — drop-in twin of the reference's `vampnet.interface.Interface` (interface.py:54-575) whose
+encode / build_mask / vamp / coarse_vamp / coarse_to_fine / decode run on the MI355X engine.
+
+Same method names, argument meaning, defaults, return shapes and error behaviour (asserts) as the
+reference; tokens and masks are torch LongTensors on `self.device`.  The control flow here is host
+orchestration (chunking, padding, stitching); every FLOP is in libvampnet_hip.so.
+
+Additions that the reference does not have (all optional, defaults reproduce the reference):
+  * `rng="torch" | "device"`: parity mode replays torch's CPU generator stream (bit-exact tokens vs the
+    CPU reference, tie-audit caveat in DESIGN.md); "device" uses the in-kernel Philox stream (fast mode).
+  * batch sharding over the GPUs of a node: construct with `process_group=` (one process per GPU,
+    torch.distributed "nccl" = RCCL).  `vamp()` then takes the GLOBAL batch on every rank, runs the
+    coarse + c2f loops on its contiguous slice of batch items and finishes with ONE all-gather of the
+    (B,14,T) token tensor.  The batch-wide N0 quirk (transformer.py:766) is honoured by
+    computing N0 on the global tensors, which every rank holds — no data-path collective.
+"""
+import math
+from pathlib import Path
+
+import torch
+
+from . import masks
+from .engine import Engine, VampNetModel
+
+
+def _load_checkpoint(path):
+    """audiotools BaseModel.load format [UNVERIFIED-DEP, SURVEY.md App. C]:
+    torch.save({"state_dict": ..., "metadata": {"kwargs": {...ctor kwargs...}}})."""
+    ckpt = torch.load(Path(path), map_location="cpu", weights_only=False)
+    if "state_dict" not in ckpt:
+        raise ValueError(f"{path}: not an audiotools-format checkpoint (no 'state_dict')")
+    return ckpt["state_dict"], dict(ckpt.get("metadata", {}).get("kwargs", {}))
+
+
+_MODEL_KEYS = ("n_heads", "n_layers", "n_codebooks", "n_conditioning_codebooks", "latent_dim", "embedding_dim",
+               "vocab_size")
+_DEFAULT_KW = dict(n_heads=20, n_layers=16, n_codebooks=9, n_conditioning_codebooks=0, latent_dim=8,
+                   embedding_dim=1280, vocab_size=1024)          # VampNet.__init__ defaults, transformer.py:536-545
+
+
+def _codec_codebooks(codec):
+    """codec.quantizer.quantizers[i].codebook.weight, the only codec state the sampling loop reads (layers.py:145)."""
+    return torch.stack([q.codebook.weight.detach().float().cpu() for q in codec.quantizer.quantizers])
+
+
+class Interface:
+    def __init__(self, coarse_ckpt: str = None, coarse_lora_ckpt: str = None, coarse2fine_ckpt: str = None,
+                 coarse2fine_lora_ckpt: str = None, codec_ckpt: str = None,
+                 wavebeat_ckpt: str = None, device: str = "cuda:0", coarse_chunk_size_s: int = 10,
+                 coarse2fine_chunk_size_s: int = 3, compile=True, *, codec=None, max_batch: int = 8,
+                 rng: str = "torch", process_group=None):
+        assert codec_ckpt is not None or codec is not None, "must provide a codec checkpoint"
+        assert coarse_ckpt is not None, "must provide a coarse checkpoint"
+        if codec is None:
+            from .codec import DacCodec
+            codec = DacCodec.load(codec_ckpt, device=device)
+        csd, ckw = _load_checkpoint(coarse_ckpt)
+        if coarse_lora_ckpt is not None:
+            csd.update(torch.load(coarse_lora_ckpt, map_location="cpu"))          # interface.py:45, strict=False
+        fsd = fkw = None
+        if coarse2fine_ckpt is not None:
+            fsd, fkw = _load_checkpoint(coarse2fine_ckpt)
+            if coarse2fine_lora_ckpt is not None:
+                fsd.update(torch.load(coarse2fine_lora_ckpt, map_location="cpu"))
+        self._init(codec, csd, ckw, fsd, fkw, device, coarse_chunk_size_s, coarse2fine_chunk_size_s, max_batch, rng,
+                   process_group)
+        self.coarse_path = Path(coarse_ckpt)
+        self.c2f_path = Path(coarse2fine_ckpt) if coarse2fine_ckpt is not None else None
+        self.codec_path = Path(codec_ckpt) if codec_ckpt is not None else None
+
+    @classmethod
+    def from_state_dicts(cls, codec, coarse_sd, coarse_kwargs, c2f_sd=None, c2f_kwargs=None, device="cuda:0",
+                         coarse_chunk_size_s=10, coarse2fine_chunk_size_s=3, max_batch=8, rng="torch",
+                         process_group=None):
+        """Build from in-memory reference-format state_dicts (what the checkpoints hold)."""
+        self = object.__new__(cls)
+        self._init(codec, coarse_sd, coarse_kwargs, c2f_sd, c2f_kwargs, device, coarse_chunk_size_s,
+                   coarse2fine_chunk_size_s, max_batch, rng, process_group)
+        self.coarse_path = self.c2f_path = self.codec_path = None
+        return self
+
+    def _init(self, codec, csd, ckw, fsd, fkw, device, coarse_chunk_s, c2f_chunk_s, max_batch, rng, process_group):
+        self.codec = codec
+        self.device = torch.device(device)
+        self.engine = Engine(device)
+        self.loudness = -24.0
+        self.beat_tracker = None
+        self.rng = rng
+        self.max_batch = max_batch
+        self.pg = process_group
+        if process_group is not None:
+            import torch.distributed as dist
+            self.rank, self.world = dist.get_rank(process_group), dist.get_world_size(process_group)
+        else:
+            self.rank, self.world = 0, 1
+        self._codebooks = _codec_codebooks(codec)
+        self.coarse = self._make_model(csd, ckw, coarse_chunk_s)
+        self.c2f = self._make_model(fsd, fkw, c2f_chunk_s) if fsd is not None else None
+
+    def _make_model(self, sd, kw, chunk_s):
+        kwargs = dict(_DEFAULT_KW)
+        kwargs.update({k: v for k, v in (kw or {}).items() if k in _MODEL_KEYS})
+        return VampNetModel(self.engine, sd, self._codebooks, max_batch=self.max_batch,
+                            max_T=self.s2t(chunk_s), chunk_size_s=chunk_s, **kwargs)
+
+    # ---- reference API that needs the network / other models -----------------------------------
+    @classmethod
+    def default(cls):
+        raise RuntimeError("Interface.default() downloads checkpoints from the HF hub (vampnet/__init__.py:20-47); "
+                           "pass local checkpoint paths instead")
+
+    def load_finetuned(self, name: str):
+        raise RuntimeError("load_finetuned() needs the HF hub; use reload(coarse_ckpt=..., c2f_ckpt=...) with local paths")
+
+    def reload(self, coarse_ckpt: str = None, c2f_ckpt: str = None):
+        """Hot-swap weights (interface.py:146-174); no-op when the path is already loaded."""
+        if coarse_ckpt is not None and self.coarse_path != Path(coarse_ckpt):
+            sd, kw = _load_checkpoint(coarse_ckpt)
+            self.coarse = self._make_model(sd, kw, self.coarse.chunk_size_s)
+            self.coarse_path = Path(coarse_ckpt)
+        if c2f_ckpt is not None and self.c2f_path != Path(c2f_ckpt):
+            sd, kw = _load_checkpoint(c2f_ckpt)
+            self.c2f = self._make_model(sd, kw, self.c2f.chunk_size_s if self.c2f is not None else 3)
+            self.c2f_path = Path(c2f_ckpt)
+
+    # ---- unit conversion (interface.py:176-189) -------------------------------------------------
+    def s2t(self, seconds: float):
+        return masks.seconds_to_tokens(seconds, self.codec.sample_rate, self.codec.hop_length)
+
+    def s2t2s(self, seconds: float):
+        return self.t2s(self.s2t(seconds))
+
+    def t2s(self, tokens: int):
+        return tokens * self.codec.hop_length / self.codec.sample_rate
+
+    def to(self, device):
+        if torch.device(device) != self.device:
+            raise RuntimeError("the engine is bound to its GPU at construction; build a new Interface instead")
+        return self
+
+    def set_chunk_size(self, chunk_size_s: float):
+        """interface.py:324-325 — note the coarse workspace was sized for the construction-time chunk."""
+        if self.s2t(chunk_size_s) > self.coarse.dims.max_T:
+            raise ValueError("chunk larger than the workspace allocated at construction")
+        self.coarse.chunk_size_s = chunk_size_s
+
+    # ---- codec --------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def encode(self, signal):
+        """interface.py:219-224 (incl. _preprocess :206-217) — delegated to the codec object."""
+        if not hasattr(self.codec, "encode_signal"):
+            raise RuntimeError("this codec object cannot encode audio (synthetic-codebook stand-in)")
+        return self.codec.encode_signal(signal, loudness=self.loudness).to(self.device)
+
+    @torch.inference_mode()
+    def decode(self, z: torch.Tensor):
+        """interface.py:203-204 -> VampNet.decode (transformer.py:661-684): MASK -> 0, codes -> audio."""
+        if not hasattr(self.codec, "decode_codes"):
+            raise RuntimeError("this codec object cannot decode audio (synthetic-codebook stand-in)")
+        assert z.ndim == 3
+        z = z.masked_fill(z == self.coarse.mask_token, 0)
+        return self.codec.decode_codes(z)
+
+    # ---- masks --------------------------------------------------------------------------------
+    def build_mask(self, z: torch.Tensor, sig=None, rand_mask_intensity: float = 1.0, prefix_s: float = 0.0,
+                   suffix_s: float = 0.0, periodic_prompt: int = 7, periodic_prompt_width: int = 1,
+                   onset_mask_width: int = 0, _dropout: float = 0.0, upper_codebook_mask: int = 3, ncc: int = 0):
+        """interface.py:454-489.  RNG consumption identical to the reference on CPU (vampnet_amd/masks.py)."""
+        onset = None
+        if onset_mask_width > 0:
+            assert sig is not None, "must provide a signal to use onset mask"
+            raise NotImplementedError("onset_mask needs librosa (not in this image); pass onset_mask_width=0")
+        return masks.build_mask(z, rand_mask_intensity=rand_mask_intensity, n_prefix=self.s2t(prefix_s),
+                                n_suffix=self.s2t(suffix_s), periodic_prompt=periodic_prompt,
+                                periodic_prompt_width=periodic_prompt_width, onset_mask=onset, dropout=_dropout,
+                                upper_codebook_mask=upper_codebook_mask, ncc=ncc)
+
+    # ---- batch sharding helpers ---------------------------------------------------------------
+    def _shard(self, B):
+        """Contiguous block partition of B batch items over the ranks: item b -> rank b // ceil(B / world)."""
+        per = math.ceil(B / self.world)
+        b0 = min(self.rank * per, B)
+        return b0, min(b0 + per, B)
+
+    def _generate(self, model, start_tokens, mask, gen_fn=None, **kwargs):
+        """model.generate on this rank's slice of the (global) batch with the global N0."""
+        rng = kwargs.pop("rng", self.rng)
+        if self.world == 1:
+            if gen_fn is not None:
+                return gen_fn(codec=self.codec, start_tokens=start_tokens, mask=mask, return_signal=False, **kwargs)
+            return model.generate(codec=self.codec, start_tokens=start_tokens, mask=mask, return_signal=False,
+                                  rng=rng, **kwargs)
+        B = start_tokens.shape[0]
+        b0, b1 = self._shard(B)
+        if mask is None:
+            mask = torch.ones_like(start_tokens)
+            mask[:, :model.n_conditioning_codebooks, :] = 0
+        n0 = int(((mask != 0) | (start_tokens == model.mask_token)).sum().item())        # global, transformer.py:766
+        # rows of other ranks: a MASK-free stand-in (masked slots -> token 0, others keep the input) so that the
+        # next stage's global N0 = #(mask | token == MASK) equals what the real tokens would give
+        out = torch.where(mask != 0, torch.zeros_like(start_tokens), start_tokens)
+        if b1 > b0:
+            out[b0:b1] = model.generate(codec=self.codec, start_tokens=start_tokens[b0:b1], mask=mask[b0:b1],
+                                        return_signal=False, rng=rng, n0_override=n0, global_batch=B,
+                                        batch_offset=b0, **kwargs)
+        return out          # rows outside [b0, b1) are stand-ins until vamp()'s final all-gather
+
+    def _allgather_batch(self, z):
+        """The single exchange step: every rank contributes its block of batch items (RCCL all-gather over xGMI)."""
+        if self.world == 1:
+            return z
+        import torch.distributed as dist
+        B = z.shape[0]
+        per = math.ceil(B / self.world)
+        b0, b1 = self._shard(B)
+        local = torch.zeros((per,) + tuple(z.shape[1:]), dtype=z.dtype, device=z.device)
+        local[:b1 - b0] = z[b0:b1]
+        full = torch.empty((per * self.world,) + tuple(z.shape[1:]), dtype=z.dtype, device=z.device)
+        dist.all_gather_into_tensor(full, local, group=self.pg)
+        return full[:B].contiguous()
+
+    # ---- the hot path --------------------------------------------------------------------------
+    @torch.inference_mode()
+    def coarse_to_fine(self, z: torch.Tensor, mask: torch.Tensor = None, return_mask: bool = False, **kwargs):
+        """interface.py:328-380: pad T to a multiple of the c2f chunk (z <- 0, mask <- 1), condition on the
+        coarse codebooks, generate each chunk independently, trim."""
+        assert self.c2f is not None, "No coarse2fine model loaded"
+        c2f = self.c2f
+        length = z.shape[-1]
+        chunk_len = self.s2t(c2f.chunk_size_s)
+        n_chunks = math.ceil(length / chunk_len)
+        pad = (-length) % chunk_len
+        if pad:
+            z = torch.nn.functional.pad(z, (0, pad))
+            mask = torch.nn.functional.pad(mask, (0, pad), value=1) if mask is not None else None
+        missing = c2f.n_codebooks - z.shape[1]
+        if missing > 0:
+            z = torch.cat([z, torch.zeros(z.shape[0], missing, z.shape[-1], dtype=torch.long, device=z.device)], dim=1)
+        if mask is not None:
+            mask = mask.clone()
+            mask[:, :c2f.n_conditioning_codebooks, :] = 0
+        pieces = []
+        for i in range(n_chunks):
+            sl = slice(i * chunk_len, (i + 1) * chunk_len)
+            pieces.append(self._generate(c2f, z[:, :, sl].contiguous(),
+                                         mask[:, :, sl].contiguous() if mask is not None else None,
+                                         time_steps=chunk_len, cfg_guidance=None, **kwargs))
+        fine_z = torch.cat(pieces, dim=-1)
+        if return_mask:
+            return (fine_z[:, :, :length].clone(),
+                    masks.apply_mask(fine_z, mask, c2f.mask_token)[0][:, :, :length].clone())
+        return fine_z[:, :, :length].clone()
+
+    @torch.inference_mode()
+    def coarse_vamp(self, z, mask, return_mask=False, gen_fn=None, **kwargs):
+        """interface.py:383-452: coarse codebooks only, 10 s chunks generated independently; the first and last
+        timestep of every chunk that has any unmasked token are forced unmasked (:407-413)."""
+        coarse = self.coarse
+        nC = coarse.n_codebooks
+        cz = z[:, :nC, :].clone()
+        mask = mask[:, :nC, :]
+        chunk_len = self.s2t(coarse.chunk_size_s)
+        n_chunks = math.ceil(cz.shape[-1] / chunk_len)
+        masked_parts, vamped_parts = [], []
+        for i in range(n_chunks):
+            sl = slice(i * chunk_len, (i + 1) * chunk_len)
+            chunk, mchunk = cz[:, :, sl], mask[:, :, sl]
+            if bool(torch.any(mchunk == 0)):
+                mchunk = mchunk.clone()
+                mchunk[:, :, 0] = 0
+                mchunk[:, :, -1] = 0
+            chunk_masked, mchunk = masks.apply_mask(chunk, mchunk, coarse.mask_token)
+            masked_parts.append(chunk_masked)
+            vamped_parts.append(self._generate(coarse, chunk_masked.contiguous(), mchunk.contiguous(), gen_fn=gen_fn,
+                                               time_steps=chunk_len, **kwargs))
+        cz_masked = torch.cat(masked_parts, dim=-1)
+        c_vamp = torch.cat(vamped_parts, dim=-1)
+        c_vamp = torch.cat([c_vamp, z[:, nC:, :]], dim=1)
+        if return_mask:
+            return c_vamp, cz_masked
+        return c_vamp
+
+    def vamp(self, codes: torch.Tensor, mask: torch.Tensor, batch_size: int = 1, feedback_steps: int = 1,
+             time_stretch_factor: int = 1, return_mask: bool = False, **kwargs):
+        """interface.py:491-562.  `kwargs` reach only the coarse stage; c2f always runs 2 steps at temperature 1
+        (SURVEY.md §0 fact 6)."""
+        rng = kwargs.get("rng", self.rng)
+        z = codes.to(self.device).expand(batch_size, -1, -1)
+        mask = mask.to(self.device).expand(batch_size, -1, -1)
+        if time_stretch_factor > 1:
+            z = z.repeat_interleave(time_stretch_factor, dim=-1)
+            mask = mask.repeat_interleave(time_stretch_factor, dim=-1)
+            added = torch.ones_like(mask)
+            added[:, :, ::time_stretch_factor] = 0
+            mask = (mask.bool() | added.bool()).long()
+        zv = z
+        for i in range(feedback_steps):
+            zv, mask_z = self.coarse_vamp(zv, mask=mask, return_mask=True, **kwargs)
+            mask_z = mask_z.roll(shifts=(i + 1) % feedback_steps, dims=-1)
+        if zv.shape[1] < z.shape[1]:
+            zv = torch.cat([zv, z[:, self.coarse.n_codebooks:, :]], dim=1)
+        zv, fine_mask = self.coarse_to_fine(zv, mask=mask, typical_filtering=True, _sampling_steps=2,
+                                            return_mask=True, rng=rng)
+        zv = self._allgather_batch(zv)
+        if self.world > 1:      # masked view of the gathered tokens (apply_mask is elementwise)
+            full_mask = mask.clone()
+            full_mask[:, :self.c2f.n_conditioning_codebooks, :] = 0
+            fine_mask = masks.apply_mask(zv, full_mask, self.c2f.mask_token)[0]
+        mask_z = torch.cat([mask_z[:, :self.coarse.n_codebooks, :], fine_mask[:, self.coarse.n_codebooks:, :]], dim=1)
+        if return_mask:
+            return zv, mask_z.cpu()
+        return zv
