@@ -88,6 +88,7 @@ class Interface:
         self.rng = rng
         self.max_batch = max_batch
         self.pg = process_group
+        self._call_idx = 0
         if process_group is not None:
             import torch.distributed as dist
             self.rank, self.world = dist.get_rank(process_group), dist.get_world_size(process_group)
@@ -185,6 +186,12 @@ class Interface:
     def _generate(self, model, start_tokens, mask, gen_fn=None, **kwargs):
         """model.generate on this rank's slice of the (global) batch with the global N0."""
         rng = kwargs.pop("rng", self.rng)
+        if rng == "device" and kwargs.get("device_seed") is not None:
+            # one independent Philox stream per generate() call of a vamp(): chunks / stages must not share noise
+            kwargs["device_seed"] = (int(kwargs["device_seed"]) * 0x9E3779B97F4A7C15 + self._call_idx) & (2 ** 64 - 1)
+            self._call_idx += 1
+        elif rng != "device":
+            kwargs.pop("device_seed", None)
         if self.world == 1:
             if gen_fn is not None:
                 return gen_fn(codec=self.codec, start_tokens=start_tokens, mask=mask, return_signal=False, **kwargs)
@@ -285,6 +292,7 @@ class Interface:
         """interface.py:491-562.  `kwargs` reach only the coarse stage; c2f always runs 2 steps at temperature 1
         (SURVEY.md §0 fact 6)."""
         rng = kwargs.get("rng", self.rng)
+        self._call_idx = 0
         z = codes.to(self.device).expand(batch_size, -1, -1)
         mask = mask.to(self.device).expand(batch_size, -1, -1)
         if time_stretch_factor > 1:
@@ -300,7 +308,7 @@ class Interface:
         if zv.shape[1] < z.shape[1]:
             zv = torch.cat([zv, z[:, self.coarse.n_codebooks:, :]], dim=1)
         zv, fine_mask = self.coarse_to_fine(zv, mask=mask, typical_filtering=True, _sampling_steps=2,
-                                            return_mask=True, rng=rng)
+                                            return_mask=True, rng=rng, device_seed=kwargs.get("device_seed"))
         zv = self._allgather_batch(zv)
         if self.world > 1:      # masked view of the gathered tokens (apply_mask is elementwise)
             full_mask = mask.clone()
