@@ -1,0 +1,150 @@
+"""CPU tests of the Interface twin's host orchestration (chunking, padding, edge un-mask, stitching, batch sharding)
+with an oracle-backed stand-in for the device model — the HIP engine itself is covered by `-m gpu` tests.
+Includes the world_size-2 gloo test of the batch-shard + all-gather protocol."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import vampnet_oracle as O, weights as W
+from tests.gpu_common import SynthCodec
+from vampnet_amd.engine import draw_noise_host, seed_all
+from vampnet_amd.interface import Interface
+
+
+class OracleBackedModel:
+    """Same surface as vampnet_amd.engine.VampNetModel.generate, computing with the CPU oracle.  It consumes the
+    product's own noise ledger (draw_noise_host) and honours n0_override / global_batch / batch_offset, so the
+    sharding protocol is exercised end to end."""
+
+    def __init__(self, sd, dims, cb, chunk_size_s):
+        self.sd, self.dims, self.cb = sd, dims, cb
+        self.n_codebooks, self.n_conditioning_codebooks = dims["n_codebooks"], dims["n_cond"]
+        self.n_predict_codebooks = self.n_codebooks - self.n_conditioning_codebooks
+        self.mask_token = dims["vocab"]
+        self.chunk_size_s = chunk_size_s
+
+    def generate(self, codec=None, start_tokens=None, mask=None, _sampling_steps=12, temperature=1.0,
+                 mask_temperature=10.5, seed=None, sample_cutoff=1.0, rng="torch", n0_override=None,
+                 global_batch=None, batch_offset=0, **_):
+        if seed is not None:
+            seed_all(seed)
+        B, Cn, T = start_tokens.shape
+        if mask is None:
+            mask = torch.ones_like(start_tokens)
+            mask[:, :self.n_conditioning_codebooks] = 0
+        N = T * self.n_predict_codebooks
+        exp, unif = draw_noise_host(global_batch or B, N, 1024, _sampling_steps, sample_cutoff, batch_offset, B)
+        noise = [dict(exp=exp[i] if (i / _sampling_steps) <= sample_cutoff else None, unif=unif[i])
+                 for i in range(_sampling_steps)]
+        return O.generate(self.sd, self.dims, self.cb, start_tokens, mask, sampling_steps=_sampling_steps,
+                          temperature=temperature, mask_temperature=mask_temperature, sample_cutoff=sample_cutoff,
+                          n0_override=n0_override, noise=noise)
+
+
+def make_interface(pg=None):
+    cb = W.synth_codebooks()
+    csd, fsd = W.synth_state_dict(W.TINY_COARSE_DIMS, 0), W.synth_state_dict(W.TINY_C2F_DIMS, 1)
+    itf = object.__new__(Interface)
+    itf.codec = SynthCodec(cb)
+    itf.device = torch.device("cpu")
+    itf.rng, itf.pg, itf._call_idx, itf.beat_tracker, itf.loudness = "torch", pg, 0, None, -24.0
+    if pg is not None:
+        import torch.distributed as dist
+        itf.rank, itf.world = dist.get_rank(pg), dist.get_world_size(pg)
+    else:
+        itf.rank, itf.world = 0, 1
+    itf.coarse = OracleBackedModel(csd, W.TINY_COARSE_DIMS, cb, 10)
+    itf.c2f = OracleBackedModel(fsd, W.TINY_C2F_DIMS, cb, 3)
+    return itf, O.OracleModels(csd, W.TINY_COARSE_DIMS, fsd, W.TINY_C2F_DIMS, cb)
+
+
+@pytest.mark.parametrize("T", [100, 575, 600, 1200])
+@pytest.mark.parametrize("B,kw", [(1, dict(seed=0, _sampling_steps=3)),
+                                  (3, dict(seed=1, _sampling_steps=2, sample_cutoff=0.5, temperature=0.7))])
+def test_vamp_orchestration_matches_oracle(T, B, kw):
+    itf, models = make_interface()
+    z = W.synth_codes(1, 14, T, seed=6)
+    torch.manual_seed(3)
+    mask = itf.build_mask(z)
+    ref, ref_m = O.vamp(models, z, mask, batch_size=B, return_mask=True, **kw)
+    got, got_m = itf.vamp(z, mask, batch_size=B, return_mask=True, **kw)
+    assert torch.equal(ref, got) and torch.equal(ref_m, got_m)
+
+
+def test_vamp_time_stretch_and_feedback():
+    itf, models = make_interface()
+    z = W.synth_codes(1, 14, 90, seed=2)
+    torch.manual_seed(1)
+    mask = itf.build_mask(z, periodic_prompt=3)
+    kw = dict(batch_size=2, time_stretch_factor=2, feedback_steps=2, seed=5, _sampling_steps=2)
+    ref = O.vamp(models, z, mask, **kw)
+    got = itf.vamp(z, mask, **kw)
+    assert got.shape == (2, 14, 180) and torch.equal(ref, got)
+
+
+def test_coarse_vamp_and_c2f_separately():
+    itf, models = make_interface()
+    z = W.synth_codes(2, 14, 300, seed=8)
+    torch.manual_seed(2)
+    mask = itf.build_mask(z, periodic_prompt=5, upper_codebook_mask=4)
+    a, am = O.coarse_vamp(models, z, mask, return_mask=True, seed=3, _sampling_steps=2)
+    b, bm = itf.coarse_vamp(z, mask, return_mask=True, seed=3, _sampling_steps=2)
+    assert torch.equal(a, b) and torch.equal(am, bm)
+    torch.manual_seed(9)
+    c = O.coarse_to_fine(models, a, mask=mask, _sampling_steps=2)
+    torch.manual_seed(9)
+    d = itf.coarse_to_fine(b, mask=mask, _sampling_steps=2)
+    assert torch.equal(c, d)
+
+
+# ---------------------------------------------------------------------------------------- 2-rank gloo
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, B, T, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    itf, _ = make_interface(dist.group.WORLD)
+    z = W.synth_codes(B, 14, T, seed=6)
+    torch.manual_seed(3)
+    mask = itf.build_mask(z)
+    out = itf.vamp(z, mask, batch_size=B, seed=11, _sampling_steps=3)
+    q.put((rank, out.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [4, 3])
+def test_batch_shard_two_ranks_gloo(B):
+    """Every rank holds the global batch, computes its contiguous block of items with the GLOBAL N0 and the global
+    noise stream, then one all-gather: the result on every rank equals the unsharded oracle vamp()
+    (B = 3: ragged shards 2 + 1)."""
+    T = 200
+    _, models = make_interface()
+    z = W.synth_codes(B, 14, T, seed=6)
+    torch.manual_seed(3)
+    mask = O.build_mask(z)
+    ref = O.vamp(models, z, mask, batch_size=B, seed=11, _sampling_steps=3)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, T, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert (got[r] == ref.numpy()).all(), f"rank {r} differs from the unsharded result"
