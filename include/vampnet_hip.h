@@ -166,6 +166,10 @@ int vn_gemm_f32(vn_ctx* ctx, const float* A, const float* W, const float* bias, 
 int vn_attention_f32(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
                      float* out, int B, int H, int T, int num_buckets, int max_distance, void* stream);
 
+/* tuning hook (scripts/gemm_sweep.py): force the GEMM block tile (bm x bn in {128,64}^2; 0,0 = automatic) and the
+ * tile walk order (0 column-major, 1 grouped 8-row patches, -1 keep).  Process-global; not for production use.   */
+int vn_debug_gemm_config(int bm, int bn, int order);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,7 @@ SYMBOLS = {
                                  _P, _P, _P, _P]),
     "vn_rmsnorm_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "vn_gemm_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "vn_debug_gemm_config": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "vn_attention_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
 }
 

@@ -7,7 +7,7 @@
 //   * v_mfma_f32_32x32x2_f32: exact f32 (bitwise an fmaf chain), 64 cycles/instr/SIMD = the f32
 //     vector peak (157.3 TF chip).  One wave per SIMD with >= 1 independent 32x32 accumulator already
 //     issues back to back (dependent latency == issue interval == 64 cycles).
-//   * block = 256 threads = 2x2 waves; block tile BM x BN (128x128 default), wave tile BM/2 x BN/2 made of
+//   * block = 256 threads = 2x2 waves; block tile BM x BN in {128,64}^2, wave tile BM/2 x BN/2 made of
 //     32x32 MFMA tiles; BK = 32 floats (one 128-byte line per row per k-tile).
 //   * global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 rows x 128 B per wave instruction),
 //     double-buffered: tile t+1 streams in while tile t is multiplied; one barrier per k-tile.
@@ -21,7 +21,22 @@
 //     they sit in the same lane of adjacent MFMA tiles), QKV head-major scatter.
 //   * rows >= M are clamped on load (duplicate last row) and masked on store, so M needs no padding.
 //   * blockIdx -> tile mapping is XCD-aware (block b runs on XCD b % 8): each XCD owns a contiguous
-//     range of the tile grid so neighbouring tiles share A/W panels in one 4 MiB L2.
+//     range of the tile walk, and the walk goes in 8-row groups so co-resident tiles form 8x8 patches
+//     that share A/W panels through the XCD's 4 MiB L2.
+//
+// Two schedulers over the same tile body:
+//   data-parallel  one block per output tile.  A CU retires about one 128x128-equivalent tile per unit
+//                  time whether it holds 1 or 2 blocks (they share the matrix pipes), so a launch costs
+//                  ceil(tiles / 256) units: M = 4600 x N = 3840 (1080 tiles) wastes 16 % in the last round.
+//   stream-K       2 persistent blocks per CU, each given an EQUAL share of all (tile, k-tile) iterations;
+//                  a tile split between blocks b < b+1 < ... is finished by the block that ran its FIRST
+//                  k-range (the last thing that block does), adding the later ranges' partial sums, which
+//                  their owners computed first and published to a workspace slab — so nobody waits in
+//                  steady state and the summation order is fixed (deterministic, run-to-run bitwise).
+//                  Hand-off follows the guide's §6 G16 recipe R1: write-through (sc1) 16-byte slab stores ->
+//                  per-wave vmcnt(0) -> __syncthreads -> one-lane relaxed agent flag store; consumer: relaxed poll ->
+//                  one agent-scope acquire -> __syncthreads -> plain loads; the consumer re-zeroes the flag.
+#include <stdlib.h>
 #include "vn_common.h"
 
 #define BK 32
@@ -36,6 +51,7 @@ struct GemmCfg {
     static constexpr int LDS_BYTES = 2 * STAGE_FLOATS * 4;
     static constexpr int A_INSTR = BM / 32;       // DMA wave-instructions per wave for A (BM/8 total / 4 waves)
     static constexpr int B_INSTR = BN / 32;
+    static constexpr int SLAB_FLOATS = BM * BN;   // stream-K partial-sum slab per block
 };
 
 __device__ __forceinline__ float vn_gelu_tanh(float x) {
@@ -45,31 +61,43 @@ __device__ __forceinline__ float vn_gelu_tanh(float x) {
     return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x3)));
 }
 
-template <int BM, int BN, int EPI>
-__global__ __launch_bounds__(256, 2) void vn_gemm_f32_kernel(vn_gemm_args p, int tiles_m, int tiles_n) {
+// XCD-aware bijective remap of a linear block id (guide §5: "XCD swizzle must be bijective")
+__device__ __forceinline__ int vn_xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// position t of the tile walk -> (tm, tn).  order 1: row-groups of 8 tiles (tm fastest inside a group, then tn):
+// 64 consecutive positions form an 8 x 8 patch sharing 8 A and 8 W row-panels; order 0: column-major.
+__device__ __forceinline__ void vn_tile_coords(int t, int tiles_m, int tiles_n, int order, int& tm, int& tn) {
+    if (order == 1) {
+        constexpr int GROUP_M = 8;
+        const int per_group = GROUP_M * tiles_n;
+        const int grp = t / per_group;
+        const int first_m = grp * GROUP_M;
+        const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+        const int in_grp = t - grp * per_group;
+        tm = first_m + in_grp % gsz;
+        tn = in_grp / gsz;
+    } else {
+        tn = t / tiles_m;
+        tm = t - tn * tiles_m;
+    }
+}
+
+// acc += A[m0.., kb*BK .. ke*BK) * W[n0.., same k)^T   for one block tile; all 256 threads participate.
+template <int BM, int BN>
+__device__ __forceinline__ void vn_gemm_mac(const vn_gemm_args& p, float* lds, int m0, int n0, int kb, int ke,
+                                            f32x16 (&acc)[GemmCfg<BM, BN>::MI][GemmCfg<BM, BN>::NI]) {
     using Cfg = GemmCfg<BM, BN>;
     constexpr int MI = Cfg::MI, NI = Cfg::NI;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
-    // ---- XCD-aware tile mapping (bijective for any grid size; guide §5 "XCD swizzle must be bijective")
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, idx = bid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    // walk tiles column-panel-major inside the XCD chunk: consecutive blocks share the W panel
-    const int tn = bid / tiles_m;
-    const int tm = bid - tn * tiles_m;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    // ---- per-lane DMA source pointers (chunk p = 16-byte slot index inside the tile image)
+    // per-lane DMA source pointers (pidx = 16-byte slot index inside the tile image)
     const float* srcA[Cfg::A_INSTR];
     const float* srcB[Cfg::B_INSTR];
 #pragma unroll
@@ -88,7 +116,6 @@ __global__ __launch_bounds__(256, 2) void vn_gemm_f32_kernel(vn_gemm_args p, int
         gn = gn < p.N ? gn : p.N - 1;
         srcB[q] = p.W + (size_t)gn * p.K + slot * 4;
     }
-
     auto stage = [&](int buf, int k0) {
         float* dA = lds + buf * Cfg::STAGE_FLOATS;
         float* dB = dA + Cfg::A_FLOATS;
@@ -104,26 +131,16 @@ __global__ __launch_bounds__(256, 2) void vn_gemm_f32_kernel(vn_gemm_args p, int
                 (__attribute__((address_space(3))) void*)(dB + (wave * Cfg::B_INSTR + q) * 256), 16, 0, 0);
     };
 
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
     // fragment read offsets (floats) inside a stage: row*32 + ((2s + h) ^ (row&7))*4 ; row&7 == lane&7
     const int l31 = lane & 31, h = lane >> 5, sw = lane & 7;
     const int aRow = (wm * (BM / 2) + l31) * BK;
     const int bRow = (wn * (BN / 2) + l31) * BK;
 
-    const int nk = p.K / BK;
-    stage(0, 0);
+    stage(0, kb * BK);
     __syncthreads();   // glds in flight -> hipcc emits vmcnt(0) before the barrier (guide §5)
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
+    for (int kt = kb; kt < ke; ++kt) {
+        const int cur = (kt - kb) & 1;
+        if (kt + 1 < ke) stage(cur ^ 1, (kt + 1) * BK);
         const float* sA = lds + cur * Cfg::STAGE_FLOATS;
         const float* sB = sA + Cfg::A_FLOATS;
 #pragma unroll
@@ -144,8 +161,15 @@ __global__ __launch_bounds__(256, 2) void vn_gemm_f32_kernel(vn_gemm_args p, int
         }
         __syncthreads();   // tile kt consumed by all waves; tile kt+1 landed (vmcnt(0) + barrier)
     }
+}
 
-    // ---- epilogue.  C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+// C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <int BM, int BN, int EPI>
+__device__ __forceinline__ void vn_gemm_epilogue(const vn_gemm_args& p, int m0, int n0,
+                                                 f32x16 (&acc)[GemmCfg<BM, BN>::MI][GemmCfg<BM, BN>::NI]) {
+    constexpr int MI = GemmCfg<BM, BN>::MI, NI = GemmCfg<BM, BN>::NI;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
     const int colw = n0 + wn * (BN / 2) + l31;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -186,36 +210,225 @@ __global__ __launch_bounds__(256, 2) void vn_gemm_f32_kernel(vn_gemm_args p, int
     }
 }
 
+template <int MI, int NI>
+__device__ __forceinline__ void vn_acc_zero(f32x16 (&acc)[MI][NI]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// data-parallel scheduler: one block per tile
+// ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int EPI>
-static int launch_cfg(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
+__global__ __launch_bounds__(256, 2) void vn_gemm_f32_kernel(vn_gemm_args p, int tiles_m, int tiles_n, int order) {
+    using Cfg = GemmCfg<BM, BN>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int tm, tn;
+    vn_tile_coords(vn_xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, order, tm, tn);
+    f32x16 acc[Cfg::MI][Cfg::NI];
+    vn_acc_zero(acc);
+    vn_gemm_mac<BM, BN>(p, lds, tm * BM, tn * BN, 0, p.K / BK, acc);
+    vn_gemm_epilogue<BM, BN, EPI>(p, tm * BM, tn * BN, acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// stream-K scheduler: G persistent blocks, equal shares of the tiles*nk iteration space
+// ---------------------------------------------------------------------------------------------
+#define SK_SPIN_LIMIT (1 << 24)
+
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256, 2) void vn_gemm_f32_sk_kernel(vn_gemm_args p, int tiles_m, int tiles_n, int order,
+                                                               float* __restrict__ slabs, unsigned* flags,
+                                                               unsigned* errword) {
+    using Cfg = GemmCfg<BM, BN>;
+    constexpr int MI = Cfg::MI, NI = Cfg::NI;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int G = gridDim.x;
+    const int nk = p.K / BK;
+    const long total = (long)tiles_m * tiles_n * nk;
+    const int b = vn_xcd_remap(blockIdx.x, G);          // neighbours in the walk sit on one XCD
+    long it = total * b / G;
+    const long end = total * (b + 1) / G;
+    const int tid = threadIdx.x;
+    typedef __attribute__((address_space(1))) unsigned gu32;
+
+    while (it < end) {
+        const int tile = (int)(it / nk);
+        const int kb = (int)(it - (long)tile * nk);
+        const long rem = end - it;
+        const int ke = (long)(nk - kb) < rem ? nk : kb + (int)rem;
+        int tm, tn;
+        vn_tile_coords(tile, tiles_m, tiles_n, order, tm, tn);
+        const int m0 = tm * BM, n0 = tn * BN;
+        f32x16 acc[MI][NI];
+        vn_acc_zero(acc);
+        vn_gemm_mac<BM, BN>(p, lds, m0, n0, kb, ke, acc);
+
+        if (kb != 0) {
+            // a later k-range of a tile that an earlier block owns: publish the partial sums (only ever the FIRST
+            // segment of a block, so one slab per block suffices)
+            // write-through (sc1) 16-byte stores: the data goes to memory past this XCD's L2, so no release fence
+            // (no L2 write-back of everybody's dirty C tiles) is needed before the flag (guide G16 recipe R1)
+            __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                slabs + (size_t)b * Cfg::SLAB_FLOATS, 0, Cfg::SLAB_FLOATS * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc,
+                                                               (((i * NI + j) * 4 + q) * 256 + tid) * 16, 0, 16 /*sc1*/);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY storing wave drains its stores
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store((gu32*)(flags + b), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (ke < nk) {
+                // owner of the tile's first k-range: add the later ranges (blocks b+1, b+2, ... in k order)
+                const long tile_end = (long)(tile + 1) * nk;
+                for (int pb = b + 1; pb < G; ++pb) {
+                    if (tid == 0) {
+                        unsigned spins = 0;
+                        while (__hip_atomic_load((gu32*)(flags + pb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                            __builtin_amdgcn_s_sleep(8);
+                            if (++spins > SK_SPIN_LIMIT) {   // never hang the GPU: record and fall through
+                                __hip_atomic_store((gu32*)errword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
+                    __syncthreads();
+                    const f32x4* slab = (const f32x4*)(slabs + (size_t)pb * Cfg::SLAB_FLOATS);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const f32x4 v = slab[((i * NI + j) * 4 + q) * 256 + tid];
+                                acc[i][j][4 * q] += v[0];
+                                acc[i][j][4 * q + 1] += v[1];
+                                acc[i][j][4 * q + 2] += v[2];
+                                acc[i][j][4 * q + 3] += v[3];
+                            }
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_store((gu32*)(flags + pb), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (total * (pb + 1) / G >= tile_end) break;      // block pb reached the end of this tile
+                }
+            }
+            vn_gemm_epilogue<BM, BN, EPI>(p, m0, n0, acc);
+        }
+        it += ke - kb;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+// tuning hooks (scripts/gemm_sweep.py): force a tile / scheduler / tile order
+static int g_order = 1;
+static int g_force_bm = 0, g_force_bn = 0;
+static int g_sched = -1;          // -1 auto, 0 data-parallel, 1 stream-K
+static void read_env_once() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    if (const char* e = getenv("VN_GEMM_ORDER")) g_order = atoi(e);
+    if (const char* e = getenv("VN_GEMM_TILE")) sscanf(e, "%dx%d", &g_force_bm, &g_force_bn);
+    if (const char* e = getenv("VN_GEMM_SCHED")) g_sched = atoi(e);
+}
+
+extern "C" int vn_debug_gemm_config(int bm, int bn, int order) {
+    read_env_once();
+    g_force_bm = bm; g_force_bn = bn;
+    if (order >= 0) { g_order = order & 1; g_sched = (order >> 1) - 1; }   // order bits: [0] walk, [2:1] sched+1
+    return VN_OK;
+}
+
+// stream-K workspace (per process; GEMMs of one ctx run on one stream at a time, see vampnet_hip.h)
+#define SK_MAX_BLOCKS 512
+static float* g_sk_slabs = nullptr;
+static unsigned* g_sk_flags = nullptr;     // [SK_MAX_BLOCKS] flags + [1] error word
+static int sk_workspace(vn_ctx* ctx) {
+    if (g_sk_slabs) return VN_OK;
+    VN_HIP_CHECK(ctx, hipMalloc((void**)&g_sk_slabs, (size_t)SK_MAX_BLOCKS * 128 * 128 * sizeof(float)));
+    VN_HIP_CHECK(ctx, hipMalloc((void**)&g_sk_flags, (SK_MAX_BLOCKS + 64) * sizeof(unsigned)));
+    VN_HIP_CHECK(ctx, hipMemset(g_sk_flags, 0, (SK_MAX_BLOCKS + 64) * sizeof(unsigned)));
+    return VN_OK;
+}
+
+template <int BM, int BN, int EPI>
+static int launch_cfg(vn_ctx* ctx, const vn_gemm_args& a, bool streamk, hipStream_t s) {
     using Cfg = GemmCfg<BM, BN>;
     const int tiles_m = vn_cdiv(a.M, BM), tiles_n = vn_cdiv(a.N, BN);
-    auto kern = vn_gemm_f32_kernel<BM, BN, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              Cfg::LDS_BYTES));
-        attr_set = true;
+    if (streamk) {
+        int rc = sk_workspace(ctx);
+        if (rc) return rc;
     }
     const int pi = vn_prof_pre(ctx, 0, 2.0 * a.M * (double)a.N * a.K, s);
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), Cfg::LDS_BYTES, s, a, tiles_m, tiles_n);
+    if (streamk) {
+        const long total = (long)tiles_m * tiles_n * (a.K / BK);
+        int G = SK_MAX_BLOCKS;
+        if (total < G) G = (int)total;
+        hipLaunchKernelGGL((vn_gemm_f32_sk_kernel<BM, BN, EPI>), dim3(G), dim3(256), Cfg::LDS_BYTES, s, a, tiles_m,
+                           tiles_n, g_order, g_sk_slabs, g_sk_flags, g_sk_flags + SK_MAX_BLOCKS);
+    } else {
+        hipLaunchKernelGGL((vn_gemm_f32_kernel<BM, BN, EPI>), dim3(tiles_m * tiles_n), dim3(256), Cfg::LDS_BYTES, s, a,
+                           tiles_m, tiles_n, g_order);
+    }
     vn_prof_post(ctx, pi, s);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
 }
 
+// Cost model, in units of (tile area / efficiency), calibrated on MI355X (profiles/r01_gemm_sweep.txt):
+//   a CU retires one block-tile per (bm*bn/eff) whether it hosts 1 or 2 blocks (shared matrix pipes), so
+//   data-parallel costs ceil(blocks/256) rounds; stream-K costs the exact share + a fix-up overhead of about
+//   0.2 x (128x128 tile at K=1280) = ~16-20 us (slab write + read, pipeline refill per segment).
+static double dp_cost(int M, int N, int K, int bm, int bn, double eff) {
+    const double blocks = (double)vn_cdiv(M, bm) * vn_cdiv(N, bn);
+    return ceil(blocks / 256.0) * (double)bm * bn / eff;
+}
+static double sk_cost(int M, int N, int K, int bm, int bn, double eff) {
+    const double blocks = (double)vn_cdiv(M, bm) * vn_cdiv(N, bn);
+    return blocks / 256.0 * (double)bm * bn / eff + 0.2 * 16384.0 * 1280.0 / (double)K;
+}
+
 template <int EPI>
 static int launch_epi(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
-    // tile choice: fill 256 CUs.  128x128 once that yields >= 2 waves of blocks, else 64-row tiles.
-    const long big = (long)vn_cdiv(a.M, 128) * vn_cdiv(a.N, 128);
-    if constexpr (EPI == VN_EPI_GEGLU) {
-        if (big >= 512) return launch_cfg<128, 128, EPI>(ctx, a, s);
-        return launch_cfg<64, 128, EPI>(ctx, a, s);
-    } else {
-        if (big >= 512) return launch_cfg<128, 128, EPI>(ctx, a, s);
-        if ((long)vn_cdiv(a.M, 64) * vn_cdiv(a.N, 128) >= 256) return launch_cfg<64, 128, EPI>(ctx, a, s);
-        return launch_cfg<64, 64, EPI>(ctx, a, s);
+    read_env_once();
+    int bm = g_force_bm, bn = g_force_bn;
+    bool sk = g_sched == 1;
+    if (!bm) {
+        const bool geglu = (EPI == VN_EPI_GEGLU);
+        struct { int bm, bn; double eff; } cand[] = {{128, 128, 1.00}, {64, 128, 0.94}, {128, 64, 0.93}, {64, 64, 0.89}};
+        double best = 1e300;
+        for (auto& c : cand) {
+            if (geglu && c.bn != 128) continue;
+            if (g_sched != 1) {
+                const double cost = dp_cost(a.M, a.N, a.K, c.bm, c.bn, c.eff);
+                if (cost < best) { best = cost; bm = c.bm; bn = c.bn; sk = false; }
+            }
+            if (g_sched != 0) {
+                const double cost = sk_cost(a.M, a.N, a.K, c.bm, c.bn, c.eff);
+                if (cost < best) { best = cost; bm = c.bm; bn = c.bn; sk = true; }
+            }
+        }
     }
+    if (bm == 128 && bn == 128) return launch_cfg<128, 128, EPI>(ctx, a, sk, s);
+    if (bm == 64 && bn == 128) return launch_cfg<64, 128, EPI>(ctx, a, sk, s);
+    if constexpr (EPI != VN_EPI_GEGLU) {
+        if (bm == 128 && bn == 64) return launch_cfg<128, 64, EPI>(ctx, a, sk, s);
+        if (bm == 64 && bn == 64) return launch_cfg<64, 64, EPI>(ctx, a, sk, s);
+    }
+    return vn_fail(ctx, VN_ERR_INVALID, "gemm: unsupported tile %s%ldx%ld", "", bm, bn);
 }
 
 int vn_launch_gemm_f32(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s) {
