@@ -86,7 +86,8 @@ typedef struct {
     float   mask_temperature;    /* 10.5                                                        */
     double  sample_cutoff;       /* sample iff (i/steps) <= sample_cutoff, compared in double like
                                     the reference's Python floats (transformer.py:852)          */
-    float   top_p;               /* <= 0 or >= 1: disabled (transformer.py:1001-1016)           */
+    float   top_p;               /* nucleus filtering when 0 < top_p < 1 (transformer.py:1001-1016);
+                                    otherwise disabled                                          */
     int64_t n0_override;         /* < 0: N0 = masked count over THIS batch (transformer.py:766);
                                     >= 0: the global batch's N0 when this call sees a shard     */
     uint64_t seed;               /* device-RNG seed (used only where a noise pointer is NULL)   */
@@ -144,10 +145,11 @@ int vn_generate(vn_model* model, const int64_t* start_tokens, const int64_t* mas
 /* One sampling step on caller-provided logits (teacher-forced parity tests):
  * sample_from_logits + the where()/inf bookkeeping + mask_by_random_topk + re-mask
  * (transformer.py:852-927, 952-1074).
- * z_masked dev int64 [B][C][T] in/out; logits dev f32 [B][T][Cp][vocab];
+ * z_masked dev int64 [B][C][T] in/out; logits dev f32 [B][T][Cp][vocab] (filtered IN PLACE when top_p is
+ * active, like the reference's `logits[indices_to_remove] = -inf`, transformer.py:1016);
  * exp_noise dev f32 [B*T*Cp][vocab] or NULL; unif_noise dev f32 [B][T*Cp] or NULL;
  * sampled_out dev int64 [B][C][T] (tokens before re-masking; conditioning codebooks copied).   */
-int vn_sample_step(vn_model* model, int64_t* z_masked, const float* logits, int B, int T,
+int vn_sample_step(vn_model* model, int64_t* z_masked, float* logits, int B, int T,
                    int step, const vn_sample_params* params, int64_t num_to_mask_sched,
                    const float* exp_noise, const float* unif_noise, int64_t* sampled_out, void* stream);
 

@@ -86,6 +86,7 @@ def test_forward_full_size_vs_reference_probe(eng, name, dims, T, seed):
 
 # ---------------------------------------------------------------------------------------- one sampling step
 STEP_CASES = [dict(B=1, T=50, steps=6, kw=dict()),
+              dict(B=2, T=31, steps=3, kw=dict(top_p=0.8)),
               dict(B=3, T=41, steps=5, kw=dict(temperature=0.8, mask_temperature=7.0)),
               dict(B=2, T=33, steps=4, kw=dict(sample_cutoff=-1.0, mask_temperature=0.0)),
               dict(B=2, T=29, steps=3, kw=dict(temperature=0.0, sample_cutoff=0.5))]
@@ -113,7 +114,7 @@ def test_sample_step_teacher_forced(tiny, which, case):
         z_next, sampled = model.sample_step(t["z_in"], logits_native, i, steps, n0,
                                             temperature=kw.get("temperature", 1.0),
                                             mask_temperature=kw.get("mask_temperature", 10.5),
-                                            sample_cutoff=kw.get("sample_cutoff", 1.0),
+                                            sample_cutoff=kw.get("sample_cutoff", 1.0), top_p=kw.get("top_p"),
                                             exp_noise=exp, unif_noise=t["unif"].cuda())
         want_sampled = torch.cat([z[:, :dims["n_cond"]], O.codebook_unflatten(t["sampled"], Cp)], dim=1)
         assert torch.equal(sampled.cpu(), want_sampled), f"step {i}: sampled tokens differ"
@@ -122,6 +123,8 @@ def test_sample_step_teacher_forced(tiny, which, case):
 
 # ---------------------------------------------------------------------------------------- generate
 GEN_CASES = [dict(B=1, T=50, kw=dict(_sampling_steps=6, seed=0)),
+             dict(B=2, T=33, kw=dict(_sampling_steps=4, seed=3, top_p=0.9)),
+             dict(B=1, T=40, kw=dict(_sampling_steps=3, seed=8, top_p=0.3, temperature=0.7)),
              dict(B=3, T=41, kw=dict(_sampling_steps=5, seed=1, temperature=0.8, mask_temperature=7.0)),
              dict(B=1, T=50, kw=dict(_sampling_steps=6, seed=2, sample_cutoff=-1, mask_temperature=0.0)),
              dict(B=1, T=50, kw=dict(_sampling_steps=4, seed=4, temperature=1e-8)),
@@ -149,8 +152,6 @@ def test_generate_vs_golden(tiny):
     g = np.load(os.path.join(G, "generate_tiny.npz"))
     for idx, m in enumerate(g["meta"]):
         which, B, T, kw = ast.literal_eval(str(m))
-        if "top_p" in kw:
-            continue                      # nucleus filtering not on the device yet (engine raises, see below)
         torch.manual_seed(kw["seed"])
         e = torch.empty(4, 1024).exponential_(1)
         u = torch.zeros(2, 100).uniform_(1e-20, 1)
@@ -184,8 +185,6 @@ def test_generate_edge_cases(tiny):
     assert torch.equal(out[:, :4], z14[:, :4])
     # unsupported / misuse
     from vampnet_amd import VnError
-    with pytest.raises(VnError):
-        model.generate(start_tokens=z, mask=torch.ones_like(z), top_p=0.9, seed=0)
     with pytest.raises(ValueError):
         model.generate(start_tokens=None)
     with pytest.raises(VnError):

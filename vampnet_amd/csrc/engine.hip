@@ -283,8 +283,12 @@ static long host_k_sched(int i, int steps, long n0) {
 }
 
 static int sample_step(vn_model* m, int B, int T, int step, const vn_sample_params* p, long k_sched,
-                       const float* logits, const float* exp_noise, const float* unif_noise, bool want_sampled,
+                       float* logits, const float* exp_noise, const float* unif_noise, bool want_sampled,
                        hipStream_t s) {
+    if (p->top_p > 0.f && p->top_p < 1.f) {       // transformer.py:1001 "top_p is not None and top_p < 1.0"
+        int rc0 = vn_launch_top_p(m->ctx, logits, m->z, B, T, m->d.n_codebooks, m->d.n_cond, m->d.vocab, p->top_p, s);
+        if (rc0) return rc0;
+    }
     vn_sample_args sa{};
     sa.logits = logits; sa.z = m->z; sa.exp_noise = exp_noise; sa.sampled = m->sampled; sa.psel = m->psel;
     sa.B = B; sa.T = T; sa.C = m->d.n_codebooks; sa.n_cond = m->d.n_cond; sa.V = m->d.vocab;
@@ -307,12 +311,10 @@ static int sample_step(vn_model* m, int B, int T, int step, const vn_sample_para
 static int params_check(vn_model* m, const vn_sample_params* p) {
     if (!p) return vn_fail(m->ctx, VN_ERR_INVALID, "params is NULL%s", "");
     if (p->steps <= 0) return vn_fail(m->ctx, VN_ERR_INVALID, "steps must be > 0%s", "");
-    if (p->top_p > 0.f && p->top_p < 1.f)
-        return vn_fail(m->ctx, VN_ERR_UNSUPPORTED, "top_p in (0,1) is not implemented on the device yet%s", "");
     return VN_OK;
 }
 
-extern "C" int vn_sample_step(vn_model* m, int64_t* z_masked, const float* logits, int B, int T, int step,
+extern "C" int vn_sample_step(vn_model* m, int64_t* z_masked, float* logits, int B, int T, int step,
                               const vn_sample_params* params, int64_t num_to_mask_sched, const float* exp_noise,
                               const float* unif_noise, int64_t* sampled_out, void* stream) {
     int rc = shape_check(m, B, T);

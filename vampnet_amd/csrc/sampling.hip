@@ -133,6 +133,102 @@ __global__ __launch_bounds__(256) void vn_sample_kernel(vn_sample_args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Nucleus (top-p) filtering, transformer.py:1001-1016, in place on the logits of the currently-masked rows:
+//   v, idx = logits.sort(descending); cum = softmax(v).cumsum(-1)  (fp64 running sum rounded to fp32 per element,
+//   as torch's CPU cumsum does); remove[j] = cum[j-1] > top_p (the first token over the threshold is kept);
+//   logits[removed] = -inf.
+// One wave per row.  The descending rank of every logit is found by counting (1024 broadcast LDS reads x 16
+// compares per lane; ties broken by index), probabilities are scattered to their sorted position in LDS, an
+// exclusive fp64 prefix sum over the sorted order (16 sequential adds per lane + a 64-lane shuffle scan) gives the
+// mass strictly before each position, and the decision is gathered back by rank.  HBM: 4*V read + 4*V written per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vn_top_p_kernel(float* __restrict__ logits, const int32_t* __restrict__ z,
+                                                       int B, int T, int C, int n_cond, int V, float top_p) {
+    __shared__ float s_log[4][1024];
+    __shared__ float s_p[4][1024];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int Cp = C - n_cond, N = T * Cp;
+    const long row = (long)blockIdx.x * 4 + w;
+    if (row >= (long)B * N) return;
+    const int b = (int)(row / N), n = (int)(row - (long)b * N);
+    const int t = n / Cp, c = n - t * Cp;
+    if (z[((size_t)b * C + n_cond + c) * T + t] != V) return;          // wave-uniform: only rows being sampled
+    f32x4* lrow = (f32x4*)(logits + (size_t)row * V);
+    float x[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 l = lrow[lane + 64 * i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x[4 * i + e] = l[e];
+            s_log[w][(lane + 64 * i) * 4 + e] = l[e];
+            mx = fmaxf(mx, l[e]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float p[16], sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { p[k] = expf(x[k] - mx); sum += p[k]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    __builtin_amdgcn_wave_barrier();
+    // descending rank of each of this lane's 16 logits: #(l_j > l_i) + #(l_j == l_i and j < i)
+    int rank[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) rank[k] = 0;
+    for (int jj = 0; jj < 1024; ++jj) {
+        const float lj = s_log[w][jj];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int idx = (lane + 64 * (k >> 2)) * 4 + (k & 3);
+            rank[k] += (lj > x[k]) || (lj == x[k] && jj < idx);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s_p[w][rank[k]] = p[k] / sum;
+    __builtin_amdgcn_wave_barrier();
+    // exclusive fp64 prefix over the sorted order; lane owns sorted positions [16*lane, 16*lane + 16)
+    double run = 0.0, pre[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { pre[k] = run; run += (double)s_p[w][16 * lane + k]; }
+    double incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    const double base = incl - run;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int pos = 16 * lane + k;
+        // cum[pos-1] = fp32(fp64 sum of positions 0..pos-1); position 0 is never removed (F.pad(..., value=False))
+        s_log[w][pos] = (pos > 0 && (float)(base + pre[k]) > top_p) ? 1.0f : 0.0f;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = s_log[w][rank[4 * i + e]] != 0.0f ? -INFINITY : x[4 * i + e];
+        lrow[lane + 64 * i] = o;
+    }
+}
+
+int vn_launch_top_p(vn_ctx* ctx, float* logits, const int32_t* z, int B, int T, int C, int n_cond, int V, float top_p,
+                    hipStream_t s) {
+    if (V != 1024) return vn_fail(ctx, VN_ERR_UNSUPPORTED, "top_p: vocab=%s%ld unsupported (1024)", "", V);
+    const long rows = (long)B * T * (C - n_cond);
+    if (rows <= 0) return VN_OK;
+    hipLaunchKernelGGL(vn_top_p_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, z, B, T, C, n_cond, V,
+                       top_p);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
 int vn_launch_sample(vn_ctx* ctx, const vn_sample_args& a, hipStream_t s) {
     const long rows = (long)a.B * a.T * (a.C - a.n_cond);
     if (rows <= 0) return VN_OK;

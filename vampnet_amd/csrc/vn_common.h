@@ -101,6 +101,9 @@ struct vn_sample_args {
     long batch_offset;        // global index of item 0 (device RNG only)
 };
 int vn_launch_sample(vn_ctx* ctx, const vn_sample_args& a, hipStream_t s);
+// in-place nucleus filter on the logits of the masked rows (transformer.py:1001-1016)
+int vn_launch_top_p(vn_ctx* ctx, float* logits, const int32_t* z, int B, int T, int C, int n_cond, int V, float top_p,
+                    hipStream_t s);
 
 struct vn_remask_args {
     const int32_t* sampled;   // [B][N]
