@@ -104,13 +104,13 @@ const char* vn_last_error(const vn_ctx* ctx);
 const char* vn_version(void);
 
 /* ---- kernel timing (bench.py's roofline leg) ------------------------------------------------
- * While enabled, every launch of the two MFMA kernels (vn_gemm_f32_kernel, vn_attention_kernel) made
- * through this ctx is bracketed by hipEvents on the launch stream.  vn_profile_end synchronises the
- * recorded events and returns, per class c in {0: gemm, 1: attention}:
+ * While enabled, every launch of the MFMA kernels (vn_gemm_f32[_sk]_kernel, vn_attention_kernel,
+ * vn_conv1d_f32_kernel) made through this ctx is bracketed by hipEvents on the launch stream.
+ * vn_profile_end synchronises the recorded events and returns, per class c in {0: gemm, 1: attention, 2: conv1d}:
  *   stats[3c+0] = launches, stats[3c+1] = total kernel time in ms, stats[3c+2] = algorithmic FLOPs
- * (2*M*N*K per GEMM launch; 4*T*T*64 per (b,h) for attention).                                   */
+ * (2*M*N*K per GEMM / conv launch; 4*T*T*64 per (b,h) for attention).                            */
 int vn_profile_begin(vn_ctx* ctx, int max_launches);
-int vn_profile_end(vn_ctx* ctx, double* stats6);
+int vn_profile_end(vn_ctx* ctx, double* stats9);
 
 /* ---- weights ------------------------------------------------------------------------------ */
 /* total number of floats in the packed blob */
@@ -167,6 +167,35 @@ int vn_gemm_f32(vn_ctx* ctx, const float* A, const float* W, const float* bias, 
  * rel_bias dev f32 [num_buckets][H]; out dev f32 [B][T][H*64].                                */
 int vn_attention_f32(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
                      float* out, int B, int H, int T, int num_buckets, int max_distance, void* stream);
+
+/* ---- DAC codec layers (Interface.encode / Interface.decode; PARITY UNPINNED: the codec source
+ * `lac` is not part of the reference tree) -------------------------------------------------------------------
+ * All activations are channels-last [B][T][C] fp32.
+ *
+ * vn_conv1d_f32: y[b][t_out][co] = act( bias[co] + sum_{j<taps} sum_ci w[co][j][ci] * x[b][t_in][ci] (+ resid) )
+ *   for t' in [0, T_rows): t_in = t'*in_stride + j*dil - pad (zero outside [0, T_in)),
+ *   t_out = t'*out_stride + out_off (rows outside [0, T_out) are dropped).
+ *   w dev [C_out][taps][C_in] (C_in % 32 == 0); y raw result or NULL; y2 = snake(result, alpha) or NULL
+ *   (Snake1d of the NEXT layer fused: vampnet/modules/layers.py:12-18); act 1 = tanh.
+ *   Covers WNConv1d (any k/dilation/stride) and, one call per phase, WNConvTranspose1d(k=2s, stride s).       */
+int vn_conv1d_f32(vn_ctx* ctx, const float* x, const float* w, const float* bias, const float* resid,
+                  const float* alpha, float* y, float* y2, int B, int T_in, int T_rows, int T_out, int C_in,
+                  int C_out, int taps, int in_stride, int dil, int pad, int out_stride, int out_off, int act,
+                  void* stream);
+/* encoder stem WNConv1d(1 -> C, k=7, pad 3): x dev [B][T], w dev [C][7]; y / y2 as above                      */
+int vn_dac_conv_in_f32(vn_ctx* ctx, const float* x, const float* w, const float* bias, const float* alpha,
+                       float* y, float* y2, int B, int T, int C, void* stream);
+/* decoder head WNConv1d(C -> 1, k=7, pad 3) + tanh on the snake-activated input xs [B][T][C]; w dev [7][C]   */
+int vn_dac_conv_out_f32(vn_ctx* ctx, const float* xs, const float* w, float bias, float* y, int B, int T, int C,
+                        void* stream);
+/* residual VQ encode (codec.encode(...)["codes"], interface.py:223): z dev [B*T][L] -> codes dev int64 [B][n][T];
+ * win [n][8][L], bin [n][8], cb [n][Kc][8], wout [n][L][8], bout [n][L]                                       */
+int vn_rvq_encode_f32(vn_ctx* ctx, const float* z, const float* win, const float* bin, const float* cb,
+                      const float* wout, const float* bout, int64_t* codes, int B, int T, int L, int n_levels,
+                      int codebook_size, void* stream);
+/* codes -> z_q = sum_i out_proj_i(codebook_i[code_i])  (quantizer.from_latents(from_codes(z)), transformer.py:671-672) */
+int vn_rvq_decode_f32(vn_ctx* ctx, const int64_t* codes, const float* cb, const float* wout, const float* bout,
+                      float* zq, int B, int T, int L, int n_levels, int codebook_size, void* stream);
 
 /* tuning hook (scripts/gemm_sweep.py): force the GEMM block tile (bm x bn in {128,64}^2; 0,0 = automatic) and the
  * tile walk order (0 column-major, 1 grouped 8-row patches, -1 keep).  Process-global; not for production use.   */

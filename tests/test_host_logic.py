@@ -157,3 +157,14 @@ def test_mask_schedule_matches_reference_arithmetic():
                 want = torch.floor(O.gamma(r) * torch.tensor(n0)).long()[0].item()
                 assert got[i] == want
             assert got[-1] == 0
+
+
+def test_bs1770_loudness_reference_tone():
+    """ITU-R BS.1770: a 0 dBFS 997 Hz sine reads -3.01 LKFS (per channel)."""
+    from vampnet_amd.codec import integrated_loudness
+    sr = 44100
+    t = np.arange(sr * 5) / sr
+    x = np.sin(2 * np.pi * 997 * t)[None]
+    assert abs(integrated_loudness(x, sr) - (-3.01)) < 0.1
+    assert abs(integrated_loudness(0.1 * x, sr) - (-23.01)) < 0.1
+    assert integrated_loudness(np.zeros((1, sr)), sr) == -70.0

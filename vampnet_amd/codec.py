@@ -1,0 +1,322 @@
+"""DAC / `lac.LAC` codec on the MI355X engine — what `Interface.encode` / `Interface.decode` call
+(reference call sites: interface.py:215,223; transformer.py:661-684; layers.py:145).
+
+PARITY UNPINNED: the codec's source (`lac`, an unpinned git dependency) and weights are not available; this
+implements the published Descript-Audio-Codec layer graph and is tested against
+oracle/dac_oracle.py on seeded synthetic weights.  Hyper-parameters come from the checkpoint's metadata kwargs.
+
+Host side = layer graph + weight packing (weight-norm folded, channels-last tap-major conv weights, transposed
+convolutions split into `stride` polyphase 2-tap convolutions); every FLOP runs in libvampnet_hip.so:
+vn_conv1d_f32 (exact-f32 MFMA implicit GEMM with fused bias / residual / next-layer Snake), vn_dac_conv_in/out,
+vn_rvq_encode/decode.  Activations are channels-last [B][T][C] fp32 on the device.
+"""
+import math
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .engine import Engine
+
+DEFAULT_CFG = dict(encoder_dim=64, encoder_rates=[2, 4, 8, 12], latent_dim=None, decoder_dim=1536,
+                   decoder_rates=[12, 8, 4, 2], n_codebooks=14, codebook_size=1024, codebook_dim=8, sample_rate=44100)
+
+
+class AudioSignal:
+    """Minimal stand-in for audiotools.AudioSignal (not installed): samples (B, C, T) + sample_rate."""
+
+    def __init__(self, samples, sample_rate=44100):
+        if isinstance(samples, np.ndarray):
+            samples = torch.from_numpy(samples)
+        if samples.ndim == 1:
+            samples = samples[None, None]
+        elif samples.ndim == 2:
+            samples = samples[None]
+        self.samples = samples.float()
+        self.sample_rate = int(sample_rate)
+
+    @property
+    def audio_data(self):
+        return self.samples
+
+    @property
+    def duration(self):
+        return self.samples.shape[-1] / self.sample_rate
+
+    def cpu(self):
+        return AudioSignal(self.samples.cpu(), self.sample_rate)
+
+    def to(self, device):
+        return AudioSignal(self.samples.to(device), self.sample_rate)
+
+    def clone(self):
+        return AudioSignal(self.samples.clone(), self.sample_rate)
+
+    def write(self, path):
+        import wave
+        x = (self.samples[0].clamp(-1, 1).cpu().numpy().T * 32767.0).astype("<i2")
+        with wave.open(str(path), "wb") as f:
+            f.setnchannels(x.shape[1]); f.setsampwidth(2); f.setframerate(self.sample_rate)
+            f.writeframes(x.tobytes())
+        return self
+
+    @classmethod
+    def from_wav(cls, path):
+        import wave
+        with wave.open(str(path), "rb") as f:
+            n, ch, sr, sw = f.getnframes(), f.getnchannels(), f.getframerate(), f.getsampwidth()
+            raw = f.readframes(n)
+        assert sw == 2, "16-bit PCM only"
+        x = np.frombuffer(raw, dtype="<i2").reshape(-1, ch).T.astype(np.float32) / 32768.0
+        return cls(torch.from_numpy(x.copy())[None], sr)
+
+
+def _k_weighting(sr):
+    """ITU-R BS.1770 K-weighting biquads (pre-filter shelf + RLB high-pass), bilinear-designed for `sr`."""
+    f0, G, Q = 1681.974450955533, 3.999843853973347, 0.7071752369554196
+    K = math.tan(math.pi * f0 / sr)
+    Vh = 10 ** (G / 20)
+    Vb = Vh ** 0.4996667741545416
+    a0 = 1 + K / Q + K * K
+    b1 = [(Vh + Vb * K / Q + K * K) / a0, 2 * (K * K - Vh) / a0, (Vh - Vb * K / Q + K * K) / a0]
+    a1 = [1.0, 2 * (K * K - 1) / a0, (1 - K / Q + K * K) / a0]
+    f0, Q = 38.13547087602444, 0.5003270373238773
+    K = math.tan(math.pi * f0 / sr)
+    a0 = 1 + K / Q + K * K
+    b2 = [1.0, -2.0, 1.0]
+    a2 = [1.0, 2 * (K * K - 1) / a0, (1 - K / Q + K * K) / a0]
+    return (b1, a1), (b2, a2)
+
+
+def integrated_loudness(x, sr):
+    """BS.1770-4 gated integrated loudness (LUFS) of x (C, T) on the host — what audiotools' `normalize(-24)`
+    measures [UNVERIFIED-DEP]."""
+    from scipy.signal import lfilter
+    x = np.asarray(x, dtype=np.float64)
+    for b, a in _k_weighting(sr):
+        x = lfilter(b, a, x, axis=-1)
+    blk, hop = int(0.4 * sr), int(0.1 * sr)
+    if x.shape[-1] < blk:
+        x = np.pad(x, ((0, 0), (0, blk - x.shape[-1])))
+    n = 1 + (x.shape[-1] - blk) // hop
+    z = np.stack([np.mean(x[:, i * hop:i * hop + blk] ** 2, axis=-1) for i in range(n)], axis=-1)   # (C, n)
+    lk = -0.691 + 10 * np.log10(np.maximum(z.sum(0), 1e-12))
+    keep = lk > -70.0
+    if not keep.any():
+        return -70.0
+    rel = -0.691 + 10 * np.log10(np.maximum(z[:, keep].mean(-1).sum(), 1e-12)) - 10.0
+    keep2 = keep & (lk > rel)
+    if not keep2.any():
+        return -70.0
+    return float(-0.691 + 10 * np.log10(np.maximum(z[:, keep2].mean(-1).sum(), 1e-12)))
+
+
+class _Quantizer:
+    """Exposes codec.quantizer.quantizers[i].codebook.weight like lac.LAC (read at layers.py:145)."""
+
+    class _Q:
+        def __init__(self, w):
+            self.codebook = type("Codebook", (), {"weight": w})()
+
+    def __init__(self, codebooks):
+        self.quantizers = [_Quantizer._Q(codebooks[i]) for i in range(codebooks.shape[0])]
+
+
+def _fold(sd, key):
+    if key + ".weight_v" in sd:
+        return torch._weight_norm(sd[key + ".weight_v"].float(), sd[key + ".weight_g"].float(), 0)
+    return sd[key + ".weight"].float()
+
+
+class DacCodec:
+    def __init__(self, sd: dict, cfg: dict = None, device="cuda:0", engine: Engine = None):
+        cfg = dict(DEFAULT_CFG, **(cfg or {}))
+        self.cfg = cfg
+        self.engine = engine or Engine(device)
+        self.lib = self.engine.lib
+        self.device = self.engine.device
+        self.sample_rate = int(cfg["sample_rate"])
+        self.hop_length = int(np.prod(cfg["encoder_rates"]))
+        self.latent_dim = cfg["latent_dim"] or cfg["encoder_dim"] * 2 ** len(cfg["encoder_rates"])
+        self.n_codebooks = cfg["n_codebooks"]
+        dev = self.device
+
+        def conv(key):          # Conv1d (Cout, Cin, k) -> [Cout][k][Cin]
+            w = _fold(sd, key)
+            return dict(w=w.permute(0, 2, 1).contiguous().to(dev), b=sd[key + ".bias"].float().to(dev),
+                        cout=w.shape[0], cin=w.shape[1], k=w.shape[2])
+
+        def convT(key, s):      # ConvTranspose1d (Cin, Cout, 2s) -> per phase r: [Cout][2][Cin] = w[ci][co][r + jj*s]
+            w = _fold(sd, key)
+            ph = torch.stack([torch.stack([w[:, :, r], w[:, :, r + s]], dim=0).permute(2, 0, 1) for r in range(s)])
+            return dict(w=ph.contiguous().to(dev), b=sd[key + ".bias"].float().to(dev), cout=w.shape[1], cin=w.shape[0], s=s)
+
+        def alpha(key):
+            return sd[key + ".alpha"].float().reshape(-1).contiguous().to(dev)
+
+        def res(p):
+            return dict(a1=alpha(p + ".block.0"), c7=conv(p + ".block.1"), a2=alpha(p + ".block.2"), c1=conv(p + ".block.3"))
+
+        e = {}
+        w0 = _fold(sd, "encoder.block.0")
+        e["stem"] = dict(w=w0.reshape(w0.shape[0], 7).contiguous().to(dev), b=sd["encoder.block.0.bias"].float().to(dev),
+                         c=w0.shape[0])
+        e["blocks"] = []
+        for i, s in enumerate(cfg["encoder_rates"]):
+            p = f"encoder.block.{1 + i}"
+            e["blocks"].append(dict(res=[res(f"{p}.block.{j}") for j in range(3)], a=alpha(p + ".block.3"),
+                                    down=conv(p + ".block.4"), s=s))
+        n = len(cfg["encoder_rates"])
+        e["a_out"] = alpha(f"encoder.block.{n + 1}")
+        e["out"] = conv(f"encoder.block.{n + 2}")
+        self.enc = e
+        q = "quantizer.quantizers."
+        L = self.latent_dim
+        self.rvq = dict(
+            win=torch.stack([_fold(sd, f"{q}{i}.in_proj").reshape(-1, L) for i in range(self.n_codebooks)]).contiguous().to(dev),
+            bin=torch.stack([sd[f"{q}{i}.in_proj.bias"].float() for i in range(self.n_codebooks)]).contiguous().to(dev),
+            cb=torch.stack([sd[f"{q}{i}.codebook.weight"].float() for i in range(self.n_codebooks)]).contiguous().to(dev),
+            wout=torch.stack([_fold(sd, f"{q}{i}.out_proj").reshape(L, -1) for i in range(self.n_codebooks)]).contiguous().to(dev),
+            bout=torch.stack([sd[f"{q}{i}.out_proj.bias"].float() for i in range(self.n_codebooks)]).contiguous().to(dev))
+        self.quantizer = _Quantizer(torch.stack([sd[f"{q}{i}.codebook.weight"].float() for i in range(self.n_codebooks)]))
+        d = {"in": conv("decoder.model.0"), "blocks": []}
+        for i, s in enumerate(cfg["decoder_rates"]):
+            p = f"decoder.model.{1 + i}"
+            d["blocks"].append(dict(a=alpha(p + ".block.0"), up=convT(p + ".block.1", s),
+                                    res=[res(f"{p}.block.{2 + j}") for j in range(3)], s=s))
+        n = len(cfg["decoder_rates"])
+        d["a_out"] = alpha(f"decoder.model.{n + 1}")
+        wl = _fold(sd, f"decoder.model.{n + 2}")                                   # (1, C, 7) -> [7][C]
+        d["head_w"] = wl[0].t().contiguous().to(dev)
+        d["head_b"] = float(sd[f"decoder.model.{n + 2}.bias"].float().item())
+        self.dec = d
+
+    @classmethod
+    def load(cls, path, device="cuda:0", engine=None):
+        ckpt = torch.load(Path(path), map_location="cpu", weights_only=False)
+        kw = dict(ckpt.get("metadata", {}).get("kwargs", {}))
+        return cls(ckpt["state_dict"], {k: v for k, v in kw.items() if k in DEFAULT_CFG}, device=device, engine=engine)
+
+    # ---- kernels ------------------------------------------------------------------------------
+    def _conv(self, x, c, *, T_in, T_rows, T_out, w=None, taps=None, in_stride=1, dil=1, pad=0, out_stride=1,
+              out_off=0, resid=None, alpha=None, want_raw=True, act=0, y=None, y2=None):
+        B = x.shape[0]
+        cout, cin = c["cout"], c["cin"]
+        if want_raw and y is None:
+            y = torch.empty(B, T_out, cout, device=self.device, dtype=torch.float32)
+        if alpha is not None and y2 is None:
+            y2 = torch.empty(B, T_out, cout, device=self.device, dtype=torch.float32)
+        w = c["w"] if w is None else w
+        taps = c.get("k", 2) if taps is None else taps
+        self.engine.check(self.lib.vn_conv1d_f32(
+            self.engine.handle, x.data_ptr(), w.data_ptr(), c["b"].data_ptr(),
+            resid.data_ptr() if resid is not None else None, alpha.data_ptr() if alpha is not None else None,
+            y.data_ptr() if y is not None else None, y2.data_ptr() if y2 is not None else None,
+            B, T_in, T_rows, T_out, cin, cout, taps, in_stride, dil, pad, out_stride, out_off, act,
+            self.engine.stream()), "vn_conv1d_f32")
+        return y, y2
+
+    def _res_unit(self, x, s, r, dil, alpha_next, T):
+        _, hs = self._conv(s, r["c7"], T_in=T, T_rows=T, T_out=T, dil=dil, pad=3 * dil, alpha=r["a2"], want_raw=False)
+        return self._conv(hs, r["c1"], T_in=T, T_rows=T, T_out=T, resid=x, alpha=alpha_next)
+
+    # ---- reference API ------------------------------------------------------------------------
+    def preprocess(self, audio_data, sample_rate=None):
+        """DAC.preprocess (interface.py:215): right-pad to a multiple of hop_length; returns (audio, length)."""
+        if sample_rate is not None:
+            assert sample_rate == self.sample_rate
+        length = audio_data.shape[-1]
+        pad = math.ceil(length / self.hop_length) * self.hop_length - length
+        return torch.nn.functional.pad(audio_data, (0, pad)), length
+
+    @torch.inference_mode()
+    def encode(self, audio_data, sample_rate=None):
+        """codec.encode(samples, sr) (interface.py:223): audio (B,1,L), L % hop == 0 -> {"codes": (B,n,T) int64, "z": ...}"""
+        x = audio_data.to(self.device, torch.float32)
+        B, ch, L = x.shape
+        assert ch == 1 and L % self.hop_length == 0, "mono audio padded by preprocess() expected"
+        x = x.reshape(B, L).contiguous()
+        e, eng = self.enc, self.engine
+        C0 = e["stem"]["c"]
+        cur = torch.empty(B, L, C0, device=self.device)
+        s = torch.empty(B, L, C0, device=self.device)
+        eng.check(self.lib.vn_dac_conv_in_f32(eng.handle, x.data_ptr(), e["stem"]["w"].data_ptr(), e["stem"]["b"].data_ptr(),
+                                              e["blocks"][0]["res"][0]["a1"].data_ptr(), cur.data_ptr(), s.data_ptr(), B, L, C0,
+                                              eng.stream()), "vn_dac_conv_in_f32")
+        T = L
+        nb = len(e["blocks"])
+        for bi, blk in enumerate(e["blocks"]):
+            for j, dil in enumerate((1, 3, 9)):
+                a_next = blk["res"][j + 1]["a1"] if j < 2 else blk["a"]
+                cur, s = self._res_unit(cur, s, blk["res"][j], dil, a_next, T)
+            st = blk["s"]
+            pad = math.ceil(st / 2)
+            T_out = (T + 2 * pad - 2 * st) // st + 1
+            a_next = e["blocks"][bi + 1]["res"][0]["a1"] if bi + 1 < nb else e["a_out"]
+            cur, s = self._conv(s, blk["down"], T_in=T, T_rows=T_out, T_out=T_out, in_stride=st, pad=pad, alpha=a_next,
+                                want_raw=bi + 1 < nb)
+            T = T_out
+        z, _ = self._conv(s, e["out"], T_in=T, T_rows=T, T_out=T, pad=1)
+        codes = torch.empty(B, self.n_codebooks, T, device=self.device, dtype=torch.int64)
+        r = self.rvq
+        eng.check(self.lib.vn_rvq_encode_f32(eng.handle, z.data_ptr(), r["win"].data_ptr(), r["bin"].data_ptr(),
+                                             r["cb"].data_ptr(), r["wout"].data_ptr(), r["bout"].data_ptr(), codes.data_ptr(),
+                                             B, T, self.latent_dim, self.n_codebooks, self.cfg["codebook_size"], eng.stream()),
+                  "vn_rvq_encode_f32")
+        return {"codes": codes, "z": z}
+
+    @torch.inference_mode()
+    def decode_codes(self, codes):
+        """codes (B,n,T) -> audio (B,1,T*hop): codec.decode(codec.quantizer.from_latents(from_codes(z))[0])["audio"]
+        (transformer.py:669-675)."""
+        codes = codes.to(self.device, torch.int64).contiguous()
+        B, n, T = codes.shape
+        eng, d, r = self.engine, self.dec, self.rvq
+        zq = torch.empty(B, T, self.latent_dim, device=self.device)
+        eng.check(self.lib.vn_rvq_decode_f32(eng.handle, codes.data_ptr(), r["cb"].data_ptr(), r["wout"].data_ptr(),
+                                             r["bout"].data_ptr(), zq.data_ptr(), B, T, self.latent_dim, n,
+                                             self.cfg["codebook_size"], eng.stream()), "vn_rvq_decode_f32")
+        _, s = self._conv(zq, d["in"], T_in=T, T_rows=T, T_out=T, pad=3, alpha=d["blocks"][0]["a"], want_raw=False)
+        nb = len(d["blocks"])
+        cur = None
+        for bi, blk in enumerate(d["blocks"]):
+            st, up = blk["s"], blk["up"]
+            pad = math.ceil(st / 2)
+            T_out = (T - 1) * st - 2 * pad + 2 * st
+            y = torch.empty(B, T_out, up["cout"], device=self.device)
+            y2 = torch.empty(B, T_out, up["cout"], device=self.device)
+            for ph in range(st):        # polyphase: output rows t = t'*st + ph - pad read x[t'] and x[t'-1]
+                self._conv(s, up, w=up["w"][ph], taps=2, T_in=T, T_rows=T + 1, T_out=T_out, in_stride=1, dil=-1, pad=0,
+                           out_stride=st, out_off=ph - pad, alpha=blk["res"][0]["a1"], y=y, y2=y2)
+            cur, s, T = y, y2, T_out
+            for j, dil in enumerate((1, 3, 9)):
+                a_next = blk["res"][j + 1]["a1"] if j < 2 else (d["blocks"][bi + 1]["a"] if bi + 1 < nb else d["a_out"])
+                cur, s = self._res_unit(cur, s, blk["res"][j], dil, a_next, T)
+        audio = torch.empty(B, T, device=self.device)
+        eng.check(self.lib.vn_dac_conv_out_f32(eng.handle, s.data_ptr(), d["head_w"].data_ptr(), d["head_b"], audio.data_ptr(),
+                                               B, T, s.shape[-1], eng.stream()), "vn_dac_conv_out_f32")
+        return audio.reshape(B, 1, T)
+
+    def decode(self, z_or_codes):
+        return {"audio": self.decode_codes(z_or_codes)}
+
+    # ---- Interface helpers (interface.py:206-224, 203-204) --------------------------------------
+    def encode_signal(self, signal, loudness=-24.0):
+        """Interface._preprocess + encode: resample -> mono -> loudness-normalise -> peak-limit -> pad -> codes."""
+        x, sr = signal.samples.float().cpu(), signal.sample_rate
+        if sr != self.sample_rate:
+            from scipy.signal import resample_poly
+            g = math.gcd(sr, self.sample_rate)
+            x = torch.from_numpy(resample_poly(x.numpy(), self.sample_rate // g, sr // g, axis=-1).astype(np.float32))
+        x = x.mean(dim=1, keepdim=True)                                           # to_mono
+        for b in range(x.shape[0]):                                               # normalize(loudness)
+            lufs = integrated_loudness(x[b].numpy(), self.sample_rate)
+            if lufs > -70.0:
+                x[b] *= 10 ** ((loudness - lufs) / 20)
+        peak = x.abs().amax(dim=(1, 2), keepdim=True)                             # ensure_max_of_audio(1.0)
+        x = torch.where(peak > 1.0, x / peak.clamp_min(1e-12), x)
+        x, _ = self.preprocess(x, self.sample_rate)
+        return self.encode(x, self.sample_rate)["codes"]
+
+    def decode_signal(self, codes):
+        return AudioSignal(self.decode_codes(codes), self.sample_rate)

@@ -138,7 +138,7 @@ extern "C" int vn_profile_begin(vn_ctx* ctx, int max_launches) {
 extern "C" int vn_profile_end(vn_ctx* ctx, double* st) {
     if (!ctx || !st) return VN_ERR_INVALID;
     vn_prof& p = ctx->prof;
-    for (int i = 0; i < 6; ++i) st[i] = 0.0;
+    for (int i = 0; i < 9; ++i) st[i] = 0.0;
     p.on = false;
     for (int i = 0; i < p.n; ++i) {
         VN_HIP_CHECK(ctx, hipEventSynchronize(p.ev[2 * i + 1]));

@@ -58,9 +58,9 @@ class Engine:
 
     def profile_end(self):
         """{'gemm': (launches, ms, flops), 'attention': (...)} for the launches since profile_begin."""
-        st = (C.c_double * 6)()
+        st = (C.c_double * 9)()
         self.check(self.lib.vn_profile_end(self.handle, st), "vn_profile_end")
-        return {"gemm": tuple(st[0:3]), "attention": tuple(st[3:6])}
+        return {"gemm": tuple(st[0:3]), "attention": tuple(st[3:6]), "conv1d": tuple(st[6:9])}
 
     def __del__(self):
         try:

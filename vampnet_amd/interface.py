@@ -156,11 +156,11 @@ class Interface:
     @torch.inference_mode()
     def decode(self, z: torch.Tensor):
         """interface.py:203-204 -> VampNet.decode (transformer.py:661-684): MASK -> 0, codes -> audio."""
-        if not hasattr(self.codec, "decode_codes"):
+        if not hasattr(self.codec, "decode_signal"):
             raise RuntimeError("this codec object cannot decode audio (synthetic-codebook stand-in)")
         assert z.ndim == 3
         z = z.masked_fill(z == self.coarse.mask_token, 0)
-        return self.codec.decode_codes(z)
+        return self.codec.decode_signal(z)          # AudioSignal(audio (B,1,T*hop), codec.sample_rate)
 
     # ---- masks --------------------------------------------------------------------------------
     def build_mask(self, z: torch.Tensor, sig=None, rand_mask_intensity: float = 1.0, prefix_s: float = 0.0,
