@@ -29,10 +29,25 @@ def cpu_baseline(threads=None):
     bounded sample: 2 coarse sampling steps (B=1, T=575) + 2 c2f steps (B=1, T=173), extrapolated to the 12 + 8
     steps of one clip (every step costs the same: one forward + sampling)."""
     from oracle import vampnet_oracle as O, weights as W
+    cb = W.synth_codebooks()
     if threads:
         torch.set_num_threads(threads)
+    else:
+        # torch's default (one thread per logical CPU) over-subscribes big hosts: probe a c2f step at a few counts
+        sd = W.synth_state_dict(W.C2F_DIMS, 1)
+        z = W.synth_codes(1, 14, 173, seed=2)
+        mask = torch.ones_like(z)
+        mask[:, :4] = 0
+        best = (1e30, torch.get_num_threads())
+        for n in sorted({min(os.cpu_count() or 8, c) for c in (16, 32, 64, 128)}):
+            torch.set_num_threads(n)
+            O.generate(sd, W.C2F_DIMS, cb, z, mask, sampling_steps=1, seed=0)
+            t0 = time.perf_counter()
+            O.generate(sd, W.C2F_DIMS, cb, z, mask, sampling_steps=1, seed=0)
+            best = min(best, (time.perf_counter() - t0, n))
+        torch.set_num_threads(best[1])
+        del sd
     cores = torch.get_num_threads()
-    cb = W.synth_codebooks()
     out = {}
     for name, dims, T, seed in (("coarse", W.COARSE_DIMS, 575, 0), ("c2f", W.C2F_DIMS, 173, 1)):
         sd = W.synth_state_dict(dims, seed)
@@ -68,13 +83,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    # debugging aid (single-GPU boxes): VN_BENCH_ONE_GPU=1 maps every rank to cuda:0 and uses gloo for the exchange
+    one_gpu = os.environ.get("VN_BENCH_ONE_GPU") == "1"
+    dev_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(device))     # "nccl" is RCCL on ROCm
         pg = dist.group.WORLD
 
     from oracle import weights as W            # synthetic weights/inputs only (no oracle compute on this path)
@@ -97,6 +118,20 @@ def main():
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
+
+    if one_gpu and world > 1:       # gloo has no device all_gather_into_tensor: stage the token exchange through the host
+        import torch.distributed as dist
+
+        def _gather_via_host(z, _itf=itf):
+            B_ = z.shape[0]
+            per = -(-B_ // _itf.world)
+            b0, b1 = _itf._shard(B_)
+            local = torch.zeros((per,) + tuple(z.shape[1:]), dtype=z.dtype)
+            local[:b1 - b0] = z[b0:b1].cpu()
+            full = [torch.empty_like(local) for _ in range(_itf.world)]
+            dist.all_gather(full, local)
+            return torch.cat(full)[:B_].to(z.device)
+        itf._allgather_batch = _gather_via_host
 
     for i in range(args.warmup):
         itf.vamp(codes, mask, device_seed=100 + i, **kw)

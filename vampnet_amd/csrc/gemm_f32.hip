@@ -210,6 +210,16 @@ __device__ __forceinline__ void vn_gemm_epilogue(const vn_gemm_args& p, int m0, 
     }
 }
 
+// De-phase the two blocks that share a CU: blocks are dispatched round-robin over the 8 XCDs and, inside an XCD, over
+// its 32 CUs, so dispatch index (blockIdx/8) and (blockIdx/8 + 32) are co-resident and would otherwise run in lock
+// step and hit their per-k-tile barriers together (matrix pipes idle).  The second-slot block sleeps first.
+__device__ __forceinline__ void vn_stagger(int order) {
+    const int units = (order >> 8) & 0xff;
+    if (units && (((blockIdx.x >> 3) >> 5) & 1)) {
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);      // 16 * 64 = 1024 cycles per unit
+    }
+}
+
 template <int MI, int NI>
 __device__ __forceinline__ void vn_acc_zero(f32x16 (&acc)[MI][NI]) {
 #pragma unroll
@@ -247,6 +257,8 @@ __global__ __launch_bounds__(256, 2) void vn_gemm_f32_sk_kernel(vn_gemm_args p, 
     using Cfg = GemmCfg<BM, BN>;
     constexpr int MI = Cfg::MI, NI = Cfg::NI;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    vn_stagger(order);
+    order &= 1;
     const int G = gridDim.x;
     const int nk = p.K / BK;
     const long total = (long)tiles_m * tiles_n * nk;
@@ -334,6 +346,7 @@ __global__ __launch_bounds__(256, 2) void vn_gemm_f32_sk_kernel(vn_gemm_args p, 
 // ---------------------------------------------------------------------------------------------
 // tuning hooks (scripts/gemm_sweep.py): force a tile / scheduler / tile order
 static int g_order = 1;
+static int g_stagger = 2;      // stream-K: second-slot blocks start 2 x 1024 cycles late (measured +2..6 %)
 static int g_force_bm = 0, g_force_bn = 0;
 static int g_sched = -1;          // -1 auto, 0 data-parallel, 1 stream-K
 static void read_env_once() {
@@ -348,7 +361,7 @@ static void read_env_once() {
 extern "C" int vn_debug_gemm_config(int bm, int bn, int order) {
     read_env_once();
     g_force_bm = bm; g_force_bn = bn;
-    if (order >= 0) { g_order = order & 1; g_sched = (order >> 1) - 1; }   // order bits: [0] walk, [2:1] sched+1
+    if (order >= 0) { g_order = order & 1; g_sched = ((order >> 1) & 3) - 1; if (order >> 8) g_stagger = ((order >> 8) & 0xff) - 1; }   // bits: [0] walk, [2:1] sched+1, [15:8] stagger+1
     return VN_OK;
 }
 
@@ -378,7 +391,7 @@ static int launch_cfg(vn_ctx* ctx, const vn_gemm_args& a, bool streamk, hipStrea
         int G = SK_MAX_BLOCKS;
         if (total < G) G = (int)total;
         hipLaunchKernelGGL((vn_gemm_f32_sk_kernel<BM, BN, EPI>), dim3(G), dim3(256), Cfg::LDS_BYTES, s, a, tiles_m,
-                           tiles_n, g_order, g_sk_slabs, g_sk_flags, g_sk_flags + SK_MAX_BLOCKS);
+                           tiles_n, g_order | (g_stagger << 8), g_sk_slabs, g_sk_flags, g_sk_flags + SK_MAX_BLOCKS);
     } else {
         hipLaunchKernelGGL((vn_gemm_f32_kernel<BM, BN, EPI>), dim3(tiles_m * tiles_n), dim3(256), Cfg::LDS_BYTES, s, a,
                            tiles_m, tiles_n, g_order);
