@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-per-gpu", type=int, default=8)
     ap.add_argument("--coarse-steps", type=int, default=12)
+    ap.add_argument("--coarse-only", action="store_true", help="BASELINE configs[1]: coarse_vamp only (4 codebooks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -133,14 +134,19 @@ def main():
             return torch.cat(full)[:B_].to(z.device)
         itf._allgather_batch = _gather_via_host
 
+    if args.coarse_only:
+        kw.pop("batch_size")
+        run = lambda seed: itf.coarse_vamp(codes, mask, device_seed=seed, **kw)
+    else:
+        run = lambda seed: itf.vamp(codes, mask, device_seed=seed, **kw)
     for i in range(args.warmup):
-        itf.vamp(codes, mask, device_seed=100 + i, **kw)
+        run(100 + i)
     barrier()
     if not args.no_kernel_events:
         itf.engine.profile_begin(4000 * max(args.steps, 1))
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = itf.vamp(codes, mask, device_seed=i, **kw)
+        out = run(i)
     barrier()
     elapsed = time.perf_counter() - t0
     prof = itf.engine.profile_end() if not args.no_kernel_events else None
@@ -152,7 +158,7 @@ def main():
     assert out.shape == (B, 14, 575)
 
     if rank == 0:
-        tokens = B * TOKENS_PER_CLIP * args.steps
+        tokens = B * (4 * 575 if args.coarse_only else TOKENS_PER_CLIP) * args.steps
         res = {
             "metric": "codec-tokens/s, coarse+c2f vamp(), 10 s clips", "value": tokens / elapsed,
             "unit": "codec-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -94,6 +94,10 @@ typedef struct {
     int64_t batch_offset;        /* index of this call's first item inside the GLOBAL batch: the
                                     device-RNG stream is indexed by global item, so a batch sharded
                                     over GPUs draws the same noise as the unsharded batch         */
+    int32_t call_batch;          /* items per reference generate() call when several calls are batched
+                                    into this launch (item i belongs to call i / call_batch); 0 = B */
+    int32_t global_batch;        /* global batch size of one call; 0 = call_batch.  Device-RNG item id =
+                                    (i / call_batch) * global_batch + batch_offset + i % call_batch  */
 } vn_sample_params;
 
 /* ---- context ------------------------------------------------------------------------------ */
@@ -133,8 +137,10 @@ int vn_forward(vn_model* model, const int64_t* codes, int B, int T, float* logit
 /* replaces VampNet.generate (transformer.py:686-946; spec SURVEY.md App. A), return_signal=False,
  * ctrls=None, cfg_guidance=None.
  * start_tokens dev int64 [B][C][T]; mask dev int64 [B][C][T] in {0,1};
- * num_to_mask_sched host int64 [steps] or NULL: floor(gamma((i+1)/steps) * N0) per step
- *     (transformer.py:903) as the caller computed it (bit-exact torch fp32); NULL = computed here;
+ * num_to_mask_sched host int64 [steps][B] or NULL: floor(gamma((i+1)/steps) * N0) per step AND per item
+ *     (transformer.py:903) as the caller computed it (bit-exact torch fp32).  Per item because the caller may
+ *     batch items that belong to different reference generate() calls (e.g. the 4 coarse-to-fine chunks of
+ *     interface.py:360-374), each with its own batch-wide N0.  NULL = computed here from one N0;
  * exp_noise  dev f32 [steps][B*T*Cp][vocab] Exp(1) draws (multinomial replay) or NULL
  *     = device Philox stream;  unif_noise dev f32 [steps][B][T*Cp] U(1e-20,1) or NULL likewise;
  * out_tokens dev int64 [B][C][T].                                                              */
@@ -150,7 +156,7 @@ int vn_generate(vn_model* model, const int64_t* start_tokens, const int64_t* mas
  * exp_noise dev f32 [B*T*Cp][vocab] or NULL; unif_noise dev f32 [B][T*Cp] or NULL;
  * sampled_out dev int64 [B][C][T] (tokens before re-masking; conditioning codebooks copied).   */
 int vn_sample_step(vn_model* model, int64_t* z_masked, float* logits, int B, int T,
-                   int step, const vn_sample_params* params, int64_t num_to_mask_sched,
+                   int step, const vn_sample_params* params, const int64_t* num_to_mask_sched /* host [B] */,
                    const float* exp_noise, const float* unif_noise, int64_t* sampled_out, void* stream);
 
 /* ---- single kernels (unit tests / profiling; same kernels the model uses) ------------------ */

@@ -15,6 +15,10 @@ from vampnet_amd.engine import draw_noise_host, seed_all
 from vampnet_amd.interface import Interface
 
 
+class _Dims(dict):
+    max_batch = 16
+
+
 class OracleBackedModel:
     """Same surface as vampnet_amd.engine.VampNetModel.generate, computing with the CPU oracle.  It consumes the
     product's own noise ledger (draw_noise_host) and honours n0_override / global_batch / batch_offset, so the
@@ -27,12 +31,34 @@ class OracleBackedModel:
         self.mask_token = dims["vocab"]
         self.chunk_size_s = chunk_size_s
 
+    generate_batched_calls = True
+
+    def draw_noise(self, B, T, steps, sample_cutoff, batch_offset=0, local_batch=None, pin=True):
+        return draw_noise_host(B, T * self.n_predict_codebooks, 1024, steps, sample_cutoff, batch_offset,
+                               B if local_batch is None else local_batch, False)
+
     def generate(self, codec=None, start_tokens=None, mask=None, _sampling_steps=12, temperature=1.0,
                  mask_temperature=10.5, seed=None, sample_cutoff=1.0, rng="torch", n0_override=None,
-                 global_batch=None, batch_offset=0, **_):
+                 global_batch=None, batch_offset=0, noise=None, call_batch=None, **_):
         if seed is not None:
             seed_all(seed)
         B, Cn, T = start_tokens.shape
+        if isinstance(n0_override, (list, tuple)):
+            # several reference calls batched by Interface._generate_calls: un-batch and run them one by one with
+            # the ledger slices the product assembled (checks its interleaving against the sequential oracle)
+            nb = call_batch
+            exp, unif = noise
+            N = T * self.n_predict_codebooks
+            outs = []
+            for c in range(B // nb):
+                sl = slice(c * nb, (c + 1) * nb)
+                nz = [dict(exp=exp[i, c * nb * N:(c + 1) * nb * N] if (i / _sampling_steps) <= sample_cutoff else None,
+                           unif=unif[i, sl]) for i in range(_sampling_steps)]
+                outs.append(O.generate(self.sd, self.dims, self.cb, start_tokens[sl], mask[sl],
+                                       sampling_steps=_sampling_steps, temperature=temperature,
+                                       mask_temperature=mask_temperature, sample_cutoff=sample_cutoff,
+                                       n0_override=n0_override[c * nb], noise=nz))
+            return torch.cat(outs)
         if mask is None:
             mask = torch.ones_like(start_tokens)
             mask[:, :self.n_conditioning_codebooks] = 0
@@ -45,7 +71,7 @@ class OracleBackedModel:
                           n0_override=n0_override, noise=noise)
 
 
-def make_interface(pg=None):
+def make_interface(pg=None, c2f_max_batch=16):
     cb = W.synth_codebooks()
     csd, fsd = W.synth_state_dict(W.TINY_COARSE_DIMS, 0), W.synth_state_dict(W.TINY_C2F_DIMS, 1)
     itf = object.__new__(Interface)
@@ -59,6 +85,8 @@ def make_interface(pg=None):
         itf.rank, itf.world = 0, 1
     itf.coarse = OracleBackedModel(csd, W.TINY_COARSE_DIMS, cb, 10)
     itf.c2f = OracleBackedModel(fsd, W.TINY_C2F_DIMS, cb, 3)
+    itf.c2f.dims = _Dims(W.TINY_C2F_DIMS)            # dict for the oracle + .max_batch like vn_dims
+    itf.c2f.dims.max_batch = c2f_max_batch
     return itf, O.OracleModels(csd, W.TINY_COARSE_DIMS, fsd, W.TINY_C2F_DIMS, cb)
 
 
@@ -73,6 +101,18 @@ def test_vamp_orchestration_matches_oracle(T, B, kw):
     ref, ref_m = O.vamp(models, z, mask, batch_size=B, return_mask=True, **kw)
     got, got_m = itf.vamp(z, mask, batch_size=B, return_mask=True, **kw)
     assert torch.equal(ref, got) and torch.equal(ref_m, got_m)
+
+
+@pytest.mark.parametrize("c2f_max_batch", [1, 3, 5, 64])
+def test_c2f_chunk_batching_groups(c2f_max_batch):
+    """coarse_to_fine batches its chunks into as many launches as the c2f workspace allows (1 = sequential)."""
+    itf, models = make_interface(c2f_max_batch=c2f_max_batch)
+    z = W.synth_codes(1, 14, 800, seed=6)
+    torch.manual_seed(3)
+    mask = itf.build_mask(z)
+    ref = O.vamp(models, z, mask, batch_size=2, seed=4, _sampling_steps=2)
+    got = itf.vamp(z, mask, batch_size=2, seed=4, _sampling_steps=2)
+    assert torch.equal(ref, got)
 
 
 def test_vamp_time_stretch_and_feedback():

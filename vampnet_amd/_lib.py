@@ -21,7 +21,8 @@ class vn_dims(C.Structure):
 class vn_sample_params(C.Structure):
     _fields_ = [("steps", C.c_int32), ("temperature", C.c_float), ("mask_temperature", C.c_float),
                 ("sample_cutoff", C.c_double), ("top_p", C.c_float), ("n0_override", C.c_int64),
-                ("seed", C.c_uint64), ("batch_offset", C.c_int64)]
+                ("seed", C.c_uint64), ("batch_offset", C.c_int64), ("call_batch", C.c_int32),
+                ("global_batch", C.c_int32)]
 
 
 # tensor ids of the packed weight blob (enum in vampnet_hip.h)
@@ -46,7 +47,7 @@ SYMBOLS = {
     "vn_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "vn_generate": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(vn_sample_params), C.POINTER(C.c_int64),
                               _P, _P, _P, _P]),
-    "vn_sample_step": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(vn_sample_params), C.c_int64,
+    "vn_sample_step": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(vn_sample_params), C.POINTER(C.c_int64),
                                  _P, _P, _P, _P]),
     "vn_rmsnorm_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "vn_gemm_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

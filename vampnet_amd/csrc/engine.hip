@@ -6,6 +6,8 @@
 #include <vector>
 #include "vn_common.h"
 
+#define VN_MAX_STEPS 256
+
 struct vn_model {
     vn_ctx* ctx;
     vn_dims d;
@@ -14,6 +16,7 @@ struct vn_model {
     // workspace (device)
     float *x, *y, *qkv, *g, *logits, *bias_full, *psel;
     int32_t *z, *z_sampled, *sampled, *count, *lut;
+    int64_t* ksched;         // device [max_steps][max_batch] per-item mask schedule of the running generate()
     int bias_T;              // T the expanded bias table is currently built for (-1 = none)
     long max_rows;
 };
@@ -172,6 +175,7 @@ extern "C" void vn_model_destroy(vn_model* m) {
     for (float* p : fb) (void)hipFree(p);
     int32_t* ib[] = {m->z, m->z_sampled, m->sampled, m->count, m->lut};
     for (int32_t* p : ib) (void)hipFree(p);
+    (void)hipFree(m->ksched);
     delete m;
 }
 
@@ -199,7 +203,8 @@ extern "C" int vn_model_create(vn_ctx* ctx, const vn_dims* dims, const float* bl
         (rc = dev_alloc(ctx, &m->bias_full, (size_t)m->H * (2 * dims->max_T - 1))) ||
         (rc = dev_alloc(ctx, &m->psel, B * N)) || (rc = dev_alloc(ctx, &m->z, ztot)) ||
         (rc = dev_alloc(ctx, &m->z_sampled, ztot)) || (rc = dev_alloc(ctx, &m->sampled, B * N)) ||
-        (rc = dev_alloc(ctx, &m->count, (size_t)16)) || (rc = dev_alloc(ctx, &m->lut, (size_t)2 * dims->max_T))) {
+        (rc = dev_alloc(ctx, &m->count, (size_t)16)) || (rc = dev_alloc(ctx, &m->lut, (size_t)2 * dims->max_T)) ||
+        (rc = dev_alloc(ctx, &m->ksched, (size_t)VN_MAX_STEPS * B))) {
         vn_model_destroy(m);
         return rc;
     }
@@ -282,7 +287,7 @@ static long host_k_sched(int i, int steps, long n0) {
     return (long)floorf(gm * (float)n0);
 }
 
-static int sample_step(vn_model* m, int B, int T, int step, const vn_sample_params* p, long k_sched,
+static int sample_step(vn_model* m, int B, int T, int step, const vn_sample_params* p, const int64_t* k_sched_dev,
                        float* logits, const float* exp_noise, const float* unif_noise, bool want_sampled,
                        hipStream_t s) {
     if (p->top_p > 0.f && p->top_p < 1.f) {       // transformer.py:1001 "top_p is not None and top_p < 1.0"
@@ -295,6 +300,8 @@ static int sample_step(vn_model* m, int B, int T, int step, const vn_sample_para
     sa.temperature = p->temperature > 0.f ? p->temperature : 1.0f;                  // transformer.py:1019-1023
     sa.do_sample = ((double)step / (double)p->steps) <= p->sample_cutoff ? 1 : 0;  // transformer.py:852-855 (Python doubles)
     sa.seed = p->seed; sa.step = (uint32_t)step; sa.batch_offset = (long)p->batch_offset;
+    sa.call_batch = p->call_batch > 0 ? p->call_batch : B;
+    sa.global_batch = p->global_batch > 0 ? p->global_batch : sa.call_batch;
     int rc = vn_launch_sample(m->ctx, sa, s);
     if (rc) return rc;
     const float r = (float)((double)(step + 1) / (double)p->steps);   // torch.tensor(python float) -> f32 (util.py:6-7)
@@ -303,8 +310,9 @@ static int sample_step(vn_model* m, int B, int T, int step, const vn_sample_para
     ra.out_sampled = want_sampled ? m->z_sampled : nullptr;
     ra.B = B; ra.T = T; ra.C = m->d.n_codebooks; ra.n_cond = m->d.n_cond; ra.V = m->d.vocab;
     ra.mask_temp = p->mask_temperature * (1.0f - r);                               // transformer.py:917-919
-    ra.k_sched = k_sched; ra.last_step = (step == p->steps - 1);
+    ra.k_sched = k_sched_dev; ra.last_step = (step == p->steps - 1);
     ra.seed = p->seed; ra.step = (uint32_t)step; ra.batch_offset = (long)p->batch_offset;
+    ra.call_batch = sa.call_batch; ra.global_batch = sa.global_batch;
     return vn_launch_remask(m->ctx, ra, s);
 }
 
@@ -315,7 +323,7 @@ static int params_check(vn_model* m, const vn_sample_params* p) {
 }
 
 extern "C" int vn_sample_step(vn_model* m, int64_t* z_masked, float* logits, int B, int T, int step,
-                              const vn_sample_params* params, int64_t num_to_mask_sched, const float* exp_noise,
+                              const vn_sample_params* params, const int64_t* num_to_mask_sched, const float* exp_noise,
                               const float* unif_noise, int64_t* sampled_out, void* stream) {
     int rc = shape_check(m, B, T);
     if (rc) return rc;
@@ -324,8 +332,9 @@ extern "C" int vn_sample_step(vn_model* m, int64_t* z_masked, float* logits, int
     hipStream_t s = (hipStream_t)stream;
     const long n = (long)B * m->d.n_codebooks * T;
     if ((rc = vn_launch_i64_to_i32(m->ctx, z_masked, m->z, n, s))) return rc;
-    if ((rc = sample_step(m, B, T, step, params, (long)num_to_mask_sched, logits, exp_noise, unif_noise,
-                          sampled_out != nullptr, s)))
+    if (!num_to_mask_sched) return vn_fail(m->ctx, VN_ERR_INVALID, "num_to_mask_sched is NULL%s", "");
+    VN_HIP_CHECK(m->ctx, hipMemcpyAsync(m->ksched, num_to_mask_sched, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    if ((rc = sample_step(m, B, T, step, params, m->ksched, logits, exp_noise, unif_noise, sampled_out != nullptr, s)))
         return rc;
     if ((rc = vn_launch_i32_to_i64(m->ctx, m->z, z_masked, n, s))) return rc;
     if (sampled_out) rc = vn_launch_i32_to_i64(m->ctx, m->z_sampled, sampled_out, n, s);
@@ -345,10 +354,11 @@ extern "C" int vn_generate(vn_model* m, const int64_t* start_tokens, const int64
     const long N = (long)T * m->Cp, V = m->d.vocab;
     VN_HIP_CHECK(ctx, hipMemsetAsync(m->count, 0, sizeof(int32_t), s));
     if ((rc = vn_launch_apply_mask(ctx, start_tokens, mask, m->z, m->count, n, (int)V, s))) return rc;   // :762-766
+    if (p->steps > VN_MAX_STEPS) return vn_fail(ctx, VN_ERR_INVALID, "steps=%s%ld exceeds VN_MAX_STEPS", "", p->steps);
     long n0 = p->n0_override;
-    std::vector<long> ks(p->steps);
+    std::vector<int64_t> ks((size_t)p->steps * B);
     if (sched) {
-        for (int i = 0; i < p->steps; ++i) ks[i] = (long)sched[i];
+        for (size_t i = 0; i < ks.size(); ++i) ks[i] = sched[i];
     } else {
         if (n0 < 0) {   // one blocking read of the batch-wide masked count (transformer.py:766)
             int32_t c = 0;
@@ -356,13 +366,16 @@ extern "C" int vn_generate(vn_model* m, const int64_t* start_tokens, const int64
             VN_HIP_CHECK(ctx, hipStreamSynchronize(s));
             n0 = c;
         }
-        for (int i = 0; i < p->steps; ++i) ks[i] = host_k_sched(i, p->steps, n0);
+        for (int i = 0; i < p->steps; ++i)
+            for (int b = 0; b < B; ++b) ks[(size_t)i * B + b] = host_k_sched(i, p->steps, n0);
     }
+    // pageable-host H2D: the runtime stages the source before returning, so `ks` may die at scope exit
+    VN_HIP_CHECK(ctx, hipMemcpyAsync(m->ksched, ks.data(), ks.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
     for (int i = 0; i < p->steps; ++i) {
         if ((rc = forward_i32(m, m->z, B, T, m->logits, s))) return rc;
         const float* en = exp_noise ? exp_noise + (size_t)i * B * N * V : nullptr;
         const float* un = unif_noise ? unif_noise + (size_t)i * B * N : nullptr;
-        if ((rc = sample_step(m, B, T, i, p, ks[i], m->logits, en, un, i == p->steps - 1, s))) return rc;
+        if ((rc = sample_step(m, B, T, i, p, m->ksched + (size_t)i * B, m->logits, en, un, i == p->steps - 1, s))) return rc;
     }
     return vn_launch_i32_to_i64(ctx, m->z_sampled, out_tokens, n, s);                   // transformer.py:935-946
 }

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void vn_sample_kernel(vn_sample_args a) {
             if (nrow) {
                 e4 = nrow[lane + 64 * i];
             } else {
-                const long grow = row + a.batch_offset * N;   // global row
+                const long grow = ((long)(b / a.call_batch) * a.global_batch + a.batch_offset + b % a.call_batch) * N + n;   // global row
                 const uint4 r = vn_philox4x32_10(make_uint4((uint32_t)grow, (uint32_t)(grow >> 32), lane + 64 * i, 0x53414d50u),
                                                  make_uint2((uint32_t)a.seed ^ (a.step * 0x9E3779B9u), (uint32_t)(a.seed >> 32)));
                 e4[0] = fmaxf(-logf(vn_u01_open(r.x)), 1e-30f);
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(1024) void vn_remask_kernel(vn_remask_args a) {
         if (a.unif_noise) {
             u = a.unif_noise[(size_t)b * N + n];
         } else {
-            const long gb = b + a.batch_offset;
+            const long gb = (long)(b / a.call_batch) * a.global_batch + a.batch_offset + b % a.call_batch;
             const uint4 r = vn_philox4x32_10(make_uint4((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)n, 0x4d41534bu),
                                              make_uint2((uint32_t)a.seed ^ (a.step * 0x9E3779B9u), (uint32_t)(a.seed >> 32)));
             u = fmaxf(((float)(r.x >> 8) + 0.5f) * (1.0f / 16777216.0f), 1e-20f);
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(1024) void vn_remask_kernel(vn_remask_args a) {
     if ((tid & 63) == 0 && local) atomicAdd(&s_count, local);
     __syncthreads();
     const int count = s_count;
-    long k = a.k_sched;
+    long k = (long)a.k_sched[b];
     if (!a.last_step) {
         long lim = (long)count - 1;
         k = k < lim ? k : lim;

@@ -99,6 +99,7 @@ struct vn_sample_args {
     uint64_t seed;
     uint32_t step;
     long batch_offset;        // global index of item 0 (device RNG only)
+    int call_batch, global_batch;   // RNG item id = (b / call_batch) * global_batch + batch_offset + b % call_batch
 };
 int vn_launch_sample(vn_ctx* ctx, const vn_sample_args& a, hipStream_t s);
 // in-place nucleus filter on the logits of the masked rows (transformer.py:1001-1016)
@@ -113,11 +114,12 @@ struct vn_remask_args {
     int32_t* out_sampled;     // [B][C][T] or null: sampled tokens unflattened (+ cond codebooks from z)
     int B, T, C, n_cond, V;
     float mask_temp;          // mask_temperature * (1 - r)
-    long k_sched;             // floor(gamma(r) * N0)
+    const int64_t* k_sched;   // device [B]: floor(gamma(r) * N0) per item (items of different calls may be batched)
     int last_step;
     uint64_t seed;
     uint32_t step;
     long batch_offset;
+    int call_batch, global_batch;
 };
 int vn_launch_remask(vn_ctx* ctx, const vn_remask_args& a, hipStream_t s);
 

@@ -230,11 +230,12 @@ class VampNetModel:
         return logits.reshape(B, T * self.n_predict_codebooks, self.vocab_size).permute(0, 2, 1)
 
     # ---- sampling ------------------------------------------------------------------------------
-    def _params(self, steps, temperature, mask_temperature, sample_cutoff, top_p, n0_override, seed, batch_offset=0):
+    def _params(self, steps, temperature, mask_temperature, sample_cutoff, top_p, n0_override, seed, batch_offset=0,
+                call_batch=0, global_batch=0):
         return vn_sample_params(int(steps), float(temperature), float(mask_temperature), float(sample_cutoff),
                                 float(top_p) if top_p is not None else 0.0,
                                 int(n0_override) if n0_override is not None else -1,
-                                int(seed) & 0xFFFFFFFFFFFFFFFF, int(batch_offset))
+                                int(seed) & 0xFFFFFFFFFFFFFFFF, int(batch_offset), int(call_batch), int(global_batch))
 
     @staticmethod
     def mask_schedule(steps: int, n0: int):
@@ -266,13 +267,15 @@ class VampNetModel:
                  sample_cutoff: float = 1.0, return_signal=False, debug=False, causal_weight: float = 0.0,
                  cfg_scale: float = 3.0, cfg_guidance: float = None, cond=None,
                  rng: str = "torch", n0_override: int = None, device_seed: int = None,
-                 global_batch: int = None, batch_offset: int = 0):
+                 global_batch: int = None, batch_offset: int = 0, noise=None, call_batch: int = None):
         """Drop-in for VampNet.generate (transformer.py:686-946).  Extra keywords (not in the reference):
           rng="torch"  : parity mode — noise is drawn from torch's CPU generator in the reference's order;
           rng="device" : fast mode — Philox stream on the GPU (seeded by `device_seed` or the torch generator);
           n0_override  : the global batch's masked-token count when this call sees a shard (SURVEY.md §8(e));
           global_batch / batch_offset : size of the global batch and index of this shard's first item, so that
-                         both RNG modes draw the noise the unsharded call would.
+                         both RNG modes draw the noise the unsharded call would;
+          n0_override may be a per-item list and `noise` a pre-drawn (exp, unif) ledger when the caller batches
+                         items of several reference generate() calls (Interface.coarse_to_fine's chunks).
         `typical_filtering/typical_mass/typical_min_tokens` are accepted and have no effect, exactly like the
         reference (transformer.py:989-993 discards the filter's result)."""
         if ctrls is not None or cfg_guidance is not None:
@@ -296,11 +299,21 @@ class VampNetModel:
         steps = int(_sampling_steps)
         if n0_override is None:
             n0 = int(((mask != 0) | (z == self.mask_token)).sum().item())   # transformer.py:762-766, batch-wide
+            n0_items = [n0] * B
+        elif isinstance(n0_override, (list, tuple)):                         # items from different reference calls
+            n0_items = [int(v) for v in n0_override]
+            assert len(n0_items) == B
+            n0 = n0_items[0]
         else:
             n0 = int(n0_override)
-        sched = (C.c_int64 * steps)(*self.mask_schedule(steps, n0))
+            n0_items = [n0] * B
+        per_n0 = {v: self.mask_schedule(steps, v) for v in set(n0_items)}
+        sched = (C.c_int64 * (steps * B))(*[per_n0[n0_items[b]][i] for i in range(steps) for b in range(B)])
         if rng == "torch":
-            exp, unif = self.draw_noise(global_batch or B, T, steps, sample_cutoff, batch_offset, B)
+            if noise is not None:
+                exp, unif = noise                                  # pre-drawn ledger [steps, B*N, V], [steps, B, N]
+            else:
+                exp, unif = self.draw_noise(global_batch or B, T, steps, sample_cutoff, batch_offset, B)
             exp = exp.to(self.device, non_blocking=True)
             unif = unif.to(self.device, non_blocking=True)
             exp_p, unif_p = exp.data_ptr(), unif.data_ptr()
@@ -311,7 +324,8 @@ class VampNetModel:
             dseed = device_seed if device_seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
         else:
             raise ValueError("rng must be 'torch' or 'device'")
-        params = self._params(steps, temperature, mask_temperature, sample_cutoff, top_p, n0, dseed, batch_offset)
+        params = self._params(steps, temperature, mask_temperature, sample_cutoff, top_p, n0, dseed, batch_offset,
+                              call_batch or 0, (global_batch or 0) if call_batch else 0)
         out = torch.empty_like(z)
         self.engine.check(self.lib.vn_generate(self.handle, z.data_ptr(), mask.data_ptr(), B, T, C.byref(params),
                                                sched, exp_p, unif_p, out.data_ptr(), self.engine.stream()),
@@ -319,6 +333,8 @@ class VampNetModel:
         if exp is not None:      # keep the noise alive until the enqueued work has consumed it
             torch.cuda.current_stream(self.device).synchronize()
         return out
+
+    generate_batched_calls = True       # marker: generate() accepts per-item n0_override + a pre-drawn noise ledger
 
     @torch.inference_mode()
     def sample_step(self, z_masked, logits_native, step, steps, n0, *, temperature=1.0, mask_temperature=10.5,
@@ -329,7 +345,7 @@ class VampNetModel:
         B, Cn, T = z.shape
         sampled = torch.empty_like(z)
         params = self._params(steps, temperature, mask_temperature, sample_cutoff, top_p, n0, device_seed)
-        k = self.mask_schedule(steps, n0)[step]
+        k = (C.c_int64 * B)(*([self.mask_schedule(steps, n0)[step]] * B))
         self.engine.check(self.lib.vn_sample_step(
             self.handle, z.data_ptr(), logits_native.contiguous().data_ptr(), B, T, step, C.byref(params), k,
             exp_noise.data_ptr() if exp_noise is not None else None,

@@ -96,12 +96,14 @@ class Interface:
             self.rank, self.world = 0, 1
         self._codebooks = _codec_codebooks(codec)
         self.coarse = self._make_model(csd, ckw, coarse_chunk_s)
-        self.c2f = self._make_model(fsd, fkw, c2f_chunk_s) if fsd is not None else None
+        # the coarse-to-fine chunks of one coarse chunk are batched into one launch: size its workspace for them
+        per_coarse = math.ceil(self.s2t(coarse_chunk_s) / self.s2t(c2f_chunk_s)) if fsd is not None else 1
+        self.c2f = self._make_model(fsd, fkw, c2f_chunk_s, max_batch * per_coarse) if fsd is not None else None
 
-    def _make_model(self, sd, kw, chunk_s):
+    def _make_model(self, sd, kw, chunk_s, max_batch=None):
         kwargs = dict(_DEFAULT_KW)
         kwargs.update({k: v for k, v in (kw or {}).items() if k in _MODEL_KEYS})
-        return VampNetModel(self.engine, sd, self._codebooks, max_batch=self.max_batch,
+        return VampNetModel(self.engine, sd, self._codebooks, max_batch=max_batch or self.max_batch,
                             max_T=self.s2t(chunk_s), chunk_size_s=chunk_s, **kwargs)
 
     # ---- reference API that needs the network / other models -----------------------------------
@@ -212,6 +214,58 @@ class Interface:
                                         batch_offset=b0, **kwargs)
         return out          # rows outside [b0, b1) are stand-ins until vamp()'s final all-gather
 
+    def _generate_calls(self, model, starts, masks_, **kwargs):
+        """Several reference generate() calls of identical shape (the coarse-to-fine chunks, interface.py:360-374)
+        executed as one device batch.  Call c keeps its own batch-wide N0 (transformer.py:766), its own slice of the
+        torch noise stream (drawn call after call, in the reference's order) or its own Philox stream."""
+        rng = kwargs.pop("rng", self.rng)
+        dseed = kwargs.pop("device_seed", None)
+        if kwargs.get("seed") is not None:
+            raise ValueError("seed= reseeds per call; batched calls take the ambient generator (c2f never passes seed)")
+        steps = int(kwargs.get("_sampling_steps", 12))
+        cutoff = kwargs.get("sample_cutoff", 1.0)
+        nC = len(starts)
+        Bg = starts[0].shape[0]
+        b0, b1 = self._shard(Bg)
+        nb = b1 - b0
+        n0s, exps, unifs, zs, ms = [], [], [], [], []
+        for st, mk in zip(starts, masks_):
+            if mk is None:
+                mk = torch.ones_like(st)
+                mk[:, :model.n_conditioning_codebooks, :] = 0
+            n0 = int(((mk != 0) | (st == model.mask_token)).sum().item())              # GLOBAL batch of this call
+            n0s += [n0] * nb
+            if rng == "torch":
+                e, u = model.draw_noise(Bg, st.shape[-1], steps, cutoff, b0, nb, pin=False)
+                exps.append(e)
+                unifs.append(u)
+            zs.append(st[b0:b1])
+            ms.append(mk[b0:b1])
+        noise = None
+        if rng == "torch":
+            N = unifs[0].shape[-1]
+            exp = torch.stack([e.view(steps, nb, N, -1) for e in exps], dim=1).reshape(steps, nC * nb * N, -1)
+            unif = torch.stack(unifs, dim=1).reshape(steps, nC * nb, N)
+            noise = (exp.pin_memory(), unif.pin_memory()) if torch.cuda.is_available() else (exp, unif)
+        elif dseed is not None:
+            dseed = (int(dseed) * 0x9E3779B97F4A7C15 + self._call_idx) & (2 ** 64 - 1)
+            self._call_idx += nC
+        outs = []
+        if nb > 0:
+            res = model.generate(codec=self.codec, start_tokens=torch.cat(zs).contiguous(), mask=torch.cat(ms).contiguous(),
+                                 return_signal=False, rng=rng, n0_override=n0s, noise=noise, device_seed=dseed,
+                                 batch_offset=b0, call_batch=nb, global_batch=Bg, **kwargs)
+            res = res.view(nC, nb, *res.shape[1:])
+        for c, (st, mk) in enumerate(zip(starts, masks_)):
+            if mk is None:
+                mk = torch.ones_like(st)
+                mk[:, :model.n_conditioning_codebooks, :] = 0
+            out = torch.where(mk != 0, torch.zeros_like(st), st)        # stand-in rows for other ranks' items
+            if nb > 0:
+                out[b0:b1] = res[c]
+            outs.append(out)
+        return outs
+
     def _allgather_batch(self, z):
         """The single exchange step: every rank contributes its block of batch items (RCCL all-gather over xGMI)."""
         if self.world == 1:
@@ -246,12 +300,20 @@ class Interface:
         if mask is not None:
             mask = mask.clone()
             mask[:, :c2f.n_conditioning_codebooks, :] = 0
-        pieces = []
-        for i in range(n_chunks):
-            sl = slice(i * chunk_len, (i + 1) * chunk_len)
-            pieces.append(self._generate(c2f, z[:, :, sl].contiguous(),
-                                         mask[:, :, sl].contiguous() if mask is not None else None,
-                                         time_steps=chunk_len, cfg_guidance=None, **kwargs))
+        chunks = [z[:, :, i * chunk_len:(i + 1) * chunk_len] for i in range(n_chunks)]
+        mchunks = [mask[:, :, i * chunk_len:(i + 1) * chunk_len] if mask is not None else None for i in range(n_chunks)]
+        if n_chunks > 1 and hasattr(c2f, "generate_batched_calls"):
+            # the chunks are independent generate() calls of equal length: run them as ONE device batch of
+            # n_chunks*B items (4x larger GEMMs), each item keeping its own call's N0 and noise stream
+            b0, b1 = self._shard(z.shape[0])
+            grp = max(1, c2f.dims.max_batch // max(1, b1 - b0))         # calls per launch that fit the workspace
+            pieces = []
+            for g0 in range(0, n_chunks, grp):
+                pieces += self._generate_calls(c2f, chunks[g0:g0 + grp], mchunks[g0:g0 + grp], time_steps=chunk_len,
+                                               cfg_guidance=None, **dict(kwargs))
+        else:
+            pieces = [self._generate(c2f, ch.contiguous(), m.contiguous() if m is not None else None,
+                                     time_steps=chunk_len, cfg_guidance=None, **kwargs) for ch, m in zip(chunks, mchunks)]
         fine_z = torch.cat(pieces, dim=-1)
         if return_mask:
             return (fine_z[:, :, :length].clone(),
