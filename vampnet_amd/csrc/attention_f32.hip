@@ -21,11 +21,25 @@
 //
 // Algorithmic FLOPs: 4*T*T*64 per (b,h)  (2 GEMMs); HBM bytes: Q,K,V read + O written = 4*T*64*4 per (b,h)
 // (K/V are re-read by the ceil(T/64) q-blocks of a head, from L2).
+#include <stdlib.h>
 #include "vn_common.h"
 
 #define ATT_KT 64        // keys per tile
 #define ATT_LD 68        // padded LDS row (floats)
 
+// exp(x) for x <= 0 with fp32-level accuracy at a third of ocml expf's instruction count: x*log2(e) is split into a
+// rounded product and its exact fma remainder (plus the constant's low part), v_exp_f32 evaluates 2^hi (1 ulp) and the
+// remainder is applied to first order (|lo| < 2^-22, so the dropped term is < 2^-45 relative).
+__device__ __forceinline__ float vn_exp_neg(float x) {
+    x = fmaxf(x, -104.0f);                                     // -inf (masked key / first tile) -> exp2(-150) = 0, no NaN
+    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f;
+    const float hi = x * L2E_HI;
+    const float lo = fmaf(x, L2E_HI, -hi) + x * L2E_LO;
+    const float e = __builtin_amdgcn_exp2f(hi);               // v_exp_f32; exp2(-inf) = 0, flushes below 2^-126
+    return fmaf(e, lo * 0.693147182464599609375f, e);
+}
+
+template <int VARIANT>
 __global__ __launch_bounds__(256) void vn_attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                            const float* __restrict__ v,
                                                            const float* __restrict__ bias_full,  // [H][2T-1]
@@ -127,13 +141,13 @@ __global__ __launch_bounds__(256) void vn_attention_kernel(const float* __restri
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);          // finite: every tile has >= 1 valid key
-        const float alpha = expf(m_run - m_new);       // first tile: exp(-inf) = 0
+        const float alpha = (VARIANT & 1) ? vn_exp_neg(m_run - m_new) : expf(m_run - m_new);   // first tile: exp(-inf) = 0
         float lsum = 0.f;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pexp = expf(sacc[u][r] - m_new);
+                const float pexp = (VARIANT & 1) ? vn_exp_neg(sacc[u][r] - m_new) : expf(sacc[u][r] - m_new);
                 sacc[u][r] = pexp;
                 lsum += pexp;
             }
@@ -187,14 +201,17 @@ int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float
     const size_t lds = (size_t)(2 * ATT_KT * ATT_LD + 2 * T - 1 + 3) * sizeof(float);
     if (lds > 160 * 1024) return vn_fail(ctx, VN_ERR_INVALID, "attention: T=%s%ld too long for the LDS bias table", "", T);
     static bool attr_set = false;
+    static int variant = 1;      // 1: split-product exp2 (default); 0: ocml expf (A/B reference, VN_ATTN_VARIANT=0)
     if (!attr_set) {
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_kernel,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (const char* e = getenv("VN_ATTN_VARIANT")) variant = atoi(e) & 1;
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s);
-    hipLaunchKernelGGL(vn_attention_kernel, dim3(vn_cdiv(T, 64), H, B), dim3(256), lds, s, q, k, v, relbias_full, out,
-                       B, H, T);
+    const dim3 grid(vn_cdiv(T, 64), H, B);
+    if (variant == 0) hipLaunchKernelGGL(vn_attention_kernel<0>, grid, dim3(256), lds, s, q, k, v, relbias_full, out, B, H, T);
+    else hipLaunchKernelGGL(vn_attention_kernel<1>, grid, dim3(256), lds, s, q, k, v, relbias_full, out, B, H, T);
     vn_prof_post(ctx, pi, s);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
