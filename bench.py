@@ -173,12 +173,16 @@ def main():
                        "s_per_clip": elapsed / args.steps / B * world},
         }
         if prof is not None:
-            n, ms, fl = prof["gemm"]
-            an, ams, afl = prof["attention"]
-            res["roofline"] = {"bound": "mfma", "kernel": "vn_gemm_f32_kernel", "achieved": fl / (ms * 1e-3) / 1e12 if ms else None,
+            n, ms, fl, gbytes = prof["gemm"]
+            an, ams, afl, _ = prof["attention"]
+            traffic = None      # fabric bytes per launch from the committed rocprofv3 --pmc passes of this same command
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            if os.path.exists(tpath) and world == 1 and args.batch_per_gpu == 8 and not args.coarse_only:
+                traffic = json.load(open(tpath))["bytes_per_launch"]
+            res["roofline"] = {"bound": "mfma", "kernel": "vn_gemm_f32[_sk]_kernel", "achieved": fl / (ms * 1e-3) / 1e12 if ms else None,
                                "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
                                "frac": (fl / (ms * 1e-3) / 1e12) / PEAK_F32_MFMA_TF if ms else None,
-                               "traffic": None, "launches": int(n), "avg_launch_us": 1e3 * ms / n if n else None,
+                               "traffic": traffic, "algorithmic_bytes_per_launch": gbytes / n if n else None, "launches": int(n), "avg_launch_us": 1e3 * ms / n if n else None,
                                "gemm_time_frac": ms / (1e3 * elapsed) if elapsed else None,
                                "attention": {"launches": int(an), "avg_launch_us": 1e3 * ams / an if an else None,
                                              "achieved": afl / (ams * 1e-3) / 1e12 if ams else None}}

@@ -111,10 +111,11 @@ const char* vn_version(void);
  * While enabled, every launch of the MFMA kernels (vn_gemm_f32[_sk]_kernel, vn_attention_kernel,
  * vn_conv1d_f32_kernel) made through this ctx is bracketed by hipEvents on the launch stream.
  * vn_profile_end synchronises the recorded events and returns, per class c in {0: gemm, 1: attention, 2: conv1d}:
- *   stats[3c+0] = launches, stats[3c+1] = total kernel time in ms, stats[3c+2] = algorithmic FLOPs
- * (2*M*N*K per GEMM / conv launch; 4*T*T*64 per (b,h) for attention).                            */
+ *   stats[4c+0] = launches, stats[4c+1] = total kernel time in ms, stats[4c+2] = algorithmic FLOPs
+ *   (2*M*N*K per GEMM / conv launch; 4*T*T*64 per (b,h) for attention), stats[4c+3] = algorithmic operand bytes
+ *   (every fp32 operand read once + every result written once).                                  */
 int vn_profile_begin(vn_ctx* ctx, int max_launches);
-int vn_profile_end(vn_ctx* ctx, double* stats9);
+int vn_profile_end(vn_ctx* ctx, double* stats12);
 
 /* ---- weights ------------------------------------------------------------------------------ */
 /* total number of floats in the packed blob */

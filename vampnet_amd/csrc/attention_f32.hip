@@ -208,7 +208,7 @@ int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s);
+    const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
     const dim3 grid(vn_cdiv(T, 64), H, B);
     if (variant == 0) hipLaunchKernelGGL(vn_attention_kernel<0>, grid, dim3(256), lds, s, q, k, v, relbias_full, out, B, H, T);
     else hipLaunchKernelGGL(vn_attention_kernel<1>, grid, dim3(256), lds, s, q, k, v, relbias_full, out, B, H, T);

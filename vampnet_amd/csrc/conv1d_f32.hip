@@ -178,7 +178,9 @@ static int launch_conv(vn_ctx* ctx, const vn_conv_args& a, hipStream_t s) {
     const int M = a.B * a.T_rows;
     const int tiles_m = vn_cdiv(M, BM), tiles_n = vn_cdiv(a.C_out, BN);
     constexpr int LDS = 2 * (BM + BN) * BK * 4;
-    const int pi = vn_prof_pre(ctx, 2, 2.0 * M * (double)a.C_out * a.taps * a.C_in, s);
+    const double bytes = 4.0 * ((double)a.B * a.T_in * a.C_in + (double)a.C_out * a.taps * a.C_in +
+                                (double)M * a.C_out * ((a.y ? 1 : 0) + (a.y2 ? 1 : 0) + (a.resid ? 1 : 0)));
+    const int pi = vn_prof_pre(ctx, 2, 2.0 * M * (double)a.C_out * a.taps * a.C_in, s, bytes);
     hipLaunchKernelGGL((vn_conv1d_f32_kernel<BM, BN>), dim3(tiles_m * tiles_n), dim3(256), LDS, s, a, tiles_m, tiles_n);
     vn_prof_post(ctx, pi, s);
     VN_LAUNCH_CHECK(ctx);

@@ -112,7 +112,7 @@ extern "C" int vn_ctx_create(int device, vn_ctx** out) {
 static void prof_free(vn_ctx* ctx) {
     vn_prof& p = ctx->prof;
     for (int i = 0; i < 2 * p.cap; ++i) (void)hipEventDestroy(p.ev[i]);
-    delete[] p.ev; delete[] p.cls; delete[] p.flops;
+    delete[] p.ev; delete[] p.cls; delete[] p.flops; delete[] p.bytes;
     p = vn_prof();
 }
 extern "C" void vn_ctx_destroy(vn_ctx* ctx) {
@@ -129,7 +129,8 @@ extern "C" int vn_profile_begin(vn_ctx* ctx, int max_launches) {
         p.ev = new (std::nothrow) hipEvent_t[2 * (size_t)max_launches];
         p.cls = new (std::nothrow) int[max_launches];
         p.flops = new (std::nothrow) double[max_launches];
-        if (!p.ev || !p.cls || !p.flops) return VN_ERR_OOM;
+        p.bytes = new (std::nothrow) double[max_launches];
+        if (!p.ev || !p.cls || !p.flops || !p.bytes) return VN_ERR_OOM;
         for (int i = 0; i < 2 * max_launches; ++i) VN_HIP_CHECK(ctx, hipEventCreate(&p.ev[i]));
         p.cap = max_launches;
     }
@@ -141,16 +142,17 @@ extern "C" int vn_profile_begin(vn_ctx* ctx, int max_launches) {
 extern "C" int vn_profile_end(vn_ctx* ctx, double* st) {
     if (!ctx || !st) return VN_ERR_INVALID;
     vn_prof& p = ctx->prof;
-    for (int i = 0; i < 9; ++i) st[i] = 0.0;
+    for (int i = 0; i < 12; ++i) st[i] = 0.0;
     p.on = false;
     for (int i = 0; i < p.n; ++i) {
         VN_HIP_CHECK(ctx, hipEventSynchronize(p.ev[2 * i + 1]));
         float ms = 0.f;
         VN_HIP_CHECK(ctx, hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]));
         const int c = p.cls[i];
-        st[3 * c + 0] += 1.0;
-        st[3 * c + 1] += ms;
-        st[3 * c + 2] += p.flops[i];
+        st[4 * c + 0] += 1.0;
+        st[4 * c + 1] += ms;
+        st[4 * c + 2] += p.flops[i];
+        st[4 * c + 3] += p.bytes[i];
     }
     p.n = 0;
     return VN_OK;

@@ -404,7 +404,9 @@ static int launch_cfg(vn_ctx* ctx, const vn_gemm_args& a, bool streamk, hipStrea
         int rc = sk_workspace(ctx);
         if (rc) return rc;
     }
-    const int pi = vn_prof_pre(ctx, 0, 2.0 * a.M * (double)a.N * a.K, s);
+    const double n_out = (EPI == VN_EPI_GEGLU) ? a.N / 2 : a.N;
+    const double bytes = 4.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * n_out * (EPI == VN_EPI_RESIDUAL ? 2 : 1));
+    const int pi = vn_prof_pre(ctx, 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);
     if (streamk) {
         const long total = (long)tiles_m * tiles_n * (a.K / BK);
         int G = SK_MAX_BLOCKS;

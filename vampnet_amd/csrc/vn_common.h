@@ -20,6 +20,7 @@ struct vn_prof {
     hipEvent_t* ev = nullptr;      // 2 events per launch
     int* cls = nullptr;            // class per launch (0 gemm, 1 attention)
     double* flops = nullptr;
+    double* bytes = nullptr;       // algorithmic operand bytes of the launch
 };
 
 struct vn_ctx {
@@ -29,12 +30,13 @@ struct vn_ctx {
 };
 
 // bracket a launch with events when profiling is on (no-ops otherwise)
-static inline int vn_prof_pre(vn_ctx* ctx, int cls, double flops, hipStream_t s) {
+static inline int vn_prof_pre(vn_ctx* ctx, int cls, double flops, hipStream_t s, double bytes = 0.0) {
     vn_prof& p = ctx->prof;
     if (!p.on || p.n >= p.cap) return -1;
     const int i = p.n++;
     p.cls[i] = cls;
     p.flops[i] = flops;
+    p.bytes[i] = bytes;
     (void)hipEventRecord(p.ev[2 * i], s);
     return i;
 }

@@ -57,10 +57,10 @@ class Engine:
         self.check(self.lib.vn_profile_begin(self.handle, max_launches), "vn_profile_begin")
 
     def profile_end(self):
-        """{'gemm': (launches, ms, flops), 'attention': (...)} for the launches since profile_begin."""
-        st = (C.c_double * 9)()
+        """{'gemm': (launches, ms, flops, bytes), 'attention': (...), 'conv1d': (...)} since profile_begin."""
+        st = (C.c_double * 12)()
         self.check(self.lib.vn_profile_end(self.handle, st), "vn_profile_end")
-        return {"gemm": tuple(st[0:3]), "attention": tuple(st[3:6]), "conv1d": tuple(st[6:9])}
+        return {"gemm": tuple(st[0:4]), "attention": tuple(st[4:8]), "conv1d": tuple(st[8:12])}
 
     def __del__(self):
         try:
