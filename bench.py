@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 TOKENS_PER_CLIP = 14 * 575
 PEAK_F32_MFMA_TF = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
+PEAK_BF16_MFMA_TF = 2500.0         # dense bf16 MFMA (32x32x16)
 
 
 def cpu_baseline(threads=None):
@@ -73,6 +74,8 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=8)
     ap.add_argument("--coarse-steps", type=int, default=12)
     ap.add_argument("--coarse-only", action="store_true", help="BASELINE configs[1]: coarse_vamp only (4 codebooks)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = exact-fp32 MFMA (parity-backed default); bf16 = fast mode, not bit-exact")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -106,7 +109,7 @@ def main():
     cb = W.synth_codebooks()
     itf = Interface.from_state_dicts(SynthCodec(cb), W.synth_state_dict(W.COARSE_DIMS, 0), model_kwargs(W.COARSE_DIMS),
                                      W.synth_state_dict(W.C2F_DIMS, 1), model_kwargs(W.C2F_DIMS), device=device,
-                                     max_batch=args.batch_per_gpu, rng="device", process_group=pg)
+                                     max_batch=args.batch_per_gpu, rng="device", process_group=pg, precision=args.dtype)
     B = args.batch_per_gpu * world
     codes = W.synth_codes(B, 14, 575, seed=2).to(device)
     torch.manual_seed(0)
@@ -163,7 +166,7 @@ def main():
             "metric": "codec-tokens/s, coarse+c2f vamp(), 10 s clips", "value": tokens / elapsed,
             "unit": "codec-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (random-init weights of the real architecture, "
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (random-init weights of the real architecture, "
             "random codes, periodic-7 prompt mask)",
             "config": {"workload": "BASELINE configs[2]: Interface.vamp() coarse(12 steps)+c2f(4x2 steps), "
                                    f"batch {args.batch_per_gpu}/GPU x 10 s @ 44.1 kHz (T=575, 14 codebooks), "
@@ -173,15 +176,15 @@ def main():
                        "s_per_clip": elapsed / args.steps / B * world},
         }
         if prof is not None:
-            n, ms, fl, gbytes = prof["gemm"]
+            n, ms, fl, gbytes = prof["gemm_bf16"] if args.dtype == "bf16" else prof["gemm"]
             an, ams, afl, _ = prof["attention"]
             traffic = None      # fabric bytes per launch from the committed rocprofv3 --pmc passes of this same command
             tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-            if os.path.exists(tpath) and world == 1 and args.batch_per_gpu == 8 and not args.coarse_only:
+            if os.path.exists(tpath) and world == 1 and args.batch_per_gpu == 8 and not args.coarse_only and args.dtype == "f32":
                 traffic = json.load(open(tpath))["bytes_per_launch"]
             res["roofline"] = {"bound": "mfma", "kernel": "vn_gemm_f32[_sk]_kernel", "achieved": fl / (ms * 1e-3) / 1e12 if ms else None,
-                               "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                               "frac": (fl / (ms * 1e-3) / 1e12) / PEAK_F32_MFMA_TF if ms else None,
+                               "peak": PEAK_BF16_MFMA_TF if args.dtype == "bf16" else PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+                               "frac": (fl / (ms * 1e-3) / 1e12) / (PEAK_BF16_MFMA_TF if args.dtype == "bf16" else PEAK_F32_MFMA_TF) if ms else None,
                                "traffic": traffic, "algorithmic_bytes_per_launch": gbytes / n if n else None, "launches": int(n), "avg_launch_us": 1e3 * ms / n if n else None,
                                "gemm_time_frac": ms / (1e3 * elapsed) if elapsed else None,
                                "attention": {"launches": int(an), "avg_launch_us": 1e3 * ams / an if an else None,

@@ -110,12 +110,13 @@ const char* vn_version(void);
 /* ---- kernel timing (bench.py's roofline leg) ------------------------------------------------
  * While enabled, every launch of the MFMA kernels (vn_gemm_f32[_sk]_kernel, vn_attention_kernel,
  * vn_conv1d_f32_kernel) made through this ctx is bracketed by hipEvents on the launch stream.
- * vn_profile_end synchronises the recorded events and returns, per class c in {0: gemm, 1: attention, 2: conv1d}:
+ * vn_profile_end synchronises the recorded events and returns, per class c in {0: gemm f32, 1: attention, 2: conv1d,
+ * 3: gemm bf16}:
  *   stats[4c+0] = launches, stats[4c+1] = total kernel time in ms, stats[4c+2] = algorithmic FLOPs
  *   (2*M*N*K per GEMM / conv launch; 4*T*T*64 per (b,h) for attention), stats[4c+3] = algorithmic operand bytes
  *   (every fp32 operand read once + every result written once).                                  */
 int vn_profile_begin(vn_ctx* ctx, int max_launches);
-int vn_profile_end(vn_ctx* ctx, double* stats12);
+int vn_profile_end(vn_ctx* ctx, double* stats16);
 
 /* ---- weights ------------------------------------------------------------------------------ */
 /* total number of floats in the packed blob */
@@ -128,6 +129,12 @@ int vn_weights_offset(const vn_dims* dims, int tensor_id, int layer, int64_t* of
  * `blob_dev`: packed weights (layout above) in device memory, must outlive the model.        */
 int  vn_model_create(vn_ctx* ctx, const vn_dims* dims, const float* blob_dev, vn_model** out);
 void vn_model_destroy(vn_model* model);
+
+/* Optional bf16 FAST MODE (not bit-exact; the reference itself runs bf16 autocast on a GPU: interface.py:364,428).
+ * `blob_bf16_dev`: the packed weight blob converted element-wise to bf16 (same element offsets), device memory that
+ * must outlive the model; NULL switches back to exact fp32.  The GEMM A/W operands become bf16
+ * (v_mfma_f32_32x32x16_bf16, fp32 accumulate); attention, norms, residual stream, softmax and sampling stay fp32. */
+int vn_model_set_bf16(vn_model* model, const void* blob_bf16_dev);
 
 /* replaces embedding.from_codes + VampNet.forward (layers.py:134-163; transformer.py:617-639).
  * codes  dev int64 [B][C][T] (MASK = vocab allowed in any codebook)
@@ -169,6 +176,11 @@ int vn_rmsnorm_f32(vn_ctx* ctx, const float* x, const float* w, float* y, int ro
  *   3 GEGLU: W rows interleaved as VN_W_W1, C is [M][N/2] (activations.py:16-35)                */
 int vn_gemm_f32(vn_ctx* ctx, const float* A, const float* W, const float* bias, float* C,
                 int M, int N, int K, int epilogue, void* stream);
+
+/* bf16-operand GEMM of the fast mode (A16 [M][K], W16 [N][K] bf16, K % 64 == 0; fp32 accumulate/output;
+ * epilogue 0 store, 1 bias, 2 residual)                                                                        */
+int vn_gemm_bf16(vn_ctx* ctx, const void* A16, const void* W16, const float* bias, float* C, int M, int N, int K,
+                 int epilogue, void* stream);
 
 /* Self-attention core (transformer.py:229-254): q,k,v dev f32 [B][H][T][64];
  * rel_bias dev f32 [num_buckets][H]; out dev f32 [B][T][H*64].                                */

@@ -103,3 +103,21 @@ def test_attention_bias_buckets_exact(eng):
         got = eng.attention(q.cuda(), k.cuda(), v.cuda(), table.cuda()).cpu().reshape(T, H, 64)
         want = ref_soft[:, :, blk:blk + n].permute(1, 0, 2)
         np.testing.assert_allclose(got[:, :, :n].numpy(), want.numpy(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("M,N,K", [(4600, 3840, 1280), (575, 1280, 2560), (130, 256, 64), (1384, 10240, 1280)])
+def test_gemm_bf16_fast_mode(eng, M, N, K):
+    """bf16-operand GEMM (fast mode): exact products of bf16 inputs, fp32 accumulation -> compare with the fp64 product
+    of the SAME bf16-rounded operands (tolerance = fp32 accumulation order only)."""
+    from vampnet_amd import _lib
+    a16 = _rand((M, K), 3).to(torch.bfloat16)
+    w16 = (_rand((N, K), 4) / np.sqrt(K)).to(torch.bfloat16)
+    ref = a16.double() @ w16.double().t()
+    absdot = a16.abs().double() @ w16.abs().double().t()
+    tol = (2e-6 * absdot + 1e-6).numpy()
+    got = eng.gemm_bf16(a16.cuda(), w16.cuda()).cpu().double()
+    assert np.all(np.abs((got - ref).numpy()) <= tol)
+    c0 = _rand((M, N), 6)
+    out = c0.cuda().clone()
+    eng.gemm_bf16(a16.cuda(), w16.cuda(), epilogue=_lib.EPI_RESIDUAL, out=out)
+    assert np.all(np.abs((out.cpu().double() - (ref + c0.double())).numpy()) <= tol)

@@ -314,3 +314,27 @@ def test_full_vamp_properties(eng):
     assert torch.equal(out[:, :3][keep[:, :3] == 0], z[:, :3][keep[:, :3] == 0])
     out2 = itf.vamp(z, mask, batch_size=8, _sampling_steps=12, device_seed=1).cpu()
     assert torch.equal(out, out2)
+
+
+# ---------------------------------------------------------------------------------------- bf16 fast mode
+def test_bf16_fast_mode_is_close_but_not_claimed_exact(eng):
+    """precision="bf16": GEMM operands rounded to bf16 like the reference's own GPU path (torch.autocast, interface.py:364);
+    logits stay within bf16-class error of the fp32 oracle (3.9e-2 for the reference under bf16) and the
+    engine can be switched back to the exact path."""
+    from vampnet_amd.engine import VampNetModel
+    dims = W.C2F_DIMS
+    cb, sd = W.synth_codebooks(), W.synth_state_dict(dims, 1)
+    model = VampNetModel(eng, sd, cb, max_batch=2, max_T=173, precision="bf16", **model_kwargs(dims))
+    codes = W.synth_codes(2, 14, 173, seed=11)
+    codes[:, 4:, 1::2] = 1024
+    ref = O.forward(sd, dims, O.from_codes(sd, cb, codes))
+    got = model.forward_codes(codes).cpu()
+    err = (got - ref).abs()
+    agree = (got.argmax(1) == ref.argmax(1)).float().mean().item()
+    print(f"bf16 fast mode: max |dlogit| = {err.max():.3e}, mean = {err.mean():.3e}, argmax agreement = {agree:.4f}")
+    assert err.max() < 0.15 and err.mean() < 0.02 and agree > 0.9
+    z = model.generate(start_tokens=codes, mask=None, _sampling_steps=2, rng="device", device_seed=3).cpu()
+    assert z.min() >= 0 and z.max() < 1024 and torch.equal(z[:, :4], codes[:, :4])
+    model.set_precision("f32")
+    exact = model.forward_codes(codes).cpu()
+    assert (exact - ref).abs().max() < LOGIT_ATOL_FULL

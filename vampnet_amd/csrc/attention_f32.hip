@@ -43,7 +43,8 @@ template <int VARIANT>
 __global__ __launch_bounds__(256) void vn_attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                            const float* __restrict__ v,
                                                            const float* __restrict__ bias_full,  // [H][2T-1]
-                                                           float* __restrict__ out, int B, int H, int T) {
+                                                           float* __restrict__ out, uint16_t* __restrict__ out16,
+                                                           int B, int H, int T) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;
     float* Vs = Ks + ATT_KT * ATT_LD;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void vn_attention_kernel(const float* __restri
     l_tot += __shfl_xor(l_tot, 16);
     l_tot += __shfl_xor(l_tot, 32);
     if (qrow < T) {
-        float* orow = out + ((size_t)b * T + qrow) * ((size_t)H * VN_DHEAD) + h * VN_DHEAD + 16 * g;
+        const size_t ooff = ((size_t)b * T + qrow) * ((size_t)H * VN_DHEAD) + h * VN_DHEAD + 16 * g;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             f32x4 ov;
@@ -190,13 +191,20 @@ __global__ __launch_bounds__(256) void vn_attention_kernel(const float* __restri
             ov[1] = o[1][r] / l_tot;
             ov[2] = o[2][r] / l_tot;
             ov[3] = o[3][r] / l_tot;
-            *(f32x4*)(orow + 4 * r) = ov;
+            if (out16) {   // bf16 fast mode: the attention output is only the A operand of the fc GEMM
+                uint2 pk;
+                pk.x = vn_f32_to_bf16(ov[0]) | ((unsigned)vn_f32_to_bf16(ov[1]) << 16);
+                pk.y = vn_f32_to_bf16(ov[2]) | ((unsigned)vn_f32_to_bf16(ov[3]) << 16);
+                *(uint2*)(out16 + ooff + 4 * r) = pk;
+            } else {
+                *(f32x4*)(out + ooff + 4 * r) = ov;
+            }
         }
     }
 }
 
 int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* relbias_full,
-                        float* out, int B, int H, int T, hipStream_t s) {
+                        float* out, int B, int H, int T, hipStream_t s, uint16_t* out16) {
     if (B <= 0 || T <= 0) return VN_OK;
     const size_t lds = (size_t)(2 * ATT_KT * ATT_LD + 2 * T - 1 + 3) * sizeof(float);
     if (lds > 160 * 1024) return vn_fail(ctx, VN_ERR_INVALID, "attention: T=%s%ld too long for the LDS bias table", "", T);
@@ -210,8 +218,8 @@ int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float
     }
     const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
     const dim3 grid(vn_cdiv(T, 64), H, B);
-    if (variant == 0) hipLaunchKernelGGL(vn_attention_kernel<0>, grid, dim3(256), lds, s, q, k, v, relbias_full, out, B, H, T);
-    else hipLaunchKernelGGL(vn_attention_kernel<1>, grid, dim3(256), lds, s, q, k, v, relbias_full, out, B, H, T);
+    if (variant == 0) hipLaunchKernelGGL(vn_attention_kernel<0>, grid, dim3(256), lds, s, q, k, v, relbias_full, out, out16, B, H, T);
+    else hipLaunchKernelGGL(vn_attention_kernel<1>, grid, dim3(256), lds, s, q, k, v, relbias_full, out, out16, B, H, T);
     vn_prof_post(ctx, pi, s);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;

@@ -17,6 +17,9 @@ struct vn_model {
     float *x, *y, *qkv, *g, *logits, *bias_full, *psel;
     int32_t *z, *z_sampled, *sampled, *count, *lut;
     int64_t* ksched;         // device [max_steps][max_batch] per-item mask schedule of the running generate()
+    // bf16 fast mode (vn_model_set_bf16): bf16 image of the weight blob (same element offsets) + bf16 GEMM A operands
+    const uint16_t* blob16;
+    uint16_t *y16, *g16;
     int bias_T;              // T the expanded bias table is currently built for (-1 = none)
     long max_rows;
 };
@@ -142,7 +145,7 @@ extern "C" int vn_profile_begin(vn_ctx* ctx, int max_launches) {
 extern "C" int vn_profile_end(vn_ctx* ctx, double* st) {
     if (!ctx || !st) return VN_ERR_INVALID;
     vn_prof& p = ctx->prof;
-    for (int i = 0; i < 12; ++i) st[i] = 0.0;
+    for (int i = 0; i < 16; ++i) st[i] = 0.0;
     p.on = false;
     for (int i = 0; i < p.n; ++i) {
         VN_HIP_CHECK(ctx, hipEventSynchronize(p.ev[2 * i + 1]));
@@ -178,6 +181,8 @@ extern "C" void vn_model_destroy(vn_model* m) {
     int32_t* ib[] = {m->z, m->z_sampled, m->sampled, m->count, m->lut};
     for (int32_t* p : ib) (void)hipFree(p);
     (void)hipFree(m->ksched);
+    (void)hipFree(m->y16);
+    (void)hipFree(m->g16);
     delete m;
 }
 
@@ -236,31 +241,52 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
                               m->d.n_codebooks, T, m->d.vocab + 1, m->d.latent_dim, D, s)))
         return rc;
     const long plane = (long)B * H * T * VN_DHEAD;
+    const bool bf = m->blob16 != nullptr;
+    // bf16 fast mode: the four big GEMM operands (normalised rows, attention output, GEGLU output, weights) are bf16,
+    // accumulation / residual stream / attention / norms / logits stay fp32.  NOT bit-exact.
+    auto W16 = [&](int id, int layer) { return (const float*)(m->blob16 + tensor_offset(&m->d, id, layer)); };
     for (int l = 0; l < m->L; ++l) {
         // y = RMSNorm(x) ; FiLM = identity (d_cond = 0, transformer.py:554)
-        if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM1, l), m->y, M, D, m->d.eps, s))) return rc;
+        if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM1, l), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr))) return rc;
         vn_gemm_args a{};
-        a.A = m->y; a.W = W(m, VN_W_QKV, l); a.C = m->qkv; a.M = M; a.N = 3 * D; a.K = D; a.ldc = 3 * D;
+        a.A = bf ? (const float*)m->y16 : m->y; a.W = bf ? W16(VN_W_QKV, l) : W(m, VN_W_QKV, l); a.bf16 = bf;
+        a.C = m->qkv; a.M = M; a.N = 3 * D; a.K = D; a.ldc = 3 * D;
         a.T = T; a.H = H; a.qkv_plane = plane;
         if ((rc = vn_launch_gemm_f32(ctx, a, VN_EPI_QKV, s))) return rc;
-        if ((rc = vn_launch_attention(ctx, m->qkv, m->qkv + plane, m->qkv + 2 * plane, m->bias_full, m->y, B, H, T, s)))
+        if ((rc = vn_launch_attention(ctx, m->qkv, m->qkv + plane, m->qkv + 2 * plane, m->bias_full, m->y, B, H, T, s,
+                                      bf ? m->y16 : nullptr)))
             return rc;
         vn_gemm_args o{};
-        o.A = m->y; o.W = W(m, VN_W_WO, l); o.C = m->x; o.M = M; o.N = D; o.K = D; o.ldc = D;
+        o.A = bf ? (const float*)m->y16 : m->y; o.W = bf ? W16(VN_W_WO, l) : W(m, VN_W_WO, l); o.bf16 = bf;
+        o.C = m->x; o.M = M; o.N = D; o.K = D; o.ldc = D;
         if ((rc = vn_launch_gemm_f32(ctx, o, VN_EPI_RESIDUAL, s))) return rc;           // x = x + attn
-        if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM3, l), m->y, M, D, m->d.eps, s))) return rc;
+        if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM3, l), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr))) return rc;
         vn_gemm_args f1{};
-        f1.A = m->y; f1.W = W(m, VN_W_W1, l); f1.C = m->g; f1.M = M; f1.N = 4 * D; f1.K = D; f1.ldc = 2 * D;
+        f1.A = bf ? (const float*)m->y16 : m->y; f1.W = bf ? W16(VN_W_W1, l) : W(m, VN_W_W1, l); f1.bf16 = bf;
+        f1.C = m->g; f1.C16 = bf ? m->g16 : nullptr; f1.M = M; f1.N = 4 * D; f1.K = D; f1.ldc = 2 * D;
         if ((rc = vn_launch_gemm_f32(ctx, f1, VN_EPI_GEGLU, s))) return rc;             // g = p1 * gelu(p2)
         vn_gemm_args f2{};
-        f2.A = m->g; f2.W = W(m, VN_W_W2, l); f2.C = m->x; f2.M = M; f2.N = D; f2.K = 2 * D; f2.ldc = D;
+        f2.A = bf ? (const float*)m->g16 : m->g; f2.W = bf ? W16(VN_W_W2, l) : W(m, VN_W_W2, l); f2.bf16 = bf;
+        f2.C = m->x; f2.M = M; f2.N = D; f2.K = 2 * D; f2.ldc = D;
         if ((rc = vn_launch_gemm_f32(ctx, f2, VN_EPI_RESIDUAL, s))) return rc;          // x = x + ffn
     }
-    if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_FINAL_NORM), m->y, M, D, m->d.eps, s))) return rc;
+    if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_FINAL_NORM), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr))) return rc;
     vn_gemm_args c{};
-    c.A = m->y; c.W = W(m, VN_W_CLS_W); c.bias = W(m, VN_W_CLS_B); c.C = logits; c.M = M;
+    c.A = bf ? (const float*)m->y16 : m->y; c.W = bf ? W16(VN_W_CLS_W, 0) : W(m, VN_W_CLS_W); c.bf16 = bf;
+    c.bias = W(m, VN_W_CLS_B); c.C = logits; c.M = M;
     c.N = m->Cp * m->d.vocab; c.K = D; c.ldc = c.N;
     return vn_launch_gemm_f32(ctx, c, VN_EPI_BIAS, s);
+}
+
+extern "C" int vn_model_set_bf16(vn_model* m, const void* blob_bf16_dev) {
+    if (!m) return VN_ERR_INVALID;
+    if (!blob_bf16_dev) { m->blob16 = nullptr; return VN_OK; }          // back to exact fp32
+    if (m->D % 64) return vn_fail(m->ctx, VN_ERR_UNSUPPORTED, "bf16 mode needs d_model %% 64 == 0%s", "");
+    int rc;
+    if (!m->y16 && (rc = dev_alloc(m->ctx, &m->y16, (size_t)m->max_rows * m->D))) return rc;
+    if (!m->g16 && (rc = dev_alloc(m->ctx, &m->g16, (size_t)m->max_rows * 2 * m->D))) return rc;
+    m->blob16 = (const uint16_t*)blob_bf16_dev;
+    return VN_OK;
 }
 
 static int shape_check(vn_model* m, int B, int T) {
@@ -397,6 +423,17 @@ extern "C" int vn_gemm_f32(vn_ctx* ctx, const float* A, const float* Wt, const f
     vn_gemm_args a{};
     a.A = A; a.W = Wt; a.bias = bias; a.C = C; a.M = M; a.N = N; a.K = K;
     a.ldc = epilogue == VN_EPI_GEGLU ? N / 2 : N;
+    return vn_launch_gemm_f32(ctx, a, epilogue, (hipStream_t)stream);
+}
+
+extern "C" int vn_gemm_bf16(vn_ctx* ctx, const void* A16, const void* W16, const float* bias, float* C, int M, int N,
+                           int K, int epilogue, void* stream) {
+    if (!ctx || !A16 || !W16 || !C) return VN_ERR_INVALID;
+    if (epilogue < VN_EPI_STORE || epilogue > VN_EPI_RESIDUAL) return vn_fail(ctx, VN_ERR_INVALID, "bad epilogue%s", "");
+    if (epilogue == VN_EPI_BIAS && !bias) return vn_fail(ctx, VN_ERR_INVALID, "bias epilogue needs bias%s", "");
+    vn_gemm_args a{};
+    a.A = (const float*)A16; a.W = (const float*)W16; a.bias = bias; a.C = C; a.M = M; a.N = N; a.K = K; a.ldc = N;
+    a.bf16 = 1;
     return vn_launch_gemm_f32(ctx, a, epilogue, (hipStream_t)stream);
 }
 

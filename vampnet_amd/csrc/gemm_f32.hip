@@ -86,8 +86,17 @@ __device__ __forceinline__ void vn_tile_coords(int t, int tiles_m, int tiles_n, 
     }
 }
 
+// floats per operand row / k-tiles per row.  bf16 fast mode: A and W hold bf16 (the pointers are typed float* only to
+// share the staging code), a k-tile is still 128 bytes per row = 64 bf16.
+template <bool BF>
+__device__ __forceinline__ int vn_row_floats(const vn_gemm_args& p) { return BF ? p.K / 2 : p.K; }
+template <bool BF>
+__device__ __forceinline__ int vn_ktiles(const vn_gemm_args& p) { return vn_row_floats<BF>(p) / BK; }
+
 // acc += A[m0.., kb*BK .. ke*BK) * W[n0.., same k)^T   for one block tile; all 256 threads participate.
-template <int BM, int BN>
+// BF = true: the 16-byte fragment a lane reads is 8 bf16 = the operand of ONE v_mfma_f32_32x32x16_bf16 (lanes 0-31
+// carry k 0..7, lanes 32-63 k 8..15 of the 16-wide step), fp32 accumulate; same LDS image, DMA and swizzle.
+template <int BM, int BN, bool BF = false>
 __device__ __forceinline__ void vn_gemm_mac(const vn_gemm_args& p, float* lds, int m0, int n0, int kb, int ke,
                                             f32x16 (&acc)[GemmCfg<BM, BN>::MI][GemmCfg<BM, BN>::NI]) {
     using Cfg = GemmCfg<BM, BN>;
@@ -96,6 +105,7 @@ __device__ __forceinline__ void vn_gemm_mac(const vn_gemm_args& p, float* lds, i
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    const int ldk = vn_row_floats<BF>(p);
 
     // per-lane DMA source pointers (pidx = 16-byte slot index inside the tile image)
     const float* srcA[Cfg::A_INSTR];
@@ -106,7 +116,7 @@ __device__ __forceinline__ void vn_gemm_mac(const vn_gemm_args& p, float* lds, i
         const int row = pidx >> 3, slot = (pidx & 7) ^ (row & 7);
         int gm = m0 + row;
         gm = gm < p.M ? gm : p.M - 1;
-        srcA[q] = p.A + (size_t)gm * p.K + slot * 4;
+        srcA[q] = p.A + (size_t)gm * ldk + slot * 4;
     }
 #pragma unroll
     for (int q = 0; q < Cfg::B_INSTR; ++q) {
@@ -114,7 +124,7 @@ __device__ __forceinline__ void vn_gemm_mac(const vn_gemm_args& p, float* lds, i
         const int row = pidx >> 3, slot = (pidx & 7) ^ (row & 7);
         int gn = n0 + row;
         gn = gn < p.N ? gn : p.N - 1;
-        srcB[q] = p.W + (size_t)gn * p.K + slot * 4;
+        srcB[q] = p.W + (size_t)gn * ldk + slot * 4;
     }
     auto stage = [&](int buf, int k0) {
         float* dA = lds + buf * Cfg::STAGE_FLOATS;
@@ -151,13 +161,22 @@ __device__ __forceinline__ void vn_gemm_mac(const vn_gemm_args& p, float* lds, i
             for (int i = 0; i < MI; ++i) a[i] = *(const f32x4*)(sA + aRow + i * 32 * BK + off);
 #pragma unroll
             for (int j = 0; j < NI; ++j) b[j] = *(const f32x4*)(sB + bRow + j * 32 * BK + off);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
+            if constexpr (BF) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),
+                                                                            __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            }
         }
         __syncthreads();   // tile kt consumed by all waves; tile kt+1 landed (vmcnt(0) + barrier)
     }
@@ -182,7 +201,8 @@ __device__ __forceinline__ void vn_gemm_epilogue(const vn_gemm_args& p, int m0, 
                 // wave tile = 64 packed columns = 32 value (tile j=0) + 32 gate (tile j=1)
                 const int ocol = (n0 + wn * (BN / 2)) / 2 + l31;
                 const float v = acc[i][0][r], g = acc[i][NI - 1][r];
-                p.C[(size_t)row * p.ldc + ocol] = v * vn_gelu_tanh(g);
+                if (p.C16) p.C16[(size_t)row * p.ldc + ocol] = vn_f32_to_bf16(v * vn_gelu_tanh(g));   // A operand of w_2
+                else p.C[(size_t)row * p.ldc + ocol] = v * vn_gelu_tanh(g);
             } else {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
@@ -233,7 +253,7 @@ __device__ __forceinline__ void vn_acc_zero(f32x16 (&acc)[MI][NI]) {
 // ---------------------------------------------------------------------------------------------
 // data-parallel scheduler: one block per tile
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int EPI>
+template <int BM, int BN, int EPI, bool BF = false>
 __global__ __launch_bounds__(256, 2) void vn_gemm_f32_kernel(vn_gemm_args p, int tiles_m, int tiles_n, int order) {
     using Cfg = GemmCfg<BM, BN>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -241,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void vn_gemm_f32_kernel(vn_gemm_args p, int
     vn_tile_coords(vn_xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, order, tm, tn);
     f32x16 acc[Cfg::MI][Cfg::NI];
     vn_acc_zero(acc);
-    vn_gemm_mac<BM, BN>(p, lds, tm * BM, tn * BN, 0, p.K / BK, acc);
+    vn_gemm_mac<BM, BN, BF>(p, lds, tm * BM, tn * BN, 0, vn_ktiles<BF>(p), acc);
     vn_gemm_epilogue<BM, BN, EPI>(p, tm * BM, tn * BN, acc);
 }
 
@@ -250,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void vn_gemm_f32_kernel(vn_gemm_args p, int
 // ---------------------------------------------------------------------------------------------
 #define SK_SPIN_LIMIT (1 << 24)
 
-template <int BM, int BN, int EPI>
+template <int BM, int BN, int EPI, bool BF = false>
 __global__ __launch_bounds__(256, 2) void vn_gemm_f32_sk_kernel(vn_gemm_args p, int tiles_m, int tiles_n, int order,
                                                                float* __restrict__ slabs, unsigned* flags,
                                                                unsigned* errword) {
@@ -260,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void vn_gemm_f32_sk_kernel(vn_gemm_args p, 
     vn_stagger(order);
     order &= 1;
     const int G = gridDim.x;
-    const int nk = p.K / BK;
+    const int nk = vn_ktiles<BF>(p);
     const int ntiles = tiles_m * tiles_n;
     const int b = vn_xcd_remap(blockIdx.x, G);          // neighbours in the walk sit on one XCD
     const int tid = threadIdx.x;
@@ -278,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void vn_gemm_f32_sk_kernel(vn_gemm_args p, 
         vn_tile_coords(r * G + b, tiles_m, tiles_n, order, tm, tn);
         f32x16 acc[MI][NI];
         vn_acc_zero(acc);
-        vn_gemm_mac<BM, BN>(p, lds, tm * BM, tn * BN, 0, nk, acc);
+        vn_gemm_mac<BM, BN, BF>(p, lds, tm * BM, tn * BN, 0, nk, acc);
         vn_gemm_epilogue<BM, BN, EPI>(p, tm * BM, tn * BN, acc);
         __syncthreads();
     }
@@ -297,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void vn_gemm_f32_sk_kernel(vn_gemm_args p, 
         const int m0 = tm * BM, n0 = tn * BN;
         f32x16 acc[MI][NI];
         vn_acc_zero(acc);
-        vn_gemm_mac<BM, BN>(p, lds, m0, n0, kb, ke, acc);
+        vn_gemm_mac<BM, BN, BF>(p, lds, m0, n0, kb, ke, acc);
 
         if (kb != 0) {
             // a later k-range of a tile that an earlier block owns: publish the partial sums (only ever the FIRST
@@ -396,7 +416,7 @@ static int sk_workspace(vn_ctx* ctx) {
     return VN_OK;
 }
 
-template <int BM, int BN, int EPI>
+template <int BM, int BN, int EPI, bool BF = false>
 static int launch_cfg(vn_ctx* ctx, const vn_gemm_args& a, bool streamk, hipStream_t s) {
     using Cfg = GemmCfg<BM, BN>;
     const int tiles_m = vn_cdiv(a.M, BM), tiles_n = vn_cdiv(a.N, BN);
@@ -405,16 +425,17 @@ static int launch_cfg(vn_ctx* ctx, const vn_gemm_args& a, bool streamk, hipStrea
         if (rc) return rc;
     }
     const double n_out = (EPI == VN_EPI_GEGLU) ? a.N / 2 : a.N;
-    const double bytes = 4.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * n_out * (EPI == VN_EPI_RESIDUAL ? 2 : 1));
-    const int pi = vn_prof_pre(ctx, 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);
+    const double bytes = (BF ? 2.0 : 4.0) * ((double)a.M * a.K + (double)a.N * a.K) +
+                         4.0 * (double)a.M * n_out * (EPI == VN_EPI_RESIDUAL ? 2 : 1);
+    const int pi = vn_prof_pre(ctx, BF ? 3 : 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);
     if (streamk) {
-        const long total = (long)tiles_m * tiles_n * (a.K / BK);
+        const long total = (long)tiles_m * tiles_n * ((BF ? a.K / 2 : a.K) / BK);
         int G = SK_MAX_BLOCKS;
         if (total < G) G = (int)total;
-        hipLaunchKernelGGL((vn_gemm_f32_sk_kernel<BM, BN, EPI>), dim3(G), dim3(256), Cfg::LDS_BYTES, s, a, tiles_m,
+        hipLaunchKernelGGL((vn_gemm_f32_sk_kernel<BM, BN, EPI, BF>), dim3(G), dim3(256), Cfg::LDS_BYTES, s, a, tiles_m,
                            tiles_n, g_order | (g_stagger << 8), g_sk_slabs, g_sk_flags, g_sk_flags + SK_MAX_BLOCKS);
     } else {
-        hipLaunchKernelGGL((vn_gemm_f32_kernel<BM, BN, EPI>), dim3(tiles_m * tiles_n), dim3(256), Cfg::LDS_BYTES, s, a,
+        hipLaunchKernelGGL((vn_gemm_f32_kernel<BM, BN, EPI, BF>), dim3(tiles_m * tiles_n), dim3(256), Cfg::LDS_BYTES, s, a,
                            tiles_m, tiles_n, g_order);
     }
     vn_prof_post(ctx, pi, s);
@@ -456,6 +477,9 @@ static int launch_epi(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
             }
         }
     }
+    if (a.bf16) {      // fast mode: 128x128 tiles only (the k-tile is 8x shorter: per-tile fixed costs dominate, not rounds)
+        return launch_cfg<128, 128, EPI, true>(ctx, a, sk, s);
+    }
     if (bm == 128 && bn == 128) return launch_cfg<128, 128, EPI>(ctx, a, sk, s);
     if (bm == 64 && bn == 128) return launch_cfg<64, 128, EPI>(ctx, a, sk, s);
     if constexpr (EPI != VN_EPI_GEGLU) {
@@ -467,7 +491,7 @@ static int launch_epi(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
 
 int vn_launch_gemm_f32(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm: empty problem%s", "");
-    if (a.K % BK != 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm: K=%s%ld must be a multiple of 32", "", a.K);
+    if (a.K % (a.bf16 ? 2 * BK : BK) != 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm: K=%s%ld must be a multiple of 32 (64 for bf16)", "", a.K);
     if (a.N % 64 != 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm: N=%s%ld must be a multiple of 64", "", a.N);
     switch (epilogue) {
         case VN_EPI_STORE: return launch_epi<VN_EPI_STORE>(ctx, a, s);

@@ -10,6 +10,14 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// fp32 -> bf16, round to nearest even (what torch's .to(bfloat16) does); NaN not expected on this path
+__device__ __forceinline__ uint16_t vn_f32_to_bf16(float f) {
+    unsigned u = __builtin_bit_cast(unsigned, f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
 
 #define VN_WAVE 64
 #define VN_DHEAD 64
@@ -71,6 +79,8 @@ struct vn_gemm_args {
     const float* W;      // [N][K] row-major
     const float* bias;   // [N] or null
     float* C;            // epilogue dependent
+    uint16_t* C16;       // GEGLU epilogue: write bf16 instead of C (fast mode)
+    int bf16;            // 1: A and W hold bf16 (K counts elements), fp32 accumulate
     int M, N, K;
     int ldc;             // row stride of C (floats)
     // QKV scatter: C = qkv base [3][B][H][T][64]; row m = b*T + t
@@ -79,11 +89,12 @@ struct vn_gemm_args {
 };
 int vn_launch_gemm_f32(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);
 
-int vn_launch_rmsnorm(vn_ctx* ctx, const float* x, const float* w, float* y, int rows, int D, float eps, hipStream_t s);
+int vn_launch_rmsnorm(vn_ctx* ctx, const float* x, const float* w, float* y, int rows, int D, float eps, hipStream_t s,
+                      uint16_t* y16 = nullptr);
 int vn_launch_embed(vn_ctx* ctx, const int32_t* codes, const float* tables, const float* wt, const float* b,
                     float* x, int B, int C, int T, int V1, int latent, int D, hipStream_t s);
 int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* relbias_full,
-                        float* out, int B, int H, int T, hipStream_t s);
+                        float* out, int B, int H, int T, hipStream_t s, uint16_t* out16 = nullptr);
 // expands [num_buckets][H] into per-head tables over rel = key - query in [-(T-1), T-1]: out[h][rel + T - 1]
 void vn_bucket_lut_host(int T, int num_buckets, int max_distance, int32_t* lut /* [2T-1] */);
 int vn_launch_bias_expand(vn_ctx* ctx, const float* rel_bias, const int32_t* lut_dev, float* out, int H, int T,

@@ -58,9 +58,10 @@ class Engine:
 
     def profile_end(self):
         """{'gemm': (launches, ms, flops, bytes), 'attention': (...), 'conv1d': (...)} since profile_begin."""
-        st = (C.c_double * 12)()
+        st = (C.c_double * 16)()
         self.check(self.lib.vn_profile_end(self.handle, st), "vn_profile_end")
-        return {"gemm": tuple(st[0:4]), "attention": tuple(st[4:8]), "conv1d": tuple(st[8:12])}
+        return {"gemm": tuple(st[0:4]), "attention": tuple(st[4:8]), "conv1d": tuple(st[8:12]),
+                "gemm_bf16": tuple(st[12:16])}
 
     def __del__(self):
         try:
@@ -88,6 +89,17 @@ class Engine:
         self.check(self.lib.vn_gemm_f32(self.handle, a.data_ptr(), w.data_ptr(),
                                         bias.data_ptr() if bias is not None else None, out.data_ptr(),
                                         M, N, K, epilogue, self.stream()), "vn_gemm_f32")
+        return out
+
+    def gemm_bf16(self, a16, w16, bias=None, epilogue=_lib.EPI_STORE, out=None):
+        """fast-mode GEMM: a16 [M,K], w16 [N,K] torch.bfloat16 -> fp32 out (op)= a @ w.T"""
+        M, K = a16.shape
+        N = w16.shape[0]
+        if out is None:
+            out = torch.empty(M, N, device=a16.device, dtype=torch.float32)
+        self.check(self.lib.vn_gemm_bf16(self.handle, a16.data_ptr(), w16.data_ptr(),
+                                         bias.data_ptr() if bias is not None else None, out.data_ptr(), M, N, K, epilogue,
+                                         self.stream()), "vn_gemm_bf16")
         return out
 
     def attention(self, q, k, v, rel_bias, num_buckets=32, max_distance=128):
@@ -184,7 +196,7 @@ class VampNetModel:
 
     def __init__(self, engine: Engine, sd: dict, codebooks: torch.Tensor, *, n_heads, n_layers, n_codebooks,
                  n_conditioning_codebooks=0, latent_dim=8, embedding_dim=1280, vocab_size=1024,
-                 max_batch=8, max_T=575, chunk_size_s=10, **_ignored):
+                 max_batch=8, max_T=575, chunk_size_s=10, precision="f32", **_ignored):
         self.engine = engine
         self.lib = engine.lib
         self.n_heads, self.n_layers = n_heads, n_layers
@@ -202,6 +214,22 @@ class VampNetModel:
         engine.check(self.lib.vn_model_create(engine.handle, C.byref(self.dims), self.blob.data_ptr(), C.byref(h)),
                      "vn_model_create")
         self.handle = h
+        self.blob16 = None
+        self.precision = "f32"
+        self.set_precision(precision)
+
+    def set_precision(self, precision: str):
+        """"f32": exact-fp32 MFMA (parity mode, default).  "bf16": fast mode — GEMM operands in bf16 like the
+        reference's own GPU path (torch.autocast(bf16), interface.py:364,428); NOT bit-exact."""
+        if precision == "bf16":
+            if self.blob16 is None:
+                self.blob16 = self.blob.to(torch.bfloat16)          # same element offsets, RNE like torch autocast
+            self.engine.check(self.lib.vn_model_set_bf16(self.handle, self.blob16.data_ptr()), "vn_model_set_bf16")
+        elif precision == "f32":
+            self.engine.check(self.lib.vn_model_set_bf16(self.handle, None), "vn_model_set_bf16")
+        else:
+            raise ValueError("precision must be 'f32' or 'bf16'")
+        self.precision = precision
 
     @property
     def device(self):

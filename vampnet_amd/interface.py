@@ -48,7 +48,7 @@ class Interface:
                  coarse2fine_lora_ckpt: str = None, codec_ckpt: str = None,
                  wavebeat_ckpt: str = None, device: str = "cuda:0", coarse_chunk_size_s: int = 10,
                  coarse2fine_chunk_size_s: int = 3, compile=True, *, codec=None, max_batch: int = 8,
-                 rng: str = "torch", process_group=None):
+                 rng: str = "torch", process_group=None, precision: str = "f32"):
         assert codec_ckpt is not None or codec is not None, "must provide a codec checkpoint"
         assert coarse_ckpt is not None, "must provide a coarse checkpoint"
         if codec is None:
@@ -63,7 +63,7 @@ class Interface:
             if coarse2fine_lora_ckpt is not None:
                 fsd.update(torch.load(coarse2fine_lora_ckpt, map_location="cpu"))
         self._init(codec, csd, ckw, fsd, fkw, device, coarse_chunk_size_s, coarse2fine_chunk_size_s, max_batch, rng,
-                   process_group)
+                   process_group, precision)
         self.coarse_path = Path(coarse_ckpt)
         self.c2f_path = Path(coarse2fine_ckpt) if coarse2fine_ckpt is not None else None
         self.codec_path = Path(codec_ckpt) if codec_ckpt is not None else None
@@ -71,15 +71,17 @@ class Interface:
     @classmethod
     def from_state_dicts(cls, codec, coarse_sd, coarse_kwargs, c2f_sd=None, c2f_kwargs=None, device="cuda:0",
                          coarse_chunk_size_s=10, coarse2fine_chunk_size_s=3, max_batch=8, rng="torch",
-                         process_group=None):
+                         process_group=None, precision="f32"):
         """Build from in-memory reference-format state_dicts (what the checkpoints hold)."""
         self = object.__new__(cls)
         self._init(codec, coarse_sd, coarse_kwargs, c2f_sd, c2f_kwargs, device, coarse_chunk_size_s,
-                   coarse2fine_chunk_size_s, max_batch, rng, process_group)
+                   coarse2fine_chunk_size_s, max_batch, rng, process_group, precision)
         self.coarse_path = self.c2f_path = self.codec_path = None
         return self
 
-    def _init(self, codec, csd, ckw, fsd, fkw, device, coarse_chunk_s, c2f_chunk_s, max_batch, rng, process_group):
+    def _init(self, codec, csd, ckw, fsd, fkw, device, coarse_chunk_s, c2f_chunk_s, max_batch, rng, process_group,
+              precision="f32"):
+        self.precision = precision
         self.codec = codec
         self.device = torch.device(device)
         self.engine = Engine(device)
@@ -104,7 +106,7 @@ class Interface:
         kwargs = dict(_DEFAULT_KW)
         kwargs.update({k: v for k, v in (kw or {}).items() if k in _MODEL_KEYS})
         return VampNetModel(self.engine, sd, self._codebooks, max_batch=max_batch or self.max_batch,
-                            max_T=self.s2t(chunk_s), chunk_size_s=chunk_s, **kwargs)
+                            max_T=self.s2t(chunk_s), chunk_size_s=chunk_s, precision=self.precision, **kwargs)
 
     # ---- reference API that needs the network / other models -----------------------------------
     @classmethod
