@@ -12,8 +12,10 @@
 //   * global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 rows x 128 B per wave instruction),
 //     double-buffered: tile t+1 streams in while tile t is multiplied; one barrier per k-tile.
 //   * LDS image is lane-linear (DMA constraint), so the bank-conflict swizzle is applied on the SOURCE
-//     address: the 16-B slot s of row r is stored at slot s ^ (r & 7) (guide §5.4 rule 21), and
-//     fragments are read with the same XOR by ds_read_b128.
+//     address: the 16-B slot s of row r is stored at slot s ^ ((r >> 1) & 7) (guide §5.4 rule 21), and
+//     fragments are read with the same XOR by ds_read_b128.  With 128-byte rows the bank half is r & 1, so the
+//     16 rows of a ds_read_b128 lane group ({0-3,12-15,20-27} / {4-11,16-19,28-31}) land on 16 distinct 16-byte
+//     slots: conflict-free (the first version XORed r & 7 and paid a 2-way conflict on every fragment read).
 //   * k-order inside a tile: lane half h = lane>>5 reads float4 at k = 8*s + 4*h .. +3 (s = 0..3) and
 //     feeds element e to MFMA #e, i.e. MFMA (s,e) contracts k-pair {8s+e, 8s+4+e}.  Any bijection of k
 //     is a valid fp32 summation order (the reference's own order is MKL's, not specified).
@@ -113,7 +115,7 @@ __device__ __forceinline__ void vn_gemm_mac(const vn_gemm_args& p, float* lds, i
 #pragma unroll
     for (int q = 0; q < Cfg::A_INSTR; ++q) {
         const int pidx = (wave * Cfg::A_INSTR + q) * 64 + lane;
-        const int row = pidx >> 3, slot = (pidx & 7) ^ (row & 7);
+        const int row = pidx >> 3, slot = (pidx & 7) ^ ((row >> 1) & 7);
         int gm = m0 + row;
         gm = gm < p.M ? gm : p.M - 1;
         srcA[q] = p.A + (size_t)gm * ldk + slot * 4;
@@ -121,7 +123,7 @@ __device__ __forceinline__ void vn_gemm_mac(const vn_gemm_args& p, float* lds, i
 #pragma unroll
     for (int q = 0; q < Cfg::B_INSTR; ++q) {
         const int pidx = (wave * Cfg::B_INSTR + q) * 64 + lane;
-        const int row = pidx >> 3, slot = (pidx & 7) ^ (row & 7);
+        const int row = pidx >> 3, slot = (pidx & 7) ^ ((row >> 1) & 7);
         int gn = n0 + row;
         gn = gn < p.N ? gn : p.N - 1;
         srcB[q] = p.W + (size_t)gn * ldk + slot * 4;
@@ -141,8 +143,8 @@ __device__ __forceinline__ void vn_gemm_mac(const vn_gemm_args& p, float* lds, i
                 (__attribute__((address_space(3))) void*)(dB + (wave * Cfg::B_INSTR + q) * 256), 16, 0, 0);
     };
 
-    // fragment read offsets (floats) inside a stage: row*32 + ((2s + h) ^ (row&7))*4 ; row&7 == lane&7
-    const int l31 = lane & 31, h = lane >> 5, sw = lane & 7;
+    // fragment read offsets (floats) inside a stage: row*32 + ((2s + h) ^ ((row>>1)&7))*4 ; (row>>1)&7 == (lane>>1)&7
+    const int l31 = lane & 31, h = lane >> 5, sw = (lane >> 1) & 7;
     const int aRow = (wm * (BM / 2) + l31) * BK;
     const int bRow = (wn * (BN / 2) + l31) * BK;
 
@@ -477,8 +479,9 @@ static int launch_epi(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
             }
         }
     }
-    if (a.bf16) {      // fast mode: 128x128 tiles only (the k-tile is 8x shorter: per-tile fixed costs dominate, not rounds)
-        return launch_cfg<128, 128, EPI, true>(ctx, a, sk, s);
+    if (a.bf16) {      // fast mode: 128x128 data-parallel (kernels last 25-80 us: the ~20 us stream-K fix-up does not pay;
+                       // measured DP 590-770 TF vs SK 400-670 TF on the model's shapes)
+        return launch_cfg<128, 128, EPI, true>(ctx, a, g_sched == 1, s);
     }
     if (bm == 128 && bn == 128) return launch_cfg<128, 128, EPI>(ctx, a, sk, s);
     if (bm == 64 && bn == 128) return launch_cfg<64, 128, EPI>(ctx, a, sk, s);
