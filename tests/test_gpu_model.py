@@ -338,3 +338,73 @@ def test_bf16_fast_mode_is_close_but_not_claimed_exact(eng):
     model.set_precision("f32")
     exact = model.forward_codes(codes).cpu()
     assert (exact - ref).abs().max() < LOGIT_ATOL_FULL
+
+
+# ---------------------------------------------------------------------------------------- checkpoints, hot-swap, LoRA
+def _save_ckpt(path, sd, dims):
+    """audiotools BaseModel.save format: {"state_dict", "metadata": {"kwargs": ctor kwargs}}"""
+    torch.save({"state_dict": sd, "metadata": {"kwargs": model_kwargs(dims)}}, path)
+
+
+def test_interface_from_checkpoint_files_reload_and_lora(eng, tmp_path):
+    """Interface(coarse_ckpt=..., coarse2fine_ckpt=..., codec_ckpt=...) as the reference constructs it
+    (interface.py:55-113), LoRA checkpoint merged at load (interface.py:45 + loralib eval merge), reload() hot-swap
+    (interface.py:146-174)."""
+    from oracle import dac_oracle as D
+    from vampnet_amd.interface import Interface
+    cfg = dict(D.DAC_TINY_CFG, n_codebooks=14)
+    codec_sd = D.synth_dac_state_dict(cfg, 1)
+    torch.save({"state_dict": codec_sd, "metadata": {"kwargs": cfg}}, tmp_path / "codec.pth")
+    csd, fsd = W.synth_state_dict(W.TINY_COARSE_DIMS, 0), W.synth_state_dict(W.TINY_C2F_DIMS, 1)
+    _save_ckpt(tmp_path / "coarse.pth", csd, W.TINY_COARSE_DIMS)
+    _save_ckpt(tmp_path / "c2f.pth", fsd, W.TINY_C2F_DIMS)
+    g = np.random.default_rng(5)
+    lora = {}
+    for l in range(2):
+        for name, (o, i) in {"self_attn.w_qs": (256, 256), "feed_forward.w_2": (256, 512)}.items():
+            lora[f"transformer.layers.{l}.{name}.lora_A"] = torch.from_numpy(g.standard_normal((8, i)).astype(np.float32)) * 0.05
+            lora[f"transformer.layers.{l}.{name}.lora_B"] = torch.from_numpy(g.standard_normal((o, 8)).astype(np.float32)) * 0.05
+    torch.save(lora, tmp_path / "lora.pth")
+    kw = dict(codec_ckpt=str(tmp_path / "codec.pth"), coarse2fine_ckpt=str(tmp_path / "c2f.pth"), device="cuda:0",
+              max_batch=2, coarse_chunk_size_s=0.05, coarse2fine_chunk_size_s=0.02)      # hop 8 -> 276 / 111 token chunks
+    itf = Interface(coarse_ckpt=str(tmp_path / "coarse.pth"), **kw)
+    cb = torch.stack([codec_sd[f"quantizer.quantizers.{i}.codebook.weight"] for i in range(14)])
+    models = O.OracleModels(csd, W.TINY_COARSE_DIMS, fsd, W.TINY_C2F_DIMS, cb, hop_length=8,
+                            coarse_chunk_s=0.05, c2f_chunk_s=0.02)
+    z = W.synth_codes(1, 14, 300, seed=3)
+    torch.manual_seed(1)
+    mask = itf.build_mask(z)
+    ref = O.vamp(models, z, mask, batch_size=2, seed=7, _sampling_steps=3)
+    assert torch.equal(itf.vamp(z, mask, batch_size=2, seed=7, _sampling_steps=3).cpu(), ref)
+    # LoRA: W_eff = W + (B A) / 8 on the lora'd linears
+    itf_l = Interface(coarse_ckpt=str(tmp_path / "coarse.pth"), coarse_lora_ckpt=str(tmp_path / "lora.pth"), **kw)
+    merged = dict(csd)
+    for l in range(2):
+        for name in ("self_attn.w_qs", "feed_forward.w_2"):
+            k = f"transformer.layers.{l}.{name}"
+            merged[k + ".weight"] = csd[k + ".weight"] + (lora[k + ".lora_B"] @ lora[k + ".lora_A"]) / 8.0
+    models_l = O.OracleModels(merged, W.TINY_COARSE_DIMS, fsd, W.TINY_C2F_DIMS, cb, hop_length=8,
+                              coarse_chunk_s=0.05, c2f_chunk_s=0.02)
+    ref_l = O.vamp(models_l, z, mask, batch_size=1, seed=7, _sampling_steps=3)
+    assert not torch.equal(ref_l, ref[:1])
+    assert torch.equal(itf_l.vamp(z, mask, batch_size=1, seed=7, _sampling_steps=3).cpu(), ref_l)
+    # hot swap: reload() with the same path is a no-op, with a new path swaps the coarse weights
+    old = itf.coarse
+    itf.reload(coarse_ckpt=str(tmp_path / "coarse.pth"))
+    assert itf.coarse is old
+    csd2 = W.synth_state_dict(W.TINY_COARSE_DIMS, 9)
+    _save_ckpt(tmp_path / "coarse2.pth", csd2, W.TINY_COARSE_DIMS)
+    itf.reload(coarse_ckpt=str(tmp_path / "coarse2.pth"))
+    assert itf.coarse is not old
+    models2 = O.OracleModels(csd2, W.TINY_COARSE_DIMS, fsd, W.TINY_C2F_DIMS, cb, hop_length=8,
+                             coarse_chunk_s=0.05, c2f_chunk_s=0.02)
+    assert torch.equal(itf.vamp(z, mask, batch_size=1, seed=2, _sampling_steps=2).cpu(),
+                       O.vamp(models2, z, mask, batch_size=1, seed=2, _sampling_steps=2))
+
+
+def test_interface_vamp_time_stretch_feedback_gpu(tiny, itf):
+    z = W.synth_codes(1, 14, 90, seed=2)
+    torch.manual_seed(1)
+    mask = itf.build_mask(z, periodic_prompt=3)
+    kw = dict(batch_size=2, time_stretch_factor=2, feedback_steps=2, seed=5, _sampling_steps=2)
+    assert torch.equal(itf.vamp(z, mask, **kw).cpu(), O.vamp(tiny["models"], z, mask, **kw))
