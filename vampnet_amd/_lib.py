@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvampnet_hip.so")
+LIB_PATH = os.environ.get("VN_LIB") or os.path.join(_HERE, "libvampnet_hip.so")   # VN_LIB: A/B builds (tuning only)
 
 
 class VnError(RuntimeError):
