@@ -29,7 +29,8 @@ def cpu_baseline(threads=None):
     """The oracle (a port of the reference's torch-CPU path, bitwise-pinned to it) timed on the host cores on a
     bounded sample: 2 coarse sampling steps (B=1, T=575) + 2 c2f steps (B=1, T=173), extrapolated to the 12 + 8
     steps of one clip (every step costs the same: one forward + sampling)."""
-    from oracle import vampnet_oracle as O, weights as W
+    from oracle import vampnet_oracle as O            # the ONLY place bench.py touches oracle/: the CPU baseline leg
+    from vampnet_amd import synth as W
     cb = W.synth_codebooks()
     if threads:
         torch.set_num_threads(threads)
@@ -102,9 +103,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(device))     # "nccl" is RCCL on ROCm
         pg = dist.group.WORLD
 
-    from oracle import weights as W            # synthetic weights/inputs only (no oracle compute on this path)
+    from vampnet_amd import synth as W         # synthetic weights / inputs (data generators only)
     from vampnet_amd.interface import Interface
-    from tests.gpu_common import SynthCodec, model_kwargs
+    from vampnet_amd.synth import SynthCodec, model_kwargs
 
     cb = W.synth_codebooks()
     itf = Interface.from_state_dicts(SynthCodec(cb), W.synth_state_dict(W.COARSE_DIMS, 0), model_kwargs(W.COARSE_DIMS),

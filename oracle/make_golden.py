@@ -3,7 +3,7 @@ in this container.  TEST INFRASTRUCTURE.  Re-run:  python -m oracle.make_golden
 
 The reference ships no golden vectors, and /root/reference does not travel to the GPU
 box, so these fixtures are the reference's outputs frozen on seeded synthetic weights
-(oracle/weights.py: numpy PCG64 -> identical on every machine).  Each generate/vamp fixture also
+(vampnet_amd/synth.py: numpy PCG64 -> identical on every machine).  Each generate/vamp fixture also
 stores a checksum of the first torch-CPU noise draw so a consumer can tell "RNG stream differs on
 this machine" from "algorithm differs".
 """

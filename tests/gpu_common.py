@@ -5,22 +5,7 @@ import torch
 from oracle import vampnet_oracle as O, weights as W
 
 
-class SynthCodec:
-    """What Interface reads from the codec on the vamp() path (layers.py:145; interface.py:176-189)."""
-
-    class _Q:
-        def __init__(self, w):
-            self.codebook = type("CB", (), {"weight": w})()
-
-    def __init__(self, codebooks, hop_length=768, sample_rate=44100):
-        self.quantizer = type("RVQ", (), {"quantizers": [SynthCodec._Q(codebooks[i]) for i in range(codebooks.shape[0])]})()
-        self.hop_length, self.sample_rate = hop_length, sample_rate
-
-
-def model_kwargs(dims):
-    return dict(n_heads=dims["n_heads"], n_layers=dims["n_layers"], n_codebooks=dims["n_codebooks"],
-                n_conditioning_codebooks=dims["n_cond"], latent_dim=dims["latent_dim"],
-                embedding_dim=dims["d_model"], vocab_size=dims["vocab"])
+from vampnet_amd.synth import SynthCodec, model_kwargs  # noqa: F401,E402
 
 
 def to_native(logits_ref, Cp):

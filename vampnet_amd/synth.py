@@ -1,0 +1,103 @@
+"""Deterministic synthetic weights / inputs for the VampNet hot path (benchmark + test data; no model logic here).
+
+No checkpoints exist in this image (they live on the HF hub), so every
+parity test and the benchmark run on seeded random-init weights of the real architecture.
+The generator is numpy's PCG64 (`default_rng`) so the same (dims, seed) gives bit-identical
+tensors on every machine, independent of torch's CPU RNG vectorisation.
+
+Key names and shapes follow the reference state_dict (SURVEY.md App. B;
+/root/reference/vampnet/modules/transformer.py:535-604, layers.py:104-132):
+
+  embedding.special.MASK (C, 8); embedding.out_proj.{weight (D, 8C, 1), bias (D)}
+  transformer.layers.{i}.norm_1.weight (D); .self_attn.{w_qs,w_ks,w_vs,fc}.weight (D, D)
+  transformer.layers.0.self_attn.relative_attention_bias.weight (32, H)
+  transformer.layers.{i}.norm_3.weight (D); .feed_forward.w_1.weight (4D, D); .w_2.weight (D, 2D)
+  transformer.norm.weight (D)
+  classifier.layers.0.{weight_g (V*Cp,1,1), weight_v (V*Cp, D, 1), bias (V*Cp)}
+
+Scales follow PyTorch's default inits (Linear/Conv: U(+-1/sqrt(fan_in)); Embedding/MASK: N(0,1)),
+except that norm weights and weight_g are perturbed away from their trivial defaults
+(ones / ||v||) so that a kernel which forgets to apply them fails parity.
+"""
+import numpy as np
+import torch
+
+COARSE_DIMS = dict(n_heads=20, n_layers=20, n_codebooks=4, n_cond=0, latent_dim=8,
+                   d_model=1280, vocab=1024)
+C2F_DIMS = dict(n_heads=20, n_layers=16, n_codebooks=14, n_cond=4, latent_dim=8,
+                d_model=1280, vocab=1024)
+# small shapes the CPU oracle finishes in milliseconds (unit tests, golden fixtures)
+# (d_model / n_heads = 64 like the shipped configs: the HIP attention kernel is specialised for d_head 64)
+TINY_COARSE_DIMS = dict(n_heads=4, n_layers=2, n_codebooks=4, n_cond=0, latent_dim=8,
+                        d_model=256, vocab=1024)
+TINY_C2F_DIMS = dict(n_heads=4, n_layers=2, n_codebooks=14, n_cond=4, latent_dim=8,
+                     d_model=256, vocab=1024)
+
+
+def _uniform(rng, shape, bound):
+    return torch.from_numpy(rng.uniform(-bound, bound, size=shape).astype(np.float32))
+
+
+def _normal(rng, shape, std=1.0):
+    return torch.from_numpy((rng.standard_normal(size=shape) * std).astype(np.float32))
+
+
+def synth_state_dict(dims: dict, seed: int = 0) -> dict:
+    rng = np.random.default_rng(seed)
+    D, H, L = dims["d_model"], dims["n_heads"], dims["n_layers"]
+    C, nc, ld, V = dims["n_codebooks"], dims["n_cond"], dims["latent_dim"], dims["vocab"]
+    Cp = C - nc
+    sd = {}
+    sd["embedding.special.MASK"] = _normal(rng, (C, ld))
+    sd["embedding.out_proj.weight"] = _uniform(rng, (D, C * ld, 1), 1.0 / np.sqrt(C * ld))
+    sd["embedding.out_proj.bias"] = _uniform(rng, (D,), 1.0 / np.sqrt(C * ld))
+    for i in range(L):
+        p = f"transformer.layers.{i}."
+        sd[p + "norm_1.weight"] = 1.0 + _uniform(rng, (D,), 0.1)
+        for name in ("w_qs", "w_ks", "w_vs", "fc"):
+            sd[p + f"self_attn.{name}.weight"] = _uniform(rng, (D, D), 1.0 / np.sqrt(D))
+        if i == 0:
+            sd[p + "self_attn.relative_attention_bias.weight"] = _normal(rng, (32, H))
+        sd[p + "norm_3.weight"] = 1.0 + _uniform(rng, (D,), 0.1)
+        sd[p + "feed_forward.w_1.weight"] = _uniform(rng, (4 * D, D), 1.0 / np.sqrt(D))
+        sd[p + "feed_forward.w_2.weight"] = _uniform(rng, (D, 2 * D), 1.0 / np.sqrt(2 * D))
+    sd["transformer.norm.weight"] = 1.0 + _uniform(rng, (D,), 0.1)
+    v = _uniform(rng, (V * Cp, D, 1), 1.0 / np.sqrt(D))
+    sd["classifier.layers.0.weight_v"] = v
+    sd["classifier.layers.0.weight_g"] = (
+        v.norm(dim=(1, 2), keepdim=True) * (1.0 + _uniform(rng, (V * Cp, 1, 1), 0.1)))
+    sd["classifier.layers.0.bias"] = _uniform(rng, (V * Cp,), 1.0 / np.sqrt(D))
+    return sd
+
+
+def synth_codebooks(n_codebooks: int = 14, vocab: int = 1024, latent_dim: int = 8,
+                    seed: int = 1234) -> torch.Tensor:
+    """Stand-in for codec.quantizer.quantizers[i].codebook.weight (reference layers.py:145)."""
+    rng = np.random.default_rng(seed)
+    return _normal(rng, (n_codebooks, vocab, latent_dim))
+
+
+def synth_codes(batch: int, n_codebooks: int = 14, T: int = 575, vocab: int = 1024,
+                seed: int = 7) -> torch.Tensor:
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy(rng.integers(0, vocab, size=(batch, n_codebooks, T), dtype=np.int64))
+
+
+class SynthCodec:
+    """What Interface reads from a codec on the vamp() path when no real DAC checkpoint exists
+    (reference layers.py:145: quantizer.quantizers[i].codebook.weight; interface.py:176-189: hop_length, sample_rate)."""
+
+    class _Q:
+        def __init__(self, w):
+            self.codebook = type("CB", (), {"weight": w})()
+
+    def __init__(self, codebooks, hop_length=768, sample_rate=44100):
+        self.quantizer = type("RVQ", (), {"quantizers": [SynthCodec._Q(codebooks[i]) for i in range(codebooks.shape[0])]})()
+        self.hop_length, self.sample_rate = hop_length, sample_rate
+
+
+def model_kwargs(dims):
+    """dims dict -> VampNet constructor kwargs (reference transformer.py:535-552)."""
+    return dict(n_heads=dims["n_heads"], n_layers=dims["n_layers"], n_codebooks=dims["n_codebooks"],
+                n_conditioning_codebooks=dims["n_cond"], latent_dim=dims["latent_dim"],
+                embedding_dim=dims["d_model"], vocab_size=dims["vocab"])
