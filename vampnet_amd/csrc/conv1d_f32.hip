@@ -209,11 +209,15 @@ extern "C" int vn_conv1d_f32(vn_ctx* ctx, const float* x, const float* w, const 
                    in_stride, dil, pad, out_stride, out_off, act};
     hipStream_t s = (hipStream_t)stream;
     const long M = (long)B * T_rows;
-    if (C_out > 64) {
-        if (vn_cdiv((int)M, 128) * vn_cdiv(C_out, 128) >= 384) return launch_conv<128, 128>(ctx, a, s);
+    // N tile: 128 wastes (128 - C_out % 128) columns of the last tile; 64 fits 64-multiples exactly (C_out = 192: 3 x 64
+    // instead of 128 + a half-empty 128: +25 % useful MFMA work per launched tile)
+    const int pad128 = vn_cdiv(C_out, 128) * 128 - C_out, pad64 = vn_cdiv(C_out, 64) * 64 - C_out;
+    const bool wide = C_out > 64 && pad128 <= pad64;
+    if (wide) {
+        if ((long)vn_cdiv((int)M, 128) * vn_cdiv(C_out, 128) >= 384) return launch_conv<128, 128>(ctx, a, s);
         return launch_conv<64, 128>(ctx, a, s);
     }
-    if (vn_cdiv((int)M, 128) >= 384) return launch_conv<128, 64>(ctx, a, s);
+    if ((long)vn_cdiv((int)M, 128) * vn_cdiv(C_out, 64) >= 384) return launch_conv<128, 64>(ctx, a, s);
     return launch_conv<64, 64>(ctx, a, s);
 }
 
