@@ -408,3 +408,55 @@ def test_interface_vamp_time_stretch_feedback_gpu(tiny, itf):
     mask = itf.build_mask(z, periodic_prompt=3)
     kw = dict(batch_size=2, time_stretch_factor=2, feedback_steps=2, seed=5, _sampling_steps=2)
     assert torch.equal(itf.vamp(z, mask, **kw).cpu(), O.vamp(tiny["models"], z, mask, **kw))
+
+
+def test_full_size_free_running_generate_vs_oracle(eng):
+    """Full-size coarse model (333 M params, T = 575), FREE-RUNNING on the engine's own state for 4 sampling steps with
+    torch's CPU noise stream replayed, compared step by step with the oracle's trajectory.  Pass = identical tokens at
+    every step; if the trajectories ever part, the first divergent decisions must be near-ties of the oracle itself
+    (relative margin < 1e-4: the reference's own fp32 result moves by more between thread counts)."""
+    from vampnet_amd.engine import VampNetModel
+    dims = W.COARSE_DIMS
+    cb, sd = W.synth_codebooks(), W.synth_state_dict(dims, 0)
+    model = VampNetModel(eng, sd, cb, max_batch=1, max_T=575, **model_kwargs(dims))
+    z = W.synth_codes(1, 4, 575, seed=3)
+    mask = O.codebook_mask(O.periodic_mask(z, 7, 1), 3)
+    steps, trace = 4, []
+    O.generate(sd, dims, cb, z, mask, sampling_steps=steps, seed=5, trace=trace)
+    n0 = int(mask.sum())
+    state = z.masked_fill(mask.bool(), 1024)
+    for i, t in enumerate(trace):
+        assert torch.equal(state, t["z_in"])
+        lg = model.forward_codes(state, layout="native")
+        nxt, sampled = model.sample_step(state, lg, i, steps, n0, exp_noise=t["exp"].cuda(), unif_noise=t["unif"].cuda())
+        want = O.codebook_unflatten(t["sampled"], 4)
+        if torch.equal(sampled.cpu(), want) and torch.equal(nxt.cpu(), t["z_out"]):
+            state = nxt.cpu()
+            continue
+        bad = sampled.cpu() != want
+        marg = O.codebook_unflatten(sample_margins(t["logits"], t["exp"], 1.0, True), 4)
+        assert (marg[bad] < 1e-4).all() and bad.sum() <= 2, f"step {i}: divergence outside the near-tie band"
+        pytest.skip(f"trajectories parted at step {i} on an audited near-tie ({int(bad.sum())} token(s))")
+    got = model.generate(start_tokens=z, mask=mask, _sampling_steps=steps, seed=5).cpu()
+    assert torch.equal(got, O.codebook_unflatten(trace[-1]["sampled"], 4))
+
+
+def test_full_size_vamp_vs_oracle(eng):
+    """BASELINE config 1 analogue without the HF checkpoints: the whole Interface.vamp() (12 coarse steps + coarse-to-fine)
+    on the full-size coarse (333 M) and c2f (275 M) models, batch 1, seeded, torch noise replayed: all 14 x 575 tokens
+    equal the oracle's (reference fact 6: the fine codebooks are stochastic but reproducible from the seed)."""
+    from vampnet_amd.interface import Interface
+    cb = W.synth_codebooks()
+    csd, fsd = W.synth_state_dict(W.COARSE_DIMS, 0), W.synth_state_dict(W.C2F_DIMS, 1)
+    itf = Interface.from_state_dicts(SynthCodec(cb), csd, model_kwargs(W.COARSE_DIMS), fsd, model_kwargs(W.C2F_DIMS),
+                                     max_batch=1)
+    z = W.synth_codes(1, 14, 575, seed=2)
+    torch.manual_seed(0)
+    mask = itf.build_mask(z)
+    models = O.OracleModels(csd, W.COARSE_DIMS, fsd, W.C2F_DIMS, cb)
+    for kw in (dict(seed=0), dict(seed=1, sample_cutoff=-1, mask_temperature=0.0)):       # stochastic / greedy coarse stage
+        ref = O.vamp(models, z, mask, batch_size=1, _sampling_steps=12, **kw)
+        got = itf.vamp(z, mask, batch_size=1, _sampling_steps=12, **kw).cpu()
+        same = (got == ref).float().mean().item()
+        print(f"full-size vamp {kw}: token agreement {same:.6f}")
+        assert torch.equal(got, ref)
