@@ -159,7 +159,8 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert out.shape == (B, 14, 575)
+    assert tuple(out.shape) == (B, 14, 575), out.shape   # coarse_vamp also returns all 14 codebooks
+    itf.engine.health_check()
 
     if rank == 0:
         tokens = B * (4 * 575 if args.coarse_only else TOKENS_PER_CLIP) * args.steps
@@ -183,7 +184,7 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
             if os.path.exists(tpath) and world == 1 and args.batch_per_gpu == 8 and not args.coarse_only and args.dtype == "f32":
                 traffic = json.load(open(tpath))["bytes_per_launch"]
-            res["roofline"] = {"bound": "mfma", "kernel": "vn_gemm_f32[_sk]_kernel", "achieved": fl / (ms * 1e-3) / 1e12 if ms else None,
+            res["roofline"] = {"bound": "mfma", "kernel": "vn_gemm_f32[_sk]_kernel" if args.dtype == "f32" else "vn_gemm_f32_kernel<128,128,BF16>", "achieved": fl / (ms * 1e-3) / 1e12 if ms else None,
                                "peak": PEAK_BF16_MFMA_TF if args.dtype == "bf16" else PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
                                "frac": (fl / (ms * 1e-3) / 1e12) / (PEAK_BF16_MFMA_TF if args.dtype == "bf16" else PEAK_F32_MFMA_TF) if ms else None,
                                "traffic": traffic, "algorithmic_bytes_per_launch": gbytes / n if n else None, "launches": int(n), "avg_launch_us": 1e3 * ms / n if n else None,

@@ -216,6 +216,10 @@ int vn_rvq_encode_f32(vn_ctx* ctx, const float* z, const float* win, const float
 int vn_rvq_decode_f32(vn_ctx* ctx, const int64_t* codes, const float* cb, const float* wout, const float* bout,
                       float* zq, int B, int T, int L, int n_levels, int codebook_size, void* stream);
 
+/* Synchronises `stream` and reports whether any stream-K GEMM of this process ever hit its bounded-spin give-up
+ * (results would be wrong): VN_OK or VN_ERR_HIP.  The GEMM never hangs the GPU; this is how a caller finds out.   */
+int vn_health_check(vn_ctx* ctx, void* stream);
+
 /* tuning hook (scripts/gemm_sweep.py): force the GEMM block tile (bm x bn in {128,64}^2; 0,0 = automatic) and the
  * tile walk order (0 column-major, 1 grouped 8-row patches, -1 keep).  Process-global; not for production use.   */
 int vn_debug_gemm_config(int bm, int bn, int order);

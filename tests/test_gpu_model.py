@@ -314,6 +314,7 @@ def test_full_vamp_properties(eng):
     assert torch.equal(out[:, :3][keep[:, :3] == 0], z[:, :3][keep[:, :3] == 0])
     out2 = itf.vamp(z, mask, batch_size=8, _sampling_steps=12, device_seed=1).cpu()
     assert torch.equal(out, out2)
+    itf.engine.health_check()           # no stream-K tile owner ever timed out
 
 
 # ---------------------------------------------------------------------------------------- bf16 fast mode

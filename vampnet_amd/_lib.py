@@ -58,6 +58,7 @@ SYMBOLS = {
     "vn_dac_conv_out_f32": (C.c_int, [_P, _P, _P, C.c_float, _P, C.c_int, C.c_int, C.c_int, _P]),
     "vn_rvq_encode_f32": (C.c_int, [_P] * 8 + [C.c_int] * 5 + [_P]),
     "vn_rvq_decode_f32": (C.c_int, [_P] * 6 + [C.c_int] * 5 + [_P]),
+    "vn_health_check": (C.c_int, [_P, _P]),
     "vn_debug_gemm_config": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "vn_attention_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
 }

@@ -438,6 +438,17 @@ static int sk_workspace(vn_ctx* ctx) {
     return VN_OK;
 }
 
+// stream-K spin-limit indicator (a finisher gave up waiting for a partial-sum slab): 0 = healthy
+extern "C" int vn_health_check(vn_ctx* ctx, void* stream) {
+    if (!ctx) return VN_ERR_INVALID;
+    if (!g_sk_flags) return VN_OK;
+    unsigned w = 0;
+    VN_HIP_CHECK(ctx, hipMemcpyAsync(&w, g_sk_flags + SK_MAX_BLOCKS, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    VN_HIP_CHECK(ctx, hipStreamSynchronize((hipStream_t)stream));
+    if (w) return vn_fail(ctx, VN_ERR_HIP, "stream-K GEMM: a tile owner timed out waiting for a partial-sum slab%s", "");
+    return VN_OK;
+}
+
 template <int BM, int BN, int EPI, bool BF = false>
 static int launch_cfg(vn_ctx* ctx, const vn_gemm_args& a, bool streamk, hipStream_t s) {
     using Cfg = GemmCfg<BM, BN>;

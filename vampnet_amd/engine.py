@@ -53,6 +53,10 @@ class Engine:
     def version(self):
         return self.lib.vn_version().decode()
 
+    def health_check(self):
+        """Synchronise and raise if a stream-K GEMM ever gave up waiting for a partial tile (never expected)."""
+        self.check(self.lib.vn_health_check(self.handle, self.stream()), "vn_health_check")
+
     def profile_begin(self, max_launches=20000):
         self.check(self.lib.vn_profile_begin(self.handle, max_launches), "vn_profile_begin")
 
