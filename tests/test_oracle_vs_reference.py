@@ -170,3 +170,91 @@ def test_vamp_bitwise(tiny, B, kw):
     got, got_mask = O.vamp(models, z, mask, batch_size=B, return_mask=True, **kw)
     assert torch.equal(ref, got)
     assert torch.equal(ref_mask, got_mask)
+
+
+# ----------------------------------------------------------------------------- training step
+def _injected_dropout(model, masks, p):
+    """Replace every nn.Dropout of the reference stack by `x * keep * 1/(1-p)` with the injected keep-mask.
+    Per layer the reference calls: self_attn.dropout (probabilities), layer.dropout (res1), feed_forward.drop,
+    layer.dropout (res2) — transformer.py:250, :347, :82, :367."""
+    import types
+    for i, layer in enumerate(model.transformer.layers):
+        calls = {"n": 0}
+
+        def attn_drop(self, x, i=i):
+            return x * masks[(i, "attn")] * (1.0 / (1.0 - p))
+
+        def ffn_drop(self, x, i=i):
+            return x * masks[(i, "ffn")] * (1.0 / (1.0 - p))
+
+        def res_drop(self, x, i=i, calls=calls):
+            site = "res1" if calls["n"] % 2 == 0 else "res2"
+            calls["n"] += 1
+            return x * masks[(i, site)] * (1.0 / (1.0 - p))
+
+        layer.self_attn.dropout.forward = types.MethodType(attn_drop, layer.self_attn.dropout)
+        layer.feed_forward.drop.forward = types.MethodType(ffn_drop, layer.feed_forward.drop)
+        layer.dropout.forward = types.MethodType(res_drop, layer.dropout)
+
+
+@pytest.mark.parametrize("which,p", [("coarse", 0.1), ("c2f", 0.1), ("coarse", 0.0)])
+def test_train_step_vs_reference(ns, tiny, which, p):
+    """scripts/exp/train.py:237-304 restated: loss, every gradient, grad norm and the AdamW/Noam update are checked
+    against the reference's modules driven by torch.optim.AdamW + clip_grad_norm_ + vampnet.scheduler.NoamScheduler."""
+    import importlib
+    from oracle import train_oracle as TO
+    sched_mod = importlib.import_module("vampnet.scheduler")
+    dims = W.TINY_COARSE_DIMS if which == "coarse" else W.TINY_C2F_DIMS
+    sd = tiny["csd"] if which == "coarse" else tiny["fsd"]
+    model = ref_shim.build_reference_model(ns, dims, sd)
+    model.train()
+    B, T = 2, 24
+    z = W.synth_codes(B, dims["n_codebooks"], T, seed=5)
+    g = torch.Generator().manual_seed(3)
+    r = torch.tensor([0.3, 0.8])
+    mask = TO.make_training_mask(z, r, dims["n_cond"], generator=g)
+    # the reference's own mask pipeline on the same generator state gives the same mask (mask.py:40-54)
+    torch.manual_seed(9)
+    m_ref = ns.mask.codebook_unmask(ns.mask.random(z, r), dims["n_cond"])
+    torch.manual_seed(9)
+    assert torch.equal(m_ref, TO.make_training_mask(z, r, dims["n_cond"]))
+    masks = TO.draw_dropout_masks(dims, B, T, p, torch.Generator().manual_seed(4)) if p > 0 else None
+    if masks is not None:
+        _injected_dropout(model, masks, p)
+    else:
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    sched = sched_mod.NoamScheduler(opt, d_model=dims["d_model"], factor=2.0, warmup=10000)
+    sched.step()                                                      # train.py:655-ish: lr is set before the first step
+    state = {}
+    cur = {k: v.clone() for k, v in sd.items()}
+    for it in range(2):
+        z_mask, mk = ns.mask.apply_mask(z, mask, model.mask_token)
+        lat = model.embedding.from_codes(z_mask, tiny["codec"])
+        z_hat = model(lat)
+        target = ns.util.codebook_flatten(z[:, dims["n_cond"]:, :])
+        flat_mask = ns.util.codebook_flatten(mk[:, dims["n_cond"]:, :])
+        t_masked = target.masked_fill(~flat_mask.bool(), -100)
+        loss_ref = torch.nn.CrossEntropyLoss(label_smoothing=0.1)(z_hat, t_masked)
+        loss_ref.backward()
+        gref = {k: v.grad.clone() for k, v in model.named_parameters()}
+        norm_ref = torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+
+        loss, grads, logits = TO.loss_and_grads(cur, dims, tiny["cb"], z, mask, masks, p)
+        assert torch.equal(logits, z_hat.detach())
+        assert torch.equal(loss, loss_ref.detach())
+        assert set(grads) == set(gref)
+        for k in gref:
+            assert torch.equal(grads[k], gref[k]), k
+        lr = TO.noam_lr(it + 1, dims["d_model"])
+        assert lr == opt.param_groups[0]["lr"]
+        cur, norm = TO.clip_and_adamw(cur, grads, state, lr)
+        opt.step()
+        opt.zero_grad()
+        sched.step()
+        torch.testing.assert_close(norm, norm_ref, rtol=1e-6, atol=0)
+        for k, v in model.state_dict().items():
+            torch.testing.assert_close(cur[k], v, rtol=1e-6, atol=1e-9, msg=k)
