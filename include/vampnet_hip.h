@@ -220,6 +220,56 @@ int vn_rvq_decode_f32(vn_ctx* ctx, const int64_t* codes, const float* cb, const 
  * (results would be wrong): VN_OK or VN_ERR_HIP.  The GEMM never hangs the GPU; this is how a caller finds out.   */
 int vn_health_check(vn_ctx* ctx, void* stream);
 
+/* ---- training step ----------------------------------------------
+ * Replaces scripts/exp/train.py:237-304 (`train_loop`) after the codec/masking front end: VampNet.forward in train()
+ * mode (dropout at transformer.py:82, :250, :347, :367), CrossEntropyLoss(label_smoothing) over the masked targets
+ * (train.py:267-278), backward, clip_grad_norm_ (train.py:296-298), torch.optim.AdamW (train.py:299) with the learning
+ * rate of vampnet/scheduler.py:38-46 supplied by the host.  fp32 (conf/vampnet.yml:15 amp: false).
+ *
+ * Train vector = [ packed inference blob (vn_weights_size floats) | classifier weight_g | classifier weight_v ]
+ * (vn_train_param_size floats; vn_train_param_offset(which = 0: g, 1: v), rows in the packed (c, p) order of VN_W_CLS_W).
+ * Parameters, gradients and the two Adam moments are four caller-owned device buffers of that layout, so a data-parallel
+ * job all-reduces the gradient buffer between vn_train_forward_backward and vn_train_update (world_size = number of
+ * summed ranks).  Trainable: everything VampNet owns (all Linear/Conv weights incl. the shared relative-position table,
+ * norms, embedding.special.MASK); NOT the codec codebook rows inside VN_W_EMB_TABLES.  (With the real loralib the five
+ * LoRA'd linears would be frozen and only lora_A/B trained; loralib is absent from the reference tree, see DESIGN.md.) */
+typedef struct vn_train vn_train;
+typedef struct {
+    float lr, beta1, beta2, eps, weight_decay;  /* AdamW (torch defaults 1e-3, 0.9, 0.999, 1e-8, 1e-2)              */
+    float grad_clip;                            /* clip_grad_norm_ max norm; <= 0 disables (conf/vampnet.yml: 5.0)  */
+    float label_smoothing;                      /* conf/vampnet.yml:17  0.1                                         */
+    float dropout;                              /* conf/vampnet.yml:33  0.1; 0 = off                                */
+    uint64_t seed;                              /* dropout stream (counter based: independent of batch sharding)    */
+    int64_t step;                               /* optimiser step t >= 1: Adam bias correction + dropout stream     */
+    int64_t batch_offset;                       /* global index of this rank's first batch item (dropout stream)    */
+    int32_t world_size;                         /* gradient buffer holds the SUM over this many ranks (mean = / ws) */
+} vn_train_params;
+
+int  vn_train_param_size(const vn_dims* dims, int64_t* n_floats);
+int  vn_train_param_offset(const vn_dims* dims, int which, int64_t* offset, int64_t* count);
+/* `params`: the train vector in device memory; the model must have been created on its prefix (params == blob_dev).
+ * Allocates the activation stash for the model's max_batch x max_T; no allocation happens inside a step.           */
+int  vn_train_create(vn_model* model, float* params, vn_train** out);
+void vn_train_destroy(vn_train* tr);
+/* Re-derives what depends on the parameters (folded classifier weight, transposed GEMM weights, bias table).  Call once
+ * after filling `params` and after any external change to it; vn_train_update calls it itself.                      */
+int  vn_train_sync(vn_train* tr, void* stream);
+/* z_masked dev int64 [B][C][T] (MASK = vocab where masked), target dev int64 [B][T*Cp] in the reference's
+ * codebook_flatten order ("b c t -> b (t c)", util.py:35-40) with -100 = ignore (train.py:68).  Overwrites `grads`
+ * (train vector layout) with d(loss)/d(param) and *loss_dev with the mean loss over the valid targets of THIS call.   */
+int  vn_train_forward_backward(vn_train* tr, const int64_t* z_masked, const int64_t* target, int B, int T,
+                               const vn_train_params* p, float* grads, float* loss_dev, void* stream);
+/* train()-mode forward only; logits dev f32 [B][T][Cp][vocab] (parity tests / validation with dropout = 0)          */
+int  vn_train_forward(vn_train* tr, const int64_t* z_masked, int B, int T, const vn_train_params* p, float* logits,
+                      void* stream);
+/* *grad_norm_dev = || grads / world_size ||_2 ; clip ; AdamW on every trainable element ; vn_train_sync.             */
+int  vn_train_update(vn_train* tr, const float* grads, float* adam_m, float* adam_v, const vn_train_params* p,
+                     float* grad_norm_dev, void* stream);
+/* The keep-mask the kernels use at one dropout site (site 0: attention probabilities, rows = (b, h, query), cols = keys;
+ * 1: attention residual, 2: GEGLU output, 3: FFN residual; rows = (b, t)); out dev u8 [rows][cols].  For parity tests. */
+int  vn_dropout_keep_mask(vn_ctx* ctx, uint64_t seed, int64_t step, int layer, int site, float p, int64_t row0,
+                          int64_t rows, int cols, uint8_t* out, void* stream);
+
 /* tuning hook (scripts/gemm_sweep.py): force the GEMM block tile (bm x bn in {128,64}^2; 0,0 = automatic) and the
  * tile walk order (0 column-major, 1 grouped 8-row patches, -1 keep).  Process-global; not for production use.   */
 int vn_debug_gemm_config(int bm, int bn, int order);

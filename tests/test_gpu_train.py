@@ -1,0 +1,219 @@
+"""`-m gpu` parity tests of the TRAINING step (BASELINE config #5): the HIP engine's
+forward-with-dropout / cross-entropy / backward / clip + AdamW against oracle/train_oracle.py (torch CPU fp32 autograd,
+itself pinned bitwise to the reference's modules by tests/test_oracle_vs_reference.py::test_train_step_vs_reference).
+
+Dropout: the engine's counter-based keep-masks are read back through the C ABI (vn_dropout_keep_mask) and INJECTED into
+the oracle, so both sides see the same noise.  Tolerances (fp32, different summation orders; stated per assert):
+logits 2e-5 abs, loss 1e-5 rel, every gradient tensor 1e-4 of its own max-abs, updated parameters: see _check_update."""
+import pytest
+import torch
+
+from oracle import train_oracle as TO, vampnet_oracle as O, weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from vampnet_amd.engine import Engine
+    return Engine("cuda:0")
+
+
+def _trainer(engine, dims, sd, cb, **kw):
+    from vampnet_amd.train import Trainer
+    from vampnet_amd.synth import model_kwargs
+    return Trainer(engine, sd, cb, **model_kwargs(dims), **kw)
+
+
+def _masks_from_device(tr, dims, B, T, step, p):
+    if p == 0:
+        return None
+    out = {}
+    for l in range(dims["n_layers"]):
+        for site in TO.DROPOUT_SITES:
+            out[(l, site)] = tr.dropout_keep_mask(l, site, B, T, step=step, p=p).cpu()
+    return out
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _check_update(new, ref, lr):
+    """Adam's first steps move every element by ~lr * sign(g): an element whose gradient is ~0 can legitimately flip
+    (|delta| up to 2 lr) when g differs in the last bits, so: all elements within 2.1 lr, 99.9 % within 0.02 lr."""
+    tot = bad = 0
+    for k, v in ref.items():
+        d = (new[k].reshape(v.shape) - v).abs()
+        assert d.max().item() <= 2.1 * lr + 1e-7, (k, d.max().item())
+        tot += d.numel()
+        bad += int((d > 0.02 * lr + 1e-7).sum())
+    assert bad <= 1e-3 * tot, (bad, tot)
+
+
+def _check_norm(norm, norm_o, grads_o):
+    """The engine reduces the squared norm in double; torch's fp32 vector_norm (what clip_grad_norm_ uses) is itself only
+    good to ~4e-4 on the 2.6 M-element classifier gradient, so: 1e-5 against the double norm, 1e-3 against torch's."""
+    exact = torch.sqrt(sum(g.double().pow(2).sum() for g in grads_o.values())).item()
+    assert abs(norm.item() - exact) < 1e-5 * exact, (norm.item(), exact)
+    assert abs(norm.item() - norm_o.item()) < 1e-3 * norm_o.item()
+
+
+CASES = [
+    ("coarse", 2, 40, 0.1),
+    ("coarse", 3, 37, 0.0),      # ragged T (not a multiple of anything), no dropout
+    ("c2f", 2, 33, 0.1),         # conditioning codebooks: targets only on the 10 predicted ones
+]
+
+
+@pytest.mark.parametrize("which,B,T,p", CASES)
+def test_train_step_vs_oracle(engine, which, B, T, p):
+    dims = W.TINY_COARSE_DIMS if which == "coarse" else W.TINY_C2F_DIMS
+    sd = W.synth_state_dict(dims, 0 if which == "coarse" else 1)
+    # give the LoRA-free synthetic weights a non-trivial MASK row / bias table gradient path
+    cb = W.synth_codebooks()
+    tr = _trainer(engine, dims, sd, cb, max_batch=B, max_T=T, dropout=p, seed=11, use_noam=False, lr=1e-3)
+    z = W.synth_codes(B, dims["n_codebooks"], T, seed=5)
+    r = torch.linspace(0.2, 0.9, B)
+    mask = TO.make_training_mask(z, r, dims["n_cond"], generator=torch.Generator().manual_seed(3))
+    z_mask, target = tr.make_batch(z, mask=mask)
+
+    cur = {k: v.clone() for k, v in sd.items()}
+    state = {}
+    for it in range(2):
+        step = it + 1
+        masks = _masks_from_device(tr, dims, B, T, step, p)
+        if masks is not None and it == 0:
+            keep = torch.cat([m.flatten() for m in masks.values()]).mean().item()
+            assert abs(keep - (1 - p)) < 5e-3, keep                   # Bernoulli(1-p) keep rate
+        loss_o, grads_o, logits_o = TO.loss_and_grads(cur, dims, cb, z, mask, masks, p)
+
+        logits = tr.forward(z_mask, step=step).cpu()
+        lerr = (logits - logits_o).abs().max().item()
+        print(f'logits max abs err {lerr:.2e}')
+        assert lerr < 2e-5
+        loss = tr.forward_backward(z_mask, target, step=step).cpu()
+        assert abs(loss.item() - loss_o.item()) < 1e-5 * abs(loss_o.item())
+        grads = tr.export(tr.grads)
+        worst = 0.0
+        for k, g_o in grads_o.items():
+            g = grads[k].reshape(g_o.shape)
+            e = _rel(g, g_o) if g_o.abs().max() > 0 else float(g.abs().max())
+            worst = max(worst, e)
+            assert e < 1e-4, (k, e)
+        print(f"{which} step {step}: loss {loss.item():.6f} (oracle {loss_o.item():.6f}), worst grad rel err {worst:.2e}")
+
+        cur, norm_o = TO.clip_and_adamw(cur, grads_o, state, 1e-3)
+        norm = tr.update().cpu()
+        _check_norm(norm, norm_o, grads_o)
+        new = tr.state_dict()
+        _check_update(new, cur, 1e-3)
+        cur = {k: new[k].reshape(v.shape).clone() for k, v in cur.items()}   # next step: same parameters on both sides
+    engine.health_check()
+
+
+def test_codec_codebooks_are_not_trained(engine):
+    """The codec's codebook rows inside VN_W_EMB_TABLES are not VampNet parameters (train.py:257): untouched by updates,
+    no weight decay; only the MASK rows move."""
+    from vampnet_amd import _lib
+    dims = W.TINY_COARSE_DIMS
+    sd, cb = W.synth_state_dict(dims, 0), W.synth_codebooks()
+    tr = _trainer(engine, dims, sd, cb, max_batch=2, max_T=24, dropout=0.1)
+    before = tr._tensor(tr.params, _lib.W_EMB_TABLES).clone()
+    z = W.synth_codes(2, 4, 24, seed=1)
+    for _ in range(3):
+        tr.step(z, r=torch.tensor([0.5, 0.7]))
+    after = tr._tensor(tr.params, _lib.W_EMB_TABLES)
+    V, ld = dims["vocab"], dims["latent_dim"]
+    b, a = before.view(4, V + 1, ld), after.view(4, V + 1, ld)
+    assert torch.equal(b[:, :V], a[:, :V])
+    assert not torch.equal(b[:, V], a[:, V])
+
+
+def test_overfit_fixed_batch(engine):
+    """Loss on a fixed batch goes down under the reference's optimiser settings (sanity of the whole loop), and the
+    inference path (generate/forward on the same blob) sees the updated weights."""
+    dims = W.TINY_COARSE_DIMS
+    sd, cb = W.synth_state_dict(dims, 0), W.synth_codebooks()
+    tr = _trainer(engine, dims, sd, cb, max_batch=4, max_T=48, dropout=0.0, use_noam=False, lr=1e-3)
+    z = W.synth_codes(4, 4, 48, seed=2)
+    mask = TO.make_training_mask(z, torch.full((4,), 0.6), 0, generator=torch.Generator().manual_seed(1))
+    z_mask, target = tr.make_batch(z, mask=mask)
+    l0_logits = tr.model.forward_codes(z_mask).clone()
+    losses = []
+    for _ in range(30):
+        tr.forward_backward(z_mask, target)
+        losses.append(tr.loss.item())
+        tr.update()
+    assert losses[-1] < 0.7 * losses[0], losses[::5]
+    # eval-mode forward == train-mode forward with p = 0, on the updated parameters
+    ev = tr.model.forward_codes(z_mask)
+    tv = tr.forward(z_mask)
+    assert (ev - tv).abs().max().item() < 2e-5
+    assert (ev - l0_logits).abs().max().item() > 1e-3
+    # and equals the oracle run on the exported state_dict
+    new = tr.state_dict()
+    lo = O.forward(new, dims, O.from_codes(new, cb, z_mask.cpu()))
+    assert (ev.cpu() - lo).abs().max().item() < 5e-5
+
+
+def test_train_step_is_deterministic_and_shard_invariant(engine):
+    """Same inputs, same step -> bitwise same loss; the dropout stream is indexed by GLOBAL batch item, so item 1 of a
+    batch draws the mask a rank holding only that item (batch_offset = 1) draws."""
+    dims = W.TINY_COARSE_DIMS
+    sd, cb = W.synth_state_dict(dims, 0), W.synth_codebooks()
+    tr = _trainer(engine, dims, sd, cb, max_batch=2, max_T=32, dropout=0.1, seed=5)
+    z = W.synth_codes(2, 4, 32, seed=9)
+    mask = TO.make_training_mask(z, torch.tensor([0.4, 0.8]), 0, generator=torch.Generator().manual_seed(2))
+    z_mask, target = tr.make_batch(z, mask=mask)
+    a = tr.forward_backward(z_mask, target).clone()
+    ga = tr.grads.clone()
+    b = tr.forward_backward(z_mask, target).clone()
+    assert torch.equal(a, b)
+    # every gradient except the atomically-accumulated relative-position table is bitwise reproducible
+    from vampnet_amd import _lib
+    rb = tr._tensor(tr.grads, _lib.W_REL_BIAS)
+    rb_a = tr._tensor(ga, _lib.W_REL_BIAS)
+    assert (rb - rb_a).abs().max().item() <= 1e-5 * rb_a.abs().max().item()
+    rb.copy_(rb_a)
+    assert torch.equal(ga, tr.grads)
+    full = tr.dropout_keep_mask(1, "attn", 2, 32)
+    tr2 = _trainer(engine, dims, sd, cb, max_batch=1, max_T=32, dropout=0.1, seed=5, batch_offset=1)
+    part = tr2.dropout_keep_mask(1, "attn", 1, 32)
+    assert torch.equal(full[:, 1:2], part)
+
+
+@pytest.mark.parametrize("which", ["coarse", "c2f"])
+def test_full_size_train_step_vs_oracle(engine, which):
+    """Full-size models (333 M / 275 M parameters), one sequence, no dropout: loss and every gradient against CPU
+    autograd; then one clipped AdamW update."""
+    dims = W.COARSE_DIMS if which == "coarse" else W.C2F_DIMS
+    T = 575 if which == "coarse" else 173
+    sd = W.synth_state_dict(dims, 0 if which == "coarse" else 1)
+    cb = W.synth_codebooks()
+    tr = _trainer(engine, dims, sd, cb, max_batch=1, max_T=T, dropout=0.0)
+    z = W.synth_codes(1, dims["n_codebooks"], T, seed=4)
+    mask = TO.make_training_mask(z, torch.tensor([0.7]), dims["n_cond"], generator=torch.Generator().manual_seed(6))
+    z_mask, target = tr.make_batch(z, mask=mask)
+    loss = tr.forward_backward(z_mask, target).cpu()
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    loss_o, grads_o, _ = TO.loss_and_grads(sd, dims, cb, z, mask, None, 0.0)
+    assert abs(loss.item() - loss_o.item()) < 1e-5 * abs(loss_o.item())
+    grads = tr.export(tr.grads)
+    worst = ("", 0.0)
+    for k, g_o in grads_o.items():
+        e = _rel(grads[k].reshape(g_o.shape), g_o)
+        if e > worst[1]:
+            worst = (k, e)
+        assert e < 2e-4, (k, e)
+    print(f"{which} full size: loss {loss.item():.6f}, worst grad rel err {worst[1]:.2e} at {worst[0]}")
+    state = {}
+    lr = TO.noam_lr(1, dims["d_model"])                  # conf/vampnet.yml:21-22 -> 5.6e-8 at step 1
+    new_o, norm_o = TO.clip_and_adamw(sd, grads_o, state, lr)
+    norm = tr.update().cpu()
+    assert tr.last_lr == lr and tr.steps == 1
+    _check_norm(norm, norm_o, grads_o)
+    new = tr.state_dict()
+    for k, v in new_o.items():                            # at this lr the step is below fp32 resolution of most weights
+        assert (new[k].reshape(v.shape) - v).abs().max().item() < 2e-7, k
+    engine.health_check()

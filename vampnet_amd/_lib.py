@@ -25,6 +25,13 @@ class vn_sample_params(C.Structure):
                 ("global_batch", C.c_int32)]
 
 
+class vn_train_params(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("grad_clip", C.c_float), ("label_smoothing", C.c_float),
+                ("dropout", C.c_float), ("seed", C.c_uint64), ("step", C.c_int64), ("batch_offset", C.c_int64),
+                ("world_size", C.c_int32)]
+
+
 # tensor ids of the packed weight blob (enum in vampnet_hip.h)
 (W_EMB_TABLES, W_EMB_WT, W_EMB_B, W_REL_BIAS, W_FINAL_NORM, W_CLS_W, W_CLS_B,
  W_NORM1, W_QKV, W_WO, W_NORM3, W_W1, W_W2) = range(13)
@@ -59,6 +66,16 @@ SYMBOLS = {
     "vn_rvq_encode_f32": (C.c_int, [_P] * 8 + [C.c_int] * 5 + [_P]),
     "vn_rvq_decode_f32": (C.c_int, [_P] * 6 + [C.c_int] * 5 + [_P]),
     "vn_health_check": (C.c_int, [_P, _P]),
+    "vn_train_param_size": (C.c_int, [C.POINTER(vn_dims), C.POINTER(C.c_int64)]),
+    "vn_train_param_offset": (C.c_int, [C.POINTER(vn_dims), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "vn_train_create": (C.c_int, [_P, _P, C.POINTER(_P)]),
+    "vn_train_destroy": (None, [_P]),
+    "vn_train_sync": (C.c_int, [_P, _P]),
+    "vn_train_forward_backward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(vn_train_params), _P, _P, _P]),
+    "vn_train_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(vn_train_params), _P, _P]),
+    "vn_train_update": (C.c_int, [_P, _P, _P, _P, C.POINTER(vn_train_params), _P, _P]),
+    "vn_dropout_keep_mask": (C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int64, C.c_int64,
+                                       C.c_int, _P, _P]),
     "vn_debug_gemm_config": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "vn_attention_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
 }

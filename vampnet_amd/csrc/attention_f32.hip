@@ -27,18 +27,6 @@
 #define ATT_KT 64        // keys per tile
 #define ATT_LD 68        // padded LDS row (floats)
 
-// exp(x) for x <= 0 with fp32-level accuracy at a third of ocml expf's instruction count: x*log2(e) is split into a
-// rounded product and its exact fma remainder (plus the constant's low part), v_exp_f32 evaluates 2^hi (1 ulp) and the
-// remainder is applied to first order (|lo| < 2^-22, so the dropped term is < 2^-45 relative).
-__device__ __forceinline__ float vn_exp_neg(float x) {
-    x = fmaxf(x, -104.0f);                                     // -inf (masked key / first tile) -> exp2(-150) = 0, no NaN
-    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f;
-    const float hi = x * L2E_HI;
-    const float lo = fmaf(x, L2E_HI, -hi) + x * L2E_LO;
-    const float e = __builtin_amdgcn_exp2f(hi);               // v_exp_f32; exp2(-inf) = 0, flushes below 2^-126
-    return fmaf(e, lo * 0.693147182464599609375f, e);
-}
-
 template <int VARIANT>
 __global__ __launch_bounds__(256) void vn_attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                            const float* __restrict__ v,

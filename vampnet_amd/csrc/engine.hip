@@ -5,24 +5,9 @@
 #include <new>
 #include <vector>
 #include "vn_common.h"
+#include "vn_model.h"
 
 #define VN_MAX_STEPS 256
-
-struct vn_model {
-    vn_ctx* ctx;
-    vn_dims d;
-    const float* blob;
-    int Cp, D, H, L;
-    // workspace (device)
-    float *x, *y, *qkv, *g, *logits, *bias_full, *psel;
-    int32_t *z, *z_sampled, *sampled, *count, *lut;
-    int64_t* ksched;         // device [max_steps][max_batch] per-item mask schedule of the running generate()
-    // bf16 fast mode (vn_model_set_bf16): bf16 image of the weight blob (same element offsets) + bf16 GEMM A operands
-    const uint16_t* blob16;
-    uint16_t *y16, *g16;
-    int bias_T;              // T the expanded bias table is currently built for (-1 = none)
-    long max_rows;
-};
 
 static int dims_check(vn_ctx* ctx, const vn_dims* d) {
     if (!d) return vn_fail(ctx, VN_ERR_INVALID, "dims is NULL%s", "");
@@ -39,7 +24,7 @@ static int dims_check(vn_ctx* ctx, const vn_dims* d) {
 }
 
 // ---- weight blob layout ----------------------------------------------------------------------
-static long tensor_count(const vn_dims* d, int id) {
+long vn_tensor_count(const vn_dims* d, int id) {
     const long D = d->d_model, C = d->n_codebooks, Cp = C - d->n_cond, V = d->vocab, ld = d->latent_dim;
     switch (id) {
         case VN_W_EMB_TABLES: return C * (V + 1) * ld;
@@ -60,18 +45,18 @@ static long tensor_count(const vn_dims* d, int id) {
 }
 static long align64(long n) { return (n + 63) & ~63L; }   // 256-byte aligned tensors
 
-static long tensor_offset(const vn_dims* d, int id, int layer) {
+long vn_tensor_offset(const vn_dims* d, int id, int layer) {
     long off = 0;
     for (int t = VN_W_EMB_TABLES; t <= VN_W_CLS_B; ++t) {
         if (t == id) return off;
-        off += align64(tensor_count(d, t));
+        off += align64(vn_tensor_count(d, t));
     }
     long per_layer = 0;
-    for (int t = VN_W_NORM1; t <= VN_W_W2; ++t) per_layer += align64(tensor_count(d, t));
+    for (int t = VN_W_NORM1; t <= VN_W_W2; ++t) per_layer += align64(vn_tensor_count(d, t));
     off += per_layer * layer;
     for (int t = VN_W_NORM1; t <= VN_W_W2; ++t) {
         if (t == id) return off;
-        off += align64(tensor_count(d, t));
+        off += align64(vn_tensor_count(d, t));
     }
     return -1;
 }
@@ -79,7 +64,7 @@ static long tensor_offset(const vn_dims* d, int id, int layer) {
 extern "C" int vn_weights_size(const vn_dims* dims, int64_t* n_floats) {
     if (!dims || !n_floats) return VN_ERR_INVALID;
     if (dims_check(nullptr, dims) != VN_OK) return VN_ERR_INVALID;
-    *n_floats = tensor_offset(dims, VN_W_NORM1, dims->n_layers);
+    *n_floats = vn_tensor_offset(dims, VN_W_NORM1, dims->n_layers);
     return VN_OK;
 }
 
@@ -88,12 +73,12 @@ extern "C" int vn_weights_offset(const vn_dims* dims, int tensor_id, int layer, 
     if (dims_check(nullptr, dims) != VN_OK) return VN_ERR_INVALID;
     const bool per_layer = tensor_id >= VN_W_NORM1;
     if (per_layer && (layer < 0 || layer >= dims->n_layers)) return VN_ERR_INVALID;
-    *offset = tensor_offset(dims, tensor_id, per_layer ? layer : 0);
-    *count = tensor_count(dims, tensor_id);
+    *offset = vn_tensor_offset(dims, tensor_id, per_layer ? layer : 0);
+    *count = vn_tensor_count(dims, tensor_id);
     return VN_OK;
 }
 
-static const float* W(const vn_model* m, int id, int layer = 0) { return m->blob + tensor_offset(&m->d, id, layer); }
+static const float* W(const vn_model* m, int id, int layer = 0) { return m->blob + vn_tensor_offset(&m->d, id, layer); }
 
 // ---- context ---------------------------------------------------------------------------------
 extern "C" const char* vn_version(void) { return "vampnet_hip 0.1 gfx950 f32-mfma"; }
@@ -219,7 +204,7 @@ extern "C" int vn_model_create(vn_ctx* ctx, const vn_dims* dims, const float* bl
     return VN_OK;
 }
 
-static int ensure_bias(vn_model* m, int T, hipStream_t s) {
+int vn_model_ensure_bias(vn_model* m, int T, hipStream_t s) {
     if (m->bias_T == T) return VN_OK;
     std::vector<int32_t> lut(2 * T - 1);
     vn_bucket_lut_host(T, m->d.num_buckets, m->d.max_distance, lut.data());
@@ -236,7 +221,7 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
     vn_ctx* ctx = m->ctx;
     const int D = m->D, H = m->H, M = B * T;
     int rc;
-    if ((rc = ensure_bias(m, T, s))) return rc;
+    if ((rc = vn_model_ensure_bias(m, T, s))) return rc;
     if ((rc = vn_launch_embed(ctx, z, W(m, VN_W_EMB_TABLES), W(m, VN_W_EMB_WT), W(m, VN_W_EMB_B), m->x, B,
                               m->d.n_codebooks, T, m->d.vocab + 1, m->d.latent_dim, D, s)))
         return rc;
@@ -244,7 +229,7 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
     const bool bf = m->blob16 != nullptr;
     // bf16 fast mode: the four big GEMM operands (normalised rows, attention output, GEGLU output, weights) are bf16,
     // accumulation / residual stream / attention / norms / logits stay fp32.  NOT bit-exact.
-    auto W16 = [&](int id, int layer) { return (const float*)(m->blob16 + tensor_offset(&m->d, id, layer)); };
+    auto W16 = [&](int id, int layer) { return (const float*)(m->blob16 + vn_tensor_offset(&m->d, id, layer)); };
     for (int l = 0; l < m->L; ++l) {
         // y = RMSNorm(x) ; FiLM = identity (d_cond = 0, transformer.py:554)
         if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM1, l), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr))) return rc;

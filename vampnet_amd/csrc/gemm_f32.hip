@@ -59,13 +59,6 @@ struct GemmCfg {
     static constexpr int SLAB_FLOATS = BM * BN;   // stream-K partial-sum slab per block
 };
 
-__device__ __forceinline__ float vn_gelu_tanh(float x) {
-    // activations.py:16-26: 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))
-    const float c = 0.7978845608028654f;
-    float x3 = x * x * x;
-    return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x3)));
-}
-
 // XCD-aware bijective remap of a linear block id (guide §5: "XCD swizzle must be bijective")
 __device__ __forceinline__ int vn_xcd_remap(int bid, int nwg) {
     const int xcd = bid & 7, idx = bid >> 3;

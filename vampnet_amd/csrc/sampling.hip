@@ -12,18 +12,6 @@
 // caller's business: it offsets `row0`).
 #include "vn_common.h"
 
-__device__ __forceinline__ uint4 vn_philox4x32_10(uint4 c, uint2 k) {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
-        const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
-        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-        k.x += W0;
-        k.y += W1;
-    }
-    return c;
-}
 __device__ __forceinline__ float vn_u01_open(uint32_t x) {   // (0, 1]
     return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
 }

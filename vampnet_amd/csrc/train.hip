@@ -1,0 +1,371 @@
+// Host side of the VampNet TRAINING step (scripts/exp/train.py:237-304, conf/vampnet.yml) for gfx950:
+// activation stash, kernel schedule of forward-with-dropout / cross-entropy / backward / clip + AdamW, and the
+// extern "C" entry points (include/vampnet_hip.h, "training" section).  Everything is enqueued on the caller's
+// stream; there is no host<->device synchronisation inside a step (loss, gradient norm and the valid-target count
+// stay on the device).
+//
+// Parameter vector ("train vector"): [ packed inference blob | classifier weight_g | classifier weight_v ].
+// The blob's VN_W_CLS_W region is DERIVED (g * v / ||v||, re-folded after every update); its slot in the gradient
+// vector is scratch for dW and is zeroed before the norm.  Gradients, Adam moments and parameters share the layout,
+// so the optimiser is element-wise and a data-parallel job all-reduces one flat buffer (or per-stage slices of it).
+//
+// Every linear y = x W^T needs dX = dY W and dW = dY^T X.  The one GEMM kernel (gemm_f32.hip) computes A B^T with both
+// operands contiguous along the contraction axis, so
+//   dX: A = dY [M][N], B = W^T [K][N]     -> W^T copies of all GEMM weights, refreshed once per update (vn_train_sync)
+//   dW: A = dY^T [N][Mp], B = X^T [K][Mp] -> 64x64 LDS transposes of the two activations, Mp = M rounded up to 32 (zero
+//                                            filled), ~4 % of a step's time.
+#include <new>
+#include <vector>
+#include "vn_common.h"
+#include "vn_model.h"
+#include "vn_train.h"
+
+enum { SITE_ATTN = 0, SITE_RES1 = 1, SITE_FFN = 2, SITE_RES2 = 3 };
+
+struct vn_layer_stash {
+    float *x_in, *y1, *qkv, *lse, *a, *x_mid, *y3, *u, *g;
+};
+
+struct vn_train {
+    vn_model* m;
+    float* params;                 // train vector (caller owned); params == m->blob
+    long wsize, n_total, off_g, off_v;
+    int NV;                        // classifier rows = Cp * vocab
+    long Mp_max;
+    // transposed GEMM weights
+    float* wT;                     // [L][qkvT | woT | w1T | w2T] then clsT
+    long wT_layer, wT_cls;
+    std::vector<vn_layer_stash> st;
+    float *x_last, *y_f;           // X[L], final-norm output
+    // scratch
+    float *tmp, *dxa, *dxb, *dh, *dg, *du, *dy, *dqkv, *da, *At, *Bt, *partial, *row_loss, *delta, *scal;
+    double* npartial;
+    int32_t *t32, *n_valid;
+    int B, T;                      // shape of the stashed forward (0 = none)
+};
+
+static long al64(long n) { return (n + 63) & ~63L; }
+
+extern "C" int vn_train_param_size(const vn_dims* dims, int64_t* n_floats) {
+    int64_t w = 0;
+    int rc = vn_weights_size(dims, &w);
+    if (rc) return rc;
+    const long NV = (long)(dims->n_codebooks - dims->n_cond) * dims->vocab;
+    *n_floats = w + al64(NV) + al64(NV * dims->d_model);
+    return VN_OK;
+}
+
+extern "C" int vn_train_param_offset(const vn_dims* dims, int which, int64_t* offset, int64_t* count) {
+    int64_t w = 0;
+    int rc = vn_weights_size(dims, &w);
+    if (rc) return rc;
+    if (!offset || !count) return VN_ERR_INVALID;
+    const long NV = (long)(dims->n_codebooks - dims->n_cond) * dims->vocab;
+    if (which == 0) { *offset = w; *count = NV; return VN_OK; }
+    if (which == 1) { *offset = w + al64(NV); *count = NV * dims->d_model; return VN_OK; }
+    return VN_ERR_INVALID;
+}
+
+template <typename T>
+static int talloc(vn_ctx* ctx, T** p, size_t n) {
+    void* q = nullptr;
+    if (hipMalloc(&q, n * sizeof(T) + 256) != hipSuccess) {
+        vn_fail(ctx, VN_ERR_OOM, "hipMalloc of %s%ld bytes failed (training workspace)", "", (long)(n * sizeof(T)));
+        return VN_ERR_OOM;
+    }
+    *p = (T*)q;
+    return VN_OK;
+}
+
+extern "C" void vn_train_destroy(vn_train* t) {
+    if (!t) return;
+    for (auto& s : t->st) {
+        float* a[] = {s.x_in, s.y1, s.qkv, s.lse, s.a, s.x_mid, s.y3, s.u, s.g};
+        for (float* p : a) (void)hipFree(p);
+    }
+    float* b[] = {t->wT, t->x_last, t->y_f, t->tmp, t->dxa, t->dxb, t->dh, t->dg, t->du, t->dy, t->dqkv, t->da, t->At, t->Bt,
+                  t->partial, t->row_loss, t->delta, t->scal};
+    for (float* p : b) (void)hipFree(p);
+    (void)hipFree(t->npartial);
+    (void)hipFree(t->t32);
+    (void)hipFree(t->n_valid);
+    delete t;
+}
+
+static const float* P(const vn_train* t, int id, int layer = 0) { return t->params + vn_tensor_offset(&t->m->d, id, layer); }
+static float* G(const vn_train* t, float* grads, int id, int layer = 0) { return grads + vn_tensor_offset(&t->m->d, id, layer); }
+
+extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
+    if (!m || !params || !out) return VN_ERR_INVALID;
+    *out = nullptr;
+    vn_ctx* ctx = m->ctx;
+    if (params != m->blob) return vn_fail(ctx, VN_ERR_INVALID, "vn_train_create: params must be the model's weight blob (the train vector's prefix)%s", "");
+    if (m->blob16) return vn_fail(ctx, VN_ERR_UNSUPPORTED, "vn_train_create: the model is in bf16 fast mode; training is fp32%s", "");
+    vn_train* t = new (std::nothrow) vn_train();
+    if (!t) return VN_ERR_OOM;
+    t->m = m; t->params = params;
+    const vn_dims& d = m->d;
+    const long D = m->D, L = m->L, rows = m->max_rows;
+    t->NV = m->Cp * d.vocab;
+    int64_t w = 0, n = 0;
+    vn_weights_size(&d, &w);
+    vn_train_param_size(&d, &n);
+    t->wsize = w; t->n_total = n; t->off_g = w; t->off_v = w + al64(t->NV);
+    t->Mp_max = (rows + 31) & ~31L;
+    t->wT_layer = 3 * D * D + D * D + 4 * D * D + 2 * D * D;
+    t->wT_cls = t->wT_layer * L;
+    int rc = VN_OK;
+    auto A = [&](float** p, size_t cnt) { if (rc == VN_OK) rc = talloc(ctx, p, cnt); };
+    A(&t->wT, (size_t)t->wT_layer * L + (size_t)t->NV * D);
+    t->st.resize(L);
+    for (auto& s : t->st) {
+        memset(&s, 0, sizeof(s));
+        A(&s.x_in, rows * D); A(&s.y1, rows * D); A(&s.qkv, 3 * rows * D); A(&s.lse, (size_t)d.max_batch * m->H * d.max_T);
+        A(&s.a, rows * D); A(&s.x_mid, rows * D); A(&s.y3, rows * D); A(&s.u, 4 * rows * D); A(&s.g, 2 * rows * D);
+    }
+    const long wide = 4 * D > t->NV ? 4 * D : t->NV;
+    A(&t->x_last, rows * D); A(&t->y_f, rows * D); A(&t->tmp, rows * D); A(&t->dxa, rows * D); A(&t->dxb, rows * D);
+    A(&t->dh, rows * D); A(&t->dg, 2 * rows * D); A(&t->du, 4 * rows * D); A(&t->dy, rows * D); A(&t->dqkv, 3 * rows * D);
+    A(&t->da, rows * D); A(&t->At, (size_t)wide * t->Mp_max); A(&t->Bt, (size_t)2 * D * t->Mp_max);
+    size_t part = (size_t)vn_rmsnorm_bwd_blocks((int)rows) * D;
+    const size_t cs = (size_t)vn_cdiv((int)rows, 64) * (size_t)(t->NV > D ? t->NV : D);
+    if (cs > part) part = cs;
+    const size_t eb = (size_t)vn_embed_bwd_partial_floats(d.max_batch, d.max_T, d.n_codebooks, d.latent_dim, (int)D);
+    if (eb > part) part = eb;
+    A(&t->partial, part);
+    A(&t->row_loss, (size_t)rows * m->Cp); A(&t->delta, (size_t)d.max_batch * m->H * d.max_T); A(&t->scal, 16);
+    if (rc == VN_OK) rc = talloc(ctx, &t->npartial, 1024);
+    if (rc == VN_OK) rc = talloc(ctx, &t->t32, (size_t)rows * m->Cp);
+    if (rc == VN_OK) rc = talloc(ctx, &t->n_valid, 4);
+    if (rc != VN_OK) { vn_train_destroy(t); return rc; }
+    *out = t;
+    return VN_OK;
+}
+
+// re-derive everything that is a function of the parameters: folded classifier weight, W^T copies, bias table
+extern "C" int vn_train_sync(vn_train* t, void* stream) {
+    if (!t) return VN_ERR_INVALID;
+    vn_model* m = t->m;
+    vn_ctx* ctx = m->ctx;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = m->D;
+    int rc;
+    float* clsW = t->params + vn_tensor_offset(&m->d, VN_W_CLS_W, 0);
+    if ((rc = vn_launch_weight_norm_fold(ctx, t->params + t->off_g, t->params + t->off_v, clsW, t->NV, D, s))) return rc;
+    for (int l = 0; l < m->L; ++l) {
+        float* base = t->wT + t->wT_layer * l;
+        if ((rc = vn_launch_transpose(ctx, P(t, VN_W_QKV, l), base, 3 * D, D, D, 3 * D, s))) return rc;
+        if ((rc = vn_launch_transpose(ctx, P(t, VN_W_WO, l), base + 3L * D * D, D, D, D, D, s))) return rc;
+        if ((rc = vn_launch_transpose(ctx, P(t, VN_W_W1, l), base + 4L * D * D, 4 * D, D, D, 4 * D, s))) return rc;
+        if ((rc = vn_launch_transpose(ctx, P(t, VN_W_W2, l), base + 8L * D * D, D, 2 * D, 2 * D, D, s))) return rc;
+    }
+    if ((rc = vn_launch_transpose(ctx, clsW, t->wT + t->wT_cls, t->NV, D, D, t->NV, s))) return rc;
+    m->bias_T = -1;                 // the relative-position table is a parameter too
+    return VN_OK;
+}
+
+static vn_drop make_drop(const vn_train_params* p, int layer, int site, long row0) {
+    vn_drop d;
+    d.key = vn_drop_key(p->seed, (uint32_t)p->step, (uint32_t)(layer * 4 + site));
+    const double th = (double)p->dropout * 65536.0;
+    d.thresh16 = p->dropout > 0.f ? (uint32_t)(th + 0.5) : 0u;
+    d.scale = 1.0f / (1.0f - p->dropout);
+    d.row0 = row0;
+    return d;
+}
+
+static int gemm(vn_ctx* ctx, const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int epi,
+                hipStream_t s) {
+    vn_gemm_args a{};
+    a.A = A; a.W = W; a.bias = bias; a.C = C; a.M = M; a.N = N; a.K = K; a.ldc = N;
+    return vn_launch_gemm_f32(ctx, a, epi, s);
+}
+
+static int params_ok(vn_ctx* ctx, const vn_train_params* p) {
+    if (!p) return vn_fail(ctx, VN_ERR_INVALID, "train params is NULL%s", "");
+    if (!(p->dropout >= 0.f && p->dropout < 1.f)) return vn_fail(ctx, VN_ERR_INVALID, "dropout must be in [0, 1)%s", "");
+    if (!(p->label_smoothing >= 0.f && p->label_smoothing < 1.f)) return vn_fail(ctx, VN_ERR_INVALID, "label_smoothing must be in [0, 1)%s", "");
+    if (p->step < 1) return vn_fail(ctx, VN_ERR_INVALID, "optimiser step index must be >= 1%s", "");
+    if (p->world_size < 1) return vn_fail(ctx, VN_ERR_INVALID, "world_size must be >= 1%s", "");
+    return VN_OK;
+}
+
+// ---- forward in train() mode + loss + dlogits --------------------------------------------------
+static int forward_train(vn_train* t, int B, int T, const vn_train_params* p, hipStream_t s) {
+    vn_model* m = t->m;
+    vn_ctx* ctx = m->ctx;
+    const int D = m->D, H = m->H, M = B * T, L = m->L;
+    const long plane = (long)B * H * T * VN_DHEAD;
+    const long r_tok = (long)p->batch_offset * T, r_att = (long)p->batch_offset * H * T;
+    int rc;
+    if ((rc = vn_model_ensure_bias(m, T, s))) return rc;
+    if ((rc = vn_launch_embed(ctx, m->z, P(t, VN_W_EMB_TABLES), P(t, VN_W_EMB_WT), P(t, VN_W_EMB_B), t->st[0].x_in, B,
+                              m->d.n_codebooks, T, m->d.vocab + 1, m->d.latent_dim, D, s)))
+        return rc;
+    for (int l = 0; l < L; ++l) {
+        vn_layer_stash& S = t->st[l];
+        float* x_out = l + 1 < L ? t->st[l + 1].x_in : t->x_last;
+        if ((rc = vn_launch_rmsnorm(ctx, S.x_in, P(t, VN_W_NORM1, l), S.y1, M, D, m->d.eps, s))) return rc;
+        vn_gemm_args a{};
+        a.A = S.y1; a.W = P(t, VN_W_QKV, l); a.C = S.qkv; a.M = M; a.N = 3 * D; a.K = D; a.ldc = 3 * D;
+        a.T = T; a.H = H; a.qkv_plane = plane;
+        if ((rc = vn_launch_gemm_f32(ctx, a, VN_EPI_QKV, s))) return rc;
+        if ((rc = vn_launch_attention_train_fwd(ctx, S.qkv, S.qkv + plane, S.qkv + 2 * plane, m->bias_full, S.a, S.lse, B, H, T,
+                                                make_drop(p, l, SITE_ATTN, r_att), s)))
+            return rc;
+        if ((rc = gemm(ctx, S.a, P(t, VN_W_WO, l), nullptr, t->tmp, M, D, D, VN_EPI_STORE, s))) return rc;
+        if ((rc = vn_launch_resid_dropout(ctx, S.x_in, t->tmp, S.x_mid, M, D, make_drop(p, l, SITE_RES1, r_tok), s))) return rc;
+        if ((rc = vn_launch_rmsnorm(ctx, S.x_mid, P(t, VN_W_NORM3, l), S.y3, M, D, m->d.eps, s))) return rc;
+        if ((rc = gemm(ctx, S.y3, P(t, VN_W_W1, l), nullptr, S.u, M, 4 * D, D, VN_EPI_STORE, s))) return rc;
+        if ((rc = vn_launch_geglu_train(ctx, S.u, nullptr, S.g, M, 2 * D, make_drop(p, l, SITE_FFN, r_tok), false, s))) return rc;
+        if ((rc = gemm(ctx, S.g, P(t, VN_W_W2, l), nullptr, t->tmp, M, D, 2 * D, VN_EPI_STORE, s))) return rc;
+        if ((rc = vn_launch_resid_dropout(ctx, S.x_mid, t->tmp, x_out, M, D, make_drop(p, l, SITE_RES2, r_tok), s))) return rc;
+    }
+    if ((rc = vn_launch_rmsnorm(ctx, t->x_last, P(t, VN_W_FINAL_NORM), t->y_f, M, D, m->d.eps, s))) return rc;
+    return gemm(ctx, t->y_f, P(t, VN_W_CLS_W), P(t, VN_W_CLS_B), m->logits, M, t->NV, D, VN_EPI_BIAS, s);
+}
+
+// dW[N][K] = dY^T X   (dY [M][N], X [M][K]) through the two transposes
+static int grad_weight(vn_train* t, const float* dY, const float* X, float* dW, int M, int N, int K, hipStream_t s) {
+    vn_ctx* ctx = t->m->ctx;
+    const int Mp = (M + 31) & ~31;
+    int rc;
+    if ((rc = vn_launch_transpose(ctx, dY, t->At, M, N, N, Mp, s))) return rc;
+    if ((rc = vn_launch_transpose(ctx, X, t->Bt, M, K, K, Mp, s))) return rc;
+    return gemm(ctx, t->At, t->Bt, nullptr, dW, N, K, Mp, VN_EPI_STORE, s);
+}
+
+static int backward(vn_train* t, int B, int T, const vn_train_params* p, float* grads, hipStream_t s) {
+    vn_model* m = t->m;
+    vn_ctx* ctx = m->ctx;
+    const int D = m->D, H = m->H, M = B * T, L = m->L, NV = t->NV;
+    const long plane = (long)B * H * T * VN_DHEAD;
+    const long r_tok = (long)p->batch_offset * T, r_att = (long)p->batch_offset * H * T;
+    int rc;
+    float* dlog = m->logits;
+    // ---- classifier (WNConv1d 1x1, transformer.py:596-604) + final norm
+    if ((rc = gemm(ctx, dlog, t->wT + t->wT_cls, nullptr, t->dy, M, D, NV, VN_EPI_STORE, s))) return rc;
+    float* dWc = G(t, grads, VN_W_CLS_W);
+    if ((rc = grad_weight(t, dlog, t->y_f, dWc, M, NV, D, s))) return rc;
+    if ((rc = vn_launch_colsum(ctx, dlog, M, NV, t->partial, G(t, grads, VN_W_CLS_B), s))) return rc;
+    if ((rc = vn_launch_weight_norm_bwd(ctx, t->params + t->off_g, t->params + t->off_v, dWc, grads + t->off_g,
+                                        grads + t->off_v, NV, D, s)))
+        return rc;
+    VN_HIP_CHECK(ctx, hipMemsetAsync(dWc, 0, (size_t)NV * D * sizeof(float), s));   // derived tensor: not a parameter
+    float* dx = t->dxa;
+    float* dx2 = t->dxb;
+    if ((rc = vn_launch_rmsnorm_bwd(ctx, t->x_last, P(t, VN_W_FINAL_NORM), t->dy, nullptr, dx, G(t, grads, VN_W_FINAL_NORM),
+                                    t->partial, M, D, m->d.eps, s)))
+        return rc;
+    for (int l = L - 1; l >= 0; --l) {
+        vn_layer_stash& S = t->st[l];
+        const float* wTl = t->wT + t->wT_layer * l;
+        // ---- feed-forward branch (transformer.py:72-85, :360-367)
+        const vn_drop d2 = make_drop(p, l, SITE_RES2, r_tok);
+        const float* dh = dx;
+        if (d2.thresh16) { if ((rc = vn_launch_dropout_bwd(ctx, dx, t->dh, M, D, d2, s))) return rc; dh = t->dh; }
+        if ((rc = grad_weight(t, dh, S.g, G(t, grads, VN_W_W2, l), M, D, 2 * D, s))) return rc;
+        if ((rc = gemm(ctx, dh, wTl + 8L * D * D, nullptr, t->dg, M, 2 * D, D, VN_EPI_STORE, s))) return rc;
+        if ((rc = vn_launch_geglu_train(ctx, S.u, t->dg, t->du, M, 2 * D, make_drop(p, l, SITE_FFN, r_tok), true, s))) return rc;
+        if ((rc = grad_weight(t, t->du, S.y3, G(t, grads, VN_W_W1, l), M, 4 * D, D, s))) return rc;
+        if ((rc = gemm(ctx, t->du, wTl + 4L * D * D, nullptr, t->dy, M, D, 4 * D, VN_EPI_STORE, s))) return rc;
+        if ((rc = vn_launch_rmsnorm_bwd(ctx, S.x_mid, P(t, VN_W_NORM3, l), t->dy, dx, dx2, G(t, grads, VN_W_NORM3, l), t->partial,
+                                        M, D, m->d.eps, s)))
+            return rc;
+        // ---- attention branch (transformer.py:211-257, :336-347)
+        const vn_drop d1 = make_drop(p, l, SITE_RES1, r_tok);
+        const float* dh2 = dx2;
+        if (d1.thresh16) { if ((rc = vn_launch_dropout_bwd(ctx, dx2, t->dh, M, D, d1, s))) return rc; dh2 = t->dh; }
+        if ((rc = grad_weight(t, dh2, S.a, G(t, grads, VN_W_WO, l), M, D, D, s))) return rc;
+        if ((rc = gemm(ctx, dh2, wTl + 3L * D * D, nullptr, t->da, M, D, D, VN_EPI_STORE, s))) return rc;
+        if ((rc = vn_launch_attention_bwd(ctx, S.qkv, S.qkv + plane, S.qkv + 2 * plane, m->bias_full, m->lut, S.a, t->da, S.lse,
+                                          t->delta, t->dqkv, G(t, grads, VN_W_REL_BIAS), B, H, T, m->d.num_buckets,
+                                          make_drop(p, l, SITE_ATTN, r_att), s)))
+            return rc;
+        if ((rc = grad_weight(t, t->dqkv, S.y1, G(t, grads, VN_W_QKV, l), M, 3 * D, D, s))) return rc;
+        if ((rc = gemm(ctx, t->dqkv, wTl, nullptr, t->dy, M, D, 3 * D, VN_EPI_STORE, s))) return rc;
+        if ((rc = vn_launch_rmsnorm_bwd(ctx, S.x_in, P(t, VN_W_NORM1, l), t->dy, dx2, dx, G(t, grads, VN_W_NORM1, l), t->partial,
+                                        M, D, m->d.eps, s)))
+            return rc;
+    }
+    // ---- codebook embedding (layers.py:134-163)
+    return vn_launch_embed_bwd(ctx, dx, m->z, P(t, VN_W_EMB_TABLES), P(t, VN_W_EMB_WT), G(t, grads, VN_W_EMB_TABLES),
+                               G(t, grads, VN_W_EMB_WT), G(t, grads, VN_W_EMB_B), t->partial, B, m->d.n_codebooks, T,
+                               m->d.vocab + 1, m->d.latent_dim, D, s);
+}
+
+extern "C" int vn_train_forward_backward(vn_train* t, const int64_t* z_masked, const int64_t* target, int B, int T,
+                                         const vn_train_params* p, float* grads, float* loss_dev, void* stream) {
+    if (!t || !z_masked || !target || !grads || !loss_dev) return VN_ERR_INVALID;
+    vn_model* m = t->m;
+    vn_ctx* ctx = m->ctx;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = params_ok(ctx, p);
+    if (rc) return rc;
+    if (B <= 0 || T <= 0 || B > m->d.max_batch || T > m->d.max_T)
+        return vn_fail(ctx, VN_ERR_INVALID, "train step: B=%s%ld, T=%ld outside the model workspace", "", B, T);
+    VN_HIP_CHECK(ctx, hipMemsetAsync(grads, 0, (size_t)t->n_total * sizeof(float), s));
+    if ((rc = vn_launch_i64_to_i32(ctx, z_masked, m->z, (long)B * m->d.n_codebooks * T, s))) return rc;
+    if ((rc = forward_train(t, B, T, p, s))) return rc;
+    if ((rc = vn_launch_cross_entropy(ctx, m->logits, target, t->t32, (long)B * T * m->Cp, m->d.vocab, p->label_smoothing,
+                                      t->n_valid, t->row_loss, loss_dev, s)))
+        return rc;
+    t->B = B; t->T = T;
+    return backward(t, B, T, p, grads, s);
+}
+
+// logits of the train()-mode forward only (parity tests): [B][T][Cp][vocab]
+extern "C" int vn_train_forward(vn_train* t, const int64_t* z_masked, int B, int T, const vn_train_params* p, float* logits,
+                                void* stream) {
+    if (!t || !z_masked || !logits) return VN_ERR_INVALID;
+    vn_model* m = t->m;
+    vn_ctx* ctx = m->ctx;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = params_ok(ctx, p);
+    if (rc) return rc;
+    if (B <= 0 || T <= 0 || B > m->d.max_batch || T > m->d.max_T)
+        return vn_fail(ctx, VN_ERR_INVALID, "train forward: B=%s%ld, T=%ld outside the model workspace", "", B, T);
+    if ((rc = vn_launch_i64_to_i32(ctx, z_masked, m->z, (long)B * m->d.n_codebooks * T, s))) return rc;
+    if ((rc = forward_train(t, B, T, p, s))) return rc;
+    VN_HIP_CHECK(ctx, hipMemcpyAsync(logits, m->logits, (size_t)B * T * t->NV * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return VN_OK;
+}
+
+extern "C" int vn_train_update(vn_train* t, const float* grads, float* mom, float* var, const vn_train_params* p,
+                               float* grad_norm_dev, void* stream) {
+    if (!t || !grads || !mom || !var || !grad_norm_dev) return VN_ERR_INVALID;
+    vn_model* m = t->m;
+    vn_ctx* ctx = m->ctx;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = params_ok(ctx, p);
+    if (rc) return rc;
+    vn_adamw_args a;
+    a.lr = p->lr; a.beta1 = p->beta1; a.beta2 = p->beta2; a.eps = p->eps; a.weight_decay = p->weight_decay;
+    a.bc1 = (float)(1.0 - pow((double)p->beta1, (double)p->step));
+    a.bc2 = (float)(1.0 - pow((double)p->beta2, (double)p->step));
+    a.gscale = 1.0f / (float)p->world_size;
+    a.clip = p->grad_clip;
+    if ((rc = vn_launch_grad_norm(ctx, grads, t->n_total, a.gscale, t->npartial, grad_norm_dev, s))) return rc;
+    auto range = [&](long lo, long hi) {
+        return vn_launch_adamw(ctx, t->params + lo, grads + lo, mom + lo, var + lo, hi - lo, a, grad_norm_dev, s);
+    };
+    const vn_dims& d = m->d;
+    const long V1 = d.vocab + 1, ld = d.latent_dim;
+    const long tab = vn_tensor_offset(&d, VN_W_EMB_TABLES, 0);
+    for (int c = 0; c < d.n_codebooks; ++c) {      // embedding.special.MASK rows; the codec codebooks are not parameters
+        const long lo = tab + ((long)c * V1 + d.vocab) * ld;
+        if ((rc = range(lo, lo + ld))) return rc;
+    }
+    if ((rc = range(vn_tensor_offset(&d, VN_W_EMB_WT, 0), vn_tensor_offset(&d, VN_W_CLS_W, 0)))) return rc;
+    if ((rc = range(vn_tensor_offset(&d, VN_W_CLS_B, 0), t->wsize))) return rc;
+    if ((rc = range(t->off_g, t->n_total))) return rc;
+    return vn_train_sync(t, stream);
+}
+
+extern "C" int vn_dropout_keep_mask(vn_ctx* ctx, uint64_t seed, int64_t step, int layer, int site, float p, int64_t row0,
+                                    int64_t rows, int cols, uint8_t* out, void* stream) {
+    if (!ctx || !out || site < 0 || site > 3) return VN_ERR_INVALID;
+    vn_train_params tp{};
+    tp.seed = seed; tp.step = step; tp.dropout = p;
+    return vn_launch_dropout_mask(ctx, out, rows, cols, make_drop(&tp, layer, site, row0), (hipStream_t)stream);
+}

@@ -1,0 +1,691 @@
+// HBM-bound kernels of the VampNet TRAINING step (scripts/exp/train.py:237-304) for gfx950: dropout-aware
+// residual / GEGLU passes, RMSNorm backward, layout transposes that feed the backward GEMMs, the label-smoothed
+// cross-entropy (forward + gradient in one pass), weight-norm fold / backward, embedding gradients, gradient-norm
+// and the AdamW update.  All fp32; every kernel streams its operands once with 16-byte accesses.
+//
+// Determinism: column sums (norm weights, biases, loss) go through fixed-shape partial buffers + a second pass,
+// never through floating-point atomics, so a step is bitwise reproducible run to run (the only atomics of the
+// training path are the relative-position-bias gradient in attention_train.hip).
+#include "vn_common.h"
+#include "vn_train.h"
+
+// ---------------------------------------------------------------------------------------------
+// x_out = x_in + dropout(y)        (transformer.py:347, :367)      M x N, N % 4 == 0
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vn_resid_dropout_kernel(const float* __restrict__ x_in, const float* __restrict__ y,
+                                                               float* __restrict__ x_out, int M, int N4, vn_drop d) {
+    const long total = (long)M * N4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        const int row = (int)(i / N4), c4 = (int)(i - (long)row * N4);
+        f32x4 a = ((const f32x4*)x_in)[i];
+        const f32x4 b = ((const f32x4*)y)[i];
+        if (d.thresh16) {
+            const uint32_t rk = vn_drop_rowkey(d, row);
+            const uint32_t b0 = vn_drop_bits(rk, 4 * c4), b1 = vn_drop_bits(rk, 4 * c4 + 2);
+            a[0] += b[0] * vn_drop_mul(d, b0, 0);
+            a[1] += b[1] * vn_drop_mul(d, b0, 1);
+            a[2] += b[2] * vn_drop_mul(d, b1, 0);
+            a[3] += b[3] * vn_drop_mul(d, b1, 1);
+        } else {
+            a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+        }
+        ((f32x4*)x_out)[i] = a;
+    }
+}
+
+int vn_launch_resid_dropout(vn_ctx* ctx, const float* x_in, const float* y, float* x_out, int M, int N, const vn_drop& d,
+                            hipStream_t s) {
+    if (M <= 0) return VN_OK;
+    const long total = (long)M * (N / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(vn_resid_dropout_kernel, dim3(blocks), dim3(256), 0, s, x_in, y, x_out, M, N / 4, d);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// dy_out = dy_in * keep * scale   (backward of the residual-branch dropout)
+__global__ __launch_bounds__(256) void vn_dropout_bwd_kernel(const float* __restrict__ dy, float* __restrict__ out, int M,
+                                                             int N4, vn_drop d) {
+    const long total = (long)M * N4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        const int row = (int)(i / N4), c4 = (int)(i - (long)row * N4);
+        f32x4 a = ((const f32x4*)dy)[i];
+        const uint32_t rk = vn_drop_rowkey(d, row);
+        const uint32_t b0 = vn_drop_bits(rk, 4 * c4), b1 = vn_drop_bits(rk, 4 * c4 + 2);
+        a[0] *= vn_drop_mul(d, b0, 0);
+        a[1] *= vn_drop_mul(d, b0, 1);
+        a[2] *= vn_drop_mul(d, b1, 0);
+        a[3] *= vn_drop_mul(d, b1, 1);
+        ((f32x4*)out)[i] = a;
+    }
+}
+
+int vn_launch_dropout_bwd(vn_ctx* ctx, const float* dy, float* out, int M, int N, const vn_drop& d, hipStream_t s) {
+    if (M <= 0) return VN_OK;
+    if (!d.thresh16) {
+        if (dy != out) VN_HIP_CHECK(ctx, hipMemcpyAsync(out, dy, (size_t)M * N * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return VN_OK;
+    }
+    const long total = (long)M * (N / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(vn_dropout_bwd_kernel, dim3(blocks), dim3(256), 0, s, dy, out, M, N / 4, d);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// keep-mask export for the parity tests: out[row][col] = 1 if kept
+__global__ __launch_bounds__(256) void vn_dropout_mask_kernel(uint8_t* __restrict__ out, long rows, int cols, vn_drop d) {
+    const long total = rows * cols;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        const long row = i / cols;
+        const int col = (int)(i - row * cols);
+        const uint32_t bits = vn_drop_bits(vn_drop_rowkey(d, row), col);
+        out[i] = d.thresh16 == 0 || vn_drop_mul(d, bits, col) != 0.0f;
+    }
+}
+
+int vn_launch_dropout_mask(vn_ctx* ctx, uint8_t* out, long rows, int cols, const vn_drop& d, hipStream_t s) {
+    if (rows <= 0) return VN_OK;
+    hipLaunchKernelGGL(vn_dropout_mask_kernel, dim3(4096), dim3(256), 0, s, out, rows, cols, d);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEGLU on the packed w_1 output u [M][4D] (value/gate interleaved in 32-column blocks, see VN_W_W1):
+//   g[m][o] = dropout( u_val * gelu_tanh(u_gate) )          (transformer.py:80-82, activations.py:33-35)
+//   backward: du_val = dg' * gelu(gate) ; du_gate = dg' * val * gelu'(gate),  dg' = dg * keep * scale
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float vn_gelu_tanh_grad(float x) {
+    const float c = 0.7978845608028654f;
+    const float x2 = x * x;
+    const float t = tanhf(c * (x + 0.044715f * x2 * x));
+    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x2);
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void vn_geglu_train_kernel(const float* __restrict__ u, const float* __restrict__ dg,
+                                                             float* __restrict__ out, int M, int D2, vn_drop d) {
+    const int n4 = D2 / 4;
+    const long total = (long)M * n4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        const int row = (int)(i / n4), o = 4 * (int)(i - (long)row * n4);
+        const size_t ub = (size_t)row * 2 * D2 + 64 * (o >> 5) + (o & 31);
+        const f32x4 val = *(const f32x4*)(u + ub);
+        const f32x4 gate = *(const f32x4*)(u + ub + 32);
+        f32x4 m = {1.f, 1.f, 1.f, 1.f};
+        if (d.thresh16) {
+            const uint32_t rk = vn_drop_rowkey(d, row);
+            const uint32_t b0 = vn_drop_bits(rk, o), b1 = vn_drop_bits(rk, o + 2);
+            m[0] = vn_drop_mul(d, b0, 0); m[1] = vn_drop_mul(d, b0, 1);
+            m[2] = vn_drop_mul(d, b1, 0); m[3] = vn_drop_mul(d, b1, 1);
+        }
+        if constexpr (!BWD) {
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = val[e] * vn_gelu_tanh(gate[e]) * m[e];
+            *(f32x4*)(out + (size_t)row * D2 + o) = r;
+        } else {
+            const f32x4 g = *(const f32x4*)(dg + (size_t)row * D2 + o);
+            f32x4 dv, dgt;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gg = g[e] * m[e];
+                dv[e] = gg * vn_gelu_tanh(gate[e]);
+                dgt[e] = gg * val[e] * vn_gelu_tanh_grad(gate[e]);
+            }
+            *(f32x4*)(out + ub) = dv;
+            *(f32x4*)(out + ub + 32) = dgt;
+        }
+    }
+}
+
+int vn_launch_geglu_train(vn_ctx* ctx, const float* u, const float* dg, float* out, int M, int D2, const vn_drop& d,
+                          bool bwd, hipStream_t s) {
+    if (M <= 0) return VN_OK;
+    if (D2 % 32) return vn_fail(ctx, VN_ERR_INVALID, "geglu: width %s%ld must be a multiple of 32", "", D2);
+    const long total = (long)M * (D2 / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (bwd) hipLaunchKernelGGL(vn_geglu_train_kernel<true>, dim3(blocks), dim3(256), 0, s, u, dg, out, M, D2, d);
+    else hipLaunchKernelGGL(vn_geglu_train_kernel<false>, dim3(blocks), dim3(256), 0, s, u, dg, out, M, D2, d);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RMSNorm backward (transformer.py:55-58):  y = w * x * r,  r = rsqrt(mean(x^2) + eps)
+//   dx = r * (w o dy) - x * r^3 * mean(x o w o dy)      (+ dres, the gradient arriving on the residual path)
+//   dw = sum_rows dy o x * r                              -> partial[blockIdx][D], reduced by vn_reduce_rows
+// One wave per row, VN_RB rows per wave, 4 waves per block.
+// ---------------------------------------------------------------------------------------------
+#define VN_RB 8     // rows per wave
+template <int VEC>  // float4 per lane: D <= VEC * 256
+__global__ __launch_bounds__(256) void vn_rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ dy, const float* __restrict__ dres,
+                                                             float* __restrict__ dx, float* __restrict__ dw_partial,
+                                                             int rows, int D, float eps) {
+    __shared__ f32x4 red[3][64 * VEC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = D >> 2;
+    f32x4 wv[VEC], dwacc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        const int c = lane + 64 * i;
+        wv[i] = c < nv ? ((const f32x4*)w)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        dwacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int row0 = (blockIdx.x * 4 + wave) * VN_RB;
+    for (int rr = 0; rr < VN_RB; ++rr) {
+        const int row = row0 + rr;
+        if (row >= rows) break;
+        const f32x4* xr = (const f32x4*)(x + (size_t)row * D);
+        const f32x4* gr = (const f32x4*)(dy + (size_t)row * D);
+        f32x4 xv[VEC], gv[VEC];
+        float ss = 0.f, dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) { xv[i] = xr[c]; gv[i] = gr[c]; }
+            else { xv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gv[i] = xv[i]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ss += xv[i][e] * xv[i][e];
+                dot += xv[i][e] * wv[i][e] * gv[i][e];
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ss += __shfl_xor(ss, o); dot += __shfl_xor(dot, o); }
+        const float r = 1.0f / sqrtf(ss / (float)D + eps);
+        const float k = dot / (float)D * r * r * r;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const int c = lane + 64 * i;
+            if (c >= nv) continue;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = r * (wv[i][e] * gv[i][e]) - xv[i][e] * k;
+                dwacc[i][e] += gv[i][e] * (xv[i][e] * r);
+            }
+            if (dres) {
+                const f32x4 a = ((const f32x4*)(dres + (size_t)row * D))[c];
+                o[0] += a[0]; o[1] += a[1]; o[2] += a[2]; o[3] += a[3];
+            }
+            ((f32x4*)(dx + (size_t)row * D))[c] = o;
+        }
+    }
+    // block-level sum of the 4 waves' dw accumulators (fixed order: wave 0 + 1 + 2 + 3)
+    if (wave > 0)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) red[wave - 1][lane + 64 * i] = dwacc[i];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const int c = lane + 64 * i;
+            if (c >= nv) continue;
+            f32x4 a = dwacc[i];
+#pragma unroll
+            for (int k2 = 0; k2 < 3; ++k2) {
+                const f32x4 b = red[k2][c];
+                a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+            }
+            ((f32x4*)(dw_partial + (size_t)blockIdx.x * D))[c] = a;
+        }
+    }
+}
+
+// out[c] = sum_b partial[b][c]   (fixed order)
+__global__ __launch_bounds__(256) void vn_reduce_rows_kernel(const float* __restrict__ partial, int nb, int C,
+                                                             float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f;
+    for (int b = 0; b < nb; ++b) a += partial[(size_t)b * C + c];
+    out[c] = a;
+}
+
+int vn_launch_reduce_rows(vn_ctx* ctx, const float* partial, int nb, int C, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(vn_reduce_rows_kernel, dim3(vn_cdiv(C, 256)), dim3(256), 0, s, partial, nb, C, out);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+int vn_rmsnorm_bwd_blocks(int rows) { return vn_cdiv(rows, 4 * VN_RB); }
+
+int vn_launch_rmsnorm_bwd(vn_ctx* ctx, const float* x, const float* w, const float* dy, const float* dres, float* dx,
+                          float* dw, float* partial, int rows, int D, float eps, hipStream_t s) {
+    if (rows <= 0) return VN_OK;
+    if (D % 4 || D > 8 * 256) return vn_fail(ctx, VN_ERR_UNSUPPORTED, "rmsnorm_bwd: D=%s%ld unsupported", "", D);
+    const int nb = vn_rmsnorm_bwd_blocks(rows);
+    const int vec = vn_cdiv(D, 256);
+#define VN_RB_CASE(V)                                                                                              \
+    case V:                                                                                                        \
+        hipLaunchKernelGGL(vn_rmsnorm_bwd_kernel<V>, dim3(nb), dim3(256), 0, s, x, w, dy, dres, dx, partial, rows, D, eps); \
+        break;
+    switch (vec) {
+        VN_RB_CASE(1) VN_RB_CASE(2) VN_RB_CASE(3) VN_RB_CASE(4) VN_RB_CASE(5) VN_RB_CASE(6) VN_RB_CASE(7) VN_RB_CASE(8)
+    }
+#undef VN_RB_CASE
+    VN_LAUNCH_CHECK(ctx);
+    return vn_launch_reduce_rows(ctx, partial, nb, D, dw, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dst[c][r] = src[r][c]   src [R][C] (row stride lds), dst [C][ldd] with columns r in [R, ldd) zero-filled:
+// the backward GEMMs contract over the token axis, and the GEMM kernel wants the contraction axis contiguous
+// and a multiple of 32.  64x64 tiles through LDS (padded rows: conflict-free both ways), 16-byte global accesses.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vn_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R,
+                                                           int C, int lds_, int ldd) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;     // 16 x 16 threads, float4 each, 4 passes
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = r0 + ty + 16 * p, c = c0 + 4 * tx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < R) {
+            if (c + 3 < C) v = *(const f32x4*)(src + (size_t)r * lds_ + c);
+            else
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < C) v[e] = src[(size_t)r * lds_ + c + e];
+        }
+        tile[ty + 16 * p][4 * tx + 0] = v[0];
+        tile[ty + 16 * p][4 * tx + 1] = v[1];
+        tile[ty + 16 * p][4 * tx + 2] = v[2];
+        tile[ty + 16 * p][4 * tx + 3] = v[3];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int c = c0 + ty + 16 * p, r = r0 + 4 * tx;
+        if (c >= C || r >= ldd) continue;
+        f32x4 v;
+        v[0] = tile[4 * tx + 0][ty + 16 * p];
+        v[1] = tile[4 * tx + 1][ty + 16 * p];
+        v[2] = tile[4 * tx + 2][ty + 16 * p];
+        v[3] = tile[4 * tx + 3][ty + 16 * p];
+        *(f32x4*)(dst + (size_t)c * ldd + r) = v;      // ldd % 4 == 0 and r % 4 == 0: whole float4 is inside the row
+    }
+}
+
+int vn_launch_transpose(vn_ctx* ctx, const float* src, float* dst, int R, int C, int lds_, int ldd, hipStream_t s) {
+    if (R <= 0 || C <= 0) return VN_OK;
+    if (ldd % 4 || ldd < R) return vn_fail(ctx, VN_ERR_INVALID, "transpose: bad destination stride %s%ld", "", ldd);
+    hipLaunchKernelGGL(vn_transpose_kernel, dim3(vn_cdiv(ldd, 64), vn_cdiv(C, 64)), dim3(256), 0, s, src, dst, R, C, lds_, ldd);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sums of src [R][C] (bias gradients): partial[b][c] over 64-row chunks, then vn_reduce_rows.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vn_colsum_partial_kernel(const float* __restrict__ src, int R, int C,
+                                                                float* __restrict__ partial) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int r0 = blockIdx.y * 64, r1 = r0 + 64 < R ? r0 + 64 : R;
+    float a = 0.f;
+    for (int r = r0; r < r1; ++r) a += src[(size_t)r * C + c];
+    partial[(size_t)blockIdx.y * C + c] = a;
+}
+
+int vn_launch_colsum(vn_ctx* ctx, const float* src, int R, int C, float* partial, float* out, hipStream_t s) {
+    const int nb = vn_cdiv(R, 64);
+    hipLaunchKernelGGL(vn_colsum_partial_kernel, dim3(vn_cdiv(C, 256), nb), dim3(256), 0, s, src, R, C, partial);
+    VN_LAUNCH_CHECK(ctx);
+    return vn_launch_reduce_rows(ctx, partial, nb, C, out, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Label-smoothed cross-entropy over rows of V logits, mean over rows whose target != ignore (-100)
+// (train.py:267-278, conf/vampnet.yml:17; torch.nn.CrossEntropyLoss semantics):
+//   loss_row = (1-e) * (logZ - x_t) + e * (logZ - mean_c x_c)
+//   dlogits  = (softmax - (1-e) * onehot_t - e/V) / n_valid         written IN PLACE over the logits
+// One wave per row (V = VEC*256).  n_valid is counted on the device first (no host sync).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vn_ce_prepare_kernel(const int64_t* __restrict__ target, int32_t* __restrict__ t32,
+                                                            long n, int V, int32_t* __restrict__ n_valid) {
+    __shared__ int cnt[4];
+    int local = 0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        const int64_t t = target[i];
+        const bool ok = t >= 0 && t < V;
+        t32[i] = ok ? (int32_t)t : -1;
+        local += ok;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(n_valid, cnt[0] + cnt[1] + cnt[2] + cnt[3]);      // integer: order independent
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void vn_ce_kernel(float* __restrict__ logits, const int32_t* __restrict__ t32, long rows,
+                                                    float ls, const int32_t* __restrict__ n_valid,
+                                                    float* __restrict__ row_loss) {
+    const int lane = threadIdx.x & 63;
+    const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    constexpr int V = VEC * 256;
+    f32x4* xr = (f32x4*)(logits + row * V);
+    const int t = t32[row];
+    if (t < 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) xr[lane + 64 * i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lane == 0) row_loss[row] = 0.f;
+        return;
+    }
+    f32x4 x[VEC];
+    float mx = -INFINITY, sx = 0.f, xt = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        x[i] = xr[lane + 64 * i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mx = fmaxf(mx, x[i][e]);
+            sx += x[i][e];
+            if ((lane + 64 * i) * 4 + e == t) xt = x[i][e];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+        sx += __shfl_xor(sx, o);
+        xt += __shfl_xor(xt, o);
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x[i][e] = expf(x[i][e] - mx);
+            se += x[i][e];
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+    const float logZ = mx + logf(se);
+    const float inv_n = 1.0f / (float)(*n_valid);
+    if (lane == 0) row_loss[row] = (1.0f - ls) * (logZ - xt) + ls * (logZ - sx / (float)V);
+    const float inv_se = 1.0f / se, sm = ls / (float)V;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        f32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float p = x[i][e] * inv_se - sm;
+            if ((lane + 64 * i) * 4 + e == t) p -= (1.0f - ls);
+            g[e] = p * inv_n;
+        }
+        xr[lane + 64 * i] = g;
+    }
+}
+
+// loss = sum(row_loss) / n_valid  in double, one block, fixed order
+__global__ __launch_bounds__(1024) void vn_ce_finish_kernel(const float* __restrict__ row_loss, long rows,
+                                                            const int32_t* __restrict__ n_valid, float* __restrict__ loss) {
+    __shared__ double red[1024];
+    double a = 0.0;
+    for (long i = threadIdx.x; i < rows; i += 1024) a += (double)row_loss[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (float)(red[0] / (double)(*n_valid > 0 ? *n_valid : 1));
+}
+
+int vn_launch_cross_entropy(vn_ctx* ctx, float* logits, const int64_t* target, int32_t* t32, long rows, int V, float ls,
+                            int32_t* n_valid, float* row_loss, float* loss, hipStream_t s) {
+    if (V != 1024 && V != 256) return vn_fail(ctx, VN_ERR_UNSUPPORTED, "cross-entropy: vocab=%s%ld unsupported", "", V);
+    VN_HIP_CHECK(ctx, hipMemsetAsync(n_valid, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(vn_ce_prepare_kernel, dim3(256), dim3(256), 0, s, target, t32, rows, V, n_valid);
+    const int blocks = (int)((rows + 3) / 4);
+    if (V == 1024) hipLaunchKernelGGL(vn_ce_kernel<4>, dim3(blocks), dim3(256), 0, s, logits, t32, rows, ls, n_valid, row_loss);
+    else hipLaunchKernelGGL(vn_ce_kernel<1>, dim3(blocks), dim3(256), 0, s, logits, t32, rows, ls, n_valid, row_loss);
+    hipLaunchKernelGGL(vn_ce_finish_kernel, dim3(1), dim3(1024), 0, s, row_loss, rows, n_valid, loss);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight norm of the classifier (layers.py:47-48, old-style torch weight_norm, dim 0):  W[r] = g[r] * v[r] / ||v[r]||
+//   fold:     W <- g, v
+//   backward: dg[r] = (dW[r] . v[r]) / n ;  dv[r] = g/n * dW[r] - g * (dW[r] . v[r]) / n^3 * v[r]
+// One wave per row.
+// ---------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ __launch_bounds__(256) void vn_weight_norm_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                                                             const float* __restrict__ dW, float* __restrict__ outW,
+                                                             float* __restrict__ dg, float* __restrict__ dv, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = D >> 2;
+    const f32x4* vr = (const f32x4*)(v + (size_t)row * D);
+    float ss = 0.f, dot = 0.f;
+    for (int c = lane; c < nv; c += 64) {
+        const f32x4 a = vr[c];
+        ss += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+        if constexpr (BWD) {
+            const f32x4 b = ((const f32x4*)(dW + (size_t)row * D))[c];
+            dot += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ss += __shfl_xor(ss, o); dot += __shfl_xor(dot, o); }
+    const float n = sqrtf(ss), gg = g[row];
+    if constexpr (!BWD) {
+        const float k = gg / n;
+        for (int c = lane; c < nv; c += 64) {
+            f32x4 a = vr[c];
+            a[0] *= k; a[1] *= k; a[2] *= k; a[3] *= k;
+            ((f32x4*)(outW + (size_t)row * D))[c] = a;
+        }
+    } else {
+        if (lane == 0) dg[row] = dot / n;
+        const float k1 = gg / n, k2 = gg * dot / (n * n * n);
+        for (int c = lane; c < nv; c += 64) {
+            const f32x4 a = vr[c];
+            const f32x4 b = ((const f32x4*)(dW + (size_t)row * D))[c];
+            f32x4 o;
+            o[0] = k1 * b[0] - k2 * a[0]; o[1] = k1 * b[1] - k2 * a[1];
+            o[2] = k1 * b[2] - k2 * a[2]; o[3] = k1 * b[3] - k2 * a[3];
+            ((f32x4*)(dv + (size_t)row * D))[c] = o;
+        }
+    }
+}
+
+int vn_launch_weight_norm_fold(vn_ctx* ctx, const float* g, const float* v, float* W, int rows, int D, hipStream_t s) {
+    hipLaunchKernelGGL(vn_weight_norm_kernel<false>, dim3(vn_cdiv(rows, 4)), dim3(256), 0, s, g, v, nullptr, W, nullptr, nullptr, rows, D);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+int vn_launch_weight_norm_bwd(vn_ctx* ctx, const float* g, const float* v, const float* dW, float* dg, float* dv, int rows,
+                              int D, hipStream_t s) {
+    hipLaunchKernelGGL(vn_weight_norm_kernel<true>, dim3(vn_cdiv(rows, 4)), dim3(256), 0, s, g, v, dW, nullptr, dg, dv, rows, D);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Embedding backward (layers.py:134-163).  Forward: x[m][:] = b + sum_j lat[m][j] * Wt[j][:],  lat[m][c*ld + e] =
+// tables[c][z[m,c]][e]  (row `vocab` of a table = the trainable MASK special, layers.py:146-150).
+//   dWt[j][d]  = sum_m lat[m][j] * dx[m][d]      -> partial over 64-row chunks, then vn_reduce_rows
+//   dMASK[c][e] = sum_{m : z[m,c] == vocab} sum_d dx[m][d] * Wt[c*ld+e][d]
+//   db = colsum(dx)                               (vn_launch_colsum)
+// z is the int32 token buffer [B][C][T]; m = b*T + t.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vn_embed_dwt_partial_kernel(const float* __restrict__ dx, const int32_t* __restrict__ z,
+                                                                   const float* __restrict__ tables, float* __restrict__ partial,
+                                                                   int B, int C, int T, int V1, int ld, int D) {
+    // grid: (D/256, row chunks of 64, J/16)   J = C*ld; thread owns one d column and 16 j's
+    __shared__ float lat[64][16];
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    const int m0 = blockIdx.y * 64, j0 = blockIdx.z * 16;
+    const int M = B * T, J = C * ld;
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+        const int mm = i >> 4, jj = i & 15;
+        const int m = m0 + mm, j = j0 + jj;
+        float v = 0.f;
+        if (m < M && j < J) {
+            const int c = j / ld, e = j - c * ld;
+            const int b = m / T, t = m - b * T;
+            const int tok = z[((size_t)b * C + c) * T + t];
+            v = tables[((size_t)c * V1 + tok) * ld + e];
+        }
+        lat[mm][jj] = v;
+    }
+    __syncthreads();
+    if (d >= D) return;
+    float acc[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) acc[jj] = 0.f;
+    const int mend = m0 + 64 < M ? 64 : M - m0;
+    for (int mm = 0; mm < mend; ++mm) {
+        const float g = dx[(size_t)(m0 + mm) * D + d];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) acc[jj] = fmaf(lat[mm][jj], g, acc[jj]);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj)
+        if (j0 + jj < J) partial[((size_t)blockIdx.y * J + j0 + jj) * D + d] = acc[jj];
+}
+
+// dMASK: one block per (c, e)
+__global__ __launch_bounds__(256) void vn_embed_dmask_kernel(const float* __restrict__ dx, const int32_t* __restrict__ z,
+                                                             const float* __restrict__ wt, float* __restrict__ dtables,
+                                                             int B, int C, int T, int V1, int ld, int D) {
+    __shared__ float red[4];
+    const int c = blockIdx.x / ld, e = blockIdx.x - c * ld;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* w = wt + (size_t)(c * ld + e) * D;
+    const int M = B * T;
+    float acc = 0.f;
+    for (int m = wave; m < M; m += 4) {            // one wave per masked row: dot(dx[m], w)
+        const int b = m / T, t = m - b * T;
+        if (z[((size_t)b * C + c) * T + t] != V1 - 1) continue;
+        const float* g = dx + (size_t)m * D;
+        for (int d = lane; d < D; d += 64) acc = fmaf(g[d], w[d], acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) dtables[((size_t)c * V1 + (V1 - 1)) * ld + e] = red[0] + red[1] + red[2] + red[3];
+}
+
+int vn_embed_bwd_partial_floats(int B, int T, int C, int ld, int D) { return vn_cdiv(B * T, 64) * C * ld * D; }
+
+int vn_launch_embed_bwd(vn_ctx* ctx, const float* dx, const int32_t* z, const float* tables, const float* wt, float* dtables,
+                        float* dwt, float* db, float* partial, int B, int C, int T, int V1, int ld, int D, hipStream_t s) {
+    const int M = B * T, J = C * ld, nb = vn_cdiv(M, 64);
+    hipLaunchKernelGGL(vn_embed_dwt_partial_kernel, dim3(vn_cdiv(D, 256), nb, vn_cdiv(J, 16)), dim3(256), 0, s, dx, z, tables,
+                       partial, B, C, T, V1, ld, D);
+    VN_LAUNCH_CHECK(ctx);
+    int rc = vn_launch_reduce_rows(ctx, partial, nb, J * D, dwt, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(vn_embed_dmask_kernel, dim3(J), dim3(256), 0, s, dx, z, wt, dtables, B, C, T, V1, ld, D);
+    VN_LAUNCH_CHECK(ctx);
+    return vn_launch_colsum(ctx, dx, M, D, partial, db, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Relative-position-bias gradient: the attention backward accumulates d(bias)[h][key - query + T - 1] over batch
+// items, query blocks and layers (the table is shared by all layers, transformer.py:291,402); bucket it back to
+// the [num_buckets][H] embedding (transformer.py:193-209).  One thread per (bucket, h).
+// ---------------------------------------------------------------------------------------------
+__global__ void vn_relbias_bwd_kernel(const float* __restrict__ dfull, const int32_t* __restrict__ lut, float* __restrict__ dtab,
+                                      int H, int T, int nbuckets) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbuckets * H) return;
+    const int bucket = i / H, h = i - bucket * H;
+    const int nb = 2 * T - 1;
+    double a = 0.0;
+    for (int r = 0; r < nb; ++r)
+        if (lut[r] == bucket) a += (double)dfull[(size_t)h * nb + r];
+    dtab[i] = (float)a;
+}
+
+int vn_launch_relbias_bwd(vn_ctx* ctx, const float* dfull, const int32_t* lut, float* dtab, int H, int T, int nbuckets,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(vn_relbias_bwd_kernel, dim3(vn_cdiv(nbuckets * H, 64)), dim3(64), 0, s, dfull, lut, dtab, H, T, nbuckets);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gradient norm + AdamW (train.py:296-299; torch.optim.AdamW defaults + clip_grad_norm_).
+//   norm  = ||gscale * g||_2 over the whole gradient vector (non-trainable / padding entries are zero)
+//   coef  = min(1, clip / (norm + 1e-6))
+//   p    <- p * (1 - lr*wd) ; m <- b1 m + (1-b1) g' ; v <- b2 v + (1-b2) g'^2 ; p <- p - lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+// The squared norm is reduced in double through fixed-size partials (deterministic), read by the update from
+// device memory: no host round trip between backward and update.
+// ---------------------------------------------------------------------------------------------
+#define VN_NORM_BLOCKS 1024
+__global__ __launch_bounds__(256) void vn_sumsq_partial_kernel(const float* __restrict__ g, long n4, double* __restrict__ partial) {
+    __shared__ double red[4];
+    double a = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
+        const f32x4 v = ((const f32x4*)g)[i];
+        a += (double)(v[0] * v[0] + v[1] * v[1]) + (double)(v[2] * v[2] + v[3] * v[3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(1024) void vn_sumsq_finish_kernel(const double* __restrict__ partial, int n, float gscale,
+                                                               float* __restrict__ norm_out) {
+    __shared__ double red[1024];
+    red[threadIdx.x] = (int)threadIdx.x < n ? partial[threadIdx.x] : 0.0;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *norm_out = (float)(sqrt(red[0]) * (double)gscale);
+}
+
+int vn_launch_grad_norm(vn_ctx* ctx, const float* g, long n, float gscale, double* partial, float* norm_out, hipStream_t s) {
+    if (n % 4) return vn_fail(ctx, VN_ERR_INVALID, "grad_norm: length %s%ld must be a multiple of 4", "", n);
+    hipLaunchKernelGGL(vn_sumsq_partial_kernel, dim3(VN_NORM_BLOCKS), dim3(256), 0, s, g, n / 4, partial);
+    hipLaunchKernelGGL(vn_sumsq_finish_kernel, dim3(1), dim3(1024), 0, s, partial, VN_NORM_BLOCKS, gscale, norm_out);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+__global__ __launch_bounds__(256) void vn_adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, long n, vn_adamw_args a,
+                                                       const float* __restrict__ norm) {
+    float coef = a.gscale;
+    if (a.clip > 0.f) {
+        const float c = a.clip / (*norm + 1e-6f);
+        coef *= c < 1.0f ? c : 1.0f;
+    }
+    const float decay = 1.0f - a.lr * a.weight_decay;
+    const float step = a.lr / a.bc1, s2 = sqrtf(a.bc2);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        const float gg = g[i] * coef;
+        const float mm = a.beta1 * m[i] + (1.0f - a.beta1) * gg;
+        const float vv = a.beta2 * v[i] + (1.0f - a.beta2) * gg * gg;
+        m[i] = mm;
+        v[i] = vv;
+        p[i] = p[i] * decay - step * (mm / (sqrtf(vv) / s2 + a.eps));
+    }
+}
+
+int vn_launch_adamw(vn_ctx* ctx, float* p, const float* g, float* m, float* v, long n, const vn_adamw_args& a,
+                    const float* norm, hipStream_t s) {
+    if (n <= 0) return VN_OK;
+    const long nb = (n + 255) / 256;
+    hipLaunchKernelGGL(vn_adamw_kernel, dim3((int)(nb < 16384 ? nb : 16384)), dim3(256), 0, s, p, g, m, v, n, a, norm);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// packed-layout helper: i32 tokens <- i64 (B,C,T) is vn_launch_i64_to_i32 (elementwise.hip)

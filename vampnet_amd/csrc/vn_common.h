@@ -22,6 +22,78 @@ __device__ __forceinline__ uint16_t vn_f32_to_bf16(float f) {
 #define VN_WAVE 64
 #define VN_DHEAD 64
 
+#ifdef __HIPCC__
+__device__ __forceinline__ uint4 vn_philox4x32_10(uint4 c, uint2 k) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+        const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += W0;
+        k.y += W1;
+    }
+    return c;
+}
+
+__device__ __forceinline__ float vn_gelu_tanh(float x) {
+    // activations.py:16-26: 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))
+    const float c = 0.7978845608028654f;
+    float x3 = x * x * x;
+    return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x3)));
+}
+#endif
+
+#ifdef __HIPCC__
+// exp(x) for x <= 0 with fp32-level accuracy at a third of ocml expf's instruction count: x*log2(e) is split into a
+// rounded product and its exact fma remainder (plus the constant's low part), v_exp_f32 evaluates 2^hi (1 ulp) and the
+// remainder is applied to first order (|lo| < 2^-22, so the dropped term is < 2^-45 relative).
+__device__ __forceinline__ float vn_exp_neg(float x) {
+    x = fmaxf(x, -104.0f);                                     // -inf (masked key / first tile) -> exp2(-150) = 0, no NaN
+    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f;
+    const float hi = x * L2E_HI;
+    const float lo = fmaf(x, L2E_HI, -hi) + x * L2E_LO;
+    const float e = __builtin_amdgcn_exp2f(hi);               // v_exp_f32; exp2(-inf) = 0, flushes below 2^-126
+    return fmaf(e, lo * 0.693147182464599609375f, e);
+}
+#endif
+
+// ---- training-mode dropout (train_kernels.hip, attention_train.hip) ---------------------------
+// Counter-based keep-mask that does not depend on launch geometry, layout or sharding: element (row, col) of a
+// dropout site is kept iff a 16-bit slice of  mix32(rowkey(row) ^ (col >> 1))  is >= thresh16 = round(p * 65536)
+// (two columns per hash: 32-bit integer multiplies are quarter rate on CDNA, Philox would cost more than the
+// attention MFMAs it sits between).  `row` is a GLOBAL row index (batch-sharded ranks draw disjoint streams);
+// `key` already mixes (seed, optimiser step, layer, site) on the host.  Scale is the nominal 1/(1-p), as torch's.
+struct vn_drop {
+    uint32_t key;        // host: vn_drop_key(seed, step, site)
+    uint32_t thresh16;   // 0 = dropout off (p == 0): kernels skip the hash
+    float scale;         // 1 / (1 - p)
+    long row0;           // global index of row 0 of this launch
+};
+static inline uint32_t vn_mix32_host(uint32_t x) {
+    x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
+    return x;
+}
+static inline uint32_t vn_drop_key(uint64_t seed, uint32_t step, uint32_t site) {
+    return vn_mix32_host((uint32_t)seed ^ vn_mix32_host((uint32_t)(seed >> 32) ^ vn_mix32_host(step * 0x9E3779B9u + site)));
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t vn_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
+    return x;
+}
+__device__ __forceinline__ uint32_t vn_drop_rowkey(const vn_drop& d, long row) {
+    const long g = d.row0 + row;
+    return vn_mix32((uint32_t)g ^ vn_mix32(d.key ^ (uint32_t)(g >> 32)));
+}
+// keep-multiplier (0 or scale) of column `col` given the row key
+__device__ __forceinline__ uint32_t vn_drop_bits(uint32_t rowkey, int col) { return vn_mix32(rowkey ^ (uint32_t)(col >> 1)); }
+__device__ __forceinline__ float vn_drop_mul(const vn_drop& d, uint32_t bits, int col) {
+    const uint32_t v = (col & 1) ? (bits >> 16) : (bits & 0xFFFFu);
+    return v >= d.thresh16 ? d.scale : 0.0f;
+}
+#endif
+
 struct vn_prof {
     bool on = false;
     int cap = 0, n = 0;

@@ -1,0 +1,44 @@
+// Internal declarations of the training-step kernels (train_kernels.hip, attention_train.hip) used by train.hip.
+#pragma once
+#include "vn_common.h"
+
+struct vn_adamw_args {
+    float lr, beta1, beta2, eps, weight_decay;
+    float bc1, bc2;      // 1 - beta^t
+    float gscale;        // 1 / world_size when the gradient vector holds a SUM over ranks, else 1
+    float clip;          // clip_grad_norm_ max norm (<= 0: off)
+};
+
+int vn_launch_resid_dropout(vn_ctx* ctx, const float* x_in, const float* y, float* x_out, int M, int N, const vn_drop& d,
+                            hipStream_t s);
+int vn_launch_dropout_bwd(vn_ctx* ctx, const float* dy, float* out, int M, int N, const vn_drop& d, hipStream_t s);
+int vn_launch_dropout_mask(vn_ctx* ctx, uint8_t* out, long rows, int cols, const vn_drop& d, hipStream_t s);
+int vn_launch_geglu_train(vn_ctx* ctx, const float* u, const float* dg, float* out, int M, int D2, const vn_drop& d,
+                          bool bwd, hipStream_t s);
+int vn_rmsnorm_bwd_blocks(int rows);
+int vn_launch_rmsnorm_bwd(vn_ctx* ctx, const float* x, const float* w, const float* dy, const float* dres, float* dx,
+                          float* dw, float* partial, int rows, int D, float eps, hipStream_t s);
+int vn_launch_reduce_rows(vn_ctx* ctx, const float* partial, int nb, int C, float* out, hipStream_t s);
+int vn_launch_transpose(vn_ctx* ctx, const float* src, float* dst, int R, int C, int lds_, int ldd, hipStream_t s);
+int vn_launch_colsum(vn_ctx* ctx, const float* src, int R, int C, float* partial, float* out, hipStream_t s);
+int vn_launch_cross_entropy(vn_ctx* ctx, float* logits, const int64_t* target, int32_t* t32, long rows, int V, float ls,
+                            int32_t* n_valid, float* row_loss, float* loss, hipStream_t s);
+int vn_launch_weight_norm_fold(vn_ctx* ctx, const float* g, const float* v, float* W, int rows, int D, hipStream_t s);
+int vn_launch_weight_norm_bwd(vn_ctx* ctx, const float* g, const float* v, const float* dW, float* dg, float* dv, int rows,
+                              int D, hipStream_t s);
+int vn_embed_bwd_partial_floats(int B, int T, int C, int ld, int D);
+int vn_launch_embed_bwd(vn_ctx* ctx, const float* dx, const int32_t* z, const float* tables, const float* wt, float* dtables,
+                        float* dwt, float* db, float* partial, int B, int C, int T, int V1, int ld, int D, hipStream_t s);
+int vn_launch_grad_norm(vn_ctx* ctx, const float* g, long n, float gscale, double* partial, float* norm_out, hipStream_t s);
+int vn_launch_adamw(vn_ctx* ctx, float* p, const float* g, float* m, float* v, long n, const vn_adamw_args& a,
+                    const float* norm, hipStream_t s);
+
+// attention_train.hip
+// forward with probability dropout; also writes lse[b][h][t] = log sum_k exp(score)   (transformer.py:234-254, :250)
+int vn_launch_attention_train_fwd(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* relbias_full,
+                                  float* out, float* lse, int B, int H, int T, const vn_drop& d, hipStream_t s);
+// backward: dqkv token-major [B*T][3*H*64] (columns: dq | dk | dv, head-major inside each), dbias [num_buckets][H]
+// accumulated with atomics (shared by all layers), delta scratch [B][H][T]
+int vn_launch_attention_bwd(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* relbias_full,
+                            const int32_t* lut_dev, const float* out, const float* dout, const float* lse, float* delta,
+                            float* dqkv, float* dbias_tab, int B, int H, int T, int nbuckets, const vn_drop& d, hipStream_t s);

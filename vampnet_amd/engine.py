@@ -200,7 +200,7 @@ class VampNetModel:
 
     def __init__(self, engine: Engine, sd: dict, codebooks: torch.Tensor, *, n_heads, n_layers, n_codebooks,
                  n_conditioning_codebooks=0, latent_dim=8, embedding_dim=1280, vocab_size=1024,
-                 max_batch=8, max_T=575, chunk_size_s=10, precision="f32", **_ignored):
+                 max_batch=8, max_T=575, chunk_size_s=10, precision="f32", _blob=None, **_ignored):
         self.engine = engine
         self.lib = engine.lib
         self.n_heads, self.n_layers = n_heads, n_layers
@@ -212,8 +212,10 @@ class VampNetModel:
         self.chunk_size_s = chunk_size_s
         self.dims = vn_dims(n_layers, n_heads, embedding_dim, n_codebooks, n_conditioning_codebooks, vocab_size,
                             latent_dim, 32, 128, 1e-6, max_batch, max_T)
-        blob = pack_weights(self.lib, self.dims, sd, codebooks)
-        self.blob = blob.to(engine.device)               # must outlive the vn_model
+        if _blob is not None:        # vampnet_amd.train.Trainer: the model lives on the prefix of the train vector
+            self.blob = _blob
+        else:
+            self.blob = pack_weights(self.lib, self.dims, sd, codebooks).to(engine.device)   # must outlive the vn_model
         h = C.c_void_p()
         engine.check(self.lib.vn_model_create(engine.handle, C.byref(self.dims), self.blob.data_ptr(), C.byref(h)),
                      "vn_model_create")

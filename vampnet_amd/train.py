@@ -1,0 +1,222 @@
+"""Training step of one VampNet on the HIP engine — the twin of `train_loop` in the reference's
+scripts/exp/train.py:237-304 (mask -> forward in train() mode -> label-smoothed CE -> backward -> clip -> AdamW ->
+NoamScheduler), for the token-level part of the loop (the codec encode in front of it is `Interface.encode`).
+
+All arithmetic runs in libvampnet_hip.so (vn_train_* in include/vampnet_hip.h); this file only builds masks/targets
+with torch tensor ops on the device, keeps the four flat state buffers (parameters, gradients, Adam moments) and, in a
+data-parallel job, all-reduces the gradient buffer over RCCL between backward and update.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib, masks
+from ._lib import VnError, vn_dims, vn_train_params
+from .engine import Engine, VampNetModel, pack_weights
+
+IGNORE_INDEX = -100           # train.py:68
+SITES = {"attn": 0, "res1": 1, "ffn": 2, "res2": 3}
+
+
+def noam_lr(step: int, d_model: int, factor: float = 2.0, warmup: int = 10000) -> float:
+    """vampnet/scheduler.py:38-46 (conf/vampnet.yml:21-22) at `steps == step`."""
+    return factor * (d_model ** (-0.5) * min(step ** (-0.5), step * warmup ** (-1.5)))
+
+
+class Trainer:
+    """Holds model + optimiser + scheduler state of train.py's `State` for one VampNet.
+
+    `state_dict` uses the reference's parameter names; `loralib` adapters, if present, are merged at load
+    (every VampNet parameter is then trained, see include/vampnet_hip.h "training step")."""
+
+    def __init__(self, engine: Engine, sd: dict, codebooks: torch.Tensor, *, n_heads, n_layers, n_codebooks,
+                 n_conditioning_codebooks=0, latent_dim=8, embedding_dim=1280, vocab_size=1024, max_batch=8, max_T=575,
+                 lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_clip=5.0, label_smoothing=0.1,
+                 dropout=0.1, noam_factor=2.0, noam_warmup=10000, use_noam=True, seed=0, process_group=None,
+                 batch_offset=0, **_ignored):
+        self.engine, self.lib = engine, engine.lib
+        self.dims = vn_dims(n_layers, n_heads, embedding_dim, n_codebooks, n_conditioning_codebooks, vocab_size,
+                            latent_dim, 32, 128, 1e-6, max_batch, max_T)
+        self.n_codebooks, self.n_cond, self.vocab, self.D = n_codebooks, n_conditioning_codebooks, vocab_size, embedding_dim
+        self.Cp = n_codebooks - n_conditioning_codebooks
+        self.mask_token = vocab_size
+        self.hp = dict(lr=lr, beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay, grad_clip=grad_clip,
+                       label_smoothing=label_smoothing, dropout=dropout)
+        self.noam = (noam_factor, noam_warmup) if use_noam else None
+        self.seed, self.pg, self.batch_offset = seed, process_group, batch_offset
+        self.steps = 0
+        n = C.c_int64()
+        engine.check(self.lib.vn_train_param_size(C.byref(self.dims), C.byref(n)), "vn_train_param_size")
+        self.n_total = n.value
+        host = torch.zeros(self.n_total, dtype=torch.float32)
+        blob = pack_weights(self.lib, self.dims, sd, codebooks)
+        self.wsize = blob.numel()
+        host[:self.wsize] = blob
+        og, ov = self._cls_offsets()
+        V, Cp, D = vocab_size, self.Cp, embedding_dim
+        g = sd["classifier.layers.0.weight_g"].float().reshape(V, Cp).t().reshape(-1)            # (p c) -> (c p)
+        v = sd["classifier.layers.0.weight_v"].float().reshape(V, Cp, D).permute(1, 0, 2).reshape(-1)
+        host[og:og + g.numel()] = g
+        host[ov:ov + v.numel()] = v
+        dev = engine.device
+        self.params = host.to(dev)
+        self.grads = torch.zeros_like(self.params)
+        self.adam_m = torch.zeros_like(self.params)
+        self.adam_v = torch.zeros_like(self.params)
+        self.loss = torch.zeros(1, device=dev)
+        self.grad_norm = torch.zeros(1, device=dev)
+        # inference view of the same weights (generate / forward share the blob the optimiser updates)
+        self.model = VampNetModel(engine, sd, codebooks, n_heads=n_heads, n_layers=n_layers, n_codebooks=n_codebooks,
+                                  n_conditioning_codebooks=n_conditioning_codebooks, latent_dim=latent_dim,
+                                  embedding_dim=embedding_dim, vocab_size=vocab_size, max_batch=max_batch, max_T=max_T,
+                                  _blob=self.params)
+        h = C.c_void_p()
+        engine.check(self.lib.vn_train_create(self.model.handle, self.params.data_ptr(), C.byref(h)), "vn_train_create")
+        self.handle = h
+        engine.check(self.lib.vn_train_sync(self.handle, engine.stream()), "vn_train_sync")
+        self._sd_template = {k: (tuple(t.shape), t.dtype) for k, t in sd.items()}
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.vn_train_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def _cls_offsets(self):
+        off, cnt = C.c_int64(), C.c_int64()
+        out = []
+        for which in (0, 1):
+            self.engine.check(self.lib.vn_train_param_offset(C.byref(self.dims), which, C.byref(off), C.byref(cnt)),
+                              "vn_train_param_offset")
+            out.append(off.value)
+        return out
+
+    def _tp(self, step, lr=None, dropout=None):
+        hp = self.hp
+        ws = 1
+        if self.pg is not None:
+            import torch.distributed as dist
+            ws = dist.get_world_size(self.pg)
+        return vn_train_params(hp["lr"] if lr is None else lr, hp["beta1"], hp["beta2"], hp["eps"], hp["weight_decay"],
+                               hp["grad_clip"], hp["label_smoothing"], hp["dropout"] if dropout is None else dropout,
+                               self.seed, step, self.batch_offset, ws)
+
+    # ---- pieces of train_loop ------------------------------------------------------------------
+    def make_batch(self, z: torch.Tensor, r: torch.Tensor = None, mask: torch.Tensor = None, generator=None):
+        """train.py:250-278: (z_mask, target) from clean tokens z (B,C,T) and either mask ratios r (B,) or a mask."""
+        z = z.to(self.engine.device, torch.int64)
+        if mask is None:
+            probs = torch.ones_like(z, dtype=torch.float32) * masks.gamma(r.to(z.device).float())[:, None, None]
+            mask = torch.bernoulli(probs, generator=generator).round().long()          # mask.py:40-54
+        mask = mask.to(z.device).clone()
+        mask[:, :self.n_cond, :] = 0                                                    # codebook_unmask (mask.py:151-158)
+        z_mask, mask = masks.apply_mask(z, mask, self.mask_token)
+        target = z[:, self.n_cond:, :].permute(0, 2, 1).reshape(z.shape[0], -1)        # "b c t -> b (t c)" (util.py:35-40)
+        flat = mask[:, self.n_cond:, :].permute(0, 2, 1).reshape(z.shape[0], -1)
+        target = target.masked_fill(~flat.bool(), IGNORE_INDEX)
+        return z_mask.contiguous(), target.contiguous()
+
+    def forward_backward(self, z_mask, target, step=None, dropout=None):
+        """Fills self.grads / self.loss for this rank's batch (no update)."""
+        B, Cn, T = z_mask.shape
+        assert Cn == self.n_codebooks and target.shape == (B, T * self.Cp)
+        tp = self._tp(self.steps + 1 if step is None else step, dropout=dropout)
+        self.engine.check(self.lib.vn_train_forward_backward(
+            self.handle, z_mask.data_ptr(), target.data_ptr(), B, T, C.byref(tp), self.grads.data_ptr(),
+            self.loss.data_ptr(), self.engine.stream()), "vn_train_forward_backward")
+        return self.loss
+
+    def forward(self, z_mask, step=None, dropout=None):
+        """train()-mode logits [B, V, T*Cp] in the reference layout (transformer.py:634)."""
+        B, Cn, T = z_mask.shape
+        logits = torch.empty(B, T, self.Cp, self.vocab, device=self.engine.device, dtype=torch.float32)
+        tp = self._tp(self.steps + 1 if step is None else step, dropout=dropout)
+        self.engine.check(self.lib.vn_train_forward(self.handle, z_mask.data_ptr(), B, T, C.byref(tp), logits.data_ptr(),
+                                                    self.engine.stream()), "vn_train_forward")
+        return logits.permute(0, 3, 1, 2).reshape(B, self.vocab, T * self.Cp)
+
+    def update(self):
+        """(all-reduce) -> clip -> AdamW -> scheduler.step(); advances self.steps."""
+        if self.pg is not None:
+            import torch.distributed as dist
+            dist.all_reduce(self.grads, group=self.pg)                 # SUM; the update kernel divides by world_size
+            dist.all_reduce(self.loss, group=self.pg)
+            self.loss /= dist.get_world_size(self.pg)
+        step = self.steps + 1
+        lr = noam_lr(step, self.D, *self.noam) if self.noam else self.hp["lr"]
+        tp = self._tp(step, lr=lr)
+        self.engine.check(self.lib.vn_train_update(self.handle, self.grads.data_ptr(), self.adam_m.data_ptr(),
+                                                   self.adam_v.data_ptr(), C.byref(tp), self.grad_norm.data_ptr(),
+                                                   self.engine.stream()), "vn_train_update")
+        self.steps = step
+        self.last_lr = lr
+        return self.grad_norm
+
+    def step(self, z, r=None, mask=None, generator=None):
+        """One train_loop iteration; returns device scalars (no host sync): loss, grad_norm, and the lr used."""
+        z_mask, target = self.make_batch(z, r, mask, generator)
+        self.forward_backward(z_mask, target)
+        self.update()
+        return {"loss": self.loss, "other/grad_norm": self.grad_norm, "other/learning_rate": self.last_lr,
+                "other/batch_size": z.shape[0]}
+
+    # ---- debugging / parity helpers ---------------------------------------------------------------
+    def dropout_keep_mask(self, layer, site, B, T, step=None, p=None):
+        """The keep-mask of one dropout site in the REFERENCE tensor layout: attn (H,B,T,T); res1/res2 (B,T,D); ffn (B,T,2D)."""
+        H = self.dims.n_heads
+        p = self.hp["dropout"] if p is None else p
+        step = self.steps + 1 if step is None else step
+        if site == "attn":
+            rows, cols, row0 = B * H * T, T, self.batch_offset * H * T
+        else:
+            rows, cols, row0 = B * T, (2 * self.D if site == "ffn" else self.D), self.batch_offset * T
+        out = torch.empty(rows, cols, dtype=torch.uint8, device=self.engine.device)
+        self.engine.check(self.lib.vn_dropout_keep_mask(self.engine.handle, self.seed, step, layer, SITES[site], p, row0,
+                                                        rows, cols, out.data_ptr(), self.engine.stream()),
+                          "vn_dropout_keep_mask")
+        if site == "attn":
+            return out.view(B, H, T, T).permute(1, 0, 2, 3).float()
+        return out.view(B, T, cols).float()
+
+    def _tensor(self, buf, tid, layer=0):
+        off, cnt = C.c_int64(), C.c_int64()
+        self.engine.check(self.lib.vn_weights_offset(C.byref(self.dims), tid, layer, C.byref(off), C.byref(cnt)),
+                          "vn_weights_offset")
+        return buf[off.value:off.value + cnt.value]
+
+    def export(self, buf=None) -> dict:
+        """Unpacks a train-vector buffer (default: the parameters) into the reference's state_dict naming — the inverse of
+        engine.pack_weights (+ classifier weight_g / weight_v).  Used for checkpoints (`weights.pth` payload) and tests."""
+        buf = (self.params if buf is None else buf).detach().cpu()
+        d, D, V, Cp, Cn, L = self.dims, self.D, self.vocab, self.Cp, self.n_codebooks, self.dims.n_layers
+        ld = d.latent_dim
+        out = {}
+        tables = self._tensor(buf, _lib.W_EMB_TABLES).view(Cn, V + 1, ld)
+        out["embedding.special.MASK"] = tables[:, V, :].clone()
+        out["embedding.out_proj.weight"] = self._tensor(buf, _lib.W_EMB_WT).view(Cn * ld, D).t().unsqueeze(-1).clone()
+        out["embedding.out_proj.bias"] = self._tensor(buf, _lib.W_EMB_B).clone()
+        out["transformer.layers.0.self_attn.relative_attention_bias.weight"] = self._tensor(buf, _lib.W_REL_BIAS).view(32, d.n_heads).clone()
+        out["transformer.norm.weight"] = self._tensor(buf, _lib.W_FINAL_NORM).clone()
+        og, ov = self._cls_offsets()
+        out["classifier.layers.0.weight_g"] = buf[og:og + Cp * V].view(Cp, V).t().reshape(V * Cp, 1, 1).clone()
+        out["classifier.layers.0.weight_v"] = buf[ov:ov + Cp * V * D].view(Cp, V, D).permute(1, 0, 2).reshape(V * Cp, D, 1).clone()
+        out["classifier.layers.0.bias"] = self._tensor(buf, _lib.W_CLS_B).view(Cp, V).t().reshape(-1).clone()
+        for l in range(L):
+            p = f"transformer.layers.{l}."
+            out[p + "norm_1.weight"] = self._tensor(buf, _lib.W_NORM1, l).clone()
+            qkv = self._tensor(buf, _lib.W_QKV, l).view(3, D, D)
+            out[p + "self_attn.w_qs.weight"] = qkv[0].clone()
+            out[p + "self_attn.w_ks.weight"] = qkv[1].clone()
+            out[p + "self_attn.w_vs.weight"] = qkv[2].clone()
+            out[p + "self_attn.fc.weight"] = self._tensor(buf, _lib.W_WO, l).view(D, D).clone()
+            out[p + "norm_3.weight"] = self._tensor(buf, _lib.W_NORM3, l).clone()
+            w1 = self._tensor(buf, _lib.W_W1, l).view(2 * D // 32, 2, 32, D)
+            out[p + "feed_forward.w_1.weight"] = torch.cat([w1[:, 0].reshape(2 * D, D), w1[:, 1].reshape(2 * D, D)], 0)
+            out[p + "feed_forward.w_2.weight"] = self._tensor(buf, _lib.W_W2, l).view(D, 2 * D).clone()
+        return out
+
+    def state_dict(self) -> dict:
+        return self.export(self.params)
