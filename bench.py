@@ -67,6 +67,96 @@ def cpu_baseline(threads=None):
                       f"(B=1,T=173, {out['c2f']:.3f} s/step), extrapolated to 12+8 steps = {clip_s:.2f} s/clip"}
 
 
+def cpu_baseline_train(threads=16):
+    """BASELINE configs[4] on the host: one train_loop iteration of the coarse model (B=1, T=575) through the oracle
+    (torch-CPU fp32 autograd + clip + AdamW), dropout 0.1."""
+    from oracle import train_oracle as TO          # CPU baseline leg only
+    from vampnet_amd import synth as W
+    torch.set_num_threads(min(threads, os.cpu_count() or threads))
+    dims = W.COARSE_DIMS
+    sd, cb = W.synth_state_dict(dims, 0), W.synth_codebooks()
+    z = W.synth_codes(1, 4, 575, seed=2)
+    g = torch.Generator().manual_seed(0)
+    mask = TO.make_training_mask(z, torch.tensor([0.6]), 0, generator=g)
+    masks = TO.draw_dropout_masks(dims, 1, 575, 0.1, g)
+    state, times = {}, []
+    for it in range(2):                               # first iteration = warm-up
+        t0 = time.perf_counter()
+        _, grads, _ = TO.loss_and_grads(sd, dims, cb, z, mask, masks, 0.1)
+        sd, _ = TO.clip_and_adamw(sd, grads, state, TO.noam_lr(it + 1, dims["d_model"]))
+        times.append(time.perf_counter() - t0)
+    return {"value": 4 * 575 / times[-1], "unit": "codec-tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle train step (forward+CE+autograd backward+clip+AdamW), coarse model, B=1, T=575: {times[-1]:.2f} s"}
+
+
+def bench_train(args, rank, world, device, pg, barrier):
+    """BASELINE configs[4]: conf/vampnet.yml training step of the coarse model on synthetic DAC tokens, batch 8 per GPU,
+    gradient all-reduce on RCCL.  A "step" = mask -> forward (dropout 0.1) -> CE(label_smoothing 0.1) -> backward ->
+    all-reduce -> clip 5.0 -> AdamW -> Noam.  value = masked-LM tokens consumed per second over all ranks."""
+    from vampnet_amd import synth as W
+    from vampnet_amd.engine import Engine
+    from vampnet_amd.synth import model_kwargs
+    from vampnet_amd.train import Trainer
+    dims = W.COARSE_DIMS
+    Bg, T = args.batch_per_gpu, 575
+    eng = Engine(device)
+    tr = Trainer(eng, W.synth_state_dict(dims, 0), W.synth_codebooks(), **model_kwargs(dims), max_batch=Bg, max_T=T,
+                 dropout=0.1, label_smoothing=0.1, grad_clip=5.0, lr=1e-3, process_group=pg, batch_offset=rank * Bg, seed=0)
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    z = torch.randint(0, 1024, (Bg, 4, T), device=device, generator=gen)
+    rs = torch.rand(args.warmup + args.steps, Bg, device=device, generator=gen)
+
+    for i in range(args.warmup):
+        tr.step(z, r=rs[i], generator=gen)
+    barrier()
+    if not args.no_kernel_events:
+        eng.profile_begin(1200 * max(args.steps, 1))
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = tr.step(z, r=rs[args.warmup + i], generator=gen)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_end() if not args.no_kernel_events else None
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    eng.health_check()
+    loss = float(out["loss"].item())
+    assert loss == loss and loss < 20.0, loss
+    if rank != 0:
+        return
+    tokens = world * Bg * 4 * T * args.steps
+    fwd_gflop = 416.76                                     # SURVEY.md section 8(d): coarse forward per item
+    step_tflop = 3.0 * fwd_gflop * Bg / 1e3                # forward + dX + dW of every product
+    res = {"metric": "codec-tokens/s, conf/vampnet.yml training step (coarse model)", "value": tokens / elapsed,
+           "unit": "codec-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic (random-init weights of the real architecture, random DAC tokens, r ~ U(0,1))",
+           "config": {"workload": "BASELINE configs[4]: conf/vampnet.yml training step, coarse VampNet (20 layers, d=1280), "
+                                  f"batch {Bg}/GPU x T=575 x 4 codebooks, dropout 0.1, label smoothing 0.1, clip 5.0, "
+                                  "AdamW + Noam, fp32 (amp: false)",
+                      "global_batch": world * Bg, "parallelism": f"dp{world}" if world > 1 else "single GPU",
+                      "step_tflop_per_gpu": step_tflop, "achieved_tflops_per_gpu": step_tflop / (elapsed / args.steps),
+                      "final_loss": loss}}
+    if prof is not None:
+        n, ms, fl, by = prof["gemm"]
+        an, ams, afl, _ = prof["attention"]
+        res["roofline"] = {"bound": "mfma", "kernel": "vn_gemm_f32[_sk]_kernel", "achieved": fl / (ms * 1e-3) / 1e12 if ms else None,
+                           "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+                           "frac": fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF if ms else None, "traffic": None,
+                           "algorithmic_bytes_per_launch": by / n if n else None, "launches": int(n),
+                           "avg_launch_us": 1e3 * ms / n if n else None,
+                           "gemm_time_frac": ms / (1e3 * elapsed) if elapsed else None,
+                           "attention": {"launches": int(an), "avg_launch_us": 1e3 * ams / an if an else None,
+                                         "achieved": afl / (ams * 1e-3) / 1e12 if ams else None,
+                                         "time_frac": ams / (1e3 * elapsed)}}
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_train()
+    print(json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +167,8 @@ def main():
     ap.add_argument("--coarse-only", action="store_true", help="BASELINE configs[1]: coarse_vamp only (4 codebooks)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 = exact-fp32 MFMA (parity-backed default); bf16 = fast mode, not bit-exact")
+    ap.add_argument("--workload", choices=["vamp", "train"], default="vamp",
+                    help="vamp = the headline inference path (default); train = BASELINE configs[4] training step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -102,6 +194,19 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device(device))     # "nccl" is RCCL on ROCm
         pg = dist.group.WORLD
+
+    if args.workload == "train":
+        def _barrier():
+            torch.cuda.synchronize()
+            if world > 1:
+                import torch.distributed as dist
+                dist.barrier()
+            torch.cuda.synchronize()
+        bench_train(args, rank, world, device, pg, _barrier)
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
 
     from vampnet_amd import synth as W         # synthetic weights / inputs (data generators only)
     from vampnet_amd.interface import Interface

@@ -270,6 +270,10 @@ int  vn_train_update(vn_train* tr, const float* grads, float* adam_m, float* ada
 int  vn_dropout_keep_mask(vn_ctx* ctx, uint64_t seed, int64_t step, int layer, int site, float p, int64_t row0,
                           int64_t rows, int cols, uint8_t* out, void* stream);
 
+/* dst [C][ldd] = transpose(src [R][C]), columns R..ldd-1 zero-filled (ldd % 4 == 0): the layout pass in front of the
+ * weight-gradient GEMMs; exposed for tests and tuning.                                                              */
+int  vn_transpose_f32(vn_ctx* ctx, const float* src, float* dst, int R, int C, int ldd, void* stream);
+
 /* tuning hook (scripts/gemm_sweep.py): force the GEMM block tile (bm x bn in {128,64}^2; 0,0 = automatic) and the
  * tile walk order (0 column-major, 1 grouped 8-row patches, -1 keep).  Process-global; not for production use.   */
 int vn_debug_gemm_config(int bm, int bn, int order);

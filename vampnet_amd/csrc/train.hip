@@ -290,7 +290,7 @@ static int backward(vn_train* t, int B, int T, const vn_train_params* p, float* 
     }
     // ---- codebook embedding (layers.py:134-163)
     return vn_launch_embed_bwd(ctx, dx, m->z, P(t, VN_W_EMB_TABLES), P(t, VN_W_EMB_WT), G(t, grads, VN_W_EMB_TABLES),
-                               G(t, grads, VN_W_EMB_WT), G(t, grads, VN_W_EMB_B), t->partial, B, m->d.n_codebooks, T,
+                               G(t, grads, VN_W_EMB_WT), G(t, grads, VN_W_EMB_B), t->partial, t->du, B, m->d.n_codebooks, T,
                                m->d.vocab + 1, m->d.latent_dim, D, s);
 }
 
@@ -368,4 +368,10 @@ extern "C" int vn_dropout_keep_mask(vn_ctx* ctx, uint64_t seed, int64_t step, in
     vn_train_params tp{};
     tp.seed = seed; tp.step = step; tp.dropout = p;
     return vn_launch_dropout_mask(ctx, out, rows, cols, make_drop(&tp, layer, site, row0), (hipStream_t)stream);
+}
+
+// single-kernel entry point (tests / tuning): dst [C][ldd] <- src [R][C]^T, columns R..ldd-1 zero-filled
+extern "C" int vn_transpose_f32(vn_ctx* ctx, const float* src, float* dst, int R, int C, int ldd, void* stream) {
+    if (!ctx || !src || !dst) return VN_ERR_INVALID;
+    return vn_launch_transpose(ctx, src, dst, R, C, C, ldd, (hipStream_t)stream);
 }

@@ -555,40 +555,60 @@ __global__ __launch_bounds__(256) void vn_embed_dwt_partial_kernel(const float* 
         if (j0 + jj < J) partial[((size_t)blockIdx.y * J + j0 + jj) * D + d] = acc[jj];
 }
 
-// dMASK: one block per (c, e)
-__global__ __launch_bounds__(256) void vn_embed_dmask_kernel(const float* __restrict__ dx, const int32_t* __restrict__ z,
-                                                             const float* __restrict__ wt, float* __restrict__ dtables,
-                                                             int B, int C, int T, int V1, int ld, int D) {
-    __shared__ float red[4];
-    const int c = blockIdx.x / ld, e = blockIdx.x - c * ld;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* w = wt + (size_t)(c * ld + e) * D;
-    const int M = B * T;
-    float acc = 0.f;
-    for (int m = wave; m < M; m += 4) {            // one wave per masked row: dot(dx[m], w)
-        const int b = m / T, t = m - b * T;
-        if (z[((size_t)b * C + c) * T + t] != V1 - 1) continue;
-        const float* g = dx + (size_t)m * D;
-        for (int d = lane; d < D; d += 64) acc = fmaf(g[d], w[d], acc);
-    }
+// dlat[m][c*ld+e] = (z[m,c] == MASK) ? dx[m] . Wt[c*ld+e] : 0     one wave per row; column sums of dlat = dMASK
+__global__ __launch_bounds__(256) void vn_embed_dlat_kernel(const float* __restrict__ dx, const int32_t* __restrict__ z,
+                                                            const float* __restrict__ wt, float* __restrict__ dlat, int B,
+                                                            int C, int T, int V1, int ld, int D) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int M = B * T, J = C * ld;
+    if (m >= M) return;
+    const int b = m / T, t = m - b * T;
+    const f32x4* g = (const f32x4*)(dx + (size_t)m * D);
+    const int nv = D >> 2;
+    for (int c = 0; c < C; ++c) {
+        const bool masked = z[((size_t)b * C + c) * T + t] == V1 - 1;      // wave-uniform
+        for (int e = 0; e < ld; ++e) {
+            float acc = 0.f;
+            if (masked) {
+                const f32x4* w = (const f32x4*)(wt + (size_t)(c * ld + e) * D);
+                for (int i = lane; i < nv; i += 64) {
+                    const f32x4 a = g[i], bb = w[i];
+                    acc += a[0] * bb[0] + a[1] * bb[1] + a[2] * bb[2] + a[3] * bb[3];
+                }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) red[wave] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) dtables[((size_t)c * V1 + (V1 - 1)) * ld + e] = red[0] + red[1] + red[2] + red[3];
+                for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            }
+            if (lane == 0) dlat[(size_t)m * J + c * ld + e] = acc;
+        }
+    }
+}
+
+// dtables[c][V1-1][e] = colsum[c*ld+e]
+__global__ void vn_embed_dmask_scatter_kernel(const float* __restrict__ colsum, float* __restrict__ dtables, int C, int V1,
+                                              int ld) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= C * ld) return;
+    const int c = j / ld, e = j - c * ld;
+    dtables[((size_t)c * V1 + (V1 - 1)) * ld + e] = colsum[j];
 }
 
 int vn_embed_bwd_partial_floats(int B, int T, int C, int ld, int D) { return vn_cdiv(B * T, 64) * C * ld * D; }
 
 int vn_launch_embed_bwd(vn_ctx* ctx, const float* dx, const int32_t* z, const float* tables, const float* wt, float* dtables,
-                        float* dwt, float* db, float* partial, int B, int C, int T, int V1, int ld, int D, hipStream_t s) {
+                        float* dwt, float* db, float* partial, float* dlat /* [B*T*C*ld + C*ld] scratch */, int B, int C, int T,
+                        int V1, int ld, int D, hipStream_t s) {
     const int M = B * T, J = C * ld, nb = vn_cdiv(M, 64);
     hipLaunchKernelGGL(vn_embed_dwt_partial_kernel, dim3(vn_cdiv(D, 256), nb, vn_cdiv(J, 16)), dim3(256), 0, s, dx, z, tables,
                        partial, B, C, T, V1, ld, D);
     VN_LAUNCH_CHECK(ctx);
     int rc = vn_launch_reduce_rows(ctx, partial, nb, J * D, dwt, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(vn_embed_dmask_kernel, dim3(J), dim3(256), 0, s, dx, z, wt, dtables, B, C, T, V1, ld, D);
+    hipLaunchKernelGGL(vn_embed_dlat_kernel, dim3(vn_cdiv(M, 4)), dim3(256), 0, s, dx, z, wt, dlat, B, C, T, V1, ld, D);
+    VN_LAUNCH_CHECK(ctx);
+    float* colsum = dlat + (size_t)M * J;
+    if ((rc = vn_launch_colsum(ctx, dlat, M, J, partial, colsum, s))) return rc;
+    hipLaunchKernelGGL(vn_embed_dmask_scatter_kernel, dim3(vn_cdiv(J, 64)), dim3(64), 0, s, colsum, dtables, C, V1, ld);
     VN_LAUNCH_CHECK(ctx);
     return vn_launch_colsum(ctx, dx, M, D, partial, db, s);
 }
