@@ -271,7 +271,15 @@ __global__ __launch_bounds__(256) void vn_attention_bwd_dq_kernel(
                     dpacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(vfa[u][e], dof[s][e], dpacc[u], 0, 0, 0);
                 }
         }
-        // dS^T for this lane's query and keys kt*64 + 16u + 4g + r
+        // dS^T for this lane's query and keys kt*64 + 16u + 4g + r.
+        // Bias gradient: a tile whose whole key-query range falls into ONE bucket (every tile 3+ tiles off the diagonal
+        // at max_distance 128) is summed in a register and costs one LDS atomic per wave; only near-diagonal tiles pay
+        // per-element LDS atomics into the key-query table.
+        const int rel_lo = kt * ATT_KT - (qb * 64 + 63), rel_hi = kt * ATT_KT + 63 - qb * 64;
+        const int lo_c = rel_lo < -(T - 1) ? -(T - 1) : rel_lo, hi_c = rel_hi > T - 1 ? T - 1 : rel_hi;
+        const int far_bucket = lut[lo_c + T - 1];
+        const bool far = (rel_lo > 0 || rel_hi < 0) && far_bucket == lut[hi_c + T - 1];     // block-uniform
+        float far_sum = 0.f;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int key0 = kt * ATT_KT + u * 16 + 4 * g;
@@ -282,12 +290,18 @@ __global__ __launch_bounds__(256) void vn_attention_bwd_dq_kernel(
                 const int key = key0 + r;
                 const int key_c = key < T ? key : T - 1;
                 const float x = sacc[u][r] * 0.125f + bt[key_c - qrow_c + (T - 1)];
-                const float p = key < T ? vn_exp_neg(x - my_lse) : 0.f;
+                const float p = (key < T && qrow < T) ? vn_exp_neg(x - my_lse) : 0.f;
                 const float mul = d.thresh16 ? vn_drop_mul(d, r < 2 ? b0 : b1, r) : 1.0f;
                 const float ds = p * (dpacc[u][r] * mul - dl);
                 sacc[u][r] = ds;
-                if (key < T && qrow < T) atomicAdd(&dbt[key - qrow + (T - 1)], ds);
+                if (far) far_sum += ds;
+                else if (key < T && qrow < T) atomicAdd(&dbt[key - qrow + (T - 1)], ds);
             }
+        }
+        if (far) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) far_sum += __shfl_xor(far_sum, o);
+            if (lane == 0) atomicAdd(&bk[far_bucket], far_sum);
         }
         // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
 #pragma unroll

@@ -235,18 +235,21 @@ __global__ __launch_bounds__(256) void vn_rmsnorm_bwd_kernel(const float* __rest
     }
 }
 
-// out[c] = sum_b partial[b][c]   (fixed order)
+// out[c] = sum_b partial[b][c]   (fixed order: 4 interleaved row groups, then group 0 + 1 + 2 + 3)
 __global__ __launch_bounds__(256) void vn_reduce_rows_kernel(const float* __restrict__ partial, int nb, int C,
                                                              float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
     float a = 0.f;
-    for (int b = 0; b < nb; ++b) a += partial[(size_t)b * C + c];
-    out[c] = a;
+    if (c < C)
+        for (int b = part; b < nb; b += 4) a += partial[(size_t)b * C + c];
+    red[part][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (part == 0 && c < C) out[c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
 int vn_launch_reduce_rows(vn_ctx* ctx, const float* partial, int nb, int C, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(vn_reduce_rows_kernel, dim3(vn_cdiv(C, 256)), dim3(256), 0, s, partial, nb, C, out);
+    hipLaunchKernelGGL(vn_reduce_rows_kernel, dim3(vn_cdiv(C, 64)), dim3(256), 0, s, partial, nb, C, out);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
 }
