@@ -270,6 +270,14 @@ int  vn_train_update(vn_train* tr, const float* grads, float* adam_m, float* ada
 int  vn_dropout_keep_mask(vn_ctx* ctx, uint64_t seed, int64_t step, int layer, int site, float p, int64_t row0,
                           int64_t rows, int cols, uint8_t* out, void* stream);
 
+/* Training attention as a single op (tests / tuning): forward with probability dropout (keep-mask = site 0, layer 0,
+ * step 1 of vn_dropout_keep_mask) writing out [B][T][H*64] and lse [B][H][T]; when `dout` is non-NULL also the backward:
+ * dqkv [B*T][3*H*64] (dq | dk | dv, head-major inside each third) and dbias [num_buckets][H] ACCUMULATED into.
+ * Synchronous.  (transformer.py:234-254 and its autograd.)                                                          */
+int  vn_attention_train_f32(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                            float* out, float* lse, const float* dout, float* dqkv, float* dbias, int B, int H, int T,
+                            int num_buckets, int max_distance, float dropout, uint64_t seed, void* stream);
+
 /* dst [C][ldd] = transpose(src [R][C]), columns R..ldd-1 zero-filled (ldd % 4 == 0): the layout pass in front of the
  * weight-gradient GEMMs; exposed for tests and tuning.                                                              */
 int  vn_transpose_f32(vn_ctx* ctx, const float* src, float* dst, int R, int C, int ldd, void* stream);

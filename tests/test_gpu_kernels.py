@@ -121,3 +121,60 @@ def test_gemm_bf16_fast_mode(eng, M, N, K):
     out = c0.cuda().clone()
     eng.gemm_bf16(a16.cuda(), w16.cuda(), epilogue=_lib.EPI_RESIDUAL, out=out)
     assert np.all(np.abs((out.cpu().double() - (ref + c0.double())).numpy()) <= tol)
+
+
+# ----------------------------------------------------------------------------- training kernels
+@pytest.mark.parametrize("B,H,T,p", [(1, 2, 575, 0.1), (2, 3, 37, 0.0), (1, 1, 64, 0.1), (2, 2, 130, 0.1)])
+def test_attention_train_fwd_bwd_vs_autograd(eng, B, H, T, p):
+    """vn_attention_train_fwd / _bwd_dq / _bwd_dkv against torch CPU autograd of transformer.py:234-254 with the engine's
+    own dropout keep-mask injected.  Tolerances: out 2e-6 abs, gradients 2e-5 of their max-abs."""
+    import ctypes as C
+    from oracle import vampnet_oracle as O
+    lib = eng.lib
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    q, k, v = (torch.randn(B, H, T, 64, generator=g) for _ in range(3))
+    dout = torch.randn(B, T, H * 64, generator=g)
+    rel = torch.randn(32, H, generator=g) * 0.5
+    dev = lambda t: t.cuda().contiguous()
+    qd, kd, vd, dd, rd = dev(q), dev(k), dev(v), dev(dout), dev(rel)
+    out = torch.empty(B, T, H * 64, device="cuda")
+    lse = torch.empty(B, H, T, device="cuda")
+    dqkv = torch.zeros(B * T, 3 * H * 64, device="cuda")
+    dbias = torch.zeros(32, H, device="cuda")
+    seed = 77
+    eng.check(lib.vn_attention_train_f32(eng.handle, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), rd.data_ptr(),
+                                            out.data_ptr(), lse.data_ptr(), dd.data_ptr(), dqkv.data_ptr(), dbias.data_ptr(),
+                                            B, H, T, 32, 128, p, seed, eng.stream()), "vn_attention_train_f32")
+    keep = torch.ones(B * H * T, T)
+    if p > 0:
+        m8 = torch.empty(B * H * T, T, dtype=torch.uint8, device="cuda")
+        eng.check(lib.vn_dropout_keep_mask(eng.handle, seed, 1, 0, 0, p, 0, B * H * T, T, m8.data_ptr(), eng.stream()),
+                     "vn_dropout_keep_mask")
+        keep = m8.cpu().float()
+    keep = keep.view(B, H, T, T)
+    qa, ka, va, ra = (t.clone().requires_grad_(True) for t in (q, k, v, rel))
+    bias = O.compute_bias(ra, T).permute(1, 0, 2, 3)               # (H, 1, T, T) -> (1, H, T, T)
+    s = torch.einsum("bhld,bhtd->bhlt", qa, ka) / 8.0 + bias
+    pr = torch.softmax(s, dim=-1) * keep * (1.0 / (1.0 - p))
+    o = torch.einsum("bhlt,bhtd->bhld", pr, va).permute(0, 2, 1, 3).reshape(B, T, H * 64)
+    o.backward(dout)
+    assert (out.cpu() - o.detach()).abs().max().item() < 2e-6 * max(1.0, o.abs().max().item())
+    lse_ref = torch.logsumexp(s.detach(), dim=-1)
+    assert (lse.cpu() - lse_ref).abs().max().item() < 1e-5
+    got = dqkv.cpu().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)   # [3][B][H][T][64]
+    for name, a, ref in (("dq", got[0], qa.grad), ("dk", got[1], ka.grad), ("dv", got[2], va.grad)):
+        err = (a - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-5, (name, err)
+    err = (dbias.cpu() - ra.grad).abs().max().item() / ra.grad.abs().max().item()
+    assert err < 5e-5, ("dbias", err)
+
+
+@pytest.mark.parametrize("R,C", [(4600, 1280), (37, 256), (130, 4096), (64, 64)])
+def test_transpose_zero_pads(eng, R, C):
+    ldd = (R + 31) // 32 * 32
+    src = torch.randn(R, C, device="cuda")
+    dst = torch.full((C, ldd), float("nan"), device="cuda")
+    eng.check(eng.lib.vn_transpose_f32(eng.handle, src.data_ptr(), dst.data_ptr(), R, C, ldd, eng.stream()),
+                 "vn_transpose_f32")
+    assert torch.equal(dst[:, :R], src.t())
+    assert bool((dst[:, R:] == 0).all())

@@ -76,6 +76,7 @@ SYMBOLS = {
     "vn_train_update": (C.c_int, [_P, _P, _P, _P, C.POINTER(vn_train_params), _P, _P]),
     "vn_dropout_keep_mask": (C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int64, C.c_int64,
                                        C.c_int, _P, _P]),
+    "vn_attention_train_f32": (C.c_int, [_P] * 10 + [C.c_int] * 5 + [C.c_float, C.c_uint64, _P]),
     "vn_transpose_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "vn_debug_gemm_config": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "vn_attention_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

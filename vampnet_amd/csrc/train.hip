@@ -375,3 +375,37 @@ extern "C" int vn_transpose_f32(vn_ctx* ctx, const float* src, float* dst, int R
     if (!ctx || !src || !dst) return VN_ERR_INVALID;
     return vn_launch_transpose(ctx, src, dst, R, C, C, ldd, (hipStream_t)stream);
 }
+
+// single-kernel entry points for the training attention (tests / tuning).  The expanded bias table and the LUT are
+// rebuilt per call (the training step keeps them in the model workspace).
+//   q,k,v [B][H][T][64]; out [B][T][H*64]; lse [B][H][T]
+//   backward: dout [B][T][H*64] -> dqkv [B*T][3*H*64] (dq | dk | dv), dbias [num_buckets][H] (ACCUMULATED into)
+extern "C" int vn_attention_train_f32(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                                      float* out, float* lse, const float* dout, float* dqkv, float* dbias, int B, int H, int T,
+                                      int num_buckets, int max_distance, float dropout, uint64_t seed, void* stream) {
+    if (!ctx || !q || !k || !v || !rel_bias || !out || !lse || T <= 0 || H <= 0) return VN_ERR_INVALID;
+    if (dout && (!dqkv || !dbias)) return VN_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    float *full = nullptr, *delta = nullptr;
+    int32_t* lut_d = nullptr;
+    const int n = 2 * T - 1;
+    VN_HIP_CHECK(ctx, hipMalloc((void**)&full, (size_t)H * n * sizeof(float)));
+    VN_HIP_CHECK(ctx, hipMalloc((void**)&lut_d, (size_t)n * sizeof(int32_t)));
+    VN_HIP_CHECK(ctx, hipMalloc((void**)&delta, (size_t)B * H * T * sizeof(float)));
+    std::vector<int32_t> lut(n);
+    vn_bucket_lut_host(T, num_buckets, max_distance, lut.data());
+    int rc = VN_OK;
+    if (hipMemcpy(lut_d, lut.data(), n * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) rc = VN_ERR_HIP;
+    if (rc == VN_OK) rc = vn_launch_bias_expand(ctx, rel_bias, lut_d, full, H, T, s);
+    vn_train_params tp{};
+    tp.seed = seed; tp.step = 1; tp.dropout = dropout;
+    const vn_drop d = make_drop(&tp, 0, SITE_ATTN, 0);
+    if (rc == VN_OK) rc = vn_launch_attention_train_fwd(ctx, q, k, v, full, out, lse, B, H, T, d, s);
+    if (rc == VN_OK && dout)
+        rc = vn_launch_attention_bwd(ctx, q, k, v, full, lut_d, out, dout, lse, delta, dqkv, dbias, B, H, T, num_buckets, d, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(full);
+    (void)hipFree(lut_d);
+    (void)hipFree(delta);
+    return rc;
+}
