@@ -1,0 +1,181 @@
+"""CPU tests of the Trainer twin's host logic (batch/target construction, flat-vector pack/export, the data-parallel
+gradient exchange) with oracle-backed stand-ins for the two device calls — the HIP kernels are covered by
+tests/test_gpu_train.py.  Includes the world_size-2 gloo test of the DDP protocol of BASELINE configs[4]."""
+import ctypes as C
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import train_oracle as TO, vampnet_oracle as O, weights as W
+from vampnet_amd import _lib
+from vampnet_amd._lib import vn_dims
+from vampnet_amd.train import Trainer, noam_lr, IGNORE_INDEX
+
+
+class _NoEngine:
+    device = torch.device("cpu")
+
+    def __init__(self):
+        self.lib = _lib.load()          # host-only entry points (layout queries) work without a GPU
+
+    def check(self, rc, what):
+        assert rc == 0, what
+
+
+class OracleBackedTrainer(Trainer):
+    """Trainer whose two device calls are replaced by the CPU oracle; everything else (make_batch, all-reduce protocol,
+    step counting, Noam schedule, pack/export) is the product's own code."""
+
+    def __init__(self, sd, dims, cb, pg=None, batch_offset=0, **hp):
+        self.engine = _NoEngine()
+        self.lib = self.engine.lib
+        self.odims, self.cb = dims, cb
+        self.dims = vn_dims(dims["n_layers"], dims["n_heads"], dims["d_model"], dims["n_codebooks"], dims["n_cond"],
+                            dims["vocab"], dims["latent_dim"], 32, 128, 1e-6, 4, 64)
+        self.n_codebooks, self.n_cond, self.vocab, self.D = dims["n_codebooks"], dims["n_cond"], dims["vocab"], dims["d_model"]
+        self.Cp = self.n_codebooks - self.n_cond
+        self.mask_token = self.vocab
+        self.hp = dict(lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-2, grad_clip=5.0, label_smoothing=0.1,
+                       dropout=0.0)
+        self.hp.update(hp)
+        self.noam = (2.0, 10000)
+        self.seed, self.pg, self.batch_offset, self.steps = 0, pg, batch_offset, 0
+        n = C.c_int64()
+        assert self.lib.vn_train_param_size(C.byref(self.dims), C.byref(n)) == 0
+        self.n_total = n.value
+        self.params = self.pack(sd, cb)
+        self.grads = torch.zeros_like(self.params)
+        self.loss, self.grad_norm = torch.zeros(1), torch.zeros(1)
+        self.state = {}
+
+    def forward_backward(self, z_mask, target, step=None, dropout=None):
+        sd = self.export(self.params)
+        lat = O.from_codes(sd, self.cb, z_mask)
+        prm = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        logits = TO.forward_train(prm, self.odims, O.from_codes(prm, self.cb, z_mask), None, 0.0)
+        loss = torch.nn.functional.cross_entropy(logits, target, label_smoothing=self.hp["label_smoothing"],
+                                                 ignore_index=IGNORE_INDEX)
+        loss.backward()
+        self.grads = self.pack({k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in prm.items()})
+        self.loss = loss.detach().reshape(1)
+        return self.loss
+
+    def _apply_update(self, step, lr):
+        ws = 1
+        if self.pg is not None:
+            import torch.distributed as dist
+            ws = dist.get_world_size(self.pg)
+        sd = self.export(self.params)
+        grads = {k: v / ws for k, v in self.export(self.grads).items()}
+        self.state["step"] = step - 1
+        new, norm = TO.clip_and_adamw(sd, grads, self.state, lr, grad_clip=self.hp["grad_clip"])
+        self.params = self.pack(new, self.cb)
+        self.grad_norm = norm.reshape(1)
+
+
+def test_pack_export_roundtrip_and_layout():
+    dims = W.TINY_C2F_DIMS
+    sd, cb = W.synth_state_dict(dims, 1), W.synth_codebooks()
+    tr = OracleBackedTrainer(sd, dims, cb)
+    back = tr.export(tr.params)
+    for k, v in sd.items():
+        assert torch.equal(back[k].reshape(v.shape), v), k
+    # the prefix of the train vector is the inference blob (same offsets) except for the derived classifier weight
+    from vampnet_amd.engine import pack_weights
+    blob = pack_weights(tr.lib, tr.dims, sd, cb)
+    vec = tr.params[:blob.numel()].clone()
+    cw = tr._tensor(vec, _lib.W_CLS_W)
+    assert float(cw.abs().max()) == 0.0
+    cw.copy_(tr._tensor(blob, _lib.W_CLS_W))
+    assert torch.equal(vec, blob)
+
+
+def test_make_batch_matches_reference_recipe():
+    """train.py:250-278: z_mask / target from (z, mask); targets only on predicted codebooks, -100 where not masked."""
+    dims = W.TINY_C2F_DIMS
+    tr = OracleBackedTrainer(W.synth_state_dict(dims, 1), dims, W.synth_codebooks())
+    z = W.synth_codes(2, 14, 20, seed=3)
+    g = torch.Generator().manual_seed(5)
+    mask = TO.make_training_mask(z, torch.tensor([0.3, 0.9]), 4, generator=g)
+    z_mask, target = tr.make_batch(z, mask=mask)
+    zm_o, m_o = O.apply_mask(z, mask, 1024)
+    assert torch.equal(z_mask, zm_o)
+    t_o = O.codebook_flatten(z[:, 4:, :]).masked_fill(~O.codebook_flatten(m_o[:, 4:, :]).bool(), -100)
+    assert torch.equal(target, t_o)
+    # r-driven masks consume the generator exactly like pmask.random (mask.py:40-54)
+    g1, g2 = torch.Generator().manual_seed(9), torch.Generator().manual_seed(9)
+    zm1, _ = tr.make_batch(z, r=torch.tensor([0.3, 0.9]), generator=g1)
+    m2 = TO.make_training_mask(z, torch.tensor([0.3, 0.9]), 4, generator=g2)
+    assert torch.equal(zm1, O.apply_mask(z, m2, 1024)[0])
+
+
+def test_noam_schedule():
+    assert noam_lr(1, 1280) == TO.noam_lr(1, 1280)
+    assert noam_lr(10000, 1280) == pytest.approx(2.0 * 1280 ** -0.5 * 10000 ** -0.5)
+    assert noam_lr(40000, 1280) < noam_lr(10000, 1280)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _data(rank):
+    z = W.synth_codes(2, 4, 24, seed=20 + rank)
+    mask = TO.make_training_mask(z, torch.tensor([0.4, 0.8]), 0, generator=torch.Generator().manual_seed(rank))
+    return z, mask
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    dims = W.TINY_COARSE_DIMS
+    tr = OracleBackedTrainer(W.synth_state_dict(dims, 0), dims, W.synth_codebooks(), pg=dist.group.WORLD, batch_offset=2 * rank)
+    z, mask = _data(rank)
+    outs = []
+    for _ in range(2):
+        out = tr.step(z, mask=mask)
+        outs.append((float(out["loss"]), float(out["other/grad_norm"]), out["other/learning_rate"]))
+    q.put((rank, outs, {k: v.numpy() for k, v in tr.state_dict().items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_gloo():
+    """DDP semantics of the reference (audiotools Accelerator -> DistributedDataParallel): every rank back-propagates
+    the MEAN loss of its own batch, gradients are AVERAGED over ranks, then every rank applies the same clipped AdamW
+    step.  The Trainer's exchange (all-reduce SUM of the flat gradient buffer + 1/world in the update) must reproduce
+    the single-process computation on the averaged gradients, on both ranks, for two consecutive steps."""
+    dims = W.TINY_COARSE_DIMS
+    sd, cb = W.synth_state_dict(dims, 0), W.synth_codebooks()
+    state, ref = {}, []
+    cur = {k: v.clone() for k, v in sd.items()}
+    for step in (1, 2):
+        per = [TO.loss_and_grads(cur, dims, cb, *_data(r), None, 0.0) for r in range(2)]
+        grads = {k: (per[0][1][k] + per[1][1][k]) / 2 for k in per[0][1]}
+        lr = TO.noam_lr(step, dims["d_model"])
+        cur, norm = TO.clip_and_adamw(cur, grads, state, lr)
+        ref.append(((float(per[0][0]) + float(per[1][0])) / 2, float(norm), lr))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, outs, new in got:
+        for (l, n, lr), (lo, no, lro) in zip(outs, ref):
+            assert l == pytest.approx(lo, rel=1e-6) and n == pytest.approx(no, rel=1e-5) and lr == lro
+        for k, v in cur.items():
+            assert abs(torch.from_numpy(new[k]).reshape(v.shape) - v).max().item() < 1e-7, (rank, k)

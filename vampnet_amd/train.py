@@ -147,13 +147,17 @@ class Trainer:
             self.loss /= dist.get_world_size(self.pg)
         step = self.steps + 1
         lr = noam_lr(step, self.D, *self.noam) if self.noam else self.hp["lr"]
+        self._apply_update(step, lr)
+        self.steps = step
+        self.last_lr = lr
+        return self.grad_norm
+
+    def _apply_update(self, step, lr):
+        """grad norm (of grads / world_size) -> clip -> AdamW on the flat buffers -> re-derive folded/transposed weights."""
         tp = self._tp(step, lr=lr)
         self.engine.check(self.lib.vn_train_update(self.handle, self.grads.data_ptr(), self.adam_m.data_ptr(),
                                                    self.adam_v.data_ptr(), C.byref(tp), self.grad_norm.data_ptr(),
                                                    self.engine.stream()), "vn_train_update")
-        self.steps = step
-        self.last_lr = lr
-        return self.grad_norm
 
     def step(self, z, r=None, mask=None, generator=None):
         """One train_loop iteration; returns device scalars (no host sync): loss, grad_norm, and the lr used."""
@@ -220,3 +224,40 @@ class Trainer:
 
     def state_dict(self) -> dict:
         return self.export(self.params)
+
+    def pack(self, sd_like: dict, codebooks: torch.Tensor = None) -> torch.Tensor:
+        """Inverse of `export`: a state_dict-shaped set of tensors (parameters, gradients or Adam moments in the
+        reference's naming) -> flat train vector on the host.  The derived VN_W_CLS_W region and, unless `codebooks` is
+        given, the codec rows of VN_W_EMB_TABLES are left zero."""
+        d, D, V, Cp, Cn, L = self.dims, self.D, self.vocab, self.Cp, self.n_codebooks, self.dims.n_layers
+        ld = d.latent_dim
+        out = torch.zeros(self.n_total, dtype=torch.float32)
+
+        def put(tid, layer, t):
+            dst = self._tensor(out, tid, layer)
+            dst.copy_(t.contiguous().float().reshape(-1))
+
+        tables = torch.zeros(Cn, V + 1, ld)
+        tables[:, V] = sd_like["embedding.special.MASK"].float()
+        if codebooks is not None:
+            tables[:, :V] = codebooks[:Cn].float()
+        put(_lib.W_EMB_TABLES, 0, tables)
+        put(_lib.W_EMB_WT, 0, sd_like["embedding.out_proj.weight"].float().squeeze(-1).t())
+        put(_lib.W_EMB_B, 0, sd_like["embedding.out_proj.bias"])
+        put(_lib.W_REL_BIAS, 0, sd_like["transformer.layers.0.self_attn.relative_attention_bias.weight"])
+        put(_lib.W_FINAL_NORM, 0, sd_like["transformer.norm.weight"])
+        put(_lib.W_CLS_B, 0, sd_like["classifier.layers.0.bias"].float().reshape(V, Cp).t())
+        og, ov = self._cls_offsets()
+        out[og:og + Cp * V] = sd_like["classifier.layers.0.weight_g"].float().reshape(V, Cp).t().reshape(-1)
+        out[ov:ov + Cp * V * D] = sd_like["classifier.layers.0.weight_v"].float().reshape(V, Cp, D).permute(1, 0, 2).reshape(-1)
+        for l in range(L):
+            p = f"transformer.layers.{l}."
+            put(_lib.W_NORM1, l, sd_like[p + "norm_1.weight"])
+            put(_lib.W_QKV, l, torch.cat([sd_like[p + "self_attn.w_qs.weight"], sd_like[p + "self_attn.w_ks.weight"],
+                                          sd_like[p + "self_attn.w_vs.weight"]], 0))
+            put(_lib.W_WO, l, sd_like[p + "self_attn.fc.weight"])
+            put(_lib.W_NORM3, l, sd_like[p + "norm_3.weight"])
+            w1 = sd_like[p + "feed_forward.w_1.weight"].float()
+            put(_lib.W_W1, l, torch.stack([w1[:2 * D].reshape(2 * D // 32, 32, D), w1[2 * D:].reshape(2 * D // 32, 32, D)], 1))
+            put(_lib.W_W2, l, sd_like[p + "feed_forward.w_2.weight"])
+        return out
