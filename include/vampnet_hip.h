@@ -265,6 +265,18 @@ int  vn_train_forward(vn_train* tr, const int64_t* z_masked, int B, int T, const
 /* *grad_norm_dev = || grads / world_size ||_2 ; clip ; AdamW on every trainable element ; vn_train_sync.             */
 int  vn_train_update(vn_train* tr, const float* grads, float* adam_m, float* adam_v, const vn_train_params* p,
                      float* grad_norm_dev, void* stream);
+/* LoRA-only fine-tuning: train.py:696 `lora.mark_only_lora_as_trainable(model)` on loralib `Linear(r=8, lora_alpha=1)`
+ * (transformer.py:67-68, :109-114; loralib semantics per SURVEY.md App. C — the package is absent from the reference
+ * tree, parity unpinned): y = x W^T + s (x A^T) B^T with s = alpha / r; every other parameter is frozen.
+ * LoRA vector = per layer, for which in {0: w_qs, 1: w_vs, 2: fc, 3: w_1, 4: w_2}: A TRANSPOSED [K][8] then B [N][8]
+ * (w_1's B rows in the packed order of VN_W_W1); vn_lora_param_offset(layer, which, ab = 0: At, 1: B).
+ * vn_train_enable_lora: the model blob must hold the UN-merged base weights; they are snapshotted, the blob becomes
+ * W + s B A, and from then on `grads` / `adam_m` / `adam_v` of vn_train_forward_backward / vn_train_update are buffers of
+ * vn_lora_param_size floats and the update modifies `lora_params` only (then re-merges).                              */
+int  vn_lora_param_size(const vn_dims* dims, int64_t* n_floats);
+int  vn_lora_param_offset(const vn_dims* dims, int layer, int which, int ab, int64_t* offset, int64_t* count);
+int  vn_train_enable_lora(vn_train* tr, float* lora_params, float scaling, void* stream);
+
 /* The keep-mask the kernels use at one dropout site (site 0: attention probabilities, rows = (b, h, query), cols = keys;
  * 1: attention residual, 2: GEGLU output, 3: FFN residual; rows = (b, t)); out dev u8 [rows][cols].  For parity tests. */
 int  vn_dropout_keep_mask(vn_ctx* ctx, uint64_t seed, int64_t step, int layer, int site, float p, int64_t row0,

@@ -15,9 +15,11 @@ Dropout noise is INJECTED (a dict of {0,1} keep-masks) so the HIP engine and thi
 draw: `y = x * keep * (1/(1-p))`, which is what torch's dropout computes.
 
 Trainable set: with the reference imported through oracle/ref_shim.py, `loralib.Linear` is a plain `nn.Linear`
-(loralib is absent), so every VampNet parameter is trainable.  Real loralib freezes `.weight` of the
-five LoRA'd linears and trains `lora_A/B` instead — that variant is NOT restated here (parity unpinned: dependency
-absent).  The codec codebooks are not VampNet parameters (train.py:257 passes the codec in) and get no gradient.
+(loralib is absent), so every VampNet parameter is trainable — that is the PINNED mode.
+LoRA-only fine-tuning (train.py:696 `lora.mark_only_lora_as_trainable`, adapters on the five `lora.Linear`s of
+transformer.py:67-68,109-114) is restated from loralib's PUBLISHED algorithm (`lora_linear`, `add_lora`,
+`loss_and_grads(only_lora=True)`): PARITY UNPINNED, the dependency is not in the reference tree and no reference test
+holds vectors for it.  The codec codebooks are not VampNet parameters (train.py:257) and get no gradient.
 
 Pinned by tests/test_oracle_vs_reference.py::test_train_step_vs_reference (reference modules + torch.optim.AdamW +
 clip_grad_norm_ + the reference's NoamScheduler) when /root/reference is present.
@@ -56,7 +58,20 @@ def _drop(x, masks, key, p):
     return x * masks[key] * (1.0 / (1.0 - p))
 
 
-def attention_train(x, wq, wk, wv, wo, n_heads, position_bias, masks, layer, p):
+LORA_SCALING = 1.0 / 8.0      # loralib: lora_alpha / r with lora_alpha = 1 (default), r = LORA_R = 8 (transformer.py:22)
+
+
+def lora_linear(x, params, key):
+    """loralib.Linear.forward in train() mode [UNVERIFIED-DEP: loralib is absent from the reference tree; published
+    semantics, SURVEY.md App. C]:  x W^T + (lora_dropout(x) A^T B^T) * scaling, lora_dropout = identity (p = 0 default).
+    Falls back to a plain linear when the state_dict holds no adapters for `key`."""
+    y = F.linear(x, params[key + ".weight"])
+    if key + ".lora_A" in params:
+        y = y + (x @ params[key + ".lora_A"].transpose(0, 1) @ params[key + ".lora_B"].transpose(0, 1)) * LORA_SCALING
+    return y
+
+
+def attention_train(x, params, pre, n_heads, position_bias, masks, layer, p):
     """transformer.py:211-257 with the probability dropout of :250 active."""
     B, T, D = x.shape
     dh = D // n_heads
@@ -64,14 +79,16 @@ def attention_train(x, wq, wk, wv, wo, n_heads, position_bias, masks, layer, p):
     def heads(y):
         return y.view(B, T, n_heads, dh).permute(2, 0, 1, 3)
 
-    q, k, v = heads(F.linear(x, wq)), heads(F.linear(x, wk)), heads(F.linear(x, wv))
+    q = heads(lora_linear(x, params, pre + "self_attn.w_qs"))
+    k = heads(F.linear(x, params[pre + "self_attn.w_ks.weight"]))            # plain nn.Linear (transformer.py:110)
+    v = heads(lora_linear(x, params, pre + "self_attn.w_vs"))
     attn = torch.einsum("hblk,hbtk->hblt", [q, k]) / np.sqrt(q.shape[-1])
     attn = attn + position_bias
     attn = torch.softmax(attn, dim=3)
     attn = _drop(attn, masks, (layer, "attn"), p)
     out = torch.einsum("hblt,hbtv->hblv", [attn, v])
     out = out.permute(1, 2, 0, 3).reshape(B, T, D)
-    return F.linear(out, wo)
+    return lora_linear(out, params, pre + "self_attn.fc")
 
 
 def forward_train(params, dims, latents, masks=None, p=0.1):
@@ -85,14 +102,12 @@ def forward_train(params, dims, latents, masks=None, p=0.1):
     for i in range(L):
         pre = f"transformer.layers.{i}."
         y = vo.rmsnorm(x, params[pre + "norm_1.weight"])
-        y = attention_train(y, params[pre + "self_attn.w_qs.weight"], params[pre + "self_attn.w_ks.weight"],
-                            params[pre + "self_attn.w_vs.weight"], params[pre + "self_attn.fc.weight"], H, bias,
-                            masks, i, p)
+        y = attention_train(y, params, pre, H, bias, masks, i, p)
         x = x + _drop(y, masks, (i, "res1"), p)
         y = vo.rmsnorm(x, params[pre + "norm_3.weight"])
-        y = F.linear(y, params[pre + "feed_forward.w_1.weight"])
+        y = lora_linear(y, params, pre + "feed_forward.w_1")
         y = _drop(vo.gated_gelu(y), masks, (i, "ffn"), p)
-        y = F.linear(y, params[pre + "feed_forward.w_2.weight"])
+        y = lora_linear(y, params, pre + "feed_forward.w_2")
         x = x + _drop(y, masks, (i, "res2"), p)
     out = vo.rmsnorm(x, params["transformer.norm.weight"]).permute(0, 2, 1)
     w = torch._weight_norm(params["classifier.layers.0.weight_v"], params["classifier.layers.0.weight_g"], 0)
@@ -114,11 +129,32 @@ def make_training_mask(z, r, n_cond, generator=None):
     return vo.codebook_unmask(mask, n_cond)
 
 
-def loss_and_grads(sd, dims, codebooks, z, mask, masks=None, p=0.1, label_smoothing=0.1):
+LORA_KEYS = ("self_attn.w_qs", "self_attn.w_vs", "self_attn.fc", "feed_forward.w_1", "feed_forward.w_2")
+
+
+def add_lora(sd, dims, seed=0, zero_b=False, r=8):
+    """state_dict + loralib adapters for the five LoRA'd linears of every layer: lora_A (r, in) kaiming-uniform(a=sqrt 5),
+    lora_B (out, r) zeros at init (loralib.Linear.reset_parameters); `zero_b=False` fills B with small random values so
+    that gradient tests exercise both factors."""
+    g = torch.Generator().manual_seed(seed)
+    out = dict(sd)
+    for l in range(dims["n_layers"]):
+        for key in LORA_KEYS:
+            w = sd[f"transformer.layers.{l}.{key}.weight"]
+            n_out, n_in = w.shape
+            bound = 1.0 / math.sqrt(n_in)              # kaiming_uniform_(a=sqrt(5)) on (r, in): bound = sqrt(6/((1+5) in))
+            out[f"transformer.layers.{l}.{key}.lora_A"] = (torch.rand(r, n_in, generator=g) * 2 - 1) * bound
+            out[f"transformer.layers.{l}.{key}.lora_B"] = (torch.zeros(n_out, r) if zero_b
+                                                          else (torch.rand(n_out, r, generator=g) * 2 - 1) * 0.05)
+    return out
+
+
+def loss_and_grads(sd, dims, codebooks, z, mask, masks=None, p=0.1, label_smoothing=0.1, only_lora=False):
     """One forward/backward of train_loop (train.py:252-287).  z (B,C,T) int64 clean tokens, mask (B,C,T) {0,1}.
+    `only_lora`: train.py:696 lora.mark_only_lora_as_trainable — gradients only for names containing "lora_".
     Returns (loss float tensor, grads dict name -> tensor, logits)."""
     n_cond = dims["n_cond"]
-    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    params = {k: v.detach().clone().requires_grad_((not only_lora) or ("lora_" in k)) for k, v in sd.items()}
     z_mask, mask = vo.apply_mask(z, mask, dims["vocab"])
     latents = vo.from_codes(params, codebooks, z_mask)
     z_hat = forward_train(params, dims, latents, masks, p)
@@ -127,7 +163,8 @@ def loss_and_grads(sd, dims, codebooks, z, mask, masks=None, p=0.1, label_smooth
     t_masked = target.masked_fill(~flat_mask.bool(), IGNORE_INDEX)
     loss = F.cross_entropy(z_hat, t_masked, label_smoothing=label_smoothing, ignore_index=IGNORE_INDEX)
     loss.backward()
-    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in params.items()}
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in params.items()
+             if (not only_lora) or ("lora_" in k)}
     return loss.detach(), grads, z_hat.detach()
 
 

@@ -217,3 +217,61 @@ def test_full_size_train_step_vs_oracle(engine, which):
     for k, v in new_o.items():                            # at this lr the step is below fp32 resolution of most weights
         assert (new[k].reshape(v.shape) - v).abs().max().item() < 2e-7, k
     engine.health_check()
+
+
+# ----------------------------------------------------------------------------- LoRA-only fine-tuning (parity unpinned)
+@pytest.mark.parametrize("which,B,T,p", [("coarse", 2, 40, 0.1), ("c2f", 2, 33, 0.0)])
+def test_lora_finetune_step_vs_oracle(engine, which, B, T, p):
+    """train.py:696 mark_only_lora_as_trainable: only lora_A / lora_B of the five LoRA'd linears per layer get gradients and
+    updates; base weights, norms, embedding, classifier stay frozen.  Oracle = loralib's published forward restated in
+    oracle/train_oracle.py (dependency absent from the reference: parity unpinned).  Tolerances as in
+    test_train_step_vs_oracle."""
+    dims = W.TINY_COARSE_DIMS if which == "coarse" else W.TINY_C2F_DIMS
+    sd = TO.add_lora(W.synth_state_dict(dims, 0 if which == "coarse" else 1), dims, seed=3)
+    cb = W.synth_codebooks()
+    tr = _trainer(engine, dims, sd, cb, max_batch=B, max_T=T, dropout=p, seed=2, use_noam=False, lr=1e-3, only_lora=True)
+    # load/export round trip of the adapters
+    back = tr.lora_state_dict()
+    for k, v in back.items():
+        assert torch.equal(v, sd[k]), k
+    z = W.synth_codes(B, dims["n_codebooks"], T, seed=8)
+    mask = TO.make_training_mask(z, torch.linspace(0.3, 0.9, B), dims["n_cond"], generator=torch.Generator().manual_seed(4))
+    z_mask, target = tr.make_batch(z, mask=mask)
+    cur, state = {k: v.clone() for k, v in sd.items()}, {}
+    for it in range(2):
+        step = it + 1
+        masks = _masks_from_device(tr, dims, B, T, step, p)
+        loss_o, grads_o, logits_o = TO.loss_and_grads(cur, dims, cb, z, mask, masks, p, only_lora=True)
+        assert set(grads_o) == set(back)
+        logits = tr.forward(z_mask, step=step).cpu()
+        assert (logits - logits_o).abs().max().item() < 2e-5
+        loss = tr.forward_backward(z_mask, target, step=step).cpu()
+        assert abs(loss.item() - loss_o.item()) < 1e-5 * abs(loss_o.item())
+        grads = tr.export_lora(tr.grads)
+        worst = 0.0
+        for k, g_o in grads_o.items():
+            e = _rel(grads[k], g_o)
+            worst = max(worst, e)
+            assert e < 1e-4, (k, e)
+        print(f"lora {which} step {step}: loss {loss.item():.6f}, worst grad rel err {worst:.2e}")
+        new_lora, norm_o = TO.clip_and_adamw({k: cur[k] for k in grads_o}, grads_o, state, 1e-3)
+        norm = tr.update().cpu()
+        _check_norm(norm, norm_o, grads_o)
+        got = tr.lora_state_dict()
+        _check_update(got, new_lora, 1e-3)
+        cur.update({k: got[k].clone() for k in new_lora})
+    # frozen parameters did not move; the merged blob equals W + B A / 8
+    full = tr.state_dict()
+    for k, v in sd.items():
+        if "lora_" not in k:
+            assert torch.equal(full[k], v), k
+    merged = tr.export(tr.params)
+    k0 = "transformer.layers.1.feed_forward.w_1"
+    want = sd[k0 + ".weight"] + (full[k0 + ".lora_B"] @ full[k0 + ".lora_A"]) * 0.125
+    assert (merged[k0 + ".weight"] - want).abs().max().item() < 1e-6
+    # inference on the fine-tuned model == Interface-style load of base + lora.pth (merge at pack time)
+    from vampnet_amd.engine import VampNetModel
+    from vampnet_amd.synth import model_kwargs
+    ref_model = VampNetModel(engine, full, cb, **model_kwargs(dims), max_batch=B, max_T=T)
+    assert (ref_model.forward_codes(z_mask) - tr.model.forward_codes(z_mask)).abs().max().item() < 2e-5
+    engine.health_check()

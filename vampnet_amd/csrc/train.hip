@@ -15,6 +15,7 @@
 //   dW: A = dY^T [N][Mp], B = X^T [K][Mp] -> 64x64 LDS transposes of the two activations, Mp = M rounded up to 32 (zero
 //                                            filled), ~4 % of a step's time.
 #include <new>
+#include <stdlib.h>
 #include <vector>
 #include "vn_common.h"
 #include "vn_model.h"
@@ -42,7 +43,53 @@ struct vn_train {
     double* npartial;
     int32_t *t32, *n_valid;
     int B, T;                      // shape of the stashed forward (0 = none)
+    // LoRA fine-tuning (vn_train_enable_lora): the blob holds W_eff = W + s B A; w_base keeps the frozen W of the five
+    // LoRA'd linears [L][qkv 3D^2 | wo D^2 | w1 4D^2 | w2 2D^2]; lora = caller-owned [L][5][At | B] vector
+    bool lora;
+    float lora_scale;
+    float *lora_params, *w_base, *h8, *dh8;
+    long n_lora;
 };
+
+enum { LORA_Q = 0, LORA_V = 1, LORA_FC = 2, LORA_W1 = 3, LORA_W2 = 4 };
+#define LORA_R 8
+static void lora_shape(const vn_dims* d, int which, long* K, long* N) {
+    const long D = d->d_model;
+    *K = which == LORA_W2 ? 2 * D : D;
+    *N = which == LORA_W1 ? 4 * D : D;
+}
+static long lora_layer_floats(const vn_dims* d) { return 14L * LORA_R * d->d_model; }
+// offset of At (ab = 0, [K][8]) or B (ab = 1, [N][8]) of linear `which` in layer `layer`
+static long lora_offset(const vn_dims* d, int layer, int which, int ab) {
+    long off = lora_layer_floats(d) * layer;
+    for (int w = 0; w < which; ++w) {
+        long K, N;
+        lora_shape(d, w, &K, &N);
+        off += LORA_R * (K + N);
+    }
+    if (ab) {
+        long K, N;
+        lora_shape(d, which, &K, &N);
+        off += LORA_R * K;
+    }
+    return off;
+}
+
+extern "C" int vn_lora_param_size(const vn_dims* dims, int64_t* n_floats) {
+    if (!dims || !n_floats) return VN_ERR_INVALID;
+    *n_floats = lora_layer_floats(dims) * dims->n_layers;
+    return VN_OK;
+}
+
+extern "C" int vn_lora_param_offset(const vn_dims* dims, int layer, int which, int ab, int64_t* offset, int64_t* count) {
+    if (!dims || !offset || !count || layer < 0 || layer >= dims->n_layers || which < 0 || which > 4 || ab < 0 || ab > 1)
+        return VN_ERR_INVALID;
+    long K, N;
+    lora_shape(dims, which, &K, &N);
+    *offset = lora_offset(dims, layer, which, ab);
+    *count = LORA_R * (ab ? N : K);
+    return VN_OK;
+}
 
 static long al64(long n) { return (n + 63) & ~63L; }
 
@@ -89,6 +136,9 @@ extern "C" void vn_train_destroy(vn_train* t) {
     (void)hipFree(t->npartial);
     (void)hipFree(t->t32);
     (void)hipFree(t->n_valid);
+    (void)hipFree(t->w_base);
+    (void)hipFree(t->h8);
+    (void)hipFree(t->dh8);
     delete t;
 }
 
@@ -104,6 +154,7 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
     vn_train* t = new (std::nothrow) vn_train();
     if (!t) return VN_ERR_OOM;
     t->m = m; t->params = params;
+    t->lora = false; t->lora_params = t->w_base = t->h8 = t->dh8 = nullptr; t->n_lora = 0; t->lora_scale = 0.f;
     const vn_dims& d = m->d;
     const long D = m->D, L = m->L, rows = m->max_rows;
     t->NV = m->Cp * d.vocab;
@@ -132,8 +183,11 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
     if (cs > part) part = cs;
     const size_t eb = (size_t)vn_embed_bwd_partial_floats(d.max_batch, d.max_T, d.n_codebooks, d.latent_dim, (int)D);
     if (eb > part) part = eb;
+    const size_t lp = (size_t)vn_lora_up_partial_floats((int)rows, (int)(4 * D));
+    if (lp > part) part = lp;
     A(&t->partial, part);
-    A(&t->row_loss, (size_t)rows * m->Cp); A(&t->delta, (size_t)d.max_batch * m->H * d.max_T); A(&t->scal, 16);
+    A(&t->row_loss, (size_t)rows * m->Cp + (size_t)d.num_buckets * m->H);   // + room for the LoRA-mode bias-gradient sink
+    A(&t->delta, (size_t)d.max_batch * m->H * d.max_T); A(&t->scal, 16);
     if (rc == VN_OK) rc = talloc(ctx, &t->npartial, 1024);
     if (rc == VN_OK) rc = talloc(ctx, &t->t32, (size_t)rows * m->Cp);
     if (rc == VN_OK) rc = talloc(ctx, &t->n_valid, 4);
@@ -188,6 +242,93 @@ static int params_ok(vn_ctx* ctx, const vn_train_params* p) {
     if (p->step < 1) return vn_fail(ctx, VN_ERR_INVALID, "optimiser step index must be >= 1%s", "");
     if (p->world_size < 1) return vn_fail(ctx, VN_ERR_INVALID, "world_size must be >= 1%s", "");
     return VN_OK;
+}
+
+
+// ---- LoRA ------------------------------------------------------------------------------------------
+static float* blob_weight(vn_train* t, int which, int l, long* row0_floats) {
+    const vn_dims* d = &t->m->d;
+    const long D = d->d_model;
+    *row0_floats = 0;
+    switch (which) {
+        case LORA_Q: return t->params + vn_tensor_offset(d, VN_W_QKV, l);
+        case LORA_V: *row0_floats = 2 * D * D; return t->params + vn_tensor_offset(d, VN_W_QKV, l);
+        case LORA_FC: return t->params + vn_tensor_offset(d, VN_W_WO, l);
+        case LORA_W1: return t->params + vn_tensor_offset(d, VN_W_W1, l);
+        default: return t->params + vn_tensor_offset(d, VN_W_W2, l);
+    }
+}
+static const float* base_weight(const vn_train* t, int which, int l) {
+    const long D = t->m->D;
+    const float* b = t->w_base + 10L * D * D * l;
+    switch (which) {
+        case LORA_Q: return b;
+        case LORA_V: return b + 2 * D * D;
+        case LORA_FC: return b + 3 * D * D;
+        case LORA_W1: return b + 4 * D * D;
+        default: return b + 8 * D * D;
+    }
+}
+
+// blob <- W_base + s * B * A for every LoRA'd linear
+static int lora_merge_all(vn_train* t, hipStream_t s) {
+    vn_ctx* ctx = t->m->ctx;
+    const vn_dims* d = &t->m->d;
+    for (int l = 0; l < t->m->L; ++l)
+        for (int w = 0; w < 5; ++w) {
+            long K, N, r0;
+            lora_shape(d, w, &K, &N);
+            float* dst = blob_weight(t, w, l, &r0);
+            int rc = vn_launch_lora_merge(ctx, base_weight(t, w, l), t->lora_params + lora_offset(d, l, w, 1),
+                                          t->lora_params + lora_offset(d, l, w, 0), dst + r0, (int)N, (int)K, t->lora_scale, s);
+            if (rc) return rc;
+        }
+    return VN_OK;
+}
+
+extern "C" int vn_train_enable_lora(vn_train* t, float* lora_params, float scaling, void* stream) {
+    if (!t || !lora_params) return VN_ERR_INVALID;
+    vn_model* m = t->m;
+    vn_ctx* ctx = m->ctx;
+    hipStream_t s = (hipStream_t)stream;
+    if (t->lora) return vn_fail(ctx, VN_ERR_INVALID, "vn_train_enable_lora: already enabled%s", "");
+    const long D = m->D;
+    int rc;
+    if ((rc = talloc(ctx, &t->w_base, (size_t)10 * D * D * m->L))) return rc;
+    if ((rc = talloc(ctx, &t->h8, (size_t)m->max_rows * LORA_R))) return rc;
+    if ((rc = talloc(ctx, &t->dh8, (size_t)m->max_rows * LORA_R))) return rc;
+    for (int l = 0; l < m->L; ++l) {        // snapshot the frozen weights (the blob must hold the UN-merged W here)
+        float* b = t->w_base + 10L * D * D * l;
+        VN_HIP_CHECK(ctx, hipMemcpyAsync(b, P(t, VN_W_QKV, l), 3 * D * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+        VN_HIP_CHECK(ctx, hipMemcpyAsync(b + 3 * D * D, P(t, VN_W_WO, l), D * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+        VN_HIP_CHECK(ctx, hipMemcpyAsync(b + 4 * D * D, P(t, VN_W_W1, l), 4 * D * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+        VN_HIP_CHECK(ctx, hipMemcpyAsync(b + 8 * D * D, P(t, VN_W_W2, l), 2 * D * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    t->lora = true; t->lora_params = lora_params; t->lora_scale = scaling;
+    int64_t n = 0;
+    vn_lora_param_size(&m->d, &n);
+    t->n_lora = n;
+    if ((rc = lora_merge_all(t, s))) return rc;
+    return vn_train_sync(t, stream);
+}
+
+// gradients of one LoRA'd linear y = x W^T + s (x At) B^T given X [M][K] (row stride ldx) and dY [M][N] (row stride ldy)
+static int lora_grads(vn_train* t, const float* X, int ldx, const float* dY, int ldy, int l, int which, float* grads, int M,
+                      hipStream_t s) {
+    vn_ctx* ctx = t->m->ctx;
+    const vn_dims* d = &t->m->d;
+    long K, N;
+    lora_shape(d, which, &K, &N);
+    const float* At = t->lora_params + lora_offset(d, l, which, 0);
+    const float* Bm = t->lora_params + lora_offset(d, l, which, 1);
+    float* gAt = grads + lora_offset(d, l, which, 0);
+    float* gB = grads + lora_offset(d, l, which, 1);
+    int rc;
+    if ((rc = vn_launch_lora_down(ctx, X, ldx, At, t->h8, M, (int)K, 1.0f, s))) return rc;                  // h = x At
+    if ((rc = vn_launch_lora_up(ctx, dY, ldy, t->h8, gB, t->partial, M, (int)N, t->lora_scale, s))) return rc;  // dB = s dY^T h
+    if ((rc = vn_launch_lora_down(ctx, dY, ldy, Bm, t->dh8, M, (int)N, t->lora_scale, s))) return rc;         // dh = s dY B
+    rc = vn_launch_lora_up(ctx, X, ldx, t->dh8, gAt, t->partial, M, (int)K, 1.0f, s);                      // dAt = x^T dh
+    return rc;
 }
 
 // ---- forward in train() mode + loss + dlogits --------------------------------------------------
@@ -245,18 +386,25 @@ static int backward(vn_train* t, int B, int T, const vn_train_params* p, float* 
     float* dlog = m->logits;
     // ---- classifier (WNConv1d 1x1, transformer.py:596-604) + final norm
     if ((rc = gemm(ctx, dlog, t->wT + t->wT_cls, nullptr, t->dy, M, D, NV, VN_EPI_STORE, s))) return rc;
-    float* dWc = G(t, grads, VN_W_CLS_W);
-    if ((rc = grad_weight(t, dlog, t->y_f, dWc, M, NV, D, s))) return rc;
-    if ((rc = vn_launch_colsum(ctx, dlog, M, NV, t->partial, G(t, grads, VN_W_CLS_B), s))) return rc;
-    if ((rc = vn_launch_weight_norm_bwd(ctx, t->params + t->off_g, t->params + t->off_v, dWc, grads + t->off_g,
-                                        grads + t->off_v, NV, D, s)))
-        return rc;
-    VN_HIP_CHECK(ctx, hipMemsetAsync(dWc, 0, (size_t)NV * D * sizeof(float), s));   // derived tensor: not a parameter
+    // LoRA mode (mark_only_lora_as_trainable): only dX flows through the frozen tensors; their own gradients are not
+    // computed (norm-weight / bias-table by-products land in scratch).
+    const bool lora = t->lora;
+    float* junk = t->tmp;                       // >= D floats: by-product norm-weight gradients in LoRA mode
+    if (!lora) {
+        float* dWc = G(t, grads, VN_W_CLS_W);
+        if ((rc = grad_weight(t, dlog, t->y_f, dWc, M, NV, D, s))) return rc;
+        if ((rc = vn_launch_colsum(ctx, dlog, M, NV, t->partial, G(t, grads, VN_W_CLS_B), s))) return rc;
+        if ((rc = vn_launch_weight_norm_bwd(ctx, t->params + t->off_g, t->params + t->off_v, dWc, grads + t->off_g,
+                                            grads + t->off_v, NV, D, s)))
+            return rc;
+        VN_HIP_CHECK(ctx, hipMemsetAsync(dWc, 0, (size_t)NV * D * sizeof(float), s));   // derived tensor: not a parameter
+    }
     float* dx = t->dxa;
     float* dx2 = t->dxb;
-    if ((rc = vn_launch_rmsnorm_bwd(ctx, t->x_last, P(t, VN_W_FINAL_NORM), t->dy, nullptr, dx, G(t, grads, VN_W_FINAL_NORM),
-                                    t->partial, M, D, m->d.eps, s)))
+    if ((rc = vn_launch_rmsnorm_bwd(ctx, t->x_last, P(t, VN_W_FINAL_NORM), t->dy, nullptr, dx,
+                                    lora ? junk : G(t, grads, VN_W_FINAL_NORM), t->partial, M, D, m->d.eps, s)))
         return rc;
+    float* dbias = lora ? t->row_loss : G(t, grads, VN_W_REL_BIAS);     // row_loss is free once the loss is reduced
     for (int l = L - 1; l >= 0; --l) {
         vn_layer_stash& S = t->st[l];
         const float* wTl = t->wT + t->wT_layer * l;
@@ -264,30 +412,43 @@ static int backward(vn_train* t, int B, int T, const vn_train_params* p, float* 
         const vn_drop d2 = make_drop(p, l, SITE_RES2, r_tok);
         const float* dh = dx;
         if (d2.thresh16) { if ((rc = vn_launch_dropout_bwd(ctx, dx, t->dh, M, D, d2, s))) return rc; dh = t->dh; }
-        if ((rc = grad_weight(t, dh, S.g, G(t, grads, VN_W_W2, l), M, D, 2 * D, s))) return rc;
+        if (lora) rc = lora_grads(t, S.g, 2 * D, dh, D, l, LORA_W2, grads, M, s);
+        else rc = grad_weight(t, dh, S.g, G(t, grads, VN_W_W2, l), M, D, 2 * D, s);
+        if (rc) return rc;
         if ((rc = gemm(ctx, dh, wTl + 8L * D * D, nullptr, t->dg, M, 2 * D, D, VN_EPI_STORE, s))) return rc;
         if ((rc = vn_launch_geglu_train(ctx, S.u, t->dg, t->du, M, 2 * D, make_drop(p, l, SITE_FFN, r_tok), true, s))) return rc;
-        if ((rc = grad_weight(t, t->du, S.y3, G(t, grads, VN_W_W1, l), M, 4 * D, D, s))) return rc;
+        if (lora) rc = lora_grads(t, S.y3, D, t->du, 4 * D, l, LORA_W1, grads, M, s);
+        else rc = grad_weight(t, t->du, S.y3, G(t, grads, VN_W_W1, l), M, 4 * D, D, s);
+        if (rc) return rc;
         if ((rc = gemm(ctx, t->du, wTl + 4L * D * D, nullptr, t->dy, M, D, 4 * D, VN_EPI_STORE, s))) return rc;
-        if ((rc = vn_launch_rmsnorm_bwd(ctx, S.x_mid, P(t, VN_W_NORM3, l), t->dy, dx, dx2, G(t, grads, VN_W_NORM3, l), t->partial,
-                                        M, D, m->d.eps, s)))
+        if ((rc = vn_launch_rmsnorm_bwd(ctx, S.x_mid, P(t, VN_W_NORM3, l), t->dy, dx, dx2, lora ? junk : G(t, grads, VN_W_NORM3, l),
+                                        t->partial, M, D, m->d.eps, s)))
             return rc;
         // ---- attention branch (transformer.py:211-257, :336-347)
         const vn_drop d1 = make_drop(p, l, SITE_RES1, r_tok);
         const float* dh2 = dx2;
         if (d1.thresh16) { if ((rc = vn_launch_dropout_bwd(ctx, dx2, t->dh, M, D, d1, s))) return rc; dh2 = t->dh; }
-        if ((rc = grad_weight(t, dh2, S.a, G(t, grads, VN_W_WO, l), M, D, D, s))) return rc;
+        if (lora) rc = lora_grads(t, S.a, D, dh2, D, l, LORA_FC, grads, M, s);
+        else rc = grad_weight(t, dh2, S.a, G(t, grads, VN_W_WO, l), M, D, D, s);
+        if (rc) return rc;
         if ((rc = gemm(ctx, dh2, wTl + 3L * D * D, nullptr, t->da, M, D, D, VN_EPI_STORE, s))) return rc;
         if ((rc = vn_launch_attention_bwd(ctx, S.qkv, S.qkv + plane, S.qkv + 2 * plane, m->bias_full, m->lut, S.a, t->da, S.lse,
-                                          t->delta, t->dqkv, G(t, grads, VN_W_REL_BIAS), B, H, T, m->d.num_buckets,
+                                          t->delta, t->dqkv, dbias, B, H, T, m->d.num_buckets,
                                           make_drop(p, l, SITE_ATTN, r_att), s)))
             return rc;
-        if ((rc = grad_weight(t, t->dqkv, S.y1, G(t, grads, VN_W_QKV, l), M, 3 * D, D, s))) return rc;
+        if (lora) {          // w_qs and w_vs carry adapters, w_ks is a plain nn.Linear (transformer.py:109-111)
+            if ((rc = lora_grads(t, S.y1, D, t->dqkv, 3 * D, l, LORA_Q, grads, M, s))) return rc;
+            rc = lora_grads(t, S.y1, D, t->dqkv + 2 * D, 3 * D, l, LORA_V, grads, M, s);
+        } else {
+            rc = grad_weight(t, t->dqkv, S.y1, G(t, grads, VN_W_QKV, l), M, 3 * D, D, s);
+        }
+        if (rc) return rc;
         if ((rc = gemm(ctx, t->dqkv, wTl, nullptr, t->dy, M, D, 3 * D, VN_EPI_STORE, s))) return rc;
-        if ((rc = vn_launch_rmsnorm_bwd(ctx, S.x_in, P(t, VN_W_NORM1, l), t->dy, dx2, dx, G(t, grads, VN_W_NORM1, l), t->partial,
-                                        M, D, m->d.eps, s)))
+        if ((rc = vn_launch_rmsnorm_bwd(ctx, S.x_in, P(t, VN_W_NORM1, l), t->dy, dx2, dx, lora ? junk : G(t, grads, VN_W_NORM1, l),
+                                        t->partial, M, D, m->d.eps, s)))
             return rc;
     }
+    if (lora) return VN_OK;                     // embedding parameters are frozen
     // ---- codebook embedding (layers.py:134-163)
     return vn_launch_embed_bwd(ctx, dx, m->z, P(t, VN_W_EMB_TABLES), P(t, VN_W_EMB_WT), G(t, grads, VN_W_EMB_TABLES),
                                G(t, grads, VN_W_EMB_WT), G(t, grads, VN_W_EMB_B), t->partial, t->du, B, m->d.n_codebooks, T,
@@ -304,7 +465,7 @@ extern "C" int vn_train_forward_backward(vn_train* t, const int64_t* z_masked, c
     if (rc) return rc;
     if (B <= 0 || T <= 0 || B > m->d.max_batch || T > m->d.max_T)
         return vn_fail(ctx, VN_ERR_INVALID, "train step: B=%s%ld, T=%ld outside the model workspace", "", B, T);
-    VN_HIP_CHECK(ctx, hipMemsetAsync(grads, 0, (size_t)t->n_total * sizeof(float), s));
+    VN_HIP_CHECK(ctx, hipMemsetAsync(grads, 0, (size_t)(t->lora ? t->n_lora : t->n_total) * sizeof(float), s));
     if ((rc = vn_launch_i64_to_i32(ctx, z_masked, m->z, (long)B * m->d.n_codebooks * T, s))) return rc;
     if ((rc = forward_train(t, B, T, p, s))) return rc;
     if ((rc = vn_launch_cross_entropy(ctx, m->logits, target, t->t32, (long)B * T * m->Cp, m->d.vocab, p->label_smoothing,
@@ -345,6 +506,12 @@ extern "C" int vn_train_update(vn_train* t, const float* grads, float* mom, floa
     a.bc2 = (float)(1.0 - pow((double)p->beta2, (double)p->step));
     a.gscale = 1.0f / (float)p->world_size;
     a.clip = p->grad_clip;
+    if (t->lora) {               // the whole LoRA vector is trainable; then W_eff = W + s B A and the derived copies
+        if ((rc = vn_launch_grad_norm(ctx, grads, t->n_lora, a.gscale, t->npartial, grad_norm_dev, s))) return rc;
+        if ((rc = vn_launch_adamw(ctx, t->lora_params, grads, mom, var, t->n_lora, a, grad_norm_dev, s))) return rc;
+        if ((rc = lora_merge_all(t, s))) return rc;
+        return vn_train_sync(t, stream);
+    }
     if ((rc = vn_launch_grad_norm(ctx, grads, t->n_total, a.gscale, t->npartial, grad_norm_dev, s))) return rc;
     auto range = [&](long lo, long hi) {
         return vn_launch_adamw(ctx, t->params + lo, grads + lo, mom + lo, var + lo, hi - lo, a, grad_norm_dev, s);

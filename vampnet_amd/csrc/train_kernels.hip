@@ -712,3 +712,124 @@ int vn_launch_adamw(vn_ctx* ctx, float* p, const float* g, float* m, float* v, l
 }
 
 // packed-layout helper: i32 tokens <- i64 (B,C,T) is vn_launch_i64_to_i32 (elementwise.hip)
+
+// =============================================================================================
+// LoRA fine-tuning (train.py:696 `lora.mark_only_lora_as_trainable`; loralib Linear(r=8, lora_alpha=1)):
+//   y = x W^T + s * (x A^T) B^T,  s = alpha / r;  W frozen, A (r x K) and B (N x r) trained.
+// The engine keeps W_eff = W + s B A in the blob (forward and dX need nothing else) and computes the two small
+// gradients from rank-r projections.  A is stored TRANSPOSED (At [K][r]) so every rank-r operand is [C][r] row-major:
+//   down:  H[m][j]  = scale * sum_c Y[m][c] * P[c][j]          (h = x At ;  dh = s * dY B)          one wave per row
+//   up:    G[c][j]  = scale * sum_m Y[m][c] * H[m][j]          (dB = s * dY^T h ;  dAt = x^T dh)     partials + reduce
+//   merge: W_eff[n][k] = W[n][k] + s * sum_j B[n][j] * At[k][j]
+// All three stream Y / W once (HBM-bound); r is fixed to 8 (transformer.py:22 LORA_R).
+// =============================================================================================
+#define VN_LORA_R 8
+
+__global__ __launch_bounds__(256) void vn_lora_down_kernel(const float* __restrict__ Y, int ldy, const float* __restrict__ P,
+                                                           float* __restrict__ H, int M, int Cn, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float acc[VN_LORA_R];
+#pragma unroll
+    for (int j = 0; j < VN_LORA_R; ++j) acc[j] = 0.f;
+    const float* y = Y + (size_t)m * ldy;
+    for (int c = lane; c < Cn; c += 64) {
+        const float v = y[c];
+        const f32x4 p0 = *(const f32x4*)(P + (size_t)c * VN_LORA_R), p1 = *(const f32x4*)(P + (size_t)c * VN_LORA_R + 4);
+        acc[0] = fmaf(v, p0[0], acc[0]); acc[1] = fmaf(v, p0[1], acc[1]); acc[2] = fmaf(v, p0[2], acc[2]); acc[3] = fmaf(v, p0[3], acc[3]);
+        acc[4] = fmaf(v, p1[0], acc[4]); acc[5] = fmaf(v, p1[1], acc[5]); acc[6] = fmaf(v, p1[2], acc[6]); acc[7] = fmaf(v, p1[3], acc[7]);
+    }
+#pragma unroll
+    for (int j = 0; j < VN_LORA_R; ++j)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o);
+    if (lane == 0) {
+        f32x4 a = {acc[0] * scale, acc[1] * scale, acc[2] * scale, acc[3] * scale};
+        f32x4 b = {acc[4] * scale, acc[5] * scale, acc[6] * scale, acc[7] * scale};
+        *(f32x4*)(H + (size_t)m * VN_LORA_R) = a;
+        *(f32x4*)(H + (size_t)m * VN_LORA_R + 4) = b;
+    }
+}
+
+int vn_launch_lora_down(vn_ctx* ctx, const float* Y, int ldy, const float* P, float* H, int M, int Cn, float scale,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(vn_lora_down_kernel, dim3(vn_cdiv(M, 4)), dim3(256), 0, s, Y, ldy, P, H, M, Cn, scale);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// partial[chunk][c][j] over 64-row chunks; thread owns column c
+__global__ __launch_bounds__(256) void vn_lora_up_partial_kernel(const float* __restrict__ Y, int ldy, const float* __restrict__ H,
+                                                                 float* __restrict__ partial, int M, int Cn) {
+    __shared__ float hs[64][VN_LORA_R];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int m0 = blockIdx.y * 64;
+    const int mend = m0 + 64 < M ? 64 : M - m0;
+    for (int i = threadIdx.x; i < 64 * VN_LORA_R; i += 256) {
+        const int mm = i / VN_LORA_R;
+        hs[mm][i - mm * VN_LORA_R] = mm < mend ? H[(size_t)(m0 + mm) * VN_LORA_R + (i - mm * VN_LORA_R)] : 0.f;
+    }
+    __syncthreads();
+    if (c >= Cn) return;
+    float acc[VN_LORA_R];
+#pragma unroll
+    for (int j = 0; j < VN_LORA_R; ++j) acc[j] = 0.f;
+    for (int mm = 0; mm < mend; ++mm) {
+        const float v = Y[(size_t)(m0 + mm) * ldy + c];
+#pragma unroll
+        for (int j = 0; j < VN_LORA_R; ++j) acc[j] = fmaf(v, hs[mm][j], acc[j]);
+    }
+    float* dst = partial + ((size_t)blockIdx.y * Cn + c) * VN_LORA_R;
+    *(f32x4*)dst = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    *(f32x4*)(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+}
+
+__global__ __launch_bounds__(256) void vn_scale_kernel(float* __restrict__ x, long n, float s) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) x[i] *= s;
+}
+
+int vn_lora_up_partial_floats(int M, int Cn) { return vn_cdiv(M, 64) * Cn * VN_LORA_R; }
+
+int vn_launch_lora_up(vn_ctx* ctx, const float* Y, int ldy, const float* H, float* G, float* partial, int M, int Cn, float scale,
+                      hipStream_t s) {
+    const int nb = vn_cdiv(M, 64);
+    hipLaunchKernelGGL(vn_lora_up_partial_kernel, dim3(vn_cdiv(Cn, 256), nb), dim3(256), 0, s, Y, ldy, H, partial, M, Cn);
+    VN_LAUNCH_CHECK(ctx);
+    int rc = vn_launch_reduce_rows(ctx, partial, nb, Cn * VN_LORA_R, G, s);
+    if (rc) return rc;
+    if (scale != 1.0f) {
+        hipLaunchKernelGGL(vn_scale_kernel, dim3(vn_cdiv(Cn * VN_LORA_R, 256)), dim3(256), 0, s, G, (long)Cn * VN_LORA_R, scale);
+        VN_LAUNCH_CHECK(ctx);
+    }
+    return VN_OK;
+}
+
+__global__ __launch_bounds__(256) void vn_lora_merge_kernel(const float* __restrict__ W, const float* __restrict__ Bm,
+                                                            const float* __restrict__ At, float* __restrict__ Weff, int N, int K,
+                                                            float scale) {
+    const int k4 = K >> 2;
+    const long total = (long)N * k4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        const int n = (int)(i / k4), k = 4 * (int)(i - (long)n * k4);
+        f32x4 w = ((const f32x4*)W)[i];
+        const f32x4 b0 = *(const f32x4*)(Bm + (size_t)n * VN_LORA_R), b1 = *(const f32x4*)(Bm + (size_t)n * VN_LORA_R + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x4 a0 = *(const f32x4*)(At + (size_t)(k + e) * VN_LORA_R), a1 = *(const f32x4*)(At + (size_t)(k + e) * VN_LORA_R + 4);
+            const float d = b0[0] * a0[0] + b0[1] * a0[1] + b0[2] * a0[2] + b0[3] * a0[3] + b1[0] * a1[0] + b1[1] * a1[1] +
+                            b1[2] * a1[2] + b1[3] * a1[3];
+            w[e] = fmaf(scale, d, w[e]);
+        }
+        ((f32x4*)Weff)[i] = w;
+    }
+}
+
+int vn_launch_lora_merge(vn_ctx* ctx, const float* W, const float* Bm, const float* At, float* Weff, int N, int K, float scale,
+                         hipStream_t s) {
+    const long total = (long)N * (K / 4);
+    hipLaunchKernelGGL(vn_lora_merge_kernel, dim3((int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), dim3(256), 0, s, W,
+                       Bm, At, Weff, N, K, scale);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}

@@ -43,3 +43,11 @@ int vn_launch_attention_train_fwd(vn_ctx* ctx, const float* q, const float* k, c
 int vn_launch_attention_bwd(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* relbias_full,
                             const int32_t* lut_dev, const float* out, const float* dout, const float* lse, float* delta,
                             float* dqkv, float* dbias_tab, int B, int H, int T, int nbuckets, const vn_drop& d, hipStream_t s);
+
+// LoRA fine-tuning helpers (rank 8; every rank-r operand is [C][8] row-major, A stored transposed)
+int vn_launch_lora_down(vn_ctx* ctx, const float* Y, int ldy, const float* P, float* H, int M, int Cn, float scale, hipStream_t s);
+int vn_lora_up_partial_floats(int M, int Cn);
+int vn_launch_lora_up(vn_ctx* ctx, const float* Y, int ldy, const float* H, float* G, float* partial, int M, int Cn, float scale,
+                      hipStream_t s);
+int vn_launch_lora_merge(vn_ctx* ctx, const float* W, const float* Bm, const float* At, float* Weff, int N, int K, float scale,
+                         hipStream_t s);

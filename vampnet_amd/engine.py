@@ -125,9 +125,12 @@ def _merge_lora(sd, key):
     return w
 
 
-def pack_weights(lib, dims: vn_dims, sd: dict, codebooks: torch.Tensor) -> torch.Tensor:
+def pack_weights(lib, dims: vn_dims, sd: dict, codebooks: torch.Tensor, merge_lora: bool = True) -> torch.Tensor:
     """Builds the packed fp32 blob (layout: include/vampnet_hip.h) on the host from a reference-format
-    state_dict (key names: SURVEY.md App. B) and the codec codebooks [>=C, vocab, latent]."""
+    state_dict (key names: SURVEY.md App. B) and the codec codebooks [>=C, vocab, latent].  `merge_lora=False` keeps the
+    base weights un-merged (LoRA fine-tuning snapshots them and merges on the device)."""
+    if not merge_lora:
+        sd = {k: v for k, v in sd.items() if "lora_" not in k}
     n = C.c_int64()
     if lib.vn_weights_size(C.byref(dims), C.byref(n)) != 0:
         raise VnError("vn_weights_size rejected the dims (need d_model == 64 * n_heads, vocab 1024)")

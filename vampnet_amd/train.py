@@ -16,6 +16,9 @@ from ._lib import VnError, vn_dims, vn_train_params
 from .engine import Engine, VampNetModel, pack_weights
 
 IGNORE_INDEX = -100           # train.py:68
+LORA_R = 8                    # transformer.py:22
+LORA_SCALING = 1.0 / LORA_R   # loralib: lora_alpha (1) / r
+LORA_KEYS = ("self_attn.w_qs", "self_attn.w_vs", "self_attn.fc", "feed_forward.w_1", "feed_forward.w_2")
 SITES = {"attn": 0, "res1": 1, "ffn": 2, "res2": 3}
 
 
@@ -34,7 +37,7 @@ class Trainer:
                  n_conditioning_codebooks=0, latent_dim=8, embedding_dim=1280, vocab_size=1024, max_batch=8, max_T=575,
                  lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_clip=5.0, label_smoothing=0.1,
                  dropout=0.1, noam_factor=2.0, noam_warmup=10000, use_noam=True, seed=0, process_group=None,
-                 batch_offset=0, **_ignored):
+                 batch_offset=0, only_lora=False, **_ignored):
         self.engine, self.lib = engine, engine.lib
         self.dims = vn_dims(n_layers, n_heads, embedding_dim, n_codebooks, n_conditioning_codebooks, vocab_size,
                             latent_dim, 32, 128, 1e-6, max_batch, max_T)
@@ -50,7 +53,8 @@ class Trainer:
         engine.check(self.lib.vn_train_param_size(C.byref(self.dims), C.byref(n)), "vn_train_param_size")
         self.n_total = n.value
         host = torch.zeros(self.n_total, dtype=torch.float32)
-        blob = pack_weights(self.lib, self.dims, sd, codebooks)
+        self.only_lora = only_lora
+        blob = pack_weights(self.lib, self.dims, sd, codebooks, merge_lora=not only_lora)
         self.wsize = blob.numel()
         host[:self.wsize] = blob
         og, ov = self._cls_offsets()
@@ -61,9 +65,15 @@ class Trainer:
         host[ov:ov + v.numel()] = v
         dev = engine.device
         self.params = host.to(dev)
-        self.grads = torch.zeros_like(self.params)
-        self.adam_m = torch.zeros_like(self.params)
-        self.adam_v = torch.zeros_like(self.params)
+        if only_lora:
+            # train.py:696 lora.mark_only_lora_as_trainable: the optimiser state covers the adapters only
+            self._base_sd = {k: v.detach().cpu().clone() for k, v in sd.items() if "lora_" not in k}
+            self.lora = self.pack_lora(sd).to(dev)
+            self.grads = torch.zeros_like(self.lora)
+        else:
+            self.grads = torch.zeros_like(self.params)
+        self.adam_m = torch.zeros_like(self.grads)
+        self.adam_v = torch.zeros_like(self.grads)
         self.loss = torch.zeros(1, device=dev)
         self.grad_norm = torch.zeros(1, device=dev)
         # inference view of the same weights (generate / forward share the blob the optimiser updates)
@@ -74,7 +84,11 @@ class Trainer:
         h = C.c_void_p()
         engine.check(self.lib.vn_train_create(self.model.handle, self.params.data_ptr(), C.byref(h)), "vn_train_create")
         self.handle = h
-        engine.check(self.lib.vn_train_sync(self.handle, engine.stream()), "vn_train_sync")
+        if only_lora:
+            engine.check(self.lib.vn_train_enable_lora(self.handle, self.lora.data_ptr(), LORA_SCALING, engine.stream()),
+                         "vn_train_enable_lora")
+        else:
+            engine.check(self.lib.vn_train_sync(self.handle, engine.stream()), "vn_train_sync")
         self._sd_template = {k: (tuple(t.shape), t.dtype) for k, t in sd.items()}
 
     def __del__(self):
@@ -223,7 +237,66 @@ class Trainer:
         return out
 
     def state_dict(self) -> dict:
+        if self.only_lora:          # frozen base (as loaded) + the current adapters, like the reference model's state_dict()
+            return {**self._base_sd, **self.lora_state_dict()}
         return self.export(self.params)
+
+    # ---- LoRA vector <-> loralib naming -------------------------------------------------------------
+    def _lora_slot(self, layer, which, ab):
+        off, cnt = C.c_int64(), C.c_int64()
+        self.engine.check(self.lib.vn_lora_param_offset(C.byref(self.dims), layer, which, ab, C.byref(off), C.byref(cnt)),
+                          "vn_lora_param_offset")
+        return off.value, cnt.value
+
+    def _w1_perm(self):
+        """packed row order of VN_W_W1: 64*g + i <- 32*g + i (value), 64*g + 32 + i <- 2D + 32*g + i (gate)"""
+        D = self.D
+        val = torch.arange(2 * D).view(2 * D // 32, 32)
+        return torch.stack([val, val + 2 * D], 1).reshape(-1)
+
+    def pack_lora(self, sd: dict) -> torch.Tensor:
+        """loralib tensors (lora_A (r,in), lora_B (out,r)) -> engine LoRA vector; missing adapters are initialised like
+        loralib.Linear.reset_parameters (A kaiming-uniform(a=sqrt 5), B zeros)."""
+        n = C.c_int64()
+        self.engine.check(self.lib.vn_lora_param_size(C.byref(self.dims), C.byref(n)), "vn_lora_param_size")
+        out = torch.zeros(n.value, dtype=torch.float32)
+        for l in range(self.dims.n_layers):
+            for w, key in enumerate(LORA_KEYS):
+                name = f"transformer.layers.{l}.{key}"
+                n_out, n_in = sd[name + ".weight"].shape
+                a = sd.get(name + ".lora_A")
+                b = sd.get(name + ".lora_B")
+                if a is None:
+                    a = torch.empty(LORA_R, n_in)
+                    torch.nn.init.kaiming_uniform_(a, a=math.sqrt(5))
+                    b = torch.zeros(n_out, LORA_R)
+                a, b = a.float(), b.float()
+                if key == "feed_forward.w_1":
+                    b = b[self._w1_perm()]
+                oa, ca = self._lora_slot(l, w, 0)
+                ob, cb = self._lora_slot(l, w, 1)
+                out[oa:oa + ca] = a.t().contiguous().reshape(-1)            # stored transposed: At [in][r]
+                out[ob:ob + cb] = b.contiguous().reshape(-1)
+        return out
+
+    def export_lora(self, buf=None) -> dict:
+        """engine LoRA vector (parameters by default, or gradients / moments) -> {name.lora_A, name.lora_B}"""
+        buf = (self.lora if buf is None else buf).detach().cpu()
+        out = {}
+        inv = torch.argsort(self._w1_perm())
+        for l in range(self.dims.n_layers):
+            for w, key in enumerate(LORA_KEYS):
+                name = f"transformer.layers.{l}.{key}"
+                oa, ca = self._lora_slot(l, w, 0)
+                ob, cb = self._lora_slot(l, w, 1)
+                out[name + ".lora_A"] = buf[oa:oa + ca].view(-1, LORA_R).t().clone()
+                b = buf[ob:ob + cb].view(-1, LORA_R)
+                out[name + ".lora_B"] = (b[inv] if key == "feed_forward.w_1" else b).clone()
+        return out
+
+    def lora_state_dict(self) -> dict:
+        """What train.py:401-405 saves as lora.pth (loralib.lora_state_dict: the names containing 'lora_')."""
+        return self.export_lora(self.lora)
 
     def pack(self, sd_like: dict, codebooks: torch.Tensor = None) -> torch.Tensor:
         """Inverse of `export`: a state_dict-shaped set of tensors (parameters, gradients or Adam moments in the
