@@ -101,7 +101,8 @@ def bench_train(args, rank, world, device, pg, barrier):
     Bg, T = args.batch_per_gpu, 575
     eng = Engine(device)
     tr = Trainer(eng, W.synth_state_dict(dims, 0), W.synth_codebooks(), **model_kwargs(dims), max_batch=Bg, max_T=T,
-                 dropout=0.1, label_smoothing=0.1, grad_clip=5.0, lr=1e-3, process_group=pg, batch_offset=rank * Bg, seed=0)
+                 dropout=0.1, label_smoothing=0.1, grad_clip=5.0, lr=1e-3, process_group=pg, batch_offset=rank * Bg, seed=0,
+                 only_lora=args.lora_only)
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     z = torch.randint(0, 1024, (Bg, 4, T), device=device, generator=gen)
     rs = torch.rand(args.warmup + args.steps, Bg, device=device, generator=gen)
@@ -129,8 +130,10 @@ def bench_train(args, rank, world, device, pg, barrier):
         return
     tokens = world * Bg * 4 * T * args.steps
     fwd_gflop = 416.76                                     # coarse forward per item
-    step_tflop = 3.0 * fwd_gflop * Bg / 1e3                # forward + dX + dW of every product
-    res = {"metric": "codec-tokens/s, conf/vampnet.yml training step (coarse model)", "value": tokens / elapsed,
+    # forward + dX + dW of every product; LoRA-only skips the dW products (the rank-8 gradients are HBM-bound passes)
+    step_tflop = (2.0 if args.lora_only else 3.0) * fwd_gflop * Bg / 1e3
+    res = {"metric": "codec-tokens/s, " + ("LoRA-only fine-tuning step" if args.lora_only else "conf/vampnet.yml training step")
+                     + " (coarse model)", "value": tokens / elapsed,
            "unit": "codec-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic (random-init weights of the real architecture, random DAC tokens, r ~ U(0,1))",
@@ -152,7 +155,9 @@ def bench_train(args, rank, world, device, pg, barrier):
                            "attention": {"launches": int(an), "avg_launch_us": 1e3 * ams / an if an else None,
                                          "achieved": afl / (ams * 1e-3) / 1e12 if ams else None,
                                          "time_frac": ams / (1e3 * elapsed)}}
-    if not args.no_cpu_baseline:
+    if args.lora_only:
+        res["config"]["workload"] += "; LoRA-only (r=8 adapters on w_qs, w_vs, fc, w_1, w_2; everything else frozen)"
+    if not args.no_cpu_baseline and not args.lora_only:
         res["cpu_baseline"] = cpu_baseline_train()
     print(json.dumps(res), flush=True)
 
@@ -169,6 +174,8 @@ def main():
                     help="f32 = exact-fp32 MFMA (parity-backed default); bf16 = fast mode, not bit-exact")
     ap.add_argument("--workload", choices=["vamp", "train"], default="vamp",
                     help="vamp = the headline inference path (default); train = BASELINE configs[4] training step")
+    ap.add_argument("--lora-only", action="store_true",
+                    help="train workload: LoRA-only fine-tuning step (train.py:696) instead of full training")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
