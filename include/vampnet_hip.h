@@ -262,6 +262,11 @@ int  vn_train_forward_backward(vn_train* tr, const int64_t* z_masked, const int6
 /* train()-mode forward only; logits dev f32 [B][T][Cp][vocab] (parity tests / validation with dropout = 0)          */
 int  vn_train_forward(vn_train* tr, const int64_t* z_masked, int B, int T, const vn_train_params* p, float* logits,
                       void* stream);
+/* val_loop (train.py:327-377): eval()-mode forward, then for every (b, t, c) row the label-smoothed CE against
+ * target (dev int64 [B][T*Cp], every entry a valid token) -> row_loss dev f32 [B*T*Cp], and the number of classes whose
+ * logit is strictly greater than the target's -> rank dev int32 [B*T*Cp] (accuracy top-k = rank < k, train.py:155-183).    */
+int  vn_train_eval(vn_train* tr, const int64_t* z_masked, const int64_t* target, int B, int T, float label_smoothing,
+                   float* row_loss, int32_t* rank, void* stream);
 /* *grad_norm_dev = || grads / world_size ||_2 ; clip ; AdamW on every trainable element ; vn_train_sync.             */
 int  vn_train_update(vn_train* tr, const float* grads, float* adam_m, float* adam_v, const vn_train_params* p,
                      float* grad_norm_dev, void* stream);
@@ -276,6 +281,8 @@ int  vn_train_update(vn_train* tr, const float* grads, float* adam_m, float* ada
 int  vn_lora_param_size(const vn_dims* dims, int64_t* n_floats);
 int  vn_lora_param_offset(const vn_dims* dims, int layer, int which, int ab, int64_t* offset, int64_t* count);
 int  vn_train_enable_lora(vn_train* tr, float* lora_params, float scaling, void* stream);
+/* after changing `lora_params` from outside (checkpoint load): blob <- W + s B A, then vn_train_sync                    */
+int  vn_train_lora_merge(vn_train* tr, void* stream);
 
 /* The keep-mask the kernels use at one dropout site (site 0: attention probabilities, rows = (b, h, query), cols = keys;
  * 1: attention residual, 2: GEGLU output, 3: FFN residual; rows = (b, t)); out dev u8 [rows][cols].  For parity tests. */

@@ -275,3 +275,91 @@ def test_lora_finetune_step_vs_oracle(engine, which, B, T, p):
     ref_model = VampNetModel(engine, full, cb, **model_kwargs(dims), max_batch=B, max_T=T)
     assert (ref_model.forward_codes(z_mask) - tr.model.forward_codes(z_mask)).abs().max().item() < 2e-5
     engine.health_check()
+
+
+# ----------------------------------------------------------------------------- validation + checkpoint / resume
+def test_evaluate_matches_reference_metrics(engine):
+    """val_loop (train.py:327-377): loss and the eight accuracy metrics of _metrics (train.py:184-215) computed by the
+    reference's own formulas on the oracle's eval-mode logits."""
+    from einops import rearrange
+    dims = W.TINY_C2F_DIMS
+    sd, cb = W.synth_state_dict(dims, 1), W.synth_codebooks()
+    tr = _trainer(engine, dims, sd, cb, max_batch=4, max_T=30, dropout=0.1)
+    z = W.synth_codes(4, 14, 30, seed=12)
+    r = torch.tensor([0.1, 0.45, 0.6, 0.95])
+    mask = TO.make_training_mask(z, r, 4, generator=torch.Generator().manual_seed(8))
+    out = tr.evaluate(z, r=r, mask=mask)
+    zm, m = O.apply_mask(z, mask, 1024)
+    z_hat = O.forward(sd, dims, O.from_codes(sd, cb, zm))
+    target = O.codebook_flatten(z[:, 4:, :])
+    flat = O.codebook_flatten(m[:, 4:, :])
+    loss = torch.nn.functional.cross_entropy(z_hat, target.masked_fill(~flat.bool(), -100), label_smoothing=0.1)
+    assert abs(out["loss"].item() - loss.item()) < 1e-5 * loss.item()
+
+    def accuracy(preds, tgt, top_k, ignore_index=-100):            # train.py:155-183 restated
+        preds = rearrange(preds, "b p s -> (b s) p")
+        tgt = rearrange(tgt, "b s -> (b s)")
+        keep = tgt != ignore_index
+        preds, tgt = preds[keep], tgt[keep]
+        _, idx = torch.topk(preds, k=top_k, dim=-1)
+        return torch.eq(idx, tgt.unsqueeze(1)).sum(1).float().mean()
+
+    for lo, hi in ((0, 0.5), (0.5, 1.0)):
+        sel = (r >= lo) & (r < hi)
+        for k in (1, 25):
+            for name, tg in (("unmasked", target.masked_fill(flat.bool(), -100)), ("masked", target.masked_fill(~flat.bool(), -100))):
+                want = accuracy(z_hat[sel], tg[sel], k)
+                got = out[f"accuracy-{lo}-{hi}/top{k}/{name}"].cpu()
+                assert abs(got.item() - want.item()) < 1e-6, (lo, hi, k, name, got.item(), want.item())
+
+
+@pytest.mark.parametrize("only_lora", [False, True])
+def test_checkpoint_resume_and_interface_load(engine, tmp_path, only_lora):
+    """save_checkpoint writes the reference's layout (train.py:380-420); a fresh Trainer resumed from it continues
+    bit-identically (same parameters, moments, step counter, dropout stream); torch.optim.AdamW accepts optimizer.pth; the
+    Interface twin loads weights.pth (+ lora.pth) for inference."""
+    dims = W.TINY_COARSE_DIMS
+    base = W.synth_state_dict(dims, 0)
+    sd = TO.add_lora(base, dims, seed=1, zero_b=True) if only_lora else base
+    cb = W.synth_codebooks()
+    kw = dict(max_batch=2, max_T=32, dropout=0.1, seed=3, only_lora=only_lora, use_noam=False, lr=1e-3)
+    tr = _trainer(engine, dims, sd, cb, **kw)
+    z = W.synth_codes(2, 4, 32, seed=4)
+    mask = TO.make_training_mask(z, torch.tensor([0.5, 0.9]), 0, generator=torch.Generator().manual_seed(5))
+    for _ in range(3):
+        tr.step(z, mask=mask)
+    folder = tr.save_checkpoint(str(tmp_path / "run"), tag="latest")
+    tr.step(z, mask=mask)
+    want_loss, want = tr.loss.clone(), {k: v.clone() for k, v in tr.state_dict().items()}
+
+    tr2 = _trainer(engine, dims, sd, cb, **kw)
+    tr2.load_checkpoint(folder)
+    assert tr2.steps == 3
+    tr2.step(z, mask=mask)
+    assert torch.equal(tr2.loss, want_loss)
+    got = tr2.state_dict()
+    for k, v in want.items():
+        assert torch.equal(got[k], v), k
+
+    # the optimizer file is a torch.optim.AdamW state_dict over the same parameter list
+    import os
+    names = tr._param_names()
+    ps = [torch.nn.Parameter(torch.zeros(tr._sd_template[k][0])) for k in names]
+    opt = torch.optim.AdamW(ps, lr=1e-3)
+    opt.load_state_dict(torch.load(os.path.join(folder, "optimizer.pth")))
+    assert float(opt.state[ps[0]]["step"]) == 3.0
+    assert os.path.exists(os.path.join(folder, "lora.pth")) == only_lora
+
+    # inference twin reads the same files
+    from vampnet_amd.interface import _load_checkpoint
+    sd_ck, kwargs = _load_checkpoint(os.path.join(folder, "vampnet", "weights.pth"))
+    assert kwargs["n_layers"] == dims["n_layers"] and kwargs["embedding_dim"] == dims["d_model"]
+    if only_lora:
+        sd_ck.update(torch.load(os.path.join(folder, "lora.pth")))
+    from vampnet_amd.engine import VampNetModel
+    from vampnet_amd.synth import model_kwargs
+    tr3 = _trainer(engine, dims, sd, cb, **kw)
+    tr3.load_checkpoint(folder)
+    inf = VampNetModel(engine, sd_ck, cb, **model_kwargs(dims), max_batch=2, max_T=32)
+    zm, _ = tr.make_batch(z, mask=mask)
+    assert (inf.forward_codes(zm) - tr3.model.forward_codes(zm)).abs().max().item() < 2e-5

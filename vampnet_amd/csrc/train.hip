@@ -312,6 +312,14 @@ extern "C" int vn_train_enable_lora(vn_train* t, float* lora_params, float scali
     return vn_train_sync(t, stream);
 }
 
+// re-derive W_eff and its copies after the adapters were changed from outside (checkpoint load)
+extern "C" int vn_train_lora_merge(vn_train* t, void* stream) {
+    if (!t) return VN_ERR_INVALID;
+    if (!t->lora) return vn_fail(t->m->ctx, VN_ERR_INVALID, "vn_train_lora_merge: LoRA mode is not enabled%s", "");
+    int rc = lora_merge_all(t, (hipStream_t)stream);
+    return rc ? rc : vn_train_sync(t, stream);
+}
+
 // gradients of one LoRA'd linear y = x W^T + s (x At) B^T given X [M][K] (row stride ldx) and dY [M][N] (row stride ldy)
 static int lora_grads(vn_train* t, const float* X, int ldx, const float* dY, int ldy, int l, int which, float* grads, int M,
                       hipStream_t s) {
@@ -490,6 +498,23 @@ extern "C" int vn_train_forward(vn_train* t, const int64_t* z_masked, int B, int
     if ((rc = forward_train(t, B, T, p, s))) return rc;
     VN_HIP_CHECK(ctx, hipMemcpyAsync(logits, m->logits, (size_t)B * T * t->NV * sizeof(float), hipMemcpyDeviceToDevice, s));
     return VN_OK;
+}
+
+// val_loop (train.py:327-377): eval()-mode forward (dropout off) + per-row loss / rank of the true token
+extern "C" int vn_train_eval(vn_train* t, const int64_t* z_masked, const int64_t* target, int B, int T, float label_smoothing,
+                             float* row_loss, int32_t* rank, void* stream) {
+    if (!t || !z_masked || !target || !row_loss || !rank) return VN_ERR_INVALID;
+    vn_model* m = t->m;
+    vn_ctx* ctx = m->ctx;
+    hipStream_t s = (hipStream_t)stream;
+    if (B <= 0 || T <= 0 || B > m->d.max_batch || T > m->d.max_T)
+        return vn_fail(ctx, VN_ERR_INVALID, "eval: B=%s%ld, T=%ld outside the model workspace", "", B, T);
+    vn_train_params p{};
+    p.step = 1; p.world_size = 1; p.dropout = 0.f;
+    int rc;
+    if ((rc = vn_launch_i64_to_i32(ctx, z_masked, m->z, (long)B * m->d.n_codebooks * T, s))) return rc;
+    if ((rc = forward_train(t, B, T, &p, s))) return rc;
+    return vn_launch_eval_rows(ctx, m->logits, target, (long)B * T * m->Cp, m->d.vocab, label_smoothing, row_loss, rank, s);
 }
 
 extern "C" int vn_train_update(vn_train* t, const float* grads, float* mom, float* var, const vn_train_params* p,

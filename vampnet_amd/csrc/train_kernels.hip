@@ -833,3 +833,64 @@ int vn_launch_lora_merge(vn_ctx* ctx, const float* W, const float* Bm, const flo
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Validation statistics (train.py:327-377 `val_loop` + :155-215 `accuracy` / `_metrics`): for every row of V logits
+//   row_loss = label-smoothed CE against target[row]           (every row has a target here; the caller masks)
+//   rank     = number of classes with a logit strictly greater than the target's  (target in top-k  <=>  rank < k)
+// One wave per row.
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void vn_eval_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                           long rows, float ls, float* __restrict__ row_loss,
+                                                           int32_t* __restrict__ rank) {
+    const int lane = threadIdx.x & 63;
+    const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    constexpr int V = VEC * 256;
+    const f32x4* xr = (const f32x4*)(logits + row * V);
+    int t = (int)target[row];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    f32x4 x[VEC];
+    float mx = -INFINITY, sx = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        x[i] = xr[lane + 64 * i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { mx = fmaxf(mx, x[i][e]); sx += x[i][e]; }
+    }
+    const float xt = logits[row * V + t];
+    int gt = 0;
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gt += x[i][e] > xt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+        sx += __shfl_xor(sx, o);
+        gt += __shfl_xor(gt, o);
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) se += expf(x[i][e] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+    if (lane == 0) {
+        const float logZ = mx + logf(se);
+        row_loss[row] = (1.0f - ls) * (logZ - xt) + ls * (logZ - sx / (float)V);
+        rank[row] = gt;
+    }
+}
+
+int vn_launch_eval_rows(vn_ctx* ctx, const float* logits, const int64_t* target, long rows, int V, float ls, float* row_loss,
+                        int32_t* rank, hipStream_t s) {
+    if (V != 1024 && V != 256) return vn_fail(ctx, VN_ERR_UNSUPPORTED, "eval: vocab=%s%ld unsupported", "", V);
+    const int blocks = (int)((rows + 3) / 4);
+    if (V == 1024) hipLaunchKernelGGL(vn_eval_rows_kernel<4>, dim3(blocks), dim3(256), 0, s, logits, target, rows, ls, row_loss, rank);
+    else hipLaunchKernelGGL(vn_eval_rows_kernel<1>, dim3(blocks), dim3(256), 0, s, logits, target, rows, ls, row_loss, rank);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}

@@ -51,3 +51,6 @@ int vn_launch_lora_up(vn_ctx* ctx, const float* Y, int ldy, const float* H, floa
                       hipStream_t s);
 int vn_launch_lora_merge(vn_ctx* ctx, const float* W, const float* Bm, const float* At, float* Weff, int N, int K, float scale,
                          hipStream_t s);
+
+int vn_launch_eval_rows(vn_ctx* ctx, const float* logits, const int64_t* target, long rows, int V, float ls, float* row_loss,
+                        int32_t* rank, hipStream_t s);

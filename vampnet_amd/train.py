@@ -54,6 +54,14 @@ class Trainer:
         self.n_total = n.value
         host = torch.zeros(self.n_total, dtype=torch.float32)
         self.only_lora = only_lora
+        self._sd_template = {k: (tuple(t.shape), t.dtype) for k, t in sd.items()}
+        if only_lora:        # adapters that the checkpoint does not hold yet still get optimiser slots, in model order
+            for l in range(n_layers):
+                for key in LORA_KEYS:
+                    name = f"transformer.layers.{l}.{key}"
+                    n_out, n_in = sd[name + ".weight"].shape
+                    self._sd_template.setdefault(name + ".lora_A", ((LORA_R, n_in), torch.float32))
+                    self._sd_template.setdefault(name + ".lora_B", ((n_out, LORA_R), torch.float32))
         blob = pack_weights(self.lib, self.dims, sd, codebooks, merge_lora=not only_lora)
         self.wsize = blob.numel()
         host[:self.wsize] = blob
@@ -89,7 +97,6 @@ class Trainer:
                          "vn_train_enable_lora")
         else:
             engine.check(self.lib.vn_train_sync(self.handle, engine.stream()), "vn_train_sync")
-        self._sd_template = {k: (tuple(t.shape), t.dtype) for k, t in sd.items()}
 
     def __del__(self):
         try:
@@ -181,6 +188,131 @@ class Trainer:
         return {"loss": self.loss, "other/grad_norm": self.grad_norm, "other/learning_rate": self.last_lr,
                 "other/batch_size": z.shape[0]}
 
+    # ---- validation (train.py:327-377 val_loop, :155-215 accuracy / _metrics) -----------------------
+    def evaluate(self, z, r=None, mask=None, generator=None):
+        """One val_loop iteration: eval()-mode forward, CE on the masked targets and the reference's top-1 / top-25
+        accuracies split by masked / unmasked tokens and by mask ratio r in [0, 0.5) / [0.5, 1).  Per-row loss and the rank
+        of the true token come from the engine (vn_train_eval); only the bookkeeping over those B*T*Cp numbers is torch."""
+        z = z.to(self.engine.device, torch.int64)
+        if mask is None:
+            probs = torch.ones_like(z, dtype=torch.float32) * masks.gamma(r.to(z.device).float())[:, None, None]
+            mask = torch.bernoulli(probs, generator=generator).round().long()
+        mask = mask.to(z.device).clone()
+        mask[:, :self.n_cond, :] = 0
+        z_mask, mask = masks.apply_mask(z, mask, self.mask_token)
+        B, _, T = z.shape
+        target = z[:, self.n_cond:, :].permute(0, 2, 1).reshape(B, -1).contiguous()
+        flat = mask[:, self.n_cond:, :].permute(0, 2, 1).reshape(B, -1).bool()
+        row_loss = torch.empty(B, T * self.Cp, device=z.device, dtype=torch.float32)
+        rank = torch.empty(B, T * self.Cp, device=z.device, dtype=torch.int32)
+        self.engine.check(self.lib.vn_train_eval(self.handle, z_mask.contiguous().data_ptr(), target.data_ptr(), B, T,
+                                                 self.hp["label_smoothing"], row_loss.data_ptr(), rank.data_ptr(),
+                                                 self.engine.stream()), "vn_train_eval")
+        out = {"loss": row_loss[flat].mean() if bool(flat.any()) else row_loss.sum() * 0.0}
+        if r is not None:
+            r = r.to(z.device).float()
+            for lo, hi in ((0, 0.5), (0.5, 1.0)):
+                sel = ((r >= lo) & (r < hi))[:, None].expand_as(flat)
+                for k in (1, 25):
+                    hit = (rank < k).float()
+                    for name, m in (("unmasked", sel & ~flat), ("masked", sel & flat)):
+                        out[f"accuracy-{lo}-{hi}/top{k}/{name}"] = hit[m].mean()      # nan when the group is empty, like the reference
+        return out
+
+    # ---- checkpoint / resume (train.py:380-420 checkpoint(), :560-600 load) -------------------------
+    def _param_names(self):
+        names = [k for k in self._sd_template if not k.endswith("num_batches_tracked")]
+        return [k for k in names if "lora_" in k] if self.only_lora else [k for k in names if "lora_" not in k]
+
+    def optimizer_state_dict(self) -> dict:
+        """torch.optim.AdamW.state_dict() layout (parameter index = position in the state_dict order the Trainer was
+        built from = model.parameters() order for a reference checkpoint), so the reference can resume from it."""
+        exp = self.export_lora if self.only_lora else self.export
+        m, v = exp(self.adam_m), exp(self.adam_v)
+        names = self._param_names()
+        state = {}
+        if self.steps > 0:
+            for i, k in enumerate(names):
+                shp = self._sd_template[k][0]
+                state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": m[k].reshape(shp).clone(),
+                            "exp_avg_sq": v[k].reshape(shp).clone()}
+        hp = self.hp
+        group = {"lr": getattr(self, "last_lr", hp["lr"]), "betas": (hp["beta1"], hp["beta2"]), "eps": hp["eps"],
+                 "weight_decay": hp["weight_decay"], "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                 "differentiable": False, "fused": None, "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, osd: dict):
+        names = self._param_names()
+        st = osd.get("state", {})
+        if not st:
+            self.adam_m.zero_(); self.adam_v.zero_()
+            return
+        m = {k: st[i]["exp_avg"] for i, k in enumerate(names)}
+        v = {k: st[i]["exp_avg_sq"] for i, k in enumerate(names)}
+        if self.only_lora:
+            self.adam_m.copy_(self.pack_lora(m, init_missing=False))
+            self.adam_v.copy_(self.pack_lora(v, init_missing=False))
+        else:
+            self.adam_m.copy_(self.pack(m)); self.adam_v.copy_(self.pack(v))
+        self.steps = int(float(st[0]["step"]))
+
+    def scheduler_state_dict(self) -> dict:
+        """vampnet/scheduler.py:30-33: every attribute of NoamScheduler except the optimizer."""
+        f, w = self.noam if self.noam else (None, None)
+        return {"warmup": w, "factor": f, "d_model": self.D, "lr": getattr(self, "last_lr", None), "steps": self.steps}
+
+    def save_checkpoint(self, save_path: str, tag: str = "latest", fine_tune: bool = None, extra: dict = None) -> str:
+        """Writes what train.py:380-420 writes for one tag: <save_path>/<tag>/vampnet/weights.pth in the audiotools
+        BaseModel layout ({"state_dict", "metadata": {"kwargs"}}), optimizer.pth, scheduler.pth and, when
+        fine-tuning, lora.pth (= loralib.lora_state_dict).  Readable by vampnet_amd.Interface(coarse_ckpt=..., coarse_lora_ckpt=...)."""
+        import os
+        fine_tune = self.only_lora if fine_tune is None else fine_tune
+        folder = os.path.join(save_path, tag)
+        os.makedirs(os.path.join(folder, "vampnet"), exist_ok=True)
+        d = self.dims
+        kwargs = dict(n_heads=d.n_heads, n_layers=d.n_layers, n_codebooks=d.n_codebooks, n_conditioning_codebooks=d.n_cond,
+                      latent_dim=d.latent_dim, embedding_dim=d.d_model, vocab_size=d.vocab, dropout=self.hp["dropout"])
+        sd = self.state_dict()
+        if fine_tune:
+            torch.save(self.lora_state_dict(), os.path.join(folder, "lora.pth"))
+        torch.save({"state_dict": sd, "metadata": {"kwargs": kwargs, **(extra or {})}}, os.path.join(folder, "vampnet", "weights.pth"))
+        torch.save(self.optimizer_state_dict(), os.path.join(folder, "optimizer.pth"))
+        torch.save(self.scheduler_state_dict(), os.path.join(folder, "scheduler.pth"))
+        return folder
+
+    def load_checkpoint(self, folder: str):
+        """Resume: parameters (+ adapters), Adam moments and the step counter from a folder written by save_checkpoint (or by
+        the reference's checkpoint() for the same architecture)."""
+        import os
+        ck = torch.load(os.path.join(folder, "vampnet", "weights.pth"), map_location="cpu")
+        sd = ck["state_dict"]
+        lp = os.path.join(folder, "lora.pth")
+        if os.path.exists(lp):
+            sd = {**sd, **torch.load(lp, map_location="cpu")}
+        self.load_state_dict(sd)
+        op = os.path.join(folder, "optimizer.pth")
+        if os.path.exists(op):
+            self.load_optimizer_state_dict(torch.load(op, map_location="cpu"))
+        sp = os.path.join(folder, "scheduler.pth")
+        if os.path.exists(sp):
+            self.steps = int(torch.load(sp, map_location="cpu").get("steps", self.steps))
+
+    def load_state_dict(self, sd: dict):
+        """Replace the parameters (full mode: everything; LoRA mode: the adapters — the frozen base is what the Trainer was
+        built with) and re-derive the engine's folded / transposed / merged copies."""
+        if self.only_lora:
+            self.lora.copy_(self.pack_lora({**self._base_sd, **{k: v for k, v in sd.items() if "lora_" in k}}))
+            self._remerge()
+        else:
+            cb = self._tensor(self.params, _lib.W_EMB_TABLES).view(self.n_codebooks, self.vocab + 1, -1)[:, :self.vocab].cpu()
+            self.params.copy_(self.pack(sd, cb))
+            self.engine.check(self.lib.vn_train_sync(self.handle, self.engine.stream()), "vn_train_sync")
+
+    def _remerge(self):
+        """LoRA mode: W_eff = W + B A / 8 after an external change of the adapters (a zero-lr update would also decay)."""
+        self.engine.check(self.lib.vn_train_lora_merge(self.handle, self.engine.stream()), "vn_train_lora_merge")
+
     # ---- debugging / parity helpers ---------------------------------------------------------------
     def dropout_keep_mask(self, layer, site, B, T, step=None, p=None):
         """The keep-mask of one dropout site in the REFERENCE tensor layout: attn (H,B,T,T); res1/res2 (B,T,D); ffn (B,T,2D)."""
@@ -254,21 +386,22 @@ class Trainer:
         val = torch.arange(2 * D).view(2 * D // 32, 32)
         return torch.stack([val, val + 2 * D], 1).reshape(-1)
 
-    def pack_lora(self, sd: dict) -> torch.Tensor:
+    def pack_lora(self, sd: dict, init_missing: bool = True) -> torch.Tensor:
         """loralib tensors (lora_A (r,in), lora_B (out,r)) -> engine LoRA vector; missing adapters are initialised like
-        loralib.Linear.reset_parameters (A kaiming-uniform(a=sqrt 5), B zeros)."""
+        loralib.Linear.reset_parameters (A kaiming-uniform(a=sqrt 5), B zeros), or left zero (`init_missing=False`)."""
         n = C.c_int64()
         self.engine.check(self.lib.vn_lora_param_size(C.byref(self.dims), C.byref(n)), "vn_lora_param_size")
         out = torch.zeros(n.value, dtype=torch.float32)
         for l in range(self.dims.n_layers):
             for w, key in enumerate(LORA_KEYS):
                 name = f"transformer.layers.{l}.{key}"
-                n_out, n_in = sd[name + ".weight"].shape
+                n_out, n_in = self._sd_template[name + ".weight"][0]
                 a = sd.get(name + ".lora_A")
                 b = sd.get(name + ".lora_B")
                 if a is None:
-                    a = torch.empty(LORA_R, n_in)
-                    torch.nn.init.kaiming_uniform_(a, a=math.sqrt(5))
+                    a = torch.zeros(LORA_R, n_in)
+                    if init_missing:
+                        torch.nn.init.kaiming_uniform_(a, a=math.sqrt(5))
                     b = torch.zeros(n_out, LORA_R)
                 a, b = a.float(), b.float()
                 if key == "feed_forward.w_1":
