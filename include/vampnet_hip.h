@@ -259,6 +259,14 @@ int  vn_train_sync(vn_train* tr, void* stream);
  * (train vector layout) with d(loss)/d(param) and *loss_dev with the mean loss over the valid targets of THIS call.   */
 int  vn_train_forward_backward(vn_train* tr, const int64_t* z_masked, const int64_t* target, int B, int T,
                                const vn_train_params* p, float* grads, float* loss_dev, void* stream);
+/* The same step in pieces, for overlapping the data-parallel gradient exchange with the backward pass:
+ * vn_train_forward_loss = zero `grads`, forward, loss, d(loss)/d(logits); vn_train_backward runs the backward stages
+ * stage_hi >= ... >= stage_lo (n_layers = classifier + final norm, n_layers-1 .. 0 = transformer layers, -1 = embedding).
+ * After stage s has run, every gradient produced by stages >= s is final EXCEPT the shared relative-position table
+ * (VN_W_REL_BIAS, final after stage 0).  vn_train_forward_backward == forward_loss + backward(n_layers, -1).            */
+int  vn_train_forward_loss(vn_train* tr, const int64_t* z_masked, const int64_t* target, int B, int T,
+                           const vn_train_params* p, float* grads, float* loss_dev, void* stream);
+int  vn_train_backward(vn_train* tr, const vn_train_params* p, float* grads, int stage_hi, int stage_lo, void* stream);
 /* train()-mode forward only; logits dev f32 [B][T][Cp][vocab] (parity tests / validation with dropout = 0)          */
 int  vn_train_forward(vn_train* tr, const int64_t* z_masked, int B, int T, const vn_train_params* p, float* logits,
                       void* stream);

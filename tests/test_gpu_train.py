@@ -363,3 +363,53 @@ def test_checkpoint_resume_and_interface_load(engine, tmp_path, only_lora):
     inf = VampNetModel(engine, sd_ck, cb, **model_kwargs(dims), max_batch=2, max_T=32)
     zm, _ = tr.make_batch(z, mask=mask)
     assert (inf.forward_codes(zm) - tr3.model.forward_codes(zm)).abs().max().item() < 2e-5
+
+
+def test_staged_backward_with_overlapped_allreduce(engine):
+    """The data-parallel step with the gradient exchange overlapped with the backward pass (one-rank RCCL group on this
+    GPU: the collectives are identities, everything else is the real code path): same loss and gradients as the
+    monolithic call; the bucket slices tile the trainable part of the gradient vector exactly once."""
+    import os
+    import socket
+    import torch.distributed as dist
+    dims = W.TINY_COARSE_DIMS
+    sd, cb = W.synth_state_dict(dims, 0), W.synth_codebooks()
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        kw = dict(max_batch=2, max_T=32, dropout=0.1, seed=5, use_noam=False, lr=1e-3)
+        tr = _trainer(engine, dims, sd, cb, process_group=dist.group.WORLD, layers_per_bucket=1, **kw)
+        ref = _trainer(engine, dims, sd, cb, **kw)
+        assert tr.overlap and not ref.overlap
+        # bucket coverage: every trainable element exactly once, the derived classifier weight never
+        cover = torch.zeros(tr.n_total, dtype=torch.int32)
+        for _, _, slices in tr._buckets():
+            for a, b in slices:
+                cover[a:b] += 1
+        from vampnet_amd import _lib
+        cw = tr._tensor(cover, _lib.W_CLS_W)
+        assert int(cw.max()) == 0
+        cw += 1
+        assert int(cover.min()) == 1 and int(cover.max()) == 1
+        z = W.synth_codes(2, 4, 32, seed=9)
+        mask = TO.make_training_mask(z, torch.tensor([0.4, 0.8]), 0, generator=torch.Generator().manual_seed(2))
+        z_mask, target = tr.make_batch(z, mask=mask)
+        a = tr.forward_backward_overlapped(z_mask, target).clone()
+        b = ref.forward_backward(z_mask, target).clone()
+        assert torch.equal(a, b)
+        rb, rb_ref = tr._tensor(tr.grads, _lib.W_REL_BIAS), ref._tensor(ref.grads, _lib.W_REL_BIAS)
+        assert (rb - rb_ref).abs().max().item() <= 1e-5 * rb_ref.abs().max().item()     # float atomics
+        rb.copy_(rb_ref)
+        assert torch.equal(tr.grads, ref.grads)
+        for _ in range(2):                                   # whole steps through the overlapped path
+            o1 = tr.step(z, mask=mask)
+            o2 = ref.step(z, mask=mask)
+            assert abs(o1["loss"].item() - o2["loss"].item()) < 1e-6
+        for k, v in ref.state_dict().items():
+            assert (tr.state_dict()[k] - v).abs().max().item() < 1e-6, k
+    finally:
+        if own_pg:
+            dist.destroy_process_group()

@@ -43,6 +43,7 @@ class OracleBackedTrainer(Trainer):
         self.hp.update(hp)
         self.noam = (2.0, 10000)
         self.seed, self.pg, self.batch_offset, self.steps = 0, pg, batch_offset, 0
+        self.overlap, self._reduced, self.only_lora = False, False, False
         n = C.c_int64()
         assert self.lib.vn_train_param_size(C.byref(self.dims), C.byref(n)) == 0
         self.n_total = n.value

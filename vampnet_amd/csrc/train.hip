@@ -384,20 +384,28 @@ static int grad_weight(vn_train* t, const float* dY, const float* X, float* dW, 
     return gemm(ctx, t->At, t->Bt, nullptr, dW, N, K, Mp, VN_EPI_STORE, s);
 }
 
-static int backward(vn_train* t, int B, int T, const vn_train_params* p, float* grads, hipStream_t s) {
+// Backward over the stages hi >= ... >= lo of the stashed forward: stage L = classifier + final norm, stages L-1 .. 0 =
+// transformer layers, stage -1 = codebook embedding.  Between stages the running gradient lives in t->dxa, so a caller
+// may interleave its own work (e.g. the all-reduce of the gradient slices that are already final) between calls.
+static int backward_range(vn_train* t, const vn_train_params* p, float* grads, int hi, int lo, hipStream_t s) {
     vn_model* m = t->m;
     vn_ctx* ctx = m->ctx;
+    const int B = t->B, T = t->T;
     const int D = m->D, H = m->H, M = B * T, L = m->L, NV = t->NV;
     const long plane = (long)B * H * T * VN_DHEAD;
     const long r_tok = (long)p->batch_offset * T, r_att = (long)p->batch_offset * H * T;
-    int rc;
+    int rc = VN_OK;
     float* dlog = m->logits;
-    // ---- classifier (WNConv1d 1x1, transformer.py:596-604) + final norm
-    if ((rc = gemm(ctx, dlog, t->wT + t->wT_cls, nullptr, t->dy, M, D, NV, VN_EPI_STORE, s))) return rc;
     // LoRA mode (mark_only_lora_as_trainable): only dX flows through the frozen tensors; their own gradients are not
     // computed (norm-weight / bias-table by-products land in scratch).
     const bool lora = t->lora;
     float* junk = t->tmp;                       // >= D floats: by-product norm-weight gradients in LoRA mode
+    float* dx = t->dxa;
+    float* dx2 = t->dxb;
+    float* dbias = lora ? t->row_loss : G(t, grads, VN_W_REL_BIAS);     // row_loss is free once the loss is reduced
+    if (hi >= L) {
+    // ---- classifier (WNConv1d 1x1, transformer.py:596-604) + final norm
+    if ((rc = gemm(ctx, dlog, t->wT + t->wT_cls, nullptr, t->dy, M, D, NV, VN_EPI_STORE, s))) return rc;
     if (!lora) {
         float* dWc = G(t, grads, VN_W_CLS_W);
         if ((rc = grad_weight(t, dlog, t->y_f, dWc, M, NV, D, s))) return rc;
@@ -407,13 +415,11 @@ static int backward(vn_train* t, int B, int T, const vn_train_params* p, float* 
             return rc;
         VN_HIP_CHECK(ctx, hipMemsetAsync(dWc, 0, (size_t)NV * D * sizeof(float), s));   // derived tensor: not a parameter
     }
-    float* dx = t->dxa;
-    float* dx2 = t->dxb;
     if ((rc = vn_launch_rmsnorm_bwd(ctx, t->x_last, P(t, VN_W_FINAL_NORM), t->dy, nullptr, dx,
                                     lora ? junk : G(t, grads, VN_W_FINAL_NORM), t->partial, M, D, m->d.eps, s)))
         return rc;
-    float* dbias = lora ? t->row_loss : G(t, grads, VN_W_REL_BIAS);     // row_loss is free once the loss is reduced
-    for (int l = L - 1; l >= 0; --l) {
+    }
+    for (int l = (hi < L - 1 ? hi : L - 1); l >= (lo > 0 ? lo : 0); --l) {
         vn_layer_stash& S = t->st[l];
         const float* wTl = t->wT + t->wT_layer * l;
         // ---- feed-forward branch (transformer.py:72-85, :360-367)
@@ -456,15 +462,15 @@ static int backward(vn_train* t, int B, int T, const vn_train_params* p, float* 
                                         t->partial, M, D, m->d.eps, s)))
             return rc;
     }
-    if (lora) return VN_OK;                     // embedding parameters are frozen
+    if (lora || lo >= 0) return VN_OK;          // LoRA: embedding parameters are frozen
     // ---- codebook embedding (layers.py:134-163)
     return vn_launch_embed_bwd(ctx, dx, m->z, P(t, VN_W_EMB_TABLES), P(t, VN_W_EMB_WT), G(t, grads, VN_W_EMB_TABLES),
                                G(t, grads, VN_W_EMB_WT), G(t, grads, VN_W_EMB_B), t->partial, t->du, B, m->d.n_codebooks, T,
                                m->d.vocab + 1, m->d.latent_dim, D, s);
 }
 
-extern "C" int vn_train_forward_backward(vn_train* t, const int64_t* z_masked, const int64_t* target, int B, int T,
-                                         const vn_train_params* p, float* grads, float* loss_dev, void* stream) {
+extern "C" int vn_train_forward_loss(vn_train* t, const int64_t* z_masked, const int64_t* target, int B, int T,
+                                     const vn_train_params* p, float* grads, float* loss_dev, void* stream) {
     if (!t || !z_masked || !target || !grads || !loss_dev) return VN_ERR_INVALID;
     vn_model* m = t->m;
     vn_ctx* ctx = m->ctx;
@@ -480,7 +486,25 @@ extern "C" int vn_train_forward_backward(vn_train* t, const int64_t* z_masked, c
                                       t->n_valid, t->row_loss, loss_dev, s)))
         return rc;
     t->B = B; t->T = T;
-    return backward(t, B, T, p, grads, s);
+    return VN_OK;
+}
+
+extern "C" int vn_train_backward(vn_train* t, const vn_train_params* p, float* grads, int stage_hi, int stage_lo, void* stream) {
+    if (!t || !grads) return VN_ERR_INVALID;
+    vn_ctx* ctx = t->m->ctx;
+    int rc = params_ok(ctx, p);
+    if (rc) return rc;
+    if (t->B <= 0) return vn_fail(ctx, VN_ERR_INVALID, "vn_train_backward: no stashed forward (call vn_train_forward_loss first)%s", "");
+    if (stage_hi > t->m->L || stage_lo < -1 || stage_lo > stage_hi)
+        return vn_fail(ctx, VN_ERR_INVALID, "vn_train_backward: bad stage range [%s%ld, %ld]", "", stage_lo, stage_hi);
+    return backward_range(t, p, grads, stage_hi, stage_lo, (hipStream_t)stream);
+}
+
+extern "C" int vn_train_forward_backward(vn_train* t, const int64_t* z_masked, const int64_t* target, int B, int T,
+                                         const vn_train_params* p, float* grads, float* loss_dev, void* stream) {
+    int rc = vn_train_forward_loss(t, z_masked, target, B, T, p, grads, loss_dev, stream);
+    if (rc) return rc;
+    return backward_range(t, p, grads, t->m->L, -1, (hipStream_t)stream);
 }
 
 // logits of the train()-mode forward only (parity tests): [B][T][Cp][vocab]

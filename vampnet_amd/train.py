@@ -37,7 +37,7 @@ class Trainer:
                  n_conditioning_codebooks=0, latent_dim=8, embedding_dim=1280, vocab_size=1024, max_batch=8, max_T=575,
                  lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_clip=5.0, label_smoothing=0.1,
                  dropout=0.1, noam_factor=2.0, noam_warmup=10000, use_noam=True, seed=0, process_group=None,
-                 batch_offset=0, only_lora=False, **_ignored):
+                 batch_offset=0, only_lora=False, overlap_allreduce=True, layers_per_bucket=4, **_ignored):
         self.engine, self.lib = engine, engine.lib
         self.dims = vn_dims(n_layers, n_heads, embedding_dim, n_codebooks, n_conditioning_codebooks, vocab_size,
                             latent_dim, 32, 128, 1e-6, max_batch, max_T)
@@ -49,6 +49,9 @@ class Trainer:
         self.noam = (noam_factor, noam_warmup) if use_noam else None
         self.seed, self.pg, self.batch_offset = seed, process_group, batch_offset
         self.steps = 0
+        self.overlap = bool(overlap_allreduce) and process_group is not None and not only_lora
+        self.layers_per_bucket = max(1, int(layers_per_bucket))
+        self._reduced = False
         n = C.c_int64()
         engine.check(self.lib.vn_train_param_size(C.byref(self.dims), C.byref(n)), "vn_train_param_size")
         self.n_total = n.value
@@ -150,6 +153,62 @@ class Trainer:
             self.loss.data_ptr(), self.engine.stream()), "vn_train_forward_backward")
         return self.loss
 
+    # ---- data-parallel exchange overlapped with the backward pass -------------------------------------
+    def _buckets(self):
+        """[(stage_hi, stage_lo, [(begin, end) gradient slices that are final once those stages ran])]: classifier + final
+        norm first, then groups of `layers_per_bucket` layers (one contiguous slice each), last the embedding together with
+        the shared relative-position table (accumulated by every layer)."""
+        if getattr(self, "_bucket_list", None) is None:
+            L = self.dims.n_layers
+
+            def off(tid, layer=0):
+                o, c = C.c_int64(), C.c_int64()
+                self.engine.check(self.lib.vn_weights_offset(C.byref(self.dims), tid, layer, C.byref(o), C.byref(c)),
+                                  "vn_weights_offset")
+                return o.value
+            layer_start = [off(_lib.W_NORM1, l) for l in range(L)] + [self.wsize]
+            og, _ = self._cls_offsets()
+            out = [(L, L, [(off(_lib.W_FINAL_NORM), off(_lib.W_CLS_W)), (off(_lib.W_CLS_B), layer_start[0]),
+                           (og, self.n_total)])]
+            hi = L - 1
+            while hi >= 0:
+                lo = max(0, hi - self.layers_per_bucket + 1)
+                out.append((hi, lo, [(layer_start[lo], layer_start[hi + 1])]))
+                hi = lo - 1
+            out.append((-1, -1, [(0, off(_lib.W_FINAL_NORM))]))
+            self._bucket_list = out
+        return self._bucket_list
+
+    def forward_backward_overlapped(self, z_mask, target, step=None):
+        """forward + loss, then the backward in stages; as soon as a bucket of gradients is final its all-reduce is queued
+        on a side stream (RCCL runs it while the next layers back-propagate).  On return the current stream waits for all
+        collectives: self.grads holds the SUM over ranks."""
+        import torch.distributed as dist
+        B, Cn, T = z_mask.shape
+        tp = self._tp(self.steps + 1 if step is None else step)
+        st = self.engine.stream()
+        self.engine.check(self.lib.vn_train_forward_loss(self.handle, z_mask.data_ptr(), target.data_ptr(), B, T, C.byref(tp),
+                                                         self.grads.data_ptr(), self.loss.data_ptr(), st),
+                          "vn_train_forward_loss")
+        cur = torch.cuda.current_stream(self.engine.device)
+        if getattr(self, "_comm_stream", None) is None:
+            self._comm_stream = torch.cuda.Stream(self.engine.device)
+        works = []
+        for hi, lo, slices in self._buckets():
+            self.engine.check(self.lib.vn_train_backward(self.handle, C.byref(tp), self.grads.data_ptr(), hi, lo, st),
+                              "vn_train_backward")
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            with torch.cuda.stream(self._comm_stream):
+                self._comm_stream.wait_event(ev)
+                for a, b in slices:
+                    works.append(dist.all_reduce(self.grads[a:b], group=self.pg, async_op=True))
+        for w in works:
+            w.wait()
+        cur.wait_stream(self._comm_stream)
+        self._reduced = True
+        return self.loss
+
     def forward(self, z_mask, step=None, dropout=None):
         """train()-mode logits [B, V, T*Cp] in the reference layout (transformer.py:634)."""
         B, Cn, T = z_mask.shape
@@ -163,7 +222,9 @@ class Trainer:
         """(all-reduce) -> clip -> AdamW -> scheduler.step(); advances self.steps."""
         if self.pg is not None:
             import torch.distributed as dist
-            dist.all_reduce(self.grads, group=self.pg)                 # SUM; the update kernel divides by world_size
+            if not self._reduced:
+                dist.all_reduce(self.grads, group=self.pg)             # SUM; the update kernel divides by world_size
+            self._reduced = False
             dist.all_reduce(self.loss, group=self.pg)
             self.loss /= dist.get_world_size(self.pg)
         step = self.steps + 1
@@ -183,7 +244,10 @@ class Trainer:
     def step(self, z, r=None, mask=None, generator=None):
         """One train_loop iteration; returns device scalars (no host sync): loss, grad_norm, and the lr used."""
         z_mask, target = self.make_batch(z, r, mask, generator)
-        self.forward_backward(z_mask, target)
+        if self.overlap:
+            self.forward_backward_overlapped(z_mask, target)
+        else:
+            self.forward_backward(z_mask, target)
         self.update()
         return {"loss": self.loss, "other/grad_norm": self.grad_norm, "other/learning_rate": self.last_lr,
                 "other/batch_size": z.shape[0]}
