@@ -150,25 +150,43 @@ __global__ __launch_bounds__(256, 2) void vn_conv1d_f32_kernel(vn_conv_args p, i
                 tile[rl * BN + cl] = acc[i][jn][r];
             }
     __syncthreads();
-    const int ncols = (p.C_out - n0) < BN ? (p.C_out - n0) : BN;
-    for (int idx = tid; idx < BM * BN; idx += 256) {
-        const int rl = idx / BN, cl = idx - rl * BN;
-        const int m = m0 + rl;
-        if (m >= M || cl >= ncols) continue;
-        const int b = m / p.T_rows, tq = m - b * p.T_rows;
-        const int t_out = tq * p.out_stride + p.out_off;
-        if (t_out < 0 || t_out >= p.T_out) continue;
-        const int col = n0 + cl;
-        const size_t o = ((size_t)b * p.T_out + t_out) * p.C_out + col;
-        float v = tile[idx];
-        if (p.bias) v += p.bias[col];
-        if (p.resid) v += p.resid[o];
-        if (p.act == 1) v = tanhf(v);
-        if (p.y) p.y[o] = v;
+    // phase 2: each thread owns 4 consecutive output channels (bias / alpha / 1/(alpha+1e-9) live in registers) and walks
+    // down the tile rows; (batch, t') advance incrementally (no per-element integer division); 16-byte global accesses.
+    constexpr int CG = BN / 4, RPP = 256 / CG;            // column groups per row, rows per pass
+    const int cg = tid % CG, col = n0 + 4 * cg;
+    if (col < p.C_out) {                                   // C_out % 4 == 0: a float4 is valid as a whole
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, al4 = {1.f, 1.f, 1.f, 1.f}, inv4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias4 = *(const f32x4*)(p.bias + col);
         if (p.y2) {
-            const float al = p.alpha[col];
-            const float sn = sinf(al * v);
-            p.y2[o] = v + (1.0f / (al + 1e-9f)) * (sn * sn);
+            al4 = *(const f32x4*)(p.alpha + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) inv4[e] = 1.0f / (al4[e] + 1e-9f);
+        }
+        int rl = tid / CG;
+        int m = m0 + rl;
+        int b = m / p.T_rows, tq = m - b * p.T_rows;
+        for (; rl < BM && m < M; rl += RPP, m += RPP, tq += RPP) {
+            while (tq >= p.T_rows) { tq -= p.T_rows; ++b; }
+            const int t_out = tq * p.out_stride + p.out_off;
+            if (t_out < 0 || t_out >= p.T_out) continue;
+            const size_t o = ((size_t)b * p.T_out + t_out) * p.C_out + col;
+            f32x4 v = *(const f32x4*)(tile + rl * BN + 4 * cg);
+            v[0] += bias4[0]; v[1] += bias4[1]; v[2] += bias4[2]; v[3] += bias4[3];
+            if (p.resid) {
+                const f32x4 r4 = *(const f32x4*)(p.resid + o);
+                v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
+            }
+            if (p.act == 1) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
+            if (p.y) *(f32x4*)(p.y + o) = v;
+            if (p.y2) {
+                f32x4 w4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sn = sinf(al4[e] * v[e]);
+                    w4[e] = v[e] + inv4[e] * (sn * sn);
+                }
+                *(f32x4*)(p.y2 + o) = w4;
+            }
         }
     }
 }
@@ -201,6 +219,7 @@ extern "C" int vn_conv1d_f32(vn_ctx* ctx, const float* x, const float* w, const 
                              void* stream) {
     if (!ctx || !x || !w || (!y && !y2)) return VN_ERR_INVALID;
     if (C_in % BK) return vn_fail(ctx, VN_ERR_INVALID, "conv1d: C_in=%s%ld must be a multiple of 32", "", C_in);
+    if (C_out % 4) return vn_fail(ctx, VN_ERR_INVALID, "conv1d: C_out=%s%ld must be a multiple of 4", "", C_out);
     if (y2 && !alpha) return vn_fail(ctx, VN_ERR_INVALID, "conv1d: snake output needs alpha%s", "");
     if (B <= 0 || T_rows <= 0 || C_out <= 0 || taps <= 0) return vn_fail(ctx, VN_ERR_INVALID, "conv1d: empty problem%s", "");
     int rc = zero_page(ctx);
