@@ -1,4 +1,6 @@
 """-m gpu: each HIP kernel through the C ABI vs the CPU oracle (fp32, seeded)."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -178,3 +180,37 @@ def test_transpose_zero_pads(eng, R, C):
                  "vn_transpose_f32")
     assert torch.equal(dst[:, :R], src.t())
     assert bool((dst[:, R:] == 0).all())
+
+
+@pytest.mark.parametrize("B,T,cin,cout,k,dil", [(2, 30001, 96, 96, 7, 3),      # 128x96 tile (4x1 waves), ragged rows
+                                                 (2, 30001, 96, 96, 1, 1),      # k = 1 + residual (ResidualUnit tail)
+                                                 (1, 5000, 192, 96, 7, 1),      # few tiles: 64-wide fallback for C_out = 96
+                                                 (2, 9000, 64, 192, 3, 1)])
+def test_conv1d_vs_torch(eng, B, T, cin, cout, k, dil):
+    """vn_conv1d_f32 (channels-last implicit GEMM, fused bias + residual + next-layer Snake) against torch conv1d on the
+    CPU; covers every N-tile variant incl. the exact 96-wide tile of the audio-rate decoder layers.  Tolerance 2e-5 of
+    the output scale (fp32, different summation order)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(cin * 7 + cout + k)
+    x = torch.randn(B, T, cin, generator=g)
+    w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
+    bias = torch.randn(cout, generator=g) * 0.1
+    alpha = torch.rand(cout, generator=g) + 0.5
+    resid = torch.randn(B, T, cout, generator=g) if k == 1 else None
+    pad = dil * (k - 1) // 2
+    ref = F.conv1d(x.permute(0, 2, 1), w, bias, dilation=dil, padding=pad).permute(0, 2, 1)
+    if resid is not None:
+        ref = ref + resid
+    ref2 = ref + (1.0 / (alpha + 1e-9)) * torch.sin(alpha * ref) ** 2
+    xd, wd = x.cuda(), w.permute(0, 2, 1).contiguous().cuda()          # weights packed [C_out][taps][C_in]
+    y = torch.empty(B, T, cout, device="cuda")
+    y2 = torch.empty(B, T, cout, device="cuda")
+    rd = resid.cuda() if resid is not None else None
+    bd, ad = bias.cuda(), alpha.cuda()                                  # keep the device copies alive across the launch
+    eng.check(eng.lib.vn_conv1d_f32(eng.handle, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(),
+                                    rd.data_ptr() if rd is not None else None, ad.data_ptr(), y.data_ptr(),
+                                    y2.data_ptr(), B, T, T, T, cin, cout, k, 1, dil, pad, 1, 0, 0, eng.stream()),
+              "vn_conv1d_f32")
+    scale = ref.abs().max().item()
+    assert (y.cpu() - ref).abs().max().item() < 2e-5 * scale
+    assert (y2.cpu() - ref2).abs().max().item() < 2e-5 * ref2.abs().max().item()

@@ -35,15 +35,19 @@ struct vn_conv_args {
     int act;                       // 1: tanh on the result
 };
 
-template <int BM, int BN>
+// WM = waves along M (4 waves per block, WN = 4 / WM along N): 2 x 2 wave grid for the 128/64-wide tiles, 4 x 1 for the
+// 96-wide tile of the C_out = 96 audio-rate layers (each wave 32 rows x 96 columns: no padded MFMA columns).
+template <int BM, int BN, int WM = 2>
 __global__ __launch_bounds__(256, 2) void vn_conv1d_f32_kernel(vn_conv_args p, int tiles_m, int tiles_n) {
-    constexpr int MI = BM / 64, NI = BN / 64;
+    constexpr int WN = 4 / WM, WTM = BM / WM, WTN = BN / WN;
+    constexpr int MI = WTM / 32, NI = WTN / 32;
+    static_assert(MI >= 1 && NI >= 1 && MI * 32 == WTM && NI * 32 == WTN, "wave tile must be a multiple of 32 x 32");
     constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, STAGE = A_FLOATS + B_FLOATS;
     constexpr int A_INSTR = BM / 32, B_INSTR = BN / 32;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int M = p.B * p.T_rows, K = p.taps * p.C_in;
     // XCD-contiguous, row-panel-major walk (consecutive blocks share the weight panel, which is tiny here)
     int bid = blockIdx.x;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void vn_conv1d_f32_kernel(vn_conv_args p, i
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
 
     const int l31 = lane & 31, h = lane >> 5, sw = lane & 7;
-    const int aRow = (wm * (BM / 2) + l31) * BK, bRow = (wn * (BN / 2) + l31) * BK;
+    const int aRow = (wm * WTM + l31) * BK, bRow = (wn * WTN + l31) * BK;
     const int nk = K / BK;
     stage(0, 0);
     __syncthreads();
@@ -145,16 +149,16 @@ __global__ __launch_bounds__(256, 2) void vn_conv1d_f32_kernel(vn_conv_args p, i
         for (int jn = 0; jn < NI; ++jn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rl = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int cl = wn * (BN / 2) + jn * 32 + l31;
+                const int rl = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int cl = wn * WTN + jn * 32 + l31;
                 tile[rl * BN + cl] = acc[i][jn][r];
             }
     __syncthreads();
     // phase 2: each thread owns 4 consecutive output channels (bias / alpha / 1/(alpha+1e-9) live in registers) and walks
     // down the tile rows; (batch, t') advance incrementally (no per-element integer division); 16-byte global accesses.
-    constexpr int CG = BN / 4, RPP = 256 / CG;            // column groups per row, rows per pass
+    constexpr int CG = BN / 4, RPP = 256 / CG;            // column groups per row, rows per pass (BN = 96: 240 threads work)
     const int cg = tid % CG, col = n0 + 4 * cg;
-    if (col < p.C_out) {                                   // C_out % 4 == 0: a float4 is valid as a whole
+    if (col < p.C_out && tid < CG * RPP) {                 // C_out % 4 == 0: a float4 is valid as a whole
         f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, al4 = {1.f, 1.f, 1.f, 1.f}, inv4 = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) bias4 = *(const f32x4*)(p.bias + col);
         if (p.y2) {
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void vn_conv1d_f32_kernel(vn_conv_args p, i
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WM = 2>
 static int launch_conv(vn_ctx* ctx, const vn_conv_args& a, hipStream_t s) {
     const int M = a.B * a.T_rows;
     const int tiles_m = vn_cdiv(M, BM), tiles_n = vn_cdiv(a.C_out, BN);
@@ -199,7 +203,7 @@ static int launch_conv(vn_ctx* ctx, const vn_conv_args& a, hipStream_t s) {
     const double bytes = 4.0 * ((double)a.B * a.T_in * a.C_in + (double)a.C_out * a.taps * a.C_in +
                                 (double)M * a.C_out * ((a.y ? 1 : 0) + (a.y2 ? 1 : 0) + (a.resid ? 1 : 0)));
     const int pi = vn_prof_pre(ctx, 2, 2.0 * M * (double)a.C_out * a.taps * a.C_in, s, bytes);
-    hipLaunchKernelGGL((vn_conv1d_f32_kernel<BM, BN>), dim3(tiles_m * tiles_n), dim3(256), LDS, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((vn_conv1d_f32_kernel<BM, BN, WM>), dim3(tiles_m * tiles_n), dim3(256), LDS, s, a, tiles_m, tiles_n);
     vn_prof_post(ctx, pi, s);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
@@ -230,6 +234,8 @@ extern "C" int vn_conv1d_f32(vn_ctx* ctx, const float* x, const float* w, const 
     const long M = (long)B * T_rows;
     // N tile: 128 wastes (128 - C_out % 128) columns of the last tile; 64 fits 64-multiples exactly (C_out = 192: 3 x 64
     // instead of 128 + a half-empty 128: +25 % useful MFMA work per launched tile)
+    if (C_out % 96 == 0 && C_out % 64 != 0 && (long)vn_cdiv((int)M, 128) * (C_out / 96) >= 384)
+        return launch_conv<128, 96, 4>(ctx, a, s);          // C_out = 96: exact 96-wide tiles
     const int pad128 = vn_cdiv(C_out, 128) * 128 - C_out, pad64 = vn_cdiv(C_out, 64) * 64 - C_out;
     const bool wide = C_out > 64 && pad128 <= pad64;
     if (wide) {
