@@ -617,30 +617,6 @@ int vn_launch_embed_bwd(vn_ctx* ctx, const float* dx, const int32_t* z, const fl
 }
 
 // ---------------------------------------------------------------------------------------------
-// Relative-position-bias gradient: the attention backward accumulates d(bias)[h][key - query + T - 1] over batch
-// items, query blocks and layers (the table is shared by all layers, transformer.py:291,402); bucket it back to
-// the [num_buckets][H] embedding (transformer.py:193-209).  One thread per (bucket, h).
-// ---------------------------------------------------------------------------------------------
-__global__ void vn_relbias_bwd_kernel(const float* __restrict__ dfull, const int32_t* __restrict__ lut, float* __restrict__ dtab,
-                                      int H, int T, int nbuckets) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nbuckets * H) return;
-    const int bucket = i / H, h = i - bucket * H;
-    const int nb = 2 * T - 1;
-    double a = 0.0;
-    for (int r = 0; r < nb; ++r)
-        if (lut[r] == bucket) a += (double)dfull[(size_t)h * nb + r];
-    dtab[i] = (float)a;
-}
-
-int vn_launch_relbias_bwd(vn_ctx* ctx, const float* dfull, const int32_t* lut, float* dtab, int H, int T, int nbuckets,
-                          hipStream_t s) {
-    hipLaunchKernelGGL(vn_relbias_bwd_kernel, dim3(vn_cdiv(nbuckets * H, 64)), dim3(64), 0, s, dfull, lut, dtab, H, T, nbuckets);
-    VN_LAUNCH_CHECK(ctx);
-    return VN_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
 // Gradient norm + AdamW (train.py:296-299; torch.optim.AdamW defaults + clip_grad_norm_).
 //   norm  = ||gscale * g||_2 over the whole gradient vector (non-trainable / padding entries are zero)
 //   coef  = min(1, clip / (norm + 1e-6))
