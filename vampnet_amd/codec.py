@@ -303,7 +303,13 @@ class DacCodec:
     # ---- Interface helpers (interface.py:206-224, 203-204) --------------------------------------
     def encode_signal(self, signal, loudness=-24.0):
         """Interface._preprocess + encode: resample -> mono -> loudness-normalise -> peak-limit -> pad -> codes."""
-        x, sr = signal.samples.float().cpu(), signal.sample_rate
+        sig = self.preprocess_signal(signal, loudness)
+        return self.encode(sig.samples, self.sample_rate)["codes"]
+
+    def preprocess_signal(self, signal, loudness=-24.0):
+        """Interface._preprocess (interface.py:206-217): clone -> resample(codec rate) -> to_mono -> normalize(loudness) ->
+        ensure_max_of_audio(1.0) -> codec.preprocess (right-pad to the hop); returns a new AudioSignal."""
+        x, sr = signal.samples.float().cpu().clone(), signal.sample_rate
         if sr != self.sample_rate:
             from scipy.signal import resample_poly
             g = math.gcd(sr, self.sample_rate)
@@ -316,7 +322,7 @@ class DacCodec:
         peak = x.abs().amax(dim=(1, 2), keepdim=True)                             # ensure_max_of_audio(1.0)
         x = torch.where(peak > 1.0, x / peak.clamp_min(1e-12), x)
         x, _ = self.preprocess(x, self.sample_rate)
-        return self.encode(x, self.sample_rate)["codes"]
+        return AudioSignal(x, self.sample_rate)
 
     def decode_signal(self, codes):
         return AudioSignal(self.decode_codes(codes), self.sample_rate)

@@ -38,6 +38,12 @@ _DEFAULT_KW = dict(n_heads=20, n_layers=16, n_codebooks=9, n_conditioning_codebo
                    embedding_dim=1280, vocab_size=1024)          # VampNet.__init__ defaults, transformer.py:536-545
 
 
+def signal_concat(audio_signals: list):
+    """interface.py:19-25: concatenate AudioSignals along time."""
+    from .codec import AudioSignal
+    return AudioSignal(torch.cat([x.audio_data for x in audio_signals], dim=-1), sample_rate=audio_signals[0].sample_rate)
+
+
 def _codec_codebooks(codec):
     """codec.quantizer.quantizers[i].codebook.weight, the only codec state the sampling loop reads (layers.py:145)."""
     return torch.stack([q.codebook.weight.detach().float().cpu() for q in codec.quantizer.quantizers])
@@ -150,6 +156,12 @@ class Interface:
         self.coarse.chunk_size_s = chunk_size_s
 
     # ---- codec --------------------------------------------------------------------------------
+    def _preprocess(self, signal):
+        """interface.py:206-217: resample to the codec rate, mono, loudness-normalise to self.loudness, peak-limit, pad."""
+        if not hasattr(self.codec, "preprocess_signal"):
+            raise RuntimeError("this codec object cannot preprocess audio (synthetic-codebook stand-in)")
+        return self.codec.preprocess_signal(signal, loudness=self.loudness)
+
     @torch.inference_mode()
     def encode(self, signal):
         """interface.py:219-224 (incl. _preprocess :206-217) — delegated to the codec object."""
