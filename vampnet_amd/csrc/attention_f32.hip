@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void vn_attention_kernel(const float* __restri
         f32x4 sacc[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) sacc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             f32x4 kf[4];
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(256) void vn_attention_kernel(const float* __restri
                     sacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u][e], qf[s][e], sacc[u], 0, 0, 0);
         }
 
+        __builtin_amdgcn_s_setprio(0);
         // ---- online softmax over this tile's 64 keys; lane holds keys kt*64 + 16u + 4g + r for query j
         float mx = -INFINITY;
 #pragma unroll
@@ -148,6 +150,7 @@ __global__ __launch_bounds__(256) void vn_attention_kernel(const float* __restri
         }
 
         // ---- O^T += V^T . P^T : lane (j,g) reads V[key(u,g,r)][4j .. 4j+3]; tile e covers d = 4i + e
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -158,6 +161,7 @@ __global__ __launch_bounds__(256) void vn_attention_kernel(const float* __restri
                     o[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[e], sacc[u][r], o[e], 0, 0, 0);
             }
 
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();                       // every wave finished reading Ks/Vs
         if (kt + 1 < nkt) {
             write_tile();
