@@ -201,6 +201,10 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device(device))     # "nccl" is RCCL on ROCm
         pg = dist.group.WORLD
+        # build the communicator (rings over xGMI) now, outside any timed region, whatever --warmup is
+        _t = torch.ones(1, device=device) if not one_gpu else torch.ones(1)
+        dist.all_reduce(_t)
+        torch.cuda.synchronize()
 
     if args.workload == "train":
         def _barrier():
