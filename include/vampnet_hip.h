@@ -100,7 +100,10 @@ typedef struct {
                                     (i / call_batch) * global_batch + batch_offset + i % call_batch  */
 } vn_sample_params;
 
-/* ---- context ------------------------------------------------------------------------------ */
+/* ---- context ------------------------------------------------------------------------------
+ * One context per device (and per thread that drives it).  A context owns a small device scratch (stream-K partial-sum
+ * slabs, hand-off flags): all work enqueued through ONE context must be stream-ordered (one stream, or streams chained
+ * by events); use separate contexts for concurrent streams.  The reference itself is single-threaded.   */
 int  vn_ctx_create(int device, vn_ctx** out);
 void vn_ctx_destroy(vn_ctx* ctx);
 const char* vn_last_error(const vn_ctx* ctx);

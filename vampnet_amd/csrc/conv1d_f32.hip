@@ -209,11 +209,10 @@ static int launch_conv(vn_ctx* ctx, const vn_conv_args& a, hipStream_t s) {
     return VN_OK;
 }
 
-static float* g_zero_page = nullptr;
 static int zero_page(vn_ctx* ctx) {
-    if (g_zero_page) return VN_OK;
-    VN_HIP_CHECK(ctx, hipMalloc((void**)&g_zero_page, 1024));
-    VN_HIP_CHECK(ctx, hipMemset(g_zero_page, 0, 1024));
+    if (ctx->zero_page) return VN_OK;
+    VN_HIP_CHECK(ctx, hipMalloc((void**)&ctx->zero_page, 1024));
+    VN_HIP_CHECK(ctx, hipMemset(ctx->zero_page, 0, 1024));
     return VN_OK;
 }
 
@@ -228,7 +227,7 @@ extern "C" int vn_conv1d_f32(vn_ctx* ctx, const float* x, const float* w, const 
     if (B <= 0 || T_rows <= 0 || C_out <= 0 || taps <= 0) return vn_fail(ctx, VN_ERR_INVALID, "conv1d: empty problem%s", "");
     int rc = zero_page(ctx);
     if (rc) return rc;
-    vn_conv_args a{x, w, bias, resid, alpha, y, y2, g_zero_page, B, T_in, T_rows, T_out, C_in, C_out, taps,
+    vn_conv_args a{x, w, bias, resid, alpha, y, y2, ctx->zero_page, B, T_in, T_rows, T_out, C_in, C_out, taps,
                    in_stride, dil, pad, out_stride, out_off, act};
     hipStream_t s = (hipStream_t)stream;
     const long M = (long)B * T_rows;

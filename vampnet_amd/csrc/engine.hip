@@ -93,6 +93,7 @@ extern "C" int vn_ctx_create(int device, vn_ctx** out) {
     c->device = device;
     c->err[0] = 0;
     c->prof = vn_prof();
+    c->sk_slabs = nullptr; c->sk_flags = nullptr; c->zero_page = nullptr;
     if (hipSetDevice(device) != hipSuccess) { delete c; return VN_ERR_HIP; }
     *out = c;
     return VN_OK;
@@ -106,6 +107,9 @@ static void prof_free(vn_ctx* ctx) {
 extern "C" void vn_ctx_destroy(vn_ctx* ctx) {
     if (!ctx) return;
     prof_free(ctx);
+    (void)hipFree(ctx->sk_slabs);
+    (void)hipFree(ctx->sk_flags);
+    (void)hipFree(ctx->zero_page);
     delete ctx;
 }
 

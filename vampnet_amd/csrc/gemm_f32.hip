@@ -431,22 +431,21 @@ extern "C" int vn_debug_gemm_config(int bm, int bn, int order) {
 
 // stream-K workspace (per process; GEMMs of one ctx run on one stream at a time, see vampnet_hip.h)
 #define SK_MAX_BLOCKS 512
-static float* g_sk_slabs = nullptr;
-static unsigned* g_sk_flags = nullptr;     // [SK_MAX_BLOCKS] flags + [1] error word
+// per-context workspace: ctx->sk_flags = [SK_MAX_BLOCKS] flags + [1] error word
 static int sk_workspace(vn_ctx* ctx) {
-    if (g_sk_slabs) return VN_OK;
-    VN_HIP_CHECK(ctx, hipMalloc((void**)&g_sk_slabs, (size_t)SK_MAX_BLOCKS * 128 * 128 * sizeof(float)));
-    VN_HIP_CHECK(ctx, hipMalloc((void**)&g_sk_flags, (SK_MAX_BLOCKS + 64) * sizeof(unsigned)));
-    VN_HIP_CHECK(ctx, hipMemset(g_sk_flags, 0, (SK_MAX_BLOCKS + 64) * sizeof(unsigned)));
+    if (ctx->sk_slabs) return VN_OK;
+    VN_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sk_slabs, (size_t)SK_MAX_BLOCKS * 128 * 128 * sizeof(float)));
+    VN_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sk_flags, (SK_MAX_BLOCKS + 64) * sizeof(unsigned)));
+    VN_HIP_CHECK(ctx, hipMemset(ctx->sk_flags, 0, (SK_MAX_BLOCKS + 64) * sizeof(unsigned)));
     return VN_OK;
 }
 
 // stream-K spin-limit indicator (a finisher gave up waiting for a partial-sum slab): 0 = healthy
 extern "C" int vn_health_check(vn_ctx* ctx, void* stream) {
     if (!ctx) return VN_ERR_INVALID;
-    if (!g_sk_flags) return VN_OK;
+    if (!ctx->sk_flags) return VN_OK;
     unsigned w = 0;
-    VN_HIP_CHECK(ctx, hipMemcpyAsync(&w, g_sk_flags + SK_MAX_BLOCKS, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    VN_HIP_CHECK(ctx, hipMemcpyAsync(&w, ctx->sk_flags + SK_MAX_BLOCKS, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
     VN_HIP_CHECK(ctx, hipStreamSynchronize((hipStream_t)stream));
     if (w) return vn_fail(ctx, VN_ERR_HIP, "stream-K GEMM: a tile owner timed out waiting for a partial-sum slab%s", "");
     return VN_OK;
@@ -469,7 +468,7 @@ static int launch_cfg(vn_ctx* ctx, const vn_gemm_args& a, bool streamk, hipStrea
         int G = SK_MAX_BLOCKS;
         if (total < G) G = (int)total;
         hipLaunchKernelGGL((vn_gemm_f32_sk_kernel<BM, BN, EPI, BF>), dim3(G), dim3(256), Cfg::LDS_BYTES, s, a, tiles_m,
-                           tiles_n, g_order | (g_stagger << 8), g_sk_slabs, g_sk_flags, g_sk_flags + SK_MAX_BLOCKS);
+                           tiles_n, g_order | (g_stagger << 8), ctx->sk_slabs, ctx->sk_flags, ctx->sk_flags + SK_MAX_BLOCKS);
     } else {
         hipLaunchKernelGGL((vn_gemm_f32_kernel<BM, BN, EPI, BF>), dim3(tiles_m * tiles_n), dim3(256), Cfg::LDS_BYTES, s, a,
                            tiles_m, tiles_n, g_order);

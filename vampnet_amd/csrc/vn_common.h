@@ -107,6 +107,12 @@ struct vn_ctx {
     int device;
     char err[512];
     vn_prof prof;
+    // lazily allocated per-context device scratch (freed by vn_ctx_destroy): stream-K partial-sum slabs + hand-off flags
+    // (gemm_f32.hip; launches of one context must be stream-ordered with each other, see include/vampnet_hip.h) and the
+    // zero page the conv kernel DMAs its padding from (conv1d_f32.hip)
+    float* sk_slabs;
+    unsigned* sk_flags;
+    float* zero_page;
 };
 
 // bracket a launch with events when profiling is on (no-ops otherwise)
