@@ -119,6 +119,10 @@ const char* vn_version(void);
  *   (2*M*N*K per GEMM / conv launch; 4*T*T*64 per (b,h) for attention), stats[4c+3] = algorithmic operand bytes
  *   (every fp32 operand read once + every result written once).                                  */
 int vn_profile_begin(vn_ctx* ctx, int max_launches);
+/* Bracket only ~1 of every `stride` MFMA launches (selected by a hash of the launch counter, so every shape of a
+ * periodic schedule is sampled): two hipEventRecords cost ~7 us of stream time per bracketed launch (2.3 % of a B = 8
+ * vamp() step, 11 % at B = 1 with stride 1).  The returned statistics then cover the sampled launches only.       */
+int vn_profile_set_stride(vn_ctx* ctx, int stride);
 int vn_profile_end(vn_ctx* ctx, double* stats16);
 
 /* ---- weights ------------------------------------------------------------------------------ */

@@ -46,6 +46,7 @@ SYMBOLS = {
     "vn_last_error": (C.c_char_p, [_P]),
     "vn_version": (C.c_char_p, []),
     "vn_profile_begin": (C.c_int, [_P, C.c_int]),
+    "vn_profile_set_stride": (C.c_int, [_P, C.c_int]),
     "vn_profile_end": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "vn_weights_size": (C.c_int, [C.POINTER(vn_dims), C.POINTER(C.c_int64)]),
     "vn_weights_offset": (C.c_int, [C.POINTER(vn_dims), C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -102,7 +102,9 @@ static void prof_free(vn_ctx* ctx) {
     vn_prof& p = ctx->prof;
     for (int i = 0; i < 2 * p.cap; ++i) (void)hipEventDestroy(p.ev[i]);
     delete[] p.ev; delete[] p.cls; delete[] p.flops; delete[] p.bytes;
+    const unsigned stride = p.stride;
     p = vn_prof();
+    p.stride = stride;
 }
 extern "C" void vn_ctx_destroy(vn_ctx* ctx) {
     if (!ctx) return;
@@ -127,7 +129,14 @@ extern "C" int vn_profile_begin(vn_ctx* ctx, int max_launches) {
         p.cap = max_launches;
     }
     p.n = 0;
+    p.seen = 0;
     p.on = true;
+    return VN_OK;
+}
+
+extern "C" int vn_profile_set_stride(vn_ctx* ctx, int stride) {
+    if (!ctx || stride < 1) return VN_ERR_INVALID;
+    ctx->prof.stride = (unsigned)stride;
     return VN_OK;
 }
 

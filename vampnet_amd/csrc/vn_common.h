@@ -97,6 +97,7 @@ __device__ __forceinline__ float vn_drop_mul(const vn_drop& d, uint32_t bits, in
 struct vn_prof {
     bool on = false;
     int cap = 0, n = 0;
+    unsigned stride = 1, seen = 0; // vn_profile_set_stride: bracket ~1 of every `stride` launches (hash-selected)
     hipEvent_t* ev = nullptr;      // 2 events per launch
     int* cls = nullptr;            // class per launch (0 gemm, 1 attention)
     double* flops = nullptr;
@@ -119,6 +120,10 @@ struct vn_ctx {
 static inline int vn_prof_pre(vn_ctx* ctx, int cls, double flops, hipStream_t s, double bytes = 0.0) {
     vn_prof& p = ctx->prof;
     if (!p.on || p.n >= p.cap) return -1;
+    if (p.stride > 1) {            // unbiased sub-sampling: a multiplicative hash of the launch counter decides
+        const unsigned k = p.seen++ * 2654435761u;
+        if ((k >> 16) % p.stride) return -1;
+    }
     const int i = p.n++;
     p.cls[i] = cls;
     p.flops[i] = flops;

@@ -57,7 +57,9 @@ class Engine:
         """Synchronise and raise if a stream-K GEMM ever gave up waiting for a partial tile (never expected)."""
         self.check(self.lib.vn_health_check(self.handle, self.stream()), "vn_health_check")
 
-    def profile_begin(self, max_launches=20000):
+    def profile_begin(self, max_launches=20000, stride=1):
+        """Bracket (a hash-selected 1/stride sample of) the MFMA launches with hipEvents until profile_end()."""
+        self.check(self.lib.vn_profile_set_stride(self.handle, stride), "vn_profile_set_stride")
         self.check(self.lib.vn_profile_begin(self.handle, max_launches), "vn_profile_begin")
 
     def profile_end(self):
