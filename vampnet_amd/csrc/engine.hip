@@ -3,6 +3,7 @@
 // include/vampnet_hip.h.  Everything is enqueued asynchronously on the caller's stream; there is no
 // host<->device synchronisation on the generate path when the caller supplies the mask schedule.
 #include <new>
+#include <stdlib.h>
 #include <vector>
 #include "vn_common.h"
 #include "vn_model.h"
@@ -172,8 +173,10 @@ static int dev_alloc(vn_ctx* ctx, T** p, size_t n) {
     return VN_OK;
 }
 
+static void graphs_free(vn_model* m);
 extern "C" void vn_model_destroy(vn_model* m) {
     if (!m) return;
+    graphs_free(m);
     float* fb[] = {m->x, m->y, m->qkv, m->g, m->logits, m->bias_full, m->psel};
     for (float* p : fb) (void)hipFree(p);
     int32_t* ib[] = {m->z, m->z_sampled, m->sampled, m->count, m->lut};
@@ -274,6 +277,91 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
     c.bias = W(m, VN_W_CLS_B); c.C = logits; c.M = M;
     c.N = m->Cp * m->d.vocab; c.K = D; c.ldc = c.N;
     return vn_launch_gemm_f32(ctx, c, VN_EPI_BIAS, s);
+}
+
+// ---- forward as a hipGraph ---------------------------------------------------------------------------------------
+// The forward pass is ~125 launches with arguments that are fixed for a given (model, B, T, precision): inside the
+// sampling loop it is replayed 12 (coarse) / 8 (c2f) times per vamp() call.  The first call for a shape runs eagerly (it
+// also sizes lazily allocated scratch), the second is captured from the caller's stream and instantiated, later ones
+// are one hipGraphLaunch: the ~5 us CPU launch + dispatch gap per small kernel disappears (GPU idle at B = 8: 2 % -> ~0).
+// Disabled while launches are being bracketed with events (vn_profile_begin) and by VN_GRAPH=0.
+struct vn_fwd_graph_entry {
+    int B, T;
+    const void* blob16;
+    int calls;
+    bool failed;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+struct vn_fwd_graphs {
+    std::vector<vn_fwd_graph_entry> v;
+};
+
+static bool graphs_enabled() {
+    static const bool on = [] { const char* e = getenv("VN_GRAPH"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+static void graphs_free(vn_model* m) {
+    if (!m->graphs) return;
+    for (auto& e : m->graphs->v) {
+        if (e.exec) (void)hipGraphExecDestroy(e.exec);
+        if (e.graph) (void)hipGraphDestroy(e.graph);
+    }
+    delete m->graphs;
+    m->graphs = nullptr;
+}
+
+// forward on the model's own token / logits buffers (the generate loop)
+static int forward_loop(vn_model* m, int B, int T, hipStream_t s) {
+    vn_ctx* ctx = m->ctx;
+    if (!graphs_enabled() || ctx->prof.on) return forward_i32(m, m->z, B, T, m->logits, s);
+    if (!m->graphs) m->graphs = new (std::nothrow) vn_fwd_graphs();
+    if (!m->graphs) return forward_i32(m, m->z, B, T, m->logits, s);
+    vn_fwd_graph_entry* e = nullptr;
+    for (auto& c : m->graphs->v)
+        if (c.B == B && c.T == T && c.blob16 == (const void*)m->blob16) { e = &c; break; }
+    if (!e) {
+        if (m->graphs->v.size() >= 16) return forward_i32(m, m->z, B, T, m->logits, s);
+        m->graphs->v.push_back(vn_fwd_graph_entry{B, T, (const void*)m->blob16, 0, false, nullptr, nullptr});
+        e = &m->graphs->v.back();
+    }
+    int rc;
+    if ((rc = vn_model_ensure_bias(m, T, s))) return rc;        // may synchronise: never inside a capture
+    if (e->exec) {
+        if (hipGraphLaunch(e->exec, s) == hipSuccess) return VN_OK;
+        e->failed = true;
+    }
+    if (e->failed || e->calls++ == 0) return forward_i32(m, m->z, B, T, m->logits, s);
+    // second call for this shape: capture
+    if (s == nullptr || hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();                // the legacy default stream cannot be captured: stay eager for this shape
+        e->failed = true;
+        return forward_i32(m, m->z, B, T, m->logits, s);
+    }
+    rc = forward_i32(m, m->z, B, T, m->logits, s);
+    hipGraph_t g = nullptr;
+    const hipError_t ec = hipStreamEndCapture(s, &g);
+    if (rc != VN_OK || ec != hipSuccess || !g) {
+        if (g) (void)hipGraphDestroy(g);
+        e->failed = true;
+        (void)hipGetLastError();
+        return rc != VN_OK ? rc : forward_i32(m, m->z, B, T, m->logits, s);
+    }
+    hipGraphExec_t x = nullptr;
+    if (hipGraphInstantiate(&x, g, nullptr, nullptr, 0) != hipSuccess || !x) {
+        (void)hipGraphDestroy(g);
+        e->failed = true;
+        (void)hipGetLastError();
+        return forward_i32(m, m->z, B, T, m->logits, s);
+    }
+    e->graph = g;
+    e->exec = x;
+    if (hipGraphLaunch(x, s) != hipSuccess) {
+        e->failed = true;
+        return forward_i32(m, m->z, B, T, m->logits, s);
+    }
+    return VN_OK;
 }
 
 extern "C" int vn_model_set_bf16(vn_model* m, const void* blob_bf16_dev) {
@@ -398,7 +486,7 @@ extern "C" int vn_generate(vn_model* m, const int64_t* start_tokens, const int64
     // pageable-host H2D: the runtime stages the source before returning, so `ks` may die at scope exit
     VN_HIP_CHECK(ctx, hipMemcpyAsync(m->ksched, ks.data(), ks.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
     for (int i = 0; i < p->steps; ++i) {
-        if ((rc = forward_i32(m, m->z, B, T, m->logits, s))) return rc;
+        if ((rc = forward_loop(m, B, T, s))) return rc;
         const float* en = exp_noise ? exp_noise + (size_t)i * B * N * V : nullptr;
         const float* un = unif_noise ? unif_noise + (size_t)i * B * N : nullptr;
         if ((rc = sample_step(m, B, T, i, p, m->ksched + (size_t)i * B, m->logits, en, un, i == p->steps - 1, s))) return rc;

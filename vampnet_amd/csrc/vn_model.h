@@ -16,6 +16,7 @@ struct vn_model {
     uint16_t *y16, *g16;
     int bias_T;              // T the expanded bias table is currently built for (-1 = none)
     long max_rows;
+    struct vn_fwd_graphs* graphs;   // captured hipGraphs of the forward pass, per (B, T, precision) (engine.hip)
 };
 
 

@@ -14,6 +14,7 @@ Additions that the reference does not have (all optional, defaults reproduce the
     (B,14,T) token tensor.  The batch-wide N0 quirk (transformer.py:766) is honoured by
     computing N0 on the global tensors, which every rank holds — no data-path collective.
 """
+import functools
 import math
 from pathlib import Path
 
@@ -36,6 +37,34 @@ _MODEL_KEYS = ("n_heads", "n_layers", "n_codebooks", "n_conditioning_codebooks",
                "vocab_size")
 _DEFAULT_KW = dict(n_heads=20, n_layers=16, n_codebooks=9, n_conditioning_codebooks=0, latent_dim=8,
                    embedding_dim=1280, vocab_size=1024)          # VampNet.__init__ defaults, transformer.py:536-545
+
+
+def _on_engine_stream(fn):
+    """Run a public entry point on the Interface's own (non-default) HIP stream when the caller sits on the legacy default
+    stream: the engine replays the forward pass as a captured hipGraph, and the default stream cannot be captured.  The
+    side stream waits for the caller's stream first and the caller's stream waits for it afterwards, so the call looks
+    synchronous-in-stream-order exactly like the reference's torch ops."""
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        st = getattr(self, "_stream", None)
+        if st is None or getattr(self, "_in_stream", False):
+            return fn(self, *args, **kwargs)
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != 0:                       # the caller already chose a capturable stream
+            return fn(self, *args, **kwargs)
+        st.wait_stream(cur)
+        self._in_stream = True
+        try:
+            with torch.cuda.stream(st):
+                out = fn(self, *args, **kwargs)
+        finally:
+            self._in_stream = False
+        cur.wait_stream(st)
+        for t in (out if isinstance(out, tuple) else (out,)):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(cur)
+        return out
+    return wrapper
 
 
 def signal_concat(audio_signals: list):
@@ -91,6 +120,8 @@ class Interface:
         self.codec = codec
         self.device = torch.device(device)
         self.engine = Engine(device)
+        self._stream = torch.cuda.Stream(self.engine.device)      # see _on_engine_stream
+        self._in_stream = False
         self.loudness = -24.0
         self.beat_tracker = None
         self.rng = rng
@@ -296,6 +327,7 @@ class Interface:
 
     # ---- the hot path --------------------------------------------------------------------------
     @torch.inference_mode()
+    @_on_engine_stream
     def coarse_to_fine(self, z: torch.Tensor, mask: torch.Tensor = None, return_mask: bool = False, **kwargs):
         """interface.py:328-380: pad T to a multiple of the c2f chunk (z <- 0, mask <- 1), condition on the
         coarse codebooks, generate each chunk independently, trim."""
@@ -335,6 +367,7 @@ class Interface:
         return fine_z[:, :, :length].clone()
 
     @torch.inference_mode()
+    @_on_engine_stream
     def coarse_vamp(self, z, mask, return_mask=False, gen_fn=None, **kwargs):
         """interface.py:383-452: coarse codebooks only, 10 s chunks generated independently; the first and last
         timestep of every chunk that has any unmasked token are forced unmasked (:407-413)."""
@@ -363,6 +396,7 @@ class Interface:
             return c_vamp, cz_masked
         return c_vamp
 
+    @_on_engine_stream
     def vamp(self, codes: torch.Tensor, mask: torch.Tensor, batch_size: int = 1, feedback_steps: int = 1,
              time_stretch_factor: int = 1, return_mask: bool = False, **kwargs):
         """interface.py:491-562.  `kwargs` reach only the coarse stage; c2f always runs 2 steps at temperature 1
