@@ -316,6 +316,9 @@ int  vn_attention_train_f32(vn_ctx* ctx, const float* q, const float* k, const f
  * weight-gradient GEMMs; exposed for tests and tuning.                                                              */
 int  vn_transpose_f32(vn_ctx* ctx, const float* src, float* dst, int R, int C, int ldd, void* stream);
 
+/* number of forward passes of this model that were served by replaying a captured hipGraph (tests)               */
+int vn_debug_graph_replays(const vn_model* model, int64_t* count);
+
 /* tuning hook (scripts/gemm_sweep.py): force the GEMM block tile (bm x bn in {128,64}^2; 0,0 = automatic) and the
  * tile walk order (0 column-major, 1 grouped 8-row patches, -1 keep).  Process-global; not for production use.   */
 int vn_debug_gemm_config(int bm, int bn, int order);

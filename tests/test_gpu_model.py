@@ -461,3 +461,26 @@ def test_full_size_vamp_vs_oracle(eng):
         same = (got == ref).float().mean().item()
         print(f"full-size vamp {kw}: token agreement {same:.6f}")
         assert torch.equal(got, ref)
+
+
+def test_forward_graph_replay_is_used_and_exact():
+    """The generate loop replays the forward pass as a captured hipGraph from the third forward of a shape on: the result
+    stays bit-identical to the eager path (same kernels, same arguments) and to the oracle."""
+    import ctypes as C
+    from vampnet_amd.interface import Interface
+    cb = W.synth_codebooks()
+    csd, fsd = W.synth_state_dict(W.TINY_COARSE_DIMS, 0), W.synth_state_dict(W.TINY_C2F_DIMS, 1)
+    itf = Interface.from_state_dicts(SynthCodec(cb), csd, model_kwargs(W.TINY_COARSE_DIMS), fsd, model_kwargs(W.TINY_C2F_DIMS),
+                                     device="cuda:0", max_batch=2)
+    z = W.synth_codes(1, 14, 200, seed=6)
+    torch.manual_seed(3)
+    mask = itf.build_mask(z)
+    got = itf.vamp(z, mask, batch_size=2, seed=1, _sampling_steps=6).cpu()       # runs on the Interface's own stream
+    n = C.c_int64()
+    itf.engine.check(itf.engine.lib.vn_debug_graph_replays(itf.coarse.handle, C.byref(n)), "vn_debug_graph_replays")
+    assert n.value >= 4, n.value                                                  # 6 steps: eager, capture+replay, 4 replays
+    ref = O.vamp(O.OracleModels(csd, W.TINY_COARSE_DIMS, fsd, W.TINY_C2F_DIMS, cb), z, mask, batch_size=2, seed=1,
+                 _sampling_steps=6)
+    assert torch.equal(got, ref)
+    again = itf.vamp(z, mask, batch_size=2, seed=1, _sampling_steps=6).cpu()       # all-replay call
+    assert torch.equal(again, ref)

@@ -295,6 +295,7 @@ struct vn_fwd_graph_entry {
 };
 struct vn_fwd_graphs {
     std::vector<vn_fwd_graph_entry> v;
+    long replays = 0;        // forwards served by hipGraphLaunch (vn_debug_graph_replays)
 };
 
 static bool graphs_enabled() {
@@ -329,7 +330,7 @@ static int forward_loop(vn_model* m, int B, int T, hipStream_t s) {
     int rc;
     if ((rc = vn_model_ensure_bias(m, T, s))) return rc;        // may synchronise: never inside a capture
     if (e->exec) {
-        if (hipGraphLaunch(e->exec, s) == hipSuccess) return VN_OK;
+        if (hipGraphLaunch(e->exec, s) == hipSuccess) { ++m->graphs->replays; return VN_OK; }
         e->failed = true;
     }
     if (e->failed || e->calls++ == 0) return forward_i32(m, m->z, B, T, m->logits, s);
@@ -361,6 +362,13 @@ static int forward_loop(vn_model* m, int B, int T, hipStream_t s) {
         e->failed = true;
         return forward_i32(m, m->z, B, T, m->logits, s);
     }
+    ++m->graphs->replays;
+    return VN_OK;
+}
+
+extern "C" int vn_debug_graph_replays(const vn_model* m, int64_t* count) {
+    if (!m || !count) return VN_ERR_INVALID;
+    *count = m->graphs ? m->graphs->replays : 0;
     return VN_OK;
 }
 
