@@ -6,13 +6,14 @@ from collections import defaultdict
 
 path = sys.argv[1]
 marker = sys.argv[2] if len(sys.argv) > 2 else "vn_embed_kernel"
+nth = int(sys.argv[4]) if len(sys.argv) > 4 else 1          # the step starts at the nth-from-last marker launch
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
 if not starts:
     raise SystemExit(f"marker {marker} not found")
 # the grads memset of the step precedes the marker by a few dispatches: back up to the previous fillBuffer if adjacent
-i0 = starts[-1]
+i0 = starts[-nth]
 while i0 > 0 and ("fillBuffer" in rows[i0 - 1]["Kernel_Name"] or "i64_to_i32" in rows[i0 - 1]["Kernel_Name"]):
     i0 -= 1
 step = rows[i0:]
