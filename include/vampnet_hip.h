@@ -193,6 +193,9 @@ int vn_gemm_bf16(vn_ctx* ctx, const void* A16, const void* W16, const float* bia
  * rel_bias dev f32 [num_buckets][H]; out dev f32 [B][T][H*64].                                */
 int vn_attention_f32(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
                      float* out, int B, int H, int T, int num_buckets, int max_distance, void* stream);
+/* fast-mode variant: bf16 MFMA products, fp32 softmax; out16 = bf16 [B][T][H*64] (NOT bit-exact)                      */
+int vn_attention_bf16(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                      void* out16, int B, int H, int T, int num_buckets, int max_distance, void* stream);
 
 /* ---- DAC codec layers (Interface.encode / Interface.decode; PARITY UNPINNED: the codec source
  * `lac` is not part of the reference tree) -------------------------------------------------------------------

@@ -214,3 +214,24 @@ def test_conv1d_vs_torch(eng, B, T, cin, cout, k, dil):
     scale = ref.abs().max().item()
     assert (y.cpu() - ref).abs().max().item() < 2e-5 * scale
     assert (y2.cpu() - ref2).abs().max().item() < 2e-5 * ref2.abs().max().item()
+
+
+@pytest.mark.parametrize("B,H,T", [(1, 2, 575), (2, 3, 173), (1, 1, 37)])
+def test_attention_bf16_fast_mode(eng, B, H, T):
+    """vn_attention_bf16 (bf16 MFMA products, fp32 softmax) vs the fp32 formula: bf16-class error only (inputs and
+    probabilities carry 8 mantissa bits): max |err| <= 3e-2 of the output scale, mean <= 4e-3."""
+    from oracle import vampnet_oracle as O
+    g = torch.Generator().manual_seed(T)
+    q, k, v = (torch.randn(B, H, T, 64, generator=g) for _ in range(3))
+    rel = torch.randn(32, H, generator=g) * 0.5
+    qd, kd, vd, rd = q.cuda(), k.cuda(), v.cuda(), rel.cuda()
+    out = torch.empty(B, T, H * 64, device="cuda", dtype=torch.bfloat16)
+    eng.check(eng.lib.vn_attention_bf16(eng.handle, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), rd.data_ptr(), out.data_ptr(),
+                                        B, H, T, 32, 128, eng.stream()), "vn_attention_bf16")
+    bias = O.compute_bias(rel, T).permute(1, 0, 2, 3)
+    s = torch.einsum("bhld,bhtd->bhlt", q, k) / 8.0 + bias
+    ref = torch.einsum("bhlt,bhtd->bhld", torch.softmax(s, -1), v).permute(0, 2, 1, 3).reshape(B, T, H * 64)
+    err = (out.float().cpu() - ref).abs()
+    scale = ref.abs().max().item()
+    print(f"bf16 attention T={T}: max err {err.max().item():.3e}, mean {err.mean().item():.3e}, scale {scale:.2f}")
+    assert err.max().item() <= 3e-2 * scale and err.mean().item() <= 4e-3 * scale

@@ -195,6 +195,178 @@ __global__ __launch_bounds__(256) void vn_attention_kernel(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 FAST MODE attention (vn_model_set_bf16; not bit-exact — the reference's own GPU path runs this op under
+// torch.autocast(bfloat16), interface.py:364,428).  Same decomposition and transposed-product trick as the fp32 kernel,
+// on v_mfma_f32_16x16x32_bf16: K is staged as a bf16 [key][d] tile, V as a TRANSPOSED bf16 [d][key] tile (so both MFMA A
+// operands are 16-byte LDS reads), Q (pre-scaled by 1/8, exact) and the probabilities P are bf16 B operands held in
+// registers; scores, softmax state and the output accumulators stay fp32.  16 MFMAs per 64-key tile per wave (256 matrix
+// cycles) against ~1 k VALU cycles of softmax: the kernel is VALU-bound, exp is a bare v_exp_f32 (bf16 keeps 8 bits).
+// MFMA k-slot mapping of the P.V product: lane group kk carries keys {16u + 4kk + r} and {16(u+1) + 4kk + r}, r = 0..3 —
+// exactly the keys whose probabilities the lane computed — the V^T operand reads the same key sets.
+// ---------------------------------------------------------------------------------------------------------------------
+#define ATB_LDK 72        // bf16 per padded row of the K / V^T tiles (64 + 8: 144-byte rows, conflict-free 16-byte reads)
+
+__device__ __forceinline__ unsigned vn_pack_bf16x2(float a, float b) {
+    return (unsigned)vn_f32_to_bf16(a) | ((unsigned)vn_f32_to_bf16(b) << 16);
+}
+
+__global__ __launch_bounds__(256) void vn_attention_bf16_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                const float* __restrict__ v,
+                                                                const float* __restrict__ bias_full,
+                                                                uint16_t* __restrict__ out16, int B, int H, int T) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* Ks = (uint16_t*)smem;                       // [64 keys][ATB_LDK]
+    uint16_t* Vt = Ks + ATT_KT * ATB_LDK;                 // [64 d][ATB_LDK] (key along the row)
+    float* bt = (float*)(Vt + VN_DHEAD * ATB_LDK);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const size_t headoff = ((size_t)b * H + h) * (size_t)T * VN_DHEAD;
+    const float* Q = q + headoff;
+    const float* K = k + headoff;
+    const float* V = v + headoff;
+    const int qrow = qb * 64 + wave * 16 + j;
+    const int qrow_c = qrow < T ? qrow : T - 1;
+    const int nb = 2 * T - 1;
+    for (int i = tid; i < nb; i += 256) bt[i] = bias_full[(size_t)h * nb + i];
+
+    // Q fragments (B operand of S^T = K Q^T): lane (j, g) holds Q[q_j][32s + 8g .. +7] * 1/8 as bf16x8
+    bf16x8 qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const f32x4 a = *(const f32x4*)(Q + (size_t)qrow_c * VN_DHEAD + 32 * s + 8 * g);
+        const f32x4 c = *(const f32x4*)(Q + (size_t)qrow_c * VN_DHEAD + 32 * s + 8 * g + 4);
+        u32x4 pk = {vn_pack_bf16x2(a[0] * 0.125f, a[1] * 0.125f), vn_pack_bf16x2(a[2] * 0.125f, a[3] * 0.125f),
+                    vn_pack_bf16x2(c[0] * 0.125f, c[1] * 0.125f), vn_pack_bf16x2(c[2] * 0.125f, c[3] * 0.125f)};
+        qf[s] = __builtin_bit_cast(bf16x8, pk);
+    }
+
+    // staging: thread handles float4 idx = tid + 256*i (row = idx>>4 = key, c4 = idx&15 -> d = 4*c4 .. +3)
+    f32x4 kreg[4], vreg[4];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 4, c4 = idx & 15;
+            const int key = kt * ATT_KT + row;
+            if (key < T) {
+                kreg[i] = *(const f32x4*)(K + (size_t)key * VN_DHEAD + c4 * 4);
+                vreg[i] = *(const f32x4*)(V + (size_t)key * VN_DHEAD + c4 * 4);
+            } else {
+                kreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                vreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto write_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 4, c4 = idx & 15;
+            uint2 pk = {vn_pack_bf16x2(kreg[i][0], kreg[i][1]), vn_pack_bf16x2(kreg[i][2], kreg[i][3])};
+            *(uint2*)(Ks + row * ATB_LDK + c4 * 4) = pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Vt[(c4 * 4 + e) * ATB_LDK + row] = vn_f32_to_bf16(vreg[i][e]);
+        }
+    };
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nkt = (T + ATT_KT - 1) / ATT_KT;
+    load_tile(0);
+    write_tile();
+    __syncthreads();
+    const float L2E = 1.4426950408889634f;
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        // ---- S^T[key][q]: 4 key sub-tiles x 2 k-steps of 32
+        f32x4 sacc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sacc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bf16x8 kf = *(const bf16x8*)(Ks + (u * 16 + j) * ATB_LDK + 32 * s + 8 * g);
+                sacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], sacc[u], 0, 0, 0);
+            }
+        // ---- online softmax (fp32 state); lane holds keys kt*64 + 16u + 4g + r for query j
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * ATT_KT + u * 16 + 4 * g + r;
+                const int key_c = key < T ? key : T - 1;
+                float x = sacc[u][r] + bt[key_c - qrow_c + (T - 1)];
+                x = key < T ? x : -INFINITY;
+                sacc[u][r] = x;
+                mx = fmaxf(mx, x);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(fmaxf(m_run - m_new, -126.0f) * L2E);
+        const float mb = m_new * L2E;
+        float lsum = 0.f;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int up = 0; up < 2; ++up) {
+            float pv[8];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pexp = __builtin_amdgcn_exp2f(fmaxf(fmaf(sacc[2 * up + hh][r], L2E, -mb), -126.0f));
+                    lsum += pexp;
+                    pv[4 * hh + r] = pexp;
+                }
+            u32x4 pk = {vn_pack_bf16x2(pv[0], pv[1]), vn_pack_bf16x2(pv[2], pv[3]), vn_pack_bf16x2(pv[4], pv[5]),
+                        vn_pack_bf16x2(pv[6], pv[7])};
+            pf[up] = __builtin_bit_cast(bf16x8, pk);
+        }
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e][0] *= alpha; o[e][1] *= alpha; o[e][2] *= alpha; o[e][3] *= alpha;
+        }
+        // ---- O^T[d][q] += V^T[d][keys] . P^T[keys][q]; lane (i = j, kk = g) reads V^T[16e + j][{16u+4g+r}, {16(u+1)+4g+r}]
+#pragma unroll
+        for (int up = 0; up < 2; ++up)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint2 lo = *(const uint2*)(Vt + (16 * e + j) * ATB_LDK + 32 * up + 4 * g);
+                const uint2 hi = *(const uint2*)(Vt + (16 * e + j) * ATB_LDK + 32 * up + 16 + 4 * g);
+                u32x4 pk = {lo.x, lo.y, hi.x, hi.y};
+                o[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pk), pf[up], o[e], 0, 0, 0);
+            }
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            write_tile();
+            __syncthreads();
+        }
+    }
+    float l_tot = l_run;
+    l_tot += __shfl_xor(l_tot, 16);
+    l_tot += __shfl_xor(l_tot, 32);
+    if (qrow < T) {
+        // accumulator o[e][r] = O[q_j][d = 16e + 4g + r]
+        const float inv = 1.0f / l_tot;
+        const size_t ooff = ((size_t)b * T + qrow) * ((size_t)H * VN_DHEAD) + h * VN_DHEAD + 4 * g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint2 pk = {vn_pack_bf16x2(o[e][0] * inv, o[e][1] * inv), vn_pack_bf16x2(o[e][2] * inv, o[e][3] * inv)};
+            *(uint2*)(out16 + ooff + 16 * e) = pk;
+        }
+    }
+}
+
 int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* relbias_full,
                         float* out, int B, int H, int T, hipStream_t s, uint16_t* out16) {
     if (B <= 0 || T <= 0) return VN_OK;
@@ -206,10 +378,19 @@ int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float
         if (const char* e = getenv("VN_ATTN_VARIANT")) variant = atoi(e) & 1;
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
     const dim3 grid(vn_cdiv(T, 64), H, B);
+    static const bool bf16_attn = [] { const char* e = getenv("VN_ATTN_BF16"); return !(e && e[0] == '0'); }();
+    if (out16 && bf16_attn) {        // fast mode: bf16 MFMA attention (VN_ATTN_BF16=0 keeps the fp32 kernel for A/B runs)
+        const size_t lds16 = (size_t)(2 * ATT_KT * ATB_LDK) * sizeof(uint16_t) + (size_t)(2 * T - 1 + 3) * sizeof(float);
+        hipLaunchKernelGGL(vn_attention_bf16_kernel, grid, dim3(256), lds16, s, q, k, v, relbias_full, out16, B, H, T);
+        vn_prof_post(ctx, pi, s);
+        VN_LAUNCH_CHECK(ctx);
+        return VN_OK;
+    }
     if (variant == 0) hipLaunchKernelGGL(vn_attention_kernel<0>, grid, dim3(256), lds, s, q, k, v, relbias_full, out, out16, B, H, T);
     else hipLaunchKernelGGL(vn_attention_kernel<1>, grid, dim3(256), lds, s, q, k, v, relbias_full, out, out16, B, H, T);
     vn_prof_post(ctx, pi, s);

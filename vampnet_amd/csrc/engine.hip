@@ -503,6 +503,28 @@ extern "C" int vn_generate(vn_model* m, const int64_t* start_tokens, const int64
 }
 
 // ---- single-kernel entry points ---------------------------------------------------------------
+// bf16 fast-mode attention as a single op (tests): same arguments as vn_attention_f32, out16 = bf16 [B][T][H*64]
+extern "C" int vn_attention_bf16(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                                 void* out16, int B, int H, int T, int num_buckets, int max_distance, void* stream) {
+    if (!ctx || !q || !k || !v || !rel_bias || !out16 || T <= 0 || H <= 0) return VN_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    float* full = nullptr;
+    int32_t* lut_d = nullptr;
+    const int n = 2 * T - 1;
+    VN_HIP_CHECK(ctx, hipMalloc((void**)&full, (size_t)H * n * sizeof(float)));
+    VN_HIP_CHECK(ctx, hipMalloc((void**)&lut_d, (size_t)n * sizeof(int32_t)));
+    std::vector<int32_t> lut(n);
+    vn_bucket_lut_host(T, num_buckets, max_distance, lut.data());
+    int rc = VN_OK;
+    if (hipMemcpy(lut_d, lut.data(), n * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) rc = VN_ERR_HIP;
+    if (rc == VN_OK) rc = vn_launch_bias_expand(ctx, rel_bias, lut_d, full, H, T, s);
+    if (rc == VN_OK) rc = vn_launch_attention(ctx, q, k, v, full, nullptr, B, H, T, s, (uint16_t*)out16);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(full);
+    (void)hipFree(lut_d);
+    return rc;
+}
+
 extern "C" int vn_rmsnorm_f32(vn_ctx* ctx, const float* x, const float* w, float* y, int rows, int D, float eps,
                               void* stream) {
     if (!ctx || !x || !w || !y) return VN_ERR_INVALID;
