@@ -70,6 +70,9 @@ class Trainer:
         host[:self.wsize] = blob
         og, ov = self._cls_offsets()
         V, Cp, D = vocab_size, self.Cp, embedding_dim
+        if "classifier.layers.0.weight_g" not in sd:
+            raise VnError("Trainer needs the weight-normed classifier parameters classifier.layers.0.weight_g / weight_v "
+                          "(layers.py:47-48); this state_dict holds a folded weight only")
         g = sd["classifier.layers.0.weight_g"].float().reshape(V, Cp).t().reshape(-1)            # (p c) -> (c p)
         v = sd["classifier.layers.0.weight_v"].float().reshape(V, Cp, D).permute(1, 0, 2).reshape(-1)
         host[og:og + g.numel()] = g
