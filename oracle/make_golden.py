@@ -135,6 +135,56 @@ def main():
         full[f"{name}_rowsum"] = lg.double().sum(-1).numpy()
         del model, sd
     np.savez_compressed(os.path.join(OUT, "forward_full.npz"), **full)
+
+    # --- one training step of the REFERENCE modules (train.py:237-304) on the tiny models, dropout masks injected ----
+    import importlib
+    import types
+    from oracle import train_oracle as TO
+    sched_mod = importlib.import_module("vampnet.scheduler")
+    tr = {}
+    for name, dims, seed in (("coarse", W.TINY_COARSE_DIMS, 0), ("c2f", W.TINY_C2F_DIMS, 1)):
+        sd = W.synth_state_dict(dims, seed)
+        model = ref_shim.build_reference_model(ns, dims, sd)
+        model.train()
+        B, T, p = 2, 24, 0.1
+        z = W.synth_codes(B, dims["n_codebooks"], T, seed=5)
+        r = torch.tensor([0.3, 0.8])
+        mask = TO.make_training_mask(z, r, dims["n_cond"], generator=torch.Generator().manual_seed(3))
+        masks = TO.draw_dropout_masks(dims, B, T, p, torch.Generator().manual_seed(4))
+        for i, layer in enumerate(model.transformer.layers):       # inject the keep-masks (call order: attn, res1, ffn, res2)
+            calls = {"n": 0}
+            layer.self_attn.dropout.forward = types.MethodType(lambda self, x, i=i: x * masks[(i, "attn")] * (1.0 / (1.0 - p)), layer.self_attn.dropout)
+            layer.feed_forward.drop.forward = types.MethodType(lambda self, x, i=i: x * masks[(i, "ffn")] * (1.0 / (1.0 - p)), layer.feed_forward.drop)
+
+            def res_drop(self, x, i=i, calls=calls):
+                site = "res1" if calls["n"] % 2 == 0 else "res2"
+                calls["n"] += 1
+                return x * masks[(i, site)] * (1.0 / (1.0 - p))
+            layer.dropout.forward = types.MethodType(res_drop, layer.dropout)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+        sched = sched_mod.NoamScheduler(opt, d_model=dims["d_model"], factor=2.0, warmup=10000)
+        sched.step()
+        z_mask, mk = ns.mask.apply_mask(z, mask, model.mask_token)
+        z_hat = model(model.embedding.from_codes(z_mask, codec))
+        target = ns.util.codebook_flatten(z[:, dims["n_cond"]:, :])
+        flat = ns.util.codebook_flatten(mk[:, dims["n_cond"]:, :])
+        loss = torch.nn.CrossEntropyLoss(label_smoothing=0.1)(z_hat, target.masked_fill(~flat.bool(), -100))
+        loss.backward()
+        gnorm = torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        names = [k for k, _ in model.named_parameters()]
+        tr[f"{name}_loss"] = np.float32(loss.item())
+        tr[f"{name}_grad_norm"] = np.float32(gnorm.item())
+        tr[f"{name}_lr"] = np.float64(opt.param_groups[0]["lr"])
+        tr[f"{name}_names"] = np.array(names)
+        tr[f"{name}_grad_absmax"] = np.array([pp.grad.abs().max().item() for pp in model.parameters()], np.float32)
+        tr[f"{name}_grad_sum"] = np.array([pp.grad.double().sum().item() for pp in model.parameters()], np.float64)
+        for k in ("transformer.layers.1.feed_forward.w_2.weight", "transformer.layers.0.self_attn.w_qs.weight",
+                  "embedding.special.MASK", "transformer.layers.0.self_attn.relative_attention_bias.weight"):
+            tr[f"{name}_grad::{k}"] = dict(model.named_parameters())[k].grad.numpy().copy()
+        opt.step()
+        tr[f"{name}_w2_after"] = dict(model.named_parameters())["transformer.layers.1.feed_forward.w_2.weight"].detach().numpy().copy()
+        del model
+    np.savez_compressed(os.path.join(OUT, "train_tiny.npz"), **tr)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -109,3 +109,36 @@ def test_forward_full_size_probe(name, dims, T, seed):
     am = lg.argmax(-1).numpy()
     bad = np.nonzero(am != g[f"{name}_argmax"])[0]
     assert all(g[f"{name}_gap"][b] < 2e-5 for b in bad), "argmax flip outside the near-tie band"
+
+
+@pytest.mark.parametrize("name", ["coarse", "c2f"])
+def test_train_step_golden(name):
+    """oracle/train_oracle.py against one training step of the REFERENCE's own modules (train.py:237-304) frozen by
+    oracle/make_golden.py: loss, global gradient norm, per-parameter gradient statistics, four full gradient tensors
+    and the AdamW-updated w_2 of layer 1.  Bitwise on the machine that froze them; 2e-5 relative elsewhere (BLAS)."""
+    from oracle import train_oracle as TO
+    g = load("train_tiny.npz")
+    dims = W.TINY_COARSE_DIMS if name == "coarse" else W.TINY_C2F_DIMS
+    sd, cb = W.synth_state_dict(dims, 0 if name == "coarse" else 1), W.synth_codebooks()
+    B, T, p = 2, 24, 0.1
+    z = W.synth_codes(B, dims["n_codebooks"], T, seed=5)
+    mask = TO.make_training_mask(z, torch.tensor([0.3, 0.8]), dims["n_cond"], generator=torch.Generator().manual_seed(3))
+    masks = TO.draw_dropout_masks(dims, B, T, p, torch.Generator().manual_seed(4))
+    loss, grads, _ = TO.loss_and_grads(sd, dims, cb, z, mask, masks, p)
+    assert abs(loss.item() - float(g[f"{name}_loss"])) <= 2e-6 * abs(float(g[f"{name}_loss"]))
+    names = [str(n) for n in g[f"{name}_names"]]
+    assert set(names) == set(grads)
+    for i, k in enumerate(names):
+        am = float(g[f"{name}_grad_absmax"][i])
+        assert abs(grads[k].abs().max().item() - am) <= 2e-5 * max(am, 1e-12), k
+    for key in g.files:
+        if key.startswith(f"{name}_grad::"):
+            k = key.split("::", 1)[1]
+            ref = torch.from_numpy(g[key])
+            assert (grads[k] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item(), k
+    lr = TO.noam_lr(1, dims["d_model"])
+    assert lr == float(g[f"{name}_lr"])
+    new, norm = TO.clip_and_adamw(sd, grads, {}, lr)
+    assert abs(norm.item() - float(g[f"{name}_grad_norm"])) <= 1e-4 * float(g[f"{name}_grad_norm"])
+    w2 = torch.from_numpy(g[f"{name}_w2_after"])
+    assert (new["transformer.layers.1.feed_forward.w_2.weight"] - w2).abs().max().item() <= 1e-9 + 2.1 * lr
