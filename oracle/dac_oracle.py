@@ -31,12 +31,9 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-DAC_DEFAULT_CFG = dict(encoder_dim=64, encoder_rates=[2, 4, 8, 12], latent_dim=None, decoder_dim=1536,
-                       decoder_rates=[12, 8, 4, 2], n_codebooks=14, codebook_size=1024, codebook_dim=8,
-                       sample_rate=44100)
-# shapes the CPU finishes in milliseconds (channel counts stay multiples of 32 like every real layer)
-DAC_TINY_CFG = dict(encoder_dim=32, encoder_rates=[2, 4], latent_dim=None, decoder_dim=128,
-                    decoder_rates=[4, 2], n_codebooks=4, codebook_size=1024, codebook_dim=8, sample_rate=44100)
+# configs and the seeded synthetic-weight generator live in the product's data-generator module (no arithmetic there);
+# re-exported here so tests keep one import
+from vampnet_amd.synth import DAC_DEFAULT_CFG, DAC_TINY_CFG, synth_dac_state_dict  # noqa: E402,F401
 
 
 def latent_dim(cfg):
@@ -148,60 +145,3 @@ def encode(sd, cfg, audio):
 def decode(sd, cfg, codes):
     """codes (B, n, T) -> audio (B,1,T*hop)   (transformer.py:669-675, MASK already replaced by 0)"""
     return decoder(sd, cfg, from_codes(sd, cfg, codes))
-
-
-def synth_dac_state_dict(cfg, seed=0):
-    """Seeded synthetic codec weights (numpy PCG64).  PyTorch-default-like scales; snake alphas around 1;
-    weight_g perturbed from ||v|| so the weight-norm fold is exercised."""
-    rng = np.random.default_rng(seed)
-    sd = {}
-
-    def U(shape, b):
-        return torch.from_numpy(rng.uniform(-b, b, size=shape).astype(np.float32))
-
-    def conv(key, cout, cin, k, transposed=False):
-        shape = (cin, cout, k) if transposed else (cout, cin, k)
-        fan_in = (cout if transposed else cin) * k
-        v = U(shape, 1.0 / math.sqrt(fan_in))
-        sd[key + ".weight_v"] = v
-        sd[key + ".weight_g"] = v.norm(dim=(1, 2), keepdim=True) * (1.0 + U((shape[0], 1, 1), 0.1))
-        sd[key + ".bias"] = U((cout,), 1.0 / math.sqrt(fan_in))
-
-    def alpha(key, c):
-        sd[key + ".alpha"] = 1.0 + U((1, c, 1), 0.3)
-
-    def res(p, c):
-        alpha(p + ".block.0", c); conv(p + ".block.1", c, c, 7); alpha(p + ".block.2", c); conv(p + ".block.3", c, c, 1)
-
-    d = cfg["encoder_dim"]
-    conv("encoder.block.0", d, 1, 7)
-    for i, s in enumerate(cfg["encoder_rates"]):
-        d *= 2
-        p = f"encoder.block.{1 + i}"
-        for j in range(3):
-            res(f"{p}.block.{j}", d // 2)
-        alpha(p + ".block.3", d // 2)
-        conv(p + ".block.4", d, d // 2, 2 * s)
-    n = len(cfg["encoder_rates"])
-    L = latent_dim(cfg)
-    alpha(f"encoder.block.{n + 1}", d)
-    conv(f"encoder.block.{n + 2}", L, d, 3)
-    for i in range(cfg["n_codebooks"]):
-        p = f"quantizer.quantizers.{i}"
-        conv(p + ".in_proj", cfg["codebook_dim"], L, 1)
-        conv(p + ".out_proj", L, cfg["codebook_dim"], 1)
-        sd[p + ".codebook.weight"] = torch.from_numpy(
-            rng.standard_normal((cfg["codebook_size"], cfg["codebook_dim"])).astype(np.float32))
-    D = cfg["decoder_dim"]
-    conv("decoder.model.0", D, L, 7)
-    for i, s in enumerate(cfg["decoder_rates"]):
-        cin, cout = D // 2 ** i, D // 2 ** (i + 1)
-        p = f"decoder.model.{1 + i}"
-        alpha(p + ".block.0", cin)
-        conv(p + ".block.1", cout, cin, 2 * s, transposed=True)
-        for j in range(3):
-            res(f"{p}.block.{2 + j}", cout)
-    n = len(cfg["decoder_rates"])
-    alpha(f"decoder.model.{n + 1}", cout)
-    conv(f"decoder.model.{n + 2}", 1, cout, 7)
-    return sd

@@ -2,7 +2,7 @@
 import json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import dac_oracle as D            # synthetic codec weights only
+from vampnet_amd import synth as D             # seeded synthetic codec weights / configs (data generators only)
 from vampnet_amd.codec import DacCodec
 from vampnet_amd.engine import Engine
 

@@ -1,7 +1,7 @@
 """One warm DAC encode + decode at B=8 under rocprofv3 --kernel-trace; scripts/codec_trace_report.py lists the dispatches."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import dac_oracle as D
+from vampnet_amd import synth as D
 from vampnet_amd.codec import DacCodec
 from vampnet_amd.engine import Engine
 eng = Engine("cuda:0")
