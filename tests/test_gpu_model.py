@@ -484,3 +484,61 @@ def test_forward_graph_replay_is_used_and_exact():
     assert torch.equal(got, ref)
     again = itf.vamp(z, mask, batch_size=2, seed=1, _sampling_steps=6).cpu()       # all-replay call
     assert torch.equal(again, ref)
+
+
+def test_abi_error_behaviour(eng):
+    """Every entry point returns a negative status + a message (never crashes, never throws across the ABI) on bad input,
+    and the context keeps working afterwards (errors are codes + vn_last_error)."""
+    import ctypes as C
+    from vampnet_amd import _lib
+    from vampnet_amd.engine import VampNetModel
+    lib = eng.lib
+    dims = W.TINY_COARSE_DIMS
+    cb, sd = W.synth_codebooks(), W.synth_state_dict(dims, 0)
+    model = VampNetModel(eng, sd, cb, max_batch=2, max_T=40, **model_kwargs(dims))
+    h, st = model.handle, eng.stream()
+    z = W.synth_codes(2, 4, 40, seed=1).cuda()
+    logits = torch.empty(2, 40, 4, 1024, device="cuda")
+
+    def err():
+        return lib.vn_last_error(eng.handle).decode()
+
+    assert lib.vn_forward(h, z.data_ptr(), 3, 40, logits.data_ptr(), st) < 0 and err()            # B > max_batch
+    assert lib.vn_forward(h, z.data_ptr(), 2, 41, logits.data_ptr(), st) < 0                        # T > max_T
+    assert lib.vn_forward(h, z.data_ptr(), 0, 40, logits.data_ptr(), st) < 0                        # empty batch
+    p = _lib.vn_sample_params(300, 1.0, 10.5, 1.0, 0.0, -1, 0, 0, 0, 0)                             # steps > 256
+    out = torch.empty_like(z)
+    assert lib.vn_generate(h, z.data_ptr(), z.data_ptr(), 2, 40, C.byref(p), None, None, None, out.data_ptr(), st) < 0
+    p = _lib.vn_sample_params(4, 1.0, 10.5, 1.0, 0.0, -1, 0, 0, 0, 0)
+    assert lib.vn_generate(h, None, z.data_ptr(), 2, 40, C.byref(p), None, None, None, out.data_ptr(), st) < 0   # NULL tokens
+    # bad dims at model creation: d_model != 64 * heads ; vocab unsupported
+    bad = _lib.vn_dims(2, 4, 320, 4, 0, 1024, 8, 32, 128, 1e-6, 2, 40)
+    hh = C.c_void_p()
+    assert lib.vn_model_create(eng.handle, C.byref(bad), model.blob.data_ptr(), C.byref(hh)) < 0 and not hh.value
+    bad = _lib.vn_dims(2, 4, 256, 4, 0, 1000, 8, 32, 128, 1e-6, 2, 40)
+    assert lib.vn_model_create(eng.handle, C.byref(bad), model.blob.data_ptr(), C.byref(hh)) < 0
+    n = C.c_int64()
+    assert lib.vn_weights_size(C.byref(bad), C.byref(n)) < 0
+    # GEMM shape rules
+    a = torch.randn(8, 48, device="cuda")
+    w = torch.randn(64, 48, device="cuda")
+    c = torch.empty(8, 64, device="cuda")
+    assert lib.vn_gemm_f32(eng.handle, a.data_ptr(), w.data_ptr(), None, c.data_ptr(), 8, 64, 48, _lib.EPI_STORE, st) < 0   # K % 32
+    assert "multiple of 32" in err()
+    # training entry points
+    tp = _lib.vn_train_params(1e-3, 0.9, 0.999, 1e-8, 1e-2, 5.0, 0.1, 1.5, 0, 1, 0, 1)                # dropout >= 1
+    assert lib.vn_train_create(h, None, C.byref(hh)) < 0
+    from vampnet_amd.train import Trainer
+    tr = Trainer(eng, sd, cb, **model_kwargs(dims), max_batch=2, max_T=40)
+    zm, tg = tr.make_batch(z.cpu(), r=torch.tensor([0.5, 0.5]))
+    assert lib.vn_train_forward_backward(tr.handle, zm.data_ptr(), tg.data_ptr(), 2, 40, C.byref(tp), tr.grads.data_ptr(),
+                                         tr.loss.data_ptr(), st) < 0 and "dropout" in err()
+    tp = _lib.vn_train_params(1e-3, 0.9, 0.999, 1e-8, 1e-2, 5.0, 0.1, 0.1, 0, 0, 0, 1)                # step < 1
+    assert lib.vn_train_update(tr.handle, tr.grads.data_ptr(), tr.adam_m.data_ptr(), tr.adam_v.data_ptr(), C.byref(tp),
+                               tr.grad_norm.data_ptr(), st) < 0
+    assert lib.vn_train_backward(tr.handle, C.byref(_lib.vn_train_params(1e-3, 0.9, 0.999, 1e-8, 1e-2, 5.0, 0.1, 0.1, 0, 1, 0, 1)),
+                                 tr.grads.data_ptr(), 1, 2, st) < 0                                  # lo > hi / no stashed forward
+    # the context still works
+    ok = model.forward_codes(z.cpu())
+    assert torch.isfinite(ok).all()
+    eng.health_check()
