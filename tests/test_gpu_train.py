@@ -183,21 +183,23 @@ def test_train_step_is_deterministic_and_shard_invariant(engine):
     assert torch.equal(full[:, 1:2], part)
 
 
-@pytest.mark.parametrize("which", ["coarse", "c2f"])
-def test_full_size_train_step_vs_oracle(engine, which):
-    """Full-size models (333 M / 275 M parameters), one sequence, no dropout: loss and every gradient against CPU
-    autograd; then one clipped AdamW update."""
+@pytest.mark.parametrize("which,p", [("coarse", 0.0), ("c2f", 0.0), ("coarse", 0.1)])
+def test_full_size_train_step_vs_oracle(engine, which, p):
+    """Full-size models (333 M / 275 M parameters), one sequence: loss and every gradient against CPU autograd (with the
+    engine's own keep-masks injected when dropout is on); then one clipped AdamW update."""
     dims = W.COARSE_DIMS if which == "coarse" else W.C2F_DIMS
     T = 575 if which == "coarse" else 173
     sd = W.synth_state_dict(dims, 0 if which == "coarse" else 1)
     cb = W.synth_codebooks()
-    tr = _trainer(engine, dims, sd, cb, max_batch=1, max_T=T, dropout=0.0)
+    tr = _trainer(engine, dims, sd, cb, max_batch=1, max_T=T, dropout=p, seed=9)
     z = W.synth_codes(1, dims["n_codebooks"], T, seed=4)
     mask = TO.make_training_mask(z, torch.tensor([0.7]), dims["n_cond"], generator=torch.Generator().manual_seed(6))
     z_mask, target = tr.make_batch(z, mask=mask)
     loss = tr.forward_backward(z_mask, target).cpu()
     torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
-    loss_o, grads_o, _ = TO.loss_and_grads(sd, dims, cb, z, mask, None, 0.0)
+    masks = _masks_from_device(tr, dims, 1, T, 1, p)
+    loss_o, grads_o, _ = TO.loss_and_grads(sd, dims, cb, z, mask, masks, p)
+    del masks
     assert abs(loss.item() - loss_o.item()) < 1e-5 * abs(loss_o.item())
     grads = tr.export(tr.grads)
     worst = ("", 0.0)
@@ -206,7 +208,7 @@ def test_full_size_train_step_vs_oracle(engine, which):
         if e > worst[1]:
             worst = (k, e)
         assert e < 2e-4, (k, e)
-    print(f"{which} full size: loss {loss.item():.6f}, worst grad rel err {worst[1]:.2e} at {worst[0]}")
+    print(f"{which} full size (dropout {p}): loss {loss.item():.6f}, worst grad rel err {worst[1]:.2e} at {worst[0]}")
     state = {}
     lr = TO.noam_lr(1, dims["d_model"])                  # conf/vampnet.yml:21-22 -> 5.6e-8 at step 1
     new_o, norm_o = TO.clip_and_adamw(sd, grads_o, state, lr)
