@@ -406,6 +406,51 @@ __global__ __launch_bounds__(256, 2) void vn_gemm_f32_sk_kernel(vn_gemm_args p, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// two-pass split-K for SMALL-M shapes (one sequence: M = 575 rows -> 180 tiles of 64 x 64 cannot fill 256 CUs, and each
+// block walks all K / 32 k-tiles serially at one wave per SIMD).  Pass 1: grid (tiles, S), split s accumulates k-tiles
+// [s*nk/S, (s+1)*nk/S) and stores its raw partial tile to workspace[s][M][N]; pass 2 sums the S partials in fixed order and
+// applies the epilogue (residual add / plain store).  No in-kernel hand-off: the per-launch fix-up of the stream-K path
+// (slab write-through, flag, acquire) costs more than these kernels last.  Deterministic.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void vn_gemm_f32_splitk_kernel(vn_gemm_args p, int tiles_m, int tiles_n, int order,
+                                                                    int nsplit, float* __restrict__ partial) {
+    using Cfg = GemmCfg<BM, BN>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int tm, tn;
+    vn_tile_coords(vn_xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, order, tm, tn);
+    const int nk = vn_ktiles<false>(p), sp = blockIdx.y;
+    const int kb = (int)((long)nk * sp / nsplit), ke = (int)((long)nk * (sp + 1) / nsplit);
+    f32x16 acc[Cfg::MI][Cfg::NI];
+    vn_acc_zero(acc);
+    if (ke > kb) vn_gemm_mac<BM, BN, false>(p, lds, tm * BM, tn * BN, kb, ke, acc);
+    vn_gemm_args q = p;                                   // raw store of this split's partial tile
+    q.C = partial + (size_t)sp * p.M * p.N;
+    q.ldc = p.N;
+    vn_gemm_epilogue<BM, BN, VN_EPI_STORE>(q, tm * BM, tn * BN, acc);
+}
+
+template <bool RESID>
+__global__ __launch_bounds__(256) void vn_splitk_reduce_kernel(const float* __restrict__ partial, int nsplit, float* __restrict__ C,
+                                                               int M, int N4, int ldc4) {
+    const long total = (long)M * N4, plane = total;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        f32x4 a = ((const f32x4*)partial)[i];
+        for (int sp = 1; sp < nsplit; ++sp) {
+            const f32x4 b = ((const f32x4*)partial)[i + sp * plane];
+            a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+        }
+        const long row = i / N4, c4 = i - row * N4;
+        f32x4* dst = (f32x4*)C + row * ldc4 + c4;
+        if (RESID) {
+            const f32x4 r = *dst;
+            a[0] += r[0]; a[1] += r[1]; a[2] += r[2]; a[3] += r[3];
+        }
+        *dst = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 // tuning hooks (scripts/gemm_sweep.py): force a tile / scheduler / tile order
@@ -413,6 +458,7 @@ static int g_order = 1;
 static int g_stagger = 2;      // stream-K: second-slot blocks start 2 x 1024 cycles late (measured +2..6 %)
 static int g_force_bm = 0, g_force_bn = 0;
 static int g_sched = -1;          // -1 auto, 0 data-parallel, 1 stream-K
+static int g_splitk = -1;         // VN_GEMM_SPLITK: -1 auto, 0 off, >= 2 forced split count (small-M shapes only)
 static void read_env_once() {
     static bool done = false;
     if (done) return;
@@ -420,6 +466,7 @@ static void read_env_once() {
     if (const char* e = getenv("VN_GEMM_ORDER")) g_order = atoi(e);
     if (const char* e = getenv("VN_GEMM_TILE")) sscanf(e, "%dx%d", &g_force_bm, &g_force_bn);
     if (const char* e = getenv("VN_GEMM_SCHED")) g_sched = atoi(e);
+    if (const char* e = getenv("VN_GEMM_SPLITK")) g_splitk = atoi(e);
 }
 
 extern "C" int vn_debug_gemm_config(int bm, int bn, int order) {
@@ -491,9 +538,39 @@ static double sk_cost(int M, int N, int K, int bm, int bn, double eff) {
     return blocks / 256.0 * (double)bm * bn / eff + 0.2 * 16384.0 * 1280.0 / (double)K;
 }
 
+// small-M residual / plain-store GEMMs: two-pass split-K (see vn_gemm_f32_splitk_kernel)
+template <int EPI>
+static int launch_splitk(vn_ctx* ctx, const vn_gemm_args& a, int nsplit, hipStream_t s) {
+    using Cfg = GemmCfg<64, 64>;
+    int rc = sk_workspace(ctx);
+    if (rc) return rc;
+    const int tiles_m = vn_cdiv(a.M, 64), tiles_n = vn_cdiv(a.N, 64);
+    const double bytes = 4.0 * ((double)a.M * a.K + (double)a.N * a.K) + 4.0 * (double)a.M * a.N * (EPI == VN_EPI_RESIDUAL ? 2 : 1);
+    const int pi = vn_prof_pre(ctx, 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);
+    hipLaunchKernelGGL((vn_gemm_f32_splitk_kernel<64, 64>), dim3(tiles_m * tiles_n, nsplit), dim3(256), Cfg::LDS_BYTES, s, a, tiles_m,
+                       tiles_n, g_order, nsplit, ctx->sk_slabs);
+    const long total4 = (long)a.M * (a.N / 4);
+    const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL((vn_splitk_reduce_kernel<EPI == VN_EPI_RESIDUAL>), dim3(blocks), dim3(256), 0, s, ctx->sk_slabs, nsplit, a.C,
+                       a.M, a.N / 4, a.ldc / 4);
+    vn_prof_post(ctx, pi, s);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
 template <int EPI>
 static int launch_epi(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
     read_env_once();
+    if constexpr (EPI == VN_EPI_RESIDUAL || EPI == VN_EPI_STORE) {
+        // one sequence (M <= 640): 64 x 64 tiles fill at most 70 % of the CUs at one wave per SIMD -> split K so that every CU
+        // hosts two blocks; needs fp32 operands, a 4-aligned row stride and room in the 32 MiB slab workspace
+        if (!a.bf16 && !g_force_bm && g_sched != 1 && g_splitk != 0 && a.M <= 1280 && a.K >= 1024 && a.N % 4 == 0 && a.ldc % 4 == 0) {
+            const int tiles = vn_cdiv(a.M, 64) * vn_cdiv(a.N, 64);
+            int ns = g_splitk >= 2 ? g_splitk : (tiles >= 512 ? 0 : (tiles >= 256 ? 2 : (tiles >= 128 ? 4 : 8)));
+            while (ns > 1 && (a.K / BK) / ns < 4) ns >>= 1;
+            if (ns >= 2 && (size_t)ns * a.M * a.N <= (size_t)SK_MAX_BLOCKS * 128 * 128) return launch_splitk<EPI>(ctx, a, ns, s);
+        }
+    }
     int bm = g_force_bm, bn = g_force_bn;
     bool sk = g_sched == 1;
     if (!bm) {
