@@ -319,6 +319,16 @@ int  vn_attention_train_f32(vn_ctx* ctx, const float* q, const float* k, const f
  * weight-gradient GEMMs; exposed for tests and tuning.                                                              */
 int  vn_transpose_f32(vn_ctx* ctx, const float* src, float* dst, int R, int C, int ldd, void* stream);
 
+/* ---- torch's CPU random stream on the device (seeded parity mode at device speed; csrc/torch_rng.hip) ---------------
+ * vn_mt19937_generate continues at::mt19937 (the engine of torch's CPU generator): state624 dev u32[624] and *pos (dev
+ * int32: index of the next word to emit, 624 = block exhausted) are read and written back advanced by n words; out_raw dev
+ * u32[n] receives the tempered outputs, or NULL to skip them.  The two transforms reproduce Tensor.exponential_(1) (two
+ * words per element) and Tensor.uniform_(lo, hi) (one word per element) of float32 CPU tensors (transformer.py:28-30,
+ * :1024-1028 consume them through multinomial / gumbel_noise_like).                                                   */
+int vn_mt19937_generate(vn_ctx* ctx, uint32_t* state624, int32_t* pos, uint32_t* out_raw, int64_t n, void* stream);
+int vn_torch_exponential_f32(vn_ctx* ctx, const uint32_t* raw, float* out, int64_t n, void* stream);
+int vn_torch_uniform_f32(vn_ctx* ctx, const uint32_t* raw, float* out, int64_t n, float lo, float hi, void* stream);
+
 /* number of forward passes of this model that were served by replaying a captured hipGraph (tests)               */
 int vn_debug_graph_replays(const vn_model* model, int64_t* count);
 

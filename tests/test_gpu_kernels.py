@@ -235,3 +235,39 @@ def test_attention_bf16_fast_mode(eng, B, H, T):
     scale = ref.abs().max().item()
     print(f"bf16 attention T={T}: max err {err.max().item():.3e}, mean {err.mean().item():.3e}, scale {scale:.2f}")
     assert err.max().item() <= 3e-2 * scale and err.mean().item() <= 4e-3 * scale
+
+
+def test_torch_rng_on_device(eng):
+    """csrc/torch_rng.hip continues torch's CPU mt19937 stream on the GPU: exponential_ / uniform_ tensors of one sampling step
+    (2300 x 1024, then 2300) are bit-identical to what torch draws on the host, across block boundaries and across two
+    consecutive hand-overs; skipping words equals drawing and discarding; torch's generator ends in the same state."""
+    from vampnet_amd.torch_rng import DeviceTorchRng
+    rng = DeviceTorchRng(eng)
+    torch.manual_seed(4242)
+    _ = torch.rand(37)                                       # start mid-block
+    blob = torch.get_rng_state()
+    ref_e = torch.empty(2300, 1024).exponential_(1)
+    ref_u = torch.zeros(2300).uniform_(1e-20, 1)
+    ref_e2 = torch.empty(5, 1024).exponential_(1)
+    ref_tail = torch.rand(8)
+    end_state = torch.get_rng_state()
+
+    torch.set_rng_state(blob)
+    rng.load_from_torch()
+    e = rng.exponential_(torch.empty(2300, 1024, device="cuda"))
+    u = rng.uniform_(torch.empty(2300, device="cuda"), 1e-20, 1.0)
+    rng.store_to_torch()                                     # hand back ...
+    rng.load_from_torch()                                    # ... and over again
+    e2 = rng.exponential_(torch.empty(5, 1024, device="cuda"))
+    rng.store_to_torch()
+    n_bad = int((e.cpu() != ref_e).sum())
+    assert n_bad == 0, f"{n_bad} of {ref_e.numel()} exponentials differ"
+    assert torch.equal(u.cpu(), ref_u) and torch.equal(e2.cpu(), ref_e2)
+    assert torch.equal(torch.rand(8), ref_tail)              # host generator continues exactly where the reference's would
+    assert torch.equal(torch.get_rng_state()[:5016], end_state[:5016])
+    # skip == draw and discard
+    torch.set_rng_state(blob)
+    rng.load_from_torch()
+    rng.skip(2 * 2300 * 1024)
+    u2 = rng.uniform_(torch.empty(2300, device="cuda"), 1e-20, 1.0)
+    assert torch.equal(u2.cpu(), ref_u)

@@ -542,3 +542,37 @@ def test_abi_error_behaviour(eng):
     ok = model.forward_codes(z.cpu())
     assert torch.isfinite(ok).all()
     eng.health_check()
+
+
+def test_torch_device_rng_mode_equals_host_replay(tiny):
+    """rng="torch_device" (torch's CPU stream continued on the GPU) gives the tokens of rng="torch" (host-drawn noise) — and
+    therefore the reference's — for seeded stochastic sampling, including batched c2f calls, batch sharding arguments and
+    the state torch's generator is left in."""
+    from vampnet_amd.interface import Interface
+    model, sd, dims = pick(tiny, "coarse")
+    z = W.synth_codes(3, 4, 60, seed=5)
+    mask = O.periodic_mask(z, 5, 1).long()
+    a = model.generate(start_tokens=z, mask=mask, _sampling_steps=5, seed=7, temperature=0.9, rng="torch").cpu()
+    sa = torch.get_rng_state()
+    b = model.generate(start_tokens=z, mask=mask, _sampling_steps=5, seed=7, temperature=0.9, rng="torch_device").cpu()
+    sb = torch.get_rng_state()
+    assert torch.equal(a, b) and torch.equal(sa, sb)
+    ref = O.generate(sd, dims, tiny["cb"], z, mask, sampling_steps=5, seed=7, temperature=0.9)
+    assert torch.equal(b, ref)
+    # a shard of a global batch: items 1..2 of 3
+    c = model.generate(start_tokens=z[1:], mask=mask[1:], _sampling_steps=5, seed=7, temperature=0.9, rng="torch_device",
+                       n0_override=int((mask != 0).sum()), global_batch=3, batch_offset=1).cpu()
+    assert torch.equal(c, a[1:])
+    # whole vamp() incl. the batched coarse-to-fine chunk calls
+    cb = tiny["cb"]
+    csd, fsd = W.synth_state_dict(W.TINY_COARSE_DIMS, 0), W.synth_state_dict(W.TINY_C2F_DIMS, 1)
+    outs = {}
+    for mode in ("torch", "torch_device"):
+        itf = Interface.from_state_dicts(SynthCodec(cb), csd, model_kwargs(W.TINY_COARSE_DIMS), fsd, model_kwargs(W.TINY_C2F_DIMS),
+                                         device="cuda:0", max_batch=2, rng=mode)
+        z14 = W.synth_codes(1, 14, 400, seed=6)
+        torch.manual_seed(3)
+        m14 = itf.build_mask(z14)
+        outs[mode] = (itf.vamp(z14, m14, batch_size=2, seed=1, _sampling_steps=4).cpu(), torch.get_rng_state())
+    assert torch.equal(outs["torch"][0], outs["torch_device"][0])
+    assert torch.equal(outs["torch"][1], outs["torch_device"][1])

@@ -168,3 +168,63 @@ def test_bs1770_loudness_reference_tone():
     assert abs(integrated_loudness(x, sr) - (-3.01)) < 0.1
     assert abs(integrated_loudness(0.1 * x, sr) - (-23.01)) < 0.1
     assert integrated_loudness(np.zeros((1, sr)), sr) == -70.0
+
+
+# ----------------------------------------------------------------------------- torch CPU RNG stream (rng="torch_device")
+def _mt_raw(seed, n):
+    """at::mt19937(seed) raw outputs: numpy's MT19937 with the legacy init_genrand seeding is the same engine."""
+    import numpy as np
+    bg = np.random.MT19937()
+    bg._legacy_seeding(seed)
+    return bg.random_raw(n).astype(np.uint64)
+
+
+def test_torch_rng_stream_formulas():
+    """The two facts csrc/torch_rng.hip relies on, pinned against THIS torch build: exponential_ on a float32 CPU tensor is
+    float(-log1p(-u53)) of consecutive (hi, lo) mt19937 word pairs, uniform_(a, b) is the 24-bit mantissa formula, both
+    strictly sequential in the generator's output — for a tensor as large as one sampling step (2300 x 1024)."""
+    import numpy as np
+    n = 2300 * 1024
+    raw = _mt_raw(123, 2 * n + 2300)
+    torch.manual_seed(123)
+    x = torch.empty(2300, 1024).exponential_(1).reshape(-1).numpy()
+    r64 = (raw[0:2 * n:2] << np.uint64(32)) | raw[1:2 * n:2]
+    u = (r64 & np.uint64((1 << 53) - 1)).astype(np.float64) * 2.0 ** -53
+    assert np.array_equal(x, (-np.log1p(-u)).astype(np.float32))
+    y = torch.zeros(2300).uniform_(1e-20, 1).numpy()
+    r = raw[2 * n:2 * n + 2300]
+    emu = ((r & np.uint64((1 << 24) - 1)).astype(np.float32) * np.float32(2.0 ** -24)) * np.float32(1 - 1e-20) + np.float32(1e-20)
+    assert np.array_equal(y, emu)
+
+
+def test_torch_rng_state_parse_and_patch():
+    """torch.get_rng_state() layout used to hand the generator over to the device and back."""
+    import numpy as np
+    from vampnet_amd.torch_rng import parse_torch_rng_state, patch_torch_rng_state
+
+    def temper(y):
+        y = np.uint32(y)
+        y ^= y >> np.uint32(11)
+        y ^= (y << np.uint32(7)) & np.uint32(0x9d2c5680)
+        y ^= (y << np.uint32(15)) & np.uint32(0xefc60000)
+        y ^= y >> np.uint32(18)
+        return int(y)
+
+    torch.manual_seed(77)
+    state, pos = parse_torch_rng_state(torch.get_rng_state())
+    assert pos == 624 and state[0] == 77                              # freshly seeded: block exhausted, init_genrand(77)
+    _ = torch.empty(1000).exponential_()                              # 2000 words = 3 regenerations + 128
+    blob = torch.get_rng_state()
+    state, pos = parse_torch_rng_state(blob)
+    assert pos == 128
+    raw = _mt_raw(77, 2010)
+    assert [temper(state[pos + i]) for i in range(5)] == [int(v) for v in raw[2000:2005]]
+    # patch: move the position forward by 3 words == what drawing 3 more 32-bit randoms does
+    torch.set_rng_state(patch_torch_rng_state(blob, state, pos + 3))
+    nxt = torch.empty(2).uniform_(0, 1).numpy()                       # one word per element: (w & (2^24 - 1)) * 2^-24
+    want = [np.float32(int(raw[2003 + i]) & ((1 << 24) - 1)) * np.float32(2.0 ** -24) for i in range(2)]
+    assert nxt.tolist() == [float(w) for w in want]
+    # and a patched "block exhausted" position regenerates on the next draw
+    torch.set_rng_state(patch_torch_rng_state(blob, state, 624))
+    st2, pos2 = parse_torch_rng_state(torch.get_rng_state())
+    assert pos2 == 624 and np.array_equal(st2, state)

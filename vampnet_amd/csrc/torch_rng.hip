@@ -1,0 +1,114 @@
+// torch's CPU random stream on the device — seeded PARITY mode at device speed.
+//
+// The reference reseeds torch's global CPU generator (`seed=`, transformer.py:711-712) and then draws, per sampling step,
+// `multinomial(1)` (= one `exponential_` over (B*N, 1024)) and the Gumbel `uniform_(1e-20, 1)` over (B, N)
+// (transformer.py:28-30, :1024-1028, :1038-1074).  On the host those 2.4 M exponentials per item per step cost ≈ 57 ms
+// (0.7 s per clip).  Both distributions are plain functions of the sequential mt19937 stream of at::CPUGeneratorImpl:
+//   exponential_  (float tensor): r64 = (mt[2i] << 32) | mt[2i+1];  u = (r64 & (2^53-1)) * 2^-53;  x = float(-log1p(-u))   (double)
+//   uniform_(a,b) (float tensor): u = float(mt[i] & (2^24-1)) * 2^-24;  x = u * (b - a) + a                                   (float)
+// (pinned against torch on the host by tests/test_host_logic.py::test_torch_rng_stream_formulas and on the device by
+// tests/test_gpu_kernels.py::test_torch_rng_on_device).  So the engine can produce the SAME numbers from the generator's state:
+// one workgroup walks the mt19937 recurrence (624-word blocks, three parallel phases of 227 + the last word, double buffered
+// in LDS), tempering and the distribution transforms run at full width.  The host hands over the generator state before a
+// generate() call and takes the advanced state back afterwards, so torch's global generator ends where the reference's would.
+#include "vn_common.h"
+
+#define MT_N 624
+#define MT_M 397
+
+__device__ __forceinline__ uint32_t mt_twist(uint32_t u, uint32_t v) {
+    const uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
+    return (y >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+// state[624] + *pos (index of the next word to emit; 624 = block exhausted) -> n tempered outputs; state / pos advanced.
+// out may be NULL (advance only: another rank's rows of a sharded batch).
+__global__ __launch_bounds__(256) void vn_mt19937_kernel(uint32_t* __restrict__ state, int32_t* __restrict__ pos,
+                                                         uint32_t* __restrict__ out, long n) {
+    __shared__ uint32_t buf[2][MT_N + 8];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < MT_N; i += 256) buf[0][i] = state[i];
+    __syncthreads();
+    int cur = 0;
+    int p = *pos;
+    long done = 0;
+    while (done < n) {
+        if (p >= MT_N) {                 // next_state(): new[i] = new-or-old[i + 397 mod 624] ^ twist(old[i], old-or-new[i + 1])
+            const uint32_t* o = buf[cur];
+            uint32_t* w = buf[cur ^ 1];
+            if (tid < 227) w[tid] = o[tid + MT_M] ^ mt_twist(o[tid], o[tid + 1]);
+            __syncthreads();
+            if (tid < 227) w[227 + tid] = w[tid] ^ mt_twist(o[227 + tid], o[228 + tid]);
+            __syncthreads();
+            if (tid < 169) w[454 + tid] = w[227 + tid] ^ mt_twist(o[454 + tid], o[455 + tid]);      // i = 454 .. 622
+            __syncthreads();
+            if (tid == 0) w[623] = w[396] ^ mt_twist(o[623], w[0]);
+            __syncthreads();
+            cur ^= 1;
+            p = 0;
+        }
+        const long take = (long)(MT_N - p) < (n - done) ? (MT_N - p) : (n - done);
+        if (out)
+            for (int i = tid; i < take; i += 256) out[done + i] = mt_temper(buf[cur][p + i]);
+        p += (int)take;
+        done += take;
+        // (no barrier needed here: the next regen only reads buf[cur] / writes buf[cur^1], and every write above is to `out`)
+    }
+    __syncthreads();
+    for (int i = tid; i < MT_N; i += 256) state[i] = buf[cur][i];
+    if (tid == 0) *pos = p;
+}
+
+extern "C" int vn_mt19937_generate(vn_ctx* ctx, uint32_t* state624, int32_t* pos, uint32_t* out_raw, int64_t n, void* stream) {
+    if (!ctx || !state624 || !pos || n < 0) return VN_ERR_INVALID;
+    if (n == 0) return VN_OK;
+    hipLaunchKernelGGL(vn_mt19937_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, state624, pos, out_raw, (long)n);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// x[i] = float(-log1p(-u53(raw[2i], raw[2i+1])))          at::exponential_distribution<double> on a float tensor, lambda = 1
+__global__ __launch_bounds__(256) void vn_torch_exponential_kernel(const uint32_t* __restrict__ raw, float* __restrict__ out, long n) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        const uint2 r = ((const uint2*)raw)[i];
+        const unsigned long long r64 = ((unsigned long long)r.x << 32) | r.y;
+        const double u = (double)(r64 & ((1ULL << 53) - 1)) * 0x1.0p-53;
+        out[i] = (float)(-log1p(-u));
+    }
+}
+
+extern "C" int vn_torch_exponential_f32(vn_ctx* ctx, const uint32_t* raw, float* out, int64_t n, void* stream) {
+    if (!ctx || !raw || !out || n < 0) return VN_ERR_INVALID;
+    if (n == 0) return VN_OK;
+    const long nb = (n + 255) / 256;
+    hipLaunchKernelGGL(vn_torch_exponential_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, (hipStream_t)stream, raw,
+                       out, (long)n);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// x[i] = float(raw[i] & (2^24 - 1)) * 2^-24 * (hi - lo) + lo        at::uniform_real_distribution<float>
+__global__ __launch_bounds__(256) void vn_torch_uniform_kernel(const uint32_t* __restrict__ raw, float* __restrict__ out, long n,
+                                                               float lo, float hi) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        const float u = (float)(raw[i] & ((1u << 24) - 1)) * 0x1.0p-24f;
+        out[i] = u * (hi - lo) + lo;
+    }
+}
+
+extern "C" int vn_torch_uniform_f32(vn_ctx* ctx, const uint32_t* raw, float* out, int64_t n, float lo, float hi, void* stream) {
+    if (!ctx || !raw || !out || n < 0) return VN_ERR_INVALID;
+    if (n == 0) return VN_OK;
+    const long nb = (n + 255) / 256;
+    hipLaunchKernelGGL(vn_torch_uniform_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream, raw, out,
+                       (long)n, lo, hi);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}

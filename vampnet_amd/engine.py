@@ -53,6 +53,13 @@ class Engine:
     def version(self):
         return self.lib.vn_version().decode()
 
+    def torch_rng(self):
+        """Device-resident continuation of torch's CPU generator (rng="torch_device"), one per engine."""
+        if getattr(self, "_torch_rng", None) is None:
+            from .torch_rng import DeviceTorchRng
+            self._torch_rng = DeviceTorchRng(self)
+        return self._torch_rng
+
     def health_check(self):
         """Synchronise and raise if a stream-K GEMM ever gave up waiting for a partial tile (never expected)."""
         self.check(self.lib.vn_health_check(self.handle, self.stream()), "vn_health_check")
@@ -288,15 +295,19 @@ class VampNetModel:
             out.append(int(torch.floor(g * n0_t).long()))
         return out
 
-    def draw_noise(self, B, T, steps, sample_cutoff, batch_offset=0, local_batch=None, pin=True):
+    def draw_noise(self, B, T, steps, sample_cutoff, batch_offset=0, local_batch=None, pin=True, on_device=False):
         """Replays the reference's torch-CPU draw order: per step an Exp(1) tensor of shape
         (B*T*Cp, V) iff that step samples (multinomial), then U(1e-20, 1) of shape (B, T*Cp).  B is the GLOBAL
         batch; when this rank owns items [batch_offset, batch_offset + local_batch) only those rows are kept
-        (every rank draws the identical global stream)."""
+        (every rank draws the identical global stream).  `on_device`: the same numbers produced on the
+        GPU by continuing torch's mt19937 stream there (vampnet_amd/torch_rng.py) instead of drawing them on the host."""
         N = T * self.n_predict_codebooks
         V = self.vocab_size
         nb = B if local_batch is None else local_batch
         b0 = batch_offset
+        if on_device:
+            from .torch_rng import draw_noise_device
+            return draw_noise_device(self.engine.torch_rng(), B, N, V, steps, sample_cutoff, b0, nb)
         return draw_noise_host(B, N, V, steps, sample_cutoff, b0, nb, pin)
 
     @torch.inference_mode()
@@ -309,6 +320,8 @@ class VampNetModel:
                  global_batch: int = None, batch_offset: int = 0, noise=None, call_batch: int = None):
         """Drop-in for VampNet.generate (transformer.py:686-946).  Extra keywords (not in the reference):
           rng="torch"  : parity mode — noise is drawn from torch's CPU generator in the reference's order;
+          rng="torch_device" : the same stream, continued on the GPU (mt19937 + the two distribution transforms run in
+                         HIP; torch's generator is advanced as if the host had drawn): seed-exact at device speed;
           rng="device" : fast mode — Philox stream on the GPU (seeded by `device_seed` or the torch generator);
           n0_override  : the global batch's masked-token count when this call sees a shard (SURVEY.md §8(e));
           global_batch / batch_offset : size of the global batch and index of this shard's first item, so that
@@ -348,11 +361,12 @@ class VampNetModel:
             n0_items = [n0] * B
         per_n0 = {v: self.mask_schedule(steps, v) for v in set(n0_items)}
         sched = (C.c_int64 * (steps * B))(*[per_n0[n0_items[b]][i] for i in range(steps) for b in range(B)])
-        if rng == "torch":
+        if rng in ("torch", "torch_device"):
             if noise is not None:
                 exp, unif = noise                                  # pre-drawn ledger [steps, B*N, V], [steps, B, N]
             else:
-                exp, unif = self.draw_noise(global_batch or B, T, steps, sample_cutoff, batch_offset, B)
+                exp, unif = self.draw_noise(global_batch or B, T, steps, sample_cutoff, batch_offset, B,
+                                            on_device=(rng == "torch_device"))
             exp = exp.to(self.device, non_blocking=True)
             unif = unif.to(self.device, non_blocking=True)
             exp_p, unif_p = exp.data_ptr(), unif.data_ptr()
@@ -362,7 +376,7 @@ class VampNetModel:
             exp_p = unif_p = None
             dseed = device_seed if device_seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
         else:
-            raise ValueError("rng must be 'torch' or 'device'")
+            raise ValueError("rng must be 'torch', 'torch_device' or 'device'")
         params = self._params(steps, temperature, mask_temperature, sample_cutoff, top_p, n0, dseed, batch_offset,
                               call_batch or 0, (global_batch or 0) if call_batch else 0)
         out = torch.empty_like(z)

@@ -280,18 +280,20 @@ class Interface:
                 mk[:, :model.n_conditioning_codebooks, :] = 0
             n0 = int(((mk != 0) | (st == model.mask_token)).sum().item())              # GLOBAL batch of this call
             n0s += [n0] * nb
-            if rng == "torch":
-                e, u = model.draw_noise(Bg, st.shape[-1], steps, cutoff, b0, nb, pin=False)
+            if rng in ("torch", "torch_device"):
+                e, u = model.draw_noise(Bg, st.shape[-1], steps, cutoff, b0, nb, pin=False, **(
+                    {"on_device": True} if rng == "torch_device" else {}))
                 exps.append(e)
                 unifs.append(u)
             zs.append(st[b0:b1])
             ms.append(mk[b0:b1])
         noise = None
-        if rng == "torch":
+        if rng in ("torch", "torch_device"):
             N = unifs[0].shape[-1]
             exp = torch.stack([e.view(steps, nb, N, -1) for e in exps], dim=1).reshape(steps, nC * nb * N, -1)
             unif = torch.stack(unifs, dim=1).reshape(steps, nC * nb, N)
-            noise = (exp.pin_memory(), unif.pin_memory()) if torch.cuda.is_available() else (exp, unif)
+            pin = torch.cuda.is_available() and not exp.is_cuda
+            noise = (exp.pin_memory(), unif.pin_memory()) if pin else (exp, unif)
         elif dseed is not None:
             dseed = (int(dseed) * 0x9E3779B97F4A7C15 + self._call_idx) & (2 ** 64 - 1)
             self._call_idx += nC

@@ -1,0 +1,117 @@
+"""torch's global CPU generator, continued on the GPU (seeded parity mode at device speed).
+
+`rng="torch"` replays the reference's noise by drawing it with torch on the host (0.7 s per clip: 2.4 M `exponential_`
+samples per item per sampling step).  at::CPUGeneratorImpl is an mt19937 whose state torch exposes
+(`torch.get_rng_state()`), and both distributions the sampling loop uses are simple functions of its sequential output
+(vampnet_amd/csrc/torch_rng.hip), so the engine can continue the SAME stream on the device: the state is handed over
+before a `generate()` call and the advanced state is written back afterwards — torch's generator ends exactly where
+the reference's would, and later host-side draws (e.g. the next `build_mask`) see the reference's stream.
+
+State blob layout (legacy THGeneratorState inside CPUGeneratorImplState, 5056 bytes, verified in tests):
+  u64 seed | i32 left | i32 seeded | u64 next | u64 state[624] | normal-distribution cache (40 bytes, untouched here)
+at::mt19937 emits state[next++] after `if (--left == 0) next_state()`, i.e. left == 625 - next, "block exhausted" is
+(left, next) = (1, 624) or, right after seeding, (1, 0).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+_STATE_OFF, _N = 24, 624
+
+
+def parse_torch_rng_state(blob: torch.Tensor):
+    """-> (state uint32[624], pos) with pos = index of the next word to emit, 624 = regenerate first."""
+    b = blob.cpu().numpy()
+    if b.size != 5056:
+        raise ValueError(f"unexpected torch CPU RNG state size {b.size} (torch build with a different generator layout)")
+    left = int(b[8:12].view(np.int32)[0])
+    nxt = int(b[16:24].view(np.uint64)[0])
+    state = b[_STATE_OFF:_STATE_OFF + _N * 8].view(np.uint64).astype(np.uint32)
+    pos = _N if left == 1 else nxt
+    if left != 1 and left != _N + 1 - nxt:
+        raise ValueError(f"inconsistent mt19937 state: left={left}, next={nxt}")
+    return state, pos
+
+
+def patch_torch_rng_state(blob: torch.Tensor, state: np.ndarray, pos: int) -> torch.Tensor:
+    """Inverse of parse_torch_rng_state on a copy of `blob` (seed, normal cache untouched)."""
+    b = blob.cpu().numpy().copy()
+    b[8:12].view(np.int32)[0] = _N + 1 - pos
+    b[16:24].view(np.uint64)[0] = pos
+    b[_STATE_OFF:_STATE_OFF + _N * 8].view(np.uint64)[:] = state.astype(np.uint64)
+    return torch.from_numpy(b)
+
+
+class DeviceTorchRng:
+    """mt19937 state of torch's default CPU generator living in device memory between load_from_torch / store_to_torch."""
+
+    def __init__(self, engine):
+        self.engine, self.lib = engine, engine.lib
+        dev = engine.device
+        self.state = torch.zeros(_N, dtype=torch.int32, device=dev)       # uint32 bit patterns
+        self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._raw = None
+        self._blob = None
+
+    def _scratch(self, n_words):
+        if self._raw is None or self._raw.numel() < n_words:
+            self._raw = torch.empty(n_words, dtype=torch.int32, device=self.engine.device)
+        return self._raw
+
+    def load_from_torch(self):
+        self._blob = torch.get_rng_state()
+        state, pos = parse_torch_rng_state(self._blob)
+        self.state.copy_(torch.from_numpy(state.view(np.int32)))
+        self.pos.fill_(pos)
+
+    def store_to_torch(self):
+        """Synchronises, then advances torch's generator to where the device stream stands."""
+        state = self.state.cpu().numpy().view(np.uint32)
+        pos = int(self.pos.item())
+        torch.set_rng_state(patch_torch_rng_state(self._blob, state, pos))
+
+    def _gen(self, raw_ptr, n):
+        self.engine.check(self.lib.vn_mt19937_generate(self.engine.handle, self.state.data_ptr(), self.pos.data_ptr(), raw_ptr, n,
+                                                       self.engine.stream()), "vn_mt19937_generate")
+
+    def skip(self, n_words: int):
+        if n_words > 0:
+            self._gen(None, n_words)
+
+    def exponential_(self, out: torch.Tensor):
+        """out.exponential_(1) of a contiguous float32 tensor, from the device-resident stream (2 words per element)."""
+        n = out.numel()
+        raw = self._scratch(2 * n)
+        self._gen(raw.data_ptr(), 2 * n)
+        self.engine.check(self.lib.vn_torch_exponential_f32(self.engine.handle, raw.data_ptr(), out.data_ptr(), n,
+                                                            self.engine.stream()), "vn_torch_exponential_f32")
+        return out
+
+    def uniform_(self, out: torch.Tensor, lo: float, hi: float):
+        n = out.numel()
+        raw = self._scratch(n)
+        self._gen(raw.data_ptr(), n)
+        self.engine.check(self.lib.vn_torch_uniform_f32(self.engine.handle, raw.data_ptr(), out.data_ptr(), n, lo, hi,
+                                                        self.engine.stream()), "vn_torch_uniform_f32")
+        return out
+
+
+def draw_noise_device(rng: DeviceTorchRng, B, N, V, steps, sample_cutoff, b0=0, nb=None):
+    """Device twin of engine.draw_noise_host: the same ledger (exp [steps, nb*N, V], zeros on non-sampling steps; unif
+    [steps, nb, N]) for items [b0, b0+nb) of a global batch B, produced from — and advancing — torch's CPU generator."""
+    nb = B if nb is None else nb
+    dev = rng.engine.device
+    exp = torch.zeros(steps, nb * N, V, dtype=torch.float32, device=dev)
+    unif = torch.empty(steps, nb, N, dtype=torch.float32, device=dev)
+    rng.load_from_torch()
+    for i in range(steps):
+        if (i / steps) <= sample_cutoff:                      # transformer.py:852-855
+            rng.skip(2 * b0 * N * V)
+            rng.exponential_(exp[i])
+            rng.skip(2 * (B - b0 - nb) * N * V)
+        rng.skip(b0 * N)
+        rng.uniform_(unif[i], 1e-20, 1.0)
+        rng.skip((B - b0 - nb) * N)
+    rng.store_to_torch()
+    return exp, unif
