@@ -98,6 +98,9 @@ typedef struct {
                                     into this launch (item i belongs to call i / call_batch); 0 = B */
     int32_t global_batch;        /* global batch size of one call; 0 = call_batch.  Device-RNG item id =
                                     (i / call_batch) * global_batch + batch_offset + i % call_batch  */
+    void* const* step_events;    /* NULL, or `steps` hipEvent_t handles: before the sampling kernels of step i read the
+                                    caller-supplied noise, the stream waits for step_events[i] (noise for later steps may
+                                    still be in production on another stream while earlier steps run)                 */
 } vn_sample_params;
 
 /* ---- context ------------------------------------------------------------------------------

@@ -22,7 +22,7 @@ class vn_sample_params(C.Structure):
     _fields_ = [("steps", C.c_int32), ("temperature", C.c_float), ("mask_temperature", C.c_float),
                 ("sample_cutoff", C.c_double), ("top_p", C.c_float), ("n0_override", C.c_int64),
                 ("seed", C.c_uint64), ("batch_offset", C.c_int64), ("call_batch", C.c_int32),
-                ("global_batch", C.c_int32)]
+                ("global_batch", C.c_int32), ("step_events", C.POINTER(C.c_void_p))]
 
 
 class vn_train_params(C.Structure):

@@ -497,6 +497,7 @@ extern "C" int vn_generate(vn_model* m, const int64_t* start_tokens, const int64
         if ((rc = forward_loop(m, B, T, s))) return rc;
         const float* en = exp_noise ? exp_noise + (size_t)i * B * N * V : nullptr;
         const float* un = unif_noise ? unif_noise + (size_t)i * B * N : nullptr;
+        if (p->step_events && p->step_events[i]) VN_HIP_CHECK(ctx, hipStreamWaitEvent(s, (hipEvent_t)p->step_events[i], 0));
         if ((rc = sample_step(m, B, T, i, p, m->ksched + (size_t)i * B, m->logits, en, un, i == p->steps - 1, s))) return rc;
     }
     return vn_launch_i32_to_i64(ctx, m->z_sampled, out_tokens, n, s);                   // transformer.py:935-946

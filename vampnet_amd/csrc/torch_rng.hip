@@ -8,8 +8,8 @@
 //   uniform_(a,b) (float tensor): u = float(mt[i] & (2^24-1)) * 2^-24;  x = u * (b - a) + a                                   (float)
 // (pinned against torch on the host by tests/test_host_logic.py::test_torch_rng_stream_formulas and on the device by
 // tests/test_gpu_kernels.py::test_torch_rng_on_device).  So the engine can produce the SAME numbers from the generator's state:
-// one workgroup walks the mt19937 recurrence (624-word blocks, three parallel phases of 227 + the last word, double buffered
-// in LDS), tempering and the distribution transforms run at full width.  The host hands over the generator state before a
+// one workgroup walks the mt19937 recurrence (624-word blocks; thread t owns words t, 227+t, 454+t, whose updates chain through
+// its own registers: one barrier per block, double buffered in LDS), tempering and the distribution transforms run at full width.  The host hands over the generator state before a
 // generate() call and takes the advanced state back afterwards, so torch's global generator ends where the reference's would.
 #include "vn_common.h"
 
@@ -39,29 +39,46 @@ __global__ __launch_bounds__(256) void vn_mt19937_kernel(uint32_t* __restrict__ 
     int cur = 0;
     int p = *pos;
     long done = 0;
-    while (done < n) {
-        if (p >= MT_N) {                 // next_state(): new[i] = new-or-old[i + 397 mod 624] ^ twist(old[i], old-or-new[i + 1])
-            const uint32_t* o = buf[cur];
-            uint32_t* w = buf[cur ^ 1];
-            if (tid < 227) w[tid] = o[tid + MT_M] ^ mt_twist(o[tid], o[tid + 1]);
-            __syncthreads();
-            if (tid < 227) w[227 + tid] = w[tid] ^ mt_twist(o[227 + tid], o[228 + tid]);
-            __syncthreads();
-            if (tid < 169) w[454 + tid] = w[227 + tid] ^ mt_twist(o[454 + tid], o[455 + tid]);      // i = 454 .. 622
-            __syncthreads();
-            if (tid == 0) w[623] = w[396] ^ mt_twist(o[623], w[0]);
-            __syncthreads();
-            cur ^= 1;
-            p = 0;
-        }
-        const long take = (long)(MT_N - p) < (n - done) ? (MT_N - p) : (n - done);
+    if (p < MT_N && n > 0) {             // rest of the block the generator was in
+        const long take = (long)(MT_N - p) < n ? (MT_N - p) : n;
         if (out)
-            for (int i = tid; i < take; i += 256) out[done + i] = mt_temper(buf[cur][p + i]);
+            for (int i = tid; i < take; i += 256) out[i] = mt_temper(buf[0][p + i]);
         p += (int)take;
-        done += take;
-        // (no barrier needed here: the next regen only reads buf[cur] / writes buf[cur^1], and every write above is to `out`)
+        done = take;
     }
-    __syncthreads();
+    // whole blocks: next_state().  new[i] = X[(i + 397) mod 624] ^ twist(old[i], Y[i + 1]) where X / Y are NEW words once the index
+    // wraps.  Thread t < 227 owns words t, 227 + t, 454 + t: new[227 + t] needs new[t] and new[454 + t] needs new[227 + t] — its OWN
+    // results — so the three "phases" chain through registers; the only foreign new word is new[0] for word 623, which its owner
+    // (thread 169) recomputes.  One barrier per 624 words; every word is tempered and emitted by the thread that made it.
+    while (done < n) {
+        const int take = (n - done) < MT_N ? (int)(n - done) : MT_N;
+        const uint32_t* o = buf[cur];
+        uint32_t* w = buf[cur ^ 1];
+        uint32_t* dst = out ? out + done : nullptr;
+        if (tid < 227) {
+            const uint32_t a0 = o[tid], a1 = o[tid + 1], am = o[tid + MT_M];
+            const uint32_t b0 = o[227 + tid], b1 = o[228 + tid];
+            const uint32_t v0 = am ^ mt_twist(a0, a1);
+            const uint32_t v1 = v0 ^ mt_twist(b0, b1);
+            w[tid] = v0;
+            w[227 + tid] = v1;
+            if (dst && tid < take) dst[tid] = mt_temper(v0);
+            if (dst && 227 + tid < take) dst[227 + tid] = mt_temper(v1);
+            if (tid < 170) {                               // words 454 .. 623
+                const uint32_t c0 = o[454 + tid];
+                uint32_t c1;
+                if (tid < 169) c1 = o[455 + tid];
+                else c1 = o[MT_M] ^ mt_twist(o[0], o[1]);  // new[0], recomputed by the owner of word 623
+                const uint32_t v2 = v1 ^ mt_twist(c0, c1);
+                w[454 + tid] = v2;
+                if (dst && 454 + tid < take) dst[454 + tid] = mt_temper(v2);
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+        p = take;
+        done += take;
+    }
     for (int i = tid; i < MT_N; i += 256) state[i] = buf[cur][i];
     if (tid == 0) *pos = p;
 }

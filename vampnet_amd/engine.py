@@ -281,7 +281,7 @@ class VampNetModel:
         return vn_sample_params(int(steps), float(temperature), float(mask_temperature), float(sample_cutoff),
                                 float(top_p) if top_p is not None else 0.0,
                                 int(n0_override) if n0_override is not None else -1,
-                                int(seed) & 0xFFFFFFFFFFFFFFFF, int(batch_offset), int(call_batch), int(global_batch))
+                                int(seed) & 0xFFFFFFFFFFFFFFFF, int(batch_offset), int(call_batch), int(global_batch), None)
 
     @staticmethod
     def mask_schedule(steps: int, n0: int):
@@ -361,12 +361,19 @@ class VampNetModel:
             n0_items = [n0] * B
         per_n0 = {v: self.mask_schedule(steps, v) for v in set(n0_items)}
         sched = (C.c_int64 * (steps * B))(*[per_n0[n0_items[b]][i] for i in range(steps) for b in range(B)])
+        step_events = None
         if rng in ("torch", "torch_device"):
             if noise is not None:
                 exp, unif = noise                                  # pre-drawn ledger [steps, B*N, V], [steps, B, N]
+            elif rng == "torch_device":
+                # produce the ledger on a side stream, step by step, and let the sampling loop wait per step: the serial
+                # mt19937 walk (one CU) runs underneath the transformer forward of the earlier steps
+                from .torch_rng import draw_noise_device
+                exp, unif, step_events = draw_noise_device(self.engine.torch_rng(), global_batch or B,
+                                                           T * self.n_predict_codebooks, self.vocab_size, steps, sample_cutoff,
+                                                           batch_offset, B, overlap=True)
             else:
-                exp, unif = self.draw_noise(global_batch or B, T, steps, sample_cutoff, batch_offset, B,
-                                            on_device=(rng == "torch_device"))
+                exp, unif = self.draw_noise(global_batch or B, T, steps, sample_cutoff, batch_offset, B)
             exp = exp.to(self.device, non_blocking=True)
             unif = unif.to(self.device, non_blocking=True)
             exp_p, unif_p = exp.data_ptr(), unif.data_ptr()
@@ -379,10 +386,15 @@ class VampNetModel:
             raise ValueError("rng must be 'torch', 'torch_device' or 'device'")
         params = self._params(steps, temperature, mask_temperature, sample_cutoff, top_p, n0, dseed, batch_offset,
                               call_batch or 0, (global_batch or 0) if call_batch else 0)
+        if step_events is not None:
+            ev_arr = (C.c_void_p * steps)(*[C.c_void_p(e.cuda_event) for e in step_events])
+            params.step_events = C.cast(ev_arr, C.POINTER(C.c_void_p))
         out = torch.empty_like(z)
         self.engine.check(self.lib.vn_generate(self.handle, z.data_ptr(), mask.data_ptr(), B, T, C.byref(params),
                                                sched, exp_p, unif_p, out.data_ptr(), self.engine.stream()),
                           "vn_generate")
+        if step_events is not None:
+            self.engine.torch_rng().store_to_torch()        # waits for the side stream only; the model keeps running
         if exp is not None:      # keep the noise alive until the enqueued work has consumed it
             torch.cuda.current_stream(self.device).synchronize()
         return out

@@ -65,10 +65,22 @@ class DeviceTorchRng:
         self.state.copy_(torch.from_numpy(state.view(np.int32)))
         self.pos.fill_(pos)
 
+    def side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(self.engine.device)
+        return self._side
+
     def store_to_torch(self):
-        """Synchronises, then advances torch's generator to where the device stream stands."""
-        state = self.state.cpu().numpy().view(np.uint32)
-        pos = int(self.pos.item())
+        """Synchronises with the stream that produced the noise, then advances torch's generator to where the device
+        stream stands."""
+        side = getattr(self, "_side", None)
+        if side is not None:        # download on the producing stream: the caller's stream may hold a long generate() queue
+            with torch.cuda.stream(side):
+                state = self.state.cpu().numpy().view(np.uint32)
+                pos = int(self.pos.item())
+        else:
+            state = self.state.cpu().numpy().view(np.uint32)
+            pos = int(self.pos.item())
         torch.set_rng_state(patch_torch_rng_state(self._blob, state, pos))
 
     def _gen(self, raw_ptr, n):
@@ -97,21 +109,40 @@ class DeviceTorchRng:
         return out
 
 
-def draw_noise_device(rng: DeviceTorchRng, B, N, V, steps, sample_cutoff, b0=0, nb=None):
+def draw_noise_device(rng: DeviceTorchRng, B, N, V, steps, sample_cutoff, b0=0, nb=None, overlap=False):
     """Device twin of engine.draw_noise_host: the same ledger (exp [steps, nb*N, V], zeros on non-sampling steps; unif
-    [steps, nb, N]) for items [b0, b0+nb) of a global batch B, produced from — and advancing — torch's CPU generator."""
+    [steps, nb, N]) for items [b0, b0+nb) of a global batch B, produced from — and advancing — torch's CPU generator.
+
+    overlap=False: produced on the current stream, torch's generator updated before returning -> (exp, unif).
+    overlap=True : produced on the rng's side stream with one event per step -> (exp, unif, events); the caller makes its
+    consumer wait on events[i] and calls rng.store_to_torch() AFTER enqueueing its own work."""
     nb = B if nb is None else nb
     dev = rng.engine.device
-    exp = torch.zeros(steps, nb * N, V, dtype=torch.float32, device=dev)
-    unif = torch.empty(steps, nb, N, dtype=torch.float32, device=dev)
-    rng.load_from_torch()
-    for i in range(steps):
-        if (i / steps) <= sample_cutoff:                      # transformer.py:852-855
-            rng.skip(2 * b0 * N * V)
-            rng.exponential_(exp[i])
-            rng.skip(2 * (B - b0 - nb) * N * V)
-        rng.skip(b0 * N)
-        rng.uniform_(unif[i], 1e-20, 1.0)
-        rng.skip((B - b0 - nb) * N)
-    rng.store_to_torch()
+    cur = torch.cuda.current_stream(dev)
+    side = rng.side_stream() if overlap else cur
+    if overlap:
+        side.wait_stream(cur)
+    events = []
+    with torch.cuda.stream(side):
+        exp = torch.zeros(steps, nb * N, V, dtype=torch.float32, device=dev)
+        unif = torch.empty(steps, nb, N, dtype=torch.float32, device=dev)
+        rng.load_from_torch()
+        for i in range(steps):
+            if (i / steps) <= sample_cutoff:                      # transformer.py:852-855
+                rng.skip(2 * b0 * N * V)
+                rng.exponential_(exp[i])
+                rng.skip(2 * (B - b0 - nb) * N * V)
+            rng.skip(b0 * N)
+            rng.uniform_(unif[i], 1e-20, 1.0)
+            rng.skip((B - b0 - nb) * N)
+            if overlap:
+                ev = torch.cuda.Event()
+                ev.record(side)
+                events.append(ev)
+        if not overlap:
+            rng.store_to_torch()
+    if overlap:
+        exp.record_stream(cur)
+        unif.record_stream(cur)
+        return exp, unif, events
     return exp, unif
