@@ -242,7 +242,7 @@ def test_torch_rng_on_device(eng):
     (2300 x 1024, then 2300) are bit-identical to what torch draws on the host, across block boundaries and across two
     consecutive hand-overs; skipping words equals drawing and discarding; torch's generator ends in the same state."""
     from vampnet_amd.torch_rng import DeviceTorchRng
-    rng = DeviceTorchRng(eng)
+    rng = DeviceTorchRng(eng)                                # direct use: everything on the current stream
     torch.manual_seed(4242)
     _ = torch.rand(37)                                       # start mid-block
     blob = torch.get_rng_state()

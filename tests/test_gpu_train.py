@@ -341,7 +341,10 @@ def test_checkpoint_resume_and_interface_load(engine, tmp_path, only_lora):
     assert torch.equal(tr2.loss, want_loss)
     got = tr2.state_dict()
     for k, v in want.items():
-        assert torch.equal(got[k], v), k
+        if k.endswith("relative_attention_bias.weight"):      # its gradient is accumulated with float atomics
+            assert (got[k] - v).abs().max().item() < 1e-6, k
+        else:
+            assert torch.equal(got[k], v), k
 
     # the optimizer file is a torch.optim.AdamW state_dict over the same parameter list
     import os

@@ -60,6 +60,8 @@ class DeviceTorchRng:
         return self._raw
 
     def load_from_torch(self):
+        if getattr(self, "_producer", None) is None:
+            self._producer = torch.cuda.current_stream(self.engine.device)
         self._blob = torch.get_rng_state()
         state, pos = parse_torch_rng_state(self._blob)
         self.state.copy_(torch.from_numpy(state.view(np.int32)))
@@ -73,12 +75,11 @@ class DeviceTorchRng:
     def store_to_torch(self):
         """Synchronises with the stream that produced the noise, then advances torch's generator to where the device
         stream stands."""
-        side = getattr(self, "_side", None)
-        if side is not None:        # download on the producing stream: the caller's stream may hold a long generate() queue
-            with torch.cuda.stream(side):
-                state = self.state.cpu().numpy().view(np.uint32)
-                pos = int(self.pos.item())
-        else:
+        # download on the stream that PRODUCED the noise (set by draw_noise_device): in overlap mode that is the side stream —
+        # the caller's stream may hold a long generate() queue — otherwise the current stream; a synchronous copy on any other
+        # stream would read the state before the mt19937 kernels have advanced it
+        prod = getattr(self, "_producer", None) or torch.cuda.current_stream(self.engine.device)
+        with torch.cuda.stream(prod):
             state = self.state.cpu().numpy().view(np.uint32)
             pos = int(self.pos.item())
         torch.set_rng_state(patch_torch_rng_state(self._blob, state, pos))
@@ -123,6 +124,7 @@ def draw_noise_device(rng: DeviceTorchRng, B, N, V, steps, sample_cutoff, b0=0, 
     if overlap:
         side.wait_stream(cur)
     events = []
+    rng._producer = side
     with torch.cuda.stream(side):
         exp = torch.zeros(steps, nb * N, V, dtype=torch.float32, device=dev)
         unif = torch.empty(steps, nb, N, dtype=torch.float32, device=dev)
