@@ -312,7 +312,7 @@ int  vn_dropout_keep_mask(vn_ctx* ctx, uint64_t seed, int64_t step, int layer, i
 
 /* Training attention as a single op (tests / tuning): forward with probability dropout (keep-mask = site 0, layer 0,
  * step 1 of vn_dropout_keep_mask) writing out [B][T][H*64] and lse [B][H][T]; when `dout` is non-NULL also the backward:
- * dqkv [B*T][3*H*64] (dq | dk | dv, head-major inside each third) and dbias [num_buckets][H] ACCUMULATED into.
+ * dqkv [B*T][3*H*64] (dq | dk | dv, head-major inside each third) and dbias [num_buckets][H] ACCUMULATED into (fixed order).
  * Synchronous.  (transformer.py:234-254 and its autograd.)                                                          */
 int  vn_attention_train_f32(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
                             float* out, float* lse, const float* dout, float* dqkv, float* dbias, int B, int H, int T,

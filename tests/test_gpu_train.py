@@ -170,12 +170,8 @@ def test_train_step_is_deterministic_and_shard_invariant(engine):
     ga = tr.grads.clone()
     b = tr.forward_backward(z_mask, target).clone()
     assert torch.equal(a, b)
-    # every gradient except the atomically-accumulated relative-position table is bitwise reproducible
-    from vampnet_amd import _lib
-    rb = tr._tensor(tr.grads, _lib.W_REL_BIAS)
-    rb_a = tr._tensor(ga, _lib.W_REL_BIAS)
-    assert (rb - rb_a).abs().max().item() <= 1e-5 * rb_a.abs().max().item()
-    rb.copy_(rb_a)
+    # every gradient is bitwise reproducible run to run — including the shared relative-position table, whose gradient is
+    # reduced through per-wave tables and per-block slots in a fixed order (no floating-point atomics in the step)
     assert torch.equal(ga, tr.grads)
     full = tr.dropout_keep_mask(1, "attn", 2, 32)
     tr2 = _trainer(engine, dims, sd, cb, max_batch=1, max_T=32, dropout=0.1, seed=5, batch_offset=1)
@@ -341,10 +337,7 @@ def test_checkpoint_resume_and_interface_load(engine, tmp_path, only_lora):
     assert torch.equal(tr2.loss, want_loss)
     got = tr2.state_dict()
     for k, v in want.items():
-        if k.endswith("relative_attention_bias.weight"):      # its gradient is accumulated with float atomics
-            assert (got[k] - v).abs().max().item() < 1e-6, k
-        else:
-            assert torch.equal(got[k], v), k
+        assert torch.equal(got[k], v), k
 
     # the optimizer file is a torch.optim.AdamW state_dict over the same parameter list
     import os
@@ -405,9 +398,6 @@ def test_staged_backward_with_overlapped_allreduce(engine):
         a = tr.forward_backward_overlapped(z_mask, target).clone()
         b = ref.forward_backward(z_mask, target).clone()
         assert torch.equal(a, b)
-        rb, rb_ref = tr._tensor(tr.grads, _lib.W_REL_BIAS), ref._tensor(ref.grads, _lib.W_REL_BIAS)
-        assert (rb - rb_ref).abs().max().item() <= 1e-5 * rb_ref.abs().max().item()     # float atomics
-        rb.copy_(rb_ref)
         assert torch.equal(tr.grads, ref.grads)
         for _ in range(2):                                   # whole steps through the overlapped path
             o1 = tr.step(z, mask=mask)

@@ -11,7 +11,7 @@
 //   dq kernel : block = (64 queries, h, b), wave owns 16 queries (lane-local j = query), loops over key tiles;
 //               S^T[key][q] = K.Q^T and dP^T[key][q] = V.dO^T (A = K / V tile in LDS, B = Q / dO fragments in registers),
 //               dQ^T[d][q] += K^T[d][key] . dS^T[key][q]; also delta (written for the dk/dv kernel) and the bias gradient
-//               (LDS table over key-query, bucketed once per block, 32 global atomics per block).
+//               (per-wave LDS tables over key-query, bucketed once per block into the block's own slot: no atomics).
 //   dkv kernel: block = (64 keys, h, b), wave owns 16 keys (lane-local j = key), loops over query tiles;
 //               S[q][key] = Q.K^T and dP[q][key] = dO.V^T (A = Q / dO tile in LDS, B = K / V fragments in registers),
 //               dV^T[d][key] += dO^T[d][q] . Pd[q][key] ; dK^T[d][key] += Q^T[d][q] . dS[q][key].
@@ -175,16 +175,16 @@ __global__ __launch_bounds__(256) void vn_attention_train_fwd_kernel(const float
 __global__ __launch_bounds__(256) void vn_attention_bwd_dq_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, const float* __restrict__ bias_full,
     const int32_t* __restrict__ lut, const float* __restrict__ out, const float* __restrict__ dout,
-    const float* __restrict__ lse, float* __restrict__ delta, float* __restrict__ dqkv, float* __restrict__ dbias_tab, int B,
+    const float* __restrict__ lse, float* __restrict__ delta, float* __restrict__ dqkv, float* __restrict__ dbias_partial, int B,
     int H, int T, int nbuckets, vn_drop d) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;
     float* Vs = Ks + ATT_KT * ATT_LD;
     const int nb = 2 * T - 1;
     float* bt = Vs + ATT_KT * ATT_LD;
-    float* dbt = bt + nb;
-    float* bk = dbt + nb;           // [64] bucket sums
-    float* wscr_all = bk + 64;      // [4 waves][16 queries][80]: per-wave dS scratch for the diagonal sums
+    float* dbt_all = bt + nb;       // [4 waves][nb]: PER-WAVE d(bias) tables over key - query (plain += : run-to-run bitwise)
+    float* bk_all = dbt_all + 4 * nb;   // [4 waves][64]: per-wave sums of the single-bucket ("far") tiles
+    float* wscr_all = bk_all + 256; // [4 waves][16 queries][80]: per-wave dS scratch for the diagonal sums
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
@@ -196,10 +196,12 @@ __global__ __launch_bounds__(256) void vn_attention_bwd_dq_kernel(
     const float* V = v + headoff;
     const int qrow = qb * 64 + wave * 16 + j;
     const int qrow_c = qrow < T ? qrow : T - 1;
-    for (int i = tid; i < nb; i += 256) { bt[i] = bias_full[(size_t)h * nb + i]; dbt[i] = 0.f; }
-    if (tid < 64) bk[tid] = 0.f;
+    for (int i = tid; i < nb; i += 256) bt[i] = bias_full[(size_t)h * nb + i];
+    for (int i = tid; i < 4 * nb + 256; i += 256) dbt_all[i] = 0.f;      // the four tables and, contiguous, the far sums
     for (int i = tid; i < 4 * 16 * 80; i += 256) wscr_all[i] = 0.f;      // slots outside the tile's diagonals stay 0
     float* wscr = wscr_all + wave * (16 * 80);
+    float* dbt = dbt_all + wave * nb;
+    float* bk = bk_all + wave * 64;
 
     f32x4 qf[4], dof[4];
     float dl = 0.f;
@@ -275,9 +277,9 @@ __global__ __launch_bounds__(256) void vn_attention_bwd_dq_kernel(
                 }
         }
         // dS^T for this lane's query and keys kt*64 + 16u + 4g + r.
-        // Bias gradient: a tile whose whole key-query range falls into ONE bucket (every tile 3+ tiles off the diagonal
-        // at max_distance 128) is summed in a register and costs one LDS atomic per wave; only near-diagonal tiles pay
-        // per-element LDS atomics into the key-query table.
+        // Bias gradient, without any floating-point atomic (deterministic): a tile whose whole key-query range falls into ONE
+        // bucket (every tile 3+ tiles off the diagonal at max_distance 128) is summed in registers into the wave's far-sum
+        // slot; near-diagonal tiles add their 79 diagonal sums to the WAVE's own key-query table.
         const int rel_lo = kt * ATT_KT - (qb * 64 + 63), rel_hi = kt * ATT_KT + 63 - qb * 64;
         const int lo_c = rel_lo < -(T - 1) ? -(T - 1) : rel_lo, hi_c = rel_hi > T - 1 ? T - 1 : rel_hi;
         const int far_bucket = lut[lo_c + T - 1];
@@ -303,12 +305,12 @@ __global__ __launch_bounds__(256) void vn_attention_bwd_dq_kernel(
         if (far) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) far_sum += __shfl_xor(far_sum, o);
-            if (lane == 0) atomicAdd(&bk[far_bucket], far_sum);
+            if (lane == 0) bk[far_bucket] += far_sum;
         } else {
             // near-diagonal tile: the wave's 64 keys x 16 queries of dS go through a private LDS scratch laid out
             // [query j][diagonal i - j + 15] (row stride 80: conflict-free both ways), each lane then sums one (two)
-            // of the 79 diagonals with plain reads and issues ONE table update for it, instead of 16 LDS float
-            // atomics per lane (ds_add_f32 costs ~175 cycles per wave instruction on gfx950, measured).
+            // of the 79 diagonals with plain reads and makes ONE table update for it (16 LDS float atomics per lane cost
+            // ~175 cycles per wave instruction on gfx950, measured, and are order-dependent).
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256) void vn_attention_bwd_dq_kernel(
 #pragma unroll
                     for (int jj = 0; jj < 16; ++jj) a += wscr[jj * 80 + dg];
                     const int idx = rel0 + dg;
-                    if (idx >= 0 && idx < nb) atomicAdd(&dbt[idx], a);
+                    if (idx >= 0 && idx < nb) dbt[idx] += a;       // lanes of a wave own distinct diagonals
                 }
             }
         }
@@ -351,14 +353,59 @@ __global__ __launch_bounds__(256) void vn_attention_bwd_dq_kernel(
             *(f32x4*)(dqkv + ooff + 4 * r) = ov;
         }
     }
-    // bias gradient: rel table -> buckets -> 32 global atomics
+    // bias gradient of this block, in a fixed order: (1) the four per-wave tables are summed 0+1+2+3; (2) every bucket is one
+    // contiguous run of key - query offsets (relative_position_bucket is monotone on each side of 0), found from the LUT;
+    // (3) eight threads per bucket sum strided slices of its run, combined 0..7, plus the waves' far sums; (4) the block's
+    // nbuckets values go to ITS slot of dbias_partial (vn_dbias_reduce_kernel adds the slots up in order).
+    if (dbias_partial == nullptr) return;
+    __syncthreads();
+    int* run_lo = (int*)Ks;          // K / V tiles are dead: reuse
+    int* run_hi = run_lo + 64;
+    float* red = (float*)(run_hi + 64);       // [64 buckets][8]
+    if (tid < 64) { run_lo[tid] = 0; run_hi[tid] = 0; }
+    for (int i = tid; i < nb; i += 256) dbt_all[i] = ((dbt_all[i] + dbt_all[nb + i]) + dbt_all[2 * nb + i]) + dbt_all[3 * nb + i];
     __syncthreads();
     for (int i = tid; i < nb; i += 256) {
-        const float a = dbt[i];
-        if (a != 0.f) atomicAdd(&bk[lut[i]], a);
+        const int bkt = lut[i];
+        if (i == 0 || lut[i - 1] != bkt) run_lo[bkt] = i;
+        if (i == nb - 1 || lut[i + 1] != bkt) run_hi[bkt] = i + 1;
     }
     __syncthreads();
-    if (tid < nbuckets) atomicAdd(&dbias_tab[tid * H + h], bk[tid]);
+    for (int bkt = tid >> 3; bkt < nbuckets; bkt += 32) {
+        float a = 0.f;
+        for (int i = run_lo[bkt] + (tid & 7); i < run_hi[bkt]; i += 8) a += dbt_all[i];
+        red[bkt * 8 + (tid & 7)] = a;
+    }
+    __syncthreads();
+    if (tid < nbuckets) {
+        float a = 0.f;
+#pragma unroll
+        for (int pth = 0; pth < 8; ++pth) a += red[tid * 8 + pth];
+        a += ((bk_all[tid] + bk_all[64 + tid]) + bk_all[128 + tid]) + bk_all[192 + tid];
+        const size_t slot = ((size_t)b * H + h) * gridDim.x + qb;
+        dbias_partial[slot * 64 + tid] = a;
+    }
+}
+
+// dbias[bucket][h] (+)= sum over the slots (b, h, q-block) of n_slabs consecutive slabs (layers), in order
+__global__ void vn_dbias_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dbias, int n_slabs, long slab_floats,
+                                       int B, int H, int nqb, int nbuckets, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbuckets * H) return;
+    const int bkt = i / H, h = i - bkt * H;
+    float a = 0.f;
+    for (int l = 0; l < n_slabs; ++l)
+        for (int b = 0; b < B; ++b)
+            for (int qb = 0; qb < nqb; ++qb) a += partial[l * slab_floats + (((size_t)b * H + h) * nqb + qb) * 64 + bkt];
+    dbias[i] = accumulate ? dbias[i] + a : a;
+}
+
+int vn_launch_dbias_reduce(vn_ctx* ctx, const float* partial, float* dbias, int n_slabs, long slab_floats, int B, int H, int T,
+                           int nbuckets, bool accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(vn_dbias_reduce_kernel, dim3(vn_cdiv(nbuckets * H, 64)), dim3(64), 0, s, partial, dbias, n_slabs, slab_floats, B, H,
+                       vn_cdiv(T, 64), nbuckets, accumulate ? 1 : 0);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
 }
 
 // ---- backward: dk, dv -------------------------------------------------------------------------
@@ -532,11 +579,11 @@ int vn_launch_attention_train_fwd(vn_ctx* ctx, const float* q, const float* k, c
 
 int vn_launch_attention_bwd(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* relbias_full,
                             const int32_t* lut_dev, const float* out, const float* dout, const float* lse, float* delta,
-                            float* dqkv, float* dbias_tab, int B, int H, int T, int nbuckets, const vn_drop& d, hipStream_t s) {
+                            float* dqkv, float* dbias_partial, int B, int H, int T, int nbuckets, const vn_drop& d, hipStream_t s) {
     if (B <= 0 || T <= 0) return VN_OK;
     if (nbuckets > 64) return vn_fail(ctx, VN_ERR_UNSUPPORTED, "attention backward: num_buckets=%s%ld > 64", "", nbuckets);
     const int nb = 2 * T - 1;
-    const size_t lds_dq = (size_t)(2 * ATT_KT * ATT_LD + 2 * nb + 64 + 4 * 16 * 80 + 4) * sizeof(float);
+    const size_t lds_dq = (size_t)(2 * ATT_KT * ATT_LD + 5 * nb + 256 + 4 * 16 * 80 + 4) * sizeof(float);
     const size_t lds_kv = (size_t)(2 * ATT_KT * ATT_LD + 192 + nb + 4) * sizeof(float);
     if (lds_dq > 160 * 1024) return vn_fail(ctx, VN_ERR_INVALID, "attention backward: T=%s%ld too long", "", T);
     int rc = att_train_attrs(ctx);
@@ -545,7 +592,7 @@ int vn_launch_attention_bwd(vn_ctx* ctx, const float* q, const float* k, const f
     const double fl = 2.0 * T * (double)T * VN_DHEAD * H * B;     // one T x T x 64 product
     int pi = vn_prof_pre(ctx, 1, 3.0 * fl, s, 24.0 * T * VN_DHEAD * (double)H * B);
     hipLaunchKernelGGL(vn_attention_bwd_dq_kernel, grid, dim3(256), lds_dq, s, q, k, v, relbias_full, lut_dev, out, dout, lse,
-                       delta, dqkv, dbias_tab, B, H, T, nbuckets, d);
+                       delta, dqkv, dbias_partial, B, H, T, nbuckets, d);
     vn_prof_post(ctx, pi, s);
     pi = vn_prof_pre(ctx, 1, 4.0 * fl, s, 28.0 * T * VN_DHEAD * (double)H * B);
     hipLaunchKernelGGL(vn_attention_bwd_dkv_kernel, grid, dim3(256), lds_kv, s, q, k, v, relbias_full, dout, lse, delta, dqkv, B, H,

@@ -40,6 +40,8 @@ struct vn_train {
     float *x_last, *y_f;           // X[L], final-norm output
     // scratch
     float *tmp, *dxa, *dxb, *dh, *dg, *du, *dy, *dqkv, *da, *At, *Bt, *partial, *row_loss, *delta, *scal;
+    float* dbias_partial;          // [L][max_batch*H*ceil(max_T/64)][64] per-block bucket sums of the bias-table gradient
+    long dbias_slab;               // floats per layer slab
     double* npartial;
     int32_t *t32, *n_valid;
     int B, T;                      // shape of the stashed forward (0 = none)
@@ -131,7 +133,7 @@ extern "C" void vn_train_destroy(vn_train* t) {
         for (float* p : a) (void)hipFree(p);
     }
     float* b[] = {t->wT, t->x_last, t->y_f, t->tmp, t->dxa, t->dxb, t->dh, t->dg, t->du, t->dy, t->dqkv, t->da, t->At, t->Bt,
-                  t->partial, t->row_loss, t->delta, t->scal};
+                  t->partial, t->row_loss, t->delta, t->scal, t->dbias_partial};
     for (float* p : b) (void)hipFree(p);
     (void)hipFree(t->npartial);
     (void)hipFree(t->t32);
@@ -155,6 +157,7 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
     if (!t) return VN_ERR_OOM;
     t->m = m; t->params = params;
     t->lora = false; t->lora_params = t->w_base = t->h8 = t->dh8 = nullptr; t->n_lora = 0; t->lora_scale = 0.f;
+    t->dbias_partial = nullptr;
     const vn_dims& d = m->d;
     const long D = m->D, L = m->L, rows = m->max_rows;
     t->NV = m->Cp * d.vocab;
@@ -188,6 +191,8 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
     A(&t->partial, part);
     A(&t->row_loss, (size_t)rows * m->Cp + (size_t)d.num_buckets * m->H);   // + room for the LoRA-mode bias-gradient sink
     A(&t->delta, (size_t)d.max_batch * m->H * d.max_T); A(&t->scal, 16);
+    t->dbias_slab = (long)d.max_batch * m->H * vn_cdiv(d.max_T, 64) * 64;
+    A(&t->dbias_partial, (size_t)t->dbias_slab * L);
     if (rc == VN_OK) rc = talloc(ctx, &t->npartial, 1024);
     if (rc == VN_OK) rc = talloc(ctx, &t->t32, (size_t)rows * m->Cp);
     if (rc == VN_OK) rc = talloc(ctx, &t->n_valid, 4);
@@ -402,7 +407,6 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
     float* junk = t->tmp;                       // >= D floats: by-product norm-weight gradients in LoRA mode
     float* dx = t->dxa;
     float* dx2 = t->dxb;
-    float* dbias = lora ? t->row_loss : G(t, grads, VN_W_REL_BIAS);     // row_loss is free once the loss is reduced
     if (hi >= L) {
     // ---- classifier (WNConv1d 1x1, transformer.py:596-604) + final norm
     if ((rc = gemm(ctx, dlog, t->wT + t->wT_cls, nullptr, t->dy, M, D, NV, VN_EPI_STORE, s))) return rc;
@@ -447,7 +451,8 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
         if (rc) return rc;
         if ((rc = gemm(ctx, dh2, wTl + 3L * D * D, nullptr, t->da, M, D, D, VN_EPI_STORE, s))) return rc;
         if ((rc = vn_launch_attention_bwd(ctx, S.qkv, S.qkv + plane, S.qkv + 2 * plane, m->bias_full, m->lut, S.a, t->da, S.lse,
-                                          t->delta, t->dqkv, dbias, B, H, T, m->d.num_buckets,
+                                          t->delta, t->dqkv, lora ? nullptr : t->dbias_partial + t->dbias_slab * l, B, H, T,
+                                          m->d.num_buckets,
                                           make_drop(p, l, SITE_ATTN, r_att), s)))
             return rc;
         if (lora) {          // w_qs and w_vs carry adapters, w_ks is a plain nn.Linear (transformer.py:109-111)
@@ -460,6 +465,11 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
         if ((rc = gemm(ctx, t->dqkv, wTl, nullptr, t->dy, M, D, 3 * D, VN_EPI_STORE, s))) return rc;
         if ((rc = vn_launch_rmsnorm_bwd(ctx, S.x_in, P(t, VN_W_NORM1, l), t->dy, dx2, dx, lora ? junk : G(t, grads, VN_W_NORM1, l),
                                         t->partial, M, D, m->d.eps, s)))
+            return rc;
+    }
+    if (!lora && lo <= 0 && hi >= 0) {          // layer 0 is done: every layer's slab of the shared bias-table gradient is final
+        if ((rc = vn_launch_dbias_reduce(ctx, t->dbias_partial, G(t, grads, VN_W_REL_BIAS), L, t->dbias_slab, B, H, T,
+                                         m->d.num_buckets, false, s)))
             return rc;
     }
     if (lora || lo >= 0) return VN_OK;          // LoRA: embedding parameters are frozen
@@ -617,11 +627,16 @@ extern "C" int vn_attention_train_f32(vn_ctx* ctx, const float* q, const float* 
     tp.seed = seed; tp.step = 1; tp.dropout = dropout;
     const vn_drop d = make_drop(&tp, 0, SITE_ATTN, 0);
     if (rc == VN_OK) rc = vn_launch_attention_train_fwd(ctx, q, k, v, full, out, lse, B, H, T, d, s);
+    float* part = nullptr;
+    const long slab = (long)B * H * vn_cdiv(T, 64) * 64;
+    if (rc == VN_OK && dout && hipMalloc((void**)&part, (size_t)slab * sizeof(float)) != hipSuccess) rc = VN_ERR_OOM;
     if (rc == VN_OK && dout)
-        rc = vn_launch_attention_bwd(ctx, q, k, v, full, lut_d, out, dout, lse, delta, dqkv, dbias, B, H, T, num_buckets, d, s);
+        rc = vn_launch_attention_bwd(ctx, q, k, v, full, lut_d, out, dout, lse, delta, dqkv, part, B, H, T, num_buckets, d, s);
+    if (rc == VN_OK && dout) rc = vn_launch_dbias_reduce(ctx, part, dbias, 1, slab, B, H, T, num_buckets, true, s);
     (void)hipStreamSynchronize(s);
     (void)hipFree(full);
     (void)hipFree(lut_d);
     (void)hipFree(delta);
+    (void)hipFree(part);
     return rc;
 }

@@ -4,8 +4,8 @@
 // and the AdamW update.  All fp32; every kernel streams its operands once with 16-byte accesses.
 //
 // Determinism: column sums (norm weights, biases, loss) go through fixed-shape partial buffers + a second pass,
-// never through floating-point atomics, so a step is bitwise reproducible run to run (the only atomics of the
-// training path are the relative-position-bias gradient in attention_train.hip).
+// never through floating-point atomics, so a step is bitwise reproducible run to run (attention_train.hip reduces the
+// shared relative-position-bias gradient the same way).
 #include "vn_common.h"
 #include "vn_train.h"
 

@@ -38,11 +38,14 @@ int vn_launch_adamw(vn_ctx* ctx, float* p, const float* g, float* m, float* v, l
 // forward with probability dropout; also writes lse[b][h][t] = log sum_k exp(score)   (transformer.py:234-254, :250)
 int vn_launch_attention_train_fwd(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* relbias_full,
                                   float* out, float* lse, int B, int H, int T, const vn_drop& d, hipStream_t s);
-// backward: dqkv token-major [B*T][3*H*64] (columns: dq | dk | dv, head-major inside each), dbias [num_buckets][H]
-// accumulated with atomics (shared by all layers), delta scratch [B][H][T]
+// backward: dqkv token-major [B*T][3*H*64] (columns: dq | dk | dv, head-major inside each); delta scratch [B][H][T];
+// dbias_partial: this launch's slab [B*H*ceil(T/64)][64] of per-block bucket sums of d(bias) (or NULL to skip it) — no
+// atomics anywhere; vn_launch_dbias_reduce adds n_slabs consecutive slabs (the layers share the table) in a fixed order
 int vn_launch_attention_bwd(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* relbias_full,
                             const int32_t* lut_dev, const float* out, const float* dout, const float* lse, float* delta,
-                            float* dqkv, float* dbias_tab, int B, int H, int T, int nbuckets, const vn_drop& d, hipStream_t s);
+                            float* dqkv, float* dbias_partial, int B, int H, int T, int nbuckets, const vn_drop& d, hipStream_t s);
+int vn_launch_dbias_reduce(vn_ctx* ctx, const float* partial, float* dbias, int n_slabs, long slab_floats, int B, int H, int T,
+                           int nbuckets, bool accumulate, hipStream_t s);
 
 // LoRA fine-tuning helpers (rank 8; every rank-r operand is [C][8] row-major, A stored transposed)
 int vn_launch_lora_down(vn_ctx* ctx, const float* Y, int ldy, const float* P, float* H, int M, int Cn, float scale, hipStream_t s);
