@@ -180,3 +180,33 @@ def test_data_parallel_two_ranks_gloo():
             assert l == pytest.approx(lo, rel=1e-6) and n == pytest.approx(no, rel=1e-5) and lr == lro
         for k, v in cur.items():
             assert abs(torch.from_numpy(new[k]).reshape(v.shape) - v).max().item() < 1e-7, (rank, k)
+
+
+def test_optimizer_and_scheduler_state_roundtrip():
+    """optimizer.pth is a torch.optim.AdamW state_dict over the parameters in state_dict order; scheduler.pth carries the
+    NoamScheduler attributes (vampnet/scheduler.py:30-33).  Flat moment buffers -> state_dict -> flat buffers is lossless, and
+    torch's own AdamW accepts the file."""
+    dims = W.TINY_COARSE_DIMS
+    sd, cb = W.synth_state_dict(dims, 0), W.synth_codebooks()
+    tr = OracleBackedTrainer(sd, dims, cb)
+    tr._sd_template = {k: (tuple(v.shape), v.dtype) for k, v in sd.items()}
+    g = torch.Generator().manual_seed(1)
+    like = {k: torch.randn(v.shape, generator=g) for k, v in sd.items()}
+    tr.adam_m = tr.pack(like)
+    tr.adam_v = tr.pack({k: v.abs() for k, v in like.items()})
+    tr.steps, tr.last_lr = 7, 1.25e-4
+    osd = tr.optimizer_state_dict()
+    names = tr._param_names()
+    assert osd["param_groups"][0]["params"] == list(range(len(names))) and osd["param_groups"][0]["lr"] == 1.25e-4
+    for i, k in enumerate(names):
+        assert torch.equal(osd["state"][i]["exp_avg"], like[k]) and float(osd["state"][i]["step"]) == 7.0
+    params = [torch.nn.Parameter(torch.zeros(sd[k].shape)) for k in names]
+    opt = torch.optim.AdamW(params, lr=1e-3)
+    opt.load_state_dict(osd)
+    assert torch.equal(opt.state[params[3]]["exp_avg_sq"], like[names[3]].abs())
+    tr2 = OracleBackedTrainer(sd, dims, cb)
+    tr2._sd_template = tr._sd_template
+    tr2.adam_m, tr2.adam_v = torch.zeros_like(tr.adam_m), torch.zeros_like(tr.adam_v)
+    tr2.load_optimizer_state_dict(osd)
+    assert tr2.steps == 7 and torch.equal(tr2.adam_m, tr.adam_m) and torch.equal(tr2.adam_v, tr.adam_v)
+    assert tr.scheduler_state_dict() == {"warmup": 10000, "factor": 2.0, "d_model": dims["d_model"], "lr": 1.25e-4, "steps": 7}
