@@ -228,3 +228,60 @@ def test_torch_rng_state_parse_and_patch():
     torch.set_rng_state(patch_torch_rng_state(blob, state, 624))
     st2, pos2 = parse_torch_rng_state(torch.get_rng_state())
     assert pos2 == 624 and np.array_equal(st2, state)
+
+
+# ----------------------------------------------------------------------------- mt19937 jump-ahead (parallel torch_device noise)
+def _mt_blocks(state, n_blocks):
+    """numpy restatement of at::mt19937::next_state(): successive 624-word blocks of UNTEMPERED words."""
+    import numpy as np
+
+    def tw(u, v):
+        y = (u & np.uint32(0x80000000)) | (v & np.uint32(0x7fffffff))
+        return (y >> np.uint32(1)) ^ np.where(v & np.uint32(1), np.uint32(0x9908b0df), np.uint32(0))
+
+    out, o = [], state
+    for _ in range(n_blocks):
+        w = np.empty_like(o)
+        w[0:227] = o[397:624] ^ tw(o[0:227], o[1:228])
+        w[227:454] = w[0:227] ^ tw(o[227:454], o[228:455])
+        w[454:623] = w[227:396] ^ tw(o[454:623], o[455:624])
+        w[623] = w[396] ^ tw(o[623:624], w[0:1])[0]
+        out.append(w)
+        o = w
+    return out
+
+
+def test_mt19937_characteristic_polynomial():
+    """PHI_EXPONENTS (vampnet_amd/mt_jump.py) is the minimal polynomial of the generator: Berlekamp-Massey on 2 x 19937 + 200
+    output bits of at::mt19937 finds an LFSR of length 19937 whose reversed connection polynomial is exactly it."""
+    import numpy as np
+    from vampnet_amd import mt_jump as J
+    bg = np.random.MT19937()
+    bg._legacy_seeding(5489)
+    st = bg.state["state"]["key"].astype(np.uint32)
+    words = np.concatenate(_mt_blocks(st, (2 * 19937 + 200) // 624 + 1))
+    c, length = J.berlekamp_massey_gf2((words[:2 * 19937 + 200] & 1).tolist())
+    assert length == J.MT_DEGREE
+    phi = int(bin(c)[2:].zfill(J.MT_DEGREE + 1)[::-1], 2)
+    assert phi == J.PHI and len(J.PHI_EXPONENTS) == 135
+
+
+@pytest.mark.parametrize("steps", [1, 623, 624, 100_003, 2 * 2300 * 1024])
+def test_mt19937_jump_polynomial(steps):
+    """x_{k+J} = XOR over the set bits i of x^J mod phi of x_{k+i}: 624 sliding XORs over the next 20 560 words give the state
+    J steps ahead, and the generator continues from it."""
+    import numpy as np
+    from vampnet_amd import mt_jump as J
+    bg = np.random.MT19937()
+    bg._legacy_seeding(321)
+    st = bg.state["state"]["key"].astype(np.uint32)
+    need = steps + 3 * 624
+    stream = np.concatenate(_mt_blocks(st, need // 624 + 35))
+    g = J.jump_poly(steps)
+    assert J.poly_mul(g, J.jump_poly(5)) == J.jump_poly(steps + 5)
+    words = J.jump_poly_words(steps)
+    idx = np.nonzero(np.unpackbits(words.view(np.uint8), bitorder="little"))[0]
+    assert idx.max() < J.MT_DEGREE
+    jumped = np.array([np.bitwise_xor.reduce(stream[k + idx]) for k in range(624)], dtype=np.uint32)
+    assert np.array_equal(jumped, stream[steps:steps + 624])
+    assert np.array_equal(_mt_blocks(jumped, 1)[0], stream[steps + 624:steps + 1248])
