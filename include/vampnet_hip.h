@@ -329,6 +329,13 @@ int  vn_transpose_f32(vn_ctx* ctx, const float* src, float* dst, int R, int C, i
  * words per element) and Tensor.uniform_(lo, hi) (one word per element) of float32 CPU tensors (transformer.py:28-30,
  * :1024-1028 consume them through multinomial / gumbel_noise_like).                                                   */
 int vn_mt19937_generate(vn_ctx* ctx, uint32_t* state624, int32_t* pos, uint32_t* out_raw, int64_t n, void* stream);
+/* Jump-ahead: polys dev u32 [n_targets][624] = x^J mod phi(x) per target offset J (vampnet_amd/mt_jump.py); out_states dev u32
+ * [n_targets][624] receives the generator state J steps ahead of (state624, *pos), each at position 0.  vn_mt19937_generate_chunks
+ * then walks n_chunks such states in parallel, chunk c writing words [c*chunk_words, min((c+1)*chunk_words, total_words)).       */
+int vn_mt19937_jump(vn_ctx* ctx, const uint32_t* state624, const int32_t* pos, const uint32_t* polys, int n_targets,
+                    uint32_t* out_states, void* stream);
+int vn_mt19937_generate_chunks(vn_ctx* ctx, const uint32_t* states, int n_chunks, uint32_t* out_raw, int64_t chunk_words,
+                               int64_t total_words, void* stream);
 int vn_torch_exponential_f32(vn_ctx* ctx, const uint32_t* raw, float* out, int64_t n, void* stream);
 int vn_torch_uniform_f32(vn_ctx* ctx, const uint32_t* raw, float* out, int64_t n, float lo, float hi, void* stream);
 

@@ -553,9 +553,9 @@ def test_torch_device_rng_mode_equals_host_replay(tiny):
     z = W.synth_codes(3, 4, 60, seed=5)
     mask = O.periodic_mask(z, 5, 1).long()
     a = model.generate(start_tokens=z, mask=mask, _sampling_steps=5, seed=7, temperature=0.9, rng="torch").cpu()
-    sa = torch.get_rng_state()
+    sa = torch.rand(64)          # where the generator stands afterwards (the jump-ahead path may hand back a re-aligned window
     b = model.generate(start_tokens=z, mask=mask, _sampling_steps=5, seed=7, temperature=0.9, rng="torch_device").cpu()
-    sb = torch.get_rng_state()
+    sb = torch.rand(64)          # of the same stream: compare by what it emits next, not by the state bytes)
     assert torch.equal(a, b) and torch.equal(sa, sb)
     ref = O.generate(sd, dims, tiny["cb"], z, mask, sampling_steps=5, seed=7, temperature=0.9)
     assert torch.equal(b, ref)
@@ -573,6 +573,6 @@ def test_torch_device_rng_mode_equals_host_replay(tiny):
         z14 = W.synth_codes(1, 14, 400, seed=6)
         torch.manual_seed(3)
         m14 = itf.build_mask(z14)
-        outs[mode] = (itf.vamp(z14, m14, batch_size=2, seed=1, _sampling_steps=4).cpu(), torch.get_rng_state())
+        outs[mode] = (itf.vamp(z14, m14, batch_size=2, seed=1, _sampling_steps=4).cpu(), torch.rand(64))
     assert torch.equal(outs["torch"][0], outs["torch_device"][0])
     assert torch.equal(outs["torch"][1], outs["torch_device"][1])

@@ -87,6 +87,8 @@ SYMBOLS = {
     "vn_attention_train_f32": (C.c_int, [_P] * 10 + [C.c_int] * 5 + [C.c_float, C.c_uint64, _P]),
     "vn_transpose_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "vn_mt19937_generate": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P]),
+    "vn_mt19937_jump": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P]),
+    "vn_mt19937_generate_chunks": (C.c_int, [_P, _P, C.c_int, _P, C.c_int64, C.c_int64, _P]),
     "vn_torch_exponential_f32": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "vn_torch_uniform_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, C.c_float, _P]),
     "vn_debug_graph_replays": (C.c_int, [_P, C.POINTER(C.c_int64)]),

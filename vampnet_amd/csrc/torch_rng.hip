@@ -30,14 +30,22 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 
 // state[624] + *pos (index of the next word to emit; 624 = block exhausted) -> n tempered outputs; state / pos advanced.
 // out may be NULL (advance only: another rank's rows of a sharded batch).
+// Chunked use (vn_mt19937_generate_chunks): block c starts from states[c] at position 0 and writes words [c*chunk, (c+1)*chunk) of
+// the stream (pos == NULL, nothing written back).
 __global__ __launch_bounds__(256) void vn_mt19937_kernel(uint32_t* __restrict__ state, int32_t* __restrict__ pos,
-                                                         uint32_t* __restrict__ out, long n) {
+                                                         uint32_t* __restrict__ out, long n, long chunk) {
     __shared__ uint32_t buf[2][MT_N + 8];
     const int tid = threadIdx.x;
+    if (chunk > 0) {
+        state += (size_t)blockIdx.x * MT_N;
+        const long first = (long)blockIdx.x * chunk;
+        if (out) out += first;
+        n = n - first < chunk ? n - first : chunk;
+    }
     for (int i = tid; i < MT_N; i += 256) buf[0][i] = state[i];
     __syncthreads();
     int cur = 0;
-    int p = *pos;
+    int p = pos ? *pos : 0;
     long done = 0;
     if (p < MT_N && n > 0) {             // rest of the block the generator was in
         const long take = (long)(MT_N - p) < n ? (MT_N - p) : n;
@@ -79,6 +87,7 @@ __global__ __launch_bounds__(256) void vn_mt19937_kernel(uint32_t* __restrict__ 
         p = take;
         done += take;
     }
+    if (pos == nullptr) return;
     for (int i = tid; i < MT_N; i += 256) state[i] = buf[cur][i];
     if (tid == 0) *pos = p;
 }
@@ -86,7 +95,81 @@ __global__ __launch_bounds__(256) void vn_mt19937_kernel(uint32_t* __restrict__ 
 extern "C" int vn_mt19937_generate(vn_ctx* ctx, uint32_t* state624, int32_t* pos, uint32_t* out_raw, int64_t n, void* stream) {
     if (!ctx || !state624 || !pos || n < 0) return VN_ERR_INVALID;
     if (n == 0) return VN_OK;
-    hipLaunchKernelGGL(vn_mt19937_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, state624, pos, out_raw, (long)n);
+    hipLaunchKernelGGL(vn_mt19937_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, state624, pos, out_raw, (long)n, 0L);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+extern "C" int vn_mt19937_generate_chunks(vn_ctx* ctx, const uint32_t* states, int n_chunks, uint32_t* out_raw, int64_t chunk_words,
+                                          int64_t total_words, void* stream) {
+    if (!ctx || !states || !out_raw || n_chunks <= 0 || chunk_words <= 0 || total_words <= (int64_t)(n_chunks - 1) * chunk_words ||
+        total_words > (int64_t)n_chunks * chunk_words)
+        return VN_ERR_INVALID;
+    hipLaunchKernelGGL(vn_mt19937_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (uint32_t*)states, (int32_t*)nullptr,
+                       out_raw, (long)total_words, (long)chunk_words);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Jump-ahead (vampnet_amd/mt_jump.py): with g = x^J mod phi as a 624-word bit vector, the state J steps ahead is
+//   x_{J+k} = XOR_{i : g_i} x_{k+i},  k = 0 .. 623,   over the UNTEMPERED stream x_0 = state[pos], x_1, ...
+// One workgroup per target: 34 consecutive blocks (block 0 = the state array) are laid out in LDS (84 KiB), then every thread
+// slides the polynomial's ~10 k set bits over its three output words (uniform loop, conflict-free consecutive LDS reads).
+// The result is a state array at position 0.
+// ---------------------------------------------------------------------------------------------------------------------
+#define MT_JUMP_BLOCKS 34
+__global__ __launch_bounds__(256) void vn_mt19937_jump_kernel(const uint32_t* __restrict__ state, const int32_t* __restrict__ pos,
+                                                              const uint32_t* __restrict__ polys, uint32_t* __restrict__ out_states) {
+    extern __shared__ uint32_t Y[];                       // [MT_JUMP_BLOCKS][624]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < MT_N; i += 256) Y[i] = state[i];
+    __syncthreads();
+    for (int blk = 0; blk + 1 < MT_JUMP_BLOCKS; ++blk) {
+        const uint32_t* o = Y + blk * MT_N;
+        uint32_t* w = Y + (blk + 1) * MT_N;
+        if (tid < 227) {
+            const uint32_t v0 = o[tid + MT_M] ^ mt_twist(o[tid], o[tid + 1]);
+            const uint32_t v1 = v0 ^ mt_twist(o[227 + tid], o[228 + tid]);
+            w[tid] = v0;
+            w[227 + tid] = v1;
+            if (tid < 170) {
+                const uint32_t c1 = tid < 169 ? o[455 + tid] : (o[MT_M] ^ mt_twist(o[0], o[1]));
+                w[454 + tid] = v1 ^ mt_twist(o[454 + tid], c1);
+            }
+        }
+        __syncthreads();
+    }
+    const uint32_t* poly = polys + (size_t)blockIdx.x * MT_N;
+    const uint32_t* x = Y + *pos;                         // x_0 = state[pos]; pos == 624 starts at block 1
+    uint32_t a0 = 0, a1 = 0, a2 = 0;
+    const bool has2 = tid + 512 < MT_N;
+    for (int wd = 0; wd < MT_N; ++wd) {
+        uint32_t bits = __builtin_amdgcn_readfirstlane(poly[wd]);
+        while (bits) {
+            const int i = 32 * wd + __builtin_ctz(bits);
+            bits &= bits - 1;
+            a0 ^= x[tid + i];
+            a1 ^= x[tid + 256 + i];
+            if (has2) a2 ^= x[tid + 512 + i];
+        }
+    }
+    uint32_t* dst = out_states + (size_t)blockIdx.x * MT_N;
+    dst[tid] = a0;
+    dst[tid + 256] = a1;
+    if (has2) dst[tid + 512] = a2;
+}
+
+extern "C" int vn_mt19937_jump(vn_ctx* ctx, const uint32_t* state624, const int32_t* pos, const uint32_t* polys, int n_targets,
+                               uint32_t* out_states, void* stream) {
+    if (!ctx || !state624 || !pos || !polys || !out_states || n_targets <= 0) return VN_ERR_INVALID;
+    const size_t lds = (size_t)MT_JUMP_BLOCKS * MT_N * sizeof(uint32_t);
+    static bool attr = false;
+    if (!attr) {
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_mt19937_jump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(vn_mt19937_jump_kernel, dim3(n_targets), dim3(256), lds, (hipStream_t)stream, state624, pos, polys, out_states);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
 }

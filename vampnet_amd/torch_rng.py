@@ -101,6 +101,43 @@ class DeviceTorchRng:
                                                             self.engine.stream()), "vn_torch_exponential_f32")
         return out
 
+    CHUNK_WORDS = 1 << 21            # words per parallel chunk of the jump-ahead path (1.4 ms of serial walk each)
+
+    def exponential_block_(self, out: torch.Tensor, lead_words: int, total_words: int, chunk_words: int = None):
+        """The `out.numel()` exponentials that start `lead_words` into a block of `total_words` stream words, advancing the
+        generator by the WHOLE block (a rank's rows of a sharded batch: the rest of the block belongs to other ranks).
+        Large blocks use the jump-ahead path (vampnet_amd/mt_jump.py): the generator states at the chunk starts and at the
+        block end are computed with one workgroup each, then all chunks are walked in parallel."""
+        from . import mt_jump
+        chunk = self.CHUNK_WORDS if chunk_words is None else int(chunk_words)
+        n = out.numel()
+        length = 2 * n
+        assert 0 <= lead_words and lead_words + length <= total_words
+        if length < 2 * chunk:
+            self.skip(lead_words)
+            self.exponential_(out)
+            self.skip(total_words - lead_words - length)
+            return out
+        nc = -(-length // chunk)
+        key = (lead_words, length, total_words, chunk)
+        cache = self.__dict__.setdefault("_poly_cache", {})
+        if key not in cache:
+            offs = [lead_words + c * chunk for c in range(nc)] + [total_words]
+            polys = np.stack([mt_jump.jump_poly_words(o) for o in offs])
+            cache[key] = torch.from_numpy(polys.view(np.int32)).to(self.engine.device)
+        polys = cache[key]
+        states = torch.empty(nc + 1, _N, dtype=torch.int32, device=self.engine.device)
+        eng, st = self.engine, self.engine.stream()
+        eng.check(self.lib.vn_mt19937_jump(eng.handle, self.state.data_ptr(), self.pos.data_ptr(), polys.data_ptr(), nc + 1,
+                                           states.data_ptr(), st), "vn_mt19937_jump")
+        raw = self._scratch(length)
+        eng.check(self.lib.vn_mt19937_generate_chunks(eng.handle, states.data_ptr(), nc, raw.data_ptr(), chunk, length, st),
+                  "vn_mt19937_generate_chunks")
+        eng.check(self.lib.vn_torch_exponential_f32(eng.handle, raw.data_ptr(), out.data_ptr(), n, st), "vn_torch_exponential_f32")
+        self.state.copy_(states[nc])                       # the block end, at position 0
+        self.pos.zero_()
+        return out
+
     def uniform_(self, out: torch.Tensor, lo: float, hi: float):
         n = out.numel()
         raw = self._scratch(n)
@@ -131,9 +168,7 @@ def draw_noise_device(rng: DeviceTorchRng, B, N, V, steps, sample_cutoff, b0=0, 
         rng.load_from_torch()
         for i in range(steps):
             if (i / steps) <= sample_cutoff:                      # transformer.py:852-855
-                rng.skip(2 * b0 * N * V)
-                rng.exponential_(exp[i])
-                rng.skip(2 * (B - b0 - nb) * N * V)
+                rng.exponential_block_(exp[i], 2 * b0 * N * V, 2 * B * N * V)
             rng.skip(b0 * N)
             rng.uniform_(unif[i], 1e-20, 1.0)
             rng.skip((B - b0 - nb) * N)
