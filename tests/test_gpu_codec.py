@@ -92,3 +92,44 @@ def test_interface_encode_decode_roundtrip(eng):
     out = itf.vamp(z, mask, batch_size=2, seed=0, _sampling_steps=2)
     assert out.shape == (2, 14, 41)
     assert itf.decode(out).samples.shape == (2, 1, 41 * 8)
+
+
+def test_vamp_service_end_to_end(eng):
+    """The reference's `/vamp` endpoint body (app.py:120-263) over the HIP Interface: int16 PCM in, two loudness-matched
+    audios out, and the tokens behind them equal to driving the Interface by hand with the same seed."""
+    import numpy as np
+    from oracle import weights as W
+    from tests.gpu_common import model_kwargs
+    from vampnet_amd import serve
+    from vampnet_amd.codec import AudioSignal, DacCodec
+    from vampnet_amd.engine import seed_all
+    from vampnet_amd.interface import Interface
+    cfg = dict(D.DAC_TINY_CFG, n_codebooks=14)
+    codec = DacCodec(D.synth_dac_state_dict(cfg, 1), cfg, engine=eng)
+    itf = Interface.from_state_dicts(codec, W.synth_state_dict(W.TINY_COARSE_DIMS, 0), model_kwargs(W.TINY_COARSE_DIMS),
+                                     W.synth_state_dict(W.TINY_C2F_DIMS, 1), model_kwargs(W.TINY_C2F_DIMS), max_batch=2,
+                                     coarse_chunk_size_s=0.05, coarse2fine_chunk_size_s=0.02)     # hop 8: 276 / 111 tokens
+    n = 4413                                                                                     # 0.1 s at 44.1 kHz, not a hop multiple
+    t = np.arange(n) / 44100.0
+    pcm = ((0.3 * np.sin(2 * np.pi * 220 * t) + 0.1 * np.sin(2 * np.pi * 3000 * t)) * 32767).astype(np.int16)
+    svc = serve.VampService(itf, chunk_size_s=0.05)
+    req = dict(input_audio=(44100, pcm), sampletemp=1.0, top_p=0.0, periodic_p=3, dropout=0.0, stretch_factor=1,
+               onset_mask_width=0, typical_filtering=True, typical_mass=0.15, typical_min_tokens=64, seed=5,
+               model_choice="default", n_mask_codebooks=3, pitch_shift_amt=0, sample_cutoff=1.0, sampling_steps=3,
+               beat_mask_ms=0, num_feedback_steps=1)
+    (sr, a0), (_, a1) = svc.api_vamp(*[req[k] for k in serve.VAMP_ARG_ORDER])
+    assert sr == 44100 and a0.shape == a1.shape == (n - n % 8 + (8 if n % 8 else 0),) and a0.dtype == np.float32
+    want = float(serve._to_signal(req["input_audio"]).loudness()[0])
+    for a in (a0, a1):
+        assert np.isfinite(a).all() and abs(float(AudioSignal(a, sr).loudness()[0]) - want) < 1e-3
+    assert not np.array_equal(a0, a1)                                   # two samples of the same prompt
+    # by hand, in the order of _vamp_internal
+    seed_all(5)
+    sig = itf._preprocess(serve._to_signal(req["input_audio"]).to_mono())
+    codes = itf.encode(sig)
+    mask = itf.build_mask(codes, sig=sig, periodic_prompt=3, onset_mask_width=0, _dropout=0.0, upper_codebook_mask=3)
+    assert torch.equal(mask, svc.last_mask)
+    z = itf.vamp(codes, mask, batch_size=2, feedback_steps=1, _sampling_steps=3, temperature=1.0, top_p=None, seed=5,
+                 sample_cutoff=1.0)
+    hand = itf.decode(z).normalize(torch.tensor([want, want]))
+    assert torch.equal(torch.from_numpy(a0), hand.samples[0, 0].cpu()) and torch.equal(torch.from_numpy(a1), hand.samples[1, 0].cpu())

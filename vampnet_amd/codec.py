@@ -52,6 +52,27 @@ class AudioSignal:
     def clone(self):
         return AudioSignal(self.samples.clone(), self.sample_rate)
 
+    @property
+    def batch_size(self):
+        return self.samples.shape[0]
+
+    def to_mono(self):
+        self.samples = self.samples.mean(dim=1, keepdim=True)
+        return self
+
+    def loudness(self):
+        """Integrated loudness (LUFS) per batch item, tensor (B,) — audiotools' `AudioSignal.loudness()` [UNVERIFIED-DEP]."""
+        x = self.samples.detach().float().cpu().numpy()
+        return torch.tensor([integrated_loudness(x[b], self.sample_rate) for b in range(x.shape[0])])
+
+    def normalize(self, db=-24.0):
+        """Scale every item to `db` LUFS (scalar or per-item tensor) — audiotools' `normalize` [UNVERIFIED-DEP]."""
+        target = torch.as_tensor(db, dtype=torch.float32).reshape(-1).expand(self.batch_size)
+        have = self.loudness()
+        gain = torch.where(have > -70.0, target - have, torch.zeros(self.batch_size))      # silence stays silent
+        self.samples = self.samples * (10.0 ** (gain / 20.0)).to(self.samples.device)[:, None, None]
+        return self
+
     def write(self, path):
         import wave
         x = (self.samples[0].clamp(-1, 1).cpu().numpy().T * 32767.0).astype("<i2")
