@@ -106,7 +106,9 @@ typedef struct {
 /* ---- context ------------------------------------------------------------------------------
  * One context per device (and per thread that drives it).  A context owns a small device scratch (stream-K partial-sum
  * slabs, hand-off flags): all work enqueued through ONE context must be stream-ordered (one stream, or streams chained
- * by events); use separate contexts for concurrent streams.  The reference itself is single-threaded.   */
+ * by events); use separate contexts for concurrent streams.  The calling thread's current HIP device must be the
+ * context's device for every call (vn_ctx_create / vn_model_create select it; a host that switches devices must switch
+ * back, as torch.cuda.device does).  The reference itself is single-threaded.                           */
 int  vn_ctx_create(int device, vn_ctx** out);
 void vn_ctx_destroy(vn_ctx* ctx);
 const char* vn_last_error(const vn_ctx* ctx);

@@ -372,14 +372,13 @@ int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float
     if (B <= 0 || T <= 0) return VN_OK;
     const size_t lds = (size_t)(2 * ATT_KT * ATT_LD + 2 * T - 1 + 3) * sizeof(float);
     if (lds > 160 * 1024) return vn_fail(ctx, VN_ERR_INVALID, "attention: T=%s%ld too long for the LDS bias table", "", T);
-    static bool attr_set = false;
-    static int variant = 1;      // 1: split-product exp2 (default); 0: ocml expf (A/B reference, VN_ATTN_VARIANT=0)
-    if (!attr_set) {
-        if (const char* e = getenv("VN_ATTN_VARIANT")) variant = atoi(e) & 1;
+    // 1: split-product exp2 (default); 0: ocml expf (A/B reference, VN_ATTN_VARIANT=0)
+    static const int variant = [] { const char* e = getenv("VN_ATTN_VARIANT"); return e ? atoi(e) & 1 : 1; }();
+    if (!(ctx->attr_mask & VN_ATTR_ATTN)) {
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        ctx->attr_mask |= VN_ATTR_ATTN;
     }
     const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
     const dim3 grid(vn_cdiv(T, 64), H, B);

@@ -553,12 +553,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void v
 
 // ---- launchers ---------------------------------------------------------------------------------
 static int att_train_attrs(vn_ctx* ctx) {
-    static bool set = false;
-    if (set) return VN_OK;
+    if (ctx->attr_mask & VN_ATTR_ATTN_TRAIN) return VN_OK;
     VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_train_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    set = true;
+    ctx->attr_mask |= VN_ATTR_ATTN_TRAIN;
     return VN_OK;
 }
 

@@ -94,7 +94,7 @@ extern "C" int vn_ctx_create(int device, vn_ctx** out) {
     c->device = device;
     c->err[0] = 0;
     c->prof = vn_prof();
-    c->sk_slabs = nullptr; c->sk_flags = nullptr; c->zero_page = nullptr;
+    c->sk_slabs = nullptr; c->sk_flags = nullptr; c->zero_page = nullptr; c->attr_mask = 0;
     if (hipSetDevice(device) != hipSuccess) { delete c; return VN_ERR_HIP; }
     *out = c;
     return VN_OK;
@@ -474,9 +474,9 @@ extern "C" int vn_generate(vn_model* m, const int64_t* start_tokens, const int64
     vn_ctx* ctx = m->ctx;
     const long n = (long)B * m->d.n_codebooks * T;
     const long N = (long)T * m->Cp, V = m->d.vocab;
+    if (p->steps > VN_MAX_STEPS) return vn_fail(ctx, VN_ERR_INVALID, "steps=%s%ld exceeds VN_MAX_STEPS", "", p->steps);
     VN_HIP_CHECK(ctx, hipMemsetAsync(m->count, 0, sizeof(int32_t), s));
     if ((rc = vn_launch_apply_mask(ctx, start_tokens, mask, m->z, m->count, n, (int)V, s))) return rc;   // :762-766
-    if (p->steps > VN_MAX_STEPS) return vn_fail(ctx, VN_ERR_INVALID, "steps=%s%ld exceeds VN_MAX_STEPS", "", p->steps);
     long n0 = p->n0_override;
     std::vector<int64_t> ks((size_t)p->steps * B);
     if (sched) {
@@ -513,7 +513,10 @@ extern "C" int vn_attention_bf16(vn_ctx* ctx, const float* q, const float* k, co
     int32_t* lut_d = nullptr;
     const int n = 2 * T - 1;
     VN_HIP_CHECK(ctx, hipMalloc((void**)&full, (size_t)H * n * sizeof(float)));
-    VN_HIP_CHECK(ctx, hipMalloc((void**)&lut_d, (size_t)n * sizeof(int32_t)));
+    if (hipMalloc((void**)&lut_d, (size_t)n * sizeof(int32_t)) != hipSuccess) {
+        (void)hipFree(full);
+        return vn_fail(ctx, VN_ERR_OOM, "hipMalloc of the bucket table failed%s", "");
+    }
     std::vector<int32_t> lut(n);
     vn_bucket_lut_host(T, num_buckets, max_distance, lut.data());
     int rc = VN_OK;
@@ -563,7 +566,10 @@ extern "C" int vn_attention_f32(vn_ctx* ctx, const float* q, const float* k, con
     int32_t* lut_d = nullptr;
     const int n = 2 * T - 1;
     VN_HIP_CHECK(ctx, hipMalloc((void**)&full, (size_t)H * n * sizeof(float)));
-    VN_HIP_CHECK(ctx, hipMalloc((void**)&lut_d, (size_t)n * sizeof(int32_t)));
+    if (hipMalloc((void**)&lut_d, (size_t)n * sizeof(int32_t)) != hipSuccess) {
+        (void)hipFree(full);
+        return vn_fail(ctx, VN_ERR_OOM, "hipMalloc of the bucket table failed%s", "");
+    }
     std::vector<int32_t> lut(n);
     vn_bucket_lut_host(T, num_buckets, max_distance, lut.data());
     int rc = VN_OK;

@@ -460,13 +460,14 @@ static int g_force_bm = 0, g_force_bn = 0;
 static int g_sched = -1;          // -1 auto, 0 data-parallel, 1 stream-K
 static int g_splitk = -1;         // VN_GEMM_SPLITK: -1 auto, 0 off, >= 2 forced split count (small-M shapes only)
 static void read_env_once() {
-    static bool done = false;
-    if (done) return;
-    done = true;
-    if (const char* e = getenv("VN_GEMM_ORDER")) g_order = atoi(e);
-    if (const char* e = getenv("VN_GEMM_TILE")) sscanf(e, "%dx%d", &g_force_bm, &g_force_bn);
-    if (const char* e = getenv("VN_GEMM_SCHED")) g_sched = atoi(e);
-    if (const char* e = getenv("VN_GEMM_SPLITK")) g_splitk = atoi(e);
+    static const bool done = [] {         // function-local static: initialised once, also under concurrent first calls
+        if (const char* e = getenv("VN_GEMM_ORDER")) g_order = atoi(e);
+        if (const char* e = getenv("VN_GEMM_TILE")) sscanf(e, "%dx%d", &g_force_bm, &g_force_bn);
+        if (const char* e = getenv("VN_GEMM_SCHED")) g_sched = atoi(e);
+        if (const char* e = getenv("VN_GEMM_SPLITK")) g_splitk = atoi(e);
+        return true;
+    }();
+    (void)done;
 }
 
 extern "C" int vn_debug_gemm_config(int bm, int bn, int order) {

@@ -304,11 +304,10 @@ int vn_launch_remask(vn_ctx* ctx, const vn_remask_args& a, hipStream_t s) {
     if (a.B <= 0 || N <= 0) return VN_OK;
     const size_t lds = (size_t)N * sizeof(float);
     if (lds > 120 * 1024) return vn_fail(ctx, VN_ERR_INVALID, "remask: T*Cp=%s%ld too large", "", N);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!(ctx->attr_mask & VN_ATTR_REMASK)) {
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_remask_kernel,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-        attr_set = true;
+        ctx->attr_mask |= VN_ATTR_REMASK;
     }
     hipLaunchKernelGGL(vn_remask_kernel, dim3(a.B), dim3(1024), lds, s, a);
     VN_LAUNCH_CHECK(ctx);

@@ -164,10 +164,9 @@ extern "C" int vn_mt19937_jump(vn_ctx* ctx, const uint32_t* state624, const int3
                                uint32_t* out_states, void* stream) {
     if (!ctx || !state624 || !pos || !polys || !out_states || n_targets <= 0) return VN_ERR_INVALID;
     const size_t lds = (size_t)MT_JUMP_BLOCKS * MT_N * sizeof(uint32_t);
-    static bool attr = false;
-    if (!attr) {
+    if (!(ctx->attr_mask & VN_ATTR_MT_JUMP)) {
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_mt19937_jump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
+        ctx->attr_mask |= VN_ATTR_MT_JUMP;
     }
     hipLaunchKernelGGL(vn_mt19937_jump_kernel, dim3(n_targets), dim3(256), lds, (hipStream_t)stream, state624, pos, polys, out_states);
     VN_LAUNCH_CHECK(ctx);

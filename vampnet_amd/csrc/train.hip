@@ -489,6 +489,7 @@ extern "C" int vn_train_forward_loss(vn_train* t, const int64_t* z_masked, const
     if (rc) return rc;
     if (B <= 0 || T <= 0 || B > m->d.max_batch || T > m->d.max_T)
         return vn_fail(ctx, VN_ERR_INVALID, "train step: B=%s%ld, T=%ld outside the model workspace", "", B, T);
+    t->B = t->T = 0;
     VN_HIP_CHECK(ctx, hipMemsetAsync(grads, 0, (size_t)(t->lora ? t->n_lora : t->n_total) * sizeof(float), s));
     if ((rc = vn_launch_i64_to_i32(ctx, z_masked, m->z, (long)B * m->d.n_codebooks * T, s))) return rc;
     if ((rc = forward_train(t, B, T, p, s))) return rc;
@@ -528,6 +529,7 @@ extern "C" int vn_train_forward(vn_train* t, const int64_t* z_masked, int B, int
     if (rc) return rc;
     if (B <= 0 || T <= 0 || B > m->d.max_batch || T > m->d.max_T)
         return vn_fail(ctx, VN_ERR_INVALID, "train forward: B=%s%ld, T=%ld outside the model workspace", "", B, T);
+    t->B = t->T = 0;                            // the stash is overwritten: a pending staged backward must not use it
     if ((rc = vn_launch_i64_to_i32(ctx, z_masked, m->z, (long)B * m->d.n_codebooks * T, s))) return rc;
     if ((rc = forward_train(t, B, T, p, s))) return rc;
     VN_HIP_CHECK(ctx, hipMemcpyAsync(logits, m->logits, (size_t)B * T * t->NV * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -546,6 +548,7 @@ extern "C" int vn_train_eval(vn_train* t, const int64_t* z_masked, const int64_t
     vn_train_params p{};
     p.step = 1; p.world_size = 1; p.dropout = 0.f;
     int rc;
+    t->B = t->T = 0;                            // the stash is overwritten: a pending staged backward must not use it
     if ((rc = vn_launch_i64_to_i32(ctx, z_masked, m->z, (long)B * m->d.n_codebooks * T, s))) return rc;
     if ((rc = forward_train(t, B, T, &p, s))) return rc;
     return vn_launch_eval_rows(ctx, m->logits, target, (long)B * T * m->Cp, m->d.vocab, label_smoothing, row_loss, rank, s);
@@ -615,13 +618,14 @@ extern "C" int vn_attention_train_f32(vn_ctx* ctx, const float* q, const float* 
     float *full = nullptr, *delta = nullptr;
     int32_t* lut_d = nullptr;
     const int n = 2 * T - 1;
-    VN_HIP_CHECK(ctx, hipMalloc((void**)&full, (size_t)H * n * sizeof(float)));
-    VN_HIP_CHECK(ctx, hipMalloc((void**)&lut_d, (size_t)n * sizeof(int32_t)));
-    VN_HIP_CHECK(ctx, hipMalloc((void**)&delta, (size_t)B * H * T * sizeof(float)));
+    int rc = VN_OK;
+    if (hipMalloc((void**)&full, (size_t)H * n * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&lut_d, (size_t)n * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void**)&delta, (size_t)B * H * T * sizeof(float)) != hipSuccess)
+        rc = vn_fail(ctx, VN_ERR_OOM, "vn_attention_train_f32: scratch allocation failed%s", "");
     std::vector<int32_t> lut(n);
     vn_bucket_lut_host(T, num_buckets, max_distance, lut.data());
-    int rc = VN_OK;
-    if (hipMemcpy(lut_d, lut.data(), n * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) rc = VN_ERR_HIP;
+    if (rc == VN_OK && hipMemcpy(lut_d, lut.data(), n * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) rc = VN_ERR_HIP;
     if (rc == VN_OK) rc = vn_launch_bias_expand(ctx, rel_bias, lut_d, full, H, T, s);
     vn_train_params tp{};
     tp.seed = seed; tp.step = 1; tp.dropout = dropout;

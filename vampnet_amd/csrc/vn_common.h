@@ -114,7 +114,11 @@ struct vn_ctx {
     float* sk_slabs;
     unsigned* sk_flags;
     float* zero_page;
+    // kernels whose dynamic-LDS limit was raised on THIS context's device (hipFuncSetAttribute is per device, and one
+    // process may hold contexts on several)
+    unsigned attr_mask;
 };
+enum { VN_ATTR_ATTN = 1u, VN_ATTR_ATTN_TRAIN = 2u, VN_ATTR_REMASK = 4u, VN_ATTR_MT_JUMP = 8u };
 
 // bracket a launch with events when profiling is on (no-ops otherwise)
 static inline int vn_prof_pre(vn_ctx* ctx, int cls, double flops, hipStream_t s, double bytes = 0.0) {

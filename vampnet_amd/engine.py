@@ -409,10 +409,11 @@ class VampNetModel:
         z = z_masked.to(self.device, torch.int64).contiguous().clone()
         B, Cn, T = z.shape
         sampled = torch.empty_like(z)
+        logits_native = logits_native.contiguous()             # held in a local: the kernels read (and top-p edits) it
         params = self._params(steps, temperature, mask_temperature, sample_cutoff, top_p, n0, device_seed)
         k = (C.c_int64 * B)(*([self.mask_schedule(steps, n0)[step]] * B))
         self.engine.check(self.lib.vn_sample_step(
-            self.handle, z.data_ptr(), logits_native.contiguous().data_ptr(), B, T, step, C.byref(params), k,
+            self.handle, z.data_ptr(), logits_native.data_ptr(), B, T, step, C.byref(params), k,
             exp_noise.data_ptr() if exp_noise is not None else None,
             unif_noise.data_ptr() if unif_noise is not None else None, sampled.data_ptr(), self.engine.stream()),
             "vn_sample_step")

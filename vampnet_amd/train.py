@@ -267,12 +267,13 @@ class Trainer:
         mask = mask.to(z.device).clone()
         mask[:, :self.n_cond, :] = 0
         z_mask, mask = masks.apply_mask(z, mask, self.mask_token)
+        z_mask = z_mask.contiguous()
         B, _, T = z.shape
         target = z[:, self.n_cond:, :].permute(0, 2, 1).reshape(B, -1).contiguous()
         flat = mask[:, self.n_cond:, :].permute(0, 2, 1).reshape(B, -1).bool()
         row_loss = torch.empty(B, T * self.Cp, device=z.device, dtype=torch.float32)
         rank = torch.empty(B, T * self.Cp, device=z.device, dtype=torch.int32)
-        self.engine.check(self.lib.vn_train_eval(self.handle, z_mask.contiguous().data_ptr(), target.data_ptr(), B, T,
+        self.engine.check(self.lib.vn_train_eval(self.handle, z_mask.data_ptr(), target.data_ptr(), B, T,
                                                  self.hp["label_smoothing"], row_loss.data_ptr(), rank.data_ptr(),
                                                  self.engine.stream()), "vn_train_eval")
         out = {"loss": row_loss[flat].mean() if bool(flat.any()) else row_loss.sum() * 0.0}
