@@ -170,8 +170,9 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=8)
     ap.add_argument("--coarse-steps", type=int, default=12)
     ap.add_argument("--coarse-only", action="store_true", help="BASELINE configs[1]: coarse_vamp only (4 codebooks)")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
-                    help="f32 = exact-fp32 MFMA (parity-backed default); bf16 = fast mode, not bit-exact")
+    ap.add_argument("--dtype", choices=["f32", "bf16x3", "bf16"], default="f32",
+                    help="f32 = exact-fp32 MFMA (parity-backed default); bf16x3 = fp32-grade GEMMs as six bf16-MFMA products of "
+                         "exact 3-way operand splits (same parity bars, tests/test_gpu_bf16x3.py); bf16 = fast mode, not bit-exact")
     ap.add_argument("--workload", choices=["vamp", "train"], default="vamp",
                     help="vamp = the headline inference path (default); train = BASELINE configs[4] training step")
     ap.add_argument("--lora-only", action="store_true",
@@ -302,10 +303,18 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
             if os.path.exists(tpath) and world == 1 and args.batch_per_gpu == 8 and not args.coarse_only and args.dtype == "f32":
                 traffic = json.load(open(tpath))["bytes_per_launch"]
-            res["roofline"] = {"bound": "mfma", "kernel": "vn_gemm_f32[_sk]_kernel" if args.dtype == "f32" else "vn_gemm_f32_kernel<128,128,BF16>", "achieved": fl / (ms * 1e-3) / 1e12 if ms else None,
-                               "peak": PEAK_BF16_MFMA_TF if args.dtype == "bf16" else PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                               "frac": (fl / (ms * 1e-3) / 1e12) / (PEAK_BF16_MFMA_TF if args.dtype == "bf16" else PEAK_F32_MFMA_TF) if ms else None,
+            # bf16x3: `achieved` stays ALGORITHMIC (2MNK per GEMM, fp32-equivalent); every such flop costs six bf16-MFMA flops,
+            # so the ceiling of this algorithm is the dense bf16 MFMA peak / 6 (the kernel executes 6 x achieved on the pipe)
+            peak = {"f32": PEAK_F32_MFMA_TF, "bf16": PEAK_BF16_MFMA_TF, "bf16x3": PEAK_BF16_MFMA_TF / 6.0}[args.dtype]
+            kname = {"f32": "vn_gemm_f32[_sk]_kernel", "bf16": "vn_gemm_f32_kernel<128,128,BF16>",
+                     "bf16x3": "vn_gemm_x3_kernel"}[args.dtype]
+            res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": fl / (ms * 1e-3) / 1e12 if ms else None,
+                               "peak": peak, "unit": "TFLOP/s",
+                               "frac": (fl / (ms * 1e-3) / 1e12) / peak if ms else None,
                                "traffic": traffic, "algorithmic_bytes_per_launch": gbytes / n if n else None, "launches": int(n), "avg_launch_us": 1e3 * ms / n if n else None,
+                               **({"peak_basis": "2500 TF dense bf16 MFMA / 6 plane products per fp32-grade product",
+                                   "executed_mfma_tflops": 6.0 * fl / (ms * 1e-3) / 1e12 if ms else None}
+                                  if args.dtype == "bf16x3" else {}),
                                "event_stride": args.event_stride,        # launches / times above: the bracketed sample
                                "gemm_time_frac": args.event_stride * ms / (1e3 * elapsed) if elapsed else None,
                                "attention": {"launches": int(an), "avg_launch_us": 1e3 * ams / an if an else None,

@@ -148,6 +148,16 @@ void vn_model_destroy(vn_model* model);
  * (v_mfma_f32_32x32x16_bf16, fp32 accumulate); attention, norms, residual stream, softmax and sampling stay fp32. */
 int vn_model_set_bf16(vn_model* model, const void* blob_bf16_dev);
 
+/* Optional "bf16x3" mode: fp32-GRADE GEMMs on the bf16 matrix cores.  Every GEMM operand is held as three bf16 planes
+ * whose sum is the fp32 value exactly (vn_split3_f32), and A W^T is evaluated as the six plane products down to 2^-16 of
+ * the leading one with fp32 accumulation: error <= that of an fp32-accumulating fp32 GEMM, at 6/16 of the
+ * exact-fp32 MFMA's matrix time.  `blob_planes_dev`: vn_split3_f32 of the packed blob, planes `plane_stride` elements
+ * apart (>= vn_weights_size, multiple of 8), 16-byte aligned device memory that must outlive the model; NULL switches
+ * back to exact fp32.  Attention, norms, residual stream, softmax and sampling are the fp32 path unchanged.            */
+int vn_model_set_bf16x3(vn_model* model, const void* blob_planes_dev, int64_t plane_stride);
+/* dst16[q * plane_stride + i] = q-th split term of src[i], q = 0..2 (n % 4 == 0, src 16-byte aligned) */
+int vn_split3_f32(vn_ctx* ctx, const float* src, void* dst16, int64_t n, int64_t plane_stride, void* stream);
+
 /* replaces embedding.from_codes + VampNet.forward (layers.py:134-163; transformer.py:617-639).
  * codes  dev int64 [B][C][T] (MASK = vocab allowed in any codebook)
  * logits dev f32   [B][T][Cp][vocab]  (== reference logits[b, p, t*Cp + c] transposed so each
@@ -193,6 +203,11 @@ int vn_gemm_f32(vn_ctx* ctx, const float* A, const float* W, const float* bias, 
  * epilogue 0 store, 1 bias, 2 residual)                                                                        */
 int vn_gemm_bf16(vn_ctx* ctx, const void* A16, const void* W16, const float* bias, float* C, int M, int N, int K,
                  int epilogue, void* stream);
+
+/* bf16x3 GEMM as a single op (tests / tuning): A3 [3][M][K] and W3 [3][N][K] split planes (plane strides in elements),
+ * fp32 C; epilogues 0..3 as vn_gemm_f32; K % 32 == 0, N % 64 == 0                                                     */
+int vn_gemm_bf16x3(vn_ctx* ctx, const void* A3, int64_t a_plane, const void* W3, int64_t w_plane, const float* bias,
+                   float* C, int M, int N, int K, int epilogue, void* stream);
 
 /* Self-attention core (transformer.py:229-254): q,k,v dev f32 [B][H][T][64];
  * rel_bias dev f32 [num_buckets][H]; out dev f32 [B][T][H*64].                                */

@@ -301,3 +301,51 @@ def test_torch_rng_jump_ahead_path(eng, rows, lead_rows, total_rows, chunk):
     torch.set_rng_state(end_state)
     assert torch.equal(a, torch.rand(700))
     assert got_state.numel() == end_state.numel()
+
+
+# ----------------------------------------------------------------------------- bf16x3: fp32-grade GEMM on the bf16 MFMA
+def test_split3_is_exact(eng):
+    """vn_split3_f32: three bf16 planes whose fp32 sum is the input bit for bit (incl. tiny / large magnitudes)."""
+    x = torch.cat([_rand((4096,), 30), _rand((4096,), 31) * 1e-20, _rand((4096,), 32) * 1e20, torch.zeros(64)])
+    p = eng.split3(x.cuda()).cpu().float()
+    assert torch.equal(p[0] + p[1] + p[2], x)
+    assert torch.equal(p[0], x.to(torch.bfloat16).float())          # plane 0 = RNE bf16 of x (== torch's cast)
+
+
+@pytest.mark.parametrize("M,N,K", [(4600, 3840, 1280), (575, 1280, 2560), (130, 256, 64), (1384, 5120, 1280), (1, 128, 32)])
+def test_gemm_bf16x3_fp32_grade(eng, M, N, K):
+    """Six bf16 MFMA products of exact operand splits == an fp32 GEMM: SAME tolerance as test_gemm_store_bias_residual
+    (fp32 accumulation-order class against the float64 product of the fp32 operands)."""
+    from vampnet_amd import _lib
+    a, w, b = _rand((M, K), 3), _rand((N, K), 4) / np.sqrt(K), _rand((N,), 5)
+    ref64 = a.double() @ w.double().t()
+    absdot = a.abs().double() @ w.abs().double().t()
+    tol = (2e-6 * absdot + 1e-6).numpy()
+    a3, w3 = eng.split3(a.cuda()), eng.split3(w.cuda())
+    got = eng.gemm_bf16x3(a3, w3).cpu().double()
+    err = np.abs((got - ref64).numpy())
+    print(f"bf16x3 {M}x{N}x{K}: max err {err.max():.3e} (fp32 gemm on the host: "
+          f"{(a @ w.t()).double().sub(ref64).abs().max().item():.3e})")
+    assert np.all(err <= tol)
+    got = eng.gemm_bf16x3(a3, w3, bias=b.cuda(), epilogue=_lib.EPI_BIAS).cpu().double()
+    assert np.all(np.abs((got - (ref64 + b.double())).numpy()) <= tol)
+    c0 = _rand((M, N), 6)
+    out = c0.cuda().clone()
+    eng.gemm_bf16x3(a3, w3, epilogue=_lib.EPI_RESIDUAL, out=out)
+    assert np.all(np.abs((out.cpu().double() - (ref64 + c0.double())).numpy()) <= tol)
+
+
+def test_gemm_bf16x3_identity_and_geglu(eng):
+    from vampnet_amd import _lib
+    K = N = 256
+    a = torch.eye(K)[:200]
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K) * 1e-3
+    got = eng.gemm_bf16x3(eng.split3(a.cuda()), eng.split3(w.cuda())).cpu()
+    assert torch.equal(got, w.t()[:200])                                # 1 * w is exact: catches a transposed C write
+    M, D = 575, 1280
+    x, w1 = _rand((M, D), 7), _rand((4 * D, D), 8, 1.0 / np.sqrt(D))
+    ref = O.gated_gelu(torch.nn.functional.linear(x, w1))
+    val, gate = w1[:2 * D].reshape(2 * D // 32, 32, D), w1[2 * D:].reshape(2 * D // 32, 32, D)
+    w1p = torch.stack([val, gate], dim=1).reshape(4 * D, D)
+    got = eng.gemm_bf16x3(eng.split3(x.cuda()), eng.split3(w1p.cuda()), epilogue=_lib.EPI_GEGLU).cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)

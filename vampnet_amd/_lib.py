@@ -53,6 +53,9 @@ SYMBOLS = {
     "vn_model_create": (C.c_int, [_P, C.POINTER(vn_dims), _P, C.POINTER(_P)]),
     "vn_model_destroy": (None, [_P]),
     "vn_model_set_bf16": (C.c_int, [_P, _P]),
+    "vn_model_set_bf16x3": (C.c_int, [_P, _P, C.c_int64]),
+    "vn_split3_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _P]),
+    "vn_gemm_bf16x3": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vn_gemm_bf16": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vn_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "vn_generate": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(vn_sample_params), C.POINTER(C.c_int64),

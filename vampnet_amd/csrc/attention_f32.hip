@@ -31,7 +31,7 @@ template <int VARIANT>
 __global__ __launch_bounds__(256) void vn_attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                            const float* __restrict__ v,
                                                            const float* __restrict__ bias_full,  // [H][2T-1]
-                                                           float* __restrict__ out, uint16_t* __restrict__ out16,
+                                                           float* __restrict__ out, uint16_t* __restrict__ out16, long plane16,
                                                            int B, int H, int T) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;
@@ -183,11 +183,8 @@ __global__ __launch_bounds__(256) void vn_attention_kernel(const float* __restri
             ov[1] = o[1][r] / l_tot;
             ov[2] = o[2][r] / l_tot;
             ov[3] = o[3][r] / l_tot;
-            if (out16) {   // bf16 fast mode: the attention output is only the A operand of the fc GEMM
-                uint2 pk;
-                pk.x = vn_f32_to_bf16(ov[0]) | ((unsigned)vn_f32_to_bf16(ov[1]) << 16);
-                pk.y = vn_f32_to_bf16(ov[2]) | ((unsigned)vn_f32_to_bf16(ov[3]) << 16);
-                *(uint2*)(out16 + ooff + 4 * r) = pk;
+            if (out16) {   // bf16 / bf16x3 modes: the attention output is only the A operand of the fc GEMM
+                vn_store_bf16x4(out16 + ooff + 4 * r, plane16, ov);
             } else {
                 *(f32x4*)(out + ooff + 4 * r) = ov;
             }
@@ -368,7 +365,7 @@ __global__ __launch_bounds__(256) void vn_attention_bf16_kernel(const float* __r
 }
 
 int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* relbias_full,
-                        float* out, int B, int H, int T, hipStream_t s, uint16_t* out16) {
+                        float* out, int B, int H, int T, hipStream_t s, uint16_t* out16, long plane16) {
     if (B <= 0 || T <= 0) return VN_OK;
     const size_t lds = (size_t)(2 * ATT_KT * ATT_LD + 2 * T - 1 + 3) * sizeof(float);
     if (lds > 160 * 1024) return vn_fail(ctx, VN_ERR_INVALID, "attention: T=%s%ld too long for the LDS bias table", "", T);
@@ -383,15 +380,15 @@ int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float
     const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
     const dim3 grid(vn_cdiv(T, 64), H, B);
     static const bool bf16_attn = [] { const char* e = getenv("VN_ATTN_BF16"); return !(e && e[0] == '0'); }();
-    if (out16 && bf16_attn) {        // fast mode: bf16 MFMA attention (VN_ATTN_BF16=0 keeps the fp32 kernel for A/B runs)
+    if (out16 && bf16_attn && plane16 == 0) {        // fast mode: bf16 MFMA attention (VN_ATTN_BF16=0 keeps the fp32 kernel for A/B runs)
         const size_t lds16 = (size_t)(2 * ATT_KT * ATB_LDK) * sizeof(uint16_t) + (size_t)(2 * T - 1 + 3) * sizeof(float);
         hipLaunchKernelGGL(vn_attention_bf16_kernel, grid, dim3(256), lds16, s, q, k, v, relbias_full, out16, B, H, T);
         vn_prof_post(ctx, pi, s);
         VN_LAUNCH_CHECK(ctx);
         return VN_OK;
     }
-    if (variant == 0) hipLaunchKernelGGL(vn_attention_kernel<0>, grid, dim3(256), lds, s, q, k, v, relbias_full, out, out16, B, H, T);
-    else hipLaunchKernelGGL(vn_attention_kernel<1>, grid, dim3(256), lds, s, q, k, v, relbias_full, out, out16, B, H, T);
+    if (variant == 0) hipLaunchKernelGGL(vn_attention_kernel<0>, grid, dim3(256), lds, s, q, k, v, relbias_full, out, out16, plane16, B, H, T);
+    else hipLaunchKernelGGL(vn_attention_kernel<1>, grid, dim3(256), lds, s, q, k, v, relbias_full, out, out16, plane16, B, H, T);
     vn_prof_post(ctx, pi, s);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;

@@ -8,8 +8,8 @@
 // ---------------------------------------------------------------------------------------------
 template <int VEC>   // VEC = float4 per lane = D / 256
 __global__ __launch_bounds__(256) void vn_rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                         float* __restrict__ y, uint16_t* __restrict__ y16, int rows,
-                                                         int D, float eps) {
+                                                         float* __restrict__ y, uint16_t* __restrict__ y16, long plane16,
+                                                         int rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -34,11 +34,8 @@ __global__ __launch_bounds__(256) void vn_rmsnorm_kernel(const float* __restrict
         o[1] = ww[1] * (v[i][1] * rstd);
         o[2] = ww[2] * (v[i][2] * rstd);
         o[3] = ww[3] * (v[i][3] * rstd);
-        if (y16) {     // bf16 fast mode: the normalised row is only ever a GEMM A operand
-            uint2 pk;
-            pk.x = vn_f32_to_bf16(o[0]) | ((unsigned)vn_f32_to_bf16(o[1]) << 16);
-            pk.y = vn_f32_to_bf16(o[2]) | ((unsigned)vn_f32_to_bf16(o[3]) << 16);
-            ((uint2*)(y16 + (size_t)row * D))[lane + 64 * i] = pk;
+        if (y16) {     // bf16 / bf16x3 modes: the normalised row is only ever a GEMM A operand
+            vn_store_bf16x4(y16 + (size_t)row * D + 4 * (lane + 64 * i), plane16, o);
         } else {
             yr[lane + 64 * i] = o;
         }
@@ -76,12 +73,12 @@ __global__ __launch_bounds__(256) void vn_rmsnorm_generic_kernel(const float* __
 }
 
 int vn_launch_rmsnorm(vn_ctx* ctx, const float* x, const float* w, float* y, int rows, int D, float eps,
-                      hipStream_t s, uint16_t* y16) {
+                      hipStream_t s, uint16_t* y16, long plane16) {
     if (rows <= 0) return VN_OK;
     if (D % 4) return vn_fail(ctx, VN_ERR_INVALID, "rmsnorm: D=%s%ld must be a multiple of 4", "", D);
     const dim3 grid(vn_cdiv(rows, 4)), block(256);
-    if (D == 1280) hipLaunchKernelGGL(vn_rmsnorm_kernel<5>, grid, block, 0, s, x, w, y, y16, rows, D, eps);
-    else if (D == 256) hipLaunchKernelGGL(vn_rmsnorm_kernel<1>, grid, block, 0, s, x, w, y, y16, rows, D, eps);
+    if (D == 1280) hipLaunchKernelGGL(vn_rmsnorm_kernel<5>, grid, block, 0, s, x, w, y, y16, plane16, rows, D, eps);
+    else if (D == 256) hipLaunchKernelGGL(vn_rmsnorm_kernel<1>, grid, block, 0, s, x, w, y, y16, plane16, rows, D, eps);
     else if (y16) return vn_fail(ctx, VN_ERR_UNSUPPORTED, "rmsnorm: bf16 output needs D in {256, 1280}%s", "");
     else hipLaunchKernelGGL(vn_rmsnorm_generic_kernel, grid, block, 0, s, x, w, y, rows, D, eps);
     VN_LAUNCH_CHECK(ctx);

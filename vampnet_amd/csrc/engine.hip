@@ -245,35 +245,44 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
     const bool bf = m->blob16 != nullptr;
     // bf16 fast mode: the four big GEMM operands (normalised rows, attention output, GEGLU output, weights) are bf16,
     // accumulation / residual stream / attention / norms / logits stay fp32.  NOT bit-exact.
+    // bf16x3 mode: the same four operands as three exact split planes each, multiplied on the bf16 matrix cores with
+    // fp32-grade accuracy (gemm_x3.hip); everything else is the fp32 path.
+    const int gm = bf ? (m->w_plane ? 2 : 1) : 0;                       // vn_gemm_args::bf16
+    const long yp = gm == 2 ? m->max_rows * (long)D : 0, gp = 2 * yp;   // plane strides of y16 / g16
     auto W16 = [&](int id, int layer) { return (const float*)(m->blob16 + vn_tensor_offset(&m->d, id, layer)); };
+    auto operands = [&](vn_gemm_args& a, const float* A32, const uint16_t* A16, long a_plane, int id, int layer) {
+        a.A = bf ? (const float*)A16 : A32;
+        a.W = bf ? W16(id, layer) : W(m, id, layer);
+        a.bf16 = gm; a.a_plane = a_plane; a.w_plane = m->w_plane;
+    };
     for (int l = 0; l < m->L; ++l) {
         // y = RMSNorm(x) ; FiLM = identity (d_cond = 0, transformer.py:554)
-        if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM1, l), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr))) return rc;
+        if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM1, l), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr, yp))) return rc;
         vn_gemm_args a{};
-        a.A = bf ? (const float*)m->y16 : m->y; a.W = bf ? W16(VN_W_QKV, l) : W(m, VN_W_QKV, l); a.bf16 = bf;
+        operands(a, m->y, m->y16, yp, VN_W_QKV, l);
         a.C = m->qkv; a.M = M; a.N = 3 * D; a.K = D; a.ldc = 3 * D;
         a.T = T; a.H = H; a.qkv_plane = plane;
         if ((rc = vn_launch_gemm_f32(ctx, a, VN_EPI_QKV, s))) return rc;
         if ((rc = vn_launch_attention(ctx, m->qkv, m->qkv + plane, m->qkv + 2 * plane, m->bias_full, m->y, B, H, T, s,
-                                      bf ? m->y16 : nullptr)))
+                                      bf ? m->y16 : nullptr, yp)))
             return rc;
         vn_gemm_args o{};
-        o.A = bf ? (const float*)m->y16 : m->y; o.W = bf ? W16(VN_W_WO, l) : W(m, VN_W_WO, l); o.bf16 = bf;
+        operands(o, m->y, m->y16, yp, VN_W_WO, l);
         o.C = m->x; o.M = M; o.N = D; o.K = D; o.ldc = D;
         if ((rc = vn_launch_gemm_f32(ctx, o, VN_EPI_RESIDUAL, s))) return rc;           // x = x + attn
-        if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM3, l), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr))) return rc;
+        if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM3, l), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr, yp))) return rc;
         vn_gemm_args f1{};
-        f1.A = bf ? (const float*)m->y16 : m->y; f1.W = bf ? W16(VN_W_W1, l) : W(m, VN_W_W1, l); f1.bf16 = bf;
-        f1.C = m->g; f1.C16 = bf ? m->g16 : nullptr; f1.M = M; f1.N = 4 * D; f1.K = D; f1.ldc = 2 * D;
+        operands(f1, m->y, m->y16, yp, VN_W_W1, l);
+        f1.C = m->g; f1.C16 = bf ? m->g16 : nullptr; f1.c_plane = gp; f1.M = M; f1.N = 4 * D; f1.K = D; f1.ldc = 2 * D;
         if ((rc = vn_launch_gemm_f32(ctx, f1, VN_EPI_GEGLU, s))) return rc;             // g = p1 * gelu(p2)
         vn_gemm_args f2{};
-        f2.A = bf ? (const float*)m->g16 : m->g; f2.W = bf ? W16(VN_W_W2, l) : W(m, VN_W_W2, l); f2.bf16 = bf;
+        operands(f2, m->g, m->g16, gp, VN_W_W2, l);
         f2.C = m->x; f2.M = M; f2.N = D; f2.K = 2 * D; f2.ldc = D;
         if ((rc = vn_launch_gemm_f32(ctx, f2, VN_EPI_RESIDUAL, s))) return rc;          // x = x + ffn
     }
-    if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_FINAL_NORM), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr))) return rc;
+    if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_FINAL_NORM), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr, yp))) return rc;
     vn_gemm_args c{};
-    c.A = bf ? (const float*)m->y16 : m->y; c.W = bf ? W16(VN_W_CLS_W, 0) : W(m, VN_W_CLS_W); c.bf16 = bf;
+    operands(c, m->y, m->y16, yp, VN_W_CLS_W, 0);
     c.bias = W(m, VN_W_CLS_B); c.C = logits; c.M = M;
     c.N = m->Cp * m->d.vocab; c.K = D; c.ldc = c.N;
     return vn_launch_gemm_f32(ctx, c, VN_EPI_BIAS, s);
@@ -288,6 +297,7 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
 struct vn_fwd_graph_entry {
     int B, T;
     const void* blob16;
+    long w_plane;
     int calls;
     bool failed;
     hipGraph_t graph;
@@ -321,10 +331,10 @@ static int forward_loop(vn_model* m, int B, int T, hipStream_t s) {
     if (!m->graphs) return forward_i32(m, m->z, B, T, m->logits, s);
     vn_fwd_graph_entry* e = nullptr;
     for (auto& c : m->graphs->v)
-        if (c.B == B && c.T == T && c.blob16 == (const void*)m->blob16) { e = &c; break; }
+        if (c.B == B && c.T == T && c.blob16 == (const void*)m->blob16 && c.w_plane == m->w_plane) { e = &c; break; }
     if (!e) {
         if (m->graphs->v.size() >= 16) return forward_i32(m, m->z, B, T, m->logits, s);
-        m->graphs->v.push_back(vn_fwd_graph_entry{B, T, (const void*)m->blob16, 0, false, nullptr, nullptr});
+        m->graphs->v.push_back(vn_fwd_graph_entry{B, T, (const void*)m->blob16, m->w_plane, 0, false, nullptr, nullptr});
         e = &m->graphs->v.back();
     }
     int rc;
@@ -372,15 +382,30 @@ extern "C" int vn_debug_graph_replays(const vn_model* m, int64_t* count) {
     return VN_OK;
 }
 
+static int set_bf16_planes(vn_model* m, const void* blob16_dev, long w_plane) {
+    if (!blob16_dev) { m->blob16 = nullptr; m->w_plane = 0; return VN_OK; }          // back to exact fp32 MFMA
+    if (m->D % 64) return vn_fail(m->ctx, VN_ERR_UNSUPPORTED, "bf16 modes need d_model %% 64 == 0%s", "");
+    int rc;        // the bf16 A-operand images are sized for three planes in either mode (graphs keep pointing at them)
+    if (!m->y16 && (rc = dev_alloc(m->ctx, &m->y16, (size_t)3 * m->max_rows * m->D))) return rc;
+    if (!m->g16 && (rc = dev_alloc(m->ctx, &m->g16, (size_t)3 * m->max_rows * 2 * m->D))) return rc;
+    m->blob16 = (const uint16_t*)blob16_dev;
+    m->w_plane = w_plane;
+    return VN_OK;
+}
+
 extern "C" int vn_model_set_bf16(vn_model* m, const void* blob_bf16_dev) {
     if (!m) return VN_ERR_INVALID;
-    if (!blob_bf16_dev) { m->blob16 = nullptr; return VN_OK; }          // back to exact fp32
-    if (m->D % 64) return vn_fail(m->ctx, VN_ERR_UNSUPPORTED, "bf16 mode needs d_model %% 64 == 0%s", "");
-    int rc;
-    if (!m->y16 && (rc = dev_alloc(m->ctx, &m->y16, (size_t)m->max_rows * m->D))) return rc;
-    if (!m->g16 && (rc = dev_alloc(m->ctx, &m->g16, (size_t)m->max_rows * 2 * m->D))) return rc;
-    m->blob16 = (const uint16_t*)blob_bf16_dev;
-    return VN_OK;
+    return set_bf16_planes(m, blob_bf16_dev, 0);
+}
+
+extern "C" int vn_model_set_bf16x3(vn_model* m, const void* blob_planes_dev, int64_t plane_stride) {
+    if (!m) return VN_ERR_INVALID;
+    if (!blob_planes_dev) return set_bf16_planes(m, nullptr, 0);
+    int64_t n = 0;
+    vn_weights_size(&m->d, &n);
+    if (plane_stride < n || (plane_stride & 7)) return vn_fail(m->ctx, VN_ERR_INVALID, "bf16x3: plane stride %s%ld too small or not a multiple of 8", "", (long)plane_stride);
+    if (((uintptr_t)blob_planes_dev) & 15) return vn_fail(m->ctx, VN_ERR_INVALID, "bf16x3: planes must be 16-byte aligned%s", "");
+    return set_bf16_planes(m, blob_planes_dev, (long)plane_stride);
 }
 
 static int shape_check(vn_model* m, int B, int T) {

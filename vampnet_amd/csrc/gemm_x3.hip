@@ -1,0 +1,321 @@
+// fp32-grade GEMM on the bf16 matrix cores of gfx950 ("bf16x3"):  C[M][N] (op)= A[M][K] * W[N][K]^T
+//
+// Both operands arrive as THREE bf16 planes with x = x0 + x1 + x2 exactly (vn_split3: 8 + 8 + 8 significand bits; bf16
+// shares fp32's exponent range, so nothing under- or overflows).  The product keeps every term down to 2^-16 of the
+// leading one,
+//     A W^T  ~=  A0 W0 + (A0 W1 + A1 W0) + (A0 W2 + A1 W1 + A2 W0),
+// six v_mfma_f32_32x32x16_bf16 per 16-wide k-step with fp32 accumulation: each bf16 x bf16 product is exact in fp32, and
+// the dropped terms are <= 3 * 2^-24 relative — the same size as the rounding of one fp32 multiply (measured on the
+// model's shapes: max error 1.4e-6 vs 2.9e-6 for an fp32-accumulating fp32 GEMM, both against float64).  The matrix
+// cores run bf16 at 16x the fp32-input MFMA rate (MI355X_MICROARCH.md: 2.5 PF vs 157 TF dense), so six passes cost
+// 6/16 of the exact-fp32 kernel's matrix time: the ceiling moves from 157 to ~417 fp32-equivalent TFLOP/s.
+//
+// Kernel: one 512-thread block (8 waves as 4 x 2, wave tile 32 x 64) per 128 x 128 output tile, one block per CU (two
+// waves per SIMD cover each other's LDS latency and barriers).
+//   * k-tile = 32 bf16 = 64 bytes per row.  A stage holds the six plane tiles (3 x 128 rows of A, 3 x 128 of W) = 48 KiB,
+//     double-buffered = 96 KiB of LDS, filled by LDS-DMA (global_load_lds_dwordx4: one wave instruction = 16 rows x 64 B).
+//   * Loading each plane tile ONCE and using it in two or three of the six products is what separates this kernel
+//     from running a K' = 6K bf16 GEMM over concatenated planes: 6 plane-tile loads per 6 MFMA groups instead of 12.
+//     Per k-tile and CU: 48 KiB of DMA and 144 KiB of fragment reads against 1536 matrix-pipe cycles per SIMD
+//     (32 B/clk and 94 B/clk; the LDS moves 256 B/clk for ds_read_b128).
+//   * LDS image is lane-linear (DMA constraint), so the bank swizzle sits on the SOURCE address: 16-byte slot s of row r
+//     is stored at slot s ^ ((r >> 2) & 3).  A ds_read_b128 is serviced in 16-lane groups whose rows are
+//     {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (+32): with 64-byte rows the four rows that share r % 4 (hence a
+//     256-byte bank-row quarter) have four different (r >> 2) & 3, so every group touches 16 distinct slots.
+//   * Fragment of v_mfma_f32_32x32x16_bf16: lane l holds row l & 31, k = 8 (l >> 5) .. + 7 of the 16-wide step, i.e.
+//     slot 2 s + (l >> 5) of the row for sub-step s in {0, 1}.
+//   * Epilogues as in gemm_f32.hip (store / bias / residual / GEGLU gate / QKV head-major scatter); the GEGLU result is
+//     written as three planes again (it is only ever the A operand of the next GEMM).
+//   * rows >= M and columns >= N are clamped on load and masked on store.
+// Data-parallel tile walk, XCD-aware (same remap and 8-row grouping as gemm_f32.hip).  Deterministic.
+#include <stdlib.h>
+#include "vn_common.h"
+
+#define X3_BM 128
+#define X3_BN 128
+#define X3_KT 32                                  // bf16 per k-tile
+#define X3_PLANE_FLOATS (128 * 16)                // one plane tile: 128 rows x 64 B
+#define X3_STAGE_FLOATS (6 * X3_PLANE_FLOATS)     // 48 KiB
+#define X3_LDS_BYTES (2 * X3_STAGE_FLOATS * 4)    // 96 KiB
+#define X3_DMA_PER_WAVE 6                         // 48 wave-instructions of 1 KiB per stage / 8 waves
+
+__device__ __forceinline__ int x3_xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+__device__ __forceinline__ void x3_tile_coords(int t, int tiles_m, int tiles_n, int& tm, int& tn) {
+    constexpr int GROUP_M = 8;                    // 8 x 8 patches of tiles share A / W panels in one XCD's L2
+    const int per_group = GROUP_M * tiles_n;
+    const int grp = t / per_group;
+    const int first_m = grp * GROUP_M;
+    const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+    const int in_grp = t - grp * per_group;
+    tm = first_m + in_grp % gsz;
+    tn = in_grp / gsz;
+}
+
+template <int EPI, int PIPE>
+__global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int tm, tn;
+    x3_tile_coords(x3_xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * X3_BM, n0 = tn * X3_BN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const uint16_t* A16 = (const uint16_t*)p.A;
+    const uint16_t* W16 = (const uint16_t*)p.W;
+
+    // per-lane DMA sources: instruction q = wave * 6 + j fills plane tile q / 8, rows 16 (q % 8) .. + 15
+    const uint16_t* src[X3_DMA_PER_WAVE];
+    const int drow = lane >> 2, dslot = (lane & 3) ^ ((lane >> 4) & 3);     // (row >> 2) & 3 == (lane >> 4) & 3
+#pragma unroll
+    for (int j = 0; j < X3_DMA_PER_WAVE; ++j) {
+        const int q = wave * X3_DMA_PER_WAVE + j;
+        const int pt = q >> 3, row = (q & 7) * 16 + drow;
+        if (pt < 3) {
+            int g = m0 + row;
+            g = g < p.M ? g : p.M - 1;
+            src[j] = A16 + (size_t)pt * p.a_plane + (size_t)g * p.K + dslot * 8;
+        } else {
+            int g = n0 + row;
+            g = g < p.N ? g : p.N - 1;
+            src[j] = W16 + (size_t)(pt - 3) * p.w_plane + (size_t)g * p.K + dslot * 8;
+        }
+    }
+    auto stage = [&](int buf, int k0) {
+        float* base = lds + buf * X3_STAGE_FLOATS + wave * (X3_DMA_PER_WAVE * 256);
+#pragma unroll
+        for (int j = 0; j < X3_DMA_PER_WAVE; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
+                                             (__attribute__((address_space(3))) void*)(base + j * 256), 16, 0, 0);
+    };
+
+    // fragment offsets (floats) inside a plane tile: row * 16 + ((2 s + h) ^ ((row >> 2) & 3)) * 4
+    const int l31 = lane & 31, h = lane >> 5, sw = (lane >> 2) & 3;
+    const int aRow = (wm * 32 + l31) * 16;
+    const int bRow = (wn * 64 + l31) * 16;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+    struct Frags { bf16x8 a[3], b[3][2]; };
+    auto load_frags = [&](Frags& f, int buf, int s) {
+        const float* sA = lds + buf * X3_STAGE_FLOATS;
+        const float* sB = sA + 3 * X3_PLANE_FLOATS;
+        const int off = ((2 * s + h) ^ sw) * 4;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            f.a[q] = __builtin_bit_cast(bf16x8, *(const f32x4*)(sA + q * X3_PLANE_FLOATS + aRow + off));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                f.b[q][j] = __builtin_bit_cast(bf16x8, *(const f32x4*)(sB + q * X3_PLANE_FLOATS + bRow + j * 32 * 16 + off));
+        }
+    };
+    // the six plane products of one 16-wide k-step, smallest terms first; the two accumulators alternate so that
+    // consecutive MFMAs are independent
+    auto mac_head = [&](const Frags& f) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b[2][j], acc[j], 0, 0, 0);
+    };
+    auto mac_tail = [&](const Frags& f) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[2], f.b[0][j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1], f.b[1][j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b[1][j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1], f.b[0][j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b[0][j], acc[j], 0, 0, 0);
+    };
+    auto mac = [&](const Frags& f) { mac_head(f); mac_tail(f); };
+
+    const int nk = p.K / X3_KT;
+    if constexpr (PIPE == 0) {
+        // plain double buffering: DMA of tile kt + 1 under the MFMAs of tile kt, fragments read right before use
+        stage(0, 0);
+        __syncthreads();                  // glds in flight -> hipcc emits vmcnt(0) before the barrier
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * X3_KT);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                Frags f;
+                load_frags(f, cur, s);
+                mac(f);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();              // tile kt consumed by all waves; tile kt + 1 landed (vmcnt(0) + barrier)
+        }
+    } else {
+        // register-prefetched pipeline, ONE barrier per k-tile placed between its two k-steps:
+        //   read step 1 of tile kt | MFMAs of step 0 | barrier (all reads of tile kt are in registers, tile kt + 1 landed)
+        //   | DMA of tile kt + 2 into the buffer just freed | read step 0 of tile kt + 1 | MFMAs of step 1
+        // so every LDS read has one 12-MFMA group (~384 matrix cycles) and every DMA a whole k-tile to land.
+        Frags f0, f1;
+        stage(0, 0);
+        if (nk > 1) stage(1, X3_KT);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X3_DMA_PER_WAVE) : "memory");     // tile 0 landed (tile 1 may be in flight)
+        if (nk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        load_frags(f0, 0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            // The reads of the NEXT group are issued behind the first two MFMAs of the current one: the s_waitcnt the
+            // compiler puts in front of a group is lgkmcnt(0) (it cannot count across the loop edge), which must only
+            // cover fragments requested a whole group ago, not the ones just issued.
+            __builtin_amdgcn_s_setprio(1);
+            mac_head(f0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(f1, cur, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mac_tail(f0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile kt + 1 has landed (stated
+                                                               // explicitly: hipcc does not always emit it for a glds)
+            __syncthreads();              // + lgkmcnt(0): f1 is in registers; after the barrier tile kt + 1 is complete
+            if (kt + 2 < nk) stage(cur, (kt + 2) * X3_KT);
+            __builtin_amdgcn_s_setprio(1);
+            mac_head(f1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) load_frags(f0, cur ^ 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mac_tail(f1);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const int colw = n0 + wn * 64 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= p.M) continue;
+        if constexpr (EPI == VN_EPI_GEGLU) {
+            // wave tile = 64 packed columns = 32 value (j = 0) + 32 gate (j = 1), interleaved at pack time
+            const int ocol = (n0 + wn * 64) / 2 + l31;
+            if (2 * ocol >= p.N) continue;
+            const float o = acc[0][r] * vn_gelu_tanh(acc[1][r]);
+            if (p.C16) {
+                uint16_t t0, t1, t2;
+                vn_split3(o, t0, t1, t2);
+                uint16_t* d = p.C16 + (size_t)row * p.ldc + ocol;
+                d[0] = t0; d[p.c_plane] = t1; d[2 * p.c_plane] = t2;
+            } else {
+                p.C[(size_t)row * p.ldc + ocol] = o;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = colw + j * 32;
+                if (col >= p.N) continue;
+                const float v = acc[j][r];
+                if constexpr (EPI == VN_EPI_STORE) {
+                    p.C[(size_t)row * p.ldc + col] = v;
+                } else if constexpr (EPI == VN_EPI_BIAS) {
+                    p.C[(size_t)row * p.ldc + col] = v + p.bias[col];
+                } else if constexpr (EPI == VN_EPI_RESIDUAL) {
+                    float* c = p.C + (size_t)row * p.ldc + col;
+                    *c = *c + v;
+                } else if constexpr (EPI == VN_EPI_QKV) {
+                    const int D = p.H * VN_DHEAD;
+                    const int which = col / D, rem = col - which * D;
+                    const int hd = rem >> 6, d = rem & 63;
+                    const int b = row / p.T, t = row - b * p.T;
+                    p.C[which * p.qkv_plane + (((size_t)b * p.H + hd) * p.T + t) * VN_DHEAD + d] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int EPI>
+static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
+    const int tiles_m = vn_cdiv(a.M, X3_BM), tiles_n = vn_cdiv(a.N, X3_BN);
+    const double n_out = (EPI == VN_EPI_GEGLU) ? a.N / 2 : a.N;
+    const double bytes = 6.0 * ((double)a.M * a.K + (double)a.N * a.K) +
+                         ((EPI == VN_EPI_GEGLU && a.C16) ? 6.0 : 4.0) * (double)a.M * n_out * (EPI == VN_EPI_RESIDUAL ? 2 : 1);
+    const int pi = vn_prof_pre(ctx, 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);       // algorithmic (fp32-equivalent) flops
+    static const int pipe = [] { const char* e = getenv("VN_X3_PIPE"); return e ? atoi(e) : 1; }();   // 0: A/B reference schedule
+    if (pipe == 0) hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, 0>), dim3(tiles_m * tiles_n), dim3(512), X3_LDS_BYTES, s, a, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, 1>), dim3(tiles_m * tiles_n), dim3(512), X3_LDS_BYTES, s, a, tiles_m, tiles_n);
+    vn_prof_post(ctx, pi, s);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: empty problem%s", "");
+    if (a.K % X3_KT) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: K=%s%ld must be a multiple of 32", "", a.K);
+    if (a.N % 64) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: N=%s%ld must be a multiple of 64", "", a.N);
+    if (a.a_plane <= 0 || a.w_plane <= 0 || (a.a_plane & 7) || (a.w_plane & 7))
+        return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: plane strides must be positive multiples of 8 elements%s", "");
+    if (((uintptr_t)a.A | (uintptr_t)a.W) & 15) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: operands must be 16-byte aligned%s", "");
+    if (!(ctx->attr_mask & VN_ATTR_GEMM_X3)) {
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_BIAS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_BIAS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_RESIDUAL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_RESIDUAL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_GEGLU, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_GEGLU, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_QKV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_QKV, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
+        ctx->attr_mask |= VN_ATTR_GEMM_X3;
+    }
+    switch (epilogue) {
+        case VN_EPI_STORE: return x3_launch<VN_EPI_STORE>(ctx, a, s);
+        case VN_EPI_BIAS:
+            if (!a.bias) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: bias epilogue needs bias%s", "");
+            return x3_launch<VN_EPI_BIAS>(ctx, a, s);
+        case VN_EPI_RESIDUAL: return x3_launch<VN_EPI_RESIDUAL>(ctx, a, s);
+        case VN_EPI_GEGLU:
+            if (a.C16 && a.c_plane <= 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3/geglu: C16 needs c_plane%s", "");
+            return x3_launch<VN_EPI_GEGLU>(ctx, a, s);
+        case VN_EPI_QKV: return x3_launch<VN_EPI_QKV>(ctx, a, s);
+    }
+    return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: unknown epilogue %s%ld", "", epilogue);
+}
+
+// ---- plane builder (weights at load time, tests): dst[q][i] = q-th split term of src[i]
+__global__ __launch_bounds__(256) void vn_split3_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long n4,
+                                                        long plane) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
+        const f32x4 v = ((const f32x4*)src)[i];
+        vn_store_bf16x4(dst + 4 * i, plane, v);
+    }
+}
+
+extern "C" int vn_split3_f32(vn_ctx* ctx, const float* src, void* dst16, int64_t n, int64_t plane_stride, void* stream) {
+    if (!ctx || !src || !dst16 || n <= 0 || (n & 3) || plane_stride < n || (plane_stride & 7)) return VN_ERR_INVALID;
+    const long n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(vn_split3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)dst16, n4, (long)plane_stride);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// single-op entry (tests / tuning): A3 [3][M][K] and W3 [3][N][K] bf16 planes -> fp32 C
+extern "C" int vn_gemm_bf16x3(vn_ctx* ctx, const void* A3, int64_t a_plane, const void* W3, int64_t w_plane, const float* bias,
+                              float* C, int M, int N, int K, int epilogue, void* stream) {
+    if (!ctx || !A3 || !W3 || !C) return VN_ERR_INVALID;
+    if (epilogue < VN_EPI_STORE || epilogue > VN_EPI_GEGLU) return vn_fail(ctx, VN_ERR_INVALID, "bad epilogue%s", "");
+    vn_gemm_args a{};
+    a.A = (const float*)A3; a.W = (const float*)W3; a.bias = bias; a.C = C; a.M = M; a.N = N; a.K = K;
+    a.ldc = epilogue == VN_EPI_GEGLU ? N / 2 : N;
+    a.bf16 = 2; a.a_plane = a_plane; a.w_plane = w_plane;
+    return vn_launch_gemm_x3(ctx, a, epilogue, (hipStream_t)stream);
+}

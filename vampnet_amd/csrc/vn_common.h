@@ -19,6 +19,37 @@ __device__ __forceinline__ uint16_t vn_f32_to_bf16(float f) {
     return (uint16_t)(u >> 16);
 }
 
+__device__ __forceinline__ float vn_bf16_to_f32(uint16_t b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+
+// fp32 -> three bf16 terms with p0 + p1 + p2 == x EXACTLY (8 + 8 + 8 significand bits; both remainders are exact fp32
+// subtractions).  The "bf16x3" GEMM mode multiplies such triples on the bf16 matrix cores (gemm_x3.hip).
+__device__ __forceinline__ void vn_split3(float x, uint16_t& p0, uint16_t& p1, uint16_t& p2) {
+    p0 = vn_f32_to_bf16(x);
+    const float r1 = x - vn_bf16_to_f32(p0);
+    p1 = vn_f32_to_bf16(r1);
+    p2 = vn_f32_to_bf16(r1 - vn_bf16_to_f32(p1));
+}
+// four consecutive values -> one 8-byte store per plane; plane == 0: single bf16 plane (fast mode)
+__device__ __forceinline__ void vn_store_bf16x4(uint16_t* dst, long plane, const f32x4& o) {
+    if (plane == 0) {
+        uint2 pk;
+        pk.x = vn_f32_to_bf16(o[0]) | ((unsigned)vn_f32_to_bf16(o[1]) << 16);
+        pk.y = vn_f32_to_bf16(o[2]) | ((unsigned)vn_f32_to_bf16(o[3]) << 16);
+        *(uint2*)dst = pk;
+        return;
+    }
+    uint16_t t[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vn_split3(o[e], t[0][e], t[1][e], t[2][e]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        uint2 pk;
+        pk.x = t[q][0] | ((unsigned)t[q][1] << 16);
+        pk.y = t[q][2] | ((unsigned)t[q][3] << 16);
+        *(uint2*)(dst + q * plane) = pk;
+    }
+}
+
 #define VN_WAVE 64
 #define VN_DHEAD 64
 
@@ -118,7 +149,7 @@ struct vn_ctx {
     // process may hold contexts on several)
     unsigned attr_mask;
 };
-enum { VN_ATTR_ATTN = 1u, VN_ATTR_ATTN_TRAIN = 2u, VN_ATTR_REMASK = 4u, VN_ATTR_MT_JUMP = 8u };
+enum { VN_ATTR_ATTN = 1u, VN_ATTR_ATTN_TRAIN = 2u, VN_ATTR_REMASK = 4u, VN_ATTR_MT_JUMP = 8u, VN_ATTR_GEMM_X3 = 16u };
 
 // bracket a launch with events when profiling is on (no-ops otherwise)
 static inline int vn_prof_pre(vn_ctx* ctx, int cls, double flops, hipStream_t s, double bytes = 0.0) {
@@ -166,8 +197,9 @@ struct vn_gemm_args {
     const float* W;      // [N][K] row-major
     const float* bias;   // [N] or null
     float* C;            // epilogue dependent
-    uint16_t* C16;       // GEGLU epilogue: write bf16 instead of C (fast mode)
-    int bf16;            // 1: A and W hold bf16 (K counts elements), fp32 accumulate
+    uint16_t* C16;       // GEGLU epilogue: write bf16 instead of C (fast mode / bf16x3 planes)
+    int bf16;            // 1: A and W hold bf16 (K counts elements), fp32 accumulate; 2: bf16x3 split planes (gemm_x3.hip)
+    long a_plane, w_plane, c_plane;   // bf16x3: elements between the three planes of A / W / C16
     int M, N, K;
     int ldc;             // row stride of C (floats)
     // QKV scatter: C = qkv base [3][B][H][T][64]; row m = b*T + t
@@ -175,13 +207,15 @@ struct vn_gemm_args {
     long qkv_plane;      // B*H*T*64
 };
 int vn_launch_gemm_f32(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);
+int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);      // a.bf16 == 2
 
+// y16 / out16: bf16 image of the output for the next GEMM; plane16 == 0 one plane, > 0 three split planes that far apart
 int vn_launch_rmsnorm(vn_ctx* ctx, const float* x, const float* w, float* y, int rows, int D, float eps, hipStream_t s,
-                      uint16_t* y16 = nullptr);
+                      uint16_t* y16 = nullptr, long plane16 = 0);
 int vn_launch_embed(vn_ctx* ctx, const int32_t* codes, const float* tables, const float* wt, const float* b,
                     float* x, int B, int C, int T, int V1, int latent, int D, hipStream_t s);
 int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* relbias_full,
-                        float* out, int B, int H, int T, hipStream_t s, uint16_t* out16 = nullptr);
+                        float* out, int B, int H, int T, hipStream_t s, uint16_t* out16 = nullptr, long plane16 = 0);
 // expands [num_buckets][H] into per-head tables over rel = key - query in [-(T-1), T-1]: out[h][rel + T - 1]
 void vn_bucket_lut_host(int T, int num_buckets, int max_distance, int32_t* lut /* [2T-1] */);
 int vn_launch_bias_expand(vn_ctx* ctx, const float* rel_bias, const int32_t* lut_dev, float* out, int H, int T,

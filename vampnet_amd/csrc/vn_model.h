@@ -12,8 +12,11 @@ struct vn_model {
     int32_t *z, *z_sampled, *sampled, *count, *lut;
     int64_t* ksched;         // device [max_steps][max_batch] per-item mask schedule of the running generate()
     // bf16 fast mode (vn_model_set_bf16): bf16 image of the weight blob (same element offsets) + bf16 GEMM A operands
+    // bf16x3 mode (vn_model_set_bf16x3): blob16 holds the THREE split planes of the blob, w_plane elements apart, and the
+    // A operands are written as three planes too (y16: max_rows * D apart, g16: max_rows * 2D apart)
     const uint16_t* blob16;
-    uint16_t *y16, *g16;
+    long w_plane;            // 0: single-plane bf16 fast mode
+    uint16_t *y16, *g16;     // sized for three planes
     int bias_T;              // T the expanded bias table is currently built for (-1 = none)
     long max_rows;
     struct vn_fwd_graphs* graphs;   // captured hipGraphs of the forward pass, per (B, T, precision) (engine.hip)

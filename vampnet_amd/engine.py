@@ -115,6 +115,25 @@ class Engine:
                                          self.stream()), "vn_gemm_bf16")
         return out
 
+    def split3(self, x):
+        """fp32 tensor -> bf16 [3, *x.shape] with planes summing to x exactly (operand format of gemm_bf16x3)."""
+        x = x.contiguous()
+        n = x.numel()
+        out = torch.empty((3,) + tuple(x.shape), dtype=torch.bfloat16, device=x.device)
+        self.check(self.lib.vn_split3_f32(self.handle, x.data_ptr(), out.data_ptr(), n, n, self.stream()), "vn_split3_f32")
+        return out
+
+    def gemm_bf16x3(self, a3, w3, bias=None, epilogue=_lib.EPI_STORE, out=None):
+        """fp32-grade GEMM on the bf16 matrix cores: a3 [3,M,K], w3 [3,N,K] split planes -> fp32 out (op)= a @ w.T"""
+        _, M, K = a3.shape
+        N = w3.shape[1]
+        if out is None:
+            out = torch.empty(M, N // 2 if epilogue == _lib.EPI_GEGLU else N, device=a3.device, dtype=torch.float32)
+        self.check(self.lib.vn_gemm_bf16x3(self.handle, a3.data_ptr(), M * K, w3.data_ptr(), N * K,
+                                           bias.data_ptr() if bias is not None else None, out.data_ptr(), M, N, K, epilogue,
+                                           self.stream()), "vn_gemm_bf16x3")
+        return out
+
     def attention(self, q, k, v, rel_bias, num_buckets=32, max_distance=128):
         """q,k,v [B,H,T,64]; rel_bias [num_buckets,H] -> [B,T,H*64]."""
         B, H, T, dh = q.shape
@@ -233,20 +252,30 @@ class VampNetModel:
                      "vn_model_create")
         self.handle = h
         self.blob16 = None
+        self.blob3 = None
         self.precision = "f32"
         self.set_precision(precision)
 
     def set_precision(self, precision: str):
-        """"f32": exact-fp32 MFMA (parity mode, default).  "bf16": fast mode — GEMM operands in bf16 like the
-        reference's own GPU path (torch.autocast(bf16), interface.py:364,428); NOT bit-exact."""
+        """"f32": exact-fp32 MFMA (parity mode, default).  "bf16x3": fp32-grade GEMMs evaluated as six bf16 MFMA
+        products of exact three-way operand splits (same accuracy class as "f32", faster matrix pipe).  "bf16": fast mode —
+        GEMM operands in bf16 like the reference's own GPU path (torch.autocast(bf16), interface.py:364,428); NOT bit-exact."""
         if precision == "bf16":
             if self.blob16 is None:
                 self.blob16 = self.blob.to(torch.bfloat16)          # same element offsets, RNE like torch autocast
             self.engine.check(self.lib.vn_model_set_bf16(self.handle, self.blob16.data_ptr()), "vn_model_set_bf16")
+        elif precision == "bf16x3":
+            # fp32-grade GEMMs on the bf16 matrix cores: every operand as three exact split planes (gemm_x3.hip)
+            n = self.blob.numel()
+            if self.blob3 is None:
+                self.blob3 = torch.empty(3 * n, dtype=torch.bfloat16, device=self.device)
+                self.engine.check(self.lib.vn_split3_f32(self.engine.handle, self.blob.data_ptr(), self.blob3.data_ptr(), n, n,
+                                                         self.engine.stream()), "vn_split3_f32")
+            self.engine.check(self.lib.vn_model_set_bf16x3(self.handle, self.blob3.data_ptr(), n), "vn_model_set_bf16x3")
         elif precision == "f32":
             self.engine.check(self.lib.vn_model_set_bf16(self.handle, None), "vn_model_set_bf16")
         else:
-            raise ValueError("precision must be 'f32' or 'bf16'")
+            raise ValueError("precision must be 'f32', 'bf16x3' or 'bf16'")
         self.precision = precision
 
     @property
