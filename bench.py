@@ -170,9 +170,10 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=8)
     ap.add_argument("--coarse-steps", type=int, default=12)
     ap.add_argument("--coarse-only", action="store_true", help="BASELINE configs[1]: coarse_vamp only (4 codebooks)")
-    ap.add_argument("--dtype", choices=["f32", "bf16x3", "bf16"], default="f32",
-                    help="f32 = exact-fp32 MFMA (parity-backed default); bf16x3 = fp32-grade GEMMs as six bf16-MFMA products of "
-                         "exact 3-way operand splits (same parity bars, tests/test_gpu_bf16x3.py); bf16 = fast mode, not bit-exact")
+    ap.add_argument("--dtype", choices=["f32", "bf16x3", "bf16"], default="bf16x3",
+                    help="bf16x3 (default) = fp32-grade GEMMs as six bf16-MFMA products of exact 3-way operand splits, fp32 "
+                         "accumulate: held to the same parity bars as f32 (tests/test_gpu_bf16x3.py: tokens bit-identical to the "
+                         "oracle and the reference's golden tokens); f32 = exact-fp32 MFMA; bf16 = fast mode, not bit-exact")
     ap.add_argument("--workload", choices=["vamp", "train"], default="vamp",
                     help="vamp = the headline inference path (default); train = BASELINE configs[4] training step")
     ap.add_argument("--lora-only", action="store_true",
@@ -294,7 +295,12 @@ def main():
                                    "typical_filtering=True, device RNG",
                        "global_batch": B, "coarse_steps": args.coarse_steps,
                        "parallelism": f"batch-shard x{world}" if world > 1 else "single GPU",
-                       "s_per_clip": elapsed / args.steps / B * world},
+                       "s_per_clip": elapsed / args.steps / B * world,
+                       "precision": {"f32": "fp32 operands on the fp32-input MFMA, fp32 accumulate",
+                                     "bf16x3": "fp32-grade: each GEMM operand = 3 exact bf16 split planes (sum == fp32 value), 6 bf16-MFMA "
+                                               "products per k-step, fp32 accumulate; attention/norms/softmax/sampling fp32; "
+                                               "same parity bars as f32 (tests/test_gpu_bf16x3.py)",
+                                     "bf16": "bf16 GEMM/attention operands (fast mode, not bit-exact)"}[args.dtype]},
         }
         if prof is not None:
             n, ms, fl, gbytes = prof["gemm_bf16"] if args.dtype == "bf16" else prof["gemm"]

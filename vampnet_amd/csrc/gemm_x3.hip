@@ -56,7 +56,8 @@ __device__ __forceinline__ void x3_tile_coords(int t, int tiles_m, int tiles_n, 
     tn = in_grp / gsz;
 }
 
-template <int EPI, int PIPE>
+// ABL (tuning only, results invalid): bit 0 = no DMA inside the k-loop, bit 1 = no fragment reads inside the k-loop
+template <int EPI, int PIPE, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int tm, tn;
@@ -86,12 +87,15 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             src[j] = W16 + (size_t)(pt - 3) * p.w_plane + (size_t)g * p.K + dslot * 8;
         }
     }
-    auto stage = [&](int buf, int k0) {
+    auto stage_piece = [&](int buf, int k0, int j) {
+        if constexpr (ABL & 4) k0 = 0;            // ablation: every tile re-reads the first one (cache-resident source)
         float* base = lds + buf * X3_STAGE_FLOATS + wave * (X3_DMA_PER_WAVE * 256);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
+                                         (__attribute__((address_space(3))) void*)(base + j * 256), 16, 0, 0);
+    };
+    auto stage = [&](int buf, int k0) {
 #pragma unroll
-        for (int j = 0; j < X3_DMA_PER_WAVE; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
-                                             (__attribute__((address_space(3))) void*)(base + j * 256), 16, 0, 0);
+        for (int j = 0; j < X3_DMA_PER_WAVE; ++j) stage_piece(buf, k0, j);
     };
 
     // fragment offsets (floats) inside a plane tile: row * 16 + ((2 s + h) ^ ((row >> 2) & 3)) * 4
@@ -137,6 +141,11 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b[0][j], acc[j], 0, 0, 0);
     };
     auto mac = [&](const Frags& f) { mac_head(f); mac_tail(f); };
+    auto mac_pair = [&](const Frags& f, int t) {          // t-th of the five pairs of mac_tail
+        const int qa = t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0, qb = (t == 0 || t == 3 || t == 4) ? 0 : 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[qa], f.b[qb][j], acc[j], 0, 0, 0);
+    };
 
     const int nk = p.K / X3_KT;
     if constexpr (PIPE == 0) {
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();              // tile kt consumed by all waves; tile kt + 1 landed (vmcnt(0) + barrier)
         }
-    } else {
+    } else if constexpr (PIPE == 1) {
         // register-prefetched pipeline, ONE barrier per k-tile placed between its two k-steps:
         //   read step 1 of tile kt | MFMAs of step 0 | barrier (all reads of tile kt are in registers, tile kt + 1 landed)
         //   | DMA of tile kt + 2 into the buffer just freed | read step 0 of tile kt + 1 | MFMAs of step 1
@@ -169,6 +178,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         if (nk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         load_frags(f0, 0, 0);
+        if constexpr (ABL & 2) load_frags(f1, 0, 1);
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
             // The reads of the NEXT group are issued behind the first two MFMAs of the current one: the s_waitcnt the
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             __builtin_amdgcn_s_setprio(1);
             mac_head(f0);
             __builtin_amdgcn_sched_barrier(0);
-            load_frags(f1, cur, 1);
+            if constexpr (!(ABL & 2)) load_frags(f1, cur, 1);
             __builtin_amdgcn_sched_barrier(0);
             mac_tail(f0);
             __builtin_amdgcn_s_setprio(0);
@@ -185,15 +195,90 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile kt + 1 has landed (stated
                                                                // explicitly: hipcc does not always emit it for a glds)
             __syncthreads();              // + lgkmcnt(0): f1 is in registers; after the barrier tile kt + 1 is complete
-            if (kt + 2 < nk) stage(cur, (kt + 2) * X3_KT);
+            if constexpr (!(ABL & 1))
+                if (kt + 2 < nk) stage(cur, (kt + 2) * X3_KT);
             __builtin_amdgcn_s_setprio(1);
             mac_head(f1);
             __builtin_amdgcn_sched_barrier(0);
-            if (kt + 1 < nk) load_frags(f0, cur ^ 1, 0);
+            if constexpr (!(ABL & 2))
+                if (kt + 1 < nk) load_frags(f0, cur ^ 1, 0);
             __builtin_amdgcn_sched_barrier(0);
             mac_tail(f1);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if constexpr (PIPE == 2) {
+        // three LDS buffers (144 KiB): the DMA of tile kt + 3 is issued at the mid-tile barrier of tile kt and has two whole
+        // k-tiles to land; raw s_barrier + counted vmcnt so that one tile stays in flight across every barrier
+        Frags f0, f1;
+        stage(0, 0);
+        if (nk > 1) stage(1, X3_KT);
+        if (nk > 2) stage(2, 2 * X3_KT);
+        if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * X3_DMA_PER_WAVE) : "memory");
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X3_DMA_PER_WAVE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_frags(f0, 0, 0);
+        int b = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int bn = b == 2 ? 0 : b + 1;
+            __builtin_amdgcn_s_setprio(1);
+            mac_head(f0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(f1, b, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mac_tail(f0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X3_DMA_PER_WAVE) : "memory");   // tile kt + 1 landed
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 3 < nk) stage(b, (kt + 3) * X3_KT);
+            __builtin_amdgcn_s_setprio(1);
+            mac_head(f1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) load_frags(f0, bn, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mac_tail(f1);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            b = bn;
+        }
+    } else {
+        // PIPE 3: as PIPE 1, with the six DMA pieces of tile kt + 2 issued one per MFMA pair instead of back to back
+        Frags f0, f1;
+        stage(0, 0);
+        if (nk > 1) stage(1, X3_KT);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X3_DMA_PER_WAVE) : "memory");
+        if (nk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        load_frags(f0, 0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            const bool more = kt + 2 < nk;
+            __builtin_amdgcn_s_setprio(1);
+            mac_head(f0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(f1, cur, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mac_tail(f0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            mac_head(f1);
+            if (more) stage_piece(cur, (kt + 2) * X3_KT, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) load_frags(f0, cur ^ 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                mac_pair(f1, t);
+                if (more) stage_piece(cur, (kt + 2) * X3_KT, t + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 
@@ -249,6 +334,45 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
                          ((EPI == VN_EPI_GEGLU && a.C16) ? 6.0 : 4.0) * (double)a.M * n_out * (EPI == VN_EPI_RESIDUAL ? 2 : 1);
     const int pi = vn_prof_pre(ctx, 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);       // algorithmic (fp32-equivalent) flops
     static const int pipe = [] { const char* e = getenv("VN_X3_PIPE"); return e ? atoi(e) : 1; }();   // 0: A/B reference schedule
+    if constexpr (EPI == VN_EPI_STORE) {
+        if (pipe == 2 || pipe == 3) {                                        // schedule experiments (store epilogue only)
+            static bool attr23 = false;
+            if (!attr23) {
+                (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X3_STAGE_FLOATS * 4);
+                (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+                attr23 = true;
+            }
+            if (pipe == 2) hipLaunchKernelGGL((vn_gemm_x3_kernel<VN_EPI_STORE, 2>), dim3(tiles_m * tiles_n), dim3(512), 3 * X3_STAGE_FLOATS * 4, s, a, tiles_m, tiles_n);
+            else hipLaunchKernelGGL((vn_gemm_x3_kernel<VN_EPI_STORE, 3>), dim3(tiles_m * tiles_n), dim3(512), X3_LDS_BYTES, s, a, tiles_m, tiles_n);
+            vn_prof_post(ctx, pi, s);
+            VN_LAUNCH_CHECK(ctx);
+            return VN_OK;
+        }
+        static const int abl = [] { const char* e = getenv("VN_X3_ABL"); return e ? atoi(e) & 7 : 0; }();     // ablations (tuning)
+        if (abl == 4) {
+            static bool attr4 = false;
+            if (!attr4) { (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES); attr4 = true; }
+            hipLaunchKernelGGL((vn_gemm_x3_kernel<VN_EPI_STORE, 1, 4>), dim3(tiles_m * tiles_n), dim3(512), X3_LDS_BYTES, s, a, tiles_m, tiles_n);
+            vn_prof_post(ctx, pi, s);
+            VN_LAUNCH_CHECK(ctx);
+            return VN_OK;
+        }
+        if (abl) {
+            static bool attr = false;
+            if (!attr) {
+                (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+                attr = true;
+            }
+            if (abl == 1) hipLaunchKernelGGL((vn_gemm_x3_kernel<VN_EPI_STORE, 1, 1>), dim3(tiles_m * tiles_n), dim3(512), X3_LDS_BYTES, s, a, tiles_m, tiles_n);
+            else if (abl == 2) hipLaunchKernelGGL((vn_gemm_x3_kernel<VN_EPI_STORE, 1, 2>), dim3(tiles_m * tiles_n), dim3(512), X3_LDS_BYTES, s, a, tiles_m, tiles_n);
+            else hipLaunchKernelGGL((vn_gemm_x3_kernel<VN_EPI_STORE, 1, 3>), dim3(tiles_m * tiles_n), dim3(512), X3_LDS_BYTES, s, a, tiles_m, tiles_n);
+            vn_prof_post(ctx, pi, s);
+            VN_LAUNCH_CHECK(ctx);
+            return VN_OK;
+        }
+    }
     if (pipe == 0) hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, 0>), dim3(tiles_m * tiles_n), dim3(512), X3_LDS_BYTES, s, a, tiles_m, tiles_n);
     else hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, 1>), dim3(tiles_m * tiles_n), dim3(512), X3_LDS_BYTES, s, a, tiles_m, tiles_n);
     vn_prof_post(ctx, pi, s);
