@@ -94,7 +94,7 @@ extern "C" int vn_ctx_create(int device, vn_ctx** out) {
     c->device = device;
     c->err[0] = 0;
     c->prof = vn_prof();
-    c->sk_slabs = nullptr; c->sk_flags = nullptr; c->zero_page = nullptr; c->attr_mask = 0;
+    c->sk_slabs = nullptr; c->sk_flags = nullptr; c->zero_page = nullptr; c->x3_ws = nullptr; c->attr_mask = 0;
     if (hipSetDevice(device) != hipSuccess) { delete c; return VN_ERR_HIP; }
     *out = c;
     return VN_OK;
@@ -113,6 +113,7 @@ extern "C" void vn_ctx_destroy(vn_ctx* ctx) {
     (void)hipFree(ctx->sk_slabs);
     (void)hipFree(ctx->sk_flags);
     (void)hipFree(ctx->zero_page);
+    (void)hipFree(ctx->x3_ws);
     delete ctx;
 }
 

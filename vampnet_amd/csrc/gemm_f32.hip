@@ -559,6 +559,17 @@ static int launch_splitk(vn_ctx* ctx, const vn_gemm_args& a, int nsplit, hipStre
     return VN_OK;
 }
 
+int vn_launch_splitk_reduce(vn_ctx* ctx, const float* partial, int nsplit, float* C, int M, int N, int ldc, bool residual,
+                            hipStream_t s) {
+    if ((N & 3) || (ldc & 3)) return vn_fail(ctx, VN_ERR_INVALID, "split-K reduce: N and ldc must be multiples of 4%s", "");
+    const long total4 = (long)M * (N / 4);
+    const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+    if (residual) hipLaunchKernelGGL((vn_splitk_reduce_kernel<true>), dim3(blocks), dim3(256), 0, s, partial, nsplit, C, M, N / 4, ldc / 4);
+    else hipLaunchKernelGGL((vn_splitk_reduce_kernel<false>), dim3(blocks), dim3(256), 0, s, partial, nsplit, C, M, N / 4, ldc / 4);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
 template <int EPI>
 static int launch_epi(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
     read_env_once();

@@ -69,6 +69,10 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
     const int wm = wave >> 1, wn = wave & 1;
     const uint16_t* A16 = (const uint16_t*)p.A;
     const uint16_t* W16 = (const uint16_t*)p.W;
+    // split-K (gridDim.y > 1, store epilogue only): split sp multiplies k-tiles [kb, ke) into its own image of C
+    const int nk_all = p.K / X3_KT;
+    const int kb = (int)((long)nk_all * blockIdx.y / gridDim.y), ke = (int)((long)nk_all * (blockIdx.y + 1) / gridDim.y);
+    if (gridDim.y > 1) p.C += (size_t)blockIdx.y * p.M * p.N;
 
     // per-lane DMA sources: instruction q = wave * 6 + j fills plane tile q / 8, rows 16 (q % 8) .. + 15
     const uint16_t* src[X3_DMA_PER_WAVE];
@@ -80,11 +84,11 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         if (pt < 3) {
             int g = m0 + row;
             g = g < p.M ? g : p.M - 1;
-            src[j] = A16 + (size_t)pt * p.a_plane + (size_t)g * p.K + dslot * 8;
+            src[j] = A16 + (size_t)pt * p.a_plane + (size_t)g * p.K + dslot * 8 + kb * X3_KT;
         } else {
             int g = n0 + row;
             g = g < p.N ? g : p.N - 1;
-            src[j] = W16 + (size_t)(pt - 3) * p.w_plane + (size_t)g * p.K + dslot * 8;
+            src[j] = W16 + (size_t)(pt - 3) * p.w_plane + (size_t)g * p.K + dslot * 8 + kb * X3_KT;
         }
     }
     auto stage_piece = [&](int buf, int k0, int j) {
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[qa], f.b[qb][j], acc[j], 0, 0, 0);
     };
 
-    const int nk = p.K / X3_KT;
+    const int nk = ke - kb;
     if constexpr (PIPE == 0) {
         // plain double buffering: DMA of tile kt + 1 under the MFMAs of tile kt, fragments read right before use
         stage(0, 0);
@@ -326,57 +330,100 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
     }
 }
 
+#define X3_WS_FLOATS (32L << 20)          // 128 MiB of split-K partial images, allocated once (graph-safe: never re-allocated)
+
+static int x3_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+template <int EPI, int PIPE, int ABL = 0>
+static void x3_go(const vn_gemm_args& a, int tiles_m, int tiles_n, int nsplit, size_t lds_bytes, hipStream_t s) {
+    // one-time per process and instantiation is enough for the tuning variants; the production variants are raised per
+    // context in vn_launch_gemm_x3
+    hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, PIPE, ABL>), dim3(tiles_m * tiles_n, nsplit), dim3(512), lds_bytes, s, a, tiles_m, tiles_n);
+}
+
+// split count for the store / residual epilogues: a launch costs ceil(tiles * ns / 256) rounds of K / ns, plus the reduce
+// pass over (ns + 1 or 2) images of C.  Constants from profiles/r01_gemm_x3_vs_f32.txt (1.45 us per k-tile and round,
+// ~3.5 TB/s for the reduce).
+static int x3_pick_split(const vn_gemm_args& a, bool residual) {
+    static const int forced = x3_env("VN_X3_SPLITK", -1);          // 0 / 1: off, 2 / 4: forced
+    const int tiles = vn_cdiv(a.M, X3_BM) * vn_cdiv(a.N, X3_BN), nk = a.K / X3_KT;
+    if (forced == 0 || forced == 1 || (a.N & 3) || (a.ldc & 3)) return 1;
+    int best = 1;
+    double best_cost = 1e300;
+    for (int ns = 1; ns <= 4; ns *= 2) {
+        if (ns > 1 && (nk / ns < 8 || (double)ns * a.M * a.N > (double)X3_WS_FLOATS)) continue;
+        if (forced > 1 && ns != forced && ns != 1) continue;
+        double cost = ceil(tiles * ns / 256.0) * (nk / (double)ns) * 1.45;
+        if (ns > 1) cost += (ns + (residual ? 2 : 1)) * 4.0 * a.M * (double)a.N / 3.5e6;
+        if (forced > 1 && ns == forced) cost = 0;
+        if (cost < best_cost) { best_cost = cost; best = ns; }
+    }
+    return best;
+}
+
 template <int EPI>
 static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
     const int tiles_m = vn_cdiv(a.M, X3_BM), tiles_n = vn_cdiv(a.N, X3_BN);
     const double n_out = (EPI == VN_EPI_GEGLU) ? a.N / 2 : a.N;
     const double bytes = 6.0 * ((double)a.M * a.K + (double)a.N * a.K) +
                          ((EPI == VN_EPI_GEGLU && a.C16) ? 6.0 : 4.0) * (double)a.M * n_out * (EPI == VN_EPI_RESIDUAL ? 2 : 1);
+    // schedule: 3 (default) = register-prefetched fragments + DMA pieces spread over the MFMA pairs; 1 = DMA back to back;
+    // 0 / 2 (store epilogue, tuning only) = plain double buffering / three LDS buffers
+    static const int pipe = x3_env("VN_X3_PIPE", 3);
+    static const int abl = x3_env("VN_X3_ABL", 0) & 7;                      // ablations (tuning only; results invalid)
     const int pi = vn_prof_pre(ctx, 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);       // algorithmic (fp32-equivalent) flops
-    static const int pipe = [] { const char* e = getenv("VN_X3_PIPE"); return e ? atoi(e) : 1; }();   // 0: A/B reference schedule
     if constexpr (EPI == VN_EPI_STORE) {
-        if (pipe == 2 || pipe == 3) {                                        // schedule experiments (store epilogue only)
-            static bool attr23 = false;
-            if (!attr23) {
-                (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X3_STAGE_FLOATS * 4);
-                (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
-                attr23 = true;
-            }
-            if (pipe == 2) hipLaunchKernelGGL((vn_gemm_x3_kernel<VN_EPI_STORE, 2>), dim3(tiles_m * tiles_n), dim3(512), 3 * X3_STAGE_FLOATS * 4, s, a, tiles_m, tiles_n);
-            else hipLaunchKernelGGL((vn_gemm_x3_kernel<VN_EPI_STORE, 3>), dim3(tiles_m * tiles_n), dim3(512), X3_LDS_BYTES, s, a, tiles_m, tiles_n);
-            vn_prof_post(ctx, pi, s);
-            VN_LAUNCH_CHECK(ctx);
-            return VN_OK;
-        }
-        static const int abl = [] { const char* e = getenv("VN_X3_ABL"); return e ? atoi(e) & 7 : 0; }();     // ablations (tuning)
-        if (abl == 4) {
-            static bool attr4 = false;
-            if (!attr4) { (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES); attr4 = true; }
-            hipLaunchKernelGGL((vn_gemm_x3_kernel<VN_EPI_STORE, 1, 4>), dim3(tiles_m * tiles_n), dim3(512), X3_LDS_BYTES, s, a, tiles_m, tiles_n);
-            vn_prof_post(ctx, pi, s);
-            VN_LAUNCH_CHECK(ctx);
-            return VN_OK;
-        }
-        if (abl) {
+        if (pipe == 0 || pipe == 2 || abl) {
             static bool attr = false;
             if (!attr) {
+                (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X3_STAGE_FLOATS * 4);
                 (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
                 (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
                 (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
                 attr = true;
             }
-            if (abl == 1) hipLaunchKernelGGL((vn_gemm_x3_kernel<VN_EPI_STORE, 1, 1>), dim3(tiles_m * tiles_n), dim3(512), X3_LDS_BYTES, s, a, tiles_m, tiles_n);
-            else if (abl == 2) hipLaunchKernelGGL((vn_gemm_x3_kernel<VN_EPI_STORE, 1, 2>), dim3(tiles_m * tiles_n), dim3(512), X3_LDS_BYTES, s, a, tiles_m, tiles_n);
-            else hipLaunchKernelGGL((vn_gemm_x3_kernel<VN_EPI_STORE, 1, 3>), dim3(tiles_m * tiles_n), dim3(512), X3_LDS_BYTES, s, a, tiles_m, tiles_n);
+            if (abl == 1) x3_go<VN_EPI_STORE, 1, 1>(a, tiles_m, tiles_n, 1, X3_LDS_BYTES, s);
+            else if (abl == 2) x3_go<VN_EPI_STORE, 1, 2>(a, tiles_m, tiles_n, 1, X3_LDS_BYTES, s);
+            else if (abl == 3) x3_go<VN_EPI_STORE, 1, 3>(a, tiles_m, tiles_n, 1, X3_LDS_BYTES, s);
+            else if (abl) x3_go<VN_EPI_STORE, 1, 4>(a, tiles_m, tiles_n, 1, X3_LDS_BYTES, s);
+            else if (pipe == 0) x3_go<VN_EPI_STORE, 0>(a, tiles_m, tiles_n, 1, X3_LDS_BYTES, s);
+            else x3_go<VN_EPI_STORE, 2>(a, tiles_m, tiles_n, 1, 3 * X3_STAGE_FLOATS * 4, s);
             vn_prof_post(ctx, pi, s);
             VN_LAUNCH_CHECK(ctx);
             return VN_OK;
         }
     }
-    if (pipe == 0) hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, 0>), dim3(tiles_m * tiles_n), dim3(512), X3_LDS_BYTES, s, a, tiles_m, tiles_n);
-    else hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, 1>), dim3(tiles_m * tiles_n), dim3(512), X3_LDS_BYTES, s, a, tiles_m, tiles_n);
+    if constexpr (EPI == VN_EPI_STORE || EPI == VN_EPI_RESIDUAL) {
+        const int ns = x3_pick_split(a, EPI == VN_EPI_RESIDUAL);
+        if (ns > 1) {
+            if (!ctx->x3_ws) VN_HIP_CHECK(ctx, hipMalloc((void**)&ctx->x3_ws, (size_t)X3_WS_FLOATS * sizeof(float)));
+            vn_gemm_args q = a;                       // every split stores its raw image [M][N] into the workspace
+            q.C = ctx->x3_ws;
+            q.ldc = a.N;
+            if (pipe == 1) x3_go<VN_EPI_STORE, 1>(q, tiles_m, tiles_n, ns, X3_LDS_BYTES, s);
+            else x3_go<VN_EPI_STORE, 3>(q, tiles_m, tiles_n, ns, X3_LDS_BYTES, s);
+            VN_LAUNCH_CHECK(ctx);
+            const int rc = vn_launch_splitk_reduce(ctx, ctx->x3_ws, ns, a.C, a.M, a.N, a.ldc, EPI == VN_EPI_RESIDUAL, s);
+            vn_prof_post(ctx, pi, s);
+            return rc;
+        }
+    }
+    if (pipe == 1) x3_go<EPI, 1>(a, tiles_m, tiles_n, 1, X3_LDS_BYTES, s);
+    else x3_go<EPI, 3>(a, tiles_m, tiles_n, 1, X3_LDS_BYTES, s);
     vn_prof_post(ctx, pi, s);
     VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+template <int EPI>
+static int x3_attrs(vn_ctx* ctx) {
+    VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
+    VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
     return VN_OK;
 }
 
@@ -388,16 +435,10 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
         return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: plane strides must be positive multiples of 8 elements%s", "");
     if (((uintptr_t)a.A | (uintptr_t)a.W) & 15) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: operands must be 16-byte aligned%s", "");
     if (!(ctx->attr_mask & VN_ATTR_GEMM_X3)) {
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_BIAS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_BIAS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_RESIDUAL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_RESIDUAL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_GEGLU, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_GEGLU, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_QKV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_QKV, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
+        int rc;
+        if ((rc = x3_attrs<VN_EPI_STORE>(ctx)) || (rc = x3_attrs<VN_EPI_BIAS>(ctx)) || (rc = x3_attrs<VN_EPI_RESIDUAL>(ctx)) ||
+            (rc = x3_attrs<VN_EPI_GEGLU>(ctx)) || (rc = x3_attrs<VN_EPI_QKV>(ctx)))
+            return rc;
         ctx->attr_mask |= VN_ATTR_GEMM_X3;
     }
     switch (epilogue) {

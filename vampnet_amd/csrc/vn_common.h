@@ -145,6 +145,7 @@ struct vn_ctx {
     float* sk_slabs;
     unsigned* sk_flags;
     float* zero_page;
+    float* x3_ws;            // split-K partial tiles of the bf16x3 GEMM (gemm_x3.hip), fixed size, allocated on first use
     // kernels whose dynamic-LDS limit was raised on THIS context's device (hipFuncSetAttribute is per device, and one
     // process may hold contexts on several)
     unsigned attr_mask;
@@ -208,6 +209,9 @@ struct vn_gemm_args {
 };
 int vn_launch_gemm_f32(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);
 int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);      // a.bf16 == 2
+// C[M][N] (row stride ldc) (+)= sum over the nsplit partial images partial[s][M][N], in fixed order (gemm_f32.hip)
+int vn_launch_splitk_reduce(vn_ctx* ctx, const float* partial, int nsplit, float* C, int M, int N, int ldc, bool residual,
+                            hipStream_t s);
 
 // y16 / out16: bf16 image of the output for the next GEMM; plane16 == 0 one plane, > 0 three split planes that far apart
 int vn_launch_rmsnorm(vn_ctx* ctx, const float* x, const float* w, float* y, int rows, int D, float eps, hipStream_t s,
