@@ -285,3 +285,41 @@ def test_mt19937_jump_polynomial(steps):
     jumped = np.array([np.bitwise_xor.reduce(stream[k + idx]) for k in range(624)], dtype=np.uint32)
     assert np.array_equal(jumped, stream[steps:steps + 624])
     assert np.array_equal(_mt_blocks(jumped, 1)[0], stream[steps + 624:steps + 1248])
+
+
+def test_bf16x3_split_numerics_on_the_host():
+    """The numerics claim behind precision="bf16x3" (DESIGN.md §3/§4), checked with torch on the CPU: (1) the three-way
+    bf16 split is EXACT (two exact fp32 remainders); (2) the six kept plane products, each exact in fp32 and accumulated in
+    fp32, are as close to the float64 product as an fp32-accumulating fp32 GEMM; (3) keeping fewer terms is not."""
+    g = torch.Generator().manual_seed(0)
+
+    def bf(x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    def split3(x):
+        p0 = bf(x)
+        r1 = x - p0
+        p1 = bf(r1)
+        return p0, p1, bf(r1 - p1)
+
+    x = torch.cat([torch.randn(4096, generator=g), torch.randn(4096, generator=g) * 1e-20, torch.randn(4096, generator=g) * 1e20])
+    p = split3(x)
+    assert torch.equal(p[0] + p[1] + p[2], x)                       # exact, incl. tiny / huge magnitudes
+    assert torch.equal(p[2], bf(p[2])) and torch.equal((x - p[0]) - p[1], p[2])
+    M, N, K = 257, 384, 1280
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    ref = A.double() @ W.double().t()
+    e_f32 = ((A @ W.t()).double() - ref).abs().max().item()
+    a, w = split3(A), split3(W)
+
+    def terms(pairs):
+        acc = torch.zeros(M, N)
+        for i, j in pairs:
+            acc = acc + a[i] @ w[j].t()
+        return (acc.double() - ref).abs().max().item()
+
+    six = terms([(0, 2), (2, 0), (1, 1), (0, 1), (1, 0), (0, 0)])
+    three = terms([(0, 1), (1, 0), (0, 0)])
+    assert six <= 1.5 * e_f32 + 1e-7, (six, e_f32)                  # fp32 class (measured: 1.4e-6 vs 2.9e-6 at K = 1280)
+    assert three > 4 * six                                          # the 2^-16 terms matter: ~2e-5
