@@ -7,7 +7,7 @@ exactly those keyword names (unloop/client.py:116-186).  This module keeps both 
 (gradio, FastAPI, OSC) binds `VampService.api_vamp` with the reference's argument list and existing clients keep working.
 
 Out of scope here (documented errors, not silent fallbacks): `pitch_shift_amt != 0` (torch_pitch_shift is absent),
-`beat_mask_ms > 0` (WaveBeat), `onset_mask_width > 0` (librosa) and the HF-hub model zoo behind `load_finetuned` —
+`beat_mask_ms > 0` (WaveBeat) and the HF-hub model zoo behind `load_finetuned` —
 `model_choice` resolves through a local `{name: (coarse_ckpt, c2f_ckpt)}` registry instead.
 """
 from typing import Dict, Optional, Sequence, Tuple
