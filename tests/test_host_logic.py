@@ -382,3 +382,23 @@ def test_onset_detect_finds_clicks_and_builds_the_mask():
     torch.manual_seed(0)
     full = M.build_mask(z, periodic_prompt=0, onset_mask=m, upper_codebook_mask=3)
     assert torch.equal(full[:, :3], m[:, :3]) and bool((full[:, 3:] == 1).all())
+
+
+def test_jump_polynomial_disk_cache(tmp_path, monkeypatch):
+    """jump_poly_words keeps its 2 496-byte results on disk (VN_CACHE_DIR): a second process does not recompute, a damaged or
+    unwritable cache only costs the recomputation."""
+    from vampnet_amd import mt_jump as J
+    monkeypatch.setenv("VN_CACHE_DIR", str(tmp_path))
+    steps = 777_777
+    want = np.frombuffer(J.jump_poly(steps).to_bytes(624 * 4, "little"), dtype=np.uint32)
+    a = J.jump_poly_words(steps)
+    f = tmp_path / f"mtjump_{steps}.bin"
+    assert np.array_equal(a, want) and f.exists() and f.stat().st_size == 2496
+    monkeypatch.setattr(J, "jump_poly", lambda s: (_ for _ in ()).throw(AssertionError("recomputed")))
+    assert np.array_equal(J.jump_poly_words(steps), want)          # served from the file
+    monkeypatch.undo()
+    monkeypatch.setenv("VN_CACHE_DIR", str(tmp_path))
+    f.write_bytes(b"short")                                         # damaged entry: recomputed and repaired
+    assert np.array_equal(J.jump_poly_words(steps), want) and f.stat().st_size == 2496
+    monkeypatch.setenv("VN_CACHE_DIR", "/proc/definitely/not/writable")
+    assert np.array_equal(J.jump_poly_words(steps), want)

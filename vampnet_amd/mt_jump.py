@@ -14,6 +14,7 @@ g is computed here with Python integers as GF(2)[x] bit vectors (squaring = bit 
 (tests/test_host_logic.py::test_mt19937_characteristic_polynomial recomputes it).
 """
 import functools
+import os
 
 import numpy as np
 
@@ -64,10 +65,32 @@ def jump_poly(steps: int) -> int:
     return r
 
 
+def _cache_dir():
+    """On-disk cache of jump polynomials (2 496 bytes each): VN_CACHE_DIR, else <package>/.cache.  Best effort: any I/O
+    problem just means the polynomial is recomputed (~40 ms)."""
+    return os.environ.get("VN_CACHE_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), ".cache")
+
+
 def jump_poly_words(steps: int) -> np.ndarray:
-    """jump_poly as 624 little-endian uint32 words (bits 19 937 .. 19 967 are zero) for the device kernel."""
-    g = jump_poly(steps)
-    return np.frombuffer(g.to_bytes(624 * 4, "little"), dtype=np.uint32).copy()
+    """jump_poly as 624 little-endian uint32 words (bits 19 937 .. 19 967 are zero) for the device kernel.  A process that
+    draws a new noise shape needs ~20 of these; they only depend on `steps`, so they are kept on disk between runs."""
+    path = os.path.join(_cache_dir(), f"mtjump_{int(steps)}.bin")
+    try:
+        raw = open(path, "rb").read()
+        if len(raw) == 624 * 4:
+            return np.frombuffer(raw, dtype="<u4").astype(np.uint32)
+    except OSError:
+        pass
+    words = np.frombuffer(jump_poly(steps).to_bytes(624 * 4, "little"), dtype="<u4").astype(np.uint32)
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(words.astype("<u4").tobytes())
+        os.replace(tmp, path)                                   # atomic: concurrent ranks may race for the same file
+    except OSError:
+        pass
+    return words
 
 
 def berlekamp_massey_gf2(bits) -> int:
