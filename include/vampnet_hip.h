@@ -214,6 +214,8 @@ int vn_gemm_bf16x3(vn_ctx* ctx, const void* A3, int64_t a_plane, const void* W3,
  * (C = A0 W0 + 2^-11 (A0 W1 + A1 W0)), fp32 accumulate: half the matrix work, two thirds of the operand bytes, the same
  * error class (vampnet_amd/csrc/gemm_h2.hip).  tile_m: 128 or 256; nsplit: k-splits (1; 2..8 for epilogues 0 / 2).     */
 int vn_split2h_f32(vn_ctx* ctx, const float* src, void* dst16, int64_t n, int64_t plane_stride, void* stream);
+/* STAGED: switch a model's GEMMs to the f16x2 kernel (weights = vn_split2h_f32 of the packed blob); NULL = back to fp32 */
+int vn_model_set_f16x2(vn_model* model, const void* blob_planes_dev, int64_t plane_stride);
 int vn_gemm_f16x2(vn_ctx* ctx, const void* A2, int64_t a_plane, const void* W2, int64_t w_plane, const float* bias,
                   float* C, int M, int N, int K, int epilogue, int tile_m, int nsplit, void* stream);
 

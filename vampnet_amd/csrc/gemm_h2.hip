@@ -294,6 +294,32 @@ static int vn_launch_gemm_h2(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, i
     return vn_fail(ctx, VN_ERR_INVALID, "gemm_h2: tile_m must be 128 or 256 (got %s%ld)", "", tile_m);
 }
 
+// model-path launcher (engine.hip, precision "f16x2"): tile height from VN_H2_TILE (128 | 256, default 128), split count for
+// the store / residual epilogues from the same cost model as gemm_x3.hip with this kernel's (estimated) k-tile time
+int vn_launch_gemm_h2_auto(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s) {
+    static const int tile_m = [] { const char* e = getenv("VN_H2_TILE"); return e && atoi(e) == 256 ? 256 : 128; }();
+    static const int forced = [] { const char* e = getenv("VN_H2_SPLITK"); return e ? atoi(e) : -1; }();
+    int ns = 1;
+    if ((epilogue == VN_EPI_STORE || epilogue == VN_EPI_RESIDUAL) && forced != 0 && forced != 1 && !(a.N & 3) && !(a.ldc & 3)) {
+        const int tiles = vn_cdiv(a.M, tile_m) * vn_cdiv(a.N, 128), nk = a.K / H2_KT;
+        const double t_ktile = tile_m == 256 ? 1.4 : 0.8;                     // us per k-tile and round: to be calibrated
+        double best = 1e300;
+        for (int c = 1; c <= 4; c *= 2) {
+            if (c > 1 && (nk / c < 8 || (double)c * a.M * a.N > (double)H2_WS_FLOATS)) continue;
+            double cost = ceil(tiles * c / 256.0) * (nk / (double)c) * t_ktile;
+            if (c > 1) cost += (c + (epilogue == VN_EPI_RESIDUAL ? 2 : 1)) * 4.0 * a.M * (double)a.N / 3.5e6;
+            if (forced > 1) cost = (c == forced) ? 0 : 1e299;
+            if (cost < best) { best = cost; ns = c; }
+        }
+    }
+    const double n_out = (epilogue == VN_EPI_GEGLU) ? a.N / 2 : a.N;
+    const double bytes = 4.0 * ((double)a.M * a.K + (double)a.N * a.K) + 4.0 * (double)a.M * n_out * (epilogue == VN_EPI_RESIDUAL ? 2 : 1);
+    const int pi = vn_prof_pre(ctx, 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);       // algorithmic (fp32-equivalent) flops
+    const int rc = vn_launch_gemm_h2(ctx, a, epilogue, tile_m, ns, s);
+    vn_prof_post(ctx, pi, s);
+    return rc;
+}
+
 // ---- plane builder: dst[0][i] = h0, dst[plane_stride + i] = h1
 __global__ __launch_bounds__(256) void vn_split2h_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long n4,
                                                          long plane) {
@@ -319,6 +345,10 @@ extern "C" int vn_split2h_f32(vn_ctx* ctx, const float* src, void* dst16, int64_
     hipLaunchKernelGGL(vn_split2h_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)dst16, n4, (long)plane_stride);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
+}
+
+int vn_launch_split2h(vn_ctx* ctx, const float* src, uint16_t* dst, long n, long plane_stride, hipStream_t s) {
+    return vn_split2h_f32(ctx, src, dst, n, plane_stride, s);
 }
 
 // single-op entry (tests / tuning): A2 [2][M][K] and W2 [2][N][K] fp16 split planes -> fp32 C

@@ -273,6 +273,7 @@ class VampNetModel:
         self.handle = h
         self.blob16 = None
         self.blob3 = None
+        self.blob2h = None
         self.precision = "f32"
         self.set_precision(precision)
 
@@ -292,10 +293,18 @@ class VampNetModel:
                 self.engine.check(self.lib.vn_split3_f32(self.engine.handle, self.blob.data_ptr(), self.blob3.data_ptr(), n, n,
                                                          self.engine.stream()), "vn_split3_f32")
             self.engine.check(self.lib.vn_model_set_bf16x3(self.handle, self.blob3.data_ptr(), n), "vn_model_set_bf16x3")
+        elif precision == "f16x2":
+            # STAGED for round 2 (csrc/gemm_h2.hip, not yet validated on a GPU): two fp16 planes per operand, three MFMA products
+            n = self.blob.numel()
+            if self.blob2h is None:
+                self.blob2h = torch.empty(2 * n, dtype=torch.float16, device=self.device)
+                self.engine.check(self.lib.vn_split2h_f32(self.engine.handle, self.blob.data_ptr(), self.blob2h.data_ptr(), n, n,
+                                                          self.engine.stream()), "vn_split2h_f32")
+            self.engine.check(self.lib.vn_model_set_f16x2(self.handle, self.blob2h.data_ptr(), n), "vn_model_set_f16x2")
         elif precision == "f32":
             self.engine.check(self.lib.vn_model_set_bf16(self.handle, None), "vn_model_set_bf16")
         else:
-            raise ValueError("precision must be 'f32', 'bf16x3' or 'bf16'")
+            raise ValueError("precision must be 'f32', 'bf16x3', 'bf16' or (staged) 'f16x2'")
         self.precision = precision
 
     @property
