@@ -246,30 +246,39 @@ static int forward_i32_h2(vn_model* m, const int32_t* z, int B, int T, float* lo
         return rc;
     const long plane = (long)B * H * T * VN_DHEAD;
     const long yp = m->max_rows * (long)D, gp = 2 * yp;
+    // VN_H2_FUSE=1: RMSNorm and the GEGLU epilogue write the planes themselves (only the attention output keeps its
+    // separate split pass); default 0 = every operand through fp32 + vn_split2h_kernel (the first thing to validate)
+    static const bool fuse = [] { const char* e = getenv("VN_H2_FUSE"); return e && e[0] == '1'; }();
     auto gemm = [&](const uint16_t* A2, long a_plane, int id, int layer, float* C, int N, int K, int ldc, int epi,
-                    const float* bias) {
+                    const float* bias, uint16_t* C16 = nullptr, long c_plane = 0) {
         vn_gemm_args a{};
         a.A = (const float*)A2; a.W = (const float*)(m->blob16 + vn_tensor_offset(&m->d, id, layer));
         a.bf16 = 3; a.a_plane = a_plane; a.w_plane = m->w_plane;
-        a.bias = bias; a.C = C; a.M = M; a.N = N; a.K = K; a.ldc = ldc;
+        a.bias = bias; a.C = C; a.C16 = C16; a.c_plane = c_plane; a.M = M; a.N = N; a.K = K; a.ldc = ldc;
         a.T = T; a.H = H; a.qkv_plane = plane;
         return vn_launch_gemm_h2_auto(ctx, a, epi, s);
     };
+    auto norm_planes = [&](const float* w) {            // m->x -> planes of RMSNorm(x) in m->y16
+        if (fuse) return vn_launch_rmsnorm_h2(ctx, m->x, w, m->y16, yp, M, D, m->d.eps, s);
+        int r = vn_launch_rmsnorm(ctx, m->x, w, m->y, M, D, m->d.eps, s);
+        return r ? r : vn_launch_split2h(ctx, m->y, m->y16, (long)M * D, yp, s);
+    };
     for (int l = 0; l < m->L; ++l) {
-        if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM1, l), m->y, M, D, m->d.eps, s))) return rc;
-        if ((rc = vn_launch_split2h(ctx, m->y, m->y16, (long)M * D, yp, s))) return rc;
+        if ((rc = norm_planes(W(m, VN_W_NORM1, l)))) return rc;
         if ((rc = gemm(m->y16, yp, VN_W_QKV, l, m->qkv, 3 * D, D, 3 * D, VN_EPI_QKV, nullptr))) return rc;
         if ((rc = vn_launch_attention(ctx, m->qkv, m->qkv + plane, m->qkv + 2 * plane, m->bias_full, m->y, B, H, T, s))) return rc;
         if ((rc = vn_launch_split2h(ctx, m->y, m->y16, (long)M * D, yp, s))) return rc;
         if ((rc = gemm(m->y16, yp, VN_W_WO, l, m->x, D, D, D, VN_EPI_RESIDUAL, nullptr))) return rc;              // x = x + attn
-        if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM3, l), m->y, M, D, m->d.eps, s))) return rc;
-        if ((rc = vn_launch_split2h(ctx, m->y, m->y16, (long)M * D, yp, s))) return rc;
-        if ((rc = gemm(m->y16, yp, VN_W_W1, l, m->g, 4 * D, D, 2 * D, VN_EPI_GEGLU, nullptr))) return rc;          // g = p1 * gelu(p2)
-        if ((rc = vn_launch_split2h(ctx, m->g, m->g16, (long)M * 2 * D, gp, s))) return rc;
+        if ((rc = norm_planes(W(m, VN_W_NORM3, l)))) return rc;
+        if (fuse) {
+            if ((rc = gemm(m->y16, yp, VN_W_W1, l, m->g, 4 * D, D, 2 * D, VN_EPI_GEGLU, nullptr, m->g16, gp))) return rc;
+        } else {
+            if ((rc = gemm(m->y16, yp, VN_W_W1, l, m->g, 4 * D, D, 2 * D, VN_EPI_GEGLU, nullptr))) return rc;      // g = p1 * gelu(p2)
+            if ((rc = vn_launch_split2h(ctx, m->g, m->g16, (long)M * 2 * D, gp, s))) return rc;
+        }
         if ((rc = gemm(m->g16, gp, VN_W_W2, l, m->x, D, 2 * D, D, VN_EPI_RESIDUAL, nullptr))) return rc;           // x = x + ffn
     }
-    if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_FINAL_NORM), m->y, M, D, m->d.eps, s))) return rc;
-    if ((rc = vn_launch_split2h(ctx, m->y, m->y16, (long)M * D, yp, s))) return rc;
+    if ((rc = norm_planes(W(m, VN_W_FINAL_NORM)))) return rc;
     const int NV = m->Cp * m->d.vocab;
     return gemm(m->y16, yp, VN_W_CLS_W, 0, logits, NV, D, NV, VN_EPI_BIAS, W(m, VN_W_CLS_B));
 }

@@ -320,6 +320,53 @@ int vn_launch_gemm_h2_auto(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hip
     return rc;
 }
 
+// ---- RMSNorm writing the two fp16 planes directly (VN_H2_FUSE=1; same arithmetic as vn_rmsnorm_kernel in elementwise.hip:
+// one wave per row, float4 loads, shuffle reduce, exact 1/sqrt) — saves the separate split pass over the normalised rows
+template <int VEC>
+__global__ __launch_bounds__(256) void vn_rmsnorm_h2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            uint16_t* __restrict__ y2, long plane, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const f32x4* xr = (const f32x4*)(x + (size_t)row * D);
+    f32x4 v[VEC];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        v[i] = xr[lane + 64 * i];
+        ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float rstd = 1.0f / sqrtf(ss / (float)D + eps);
+    const f32x4* wr = (const f32x4*)w;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        const f32x4 ww = wr[lane + 64 * i];
+        uint16_t t[2][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vn_split2h(ww[e] * (v[i][e] * rstd), t[0][e], t[1][e]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            uint2 pk;
+            pk.x = t[q][0] | ((unsigned)t[q][1] << 16);
+            pk.y = t[q][2] | ((unsigned)t[q][3] << 16);
+            *(uint2*)(y2 + q * plane + (size_t)row * D + 4 * (lane + 64 * i)) = pk;
+        }
+    }
+}
+
+int vn_launch_rmsnorm_h2(vn_ctx* ctx, const float* x, const float* w, uint16_t* y2, long plane, int rows, int D, float eps,
+                         hipStream_t s) {
+    if (rows <= 0) return VN_OK;
+    const dim3 grid(vn_cdiv(rows, 4)), block(256);
+    if (D == 1280) hipLaunchKernelGGL(vn_rmsnorm_h2_kernel<5>, grid, block, 0, s, x, w, y2, plane, rows, D, eps);
+    else if (D == 256) hipLaunchKernelGGL(vn_rmsnorm_h2_kernel<1>, grid, block, 0, s, x, w, y2, plane, rows, D, eps);
+    else return vn_fail(ctx, VN_ERR_UNSUPPORTED, "rmsnorm_h2: D=%s%ld unsupported (256 or 1280)", "", D);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
 // ---- plane builder: dst[0][i] = h0, dst[plane_stride + i] = h1
 __global__ __launch_bounds__(256) void vn_split2h_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long n4,
                                                          long plane) {
