@@ -25,6 +25,13 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name)
     assert b"gfx950" in lib.vn_version()
+    # the ctypes prototypes carry as many arguments as the C declarations (a short list would silently pass garbage)
+    code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    decls = re.findall(r"\b(?:int|void|const char\*)\s+\*?\s*(vn_\w+)\s*\(([^;{]*?)\)\s*;", code, flags=re.S)
+    assert {n for n, _ in decls} == declared
+    for name, args in decls:
+        n_args = 0 if args.strip() in ("", "void") else len(args.split(","))
+        assert n_args == len(_lib.SYMBOLS[name][1]), (name, n_args, len(_lib.SYMBOLS[name][1]))
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
