@@ -5,6 +5,8 @@ itself pinned bitwise to the reference's modules by tests/test_oracle_vs_referen
 Dropout: the engine's counter-based keep-masks are read back through the C ABI (vn_dropout_keep_mask) and INJECTED into
 the oracle, so both sides see the same noise.  Tolerances (fp32, different summation orders; stated per assert):
 logits 2e-5 abs, loss 1e-5 rel, every gradient tensor 1e-4 of its own max-abs, updated parameters: see _check_update."""
+import os
+
 import pytest
 import torch
 
@@ -436,3 +438,19 @@ def test_training_trajectory_tracks_oracle(engine):
         assert rel < 1e-4, (step, out["loss"].item(), loss_o.item())
     print(f"20-step trajectory: worst relative loss gap {worst:.2e}, final loss {out['loss'].item():.4f}")
     assert out["loss"].item() < 7.0          # and it learns (starts at ~7.1 = ln(1024) + smoothing)
+
+
+@pytest.mark.skipif(os.environ.get("VN_EXPERIMENTAL") != "1" or os.environ.get("VN_TRAIN_X3") == "1",
+                    reason="staged: training GEMMs on the bf16x3 kernel (VN_TRAIN_X3=1), not yet verified on a GPU")
+def test_training_step_on_bf16x3_gemms():
+    """STAGED (round 2): the same step-vs-oracle / determinism / trajectory tests with every training GEMM routed through
+    gemm_x3.hip (operands split on the fly).  VN_TRAIN_X3 is read once per process, hence the child process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, VN_TRAIN_X3="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_train.py", "-x", "-q", "-m", "gpu", "-k",
+                        "train_step_vs_oracle or deterministic or full_size_train_step or trajectory"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -438,3 +438,34 @@ def test_f16x2_split_numerics_on_the_host():
         got = a0 @ w0.t() + (a0 @ w1.t() + a1 @ w0.t()) / S
         e = (got.double() - ref).abs().max().item()
         assert e <= 1.5 * e_f32 + 1e-9 * scale, (K, scale, e, e_f32)
+
+
+def test_python_sources_have_no_unbound_names():
+    """A forgotten import in a `-m gpu` test file only shows up as a collection error on the GPU box: scan every Python source
+    for names that are read but bound nowhere in their module (imports, defs, assignments, arguments, builtins)."""
+    import ast
+    import builtins
+    import glob
+
+    def unbound(path):
+        tree = ast.parse(open(path).read(), path)
+        bound = set(dir(builtins)) | {"__file__", "__name__", "__doc__"}
+        for n in ast.walk(tree):
+            if isinstance(n, (ast.Import, ast.ImportFrom)):
+                bound.update((a.asname or a.name).split(".")[0] for a in n.names)
+            elif isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+                bound.add(n.name)
+            elif isinstance(n, ast.Name) and isinstance(n.ctx, (ast.Store, ast.Del)):
+                bound.add(n.id)
+            elif isinstance(n, ast.ExceptHandler) and n.name:
+                bound.add(n.name)
+            elif isinstance(n, ast.arg):
+                bound.add(n.arg)
+        return [(n.lineno, n.id) for n in ast.walk(tree)
+                if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id not in bound]
+
+    files = [f for pat in ("*.py", "vampnet_amd/*.py", "tests/*.py", "oracle/*.py", "scripts/*.py", "examples/*.py")
+             for f in glob.glob(os.path.join(ROOT, pat))]
+    assert len(files) > 30
+    bad = {os.path.relpath(f, ROOT): u for f in files if (u := unbound(f))}
+    assert not bad, bad

@@ -233,10 +233,46 @@ static vn_drop make_drop(const vn_train_params* p, int layer, int site, long row
     return d;
 }
 
+// STAGED (round 2; VN_TRAIN_X3=1, not yet run on a GPU): route every GEMM of the training step — forward, dX and dW —
+// through the bf16x3 kernel (gemm_x3.hip, verified on the inference path).  Both fp32 operands are split into their three
+// exact bf16 planes on the fly (vn_split3_f32: two extra HBM passes per GEMM, ~10 % of its time), so nothing else in
+// the step changes; bf16 keeps fp32's exponent range, which the tiny dlogits / dY magnitudes of the backward pass need
+// (an fp16-based split would not).  Scratch planes are per process and grow on demand (hipFree synchronises).
+static bool train_x3() {
+    static const bool on = [] { const char* e = getenv("VN_TRAIN_X3"); return e && e[0] == '1'; }();
+    return on;
+}
+static uint16_t* x3_scratch(int which, size_t elems) {
+    static uint16_t* buf[2] = {nullptr, nullptr};
+    static size_t cap[2] = {0, 0};
+    if (cap[which] < elems) {
+        if (buf[which]) (void)hipFree(buf[which]);
+        buf[which] = nullptr; cap[which] = 0;
+        const size_t want = elems + elems / 4;
+        if (hipMalloc((void**)&buf[which], want * sizeof(uint16_t)) != hipSuccess) return nullptr;
+        cap[which] = want;
+    }
+    return buf[which];
+}
+static int gemm_x3_on_the_fly(vn_ctx* ctx, vn_gemm_args a, int epi, hipStream_t s) {
+    if ((a.N & 63) || (a.K & 31)) return vn_launch_gemm_f32(ctx, a, epi, s);          // shapes the x3 kernel does not take
+    const long na = (long)a.M * a.K, nw = (long)a.N * a.K;
+    const long pa = (na + 63) & ~63L, pw = (nw + 63) & ~63L;
+    uint16_t* A3 = x3_scratch(0, (size_t)3 * pa);
+    uint16_t* W3 = x3_scratch(1, (size_t)3 * pw);
+    if (!A3 || !W3) return vn_fail(ctx, VN_ERR_OOM, "training bf16x3: scratch planes%s", "");
+    int rc;
+    if ((rc = vn_split3_f32(ctx, a.A, A3, na, pa, s))) return rc;
+    if ((rc = vn_split3_f32(ctx, a.W, W3, nw, pw, s))) return rc;
+    a.A = (const float*)A3; a.W = (const float*)W3; a.bf16 = 2; a.a_plane = pa; a.w_plane = pw;
+    return vn_launch_gemm_x3(ctx, a, epi, s);
+}
+
 static int gemm(vn_ctx* ctx, const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int epi,
                 hipStream_t s) {
     vn_gemm_args a{};
     a.A = A; a.W = W; a.bias = bias; a.C = C; a.M = M; a.N = N; a.K = K; a.ldc = N;
+    if (train_x3()) return gemm_x3_on_the_fly(ctx, a, epi, s);
     return vn_launch_gemm_f32(ctx, a, epi, s);
 }
 
@@ -363,7 +399,7 @@ static int forward_train(vn_train* t, int B, int T, const vn_train_params* p, hi
         vn_gemm_args a{};
         a.A = S.y1; a.W = P(t, VN_W_QKV, l); a.C = S.qkv; a.M = M; a.N = 3 * D; a.K = D; a.ldc = 3 * D;
         a.T = T; a.H = H; a.qkv_plane = plane;
-        if ((rc = vn_launch_gemm_f32(ctx, a, VN_EPI_QKV, s))) return rc;
+        if ((rc = train_x3() ? gemm_x3_on_the_fly(ctx, a, VN_EPI_QKV, s) : vn_launch_gemm_f32(ctx, a, VN_EPI_QKV, s))) return rc;
         if ((rc = vn_launch_attention_train_fwd(ctx, S.qkv, S.qkv + plane, S.qkv + 2 * plane, m->bias_full, S.a, S.lse, B, H, T,
                                                 make_drop(p, l, SITE_ATTN, r_att), s)))
             return rc;
