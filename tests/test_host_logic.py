@@ -469,3 +469,74 @@ def test_python_sources_have_no_unbound_names():
     assert len(files) > 30
     bad = {os.path.relpath(f, ROOT): u for f in files if (u := unbound(f))}
     assert not bad, bad
+
+
+def test_split_plane_gemm_lds_addressing():
+    """Model of the LDS layout of csrc/gemm_x3.hip (3 bf16 planes, verified on the GPU) and csrc/gemm_h2.hip (2 fp16 planes,
+    tile heights 128 / 256, STAGED): replay the per-lane LDS-DMA destinations and source swizzle, then check that every
+    ds_read_b128 fragment read fetches the (operand, plane, row, k) it feeds to the MFMA and that each of its four 16-lane
+    groups touches 16 distinct 16-byte slots of the 256-byte bank row (conflict-free)."""
+    def check(MI, planes):
+        BM = 128 * MI
+        APLANE = BM * 16            # floats
+        BPLANE = 128 * 16
+        STAGE = planes * APLANE + planes * BPLANE
+        NQ = (planes * BM + planes * 128) // 16
+        NPW = NQ // 8
+        assert NQ % 8 == 0
+        lds = {}                    # half index -> (op, plane, row, k)
+        for wave in range(8):
+            for j in range(NPW):
+                q = wave * NPW + j
+                for lane in range(64):
+                    drow, dslot = lane >> 2, (lane & 3) ^ ((lane >> 4) & 3)
+                    if q < planes * 8 * MI:
+                        plane, row = q // (8 * MI), (q % (8 * MI)) * 16 + drow
+                        op = "A"
+                    else:
+                        qb = q - planes * 8 * MI
+                        plane, row = qb >> 3, (qb & 7) * 16 + drow
+                        op = "W"
+                    base = (q * 256 + lane * 4) * 2
+                    for e in range(8):
+                        assert base + e not in lds
+                        lds[base + e] = (op, plane, row, dslot * 8 + e)
+        assert len(lds) == STAGE * 2, (len(lds), STAGE * 2)
+        # bank conflicts of the ds_read_b128 groups
+        groups = [[0,1,2,3,12,13,14,15,20,21,22,23,24,25,26,27], [4,5,6,7,8,9,10,11,16,17,18,19,28,29,30,31]]
+        groups += [[l + 32 for l in g] for g in groups]
+        for wave in range(8):
+            wm, wn = wave >> 1, wave & 1
+            for s in range(2):
+                for q in range(planes):
+                    for i in range(MI):
+                        addrs = {}
+                        for lane in range(64):
+                            l31, h, sw = lane & 31, lane >> 5, (lane >> 2) & 3
+                            aRow = (wm * 32 * MI + l31) * 16
+                            off = ((2 * s + h) ^ sw) * 4
+                            fo = q * APLANE + aRow + i * 32 * 16 + off
+                            addrs[lane] = fo * 4
+                            for e in range(8):
+                                assert lds[fo * 2 + e] == ("A", q, wm * 32 * MI + i * 32 + l31, (2 * s + h) * 8 + e), (MI, wave, lane)
+                        for g in groups:
+                            slots = {(addrs[l] // 16) % 16 for l in g}
+                            assert len(slots) == 16, ("bank conflict A", MI, wave, s, q, i)
+                    for j in range(2):
+                        addrs = {}
+                        for lane in range(64):
+                            l31, h, sw = lane & 31, lane >> 5, (lane >> 2) & 3
+                            bRow = (wn * 64 + l31) * 16
+                            off = ((2 * s + h) ^ sw) * 4
+                            fo = planes * APLANE + q * BPLANE + bRow + j * 32 * 16 + off
+                            addrs[lane] = fo * 4
+                            for e in range(8):
+                                assert lds[fo * 2 + e] == ("W", q, wn * 64 + j * 32 + l31, (2 * s + h) * 8 + e), (MI, wave, lane)
+                        for g in groups:
+                            assert len({(addrs[l] // 16) % 16 for l in g}) == 16, ("bank conflict W",)
+        return STAGE * 4, NPW
+
+
+    assert check(1, 3) == (48 * 1024, 6)          # gemm_x3.hip
+    assert check(1, 2) == (32 * 1024, 4)          # gemm_h2.hip, 128 x 128
+    assert check(2, 2) == (48 * 1024, 6)          # gemm_h2.hip, 256 x 128
