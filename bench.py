@@ -321,7 +321,10 @@ def main():
                                "frac": (fl / (ms * 1e-3) / 1e12) / peak if ms else None,
                                "traffic": traffic, "algorithmic_bytes_per_launch": gbytes / n if n else None, "launches": int(n), "avg_launch_us": 1e3 * ms / n if n else None,
                                **({"peak_basis": "2500 TF dense bf16 MFMA / 6 plane products per fp32-grade product",
-                                   "executed_mfma_tflops": 6.0 * fl / (ms * 1e-3) / 1e12 if ms else None}
+                                   "executed_mfma_tflops": 6.0 * fl / (ms * 1e-3) / 1e12 if ms else None,
+                                   # context: the same algorithmic rate against the fp32-input MFMA peak (157.3 TF), the
+                                   # ceiling of the exact-fp32 kernel this precision replaces
+                                   "achieved_over_f32_mfma_peak": fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF if ms else None}
                                   if args.dtype == "bf16x3" else {}),
                                "event_stride": args.event_stride,        # launches / times above: the bracketed sample
                                "gemm_time_frac": args.event_stride * ms / (1e3 * elapsed) if elapsed else None,
