@@ -188,3 +188,61 @@ def test_batch_shard_two_ranks_gloo(B):
         assert p.exitcode == 0
     for r in range(2):
         assert (got[r] == ref.numpy()).all(), f"rank {r} differs from the unsharded result"
+
+
+def test_model_registry_beats_and_onset_surface(monkeypatch):
+    """The rest of the reference Interface surface (interface.py:128-144, :226-321, :454-489): the model-zoo calls over a
+    local registry, snap_to_beats / make_beat_mask over an injected tracker, build_mask with the onset and beat masks."""
+    import numpy as np
+    from vampnet_amd.codec import AudioSignal
+    itf, _ = make_interface()
+    monkeypatch.setattr(Interface, "model_zoo", {})
+    assert Interface.available_models() == ["default"]
+    itf.load_finetuned("default")                                   # nothing registered: keeps the loaded weights
+    with pytest.raises(AssertionError):
+        itf.load_finetuned("opera")
+    Interface.register_model("opera", "/m/opera/coarse.pth", "/m/opera/c2f.pth")
+    assert Interface.available_models() == ["opera", "default"]
+    calls = []
+    itf.reload = lambda coarse_ckpt=None, c2f_ckpt=None: calls.append((coarse_ckpt, c2f_ckpt))
+    itf.load_finetuned("opera")
+    assert calls == [("/m/opera/coarse.pth", "/m/opera/c2f.pth")]
+    # s2t on arrays (beat times) like the reference
+    assert itf.s2t(np.array([0.0, 0.5, 1.0])).tolist() == [0.0, 29.0, 58.0] and itf.s2t(0.5) == 29
+    sr = itf.codec.sample_rate
+    sig = AudioSignal(torch.zeros(1, 1, 3 * sr), sr)
+    with pytest.raises(AssertionError):
+        itf.make_beat_mask(sig)
+
+    class Tracker:
+        def extract_beats(self, signal):
+            return np.array([0.5, 1.0, 1.5, 2.0, 2.5]), np.array([0.5, 2.5])
+
+    itf.beat_tracker = Tracker()
+    cut = itf.snap_to_beats(sig)
+    assert cut.length == int(2.5 * sr) - int(0.5 * sr) and sig.length == 3 * sr          # trimmed copy, input untouched
+    torch.manual_seed(0)
+    m = itf.make_beat_mask(sig, after_beat_s=0.05)
+    T = itf.s2t(3.0)
+    assert m.shape == (1, 14, T) and m.dtype == torch.long
+    open_cols = torch.nonzero(m[0, 0] == 0).flatten().tolist()
+    w = itf.s2t(0.05)
+    want = sorted({c for b in (0.5, 1.0, 1.5, 2.0, 2.5) for c in range(int(itf.s2t(b)), int(itf.s2t(b)) + w)})
+    assert open_cols == want and torch.equal(m[0, 0], m[0, 13])
+    # app.py:207-216: mask_and(build_mask, beat mask) — the caller re-masks the upper codebooks afterwards (codebook_mask)
+    z = W.synth_codes(1, 14, T, seed=2)
+    torch.manual_seed(1)
+    bm = itf.build_mask(z, periodic_prompt=0)
+    both = torch.min(bm, m)
+    assert torch.equal(both, m) and bool((bm[:, 3:] == 1).all())
+    # onset mask through build_mask
+    y = np.zeros(3 * sr, dtype=np.float32)
+    rng = np.random.default_rng(0)
+    for t0 in (0.7, 1.9):
+        i = int(t0 * sr)
+        y[i:i + 4000] += (0.5 * rng.standard_normal(4000) * np.exp(-np.arange(4000) / 800.0)).astype(np.float32)
+    y += 1e-4 * rng.standard_normal(len(y)).astype(np.float32)
+    torch.manual_seed(1)
+    om = itf.build_mask(z, sig=AudioSignal(torch.from_numpy(y)[None, None], sr), periodic_prompt=0, onset_mask_width=2)
+    cols = torch.nonzero(om[0, 0] == 0).flatten().tolist()
+    assert 4 <= len(cols) <= 8 and all(abs(c - itf.s2t(0.7)) <= 6 or abs(c - itf.s2t(1.9)) <= 6 for c in cols)

@@ -258,3 +258,41 @@ def test_train_step_vs_reference(ns, tiny, which, p):
         torch.testing.assert_close(norm, norm_ref, rtol=1e-6, atol=0)
         for k, v in model.state_dict().items():
             torch.testing.assert_close(cur[k], v, rtol=1e-6, atol=1e-9, msg=k)
+
+
+class _FakeTracker:
+    """Stands in for the WaveBeat tracker (out of scope): fixed beat / down-beat times in seconds."""
+    def __init__(self, beats, downbeats):
+        self.beats, self.downbeats = np.asarray(beats, dtype=np.float64), np.asarray(downbeats, dtype=np.float64)
+
+    def extract_beats(self, signal):
+        return self.beats, self.downbeats
+
+
+class _Sig:
+    def __init__(self, duration):
+        self.duration = duration
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(after_beat_s=0.1, before_beat_s=0.05), dict(dropout=0.4, after_beat_s=0.08),
+                                dict(mask_downbeats=False, beat_downsample_factor=2), dict(mask_upbeats=False, invert=False),
+                                dict(downbeat_downsample_factor=2, after_beat_s=0.3)])
+def test_make_beat_mask_bitwise(tiny, kw):
+    """Interface.make_beat_mask (interface.py:241-321) with an injected tracker: the product's host arithmetic
+    (vampnet_amd/masks.py::beat_mask) equals the reference's own method, incl. its bernoulli draws per beat window, the
+    down-beats-are-not-up-beats rule, python slice semantics at the clip start and the 14-codebook repeat."""
+    from vampnet_amd import masks as M
+    beats = np.array([0.01, 0.52, 1.03, 1.49, 2.0, 2.51, 3.02, 3.55, 4.01, 4.6, 5.2, 5.9])
+    downbeats = beats[::4]
+    itf = tiny["itf"]
+    itf.beat_tracker = _FakeTracker(beats, downbeats)
+    try:
+        for seed in (0, 1):
+            torch.manual_seed(seed)
+            ref = itf.make_beat_mask(_Sig(6.2), **kw)
+            a = torch.rand(2)
+            torch.manual_seed(seed)
+            got = M.beat_mask(beats, downbeats, 6.2, itf.codec.sample_rate, itf.codec.hop_length, 14, **kw)
+            assert ref.dtype == got.dtype and torch.equal(ref, got) and torch.equal(a, torch.rand(2))
+    finally:
+        itf.beat_tracker = None

@@ -114,6 +114,14 @@ def test_request_mapping_follows_vamp_internal():
     for bad in (dict(pitch_shift_amt=2), dict(beat_mask_ms=100)):
         with pytest.raises(NotImplementedError):
             svc.api_vamp(**_request(**bad))
+    # with a tracker the beat mask is AND-ed in and the upper codebooks re-masked (app.py:206-217)
+    rec.beat_tracker = object()
+    rec.make_beat_mask = lambda sig, after_beat_s: (rec.calls.append(("make_beat_mask", after_beat_s)),
+                                                    torch.zeros(1, 14, 20, dtype=torch.long))[1]
+    rec.calls.clear()
+    svc.api_vamp(**_request(beat_mask_ms=100, n_mask_codebooks=4))
+    assert ("make_beat_mask", 0.1) in rec.calls
+    assert bool((svc.last_mask[:, :4] == 0).all()) and bool((svc.last_mask[:, 4:] == 1).all())
     with pytest.raises(ValueError):
         svc.api_vamp(**_request(input_audio=None))
 

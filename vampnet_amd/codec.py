@@ -56,6 +56,16 @@ class AudioSignal:
     def batch_size(self):
         return self.samples.shape[0]
 
+    @property
+    def length(self):
+        return self.samples.shape[-1]
+
+    def trim(self, before: int, after: int):
+        """Drop `before` samples from the start and `after` from the end (audiotools' `AudioSignal.trim`)."""
+        end = self.samples.shape[-1] - after if after else self.samples.shape[-1]
+        self.samples = self.samples[..., before:end]
+        return self
+
     def to_mono(self):
         self.samples = self.samples.mean(dim=1, keepdim=True)
         return self

@@ -151,8 +151,29 @@ class Interface:
         raise RuntimeError("Interface.default() downloads checkpoints from the HF hub (vampnet/__init__.py:20-47); "
                            "pass local checkpoint paths instead")
 
+    # name -> (coarse_ckpt, c2f_ckpt): the local stand-in for the HF-hub model zoo behind vampnet.list_finetuned /
+    # download_finetuned (vampnet/__init__.py:20-47); fill it with Interface.register_model
+    model_zoo = {}
+
+    @classmethod
+    def register_model(cls, name: str, coarse_ckpt: str, c2f_ckpt: str = None):
+        cls.model_zoo[name] = (coarse_ckpt, c2f_ckpt)
+
+    @classmethod
+    def available_models(cls):
+        """interface.py:128-131: the fine-tuned model names + "default"."""
+        return [n for n in cls.model_zoo if n != "default"] + ["default"]
+
     def load_finetuned(self, name: str):
-        raise RuntimeError("load_finetuned() needs the HF hub; use reload(coarse_ckpt=..., c2f_ckpt=...) with local paths")
+        """interface.py:134-144 with the registry instead of a download; "default" without a registered path keeps the
+        weights that are loaded."""
+        assert name in self.available_models(), f"{name} is not a valid model name"
+        if name not in self.model_zoo:
+            if name == "default":
+                return
+            raise RuntimeError("load_finetuned() needs the HF hub; register local checkpoints with Interface.register_model")
+        coarse, c2f = self.model_zoo[name]
+        self.reload(coarse_ckpt=coarse, c2f_ckpt=c2f)
 
     def reload(self, coarse_ckpt: str = None, c2f_ckpt: str = None):
         """Hot-swap weights (interface.py:146-174); no-op when the path is already loaded."""
@@ -208,6 +229,34 @@ class Interface:
         assert z.ndim == 3
         z = z.masked_fill(z == self.coarse.mask_token, 0)
         return self.codec.decode_signal(z)          # AudioSignal(audio (B,1,T*hop), codec.sample_rate)
+
+    # ---- beats (interface.py:226-321): `beat_tracker` is any object with extract_beats(signal) -> (beats_s, downbeats_s);
+    # the reference's WaveBeat model is out of scope, the mask arithmetic around it is not
+    def snap_to_beats(self, signal):
+        assert getattr(self, "beat_tracker", None) is not None, "No beat tracker loaded"
+        beats, downbeats = self.beat_tracker.extract_beats(signal)
+        samples_begin = int(beats[0] * signal.sample_rate)
+        samples_end = int(beats[-1] * signal.sample_rate)
+        return signal.clone().trim(samples_begin, signal.length - samples_end)
+
+    def make_beat_mask(self, signal, before_beat_s: float = 0.0, after_beat_s: float = 0.02, mask_downbeats: bool = True,
+                       mask_upbeats: bool = True, downbeat_downsample_factor: int = None, beat_downsample_factor: int = None,
+                       dropout: float = 0.0, invert: bool = True):
+        assert self.beat_tracker is not None, "No beat tracker loaded"
+        beats, downbeats = self.beat_tracker.extract_beats(signal)
+        n_cb = self.c2f.n_codebooks if self.c2f is not None else self.coarse.n_codebooks
+        return masks.beat_mask(beats, downbeats, signal.duration, self.codec.sample_rate, self.codec.hop_length, n_cb,
+                               before_beat_s, after_beat_s, mask_downbeats, mask_upbeats, downbeat_downsample_factor,
+                               beat_downsample_factor, dropout, invert).to(self.device)
+
+    def visualize_codes(self, z: torch.Tensor):
+        """interface.py:564-573 (needs matplotlib, like the reference)."""
+        import matplotlib.pyplot as plt
+        fig = plt.figure(figsize=(10, 7))
+        fig.add_subplot(2, 1, 1)
+        plt.imshow(z[0].cpu().numpy(), aspect="auto", origin="lower", cmap="tab20", interpolation="none")
+        plt.title("codes")
+        plt.ylabel("codebook index")
 
     # ---- masks --------------------------------------------------------------------------------
     def build_mask(self, z: torch.Tensor, sig=None, rand_mask_intensity: float = 1.0, prefix_s: float = 0.0,

@@ -11,11 +11,14 @@ All draws are made on the CPU generator regardless of where `z` lives; the resul
 """
 import math
 
+import numpy as np
 import torch
 
 
-def seconds_to_tokens(seconds, sample_rate: int, hop_length: int) -> int:
-    """Interface.s2t (interface.py:176-181)."""
+def seconds_to_tokens(seconds, sample_rate: int, hop_length: int):
+    """Interface.s2t (interface.py:176-181): an int for a scalar, a float64 array of ceilings for a numpy array (beat times)."""
+    if isinstance(seconds, np.ndarray):
+        return np.ceil(seconds * sample_rate / hop_length)
     return math.ceil(seconds * sample_rate / hop_length)
 
 
@@ -94,6 +97,44 @@ def onset_mask(samples, sample_rate: int, z: torch.Tensor, hop_length: int, widt
         idx = int(idx)
         mask[:, :, idx - width:idx + width] = 0
     return mask
+
+
+def beat_mask(beats, downbeats, duration_s: float, sample_rate: int, hop_length: int, n_codebooks: int,
+              before_beat_s: float = 0.0, after_beat_s: float = 0.02, mask_downbeats: bool = True, mask_upbeats: bool = True,
+              downbeat_downsample_factor: int = None, beat_downsample_factor: int = None, dropout: float = 0.0,
+              invert: bool = True) -> torch.Tensor:
+    """Interface.make_beat_mask (interface.py:241-321) after the beat tracker: `beats` / `downbeats` are its times in seconds
+    (numpy arrays).  Marks [beat - before, beat + after) token windows (one bernoulli(1 - dropout) draw per window from the
+    torch CPU generator, in the reference's order: up-beats, then down-beats), clamps, inverts (1 = masked everywhere
+    except around the beats) and repeats over the codebooks.  Returns (1, n_codebooks, T) int64 on the CPU."""
+    s2t = lambda x: seconds_to_tokens(x, sample_rate, hop_length)
+    beats_z, downbeats_z = s2t(np.asarray(beats)), s2t(np.asarray(downbeats))
+    bz = torch.tensor(beats_z)
+    beats_z = bz[~torch.isin(bz, torch.tensor(downbeats_z))].tolist()          # a down-beat is not also an up-beat
+    downbeats_z = downbeats_z.tolist()
+    mask = torch.zeros(s2t(duration_s))
+    mask_b4, mask_after = s2t(before_beat_s), s2t(after_beat_s)
+    for name, f in (("beat", beat_downsample_factor), ("downbeat", downbeat_downsample_factor)):
+        if f is not None and f < 1:
+            raise ValueError("mask_beat_downsample_factor must be >= 1 or None")
+    beats_z = beats_z[::beat_downsample_factor or 1]
+    downbeats_z = downbeats_z[::downbeat_downsample_factor or 1]
+
+    def mark(indices):
+        for idx in indices:
+            a, b = int(idx - mask_b4), int(idx + mask_after)
+            m = torch.ones(mask[a:b].shape[0])                               # python slice semantics, incl. negative starts
+            m = m * torch.bernoulli(m * (1 - dropout)).long()
+            mask[a:b] = m
+
+    if mask_upbeats:
+        mark(beats_z)
+    if mask_downbeats:
+        mark(downbeats_z)
+    mask = mask.clamp(0, 1)
+    if invert:
+        mask = 1 - mask
+    return mask[None, None, :].bool().long().repeat(1, n_codebooks, 1)
 
 
 def build_mask(z: torch.Tensor, *, rand_mask_intensity=1.0, n_prefix=0, n_suffix=0, periodic_prompt=7,

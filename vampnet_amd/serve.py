@@ -7,7 +7,7 @@ exactly those keyword names (unloop/client.py:116-186).  This module keeps both 
 (gradio, FastAPI, OSC) binds `VampService.api_vamp` with the reference's argument list and existing clients keep working.
 
 Out of scope here (documented errors, not silent fallbacks): `pitch_shift_amt != 0` (torch_pitch_shift is absent),
-`beat_mask_ms > 0` (WaveBeat) and the HF-hub model zoo behind `load_finetuned` —
+`beat_mask_ms > 0` without an injected `interface.beat_tracker` (WaveBeat itself is not rebuilt) and the HF-hub model zoo behind `load_finetuned` —
 `model_choice` resolves through a local `{name: (coarse_ckpt, c2f_ckpt)}` registry instead.
 """
 from typing import Dict, Optional, Sequence, Tuple
@@ -147,12 +147,18 @@ class VampService:
         self._select_model(r["model_choice"])                                              # app.py:180
         if r["pitch_shift_amt"] != 0:
             raise NotImplementedError("pitch_shift_amt needs torch_pitch_shift (absent in this image)")
-        if r["beat_mask_ms"] > 0:
-            raise NotImplementedError("beat_mask_ms needs the WaveBeat tracker (out of scope, DESIGN.md §8)")
+        if r["beat_mask_ms"] > 0 and getattr(itf, "beat_tracker", None) is None:
+            raise NotImplementedError("beat_mask_ms needs a beat tracker: set interface.beat_tracker to an object with "
+                                      "extract_beats(signal) (the reference's WaveBeat model is out of scope, DESIGN.md §8)")
         codes = itf.encode(sig)
         mask = itf.build_mask(codes, sig=sig, periodic_prompt=r["periodic_p"],
                               onset_mask_width=r["onset_mask_width"], _dropout=r["dropout"],
                               upper_codebook_mask=r["n_mask_codebooks"])                   # app.py:198-205
+        if r["beat_mask_ms"] > 0:                                                          # app.py:206-217
+            beat = itf.make_beat_mask(sig, after_beat_s=r["beat_mask_ms"] / 1000.0)
+            mask = torch.min(mask, beat.to(mask.device))                                   # pmask.mask_and
+            mask = mask.clone()
+            mask[:, int(r["n_mask_codebooks"]):, :] = 1                                    # pmask.codebook_mask
         itf.set_chunk_size(self.chunk_size_s)
         top_p = r["top_p"]
         if top_p is not None and not top_p > 0:                                            # app.py:221-226
