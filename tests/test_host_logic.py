@@ -374,7 +374,7 @@ def test_onset_detect_finds_clicks_and_builds_the_mask():
     bt = ON.onset_detect(y, sr, hop, backtrack=True)
     assert len(bt) == len(times) and ((raw - bt) >= 0).all() and ((raw - bt) <= 4).all()   # rolled back to the preceding dip
     z = torch.zeros(2, 14, 575, dtype=torch.long)
-    m = M.onset_mask(torch.from_numpy(y)[None, None], sr, z, hop, width=3)
+    m = M.onset_mask_from_samples(torch.from_numpy(y)[None, None], sr, z, hop, width=3)
     assert m.shape == z.shape and m.dtype == torch.long
     cols = torch.nonzero(m[0, 0] == 0).flatten().tolist()
     exp = sorted({c for i in bt.tolist() for c in range(i - 3, i + 3)})
@@ -383,7 +383,7 @@ def test_onset_detect_finds_clicks_and_builds_the_mask():
     y2 = _click_track(sr, 2.0, [0.02])
     first = int(ON.onset_detect(y2, sr, hop)[0])
     assert first < 5
-    m2 = M.onset_mask(torch.from_numpy(y2)[None, None], sr, torch.zeros(1, 4, 115, dtype=torch.long), hop, width=5)
+    m2 = M.onset_mask_from_samples(torch.from_numpy(y2)[None, None], sr, torch.zeros(1, 4, 115, dtype=torch.long), hop, width=5)
     assert int((m2 == 0).sum()) == 0
     # composition inside build_mask: AND with the other masks, upper codebooks re-masked afterwards
     torch.manual_seed(0)

@@ -296,3 +296,62 @@ def test_make_beat_mask_bitwise(tiny, kw):
             assert ref.dtype == got.dtype and torch.equal(ref, got) and torch.equal(a, torch.rand(2))
     finally:
         itf.beat_tracker = None
+
+
+def test_mask_module_names_bitwise(ns):
+    """vampnet_amd.masks exposes vampnet/mask.py's function names and signatures: each equals the reference's function bit for
+    bit AND leaves torch's CPU generator at the same position (the functions are called in the same order under one seed)."""
+    from vampnet_amd import masks as M
+    R = ns.mask if hasattr(ns, "mask") else None
+    if R is None:
+        import importlib
+        R = importlib.import_module("vampnet.mask")
+    x = W.synth_codes(3, 14, 97, seed=8)
+    r = torch.tensor([0.1, 0.5, 0.9])
+
+    def both(f):
+        torch.manual_seed(5)
+        a = f(R)
+        ta = torch.rand(3)
+        torch.manual_seed(5)
+        b = f(M)
+        tb = torch.rand(3)
+        assert torch.equal(ta, tb), "RNG position differs"
+        if isinstance(a, tuple):
+            assert all(torch.equal(u, v) and u.dtype == v.dtype for u, v in zip(a, b))
+        else:
+            assert a.dtype == b.dtype and torch.equal(a, b)
+        return b
+
+    both(lambda P: P._gamma(r))
+    both(lambda P: P._invgamma(0.3))
+    both(lambda P: P._invgamma(torch.tensor([0.2, 0.9])))
+    both(lambda P: P.full_mask(x))
+    both(lambda P: P.empty_mask(x))
+    both(lambda P: P.random(x, r))
+    both(lambda P: P.random(x, 0.7))
+    both(lambda P: P.linear_random(x, 0.4))
+    both(lambda P: P.linear_random(x, torch.tensor([0.2, 0.5, 1.0])[:, None, None]))
+    both(lambda P: P.inpaint(x, 5, 9))
+    for P in (R, M):                       # per-item tensors: `if n_prefix > 0` is ambiguous in the reference too
+        with pytest.raises(RuntimeError):
+            P.inpaint(x, torch.tensor([0, 3, 7]), torch.tensor([2, 0, 11]))
+    both(lambda P: P.inpaint(x, 0, 0))
+    both(lambda P: P.periodic_mask(x, 7, 1, random_roll=True))
+    both(lambda P: P.periodic_mask(x, 5, 3, random_roll=False))
+    both(lambda P: P.periodic_mask(x, 0))
+    both(lambda P: P.periodic_mask(x, torch.tensor([6]), 2, random_roll=True))     # 1-element tensor: only item 0 is marked
+    for P in (R, M):
+        with pytest.raises(RuntimeError):
+            P.periodic_mask(x, torch.tensor([3, 0, 8]), 2)
+    m1 = both(lambda P: P.periodic_mask(x, 4))
+    m2 = both(lambda P: P.linear_random(x, 0.5))
+    both(lambda P: P.mask_and(m1, m2))
+    both(lambda P: P.mask_or(m1, m2))
+    both(lambda P: P.codebook_unmask(m2, 4))
+    both(lambda P: P.codebook_unmask(m2, None))
+    both(lambda P: P.codebook_mask(m1, 3))
+    both(lambda P: P.dropout(m1, 0.2))
+    both(lambda P: P.dropout(m1, 0.0))
+    both(lambda P: P.time_stretch_mask(x, 3))
+    both(lambda P: P.apply_mask(x, m2, 1024))

@@ -266,7 +266,7 @@ class Interface:
         onset = None
         if onset_mask_width > 0:
             assert sig is not None, "must provide a signal to use onset mask"
-            onset = masks.onset_mask(sig.samples, sig.sample_rate, z, self.codec.hop_length, width=onset_mask_width)
+            onset = masks.onset_mask(sig, z, self, width=onset_mask_width)
         return masks.build_mask(z, rand_mask_intensity=rand_mask_intensity, n_prefix=self.s2t(prefix_s),
                                 n_suffix=self.s2t(suffix_s), periodic_prompt=periodic_prompt,
                                 periodic_prompt_width=periodic_prompt_width, onset_mask=onset, dropout=_dropout,

@@ -85,7 +85,7 @@ def timestep_dropout(mask: torch.Tensor, p: float) -> torch.Tensor:
     return out
 
 
-def onset_mask(samples, sample_rate: int, z: torch.Tensor, hop_length: int, width: int = 1) -> torch.Tensor:
+def onset_mask_from_samples(samples, sample_rate: int, z: torch.Tensor, hop_length: int, width: int = 1) -> torch.Tensor:
     """onset_mask (mask.py:205-228): un-mask [idx - width, idx + width) around every detected onset frame of the FIRST item /
     channel of the signal.  Python slice semantics are kept on purpose: an onset closer than `width` frames to the start
     gives a negative slice start, i.e. (usually) an empty slice, exactly like the reference.  The detector restates
@@ -152,3 +152,135 @@ def build_mask(z: torch.Tensor, *, rand_mask_intensity=1.0, n_prefix=0, n_suffix
         m[:, :ncc, :] = 0
     m[:, int(upper_codebook_mask):, :] = 1
     return m.to(z.device)
+
+
+# ---- the reference module's own names and signatures (vampnet/mask.py), so that `from vampnet_amd import masks as pmask` serves
+# its callers (app.py:206-217, scripts/exp/train.py:250-254).  Same arithmetic, same torch-CPU RNG consumption; pinned against
+# the reference in tests/test_oracle_vs_reference.py::test_mask_module_names_bitwise.
+_gamma = gamma
+
+
+def _invgamma(y):
+    """mask.py:11-14"""
+    if not torch.is_tensor(y):
+        y = torch.tensor(y)[None]
+    return 2 * y.acos() / torch.pi
+
+
+def _batch(v, n):
+    """util.scalar_to_batch_tensor (util.py:6-7)"""
+    return torch.tensor(v).repeat(n)
+
+
+def full_mask(x: torch.Tensor):
+    assert x.ndim == 3, "x must be (batch, n_codebooks, seq)"
+    return torch.ones_like(x).long()
+
+
+def empty_mask(x: torch.Tensor):
+    assert x.ndim == 3, "x must be (batch, n_codebooks, seq)"
+    return torch.zeros_like(x).long()
+
+
+def random(x: torch.Tensor, r):
+    """mask.py:40-54 (the training mask, train.py:250): Bernoulli(gamma(r)) per element, r per batch item."""
+    assert x.ndim == 3, "x must be (batch, n_codebooks, seq)"
+    if not isinstance(r, torch.Tensor):
+        r = _batch(r, x.shape[0]).to(x.device)
+    probs = torch.ones_like(x) * gamma(r)[:, None, None]
+    return torch.bernoulli(probs).round().long()
+
+
+def linear_random(x: torch.Tensor, r):
+    """mask.py:56-73"""
+    assert x.ndim == 3, "x must be (batch, n_codebooks, seq)"
+    if not isinstance(r, torch.Tensor):
+        r = _batch(r, x.shape[0]).to(x.device).float()[:, None, None]
+    probs = torch.ones_like(x).float().expand(x.shape[0], x.shape[1], -1) * r
+    return torch.bernoulli(probs).round().long()
+
+
+def inpaint(x: torch.Tensor, n_prefix, n_suffix):
+    """mask.py:75-99: scalar or per-item prefix / suffix lengths."""
+    assert n_prefix is not None
+    assert n_suffix is not None
+    mask = full_mask(x)
+    if n_prefix > 0:
+        if not isinstance(n_prefix, torch.Tensor):
+            n_prefix = _batch(n_prefix, x.shape[0])
+        for i, n in enumerate(n_prefix):
+            if n > 0:
+                mask[i, :, :n] = 0
+    if n_suffix > 0:
+        if not isinstance(n_suffix, torch.Tensor):
+            n_suffix = _batch(n_suffix, x.shape[0])
+        for i, n in enumerate(n_suffix):
+            if n > 0:
+                mask[i, :, -n:] = 0
+    return mask
+
+
+def periodic_mask(x: torch.Tensor, period, width: int = 1, random_roll=False):
+    """mask.py:101-131.  A scalar period takes the vectorised path above; a tensor period is walked like the reference (which
+    only accepts one element, and then only marks the batch items it enumerates)."""
+    if not isinstance(period, torch.Tensor):
+        return periodic_prompt_mask(tuple(x.shape), int(period), width, random_roll).to(x.device)
+    mask = full_mask(x)
+    if period == 0:                     # like the reference: ambiguous (raises) for a tensor with more than one element
+        return mask
+    T = mask.shape[-1]
+    for i, factor in enumerate(period):
+        if factor == 0:
+            continue
+        for j in range(T):
+            if j % factor == 0:
+                a, b = max(0, j - width // 2), min(T - 1, j + width // 2) + 1
+                torch.bernoulli(torch.ones(b - a))                   # the reference's always-heads coin (RNG parity)
+                mask[i, :, a:b] = 0
+    if random_roll:
+        mask = torch.roll(mask, int(torch.randint(0, period[0], (1,)).item()), dims=-1)
+    return mask
+
+
+def codebook_unmask(mask: torch.Tensor, n_conditioning_codebooks):
+    if n_conditioning_codebooks is None:
+        return mask
+    mask = mask.clone()
+    mask[:, :n_conditioning_codebooks, :] = 0
+    return mask
+
+
+def codebook_mask(mask: torch.Tensor, val1: int, val2: int = None):
+    mask = mask.clone()
+    mask[:, val1:, :] = 1
+    return mask
+
+
+def mask_and(mask1: torch.Tensor, mask2: torch.Tensor):
+    assert mask1.shape == mask2.shape, "masks must be same shape"
+    return torch.min(mask1, mask2)
+
+
+def mask_or(mask1: torch.Tensor, mask2: torch.Tensor):
+    assert mask1.shape == mask2.shape, f"masks must be same shape, but got {mask1.shape} and {mask2.shape}"
+    assert mask1.max() <= 1, "mask1 must be binary"
+    assert mask2.max() <= 1, "mask2 must be binary"
+    assert mask1.min() >= 0, "mask1 must be binary"
+    assert mask2.min() >= 0, "mask2 must be binary"
+    return (mask1 + mask2).clamp(0, 1)
+
+
+def dropout(mask: torch.Tensor, p: float):
+    return timestep_dropout(mask, p)
+
+
+def time_stretch_mask(x: torch.Tensor, stretch_factor: int):
+    assert stretch_factor >= 1, "stretch factor must be >= 1"
+    T = x.shape[-1]
+    x = x.repeat_interleave(stretch_factor, dim=-1)[:, :, :T]
+    return periodic_mask(x, stretch_factor, width=1)
+
+
+def onset_mask(sig, z: torch.Tensor, interface, width: int = 1):
+    """mask.py:205-228 (signature of the reference; the detector is vampnet_amd/onsets.py)."""
+    return onset_mask_from_samples(sig.samples, sig.sample_rate, z, interface.codec.hop_length, width).to(z.device)
