@@ -355,3 +355,16 @@ def test_mask_module_names_bitwise(ns):
     both(lambda P: P.dropout(m1, 0.0))
     both(lambda P: P.time_stretch_mask(x, 3))
     both(lambda P: P.apply_mask(x, m2, 1024))
+
+
+def test_util_module_names_bitwise(ns):
+    import importlib
+    from vampnet_amd import util as U
+    R = importlib.import_module("vampnet.util")
+    z = W.synth_codes(3, 14, 41, seed=1)
+    f = R.codebook_flatten(z)
+    assert torch.equal(U.codebook_flatten(z), f)
+    assert torch.equal(U.codebook_unflatten(f, 14), R.codebook_unflatten(f, n_c=14)) and torch.equal(U.codebook_unflatten(f, 14), z)
+    for v in (3, 0.25):
+        a, b = R.scalar_to_batch_tensor(v, 5), U.scalar_to_batch_tensor(v, 5)
+        assert a.dtype == b.dtype and torch.equal(a, b)
