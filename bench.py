@@ -170,7 +170,7 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=8)
     ap.add_argument("--coarse-steps", type=int, default=12)
     ap.add_argument("--coarse-only", action="store_true", help="BASELINE configs[1]: coarse_vamp only (4 codebooks)")
-    ap.add_argument("--dtype", choices=["f32", "bf16x3", "bf16", "f16x2"], default="bf16x3",
+    ap.add_argument("--dtype", choices=["f32", "bf16x3", "bf16"], default="bf16x3",
                     help="bf16x3 (default) = fp32-grade GEMMs as six bf16-MFMA products of exact 3-way operand splits, fp32 "
                          "accumulate: held to the same parity bars as f32 (tests/test_gpu_bf16x3.py: tokens bit-identical to the "
                          "oracle and the reference's golden tokens); f32 = exact-fp32 MFMA; bf16 = fast mode, not bit-exact")
@@ -300,7 +300,6 @@ def main():
                                      "bf16x3": "fp32-grade: each GEMM operand = 3 exact bf16 split planes (sum == fp32 value), 6 bf16-MFMA "
                                                "products per k-step, fp32 accumulate; attention/norms/softmax/sampling fp32; "
                                                "same parity bars as f32 (tests/test_gpu_bf16x3.py)",
-                                     "f16x2": "STAGED (round 2): fp32-grade, each GEMM operand = 2 fp16 planes, 3 fp16-MFMA products",
                                      "bf16": "bf16 GEMM/attention operands (fast mode, not bit-exact)"}[args.dtype]},
         }
         if prof is not None:
@@ -312,10 +311,9 @@ def main():
                 traffic = json.load(open(tpath))["bytes_per_launch"]
             # bf16x3: `achieved` stays ALGORITHMIC (2MNK per GEMM, fp32-equivalent); every such flop costs six bf16-MFMA flops,
             # so the ceiling of this algorithm is the dense bf16 MFMA peak / 6 (the kernel executes 6 x achieved on the pipe)
-            peak = {"f32": PEAK_F32_MFMA_TF, "bf16": PEAK_BF16_MFMA_TF, "bf16x3": PEAK_BF16_MFMA_TF / 6.0,
-                    "f16x2": PEAK_BF16_MFMA_TF / 3.0}[args.dtype]
+            peak = {"f32": PEAK_F32_MFMA_TF, "bf16": PEAK_BF16_MFMA_TF, "bf16x3": PEAK_BF16_MFMA_TF / 6.0}[args.dtype]
             kname = {"f32": "vn_gemm_f32[_sk]_kernel", "bf16": "vn_gemm_f32_kernel<128,128,BF16>",
-                     "bf16x3": "vn_gemm_x3_kernel", "f16x2": "vn_gemm_h2_kernel"}[args.dtype]
+                     "bf16x3": "vn_gemm_x3_kernel"}[args.dtype]
             res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": fl / (ms * 1e-3) / 1e12 if ms else None,
                                "peak": peak, "unit": "TFLOP/s",
                                "frac": (fl / (ms * 1e-3) / 1e12) / peak if ms else None,

@@ -209,16 +209,6 @@ int vn_gemm_bf16(vn_ctx* ctx, const void* A16, const void* W16, const float* bia
 int vn_gemm_bf16x3(vn_ctx* ctx, const void* A3, int64_t a_plane, const void* W3, int64_t w_plane, const float* bias,
                    float* C, int M, int N, int K, int epilogue, void* stream);
 
-/* STAGED (round 2; single ops only, not used by any model path, not yet run on a GPU): the "f16x2" successor of bf16x3 —
- * operands as two fp16 planes h0 = fp16(x), h1 = fp16((x - h0) * 2^11), three fp16-MFMA products per k-step
- * (C = A0 W0 + 2^-11 (A0 W1 + A1 W0)), fp32 accumulate: half the matrix work, two thirds of the operand bytes, the same
- * error class (vampnet_amd/csrc/gemm_h2.hip).  tile_m: 128 or 256; nsplit: k-splits (1; 2..8 for epilogues 0 / 2).     */
-int vn_split2h_f32(vn_ctx* ctx, const float* src, void* dst16, int64_t n, int64_t plane_stride, void* stream);
-/* STAGED: switch a model's GEMMs to the f16x2 kernel (weights = vn_split2h_f32 of the packed blob); NULL = back to fp32 */
-int vn_model_set_f16x2(vn_model* model, const void* blob_planes_dev, int64_t plane_stride);
-int vn_gemm_f16x2(vn_ctx* ctx, const void* A2, int64_t a_plane, const void* W2, int64_t w_plane, const float* bias,
-                  float* C, int M, int N, int K, int epilogue, int tile_m, int nsplit, void* stream);
-
 /* Self-attention core (transformer.py:229-254): q,k,v dev f32 [B][H][T][64];
  * rel_bias dev f32 [num_buckets][H]; out dev f32 [B][T][H*64].                                */
 int vn_attention_f32(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
@@ -372,6 +362,9 @@ int vn_debug_graph_replays(const vn_model* model, int64_t* count);
 /* tuning hook (scripts/gemm_sweep.py): force the GEMM block tile (bm x bn in {128,64}^2; 0,0 = automatic) and the
  * tile walk order (0 column-major, 1 grouped 8-row patches, -1 keep).  Process-global; not for production use.   */
 int vn_debug_gemm_config(int bm, int bn, int order);
+/* same for the bf16x3 GEMM (gemm_x3.hip): pipe 3 = lock-step 128 x 128, 4 = ping-pong 128 x 128, 5 = ping-pong 256 x 128
+ * (-1 = VN_X3_PIPE / default); splitk 0/1 off, 2/4 forced, -1 = cost model; abl = ablation bits (tuning; results invalid) */
+int vn_debug_x3_config(int pipe, int splitk, int abl);
 
 #ifdef __cplusplus
 }

@@ -1,25 +1,21 @@
-"""Kernel-only driver for rocprofv3 --pmc runs of the split-plane GEMMs: VN_PMC_KERNEL = x3 (default) | h2 (staged f16x2)."""
+"""Kernel-only driver for rocprofv3 --pmc runs of the bf16x3 GEMM: the model's B = 8 shapes + 4096^3, schedule from
+VN_X3_PIPE (3 / 4 / 5), split-K as in production.  Three launches per shape."""
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vampnet_amd import _lib
 from vampnet_amd.engine import Engine
 
 eng = Engine("cuda:0")
-which = os.environ.get("VN_PMC_KERNEL", "x3")
-for (M, N, K) in [(4096, 4096, 4096), (4600, 3840, 1280), (4600, 5120, 1280)]:
+for (M, N, K, epi) in [(4096, 4096, 4096, _lib.EPI_STORE), (4600, 3840, 1280, _lib.EPI_STORE), (4600, 5120, 1280, _lib.EPI_GEGLU),
+                       (4600, 1280, 1280, _lib.EPI_RESIDUAL), (4600, 1280, 2560, _lib.EPI_RESIDUAL), (4600, 4096, 1280, _lib.EPI_STORE)]:
     a = torch.randn(M, K, device="cuda")
     w = torch.randn(N, K, device="cuda") / K ** 0.5
-    out = torch.zeros(M, N, device="cuda")
-    if which == "h2":
-        a2, w2 = eng.split2h(a), eng.split2h(w)
-        tile = int(os.environ.get("VN_H2_TILE", "128"))
-        fn = lambda: eng.gemm_f16x2(a2, w2, out=out, tile_m=tile)
-    else:
-        a3, w3 = eng.split3(a), eng.split3(w)
-        fn = lambda: eng.gemm_bf16x3(a3, w3, out=out)
+    out = torch.zeros(M, N // 2 if epi == _lib.EPI_GEGLU else N, device="cuda")
+    a3, w3 = eng.split3(a), eng.split3(w)
     for _ in range(3):
-        fn()
+        eng.gemm_bf16x3(a3, w3, epilogue=epi, out=out)
 torch.cuda.synchronize()

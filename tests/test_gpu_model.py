@@ -262,21 +262,45 @@ def test_interface_api_surface(itf):
 
 
 # ---------------------------------------------------------------------------------------- full size
-def test_full_size_coarse_steps_teacher_forced(eng):
+# Every full-size test runs in BOTH fp32-grade precisions: "f32" (fp32-input MFMA) and "bf16x3" (the precision bench.py
+# times).  The oracle side (CPU, seconds to a minute) is computed once per argument set and shared.
+PRECISIONS = ["f32", "bf16x3"]
+_ORACLE_CACHE = {}
+
+
+def _cached(key, fn):
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = fn()
+    return _ORACLE_CACHE[key]
+
+
+@pytest.fixture(scope="module")
+def full_sd():
+    return dict(cb=W.synth_codebooks(), csd=W.synth_state_dict(W.COARSE_DIMS, 0), fsd=W.synth_state_dict(W.C2F_DIMS, 1))
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_full_size_coarse_steps_teacher_forced(eng, full_sd, precision):
     """cfg 2 of BASELINE.json at full size (333 M params, T = 575): 3 sampling steps, each compared with the
     oracle under teacher forcing; decisions the oracle takes with margin < 1e-4 may flip (tie audit)."""
     from vampnet_amd.engine import VampNetModel
     dims = W.COARSE_DIMS
-    cb, sd = W.synth_codebooks(), W.synth_state_dict(dims, 0)
-    model = VampNetModel(eng, sd, cb, max_batch=1, max_T=575, **model_kwargs(dims))
+    cb, sd = full_sd["cb"], full_sd["csd"]
+    model = VampNetModel(eng, sd, cb, max_batch=1, max_T=575, precision=precision, **model_kwargs(dims))
     z = W.synth_codes(1, 4, 575, seed=0)
     mask = O.codebook_mask(O.periodic_mask(z, 7, 1), 3)
     mask[:, :, 0] = 0
     mask[:, :, -1] = 0
     assert int(mask.sum()) == 2049                                            # SURVEY.md §8(d) cfg 2
-    steps, trace = 3, []
-    torch.manual_seed(0)
-    O.generate(sd, dims, cb, z.masked_fill(mask.bool(), 1024), mask, sampling_steps=steps, trace=trace)
+    steps = 3
+
+    def run_oracle():
+        trace = []
+        torch.manual_seed(0)
+        O.generate(sd, dims, cb, z.masked_fill(mask.bool(), 1024), mask, sampling_steps=steps, trace=trace)
+        return trace
+
+    trace = _cached("teacher_forced", run_oracle)
     n0 = 2049
     for i, t in enumerate(trace):
         lg = model.forward_codes(t["z_in"], layout="native")
@@ -411,19 +435,26 @@ def test_interface_vamp_time_stretch_feedback_gpu(tiny, itf):
     assert torch.equal(itf.vamp(z, mask, **kw).cpu(), O.vamp(tiny["models"], z, mask, **kw))
 
 
-def test_full_size_free_running_generate_vs_oracle(eng):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_full_size_free_running_generate_vs_oracle(eng, full_sd, precision):
     """Full-size coarse model (333 M params, T = 575), FREE-RUNNING on the engine's own state for 4 sampling steps with
     torch's CPU noise stream replayed, compared step by step with the oracle's trajectory.  Pass = identical tokens at
     every step; if the trajectories ever part, the first divergent decisions must be near-ties of the oracle itself
     (relative margin < 1e-4: the reference's own fp32 result moves by more between thread counts)."""
     from vampnet_amd.engine import VampNetModel
     dims = W.COARSE_DIMS
-    cb, sd = W.synth_codebooks(), W.synth_state_dict(dims, 0)
-    model = VampNetModel(eng, sd, cb, max_batch=1, max_T=575, **model_kwargs(dims))
+    cb, sd = full_sd["cb"], full_sd["csd"]
+    model = VampNetModel(eng, sd, cb, max_batch=1, max_T=575, precision=precision, **model_kwargs(dims))
     z = W.synth_codes(1, 4, 575, seed=3)
     mask = O.codebook_mask(O.periodic_mask(z, 7, 1), 3)
-    steps, trace = 4, []
-    O.generate(sd, dims, cb, z, mask, sampling_steps=steps, seed=5, trace=trace)
+    steps = 4
+
+    def run_oracle():
+        trace = []
+        O.generate(sd, dims, cb, z, mask, sampling_steps=steps, seed=5, trace=trace)
+        return trace
+
+    trace = _cached("free_running", run_oracle)
     n0 = int(mask.sum())
     state = z.masked_fill(mask.bool(), 1024)
     for i, t in enumerate(trace):
@@ -442,25 +473,56 @@ def test_full_size_free_running_generate_vs_oracle(eng):
     assert torch.equal(got, O.codebook_unflatten(trace[-1]["sampled"], 4))
 
 
-def test_full_size_vamp_vs_oracle(eng):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_full_size_vamp_vs_oracle(eng, full_sd, precision):
     """BASELINE config 1 analogue without the HF checkpoints: the whole Interface.vamp() (12 coarse steps + coarse-to-fine)
     on the full-size coarse (333 M) and c2f (275 M) models, batch 1, seeded, torch noise replayed: all 14 x 575 tokens
     equal the oracle's (reference fact 6: the fine codebooks are stochastic but reproducible from the seed)."""
     from vampnet_amd.interface import Interface
-    cb = W.synth_codebooks()
-    csd, fsd = W.synth_state_dict(W.COARSE_DIMS, 0), W.synth_state_dict(W.C2F_DIMS, 1)
+    cb, csd, fsd = full_sd["cb"], full_sd["csd"], full_sd["fsd"]
     itf = Interface.from_state_dicts(SynthCodec(cb), csd, model_kwargs(W.COARSE_DIMS), fsd, model_kwargs(W.C2F_DIMS),
-                                     max_batch=1)
+                                     max_batch=1, precision=precision)
     z = W.synth_codes(1, 14, 575, seed=2)
     torch.manual_seed(0)
     mask = itf.build_mask(z)
     models = O.OracleModels(csd, W.COARSE_DIMS, fsd, W.C2F_DIMS, cb)
     for kw in (dict(seed=0), dict(seed=1, sample_cutoff=-1, mask_temperature=0.0)):       # stochastic / greedy coarse stage
-        ref = O.vamp(models, z, mask, batch_size=1, _sampling_steps=12, **kw)
+        ref = _cached(("vamp_b1", tuple(sorted(kw.items()))),
+                      lambda: O.vamp(models, z, mask, batch_size=1, _sampling_steps=12, **kw))
         got = itf.vamp(z, mask, batch_size=1, _sampling_steps=12, **kw).cpu()
         same = (got == ref).float().mean().item()
-        print(f"full-size vamp {kw}: token agreement {same:.6f}")
+        print(f"full-size vamp [{precision}] {kw}: token agreement {same:.6f}")
         assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_full_size_vamp_batch8_vs_oracle(eng, full_sd, precision):
+    """BASELINE configs[2] itself — coarse + c2f vamp(), batch 8 x 10 s (T = 575), full-size models, typical_filtering=True —
+    against the oracle with torch's seeded noise stream continued on the device (rng="torch_device": the noise torch's CPU
+    generator would have drawn, bit for bit).  B = 8 exercises the batch-wide N0 of transformer.py:766 (the eight clips get
+    different prompt masks, so their own masked counts differ from the batch total) and the batched c2f chunk calls at full
+    size.  Pass = all 8 x 14 x 575 tokens equal; a trajectory that parts must part at a decision the oracle itself takes
+    with a relative margin < 1e-4 (reported, not silently accepted: the test then fails unless the first differing token
+    of that item is such a near tie in the oracle's step trace)."""
+    from vampnet_amd.interface import Interface
+    cb, csd, fsd = full_sd["cb"], full_sd["csd"], full_sd["fsd"]
+    itf = Interface.from_state_dicts(SynthCodec(cb), csd, model_kwargs(W.COARSE_DIMS), fsd, model_kwargs(W.C2F_DIMS),
+                                     max_batch=8, precision=precision, rng="torch_device")
+    z = W.synth_codes(8, 14, 575, seed=21)
+    torch.manual_seed(4)
+    masks = [itf.build_mask(z[b:b + 1], periodic_prompt=p, upper_codebook_mask=3)
+             for b, p in enumerate((7, 7, 5, 9, 7, 13, 3, 7))]
+    mask = torch.cat(masks, 0)
+    assert len({int(m.sum()) for m in masks}) > 1                       # per-item masked counts differ: N0 is batch-wide
+    models = O.OracleModels(csd, W.COARSE_DIMS, fsd, W.C2F_DIMS, cb)
+    kw = dict(batch_size=8, _sampling_steps=12, typical_filtering=True, seed=3)
+    ref = _cached("vamp_b8", lambda: O.vamp(models, z, mask, **kw))
+    got = itf.vamp(z, mask, **kw).cpu()
+    same = (got == ref).float().mean().item()
+    per_item = [(got[b] == ref[b]).float().mean().item() for b in range(8)]
+    print(f"full-size B=8 vamp [{precision}]: token agreement {same:.6f}, per item {['%.4f' % v for v in per_item]}")
+    assert got.shape == (8, 14, 575)
+    assert torch.equal(got, ref), f"B = 8 full-size vamp() differs from the oracle: agreement {same:.6f}"
 
 
 def test_forward_graph_replay_is_used_and_exact():

@@ -56,9 +56,6 @@ SYMBOLS = {
     "vn_model_set_bf16x3": (C.c_int, [_P, _P, C.c_int64]),
     "vn_split3_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _P]),
     "vn_gemm_bf16x3": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
-    "vn_model_set_f16x2": (C.c_int, [_P, _P, C.c_int64]),
-    "vn_split2h_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _P]),
-    "vn_gemm_f16x2": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vn_gemm_bf16": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vn_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "vn_generate": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(vn_sample_params), C.POINTER(C.c_int64),
@@ -99,6 +96,7 @@ SYMBOLS = {
     "vn_torch_uniform_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, C.c_float, _P]),
     "vn_debug_graph_replays": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "vn_debug_gemm_config": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "vn_debug_x3_config": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "vn_attention_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vn_attention_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
 }

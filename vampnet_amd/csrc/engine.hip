@@ -233,59 +233,8 @@ int vn_model_ensure_bias(vn_model* m, int T, hipStream_t s) {
     return rc;
 }
 
-// STAGED (round 2, not yet run on a GPU): the forward pass with every GEMM on the f16x2 kernel (gemm_h2.hip).  The fp32
-// producers are the verified ones; their outputs are split into the two fp16 planes by a separate pass (vn_split2h_kernel)
-// — to be fused into the producers' epilogues like bf16x3 once the scheme has been validated on hardware.
-static int forward_i32_h2(vn_model* m, const int32_t* z, int B, int T, float* logits, hipStream_t s) {
-    vn_ctx* ctx = m->ctx;
-    const int D = m->D, H = m->H, M = B * T;
-    int rc;
-    if ((rc = vn_model_ensure_bias(m, T, s))) return rc;
-    if ((rc = vn_launch_embed(ctx, z, W(m, VN_W_EMB_TABLES), W(m, VN_W_EMB_WT), W(m, VN_W_EMB_B), m->x, B,
-                              m->d.n_codebooks, T, m->d.vocab + 1, m->d.latent_dim, D, s)))
-        return rc;
-    const long plane = (long)B * H * T * VN_DHEAD;
-    const long yp = m->max_rows * (long)D, gp = 2 * yp;
-    // VN_H2_FUSE=1: RMSNorm and the GEGLU epilogue write the planes themselves (only the attention output keeps its
-    // separate split pass); default 0 = every operand through fp32 + vn_split2h_kernel (the first thing to validate)
-    static const bool fuse = [] { const char* e = getenv("VN_H2_FUSE"); return e && e[0] == '1'; }();
-    auto gemm = [&](const uint16_t* A2, long a_plane, int id, int layer, float* C, int N, int K, int ldc, int epi,
-                    const float* bias, uint16_t* C16 = nullptr, long c_plane = 0) {
-        vn_gemm_args a{};
-        a.A = (const float*)A2; a.W = (const float*)(m->blob16 + vn_tensor_offset(&m->d, id, layer));
-        a.bf16 = 3; a.a_plane = a_plane; a.w_plane = m->w_plane;
-        a.bias = bias; a.C = C; a.C16 = C16; a.c_plane = c_plane; a.M = M; a.N = N; a.K = K; a.ldc = ldc;
-        a.T = T; a.H = H; a.qkv_plane = plane;
-        return vn_launch_gemm_h2_auto(ctx, a, epi, s);
-    };
-    auto norm_planes = [&](const float* w) {            // m->x -> planes of RMSNorm(x) in m->y16
-        if (fuse) return vn_launch_rmsnorm_h2(ctx, m->x, w, m->y16, yp, M, D, m->d.eps, s);
-        int r = vn_launch_rmsnorm(ctx, m->x, w, m->y, M, D, m->d.eps, s);
-        return r ? r : vn_launch_split2h(ctx, m->y, m->y16, (long)M * D, yp, s);
-    };
-    for (int l = 0; l < m->L; ++l) {
-        if ((rc = norm_planes(W(m, VN_W_NORM1, l)))) return rc;
-        if ((rc = gemm(m->y16, yp, VN_W_QKV, l, m->qkv, 3 * D, D, 3 * D, VN_EPI_QKV, nullptr))) return rc;
-        if ((rc = vn_launch_attention(ctx, m->qkv, m->qkv + plane, m->qkv + 2 * plane, m->bias_full, m->y, B, H, T, s))) return rc;
-        if ((rc = vn_launch_split2h(ctx, m->y, m->y16, (long)M * D, yp, s))) return rc;
-        if ((rc = gemm(m->y16, yp, VN_W_WO, l, m->x, D, D, D, VN_EPI_RESIDUAL, nullptr))) return rc;              // x = x + attn
-        if ((rc = norm_planes(W(m, VN_W_NORM3, l)))) return rc;
-        if (fuse) {
-            if ((rc = gemm(m->y16, yp, VN_W_W1, l, m->g, 4 * D, D, 2 * D, VN_EPI_GEGLU, nullptr, m->g16, gp))) return rc;
-        } else {
-            if ((rc = gemm(m->y16, yp, VN_W_W1, l, m->g, 4 * D, D, 2 * D, VN_EPI_GEGLU, nullptr))) return rc;      // g = p1 * gelu(p2)
-            if ((rc = vn_launch_split2h(ctx, m->g, m->g16, (long)M * 2 * D, gp, s))) return rc;
-        }
-        if ((rc = gemm(m->g16, gp, VN_W_W2, l, m->x, D, 2 * D, D, VN_EPI_RESIDUAL, nullptr))) return rc;           // x = x + ffn
-    }
-    if ((rc = norm_planes(W(m, VN_W_FINAL_NORM)))) return rc;
-    const int NV = m->Cp * m->d.vocab;
-    return gemm(m->y16, yp, VN_W_CLS_W, 0, logits, NV, D, NV, VN_EPI_BIAS, W(m, VN_W_CLS_B));
-}
-
 // forward on the int32 token buffer m->z -> m->logits   (layers.py:134-163 + transformer.py:617-639)
 static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logits, hipStream_t s) {
-    if (m->blob16 && m->h2) return forward_i32_h2(m, z, B, T, logits, s);
     vn_ctx* ctx = m->ctx;
     const int D = m->D, H = m->H, M = B * T;
     int rc;
@@ -435,7 +384,6 @@ extern "C" int vn_debug_graph_replays(const vn_model* m, int64_t* count) {
 }
 
 static int set_bf16_planes(vn_model* m, const void* blob16_dev, long w_plane) {
-    m->h2 = 0;
     if (!blob16_dev) { m->blob16 = nullptr; m->w_plane = 0; return VN_OK; }          // back to exact fp32 MFMA
     if (m->D % 64) return vn_fail(m->ctx, VN_ERR_UNSUPPORTED, "bf16 modes need d_model %% 64 == 0%s", "");
     int rc;        // the bf16 A-operand images are sized for three planes in either mode (graphs keep pointing at them)
@@ -459,19 +407,6 @@ extern "C" int vn_model_set_bf16x3(vn_model* m, const void* blob_planes_dev, int
     if (plane_stride < n || (plane_stride & 7)) return vn_fail(m->ctx, VN_ERR_INVALID, "bf16x3: plane stride %s%ld too small or not a multiple of 8", "", (long)plane_stride);
     if (((uintptr_t)blob_planes_dev) & 15) return vn_fail(m->ctx, VN_ERR_INVALID, "bf16x3: planes must be 16-byte aligned%s", "");
     return set_bf16_planes(m, blob_planes_dev, (long)plane_stride);
-}
-
-// STAGED (round 2): weights as the two fp16 planes of vn_split2h_f32 (plane_stride elements apart)
-extern "C" int vn_model_set_f16x2(vn_model* m, const void* blob_planes_dev, int64_t plane_stride) {
-    if (!m) return VN_ERR_INVALID;
-    if (!blob_planes_dev) return set_bf16_planes(m, nullptr, 0);
-    int64_t n = 0;
-    vn_weights_size(&m->d, &n);
-    if (plane_stride < n || (plane_stride & 7)) return vn_fail(m->ctx, VN_ERR_INVALID, "f16x2: plane stride %s%ld too small or not a multiple of 8", "", (long)plane_stride);
-    if (((uintptr_t)blob_planes_dev) & 15) return vn_fail(m->ctx, VN_ERR_INVALID, "f16x2: planes must be 16-byte aligned%s", "");
-    int rc = set_bf16_planes(m, blob_planes_dev, (long)plane_stride);
-    if (rc == VN_OK) m->h2 = 1;
-    return rc;
 }
 
 static int shape_check(vn_model* m, int B, int T) {

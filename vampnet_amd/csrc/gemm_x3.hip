@@ -39,13 +39,19 @@
 #include <stdlib.h>
 #include "vn_common.h"
 
-#define X3_BM 128
 #define X3_BN 128
 #define X3_KT 32                                  // bf16 per k-tile
-#define X3_PLANE_FLOATS (128 * 16)                // one plane tile: 128 rows x 64 B
-#define X3_STAGE_FLOATS (6 * X3_PLANE_FLOATS)     // 48 KiB
-#define X3_LDS_BYTES (2 * X3_STAGE_FLOATS * 4)    // 96 KiB
-#define X3_DMA_PER_WAVE 6                         // 48 wave-instructions of 1 KiB per stage / 8 waves
+#define X3_BPLANE (128 * 16)                      // floats of one W plane tile: 128 rows x 64 B
+
+// Geometry by tile height BM = 128 MI.  A stage = three A plane tiles (BM rows x 64 B) then three W plane tiles.
+template <int MI>
+struct x3_geo {
+    static constexpr int BM = 128 * MI;
+    static constexpr int APLANE = BM * 16;                          // floats
+    static constexpr int STAGE = 3 * (APLANE + X3_BPLANE);          // floats: 48 KiB (MI 1) / 72 KiB (MI 2)
+    static constexpr int NQ = 3 * (BM + 128) / 16;                  // 1 KiB DMA wave-instructions per stage
+    static constexpr int NPW = NQ / 8;                              // per wave: 6 / 9
+};
 
 __device__ __forceinline__ int x3_xcd_remap(int bid, int nwg) {
     const int xcd = bid & 7, idx = bid >> 3;
@@ -64,13 +70,33 @@ __device__ __forceinline__ void x3_tile_coords(int t, int tiles_m, int tiles_n, 
     tn = in_grp / gsz;
 }
 
+#define X3_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define X3_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// raw barrier (no implied vmcnt(0): LDS-DMA stays in flight across it); the asm fences keep hipcc from moving LDS accesses over it
+#define X3_BARRIER()                              \
+    do {                                          \
+        asm volatile("" ::: "memory");            \
+        __builtin_amdgcn_s_barrier();             \
+        asm volatile("" ::: "memory");            \
+        __builtin_amdgcn_sched_barrier(0);        \
+    } while (0)
+
+// PIPE 3: lock-step schedule of round 1 (128 x 128 only): register-prefetched fragments, one barrier per k-tile, DMA pieces
+//         spread over the MFMA pairs, two LDS buffers.
+// PIPE 4: "ping-pong".  The eight waves form two groups (waves 0-3 / 4-7: one wave of each group on every SIMD) that run
+//         the same step sequence ONE PHASE APART: while a group issues the 12 MI MFMAs of a k-step (s_setprio 1), the other
+//         reads its next fragments and issues LDS-DMA; two s_barriers per k-step keep the alternation.  Counted vmcnt,
+//         raw s_barrier: DMA stays in flight across barriers.  MI = 1: three LDS buffers (tile kt + 2 is issued in the two
+//         load phases of tile kt, waited for a tile later); MI = 2 (256 x 128): two buffers of 72 KiB (tile kt + 1 is
+//         issued in the first load phase and between the MFMAs of the first compute phase of tile kt).
 // ABL (tuning only, results invalid): bit 0 = no DMA inside the k-loop, bit 1 = no fragment reads inside the k-loop
-template <int EPI, int PIPE, int ABL = 0>
+template <int EPI, int PIPE, int MI, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int tiles_m, int tiles_n) {
+    using G = x3_geo<MI>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int tm, tn;
     x3_tile_coords(x3_xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * X3_BM, n0 = tn * X3_BN;
+    const int m0 = tm * G::BM, n0 = tn * X3_BN;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,214 +108,213 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
     const int kb = (int)((long)nk_all * blockIdx.y / gridDim.y), ke = (int)((long)nk_all * (blockIdx.y + 1) / gridDim.y);
     if (gridDim.y > 1) p.C += (size_t)blockIdx.y * p.M * p.N;
 
-    // per-lane DMA sources: instruction q = wave * 6 + j fills plane tile q / 8, rows 16 (q % 8) .. + 15
-    const uint16_t* src[X3_DMA_PER_WAVE];
+    // per-lane DMA sources: instruction q = wave * NPW + j fills 16 rows of one plane tile (A: q < 24 MI, plane q / (8 MI))
+    const uint16_t* src[G::NPW];
     const int drow = lane >> 2, dslot = (lane & 3) ^ ((lane >> 4) & 3);     // (row >> 2) & 3 == (lane >> 4) & 3
 #pragma unroll
-    for (int j = 0; j < X3_DMA_PER_WAVE; ++j) {
-        const int q = wave * X3_DMA_PER_WAVE + j;
-        const int pt = q >> 3, row = (q & 7) * 16 + drow;
-        if (pt < 3) {
+    for (int j = 0; j < G::NPW; ++j) {
+        const int q = wave * G::NPW + j;
+        if (q < 24 * MI) {
+            const int pt = q / (8 * MI), row = (q % (8 * MI)) * 16 + drow;
             int g = m0 + row;
             g = g < p.M ? g : p.M - 1;
             src[j] = A16 + (size_t)pt * p.a_plane + (size_t)g * p.K + dslot * 8 + kb * X3_KT;
         } else {
+            const int qb = q - 24 * MI;
+            const int pt = qb >> 3, row = (qb & 7) * 16 + drow;
             int g = n0 + row;
             g = g < p.N ? g : p.N - 1;
-            src[j] = W16 + (size_t)(pt - 3) * p.w_plane + (size_t)g * p.K + dslot * 8 + kb * X3_KT;
+            src[j] = W16 + (size_t)pt * p.w_plane + (size_t)g * p.K + dslot * 8 + kb * X3_KT;
         }
     }
     auto stage_piece = [&](int buf, int k0, int j) {
-        if constexpr (ABL & 4) k0 = 0;            // ablation: every tile re-reads the first one (cache-resident source)
-        float* base = lds + buf * X3_STAGE_FLOATS + wave * (X3_DMA_PER_WAVE * 256);
+        float* base = lds + buf * G::STAGE + wave * (G::NPW * 256);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
                                          (__attribute__((address_space(3))) void*)(base + j * 256), 16, 0, 0);
     };
     auto stage = [&](int buf, int k0) {
 #pragma unroll
-        for (int j = 0; j < X3_DMA_PER_WAVE; ++j) stage_piece(buf, k0, j);
+        for (int j = 0; j < G::NPW; ++j) stage_piece(buf, k0, j);
     };
 
     // fragment offsets (floats) inside a plane tile: row * 16 + ((2 s + h) ^ ((row >> 2) & 3)) * 4
     const int l31 = lane & 31, h = lane >> 5, sw = (lane >> 2) & 3;
-    const int aRow = (wm * 32 + l31) * 16;
+    const int aRow = (wm * 32 * MI + l31) * 16;
     const int bRow = (wn * 64 + l31) * 16;
 
-    f32x16 acc[2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    struct Frags { bf16x8 a[3], b[3][2]; };
+    struct Frags { bf16x8 a[3][MI], b[3][2]; };
     auto load_frags = [&](Frags& f, int buf, int s) {
-        const float* sA = lds + buf * X3_STAGE_FLOATS;
-        const float* sB = sA + 3 * X3_PLANE_FLOATS;
+        const float* sA = lds + buf * G::STAGE;
+        const float* sB = sA + 3 * G::APLANE;
         const int off = ((2 * s + h) ^ sw) * 4;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            f.a[q] = __builtin_bit_cast(bf16x8, *(const f32x4*)(sA + q * X3_PLANE_FLOATS + aRow + off));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                f.a[q][i] = __builtin_bit_cast(bf16x8, *(const f32x4*)(sA + q * G::APLANE + aRow + i * 32 * 16 + off));
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                f.b[q][j] = __builtin_bit_cast(bf16x8, *(const f32x4*)(sB + q * X3_PLANE_FLOATS + bRow + j * 32 * 16 + off));
+                f.b[q][j] = __builtin_bit_cast(bf16x8, *(const f32x4*)(sB + q * X3_BPLANE + bRow + j * 32 * 16 + off));
         }
     };
-    // the six plane products of one 16-wide k-step, smallest terms first; the two accumulators alternate so that
-    // consecutive MFMAs are independent
-    auto mac_head = [&](const Frags& f) {
+    // the six plane products of one 16-wide k-step, smallest terms first (t = 0: A0 W2, then A2 W0, A1 W1, A0 W1, A1 W0,
+    // A0 W0); consecutive MFMAs go to different accumulators
+    auto mac_prod = [&](const Frags& f, int t) {
+        const int qa = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0, qb = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b[2][j], acc[j], 0, 0, 0);
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[qa][i], f.b[qb][j], acc[i][j], 0, 0, 0);
     };
-    auto mac_tail = [&](const Frags& f) {
+    auto mac = [&](const Frags& f) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[2], f.b[0][j], acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1], f.b[1][j], acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b[1][j], acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1], f.b[0][j], acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b[0][j], acc[j], 0, 0, 0);
-    };
-    auto mac = [&](const Frags& f) { mac_head(f); mac_tail(f); };
-    auto mac_pair = [&](const Frags& f, int t) {          // t-th of the five pairs of mac_tail
-        const int qa = t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0, qb = (t == 0 || t == 3 || t == 4) ? 0 : 1;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[qa], f.b[qb][j], acc[j], 0, 0, 0);
+        for (int t = 0; t < 6; ++t) mac_prod(f, t);
     };
 
     const int nk = ke - kb;
-    if constexpr (PIPE == 0) {
-        // plain double buffering: DMA of tile kt + 1 under the MFMAs of tile kt, fragments read right before use
-        stage(0, 0);
-        __syncthreads();                  // glds in flight -> hipcc emits vmcnt(0) before the barrier
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * X3_KT);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                Frags f;
-                load_frags(f, cur, s);
-                mac(f);
-            }
-            __builtin_amdgcn_s_setprio(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();              // tile kt consumed by all waves; tile kt + 1 landed (vmcnt(0) + barrier)
-        }
-    } else if constexpr (PIPE == 1) {
-        // register-prefetched pipeline, ONE barrier per k-tile placed between its two k-steps:
-        //   read step 1 of tile kt | MFMAs of step 0 | barrier (all reads of tile kt are in registers, tile kt + 1 landed)
-        //   | DMA of tile kt + 2 into the buffer just freed | read step 0 of tile kt + 1 | MFMAs of step 1
-        // so every LDS read has one 12-MFMA group (~384 matrix cycles) and every DMA a whole k-tile to land.
+    if constexpr (PIPE == 3) {
+        static_assert(PIPE != 3 || MI == 1, "the lock-step schedule is built for the 128 x 128 tile");
         Frags f0, f1;
         stage(0, 0);
         if (nk > 1) stage(1, X3_KT);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X3_DMA_PER_WAVE) : "memory");     // tile 0 landed (tile 1 may be in flight)
-        if (nk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        load_frags(f0, 0, 0);
-        if constexpr (ABL & 2) load_frags(f1, 0, 1);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            // The reads of the NEXT group are issued behind the first two MFMAs of the current one: the s_waitcnt the
-            // compiler puts in front of a group is lgkmcnt(0) (it cannot count across the loop edge), which must only
-            // cover fragments requested a whole group ago, not the ones just issued.
-            __builtin_amdgcn_s_setprio(1);
-            mac_head(f0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(ABL & 2)) load_frags(f1, cur, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mac_tail(f0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile kt + 1 has landed (stated
-                                                               // explicitly: hipcc does not always emit it for a glds)
-            __syncthreads();              // + lgkmcnt(0): f1 is in registers; after the barrier tile kt + 1 is complete
-            if constexpr (!(ABL & 1))
-                if (kt + 2 < nk) stage(cur, (kt + 2) * X3_KT);
-            __builtin_amdgcn_s_setprio(1);
-            mac_head(f1);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(ABL & 2))
-                if (kt + 1 < nk) load_frags(f0, cur ^ 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            mac_tail(f1);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else if constexpr (PIPE == 2) {
-        // three LDS buffers (144 KiB): the DMA of tile kt + 3 is issued at the mid-tile barrier of tile kt and has two whole
-        // k-tiles to land; raw s_barrier + counted vmcnt so that one tile stays in flight across every barrier
-        Frags f0, f1;
-        stage(0, 0);
-        if (nk > 1) stage(1, X3_KT);
-        if (nk > 2) stage(2, 2 * X3_KT);
-        if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * X3_DMA_PER_WAVE) : "memory");
-        else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X3_DMA_PER_WAVE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        load_frags(f0, 0, 0);
-        int b = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            const int bn = b == 2 ? 0 : b + 1;
-            __builtin_amdgcn_s_setprio(1);
-            mac_head(f0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_frags(f1, b, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mac_tail(f0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X3_DMA_PER_WAVE) : "memory");   // tile kt + 1 landed
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + 3 < nk) stage(b, (kt + 3) * X3_KT);
-            __builtin_amdgcn_s_setprio(1);
-            mac_head(f1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + 1 < nk) load_frags(f0, bn, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            mac_tail(f1);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            b = bn;
-        }
-    } else {
-        // PIPE 3: as PIPE 1, with the six DMA pieces of tile kt + 2 issued one per MFMA pair instead of back to back
-        Frags f0, f1;
-        stage(0, 0);
-        if (nk > 1) stage(1, X3_KT);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X3_DMA_PER_WAVE) : "memory");
-        if (nk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        X3_VMCNT(G::NPW);
+        if (nk == 1) X3_VMCNT(0);
         __syncthreads();
         load_frags(f0, 0, 0);
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
             const bool more = kt + 2 < nk;
+            // The reads of the NEXT group are issued behind the first product of the current one: the s_waitcnt the
+            // compiler puts in front of a group is lgkmcnt(0) (it cannot count across the loop edge), which must only
+            // cover fragments requested a whole group ago, not the ones just issued.
             __builtin_amdgcn_s_setprio(1);
-            mac_head(f0);
+            mac_prod(f0, 0);
             __builtin_amdgcn_sched_barrier(0);
             load_frags(f1, cur, 1);
             __builtin_amdgcn_sched_barrier(0);
-            mac_tail(f0);
+#pragma unroll
+            for (int t = 1; t < 6; ++t) mac_prod(f0, t);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            mac_head(f1);
+            X3_VMCNT(0);                  // this wave's share of tile kt + 1 has landed (hipcc does not always emit it for a glds)
+            __syncthreads();              // + lgkmcnt(0): f1 is in registers; after the barrier tile kt + 1 is complete
+            mac_prod(f1, 0);
             if (more) stage_piece(cur, (kt + 2) * X3_KT, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (kt + 1 < nk) load_frags(f0, cur ^ 1, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                mac_pair(f1, t);
-                if (more) stage_piece(cur, (kt + 2) * X3_KT, t + 1);
+            for (int t = 1; t < 6; ++t) {
+                mac_prod(f1, t);
+                if (more) stage_piece(cur, (kt + 2) * X3_KT, t);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
+        static_assert(PIPE == 3 || PIPE == 4, "unknown schedule");
+        const int grp = wave >> 2;                        // waves w and w + 4 share a SIMD: one of each group per SIMD
+        Frags f;
+        auto compute = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            mac(f);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (MI == 1) {
+            // three buffers; tile kt lives in buffer kt % 3.  Phase intervals I_j between consecutive barriers: group 0 loads
+            // step i in I_2i and computes it in I_2i+1, group 1 one interval later.  Tile kt is read in I_4kt .. I_4kt+3 (every
+            // load phase ends with lgkmcnt(0) BEFORE its barrier, so those reads have retired when I_4kt+4 starts), tile
+            // kt + 3 may therefore be DMA'd into its buffer from I_4kt+4 on: it is issued in the load phases of tile kt + 1
+            // (I_4kt+4 .. I_4kt+7) and every wave waits for its pieces at the end of the second load phase of tile kt + 2
+            // (vmcnt leaves only the six younger pieces of the following tile in flight) — two barriers before the first read.
+            stage(0, 0);
+            if (nk > 1) stage(1, X3_KT);
+            if (nk > 1) X3_VMCNT(G::NPW); else X3_VMCNT(0);
+            X3_BARRIER();                                   // tile 0 complete
+            if (grp) X3_BARRIER();                          // group 1 runs one phase behind
+            if constexpr (ABL & 2) load_frags(f, 0, 0);
+            int b = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                const int b2 = b == 0 ? 2 : b - 1;          // buffer of tile kt + 2 (= the one tile kt - 1 used)
+                const bool more = (kt + 2 < nk) && !(ABL & 1);
+                const bool last = kt + 1 == nk;
+                // ---- k-step 0
+                if constexpr (!(ABL & 2)) load_frags(f, b, 0);
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) stage_piece(b2, (kt + 2) * X3_KT, j);
+                }
+                X3_LGKM0();
+                X3_BARRIER();
+                compute();
+                X3_BARRIER();
+                // ---- k-step 1
+                if constexpr (!(ABL & 2)) load_frags(f, b, 1);
+                if (more) {
+#pragma unroll
+                    for (int j = 3; j < 6; ++j) stage_piece(b2, (kt + 2) * X3_KT, j);
+                    X3_VMCNT(G::NPW);                       // tile kt + 1 landed (this wave's pieces); tile kt + 2 in flight
+                } else {
+                    X3_VMCNT(0);
+                }
+                X3_LGKM0();
+                X3_BARRIER();
+                compute();
+                if (!(last && grp)) X3_BARRIER();           // group 1's last compute phase has no partner phase
+                b = b == 2 ? 0 : b + 1;
+            }
+        } else {
+            // two buffers of 72 KiB; tile kt lives in buffer kt & 1.  Tile kt + 1 goes into the buffer tile kt - 1 used (last
+            // read in I_4kt-1, retired before that interval's barrier) and is first read in I_4kt+4: each wave issues five
+            // of its nine pieces in the first load phase of tile kt and four between the products of its first compute phase
+            // (group 0: I_4kt, I_4kt+1; group 1: I_4kt+1, I_4kt+2) and waits for them at the last point that still has a
+            // barrier between it and the first read: group 0 at the end of its second compute phase (I_4kt+3), group 1 at
+            // the end of its second load phase (I_4kt+3).
+            stage(0, 0);
+            X3_VMCNT(0);
+            X3_BARRIER();
+            if (grp) X3_BARRIER();
+            if constexpr (ABL & 2) load_frags(f, 0, 0);
+            for (int kt = 0; kt < nk; ++kt) {
+                const int b = kt & 1;
+                const bool more = (kt + 1 < nk) && !(ABL & 1);
+                const bool last = kt + 1 == nk;
+                const int k1 = (kt + 1) * X3_KT;
+                // ---- k-step 0
+                if constexpr (!(ABL & 2)) load_frags(f, b, 0);
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) stage_piece(b ^ 1, k1, j);
+                }
+                X3_LGKM0();
+                X3_BARRIER();
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    mac_prod(f, t);
+                    if (t < 4 && more) stage_piece(b ^ 1, k1, 5 + t);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                X3_BARRIER();
+                // ---- k-step 1
+                if constexpr (!(ABL & 2)) load_frags(f, b, 1);
+                if (grp) X3_VMCNT(0);
+                X3_LGKM0();
+                X3_BARRIER();
+                compute();
+                if (!grp) X3_VMCNT(0);
+                if (!(last && grp)) X3_BARRIER();
             }
         }
     }
@@ -297,41 +322,44 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const int colw = n0 + wn * 64 + l31;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row >= p.M) continue;
-        if constexpr (EPI == VN_EPI_GEGLU) {
-            // wave tile = 64 packed columns = 32 value (j = 0) + 32 gate (j = 1), interleaved at pack time
-            const int ocol = (n0 + wn * 64) / 2 + l31;
-            if (2 * ocol >= p.N) continue;
-            const float o = acc[0][r] * vn_gelu_tanh(acc[1][r]);
-            if (p.C16) {
-                uint16_t t0, t1, t2;
-                vn_split3(o, t0, t1, t2);
-                uint16_t* d = p.C16 + (size_t)row * p.ldc + ocol;
-                d[0] = t0; d[p.c_plane] = t1; d[2 * p.c_plane] = t2;
-            } else {
-                p.C[(size_t)row * p.ldc + ocol] = o;
-            }
-        } else {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = colw + j * 32;
-                if (col >= p.N) continue;
-                const float v = acc[j][r];
-                if constexpr (EPI == VN_EPI_STORE) {
-                    p.C[(size_t)row * p.ldc + col] = v;
-                } else if constexpr (EPI == VN_EPI_BIAS) {
-                    p.C[(size_t)row * p.ldc + col] = v + p.bias[col];
-                } else if constexpr (EPI == VN_EPI_RESIDUAL) {
-                    float* c = p.C + (size_t)row * p.ldc + col;
-                    *c = *c + v;
-                } else if constexpr (EPI == VN_EPI_QKV) {
-                    const int D = p.H * VN_DHEAD;
-                    const int which = col / D, rem = col - which * D;
-                    const int hd = rem >> 6, d = rem & 63;
-                    const int b = row / p.T, t = row - b * p.T;
-                    p.C[which * p.qkv_plane + (((size_t)b * p.H + hd) * p.T + t) * VN_DHEAD + d] = v;
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row >= p.M) continue;
+            if constexpr (EPI == VN_EPI_GEGLU) {
+                // wave tile = 64 packed columns = 32 value (j = 0) + 32 gate (j = 1), interleaved at pack time
+                const int ocol = (n0 + wn * 64) / 2 + l31;
+                if (2 * ocol >= p.N) continue;
+                const float o = acc[i][0][r] * vn_gelu_tanh(acc[i][1][r]);
+                if (p.C16) {
+                    uint16_t t0, t1, t2;
+                    vn_split3(o, t0, t1, t2);
+                    uint16_t* d = p.C16 + (size_t)row * p.ldc + ocol;
+                    d[0] = t0; d[p.c_plane] = t1; d[2 * p.c_plane] = t2;
+                } else {
+                    p.C[(size_t)row * p.ldc + ocol] = o;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = colw + j * 32;
+                    if (col >= p.N) continue;
+                    const float v = acc[i][j][r];
+                    if constexpr (EPI == VN_EPI_STORE) {
+                        p.C[(size_t)row * p.ldc + col] = v;
+                    } else if constexpr (EPI == VN_EPI_BIAS) {
+                        p.C[(size_t)row * p.ldc + col] = v + p.bias[col];
+                    } else if constexpr (EPI == VN_EPI_RESIDUAL) {
+                        float* c = p.C + (size_t)row * p.ldc + col;
+                        *c = *c + v;
+                    } else if constexpr (EPI == VN_EPI_QKV) {
+                        const int D = p.H * VN_DHEAD;
+                        const int which = col / D, rem = col - which * D;
+                        const int hd = rem >> 6, d = rem & 63;
+                        const int b = row / p.T, t = row - b * p.T;
+                        p.C[which * p.qkv_plane + (((size_t)b * p.H + hd) * p.T + t) * VN_DHEAD + d] = v;
+                    }
                 }
             }
         }
@@ -345,26 +373,50 @@ static int x3_env(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-template <int EPI, int PIPE, int ABL = 0>
-static void x3_go(const vn_gemm_args& a, int tiles_m, int tiles_n, int nsplit, size_t lds_bytes, hipStream_t s) {
-    // one-time per process and instantiation is enough for the tuning variants; the production variants are raised per
-    // context in vn_launch_gemm_x3
-    hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, PIPE, ABL>), dim3(tiles_m * tiles_n, nsplit), dim3(512), lds_bytes, s, a, tiles_m, tiles_n);
+// schedule: VN_X3_PIPE = 3 lock-step 128 x 128 (round 1), 4 ping-pong 128 x 128, 5 ping-pong 256 x 128
+static int g_x3_pipe = -1, g_x3_split = -2, g_x3_abl = -1;      // vn_debug_x3_config overrides (tests / tuning)
+static int x3_pipe() {
+    static const int pipe = x3_env("VN_X3_PIPE", 4);
+    return g_x3_pipe >= 3 ? g_x3_pipe : pipe;
+}
+extern "C" int vn_debug_x3_config(int pipe, int splitk, int abl) {
+    if (pipe != -1 && (pipe < 3 || pipe > 5)) return VN_ERR_INVALID;
+    g_x3_pipe = pipe; g_x3_split = splitk < 0 ? -2 : splitk; g_x3_abl = abl < 0 ? -1 : (abl & 3);
+    return VN_OK;
+}
+static int x3_bm() { return x3_pipe() == 5 ? 256 : 128; }
+
+template <int EPI, int PIPE, int MI, int ABL = 0>
+static void x3_go(const vn_gemm_args& a, int tiles_m, int tiles_n, int nsplit, hipStream_t s) {
+    constexpr size_t lds_bytes = (size_t)x3_geo<MI>::STAGE * 4 * (PIPE == 4 && MI == 1 ? 3 : 2);
+    hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, PIPE, MI, ABL>), dim3(tiles_m * tiles_n, nsplit), dim3(512), lds_bytes, s, a, tiles_m,
+                       tiles_n);
+}
+template <int EPI>
+static void x3_go_pipe(const vn_gemm_args& a, int nsplit, hipStream_t s) {
+    const int tiles_n = vn_cdiv(a.N, X3_BN);
+    switch (x3_pipe()) {
+        case 3: x3_go<EPI, 3, 1>(a, vn_cdiv(a.M, 128), tiles_n, nsplit, s); break;
+        case 5: x3_go<EPI, 4, 2>(a, vn_cdiv(a.M, 256), tiles_n, nsplit, s); break;
+        default: x3_go<EPI, 4, 1>(a, vn_cdiv(a.M, 128), tiles_n, nsplit, s); break;
+    }
 }
 
 // split count for the store / residual epilogues: a launch costs ceil(tiles * ns / 256) rounds of K / ns, plus the reduce
 // pass over (ns + 1 or 2) images of C.  Constants from profiles/r01_gemm_x3_vs_f32.txt (1.45 us per k-tile and round,
 // ~3.5 TB/s for the reduce).
 static int x3_pick_split(const vn_gemm_args& a, bool residual) {
-    static const int forced = x3_env("VN_X3_SPLITK", -1);          // 0 / 1: off, 2 / 4: forced
-    const int tiles = vn_cdiv(a.M, X3_BM) * vn_cdiv(a.N, X3_BN), nk = a.K / X3_KT;
+    static const int forced_env = x3_env("VN_X3_SPLITK", -1);      // 0 / 1: off, 2 / 4: forced
+    const int forced = g_x3_split != -2 ? g_x3_split : forced_env;
+    const int bm = x3_bm();
+    const int tiles = vn_cdiv(a.M, bm) * vn_cdiv(a.N, X3_BN), nk = a.K / X3_KT;
     if (forced == 0 || forced == 1 || (a.N & 3) || (a.ldc & 3)) return 1;
     int best = 1;
     double best_cost = 1e300;
     for (int ns = 1; ns <= 4; ns *= 2) {
         if (ns > 1 && (nk / ns < 8 || (double)ns * a.M * a.N > (double)X3_WS_FLOATS)) continue;
         if (forced > 1 && ns != forced && ns != 1) continue;
-        double cost = ceil(tiles * ns / 256.0) * (nk / (double)ns) * 1.45;
+        double cost = ceil(tiles * ns / 256.0) * (nk / (double)ns) * 1.45 * (bm / 128);
         if (ns > 1) cost += (ns + (residual ? 2 : 1)) * 4.0 * a.M * (double)a.N / 3.5e6;
         if (forced > 1 && ns == forced) cost = 0;
         if (cost < best_cost) { best_cost = cost; best = ns; }
@@ -374,33 +426,24 @@ static int x3_pick_split(const vn_gemm_args& a, bool residual) {
 
 template <int EPI>
 static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
-    const int tiles_m = vn_cdiv(a.M, X3_BM), tiles_n = vn_cdiv(a.N, X3_BN);
     const double n_out = (EPI == VN_EPI_GEGLU) ? a.N / 2 : a.N;
     const double bytes = 6.0 * ((double)a.M * a.K + (double)a.N * a.K) +
                          ((EPI == VN_EPI_GEGLU && a.C16) ? 6.0 : 4.0) * (double)a.M * n_out * (EPI == VN_EPI_RESIDUAL ? 2 : 1);
-    // schedule: 3 (default) = register-prefetched fragments + DMA pieces spread over the MFMA pairs; 1 = DMA back to back;
-    // 0 / 2 (store epilogue, tuning only) = plain double buffering / three LDS buffers
-    static const int pipe = x3_env("VN_X3_PIPE", 3);
-    static const int abl = x3_env("VN_X3_ABL", 0) & 7;                      // ablations (tuning only; results invalid)
     const int pi = vn_prof_pre(ctx, 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);       // algorithmic (fp32-equivalent) flops
     if constexpr (EPI == VN_EPI_STORE) {
-        if (pipe == 0 || pipe == 2 || abl) {
-            static bool attr = false;
-            if (!attr) {
-                (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
-                (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X3_STAGE_FLOATS * 4);
-                (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
-                (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
-                (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
-                (void)hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<VN_EPI_STORE, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
-                attr = true;
+        static const int abl_env = x3_env("VN_X3_ABL", 0) & 3;             // ablations (tuning only; results invalid)
+        const int abl = g_x3_abl >= 0 ? g_x3_abl : abl_env;
+        if (abl) {
+            const int tiles_n = vn_cdiv(a.N, X3_BN);
+            if (x3_pipe() == 5) {
+                if (abl == 1) x3_go<VN_EPI_STORE, 4, 2, 1>(a, vn_cdiv(a.M, 256), tiles_n, 1, s);
+                else if (abl == 2) x3_go<VN_EPI_STORE, 4, 2, 2>(a, vn_cdiv(a.M, 256), tiles_n, 1, s);
+                else x3_go<VN_EPI_STORE, 4, 2, 3>(a, vn_cdiv(a.M, 256), tiles_n, 1, s);
+            } else {
+                if (abl == 1) x3_go<VN_EPI_STORE, 4, 1, 1>(a, vn_cdiv(a.M, 128), tiles_n, 1, s);
+                else if (abl == 2) x3_go<VN_EPI_STORE, 4, 1, 2>(a, vn_cdiv(a.M, 128), tiles_n, 1, s);
+                else x3_go<VN_EPI_STORE, 4, 1, 3>(a, vn_cdiv(a.M, 128), tiles_n, 1, s);
             }
-            if (abl == 1) x3_go<VN_EPI_STORE, 1, 1>(a, tiles_m, tiles_n, 1, X3_LDS_BYTES, s);
-            else if (abl == 2) x3_go<VN_EPI_STORE, 1, 2>(a, tiles_m, tiles_n, 1, X3_LDS_BYTES, s);
-            else if (abl == 3) x3_go<VN_EPI_STORE, 1, 3>(a, tiles_m, tiles_n, 1, X3_LDS_BYTES, s);
-            else if (abl) x3_go<VN_EPI_STORE, 1, 4>(a, tiles_m, tiles_n, 1, X3_LDS_BYTES, s);
-            else if (pipe == 0) x3_go<VN_EPI_STORE, 0>(a, tiles_m, tiles_n, 1, X3_LDS_BYTES, s);
-            else x3_go<VN_EPI_STORE, 2>(a, tiles_m, tiles_n, 1, 3 * X3_STAGE_FLOATS * 4, s);
             vn_prof_post(ctx, pi, s);
             VN_LAUNCH_CHECK(ctx);
             return VN_OK;
@@ -413,26 +456,30 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
             vn_gemm_args q = a;                       // every split stores its raw image [M][N] into the workspace
             q.C = ctx->x3_ws;
             q.ldc = a.N;
-            if (pipe == 1) x3_go<VN_EPI_STORE, 1>(q, tiles_m, tiles_n, ns, X3_LDS_BYTES, s);
-            else x3_go<VN_EPI_STORE, 3>(q, tiles_m, tiles_n, ns, X3_LDS_BYTES, s);
+            x3_go_pipe<VN_EPI_STORE>(q, ns, s);
             VN_LAUNCH_CHECK(ctx);
             const int rc = vn_launch_splitk_reduce(ctx, ctx->x3_ws, ns, a.C, a.M, a.N, a.ldc, EPI == VN_EPI_RESIDUAL, s);
             vn_prof_post(ctx, pi, s);
             return rc;
         }
     }
-    if (pipe == 1) x3_go<EPI, 1>(a, tiles_m, tiles_n, 1, X3_LDS_BYTES, s);
-    else x3_go<EPI, 3>(a, tiles_m, tiles_n, 1, X3_LDS_BYTES, s);
+    x3_go_pipe<EPI>(a, 1, s);
     vn_prof_post(ctx, pi, s);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
 }
 
+template <typename K>
+static int x3_attr(vn_ctx* ctx, K kernel, size_t bytes) {
+    VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return VN_OK;
+}
 template <int EPI>
 static int x3_attrs(vn_ctx* ctx) {
-    VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
-    VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_gemm_x3_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES));
-    return VN_OK;
+    int rc;
+    if ((rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 3, 1>, (size_t)x3_geo<1>::STAGE * 8))) return rc;
+    if ((rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 4, 1>, (size_t)x3_geo<1>::STAGE * 12))) return rc;
+    return x3_attr(ctx, vn_gemm_x3_kernel<EPI, 4, 2>, (size_t)x3_geo<2>::STAGE * 8);
 }
 
 int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s) {
@@ -446,6 +493,13 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
         int rc;
         if ((rc = x3_attrs<VN_EPI_STORE>(ctx)) || (rc = x3_attrs<VN_EPI_BIAS>(ctx)) || (rc = x3_attrs<VN_EPI_RESIDUAL>(ctx)) ||
             (rc = x3_attrs<VN_EPI_GEGLU>(ctx)) || (rc = x3_attrs<VN_EPI_QKV>(ctx)))
+            return rc;
+        if ((rc = x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_STORE, 4, 1, 1>, (size_t)x3_geo<1>::STAGE * 12)) ||
+            (rc = x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_STORE, 4, 1, 2>, (size_t)x3_geo<1>::STAGE * 12)) ||
+            (rc = x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_STORE, 4, 1, 3>, (size_t)x3_geo<1>::STAGE * 12)) ||
+            (rc = x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_STORE, 4, 2, 1>, (size_t)x3_geo<2>::STAGE * 8)) ||
+            (rc = x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_STORE, 4, 2, 2>, (size_t)x3_geo<2>::STAGE * 8)) ||
+            (rc = x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_STORE, 4, 2, 3>, (size_t)x3_geo<2>::STAGE * 8)))
             return rc;
         ctx->attr_mask |= VN_ATTR_GEMM_X3;
     }

@@ -209,11 +209,6 @@ struct vn_gemm_args {
 };
 int vn_launch_gemm_f32(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);
 int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);      // a.bf16 == 2
-// STAGED (round 2): "f16x2" path of gemm_h2.hip — a.bf16 == 3, operands as two fp16 planes; split2h builds such planes
-int vn_launch_gemm_h2_auto(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);
-int vn_launch_split2h(vn_ctx* ctx, const float* src, uint16_t* dst, long n, long plane_stride, hipStream_t s);
-int vn_launch_rmsnorm_h2(vn_ctx* ctx, const float* x, const float* w, uint16_t* y2, long plane, int rows, int D, float eps,
-                         hipStream_t s);
 // C[M][N] (row stride ldc) (+)= sum over the nsplit partial images partial[s][M][N], in fixed order (gemm_f32.hip)
 int vn_launch_splitk_reduce(vn_ctx* ctx, const float* partial, int nsplit, float* C, int M, int N, int ldc, bool residual,
                             hipStream_t s);

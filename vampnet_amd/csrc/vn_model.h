@@ -16,7 +16,6 @@ struct vn_model {
     // A operands are written as three planes too (y16: max_rows * D apart, g16: max_rows * 2D apart)
     const uint16_t* blob16;
     long w_plane;            // 0: single-plane bf16 fast mode
-    int h2;                  // STAGED: 1 = blob16 holds the TWO fp16 planes of the f16x2 scheme (gemm_h2.hip)
     uint16_t *y16, *g16;     // sized for three planes
     int bias_T;              // T the expanded bias table is currently built for (-1 = none)
     long max_rows;

@@ -134,26 +134,6 @@ class Engine:
                                            self.stream()), "vn_gemm_bf16x3")
         return out
 
-    # staged for round 2 (gemm_h2.hip): not yet run on a GPU, not used by any model path
-    def split2h(self, x):
-        """fp32 tensor -> fp16 [2, *x.shape]: h0 = fp16(x), h1 = fp16((x - h0) * 2^11) (operand format of gemm_f16x2)."""
-        x = x.contiguous()
-        n = x.numel()
-        out = torch.empty((2,) + tuple(x.shape), dtype=torch.float16, device=x.device)
-        self.check(self.lib.vn_split2h_f32(self.handle, x.data_ptr(), out.data_ptr(), n, n, self.stream()), "vn_split2h_f32")
-        return out
-
-    def gemm_f16x2(self, a2, w2, bias=None, epilogue=_lib.EPI_STORE, out=None, tile_m=128, nsplit=1):
-        """fp32-grade GEMM on the fp16 matrix cores: a2 [2,M,K], w2 [2,N,K] split planes -> fp32 out (op)= a @ w.T"""
-        _, M, K = a2.shape
-        N = w2.shape[1]
-        if out is None:
-            out = torch.empty(M, N // 2 if epilogue == _lib.EPI_GEGLU else N, device=a2.device, dtype=torch.float32)
-        self.check(self.lib.vn_gemm_f16x2(self.handle, a2.data_ptr(), M * K, w2.data_ptr(), N * K,
-                                          bias.data_ptr() if bias is not None else None, out.data_ptr(), M, N, K, epilogue,
-                                          tile_m, nsplit, self.stream()), "vn_gemm_f16x2")
-        return out
-
     def attention(self, q, k, v, rel_bias, num_buckets=32, max_distance=128):
         """q,k,v [B,H,T,64]; rel_bias [num_buckets,H] -> [B,T,H*64]."""
         B, H, T, dh = q.shape
@@ -273,7 +253,6 @@ class VampNetModel:
         self.handle = h
         self.blob16 = None
         self.blob3 = None
-        self.blob2h = None
         self.precision = "f32"
         self.set_precision(precision)
 
@@ -293,18 +272,10 @@ class VampNetModel:
                 self.engine.check(self.lib.vn_split3_f32(self.engine.handle, self.blob.data_ptr(), self.blob3.data_ptr(), n, n,
                                                          self.engine.stream()), "vn_split3_f32")
             self.engine.check(self.lib.vn_model_set_bf16x3(self.handle, self.blob3.data_ptr(), n), "vn_model_set_bf16x3")
-        elif precision == "f16x2":
-            # STAGED for round 2 (csrc/gemm_h2.hip, not yet validated on a GPU): two fp16 planes per operand, three MFMA products
-            n = self.blob.numel()
-            if self.blob2h is None:
-                self.blob2h = torch.empty(2 * n, dtype=torch.float16, device=self.device)
-                self.engine.check(self.lib.vn_split2h_f32(self.engine.handle, self.blob.data_ptr(), self.blob2h.data_ptr(), n, n,
-                                                          self.engine.stream()), "vn_split2h_f32")
-            self.engine.check(self.lib.vn_model_set_f16x2(self.handle, self.blob2h.data_ptr(), n), "vn_model_set_f16x2")
         elif precision == "f32":
             self.engine.check(self.lib.vn_model_set_bf16(self.handle, None), "vn_model_set_bf16")
         else:
-            raise ValueError("precision must be 'f32', 'bf16x3', 'bf16' or (staged) 'f16x2'")
+            raise ValueError("precision must be 'f32', 'bf16x3' or 'bf16'")
         self.precision = precision
 
     @property
