@@ -5,7 +5,9 @@ A "step" = one full Interface.vamp() (coarse 12 sampling steps + coarse-to-fine 
 synthetic 10 s clips (T = 575 tokens, 14 codebooks) that is already resident in HBM.  Workload = BASELINE.json
 configs[2] ("coarse + c2f full vamp(), batch=8, 10 s clips, typical_filtering=True, 1xMI355X"); with --gpus N each
 GPU keeps 8 clips (weak scaling; N = 8 is configs[3], batch 64 sharded 8-way with one all-gather of the tokens).
-Random-init weights of the real architecture (no checkpoints in this image), device Philox RNG, exact-fp32 MFMA.
+Random-init weights of the real architecture (no checkpoints in this image), device Philox RNG; default precision
+"bf16x3" (fp32-grade GEMMs as six bf16-MFMA products of exact 3-way operand splits; --dtype f32 = fp32-input MFMA).
+--config 1 = BASELINE configs[1] (coarse model only, batch 1, 12 steps); --config 2 (default) = configs[2].
 
 Prints ONE JSON line on rank 0.
 """
@@ -25,46 +27,91 @@ PEAK_F32_MFMA_TF = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 PEAK_BF16_MFMA_TF = 2500.0         # dense bf16 MFMA (32x32x16)
 
 
-def cpu_baseline(threads=None):
-    """The oracle (a port of the reference's torch-CPU path, bitwise-pinned to it) timed on the host cores on a
-    bounded sample: 2 coarse sampling steps (B=1, T=575) + 2 c2f steps (B=1, T=173), extrapolated to the 12 + 8
-    steps of one clip (every step costs the same: one forward + sampling)."""
+def _host_facts():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"os_cpu_count": os.cpu_count(), "cpu_model": model}
+
+
+def _ref_models():
+    """The reference's OWN modules (vampnet.modules.transformer.VampNet + vampnet.interface.Interface through the import shim),
+    when /root/reference is mounted (this container; never on the GPU box) -> callable(z, mask) running Interface.vamp."""
+    try:
+        from oracle import ref_shim                      # CPU baseline leg only
+        if not ref_shim.reference_available():
+            return None
+        from vampnet_amd import synth as W
+        ns = ref_shim.load_reference()
+        cb = W.synth_codebooks()
+        coarse = ref_shim.build_reference_model(ns, W.COARSE_DIMS, W.synth_state_dict(W.COARSE_DIMS, 0))
+        c2f = ref_shim.build_reference_model(ns, W.C2F_DIMS, W.synth_state_dict(W.C2F_DIMS, 1))
+        itf = ref_shim.build_reference_interface(ns, coarse, c2f, ref_shim.FakeCodec(cb))
+        return lambda z, mask, **kw: itf.vamp(z, mask, **kw)
+    except Exception:
+        return None
+
+
+def cpu_baseline(threads=None, coarse_only=False):
+    """The CPU path timed on the host cores over ONE WHOLE 10 s clip (12 coarse steps + 4 x 2 c2f steps, B = 1; coarse_only:
+    the 12 coarse steps of configs[1]) after a one-step warm-up of each model.  kind = "reference": the reference's own
+    modules through oracle/ref_shim.py (only where /root/reference is mounted); kind = "port": the oracle, a port of the
+    reference's torch-CPU path that the tests pin bitwise to it (tests/test_oracle_vs_reference.py, tests/golden/)."""
     from oracle import vampnet_oracle as O            # the ONLY place bench.py touches oracle/: the CPU baseline leg
     from vampnet_amd import synth as W
     cb = W.synth_codebooks()
+    csd, fsd = W.synth_state_dict(W.COARSE_DIMS, 0), W.synth_state_dict(W.C2F_DIMS, 1)
+    z = W.synth_codes(1, 14, 575, seed=2)
+    torch.manual_seed(0)
+    mask = O.build_mask(z)                             # periodic_prompt=7, upper_codebook_mask=3
+    m1 = torch.ones(1, 14, 173, dtype=torch.long)
+    m1[:, :4] = 0
+
+    def warm():
+        O.generate(csd, W.COARSE_DIMS, cb, z[:, :4], mask[:, :4], sampling_steps=1, seed=0)
+        O.generate(fsd, W.C2F_DIMS, cb, z[:, :, :173], m1, sampling_steps=1, seed=0)
+
+    probe = []
     if threads:
         torch.set_num_threads(threads)
     else:
         # torch's default (one thread per logical CPU) over-subscribes big hosts: probe a c2f step at a few counts
-        sd = W.synth_state_dict(W.C2F_DIMS, 1)
-        z = W.synth_codes(1, 14, 173, seed=2)
-        mask = torch.ones_like(z)
-        mask[:, :4] = 0
         best = (1e30, torch.get_num_threads())
         for n in sorted({min(os.cpu_count() or 8, c) for c in (16, 32, 64, 128)}):
             torch.set_num_threads(n)
-            O.generate(sd, W.C2F_DIMS, cb, z, mask, sampling_steps=1, seed=0)
+            O.generate(fsd, W.C2F_DIMS, cb, z[:, :, :173], m1, sampling_steps=1, seed=0)
             t0 = time.perf_counter()
-            O.generate(sd, W.C2F_DIMS, cb, z, mask, sampling_steps=1, seed=0)
-            best = min(best, (time.perf_counter() - t0, n))
+            O.generate(fsd, W.C2F_DIMS, cb, z[:, :, :173], m1, sampling_steps=1, seed=0)
+            dt = time.perf_counter() - t0
+            probe.append((n, round(dt, 3)))
+            best = min(best, (dt, n))
         torch.set_num_threads(best[1])
-        del sd
     cores = torch.get_num_threads()
-    out = {}
-    for name, dims, T, seed in (("coarse", W.COARSE_DIMS, 575, 0), ("c2f", W.C2F_DIMS, 173, 1)):
-        sd = W.synth_state_dict(dims, seed)
-        z = W.synth_codes(1, dims["n_codebooks"], T, seed=2)
-        mask = torch.ones_like(z)
-        mask[:, :dims["n_cond"]] = 0
-        O.generate(sd, dims, cb, z, mask, sampling_steps=1, seed=0)            # warm-up
-        t0 = time.perf_counter()
-        O.generate(sd, dims, cb, z, mask, sampling_steps=2, seed=0)
-        out[name] = (time.perf_counter() - t0) / 2
-        del sd
-    clip_s = 12 * out["coarse"] + 8 * out["c2f"]
-    return {"value": TOKENS_PER_CLIP / clip_s, "unit": "codec-tokens/s", "cores": cores, "kind": "port",
-            "sample": f"oracle.generate: 2 coarse steps (B=1,T=575, {out['coarse']:.3f} s/step) + 2 c2f steps "
-                      f"(B=1,T=173, {out['c2f']:.3f} s/step), extrapolated to 12+8 steps = {clip_s:.2f} s/clip"}
+    ref = None if coarse_only else _ref_models()       # the coarse-only line is timed through the port in every environment
+    kind = "reference" if ref is not None else "port"
+    models = O.OracleModels(csd, W.COARSE_DIMS, fsd, W.C2F_DIMS, cb)
+    warm()
+    t0 = time.perf_counter()
+    if coarse_only:
+        O.coarse_vamp(models, z, mask, _sampling_steps=12, seed=0)
+        tokens = 4 * 575
+    else:
+        if ref is not None:
+            ref(z, mask, batch_size=1, _sampling_steps=12, seed=0, typical_filtering=True)
+        else:
+            O.vamp(models, z, mask, batch_size=1, _sampling_steps=12, seed=0, typical_filtering=True)
+        tokens = TOKENS_PER_CLIP
+    clip_s = time.perf_counter() - t0
+    what = "12 coarse steps (B=1, T=575)" if coarse_only else "12 coarse steps (T=575) + 4 chunks x 2 c2f steps (T=173), B=1"
+    return {"value": tokens / clip_s, "unit": "codec-tokens/s", "cores": cores, "kind": kind,
+            "sample": f"one whole clip, not extrapolated: {what} = {clip_s:.2f} s after a 1-step warm-up of each model; "
+                      f"torch {torch.__version__} CPU fp32, {cores} threads (c2f-step probe {probe})",
+            **_host_facts()}
 
 
 def cpu_baseline_train(threads=16):
@@ -169,7 +216,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-per-gpu", type=int, default=8)
     ap.add_argument("--coarse-steps", type=int, default=12)
-    ap.add_argument("--coarse-only", action="store_true", help="BASELINE configs[1]: coarse_vamp only (4 codebooks)")
+    ap.add_argument("--coarse-only", action="store_true", help="coarse_vamp only (4 codebooks)")
+    ap.add_argument("--config", type=int, choices=[1, 2], default=2,
+                    help="BASELINE.json configs index: 1 = coarse model only, batch 1, 12 sampling steps (= --coarse-only "
+                         "--batch-per-gpu 1); 2 (default) = coarse + c2f vamp(), batch 8")
     ap.add_argument("--dtype", choices=["f32", "bf16x3", "bf16"], default="bf16x3",
                     help="bf16x3 (default) = fp32-grade GEMMs as six bf16-MFMA products of exact 3-way operand splits, fp32 "
                          "accumulate: held to the same parity bars as f32 (tests/test_gpu_bf16x3.py: tokens bit-identical to the "
@@ -183,6 +233,8 @@ def main():
     ap.add_argument("--event-stride", type=int, default=8,
                     help="bracket ~1 of every N MFMA launches with hipEvents (1 = all: +2.3 %% step time at B=8)")
     args = ap.parse_args()
+    if args.config == 1:
+        args.coarse_only, args.batch_per_gpu = True, 1
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -285,14 +337,20 @@ def main():
     if rank == 0:
         tokens = B * (4 * 575 if args.coarse_only else TOKENS_PER_CLIP) * args.steps
         res = {
-            "metric": "codec-tokens/s, coarse+c2f vamp(), 10 s clips", "value": tokens / elapsed,
+            "metric": "codec-tokens/s, coarse vamp (4 codebooks), 10 s clips" if args.coarse_only else
+                      "codec-tokens/s, coarse+c2f vamp(), 10 s clips", "value": tokens / elapsed,
             "unit": "codec-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (random-init weights of the real architecture, "
             "random codes, periodic-7 prompt mask)",
-            "config": {"workload": "BASELINE configs[2]: Interface.vamp() coarse(12 steps)+c2f(4x2 steps), "
-                                   f"batch {args.batch_per_gpu}/GPU x 10 s @ 44.1 kHz (T=575, 14 codebooks), "
-                                   "typical_filtering=True, device RNG",
+            "config": {"workload": (f"BASELINE configs[1]: Interface.coarse_vamp(), coarse model only ({args.coarse_steps} sampling "
+                                    f"steps), batch {args.batch_per_gpu}/GPU x 10 s @ 44.1 kHz (T=575, 4 codebooks), device RNG"
+                                    if args.coarse_only else
+                                    f"BASELINE configs[2]: Interface.vamp() coarse({args.coarse_steps} steps)+c2f(4x2 steps), "
+                                    f"batch {args.batch_per_gpu}/GPU x 10 s @ 44.1 kHz (T=575, 14 codebooks), "
+                                    "typical_filtering=True, device RNG"),
+                       "codec": "outside the timed region (tokens in, tokens out); DAC encode/decode parity is UNPINNED "
+                                "(lac sources and weights absent) and no codec figure is part of this line",
                        "global_batch": B, "coarse_steps": args.coarse_steps,
                        "parallelism": f"batch-shard x{world}" if world > 1 else "single GPU",
                        "s_per_clip": elapsed / args.steps / B * world,
@@ -306,8 +364,8 @@ def main():
             n, ms, fl, gbytes = prof["gemm_bf16"] if args.dtype == "bf16" else prof["gemm"]
             an, ams, afl, _ = prof["attention"]
             traffic = None      # fabric bytes per launch from the committed rocprofv3 --pmc passes of this same command
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-            if os.path.exists(tpath) and world == 1 and args.batch_per_gpu == 8 and not args.coarse_only and args.dtype == "f32":
+            tpath = os.path.join(ROOT, "profiles", {"f32": "r01_traffic.json", "bf16x3": "r02_traffic_x3.json"}.get(args.dtype, "-"))
+            if os.path.exists(tpath) and world == 1 and args.batch_per_gpu == 8 and not args.coarse_only:
                 traffic = json.load(open(tpath))["bytes_per_launch"]
             # bf16x3: `achieved` stays ALGORITHMIC (2MNK per GEMM, fp32-equivalent); every such flop costs six bf16-MFMA flops,
             # so the ceiling of this algorithm is the dense bf16 MFMA peak / 6 (the kernel executes 6 x achieved on the pipe)
@@ -329,7 +387,7 @@ def main():
                                "attention": {"launches": int(an), "avg_launch_us": 1e3 * ams / an if an else None,
                                              "achieved": afl / (ams * 1e-3) / 1e12 if ams else None}}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline"] = cpu_baseline(coarse_only=args.coarse_only)
         print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -1,0 +1,108 @@
+"""CPU tests of vampnet_amd/checkpoint.py — the reader behind `VampNet.load` / `DAC.load` (interface.py:27-50,70; audiotools
+`BaseModel.load`: torch.package archive first, `{"state_dict", "metadata": {"kwargs"}}` dict second) — of the trust rule for
+files that execute code, and of the codec kwargs / state_dict validation."""
+import pathlib
+
+import pytest
+import torch
+
+from oracle import weights as W
+from vampnet_amd import checkpoint as CK
+from vampnet_amd.synth import model_kwargs
+
+
+def _sd():
+    return W.synth_state_dict(W.TINY_COARSE_DIMS, 0)
+
+
+def test_dict_checkpoint_with_kwargs_variants(tmp_path):
+    sd = _sd()
+    kw = dict(model_kwargs(W.TINY_COARSE_DIMS), dropout=0.1, r_cond_dim=0, noise_mode="mask", max_seq_len=1024,
+              num_reg_tokens=0, flash_attn=False)                      # VampNet.__init__ carries more keys than the engine needs
+    torch.save({"state_dict": sd, "metadata": {"kwargs": kw, "version": "0.0.1"}}, tmp_path / "coarse.pth")
+    got, gkw = CK.load_model_checkpoint(tmp_path / "coarse.pth")
+    assert gkw == kw and list(got) == list(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    torch.save({"state_dict": sd}, tmp_path / "bare.pth")             # no metadata at all: constructor defaults apply
+    assert CK.load_model_checkpoint(tmp_path / "bare.pth")[1] == {}
+    torch.save({"weights": sd}, tmp_path / "other.pth")
+    with pytest.raises(ValueError, match="state_dict"):
+        CK.load_model_checkpoint(tmp_path / "other.pth")
+    with pytest.raises(FileNotFoundError):
+        CK.load_model_checkpoint(tmp_path / "missing.pth")
+
+
+def test_untrusted_pickles_are_refused(tmp_path, monkeypatch):
+    """weights_only=True reads tensors + primitives; a checkpoint that needs arbitrary unpickling is refused unless trusted."""
+    sd = _sd()
+    torch.save({"state_dict": sd, "metadata": {"kwargs": {"n_heads": 4}, "path": pathlib.Path("/x")}}, tmp_path / "obj.pth")
+    monkeypatch.delenv("VN_TRUST_CHECKPOINTS", raising=False)
+    with pytest.raises(PermissionError, match="weights_only"):
+        CK.load_model_checkpoint(tmp_path / "obj.pth")
+    assert CK.load_model_checkpoint(tmp_path / "obj.pth", trusted=True)[1] == {"n_heads": 4}
+    monkeypatch.setenv("VN_TRUST_CHECKPOINTS", "1")
+    assert CK.load_model_checkpoint(tmp_path / "obj.pth")[1] == {"n_heads": 4}
+    torch.save({"a.lora_A": torch.ones(2, 3)}, tmp_path / "lora.pth")
+    assert torch.equal(CK.load_tensor_dict(tmp_path / "lora.pth")["a.lora_A"], torch.ones(2, 3))
+
+
+@pytest.mark.filterwarnings("ignore::UserWarning")
+def test_torch_package_branch(tmp_path, monkeypatch):
+    """`BaseModel.load` tries `_load_package` first: <Class>/<Class>.pth (+ .metadata) inside a torch.package archive."""
+    from torch import package
+    from tests import pkg_model
+    sd, kw = _sd(), model_kwargs(W.TINY_COARSE_DIMS)
+    model = pkg_model.VampNet(sd, **kw)
+    with package.PackageExporter(str(tmp_path / "coarse.pth")) as pe:
+        pe.extern(["torch.**"])
+        pe.intern("tests.**")
+        pe.save_pickle("VampNet", "VampNet.pth", model)
+        pe.save_pickle("VampNet", "VampNet.metadata", {"kwargs": kw})
+    with package.PackageExporter(str(tmp_path / "nometa.pth")) as pe:
+        pe.extern(["torch.**"])
+        pe.intern("tests.**")
+        pe.save_pickle("VampNet", "VampNet.pth", model)
+    assert CK.is_torch_package(tmp_path / "coarse.pth")
+    torch.save({"state_dict": sd}, tmp_path / "dict.pth")
+    assert not CK.is_torch_package(tmp_path / "dict.pth")            # torch.save also writes zip files
+    monkeypatch.delenv("VN_TRUST_CHECKPOINTS", raising=False)
+    with pytest.raises(PermissionError, match="executes the code"):
+        CK.load_model_checkpoint(tmp_path / "coarse.pth")
+    got, gkw = CK.load_model_checkpoint(tmp_path / "coarse.pth", trusted=True)
+    assert gkw == kw and list(got) == list(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    # no metadata inside: constructor kwargs are read off the module's attributes
+    from vampnet_amd.interface import _MODEL_KEYS
+    _, akw = CK.load_model_checkpoint(tmp_path / "nometa.pth", kwarg_keys=_MODEL_KEYS, trusted=True)
+    assert akw == {k: kw[k] for k in _MODEL_KEYS}
+    with pytest.raises(ValueError, match="no .* model inside"):
+        CK.load_model_checkpoint(_wrong_package(tmp_path), trusted=True)
+
+
+def _wrong_package(tmp_path):
+    from torch import package
+    with package.PackageExporter(str(tmp_path / "wrong.pth")) as pe:
+        pe.extern(["torch.**"])
+        pe.save_pickle("Something", "Something.pth", {"x": 1})
+    return tmp_path / "wrong.pth"
+
+
+def test_codec_kwargs_and_state_dict_validation():
+    """A published DAC checkpoint's kwargs (descript-audio-codec 44 kHz: rates 2·4·8·8, 9 codebooks, quantizer_dropout, ...) is
+    accepted and reduced to what the conv stacks need; a state_dict of another architecture fails with a message."""
+    from oracle import dac_oracle as D
+    from vampnet_amd.codec import DEFAULT_CFG, normalize_codec_kwargs, validate_codec_state_dict
+    dac44 = dict(encoder_dim=64, encoder_rates=[2, 4, 8, 8], latent_dim=None, decoder_dim=1536, decoder_rates=[8, 8, 4, 2],
+                 n_codebooks=9, codebook_size=1024, codebook_dim=8, quantizer_dropout=0.5, sample_rate=44100)
+    cfg = normalize_codec_kwargs(dac44)
+    assert "quantizer_dropout" not in cfg and cfg["encoder_rates"] == [2, 4, 8, 8] and cfg["n_codebooks"] == 9
+    assert normalize_codec_kwargs(dict(dac44, codebook_dim=[8] * 9))["codebook_dim"] == 8
+    with pytest.raises(ValueError, match="per-level"):
+        normalize_codec_kwargs(dict(dac44, codebook_dim=[8, 16]))
+    tiny = dict(D.DAC_TINY_CFG)
+    sd = D.synth_dac_state_dict(tiny, 1)
+    validate_codec_state_dict(sd, dict(DEFAULT_CFG, **tiny))
+    with pytest.raises(ValueError, match="n_codebooks"):
+        validate_codec_state_dict(sd, dict(DEFAULT_CFG, **dict(tiny, n_codebooks=tiny["n_codebooks"] + 1)))
+    with pytest.raises(ValueError, match="encoder_dim"):
+        validate_codec_state_dict(sd, dict(DEFAULT_CFG, **dict(tiny, encoder_dim=2 * tiny["encoder_dim"])))
+    with pytest.raises(ValueError, match="not a DAC-family"):
+        validate_codec_state_dict(_sd(), dict(DEFAULT_CFG, **tiny))

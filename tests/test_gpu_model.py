@@ -143,7 +143,7 @@ def test_generate_vs_oracle(tiny, which, case):
     mask[:, :dims["n_cond"]] = 0
     ref = O.generate(sd, dims, tiny["cb"], z.clone(), mask.clone(), **O._gen_kwargs(dict(case["kw"])))
     tail_ref = torch.rand(2)
-    got = model.generate(start_tokens=z.clone(), mask=mask.clone(), typical_filtering=True, **case["kw"]).cpu()
+    got = model.generate(return_signal=False, start_tokens=z.clone(), mask=mask.clone(), typical_filtering=True, **case["kw"]).cpu()
     assert torch.equal(torch.rand(2), tail_ref), "torch CPU generator not left where the reference leaves it"
     assert torch.equal(got, ref)
 
@@ -160,7 +160,7 @@ def test_generate_vs_golden(tiny):
         model, _, _ = pick(tiny, which)
         z = torch.from_numpy(g[f"case{idx}_z"].astype(np.int64))
         mask = torch.from_numpy(g[f"case{idx}_mask"].astype(np.int64))
-        got = model.generate(start_tokens=z, mask=mask, **kw).cpu().numpy()
+        got = model.generate(return_signal=False, start_tokens=z, mask=mask, **kw).cpu().numpy()
         assert np.array_equal(got, g[f"case{idx}_out"].astype(np.int64)), m
 
 
@@ -168,27 +168,27 @@ def test_generate_edge_cases(tiny):
     model, sd, dims = pick(tiny, "coarse")
     z = W.synth_codes(2, 4, 40, seed=1)
     # nothing masked -> tokens unchanged
-    out = model.generate(start_tokens=z, mask=torch.zeros_like(z), _sampling_steps=3, seed=0).cpu()
+    out = model.generate(return_signal=False, start_tokens=z, mask=torch.zeros_like(z), _sampling_steps=3, seed=0).cpu()
     assert torch.equal(out, z)
     # everything masked, one step, 2-D mask broadcast over codebooks (transformer.py:752-753)
     m2 = torch.ones(2, 40, dtype=torch.long)
     ref = O.generate(sd, dims, tiny["cb"], z, m2, sampling_steps=1, seed=3)
-    out = model.generate(start_tokens=z, mask=m2, _sampling_steps=1, seed=3).cpu()
+    out = model.generate(return_signal=False, start_tokens=z, mask=m2, _sampling_steps=1, seed=3).cpu()
     assert torch.equal(out, ref)
     # mask=None default: all of the non-conditioning codebooks (transformer.py:749-751)
     c2f, fsd, fd = pick(tiny, "c2f")
     z14 = W.synth_codes(1, 14, 30, seed=2)
     ref = O.generate(fsd, fd, tiny["cb"], z14, torch.cat([torch.zeros(1, 4, 30), torch.ones(1, 10, 30)], 1).long(),
                      sampling_steps=2, seed=4)
-    out = c2f.generate(start_tokens=z14, mask=None, _sampling_steps=2, seed=4).cpu()
+    out = c2f.generate(return_signal=False, start_tokens=z14, mask=None, _sampling_steps=2, seed=4).cpu()
     assert torch.equal(out, ref)
     assert torch.equal(out[:, :4], z14[:, :4])
     # unsupported / misuse
     from vampnet_amd import VnError
     with pytest.raises(ValueError):
-        model.generate(start_tokens=None)
+        model.generate(start_tokens=None, return_signal=False)
     with pytest.raises(VnError):
-        model.generate(start_tokens=W.synth_codes(5, 4, 40), mask=None)      # beyond max_batch
+        model.generate(return_signal=False, start_tokens=W.synth_codes(5, 4, 40), mask=None)      # beyond max_batch
 
 
 def test_device_rng_mode_properties(tiny):
@@ -198,14 +198,14 @@ def test_device_rng_mode_properties(tiny):
     B, T = 4, 120
     z = W.synth_codes(B, 4, T, seed=5)
     mask = O.periodic_mask(z, 7, 1).long()
-    a = model.generate(start_tokens=z, mask=mask, _sampling_steps=6, rng="device", device_seed=42).cpu()
-    b = model.generate(start_tokens=z, mask=mask, _sampling_steps=6, rng="device", device_seed=42).cpu()
-    c = model.generate(start_tokens=z, mask=mask, _sampling_steps=6, rng="device", device_seed=43).cpu()
+    a = model.generate(return_signal=False, start_tokens=z, mask=mask, _sampling_steps=6, rng="device", device_seed=42).cpu()
+    b = model.generate(return_signal=False, start_tokens=z, mask=mask, _sampling_steps=6, rng="device", device_seed=42).cpu()
+    c = model.generate(return_signal=False, start_tokens=z, mask=mask, _sampling_steps=6, rng="device", device_seed=43).cpu()
     assert torch.equal(a, b) and not torch.equal(a, c)
     assert a.min() >= 0 and a.max() < 1024
     assert torch.equal(a[mask == 0], z[mask == 0])
     n0 = int(mask.sum())
-    halves = [model.generate(start_tokens=z[i:i + 2], mask=mask[i:i + 2], _sampling_steps=6, rng="device",
+    halves = [model.generate(return_signal=False, start_tokens=z[i:i + 2], mask=mask[i:i + 2], _sampling_steps=6, rng="device",
                              device_seed=42, n0_override=n0, global_batch=B, batch_offset=i).cpu() for i in (0, 2)]
     assert torch.equal(torch.cat(halves), a)
 
@@ -358,7 +358,7 @@ def test_bf16_fast_mode_is_close_but_not_claimed_exact(eng):
     agree = (got.argmax(1) == ref.argmax(1)).float().mean().item()
     print(f"bf16 fast mode: max |dlogit| = {err.max():.3e}, mean = {err.mean():.3e}, argmax agreement = {agree:.4f}")
     assert err.max() < 0.15 and err.mean() < 0.02 and agree > 0.9
-    z = model.generate(start_tokens=codes, mask=None, _sampling_steps=2, rng="device", device_seed=3).cpu()
+    z = model.generate(return_signal=False, start_tokens=codes, mask=None, _sampling_steps=2, rng="device", device_seed=3).cpu()
     assert z.min() >= 0 and z.max() < 1024 and torch.equal(z[:, :4], codes[:, :4])
     model.set_precision("f32")
     exact = model.forward_codes(codes).cpu()
@@ -469,7 +469,7 @@ def test_full_size_free_running_generate_vs_oracle(eng, full_sd, precision):
         marg = O.codebook_unflatten(sample_margins(t["logits"], t["exp"], 1.0, True), 4)
         assert (marg[bad] < 1e-4).all() and bad.sum() <= 2, f"step {i}: divergence outside the near-tie band"
         pytest.skip(f"trajectories parted at step {i} on an audited near-tie ({int(bad.sum())} token(s))")
-    got = model.generate(start_tokens=z, mask=mask, _sampling_steps=steps, seed=5).cpu()
+    got = model.generate(return_signal=False, start_tokens=z, mask=mask, _sampling_steps=steps, seed=5).cpu()
     assert torch.equal(got, O.codebook_unflatten(trace[-1]["sampled"], 4))
 
 
@@ -614,15 +614,15 @@ def test_torch_device_rng_mode_equals_host_replay(tiny):
     model, sd, dims = pick(tiny, "coarse")
     z = W.synth_codes(3, 4, 60, seed=5)
     mask = O.periodic_mask(z, 5, 1).long()
-    a = model.generate(start_tokens=z, mask=mask, _sampling_steps=5, seed=7, temperature=0.9, rng="torch").cpu()
+    a = model.generate(return_signal=False, start_tokens=z, mask=mask, _sampling_steps=5, seed=7, temperature=0.9, rng="torch").cpu()
     sa = torch.rand(64)          # where the generator stands afterwards (the jump-ahead path may hand back a re-aligned window
-    b = model.generate(start_tokens=z, mask=mask, _sampling_steps=5, seed=7, temperature=0.9, rng="torch_device").cpu()
+    b = model.generate(return_signal=False, start_tokens=z, mask=mask, _sampling_steps=5, seed=7, temperature=0.9, rng="torch_device").cpu()
     sb = torch.rand(64)          # of the same stream: compare by what it emits next, not by the state bytes)
     assert torch.equal(a, b) and torch.equal(sa, sb)
     ref = O.generate(sd, dims, tiny["cb"], z, mask, sampling_steps=5, seed=7, temperature=0.9)
     assert torch.equal(b, ref)
     # a shard of a global batch: items 1..2 of 3
-    c = model.generate(start_tokens=z[1:], mask=mask[1:], _sampling_steps=5, seed=7, temperature=0.9, rng="torch_device",
+    c = model.generate(return_signal=False, start_tokens=z[1:], mask=mask[1:], _sampling_steps=5, seed=7, temperature=0.9, rng="torch_device",
                        n0_override=int((mask != 0).sum()), global_batch=3, batch_offset=1).cpu()
     assert torch.equal(c, a[1:])
     # whole vamp() incl. the batched coarse-to-fine chunk calls

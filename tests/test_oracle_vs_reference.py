@@ -368,22 +368,3 @@ def test_util_module_names_bitwise(ns):
     for v in (3, 0.25):
         a, b = R.scalar_to_batch_tensor(v, 5), U.scalar_to_batch_tensor(v, 5)
         assert a.dtype == b.dtype and torch.equal(a, b)
-
-
-def test_noam_scheduler_matches_reference(ns):
-    import importlib
-    from vampnet_amd.scheduler import NoamScheduler
-    R = importlib.import_module("vampnet.scheduler")
-    pa, pb = [torch.nn.Parameter(torch.zeros(2))], [torch.nn.Parameter(torch.zeros(2))]
-    oa, ob = torch.optim.AdamW(pa, lr=1.0), torch.optim.AdamW(pb, lr=1.0)
-    a, b = R.NoamScheduler(oa, d_model=1280, factor=2.0, warmup=10000), NoamScheduler(ob, d_model=1280, factor=2.0, warmup=10000)
-    for i in range(1, 30):
-        a.step()
-        b.step()
-        assert a.lr == b.lr and oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"]
-    assert a.state_dict() == b.state_dict()
-    b2 = NoamScheduler(ob)
-    b2.load_state_dict(a.state_dict())
-    a.step()
-    b2.step()
-    assert a.lr == b2.lr

@@ -183,9 +183,10 @@ def test_data_parallel_two_ranks_gloo():
 
 
 def test_optimizer_and_scheduler_state_roundtrip():
-    """optimizer.pth is a torch.optim.AdamW state_dict over the parameters in state_dict order; scheduler.pth carries the
-    NoamScheduler attributes (vampnet/scheduler.py:30-33).  Flat moment buffers -> state_dict -> flat buffers is lossless, and
-    torch's own AdamW accepts the file."""
+    """optimizer.pth is a torch.optim.AdamW state_dict over the parameters in model.parameters() order; scheduler.pth carries
+    the NoamScheduler attributes (vampnet/scheduler.py:30-33) as the reference holds them after N updates: its scheduler has
+    stepped N + 1 times (once at construction, train.py:596).  Flat moment buffers -> state_dict -> flat buffers is lossless,
+    and torch's own AdamW accepts the file."""
     dims = W.TINY_COARSE_DIMS
     sd, cb = W.synth_state_dict(dims, 0), W.synth_codebooks()
     tr = OracleBackedTrainer(sd, dims, cb)
@@ -194,10 +195,11 @@ def test_optimizer_and_scheduler_state_roundtrip():
     like = {k: torch.randn(v.shape, generator=g) for k, v in sd.items()}
     tr.adam_m = tr.pack(like)
     tr.adam_v = tr.pack({k: v.abs() for k, v in like.items()})
-    tr.steps, tr.last_lr = 7, 1.25e-4
+    tr.steps, tr.last_lr = 7, noam_lr(7, dims["d_model"])
     osd = tr.optimizer_state_dict()
     names = tr._param_names()
-    assert osd["param_groups"][0]["params"] == list(range(len(names))) and osd["param_groups"][0]["lr"] == 1.25e-4
+    assert osd["param_groups"][0]["params"] == list(range(len(names)))
+    assert osd["param_groups"][0]["lr"] == noam_lr(8, dims["d_model"])          # what the reference's group holds after 7 updates
     for i, k in enumerate(names):
         assert torch.equal(osd["state"][i]["exp_avg"], like[k]) and float(osd["state"][i]["step"]) == 7.0
     params = [torch.nn.Parameter(torch.zeros(sd[k].shape)) for k in names]
@@ -209,4 +211,95 @@ def test_optimizer_and_scheduler_state_roundtrip():
     tr2.adam_m, tr2.adam_v = torch.zeros_like(tr.adam_m), torch.zeros_like(tr.adam_v)
     tr2.load_optimizer_state_dict(osd)
     assert tr2.steps == 7 and torch.equal(tr2.adam_m, tr.adam_m) and torch.equal(tr2.adam_v, tr.adam_v)
-    assert tr.scheduler_state_dict() == {"warmup": 10000, "factor": 2.0, "d_model": dims["d_model"], "lr": 1.25e-4, "steps": 7}
+    assert tr.scheduler_state_dict() == {"warmup": 10000, "factor": 2.0, "d_model": dims["d_model"],
+                                         "lr": noam_lr(8, dims["d_model"]), "steps": 8}
+    short = dict(osd, param_groups=[dict(osd["param_groups"][0], params=list(range(len(names) - 2)))])
+    with pytest.raises(ValueError, match="indexes"):
+        tr2.load_optimizer_state_dict(short)
+
+
+@pytest.mark.reference
+def test_resume_is_in_step_with_the_reference_scheduler(tmp_path):
+    """A (optimizer.pth, scheduler.pth) pair as the REFERENCE's train loop leaves it — AdamW over model.parameters(),
+    `scheduler.step()` once at construction and after every update (train.py:596, :299-301) — resumes in the Trainer at the
+    same update count, and the next update uses the rate the reference would use (lr(N + 1)); and the other way round."""
+    import importlib
+    from oracle import ref_shim
+    if not ref_shim.reference_available():
+        pytest.skip("needs /root/reference")
+    ref_shim.load_reference()
+    R = importlib.import_module("vampnet.scheduler")
+    dims = W.TINY_COARSE_DIMS
+    sd, cb = W.synth_state_dict(dims, 0), W.synth_codebooks()
+    tr = OracleBackedTrainer(sd, dims, cb)
+    tr._sd_template = {k: (tuple(v.shape), v.dtype) for k, v in sd.items()}
+    names = tr._param_names()
+    params = [torch.nn.Parameter(sd[k].clone()) for k in names]
+    opt = torch.optim.AdamW(params)
+    sched = R.NoamScheduler(opt, d_model=dims["d_model"], factor=2.0, warmup=10000)
+    sched.step()
+    g = torch.Generator().manual_seed(0)
+    for _ in range(3):                                    # three reference updates
+        for p_ in params:
+            p_.grad = torch.randn(p_.shape, generator=g) * 1e-3
+        opt.step()
+        sched.step()
+    torch.save(opt.state_dict(), tmp_path / "optimizer.pth")
+    torch.save(sched.state_dict(), tmp_path / "scheduler.pth")
+    from vampnet_amd.checkpoint import load_tensor_dict
+    tr.adam_m, tr.adam_v = torch.zeros(tr.n_total), torch.zeros(tr.n_total)
+    tr.load_optimizer_state_dict(load_tensor_dict(tmp_path / "optimizer.pth"))
+    assert tr.steps == 3
+    assert torch.equal(tr.export(tr.adam_m)[names[5]].reshape(params[5].shape), opt.state[params[5]]["exp_avg"])
+    assert noam_lr(tr.steps + 1, tr.D, *tr.noam) == sched.lr == opt.param_groups[0]["lr"]     # rate of update 4 on both sides
+    assert tr.scheduler_state_dict() == sched.state_dict()
+    assert tr.optimizer_state_dict()["param_groups"][0]["lr"] == opt.state_dict()["param_groups"][0]["lr"]
+    sched2 = R.NoamScheduler(torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))]), d_model=dims["d_model"])
+    sched2.load_state_dict(tr.scheduler_state_dict())     # the reference resuming from the Trainer's file
+    sched2.step()
+    assert sched2.lr == noam_lr(5, dims["d_model"])       # after its 4th update it prepares the 5th
+
+
+def test_optimizer_indices_follow_the_reference_parameter_order_with_adapters():
+    """The reference's AdamW indexes model.parameters(), where every loralib Linear contributes weight, lora_A, lora_B in that
+    order (transformer.py:67-68,109-114; w_ks is a plain Linear).  LoRA mode therefore writes / reads its adapter moments at
+    THOSE indices (not 0..n-1 of the adapters), full mode skips the adapter slots, and a file for another parameter list is
+    refused."""
+    from vampnet_amd.train import LORA_KEYS, LORA_R
+    dims = W.TINY_COARSE_DIMS
+    base, cb = W.synth_state_dict(dims, 0), W.synth_codebooks()
+    g = torch.Generator().manual_seed(3)
+    sd = {}
+    for k, v in base.items():                             # a checkpoint that already holds adapters, in module order
+        sd[k] = v
+        stem = k[:-len(".weight")]
+        if k.endswith(".weight") and any(stem.endswith(key) for key in LORA_KEYS):
+            sd[stem + ".lora_A"] = torch.randn(LORA_R, v.shape[1], generator=g) * 0.02
+            sd[stem + ".lora_B"] = torch.randn(v.shape[0], LORA_R, generator=g) * 0.02
+    allnames = list(sd)
+    tr = OracleBackedTrainer(base, dims, cb)
+    tr._sd_template = {k: (tuple(v.shape), v.dtype) for k, v in sd.items()}
+    assert tr._all_param_names() == allnames
+    n_lora = 2 * len(LORA_KEYS) * dims["n_layers"]
+    assert len(tr._param_names()) == len(allnames) - n_lora
+    like = {k: torch.randn(v.shape, generator=g) for k, v in base.items()}
+    tr.adam_m, tr.adam_v, tr.steps = tr.pack(like), tr.pack({k: v.abs() for k, v in like.items()}), 2
+    osd = tr.optimizer_state_dict()
+    assert osd["param_groups"][0]["params"] == list(range(len(allnames)))
+    lora_idx = {i for i, k in enumerate(allnames) if "lora_" in k}
+    assert set(osd["state"]) == set(range(len(allnames))) - lora_idx            # full mode: adapters carry no moments
+    k = "transformer.layers.1.feed_forward.w_2.weight"
+    assert torch.equal(osd["state"][allnames.index(k)]["exp_avg"], like[k])
+    # a reference file with state on every parameter: base moments land at their own indices, adapter entries are ignored
+    ref_state = {i: {"step": torch.tensor(5.0), "exp_avg": torch.full(tuple(sd[n].shape), float(i)),
+                     "exp_avg_sq": torch.full(tuple(sd[n].shape), float(i) + 0.5)} for i, n in enumerate(allnames)}
+    tr.load_optimizer_state_dict({"state": ref_state, "param_groups": [{"params": list(range(len(allnames)))}]})
+    assert tr.steps == 5
+    got = tr.export(tr.adam_m)
+    for n in (k, "transformer.layers.0.self_attn.w_ks.weight", "embedding.out_proj.bias"):
+        assert torch.all(got[n] == float(allnames.index(n))), n
+    # LoRA mode view of the same template: adapter indices are positions in the FULL list
+    tr.only_lora = True
+    assert [allnames.index(n) for n in tr._param_names()] == sorted(lora_idx)
+    with pytest.raises(ValueError, match="indexes"):
+        tr.load_optimizer_state_dict({"state": ref_state, "param_groups": [{"params": list(range(len(base)))}]})

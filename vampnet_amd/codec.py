@@ -22,6 +22,45 @@ DEFAULT_CFG = dict(encoder_dim=64, encoder_rates=[2, 4, 8, 12], latent_dim=None,
                    decoder_rates=[12, 8, 4, 2], n_codebooks=14, codebook_size=1024, codebook_dim=8, sample_rate=44100)
 
 
+def normalize_codec_kwargs(kw: dict) -> dict:
+    """metadata.kwargs of a DAC-family checkpoint -> the subset DacCodec consumes."""
+    cfg = {k: v for k, v in (kw or {}).items() if k in DEFAULT_CFG}
+    cd = cfg.get("codebook_dim")
+    if isinstance(cd, (list, tuple)):
+        if len(set(cd)) != 1:
+            raise ValueError(f"per-level codebook_dim {list(cd)} is not supported (one width for all levels)")
+        cfg["codebook_dim"] = int(cd[0])
+    for k in ("encoder_rates", "decoder_rates"):
+        if k in cfg:
+            cfg[k] = [int(r) for r in cfg[k]]
+    return cfg
+
+
+def validate_codec_state_dict(sd: dict, cfg: dict):
+    """Shape check of a codec state_dict against its kwargs before any kernel sees it: a clear error instead of a KeyError
+    deep in the packer when the file belongs to another architecture (weight-normed convs hold weight_g / weight_v)."""
+    def shape(key):
+        for k in (key + ".weight_v", key + ".weight"):
+            if k in sd:
+                return tuple(sd[k].shape)
+        raise ValueError(f"codec checkpoint has no tensor {key}.weight[_v]: not a DAC-family state_dict")
+    ed, n = int(cfg["encoder_dim"]), int(cfg["n_codebooks"])
+    if shape("encoder.block.0") != (ed, 1, 7):
+        raise ValueError(f"encoder stem is {shape('encoder.block.0')}, kwargs say encoder_dim={ed}")
+    latent = cfg["latent_dim"] or ed * 2 ** len(cfg["encoder_rates"])
+    levels = sorted({int(k.split(".")[2]) for k in sd if k.startswith("quantizer.quantizers.")})
+    if levels != list(range(n)):
+        raise ValueError(f"checkpoint holds quantizer levels {levels}, kwargs say n_codebooks={n}")
+    for i in range(n):
+        cb = tuple(sd[f"quantizer.quantizers.{i}.codebook.weight"].shape)
+        if cb != (int(cfg["codebook_size"]), int(cfg["codebook_dim"])):
+            raise ValueError(f"codebook {i} is {cb}, kwargs say ({cfg['codebook_size']}, {cfg['codebook_dim']})")
+        if shape(f"quantizer.quantizers.{i}.in_proj")[:2] != (int(cfg["codebook_dim"]), latent):
+            raise ValueError(f"quantizer {i} in_proj is {shape(f'quantizer.quantizers.{i}.in_proj')}, latent_dim should be {latent}")
+    if shape("decoder.model.0")[:2] != (int(cfg["decoder_dim"]), latent):
+        raise ValueError(f"decoder stem is {shape('decoder.model.0')}, kwargs say decoder_dim={cfg['decoder_dim']}, latent {latent}")
+
+
 class AudioSignal:
     """Minimal stand-in for audiotools.AudioSignal (not installed): samples (B, C, T) + sample_rate."""
 
@@ -223,10 +262,15 @@ class DacCodec:
         self.dec = d
 
     @classmethod
-    def load(cls, path, device="cuda:0", engine=None):
-        ckpt = torch.load(Path(path), map_location="cpu", weights_only=False)
-        kw = dict(ckpt.get("metadata", {}).get("kwargs", {}))
-        return cls(ckpt["state_dict"], {k: v for k, v in kw.items() if k in DEFAULT_CFG}, device=device, engine=engine)
+    def load(cls, path, device="cuda:0", engine=None, trusted=False):
+        """`DAC.load(Path(codec_ckpt))` (interface.py:70): audiotools dict checkpoint or torch.package archive
+        (vampnet_amd/checkpoint.py).  `metadata.kwargs` of a published DAC / lac checkpoint carries more keys than the conv
+        stacks need (`quantizer_dropout`, ...): unknown keys are dropped, `codebook_dim` may be an int or a per-level list."""
+        from .checkpoint import load_model_checkpoint
+        sd, kw = load_model_checkpoint(path, package_name="DAC", kwarg_keys=tuple(DEFAULT_CFG), trusted=trusted)
+        cfg = normalize_codec_kwargs(kw)
+        validate_codec_state_dict(sd, dict(DEFAULT_CFG, **cfg))
+        return cls(sd, cfg, device=device, engine=engine)
 
     # ---- kernels ------------------------------------------------------------------------------
     def _conv(self, x, c, *, T_in, T_rows, T_out, w=None, taps=None, in_stride=1, dil=1, pad=0, out_stride=1,

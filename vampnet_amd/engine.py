@@ -343,7 +343,7 @@ class VampNetModel:
     def generate(self, codec=None, time_steps: int = 300, _sampling_steps: int = 12, start_tokens=None,
                  temperature: float = 1.0, mask=None, mask_temperature: float = 10.5, ctrls=None, ctrl_masks=None,
                  typical_filtering=True, typical_mass=0.15, typical_min_tokens=64, top_p=None, seed: int = None,
-                 sample_cutoff: float = 1.0, return_signal=False, debug=False, causal_weight: float = 0.0,
+                 sample_cutoff: float = 1.0, return_signal=True, debug=False, causal_weight: float = 0.0,
                  cfg_scale: float = 3.0, cfg_guidance: float = None, cond=None,
                  rng: str = "torch", n0_override: int = None, device_seed: int = None,
                  global_batch: int = None, batch_offset: int = 0, noise=None, call_batch: int = None):
@@ -361,8 +361,9 @@ class VampNetModel:
         reference (transformer.py:989-993 discards the filter's result)."""
         if ctrls is not None or cfg_guidance is not None:
             raise NotImplementedError("ctrls / cfg_guidance are never used by Interface (SURVEY.md App. A.3)")
-        if return_signal:
-            raise NotImplementedError("return_signal=True: decode through Interface.decode")
+        if return_signal and not hasattr(codec, "decode_signal"):
+            raise ValueError("return_signal=True (the reference's default, transformer.py:704) decodes the sampled tokens through "
+                             "`codec` (transformer.py:943-944): pass a codec that can decode, or return_signal=False for tokens")
         if seed is not None:
             seed_all(seed)
         z = start_tokens
@@ -426,7 +427,17 @@ class VampNetModel:
             self.engine.torch_rng().store_to_torch()        # waits for the side stream only; the model keeps running
         if exp is not None:      # keep the noise alive until the enqueued work has consumed it
             torch.cuda.current_stream(self.device).synchronize()
-        return out
+        return self.decode(out, codec) if return_signal else out
+
+    @torch.inference_mode()
+    def decode(self, z, codec):
+        """VampNet.decode (transformer.py:661-684): MASK -> 0, codebook rows -> quantizer.from_latents -> codec.decode ->
+        AudioSignal at codec.sample_rate.  (The reference then looks for time steps whose codebooks are ALL the mask token to
+        silence them, but it searches the tensor it has just cleared of mask tokens — :668 vs :678-682 — so nothing is ever
+        silenced; same here.)"""
+        assert z.ndim == 3
+        z = z.masked_fill(z == self.mask_token, 0)
+        return codec.decode_signal(z)
 
     generate_batched_calls = True       # marker: generate() accepts per-item n0_override + a pre-drawn noise ledger
 

@@ -21,16 +21,26 @@ from pathlib import Path
 import torch
 
 from . import masks
+from .checkpoint import load_model_checkpoint, load_tensor_dict
 from .engine import Engine, VampNetModel
 
 
 def _load_checkpoint(path):
-    """audiotools BaseModel.load format [UNVERIFIED-DEP, SURVEY.md App. C]:
-    torch.save({"state_dict": ..., "metadata": {"kwargs": {...ctor kwargs...}}})."""
-    ckpt = torch.load(Path(path), map_location="cpu", weights_only=False)
-    if "state_dict" not in ckpt:
-        raise ValueError(f"{path}: not an audiotools-format checkpoint (no 'state_dict')")
-    return ckpt["state_dict"], dict(ckpt.get("metadata", {}).get("kwargs", {}))
+    """`VampNet.load(location=Path(ckpt), map_location="cpu", strict=False)` (interface.py:34): audiotools dict checkpoint or
+    torch.package archive -> (state_dict, constructor kwargs); formats and the trust rule in vampnet_amd/checkpoint.py."""
+    return load_model_checkpoint(path, package_name="VampNet", kwarg_keys=_MODEL_KEYS)
+
+
+def _load_lora(sd, lora_ckpt):
+    """interface.py:37-46: `model.load_state_dict(torch.load(lora_ckpt), strict=False)`.  The reference asks on stdin
+    whether to go on when the file is missing; a service cannot — VN_LORA_MISSING_OK=1 answers "y", anything else aborts
+    with the reference's exception text."""
+    if not Path(lora_ckpt).exists():
+        import os
+        if os.environ.get("VN_LORA_MISSING_OK") == "1":
+            return
+        raise Exception(f"lora checkpoint {lora_ckpt} does not exist. aborting")
+    sd.update(load_tensor_dict(lora_ckpt))
 
 
 _MODEL_KEYS = ("n_heads", "n_layers", "n_codebooks", "n_conditioning_codebooks", "latent_dim", "embedding_dim",
@@ -91,12 +101,12 @@ class Interface:
             codec = DacCodec.load(codec_ckpt, device=device)
         csd, ckw = _load_checkpoint(coarse_ckpt)
         if coarse_lora_ckpt is not None:
-            csd.update(torch.load(coarse_lora_ckpt, map_location="cpu"))          # interface.py:45, strict=False
+            _load_lora(csd, coarse_lora_ckpt)
         fsd = fkw = None
         if coarse2fine_ckpt is not None:
             fsd, fkw = _load_checkpoint(coarse2fine_ckpt)
             if coarse2fine_lora_ckpt is not None:
-                fsd.update(torch.load(coarse2fine_lora_ckpt, map_location="cpu"))
+                _load_lora(fsd, coarse2fine_lora_ckpt)
         self._init(codec, csd, ckw, fsd, fkw, device, coarse_chunk_size_s, coarse2fine_chunk_size_s, max_batch, rng,
                    process_group, precision)
         self.coarse_path = Path(coarse_ckpt)
@@ -136,8 +146,11 @@ class Interface:
         self._codebooks = _codec_codebooks(codec)
         self.coarse = self._make_model(csd, ckw, coarse_chunk_s)
         # the coarse-to-fine chunks of one coarse chunk are batched into one launch: size its workspace for them
-        per_coarse = math.ceil(self.s2t(coarse_chunk_s) / self.s2t(c2f_chunk_s)) if fsd is not None else 1
-        self.c2f = self._make_model(fsd, fkw, c2f_chunk_s, max_batch * per_coarse) if fsd is not None else None
+        self.c2f = self._make_model(fsd, fkw, c2f_chunk_s, self._c2f_max_batch(coarse_chunk_s, c2f_chunk_s)) if fsd is not None else None
+
+    def _c2f_max_batch(self, coarse_chunk_s, c2f_chunk_s):
+        """workspace rows of the c2f model: every coarse-to-fine chunk of one coarse chunk, for every item, in one launch"""
+        return self.max_batch * math.ceil(self.s2t(coarse_chunk_s) / self.s2t(c2f_chunk_s))
 
     def _make_model(self, sd, kw, chunk_s, max_batch=None):
         kwargs = dict(_DEFAULT_KW)
@@ -183,7 +196,8 @@ class Interface:
             self.coarse_path = Path(coarse_ckpt)
         if c2f_ckpt is not None and self.c2f_path != Path(c2f_ckpt):
             sd, kw = _load_checkpoint(c2f_ckpt)
-            self.c2f = self._make_model(sd, kw, self.c2f.chunk_size_s if self.c2f is not None else 3)
+            chunk_s = self.c2f.chunk_size_s if self.c2f is not None else 3
+            self.c2f = self._make_model(sd, kw, chunk_s, self._c2f_max_batch(self.coarse.chunk_size_s, chunk_s))
             self.c2f_path = Path(c2f_ckpt)
 
     # ---- unit conversion (interface.py:176-189) -------------------------------------------------

@@ -57,14 +57,20 @@ class Trainer:
         self.n_total = n.value
         host = torch.zeros(self.n_total, dtype=torch.float32)
         self.only_lora = only_lora
-        self._sd_template = {k: (tuple(t.shape), t.dtype) for k, t in sd.items()}
-        if only_lora:        # adapters that the checkpoint does not hold yet still get optimiser slots, in model order
-            for l in range(n_layers):
-                for key in LORA_KEYS:
-                    name = f"transformer.layers.{l}.{key}"
-                    n_out, n_in = sd[name + ".weight"].shape
-                    self._sd_template.setdefault(name + ".lora_A", ((LORA_R, n_in), torch.float32))
-                    self._sd_template.setdefault(name + ".lora_B", ((n_out, LORA_R), torch.float32))
+        # parameter order of the reference model (= model.parameters() = what its AdamW indexes): state_dict order, with the
+        # loralib adapters right behind their Linear's weight (lora.Linear registers weight, lora_A, lora_B:
+        # transformer.py:67-68,109-114) — inserted here when the checkpoint does not hold them yet (LoRA mode only)
+        self._sd_template = {}
+        lora_parents = {f"transformer.layers.{l}.{key}.weight" for l in range(n_layers) for key in LORA_KEYS}
+        for k, t in sd.items():
+            self._sd_template[k] = (tuple(t.shape), t.dtype)
+            if only_lora and k in lora_parents:
+                name = k[:-len(".weight")]
+                n_out, n_in = t.shape
+                if name + ".lora_A" not in sd:
+                    self._sd_template[name + ".lora_A"] = ((LORA_R, n_in), torch.float32)
+                if name + ".lora_B" not in sd:
+                    self._sd_template[name + ".lora_B"] = ((n_out, LORA_R), torch.float32)
         blob = pack_weights(self.lib, self.dims, sd, codebooks, merge_lora=not only_lora)
         self.wsize = blob.numel()
         host[:self.wsize] = blob
@@ -288,47 +294,81 @@ class Trainer:
         return out
 
     # ---- checkpoint / resume (train.py:380-420 checkpoint(), :560-600 load) -------------------------
+    def _all_param_names(self):
+        """every parameter of the reference model in model.parameters() order (adapters included)"""
+        return [k for k in self._sd_template if not k.endswith("num_batches_tracked")]
+
     def _param_names(self):
-        names = [k for k in self._sd_template if not k.endswith("num_batches_tracked")]
+        """the parameters THIS trainer updates: the adapters in LoRA mode, everything else in full mode (adapters a
+        checkpoint holds are merged into their weights at load — DESIGN.md section 7 — and have no moments here)"""
+        names = self._all_param_names()
         return [k for k in names if "lora_" in k] if self.only_lora else [k for k in names if "lora_" not in k]
 
     def optimizer_state_dict(self) -> dict:
-        """torch.optim.AdamW.state_dict() layout (parameter index = position in the state_dict order the Trainer was
-        built from = model.parameters() order for a reference checkpoint), so the reference can resume from it."""
+        """torch.optim.AdamW.state_dict() layout.  Parameter index = position in the reference model's parameters()
+        (train.py:588-590 builds AdamW over ALL of them, adapters and frozen weights included), so indices line up with a
+        reference optimizer.pth whatever subset carries state: LoRA mode writes state for the adapters only (what the
+        reference has after mark_only_lora_as_trainable), full mode for every non-adapter parameter.  `lr` is what the
+        reference's param group holds after N steps: NoamScheduler has already stepped to N + 1 (train.py:596)."""
         exp = self.export_lora if self.only_lora else self.export
         m, v = exp(self.adam_m), exp(self.adam_v)
-        names = self._param_names()
+        index = {k: i for i, k in enumerate(self._all_param_names())}
         state = {}
         if self.steps > 0:
-            for i, k in enumerate(names):
+            for k in self._param_names():
                 shp = self._sd_template[k][0]
-                state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": m[k].reshape(shp).clone(),
-                            "exp_avg_sq": v[k].reshape(shp).clone()}
+                state[index[k]] = {"step": torch.tensor(float(self.steps)), "exp_avg": m[k].reshape(shp).clone(),
+                                   "exp_avg_sq": v[k].reshape(shp).clone()}
         hp = self.hp
-        group = {"lr": getattr(self, "last_lr", hp["lr"]), "betas": (hp["beta1"], hp["beta2"]), "eps": hp["eps"],
+        lr = noam_lr(self.steps + 1, self.D, *self.noam) if self.noam else hp["lr"]
+        group = {"lr": lr, "betas": (hp["beta1"], hp["beta2"]), "eps": hp["eps"],
                  "weight_decay": hp["weight_decay"], "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
-                 "differentiable": False, "fused": None, "params": list(range(len(names)))}
+                 "differentiable": False, "fused": None, "params": list(range(len(index)))}
         return {"state": state, "param_groups": [group]}
 
     def load_optimizer_state_dict(self, osd: dict):
-        names = self._param_names()
+        """Moments + step count from an AdamW state_dict indexed like optimizer_state_dict() (ours or the reference's).
+        Raises when the file was written for a different parameter list; entries for parameters this trainer does not
+        update (adapters in full mode: merged at load) are ignored, missing ones start from zero moments."""
+        allnames = self._all_param_names()
+        index = {k: i for i, k in enumerate(allnames)}
+        groups = osd.get("param_groups", [])
+        n_file = sum(len(g["params"]) for g in groups)
+        if groups and n_file != len(allnames):
+            raise ValueError(f"optimizer state indexes {n_file} parameters, this model has {len(allnames)} "
+                             f"({sum('lora_' in k for k in allnames)} of them loralib adapters): it was written for another "
+                             "architecture / adapter set")
         st = osd.get("state", {})
         if not st:
             self.adam_m.zero_(); self.adam_v.zero_()
             return
-        m = {k: st[i]["exp_avg"] for i, k in enumerate(names)}
-        v = {k: st[i]["exp_avg_sq"] for i, k in enumerate(names)}
+        names = self._param_names()
+        have = [k for k in names if index[k] in st]
+        if not have:
+            raise ValueError("optimizer state holds no entry for any parameter this trainer updates "
+                             f"({'LoRA adapters' if self.only_lora else 'base weights'})")
+        for k in have:
+            if tuple(st[index[k]]["exp_avg"].shape) != tuple(self._sd_template[k][0]):
+                raise ValueError(f"optimizer state entry {index[k]} has shape {tuple(st[index[k]]['exp_avg'].shape)}, "
+                                 f"parameter {k} is {tuple(self._sd_template[k][0])}")
+        zeros = lambda k: torch.zeros(self._sd_template[k][0])
+        m = {k: (st[index[k]]["exp_avg"] if index[k] in st else zeros(k)) for k in names}
+        v = {k: (st[index[k]]["exp_avg_sq"] if index[k] in st else zeros(k)) for k in names}
         if self.only_lora:
             self.adam_m.copy_(self.pack_lora(m, init_missing=False))
             self.adam_v.copy_(self.pack_lora(v, init_missing=False))
         else:
             self.adam_m.copy_(self.pack(m)); self.adam_v.copy_(self.pack(v))
-        self.steps = int(float(st[0]["step"]))
+        self.steps = int(float(st[index[have[0]]]["step"]))
 
     def scheduler_state_dict(self) -> dict:
-        """vampnet/scheduler.py:30-33: every attribute of NoamScheduler except the optimizer."""
+        """vampnet/scheduler.py:30-33: every attribute of NoamScheduler except the optimizer.  The reference steps its
+        scheduler once at construction (train.py:596) and once after every optimizer step, so after N updates it holds
+        steps = N + 1 and lr = lr(N + 1) — the rate the NEXT update will use."""
         f, w = self.noam if self.noam else (None, None)
-        return {"warmup": w, "factor": f, "d_model": self.D, "lr": getattr(self, "last_lr", None), "steps": self.steps}
+        nxt = self.steps + 1
+        return {"warmup": w, "factor": f, "d_model": self.D, "lr": noam_lr(nxt, self.D, f, w) if self.noam else None,
+                "steps": nxt}
 
     def save_checkpoint(self, save_path: str, tag: str = "latest", fine_tune: bool = None, extra: dict = None) -> str:
         """Writes what train.py:380-420 writes for one tag: <save_path>/<tag>/vampnet/weights.pth in the audiotools
@@ -353,18 +393,18 @@ class Trainer:
         """Resume: parameters (+ adapters), Adam moments and the step counter from a folder written by save_checkpoint (or by
         the reference's checkpoint() for the same architecture)."""
         import os
-        ck = torch.load(os.path.join(folder, "vampnet", "weights.pth"), map_location="cpu")
-        sd = ck["state_dict"]
+        from .checkpoint import load_model_checkpoint, load_tensor_dict
+        sd, _ = load_model_checkpoint(os.path.join(folder, "vampnet", "weights.pth"))
         lp = os.path.join(folder, "lora.pth")
         if os.path.exists(lp):
-            sd = {**sd, **torch.load(lp, map_location="cpu")}
+            sd = {**sd, **load_tensor_dict(lp)}
         self.load_state_dict(sd)
         op = os.path.join(folder, "optimizer.pth")
         if os.path.exists(op):
-            self.load_optimizer_state_dict(torch.load(op, map_location="cpu"))
+            self.load_optimizer_state_dict(load_tensor_dict(op))
         sp = os.path.join(folder, "scheduler.pth")
-        if os.path.exists(sp):
-            self.steps = int(torch.load(sp, map_location="cpu").get("steps", self.steps))
+        if os.path.exists(sp) and not os.path.exists(op):      # the optimizer state is authoritative; scheduler steps = N + 1
+            self.steps = max(int(load_tensor_dict(sp).get("steps", self.steps + 1)) - 1, 0)
 
     def load_state_dict(self, sd: dict):
         """Replace the parameters (full mode: everything; LoRA mode: the adapters — the frozen base is what the Trainer was
