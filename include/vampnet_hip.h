@@ -362,9 +362,10 @@ int vn_debug_graph_replays(const vn_model* model, int64_t* count);
 /* tuning hook (scripts/gemm_sweep.py): force the GEMM block tile (bm x bn in {128,64}^2; 0,0 = automatic) and the
  * tile walk order (0 column-major, 1 grouped 8-row patches, -1 keep).  Process-global; not for production use.   */
 int vn_debug_gemm_config(int bm, int bn, int order);
-/* same for the bf16x3 GEMM (gemm_x3.hip): pipe 3 = lock-step 128 x 128, 4 = ping-pong 128 x 128, 5 = ping-pong 256 x 128
- * (-1 = VN_X3_PIPE / default); splitk 0/1 off, 2/4 forced, -1 = cost model; abl = ablation bits (tuning; results invalid) */
-int vn_debug_x3_config(int pipe, int splitk, int abl);
+/* same for the bf16x3 GEMM (gemm_x3.hip): bm = tile height 128 / 256 (0 = VN_X3_BM / default); stream_k 1 / 0 = stream-K or
+ * data-parallel work distribution (-1 = VN_X3_SK / default 1); splitk (data-parallel form only) 0/1 off, 2/4 forced, -1 =
+ * cost model; abl = ablation bits (tuning; results invalid), -1 = none                                                    */
+int vn_debug_x3_config(int bm, int stream_k, int splitk, int abl);
 
 #ifdef __cplusplus
 }

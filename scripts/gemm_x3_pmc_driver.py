@@ -1,5 +1,5 @@
 """Kernel-only driver for rocprofv3 --pmc runs of the bf16x3 GEMM: the model's B = 8 shapes + 4096^3, schedule from
-VN_X3_PIPE (3 / 4 / 5), split-K as in production.  Three launches per shape."""
+VN_X3_BM (128 / 256) and VN_X3_SK (1 stream-K, 0 data-parallel).  Three launches per shape."""
 import os
 import sys
 

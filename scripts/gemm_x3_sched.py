@@ -1,6 +1,6 @@
-"""bf16x3 GEMM schedules (vn_debug_x3_config: 3 lock-step 128x128, 4 ping-pong 128x128, 5 ping-pong 256x128) on the model's
-shapes, interleaved rounds in ONE process (median of ROUNDS), real split planes of N(0,1) operands.  TF-eq = 2MNK / t
-(fp32-equivalent); the matrix pipe executes 6x that.  Second table: ablations of the ping-pong kernels (results invalid)."""
+"""bf16x3 GEMM: tile height (128 / 256) x work distribution (stream-K / data-parallel + split-K) on the model's shapes,
+interleaved rounds in ONE process (median of ROUNDS), real split planes of N(0,1) operands.  TF-eq = 2MNK / t
+(fp32-equivalent); the matrix pipe executes 6x that.  Second table: ablations of the kernels (results invalid)."""
 import statistics
 import sys
 
@@ -16,7 +16,7 @@ SHAPES = [("qkv B8", 4600, 3840, 1280, _lib.EPI_STORE), ("wo  B8", 4600, 1280, 1
           ("cls B8", 4600, 4096, 1280, _lib.EPI_BIAS), ("qkv c2f", 1384, 3840, 1280, _lib.EPI_STORE),
           ("w2  c2f", 1384, 1280, 2560, _lib.EPI_RESIDUAL), ("qkv B1", 575, 3840, 1280, _lib.EPI_STORE),
           ("sq 4096", 4096, 4096, 4096, _lib.EPI_STORE), ("sq 8192", 8192, 8192, 8192, _lib.EPI_STORE)]
-PIPES = [3, 4, 5]
+PIPES = [(128, 1), (256, 1), (128, 0), (256, 0)]
 ROUNDS = 5
 
 
@@ -32,11 +32,15 @@ def timeit(fn, n=10):
     return a.elapsed_time(b) / n * 1e-3
 
 
-def cfg(pipe, split=-1, abl=-1):
-    eng.check(eng.lib.vn_debug_x3_config(pipe, split, abl), "vn_debug_x3_config")
+def cfg(p=(0, -1), split=-1, abl=-1):
+    eng.check(eng.lib.vn_debug_x3_config(p[0], p[1], split, abl), "vn_debug_x3_config")
 
 
-print(f"{'shape':10s} " + " ".join(f"{'pipe' + str(p) + ' us':>10s} {'TF-eq':>6s} {'%pipe':>6s}" for p in PIPES))
+def name_of(p):
+    return ("sk" if p[1] else "dp") + str(p[0])
+
+
+print(f"{'shape':10s} " + " ".join(f"{name_of(p) + ' us':>10s} {'TF-eq':>6s} {'%pipe':>6s}" for p in PIPES))
 for name, M, N, K, epi in SHAPES:
     g = torch.Generator(device="cuda").manual_seed(0)
     a = torch.randn(M, K, device="cuda", generator=g)
@@ -57,17 +61,18 @@ for name, M, N, K, epi in SHAPES:
     print(row, flush=True)
     del a, w, a3, w3, out
 
-print("\nablations (store epilogue, no split-K): abl 0 = shipped, 1 = no DMA in the k-loop, 2 = no fragment reads, 3 = MFMA + barriers only")
+print("\nablations (store epilogue, data-parallel form): abl 0 = shipped, 1 = no DMA in the k-loop, 2 = no fragment reads, 3 = MFMA + barriers only, "
+      "4 = DMA of whole 128-B lines (8 rows per instruction, same volume)")
 for name, M, N, K in [("qkv B8", 4600, 3840, 1280), ("sq 4096", 4096, 4096, 4096)]:
     g = torch.Generator(device="cuda").manual_seed(0)
     a3 = eng.split3(torch.randn(M, K, device="cuda", generator=g))
     w3 = eng.split3(torch.randn(N, K, device="cuda", generator=g) / K ** 0.5)
     out = torch.zeros(M, N, device="cuda")
-    for p in (4, 5):
-        row = f"{name:8s} pipe {p}: "
-        for abl in (0, 1, 2, 3):
+    for p in ((128, 0), (256, 0)):
+        row = f"{name:8s} {name_of(p)}: "
+        for abl in (0, 1, 2, 3, 4):
             cfg(p, 1, abl)
             t = statistics.median(timeit(lambda: eng.gemm_bf16x3(a3, w3, out=out)) for _ in range(3))
             row += f"abl{abl} {2.0 * M * N * K / t / 1e12:6.1f} TF-eq ({6 * 2.0 * M * N * K / t / 2.5e15:5.1%})  "
         print(row, flush=True)
-cfg(-1)
+cfg()

@@ -313,12 +313,19 @@ def test_split3_is_exact(eng):
     assert torch.equal(p[0], x.to(torch.bfloat16).float())          # plane 0 = RNE bf16 of x (== torch's cast)
 
 
-@pytest.fixture(params=[4, 5, 3], ids=["pingpong128", "pingpong256", "lockstep128"])
+X3_CONFIGS = [(128, 1), (256, 1), (128, 0), (256, 0)]
+
+
+def _x3_cfg(eng, bm=0, sk=-1, split=-1, abl=-1):
+    eng.check(eng.lib.vn_debug_x3_config(bm, sk, split, abl), "vn_debug_x3_config")
+
+
+@pytest.fixture(params=X3_CONFIGS, ids=["sk128", "sk256", "dp128", "dp256"])
 def x3_pipe(eng, request):
-    """every schedule of gemm_x3.hip through the same bodies (process-global tuning hook; reset afterwards)"""
-    eng.check(eng.lib.vn_debug_x3_config(request.param, -1, -1), "vn_debug_x3_config")
+    """every tile height x work distribution of gemm_x3.hip through the same bodies (process-global tuning hook; reset afterwards)"""
+    _x3_cfg(eng, *request.param)
     yield request.param
-    eng.check(eng.lib.vn_debug_x3_config(-1, -1, -1), "vn_debug_x3_config")
+    _x3_cfg(eng)
 
 
 @pytest.mark.parametrize("M,N,K", [(4600, 3840, 1280), (575, 1280, 2560), (130, 256, 64), (1384, 5120, 1280), (1, 128, 32),
@@ -326,7 +333,8 @@ def x3_pipe(eng, request):
 def test_gemm_bf16x3_fp32_grade(eng, x3_pipe, M, N, K):
     """Six bf16 MFMA products of exact operand splits == an fp32 GEMM: SAME tolerance as test_gemm_store_bias_residual
     (fp32 accumulation-order class against the float64 product of the fp32 operands).  K = 32 / 64 / 96 / 160 cover the
-    one-, two-, three- and odd-tile pipelines of the ping-pong schedules."""
+    one-, two-, three- and odd-tile pipelines of the ping-pong schedules; (4600, 3840, 1280) and (575, 1280, 2560) give
+    every stream-K block two shared tiles, (1, 128, 32) a single unit, (130, 256, 64) fewer units than CUs."""
     from vampnet_amd import _lib
     a, w, b = _rand((M, K), 3), _rand((N, K), 4) / np.sqrt(K), _rand((N,), 5)
     ref64 = a.double() @ w.double().t()
@@ -346,25 +354,32 @@ def test_gemm_bf16x3_fp32_grade(eng, x3_pipe, M, N, K):
     assert np.all(np.abs((out.cpu().double() - (ref64 + c0.double())).numpy()) <= tol)
 
 
-def test_gemm_bf16x3_schedules_agree_bitwise_and_are_race_free(eng):
-    """All three schedules add the same products in the same order: bitwise-equal outputs; and 20 back-to-back launches
-    of the ping-pong kernels under a concurrently streaming kernel reproduce the same bits (LDS-DMA / barrier protocol)."""
+def test_gemm_bf16x3_schedules_agree_and_are_race_free(eng):
+    """The data-parallel kernels (tile height 128 / 256) add the same products in the same order: bitwise-equal outputs.
+    Stream-K adds a shared tile's k-ranges as separate partial sums (fp32 re-association: ~1e-6 relative) in a fixed order:
+    run-to-run bitwise.  20 back-to-back launches of each form under a concurrently streaming kernel reproduce the same
+    bits (LDS-DMA / barrier protocol, slab hand-over between the two passes)."""
     M, N, K = 4600, 3840, 1280
     a3, w3 = eng.split3(_rand((M, K), 13).cuda()), eng.split3((_rand((N, K), 14) / np.sqrt(K)).cuda())
     outs = {}
     junk = torch.empty(64 << 20, device="cuda")
     side = torch.cuda.Stream()
-    for pipe in (3, 4, 5):
-        eng.check(eng.lib.vn_debug_x3_config(pipe, 1, -1), "vn_debug_x3_config")
-        outs[pipe] = eng.gemm_bf16x3(a3, w3).clone()
+    for cfg in X3_CONFIGS:
+        _x3_cfg(eng, cfg[0], cfg[1], 1)
+        outs[cfg] = eng.gemm_bf16x3(a3, w3).clone()
         for it in range(20):
             with torch.cuda.stream(side):
                 junk.add_(1.0)                                       # uneven memory load on the other stream
             again = eng.gemm_bf16x3(a3, w3)
-            assert torch.equal(again, outs[pipe]), (pipe, it)
-    eng.check(eng.lib.vn_debug_x3_config(-1, -1, -1), "vn_debug_x3_config")
+            assert torch.equal(again, outs[cfg]), (cfg, it)
+    _x3_cfg(eng)
     torch.cuda.synchronize()
-    assert torch.equal(outs[3], outs[4]) and torch.equal(outs[3], outs[5])
+    assert torch.equal(outs[(128, 0)], outs[(256, 0)])
+    scale = outs[(128, 0)].abs().max().item()
+    for cfg in ((128, 1), (256, 1)):
+        d = (outs[cfg] - outs[(128, 0)]).abs().max().item()
+        print(f"stream-K {cfg} vs data-parallel: max |d| = {d:.3e} (|C| max {scale:.2f})")
+        assert 0 < d <= 2e-5 * scale          # really a different summation order, and only that
 
 
 def test_gemm_bf16x3_identity_and_geglu(eng, x3_pipe):

@@ -509,3 +509,66 @@ def test_split_plane_gemm_lds_addressing():
 
     assert check(1, 3) == (48 * 1024, 6)          # gemm_x3.hip, 128 x 128
     assert check(2, 3) == (72 * 1024, 9)          # gemm_x3.hip, 256 x 128 (ping-pong)
+
+
+def test_stream_k_partition_and_fixup_slab_map():
+    """Model of gemm_x3.hip's stream-K work distribution: G blocks cut the tile x k-tile unit space into contiguous ranges
+    [U lb / G, U (lb + 1) / G).  Replays the kernel's segment walk (which segment is finished in place, which goes to slab
+    2 lb or 2 lb + 1) and the fix-up kernel's search (which slabs a tile adds, in which order) for many shapes: every unit is
+    multiplied exactly once, a tile is either finished in pass 1 or rebuilt in pass 2 from exactly the slabs pass 1 wrote
+    for it, in ascending k order, and no slab is written twice."""
+    def unit0(U, lb, G):
+        return U * lb // G
+
+    def check(ntiles, nk, cus):
+        U = ntiles * nk
+        G = min(U, cus)
+        done_in_pass1, slab_of = set(), {}                  # slab index -> (tile, kb, ke)
+        covered = [0] * U
+        for lb in range(G):
+            u, u_end = unit0(U, lb, G), unit0(U, lb + 1, G)
+            assert u_end > u
+            u_first = u
+            while u < u_end:
+                t = u // nk
+                kb = u - t * nk
+                ke = kb + (u_end - u) if (u_end - u) < (nk - kb) else nk
+                for x in range(t * nk + kb, t * nk + ke):
+                    covered[x] += 1
+                if kb == 0 and ke == nk:
+                    done_in_pass1.add(t)
+                else:
+                    idx = 2 * lb + (1 if u != u_first else 0)
+                    assert idx not in slab_of
+                    slab_of[idx] = (t, kb, ke)
+                u += ke - kb
+        assert covered == [1] * U
+        launch_fixup = U % G != 0 or (U // G) % nk != 0
+        assert launch_fixup or not slab_of
+        for t in range(ntiles):
+            t0, t1 = t * nk, (t + 1) * nk
+            lb = t0 * G // U
+            while lb > 0 and unit0(U, lb, G) > t0:
+                lb -= 1
+            while lb + 1 < G and unit0(U, lb + 1, G) <= t0:
+                lb += 1
+            if unit0(U, lb + 1, G) >= t1:
+                assert t in done_in_pass1
+                continue
+            assert t not in done_in_pass1
+            got = []
+            while lb < G:
+                b0, b1 = unit0(U, lb, G), unit0(U, lb + 1, G)
+                if b0 >= t1:
+                    break
+                s0 = max(b0, t0)
+                got.append(slab_of.pop(2 * lb + (1 if s0 != b0 else 0)))
+                lb += 1
+            assert [g[0] for g in got] == [t] * len(got) and len(got) >= 2
+            assert got[0][1] == 0 and got[-1][2] == nk and all(a[2] == b[1] for a, b in zip(got, got[1:]))
+        assert not slab_of                                  # every slab written in pass 1 was consumed exactly once
+
+    for ntiles, nk in [(1080, 40), (360, 40), (360, 80), (2880, 40), (1152, 40), (540, 40), (150, 40), (50, 80), (1, 1), (2, 2),
+                       (4, 1), (1, 3), (6, 5), (256, 40), (512, 40), (257, 3), (1024, 128)]:
+        for cus in (256, 304, 8):
+            check(ntiles, nk, cus)

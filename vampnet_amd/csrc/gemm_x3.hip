@@ -10,32 +10,36 @@
 // cores run bf16 at 16x the fp32-input MFMA rate (MI355X_MICROARCH.md: 2.5 PF vs 157 TF dense), so six passes cost
 // 6/16 of the exact-fp32 kernel's matrix time: the ceiling moves from 157 to ~417 fp32-equivalent TFLOP/s.
 //
-// Kernel: one 512-thread block (8 waves as 4 x 2, wave tile 32 x 64) per 128 x 128 output tile, one block per CU (two
-// waves per SIMD cover each other's LDS latency and barriers).
-//   * k-tile = 32 bf16 = 64 bytes per row.  A stage holds the six plane tiles (3 x 128 rows of A, 3 x 128 of W) = 48 KiB,
-//     double-buffered = 96 KiB of LDS, filled by LDS-DMA (global_load_lds_dwordx4: one wave instruction = 16 rows x 64 B).
+// Kernel: one 512-thread block (8 waves as 4 x 2) per output tile of 128 MI x 128 (MI = 1, 2; wave tile 32 MI x 64), one
+// block per CU, two waves per SIMD.
+//   * k-tile = 32 bf16 = 64 bytes per row.  A stage holds the six plane tiles (3 x 128 MI rows of A, 3 x 128 of W) = 48 / 72
+//     KiB, filled by LDS-DMA (global_load_lds_dwordx4: one wave instruction = 16 rows x 64 B); three (MI = 1) or two
+//     (MI = 2) stages are resident.
 //   * Loading each plane tile ONCE and using it in two or three of the six products is what separates this kernel
 //     from running a K' = 6K bf16 GEMM over concatenated planes: 6 plane-tile loads per 6 MFMA groups instead of 12.
-//     Per k-tile and CU: 48 KiB of DMA and 144 KiB of fragment reads against 1536 matrix-pipe cycles per SIMD
-//     (32 B/clk and 94 B/clk; the LDS moves 256 B/clk for ds_read_b128).
 //   * LDS image is lane-linear (DMA constraint), so the bank swizzle sits on the SOURCE address: 16-byte slot s of row r
 //     is stored at slot s ^ ((r >> 2) & 3).  A ds_read_b128 is serviced in 16-lane groups whose rows are
 //     {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (+32): with 64-byte rows the four rows that share r % 4 (hence a
-//     256-byte bank-row quarter) have four different (r >> 2) & 3, so every group touches 16 distinct slots.
+//     256-byte bank-row quarter) have four different (r >> 2) & 3, so every group touches 16 distinct slots
+//     (SQ_LDS_BANK_CONFLICT = 0, profiles/r02_pmc_gemm_x3_pipe4.txt).
 //   * Fragment of v_mfma_f32_32x32x16_bf16: lane l holds row l & 31, k = 8 (l >> 5) .. + 7 of the 16-wide step, i.e.
 //     slot 2 s + (l >> 5) of the row for sub-step s in {0, 1}.
+//   * "Ping-pong" schedule: the eight waves form two groups (waves 0-3 / 4-7: one wave of each group on every SIMD) that
+//     run the same step sequence ONE PHASE APART — while a group issues the 12 MI MFMAs of a k-step (s_setprio 1) the other
+//     reads its next fragments and issues LDS-DMA; two raw s_barriers per k-step keep the alternation, counted vmcnt keeps
+//     the DMA in flight across them (guide section 5, 8-phase template).  Round-1's lock-step schedule ran 7-12 % slower
+//     (profiles/r02_gemm_x3_schedules.txt).
 //   * Epilogues as in gemm_f32.hip (store / bias / residual / GEGLU gate / QKV head-major scatter); the GEGLU result is
 //     written as three planes again (it is only ever the A operand of the next GEMM).
 //   * rows >= M and columns >= N are clamped on load and masked on store.
-//   * schedule (PIPE 3, default): fragments of the next k-step are read into a second register set behind the first two
-//     MFMAs of the current one, ONE barrier per k-tile sits between its two k-steps, the six DMA pieces of tile kt + 2 are
-//     issued one per MFMA pair after it.  PIPE 1 issues them back to back; PIPE 0 / 2 and the ABL ablations are tuning
-//     variants of the store epilogue (profiles/r01_gemm_x3_ablations.txt: the kernel is bound by the DMA volume).
-// Data-parallel tile walk, XCD-aware (same remap and 8-row grouping as gemm_f32.hip).  Shapes whose 128 x 128 tiles fill
-// 256 CUs badly (the N = 1280 projections: 360 tiles at B = 8, 110 / 50 for c2f / one sequence) are split along K in two
-// passes: gridDim.y splits store raw images to a workspace, vn_splitk_reduce_kernel adds them in fixed order and applies
-// the residual.  Deterministic in both forms.  On the GPU the result is within 7.5e-6 of float64 at 4600 x 3840 x 1280
-// (the fp32-input MFMA kernel: 9e-6; both accumulate K = 1280 sequentially in fp32).
+// Work distribution: "stream-K" (default).  The launch is one persistent block per CU; the tile x k-tile space, walked
+// tile after tile in an XCD-aware order (8-row tile groups, one contiguous eighth of the walk per XCD), is cut into 256
+// EQUAL contiguous ranges.  A block whose range covers a whole tile finishes it with the fused epilogue; the at most two
+// tiles it shares with its neighbours are stored as raw fp32 accumulator images ("slabs", fragment order, 16-byte
+// coalesced) and vn_gemm_x3_fixup_kernel adds a tile's slabs in k order and runs the same epilogue — deterministic, no
+// flags, no atomics.  This removes the round quantisation of a data-parallel launch (1080 tiles on 256 CUs = 5 rounds for
+// 4.2 rounds of work).  The data-parallel form (one block per tile) is kept for A/B runs (vn_debug_x3_config).
+// On the GPU the result is within 7.5e-6 of float64 at 4600 x 3840 x 1280 (the fp32-input MFMA kernel: 9e-6).
 #include <stdlib.h>
 #include "vn_common.h"
 
@@ -81,155 +85,195 @@ __device__ __forceinline__ void x3_tile_coords(int t, int tiles_m, int tiles_n, 
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
 
-// PIPE 3: lock-step schedule of round 1 (128 x 128 only): register-prefetched fragments, one barrier per k-tile, DMA pieces
-//         spread over the MFMA pairs, two LDS buffers.
-// PIPE 4: "ping-pong".  The eight waves form two groups (waves 0-3 / 4-7: one wave of each group on every SIMD) that run
-//         the same step sequence ONE PHASE APART: while a group issues the 12 MI MFMAs of a k-step (s_setprio 1), the other
-//         reads its next fragments and issues LDS-DMA; two s_barriers per k-step keep the alternation.  Counted vmcnt,
-//         raw s_barrier: DMA stays in flight across barriers.  MI = 1: three LDS buffers (tile kt + 2 is issued in the two
-//         load phases of tile kt, waited for a tile later); MI = 2 (256 x 128): two buffers of 72 KiB (tile kt + 1 is
-//         issued in the first load phase and between the MFMAs of the first compute phase of tile kt).
-// ABL (tuning only, results invalid): bit 0 = no DMA inside the k-loop, bit 1 = no fragment reads inside the k-loop
-template <int EPI, int PIPE, int MI, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int tiles_m, int tiles_n) {
-    using G = x3_geo<MI>;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    int tm, tn;
-    x3_tile_coords(x3_xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * G::BM, n0 = tn * X3_BN;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const uint16_t* A16 = (const uint16_t*)p.A;
-    const uint16_t* W16 = (const uint16_t*)p.W;
-    // split-K (gridDim.y > 1, store epilogue only): split sp multiplies k-tiles [kb, ke) into its own image of C
-    const int nk_all = p.K / X3_KT;
-    const int kb = (int)((long)nk_all * blockIdx.y / gridDim.y), ke = (int)((long)nk_all * (blockIdx.y + 1) / gridDim.y);
-    if (gridDim.y > 1) p.C += (size_t)blockIdx.y * p.M * p.N;
-
-    // per-lane DMA sources: instruction q = wave * NPW + j fills 16 rows of one plane tile (A: q < 24 MI, plane q / (8 MI))
-    const uint16_t* src[G::NPW];
-    const int drow = lane >> 2, dslot = (lane & 3) ^ ((lane >> 4) & 3);     // (row >> 2) & 3 == (lane >> 4) & 3
+// epilogue of one output tile from the accumulators in MFMA layout (shared by the GEMM kernel and the stream-K fix-up).
+// C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+template <int EPI, int MI>
+__device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 (&acc)[MI][2], int m0, int n0, int wm, int wn,
+                                            int lane) {
+    const int l31 = lane & 31, h = lane >> 5;
+    const int colw = n0 + wn * 64 + l31;
 #pragma unroll
-    for (int j = 0; j < G::NPW; ++j) {
-        const int q = wave * G::NPW + j;
-        if (q < 24 * MI) {
-            const int pt = q / (8 * MI), row = (q % (8 * MI)) * 16 + drow;
-            int g = m0 + row;
-            g = g < p.M ? g : p.M - 1;
-            src[j] = A16 + (size_t)pt * p.a_plane + (size_t)g * p.K + dslot * 8 + kb * X3_KT;
-        } else {
-            const int qb = q - 24 * MI;
-            const int pt = qb >> 3, row = (qb & 7) * 16 + drow;
-            int g = n0 + row;
-            g = g < p.N ? g : p.N - 1;
-            src[j] = W16 + (size_t)pt * p.w_plane + (size_t)g * p.K + dslot * 8 + kb * X3_KT;
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row >= p.M) continue;
+            if constexpr (EPI == VN_EPI_GEGLU) {
+                // wave tile = 64 packed columns = 32 value (j = 0) + 32 gate (j = 1), interleaved at pack time
+                const int ocol = (n0 + wn * 64) / 2 + l31;
+                if (2 * ocol >= p.N) continue;
+                const float o = acc[i][0][r] * vn_gelu_tanh(acc[i][1][r]);
+                if (p.C16) {
+                    uint16_t t0, t1, t2;
+                    vn_split3(o, t0, t1, t2);
+                    uint16_t* d = p.C16 + (size_t)row * p.ldc + ocol;
+                    d[0] = t0; d[p.c_plane] = t1; d[2 * p.c_plane] = t2;
+                } else {
+                    p.C[(size_t)row * p.ldc + ocol] = o;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = colw + j * 32;
+                    if (col >= p.N) continue;
+                    const float v = acc[i][j][r];
+                    if constexpr (EPI == VN_EPI_STORE) {
+                        p.C[(size_t)row * p.ldc + col] = v;
+                    } else if constexpr (EPI == VN_EPI_BIAS) {
+                        p.C[(size_t)row * p.ldc + col] = v + p.bias[col];
+                    } else if constexpr (EPI == VN_EPI_RESIDUAL) {
+                        float* c = p.C + (size_t)row * p.ldc + col;
+                        *c = *c + v;
+                    } else if constexpr (EPI == VN_EPI_QKV) {
+                        const int D = p.H * VN_DHEAD;
+                        const int which = col / D, rem = col - which * D;
+                        const int hd = rem >> 6, d = rem & 63;
+                        const int b = row / p.T, t = row - b * p.T;
+                        p.C[which * p.qkv_plane + (((size_t)b * p.H + hd) * p.T + t) * VN_DHEAD + d] = v;
+                    }
+                }
+            }
         }
     }
-    auto stage_piece = [&](int buf, int k0, int j) {
-        float* base = lds + buf * G::STAGE + wave * (G::NPW * 256);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
-                                         (__attribute__((address_space(3))) void*)(base + j * 256), 16, 0, 0);
-    };
-    auto stage = [&](int buf, int k0) {
-#pragma unroll
-        for (int j = 0; j < G::NPW; ++j) stage_piece(buf, k0, j);
-    };
+}
 
-    // fragment offsets (floats) inside a plane tile: row * 16 + ((2 s + h) ^ ((row >> 2) & 3)) * 4
-    const int l31 = lane & 31, h = lane >> 5, sw = (lane >> 2) & 3;
-    const int aRow = (wm * 32 * MI + l31) * 16;
-    const int bRow = (wn * 64 + l31) * 16;
+// stream-K partition: block lb of G owns units [U lb / G, U (lb + 1) / G) of the U = tiles * nk k-tile units
+__device__ __host__ __forceinline__ long x3_unit0(long U, int lb, int G) { return U * lb / G; }
 
-    f32x16 acc[MI][2];
+// slab = one tile's accumulators in fragment order: chunk c (16 bytes per lane) of wave w at ((w * 8 MI + c) * 64 + lane) * 4
+template <int MI>
+__device__ __forceinline__ void x3_slab_store(float* slab, const f32x16 (&acc)[MI][2], int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 v = {acc[i][j][4 * c], acc[i][j][4 * c + 1], acc[i][j][4 * c + 2], acc[i][j][4 * c + 3]};
+                *(f32x4*)(slab + ((size_t)(wave * 8 * MI + (i * 2 + j) * 4 + c) * 64 + lane) * 4) = v;
+            }
+}
 
-    struct Frags { bf16x8 a[3][MI], b[3][2]; };
-    auto load_frags = [&](Frags& f, int buf, int s) {
-        const float* sA = lds + buf * G::STAGE;
-        const float* sB = sA + 3 * G::APLANE;
-        const int off = ((2 * s + h) ^ sw) * 4;
+// SK = false: data-parallel, one block per output tile (gridDim.y > 1: split-K images, store epilogue only).
+// SK = true : stream-K, see the file header.  slabs: [2 G] images of (128 MI x 128) floats.
+// ABL (tuning only, results invalid): bit 0 = no DMA inside the k-loop, bit 1 = no fragment reads inside the k-loop, bit 2 =
+// every DMA instruction fetches 8 rows x 128 B (whole cache lines, same volume) instead of 16 rows x 64 B
+template <int EPI, int MI, bool SK, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int tiles_m, int tiles_n, float* slabs) {
+    using G = x3_geo<MI>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int grp = wave >> 2;                        // waves w and w + 4 share a SIMD: one of each group per SIMD
+    const uint16_t* A16 = (const uint16_t*)p.A;
+    const uint16_t* W16 = (const uint16_t*)p.W;
+    const int nk_all = p.K / X3_KT;
+    const int ntiles = tiles_m * tiles_n;
+    const int drow = (ABL & 4) ? lane >> 3 : lane >> 2;
+    const int dslot = (ABL & 4) ? lane & 7 : (lane & 3) ^ ((lane >> 4) & 3);     // (row >> 2) & 3 == (lane >> 4) & 3
+    // fragment offsets (floats) inside a plane tile: row * 16 + ((2 s + h) ^ ((row >> 2) & 3)) * 4
+    const int l31 = lane & 31, h = lane >> 5, sw = (lane >> 2) & 3;
+    const int aRow = (wm * 32 * MI + l31) * 16;
+    const int bRow = (wn * 64 + l31) * 16;
+
+    // ---- this block's work: SK: a contiguous range of k-tile units; else one tile (and one k-split of it)
+    const int lb = x3_xcd_remap(blockIdx.x, gridDim.x);
+    long u = 0, u_end = 0;
+    if constexpr (SK) {
+        const long U = (long)ntiles * nk_all;
+        u = x3_unit0(U, lb, gridDim.x);
+        u_end = x3_unit0(U, lb + 1, gridDim.x);
+    } else {
+        u = (long)lb * nk_all + (long)nk_all * blockIdx.y / gridDim.y;
+        u_end = (long)lb * nk_all + (long)nk_all * (blockIdx.y + 1) / gridDim.y;
+        if (gridDim.y > 1) p.C += (size_t)blockIdx.y * p.M * p.N;
+    }
+    const long u_first = u;
+
+    while (u < u_end) {
+        const int t = (int)(u / nk_all);
+        const int kb = (int)(u - (long)t * nk_all);
+        const int ke = (u_end - u) < (long)(nk_all - kb) ? kb + (int)(u_end - u) : nk_all;
+        int tm, tn;
+        x3_tile_coords(t, tiles_m, tiles_n, tm, tn);
+        const int m0 = tm * G::BM, n0 = tn * X3_BN;
+
+        // per-lane DMA sources: instruction q = wave * NPW + j fills 16 rows of one plane tile (A: q < 24 MI, plane q / (8 MI))
+        const uint16_t* src[G::NPW];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-                f.a[q][i] = __builtin_bit_cast(bf16x8, *(const f32x4*)(sA + q * G::APLANE + aRow + i * 32 * 16 + off));
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                f.b[q][j] = __builtin_bit_cast(bf16x8, *(const f32x4*)(sB + q * X3_BPLANE + bRow + j * 32 * 16 + off));
+        for (int j = 0; j < G::NPW; ++j) {
+            const int q = wave * G::NPW + j;
+            if (q < 24 * MI) {
+                const int pt = q / (8 * MI), row = (q % (8 * MI)) * 16 + drow;
+                int g = m0 + row;
+                g = g < p.M ? g : p.M - 1;
+                src[j] = A16 + (size_t)pt * p.a_plane + (size_t)g * p.K + dslot * 8 + kb * X3_KT;
+            } else {
+                const int qb = q - 24 * MI;
+                const int pt = qb >> 3, row = (qb & 7) * 16 + drow;
+                int g = n0 + row;
+                g = g < p.N ? g : p.N - 1;
+                src[j] = W16 + (size_t)pt * p.w_plane + (size_t)g * p.K + dslot * 8 + kb * X3_KT;
+            }
         }
-    };
-    // the six plane products of one 16-wide k-step, smallest terms first (t = 0: A0 W2, then A2 W0, A1 W1, A0 W1, A1 W0,
-    // A0 W0); consecutive MFMAs go to different accumulators
-    auto mac_prod = [&](const Frags& f, int t) {
-        const int qa = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0, qb = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
+        auto stage_piece = [&](int buf, int k0, int j) {
+            if constexpr (ABL & 4) k0 = (2 * k0) % p.K;     // a fresh 128-byte line per k-tile (probe: K % 64 == 0, data-parallel form)
+            float* base = lds + buf * G::STAGE + wave * (G::NPW * 256);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
+                                             (__attribute__((address_space(3))) void*)(base + j * 256), 16, 0, 0);
+        };
+        auto stage = [&](int buf, int k0) {
+#pragma unroll
+            for (int j = 0; j < G::NPW; ++j) stage_piece(buf, k0, j);
+        };
+
+        f32x16 acc[MI][2];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[qa][i], f.b[qb][j], acc[i][j], 0, 0, 0);
-    };
-    auto mac = [&](const Frags& f) {
 #pragma unroll
-        for (int t = 0; t < 6; ++t) mac_prod(f, t);
-    };
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nk = ke - kb;
-    if constexpr (PIPE == 3) {
-        static_assert(PIPE != 3 || MI == 1, "the lock-step schedule is built for the 128 x 128 tile");
-        Frags f0, f1;
-        stage(0, 0);
-        if (nk > 1) stage(1, X3_KT);
-        X3_VMCNT(G::NPW);
-        if (nk == 1) X3_VMCNT(0);
-        __syncthreads();
-        load_frags(f0, 0, 0);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            const bool more = kt + 2 < nk;
-            // The reads of the NEXT group are issued behind the first product of the current one: the s_waitcnt the
-            // compiler puts in front of a group is lgkmcnt(0) (it cannot count across the loop edge), which must only
-            // cover fragments requested a whole group ago, not the ones just issued.
-            __builtin_amdgcn_s_setprio(1);
-            mac_prod(f0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_frags(f1, cur, 1);
-            __builtin_amdgcn_sched_barrier(0);
+        struct Frags { bf16x8 a[3][MI], b[3][2]; };
+        auto load_frags = [&](Frags& f, int buf, int s) {
+            const float* sA = lds + buf * G::STAGE;
+            const float* sB = sA + 3 * G::APLANE;
+            const int off = ((2 * s + h) ^ sw) * 4;
 #pragma unroll
-            for (int t = 1; t < 6; ++t) mac_prod(f0, t);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            X3_VMCNT(0);                  // this wave's share of tile kt + 1 has landed (hipcc does not always emit it for a glds)
-            __syncthreads();              // + lgkmcnt(0): f1 is in registers; after the barrier tile kt + 1 is complete
-            mac_prod(f1, 0);
-            if (more) stage_piece(cur, (kt + 2) * X3_KT, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + 1 < nk) load_frags(f0, cur ^ 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < 3; ++q) {
 #pragma unroll
-            for (int t = 1; t < 6; ++t) {
-                mac_prod(f1, t);
-                if (more) stage_piece(cur, (kt + 2) * X3_KT, t);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < MI; ++i)
+                    f.a[q][i] = __builtin_bit_cast(bf16x8, *(const f32x4*)(sA + q * G::APLANE + aRow + i * 32 * 16 + off));
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    f.b[q][j] = __builtin_bit_cast(bf16x8, *(const f32x4*)(sB + q * X3_BPLANE + bRow + j * 32 * 16 + off));
             }
-        }
-    } else {
-        static_assert(PIPE == 3 || PIPE == 4, "unknown schedule");
-        const int grp = wave >> 2;                        // waves w and w + 4 share a SIMD: one of each group per SIMD
+        };
+        // the six plane products of one 16-wide k-step, smallest terms first (t = 0: A0 W2, then A2 W0, A1 W1, A0 W1, A1 W0,
+        // A0 W0); consecutive MFMAs go to different accumulators
+        auto mac_prod = [&](const Frags& f, int t) {
+            const int qa = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0, qb = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[qa][i], f.b[qb][j], acc[i][j], 0, 0, 0);
+        };
         Frags f;
         auto compute = [&]() {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
-            mac(f);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) mac_prod(f, t);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         };
+
+        const int nk = ke - kb;
+        if (u != u_first) X3_BARRIER();                     // the previous segment's last LDS reads have retired everywhere
         if constexpr (MI == 1) {
             // three buffers; tile kt lives in buffer kt % 3.  Phase intervals I_j between consecutive barriers: group 0 loads
             // step i in I_2i and computes it in I_2i+1, group 1 one interval later.  Tile kt is read in I_4kt .. I_4kt+3 (every
@@ -317,94 +361,124 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                 if (!(last && grp)) X3_BARRIER();
             }
         }
-    }
 
-    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    const int colw = n0 + wn * 64 + l31;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (row >= p.M) continue;
-            if constexpr (EPI == VN_EPI_GEGLU) {
-                // wave tile = 64 packed columns = 32 value (j = 0) + 32 gate (j = 1), interleaved at pack time
-                const int ocol = (n0 + wn * 64) / 2 + l31;
-                if (2 * ocol >= p.N) continue;
-                const float o = acc[i][0][r] * vn_gelu_tanh(acc[i][1][r]);
-                if (p.C16) {
-                    uint16_t t0, t1, t2;
-                    vn_split3(o, t0, t1, t2);
-                    uint16_t* d = p.C16 + (size_t)row * p.ldc + ocol;
-                    d[0] = t0; d[p.c_plane] = t1; d[2 * p.c_plane] = t2;
-                } else {
-                    p.C[(size_t)row * p.ldc + ocol] = o;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = colw + j * 32;
-                    if (col >= p.N) continue;
-                    const float v = acc[i][j][r];
-                    if constexpr (EPI == VN_EPI_STORE) {
-                        p.C[(size_t)row * p.ldc + col] = v;
-                    } else if constexpr (EPI == VN_EPI_BIAS) {
-                        p.C[(size_t)row * p.ldc + col] = v + p.bias[col];
-                    } else if constexpr (EPI == VN_EPI_RESIDUAL) {
-                        float* c = p.C + (size_t)row * p.ldc + col;
-                        *c = *c + v;
-                    } else if constexpr (EPI == VN_EPI_QKV) {
-                        const int D = p.H * VN_DHEAD;
-                        const int which = col / D, rem = col - which * D;
-                        const int hd = rem >> 6, d = rem & 63;
-                        const int b = row / p.T, t = row - b * p.T;
-                        p.C[which * p.qkv_plane + (((size_t)b * p.H + hd) * p.T + t) * VN_DHEAD + d] = v;
-                    }
-                }
-            }
+        if (!SK || (kb == 0 && ke == nk_all)) {
+            x3_epilogue<EPI, MI>(p, acc, m0, n0, wm, wn, lane);
+        } else {
+            // a shared tile: raw accumulators to this block's first / second slab (the fix-up kernel recomputes the same map)
+            x3_slab_store<MI>(slabs + (size_t)(2 * lb + (u != u_first ? 1 : 0)) * (G::BM * X3_BN), acc, wave, lane);
         }
+        u += nk;
     }
 }
 
-#define X3_WS_FLOATS (32L << 20)          // 128 MiB of split-K partial images, allocated once (graph-safe: never re-allocated)
+// stream-K pass 2: one block per output tile; tiles that one block computed whole were finished in pass 1 (exit); for a
+// shared tile add the slabs of the blocks whose ranges meet it, in k order, and run the epilogue.
+template <int EPI, int MI>
+__global__ __launch_bounds__(512) void vn_gemm_x3_fixup_kernel(vn_gemm_args p, int tiles_m, int tiles_n, const float* slabs, int G) {
+    const int t = blockIdx.x;
+    const int nk = p.K / X3_KT;
+    const long U = (long)tiles_m * tiles_n * nk;
+    const long t0 = (long)t * nk, t1 = t0 + nk;
+    int lb = (int)(t0 * G / U);                          // block whose range holds unit t0 (+- 1 from the integer divisions)
+    while (lb > 0 && x3_unit0(U, lb, G) > t0) --lb;
+    while (lb + 1 < G && x3_unit0(U, lb + 1, G) <= t0) ++lb;
+    if (x3_unit0(U, lb + 1, G) >= t1) return;            // one block covered [t0, t1): done in pass 1
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (; lb < G; ++lb) {
+        const long b0 = x3_unit0(U, lb, G), b1 = x3_unit0(U, lb + 1, G);
+        if (b0 >= t1) break;
+        if (b1 <= b0) continue;                          // empty range (G > U)
+        const long s0 = b0 > t0 ? b0 : t0;               // the block's segment inside this tile starts here
+        const float* slab = slabs + (size_t)(2 * lb + (s0 != b0 ? 1 : 0)) * (128 * MI * X3_BN);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 v = *(const f32x4*)(slab + ((size_t)(wave * 8 * MI + (i * 2 + j) * 4 + c) * 64 + lane) * 4);
+                    acc[i][j][4 * c] += v[0]; acc[i][j][4 * c + 1] += v[1]; acc[i][j][4 * c + 2] += v[2]; acc[i][j][4 * c + 3] += v[3];
+                }
+    }
+    int tm, tn;
+    x3_tile_coords(t, tiles_m, tiles_n, tm, tn);
+    x3_epilogue<EPI, MI>(p, acc, tm * 128 * MI, tn * X3_BN, wave >> 1, wave & 1, lane);
+}
+
+#define X3_WS_FLOATS (32L << 20)          // 128 MiB: stream-K slabs (2 x 256 x 64 / 128 KiB) or split-K images; allocated once
 
 static int x3_env(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
 }
 
-// schedule: VN_X3_PIPE = 3 lock-step 128 x 128 (round 1), 4 ping-pong 128 x 128, 5 ping-pong 256 x 128
-static int g_x3_pipe = -1, g_x3_split = -2, g_x3_abl = -1;      // vn_debug_x3_config overrides (tests / tuning)
-static int x3_pipe() {
-    static const int pipe = x3_env("VN_X3_PIPE", 4);
-    return g_x3_pipe >= 3 ? g_x3_pipe : pipe;
+// tuning / test hooks (process-global): tile height 128 / 256, stream-K on / off, forced split-K of the data-parallel form,
+// ablation bits.  Defaults: VN_X3_BM (128), VN_X3_SK (1).
+static int g_x3_bm = 0, g_x3_sk = -1, g_x3_split = -2, g_x3_abl = -1;
+static int x3_bm() {
+    static const int bm = x3_env("VN_X3_BM", 128) == 256 ? 256 : 128;
+    return g_x3_bm ? g_x3_bm : bm;
 }
-extern "C" int vn_debug_x3_config(int pipe, int splitk, int abl) {
-    if (pipe != -1 && (pipe < 3 || pipe > 5)) return VN_ERR_INVALID;
-    g_x3_pipe = pipe; g_x3_split = splitk < 0 ? -2 : splitk; g_x3_abl = abl < 0 ? -1 : (abl & 3);
+static bool x3_sk() {
+    static const int sk = x3_env("VN_X3_SK", 1);
+    return (g_x3_sk >= 0 ? g_x3_sk : sk) != 0;
+}
+extern "C" int vn_debug_x3_config(int bm, int stream_k, int splitk, int abl) {
+    if (bm != 0 && bm != 128 && bm != 256) return VN_ERR_INVALID;
+    g_x3_bm = bm; g_x3_sk = stream_k < 0 ? -1 : (stream_k != 0); g_x3_split = splitk < 0 ? -2 : splitk;
+    g_x3_abl = abl < 0 ? -1 : (abl & 7);
     return VN_OK;
 }
-static int x3_bm() { return x3_pipe() == 5 ? 256 : 128; }
 
-template <int EPI, int PIPE, int MI, int ABL = 0>
-static void x3_go(const vn_gemm_args& a, int tiles_m, int tiles_n, int nsplit, hipStream_t s) {
-    constexpr size_t lds_bytes = (size_t)x3_geo<MI>::STAGE * 4 * (PIPE == 4 && MI == 1 ? 3 : 2);
-    hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, PIPE, MI, ABL>), dim3(tiles_m * tiles_n, nsplit), dim3(512), lds_bytes, s, a, tiles_m,
-                       tiles_n);
+template <int MI>
+static constexpr size_t x3_lds_bytes() { return (size_t)x3_geo<MI>::STAGE * 4 * (MI == 1 ? 3 : 2); }
+
+static int x3_num_cus(vn_ctx* ctx) {
+    static int cus[64] = {0};
+    const int d = ctx->device & 63;
+    if (!cus[d]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || n <= 0) n = 256;
+        cus[d] = n;
+    }
+    return cus[d];
+}
+
+template <int EPI, int MI, int ABL = 0>
+static int x3_go(vn_ctx* ctx, const vn_gemm_args& a, int nsplit, bool sk, hipStream_t s) {
+    const int tiles_m = vn_cdiv(a.M, 128 * MI), tiles_n = vn_cdiv(a.N, X3_BN);
+    if (sk) {
+        const long U = (long)tiles_m * tiles_n * (a.K / X3_KT);
+        const int cus = x3_num_cus(ctx);
+        const int G = U < cus ? (int)U : cus;
+        if ((size_t)2 * G * 128 * MI * X3_BN > (size_t)X3_WS_FLOATS) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: slab workspace too small%s", "");
+        if (!ctx->x3_ws) VN_HIP_CHECK(ctx, hipMalloc((void**)&ctx->x3_ws, (size_t)X3_WS_FLOATS * sizeof(float)));
+        hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, MI, true, ABL>), dim3(G), dim3(512), x3_lds_bytes<MI>(), s, a, tiles_m, tiles_n, ctx->x3_ws);
+        VN_LAUNCH_CHECK(ctx);
+        if (U % G != 0 || (U / G) % (a.K / X3_KT) != 0)      // some tile is shared between blocks
+            hipLaunchKernelGGL((vn_gemm_x3_fixup_kernel<EPI, MI>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, tiles_m, tiles_n, ctx->x3_ws, G);
+    } else {
+        hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, MI, false, ABL>), dim3(tiles_m * tiles_n, nsplit), dim3(512), x3_lds_bytes<MI>(), s, a,
+                           tiles_m, tiles_n, (float*)nullptr);
+    }
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
 }
 template <int EPI>
-static void x3_go_pipe(const vn_gemm_args& a, int nsplit, hipStream_t s) {
-    const int tiles_n = vn_cdiv(a.N, X3_BN);
-    switch (x3_pipe()) {
-        case 3: x3_go<EPI, 3, 1>(a, vn_cdiv(a.M, 128), tiles_n, nsplit, s); break;
-        case 5: x3_go<EPI, 4, 2>(a, vn_cdiv(a.M, 256), tiles_n, nsplit, s); break;
-        default: x3_go<EPI, 4, 1>(a, vn_cdiv(a.M, 128), tiles_n, nsplit, s); break;
-    }
+static int x3_go_bm(vn_ctx* ctx, const vn_gemm_args& a, int nsplit, bool sk, hipStream_t s) {
+    return x3_bm() == 256 ? x3_go<EPI, 2>(ctx, a, nsplit, sk, s) : x3_go<EPI, 1>(ctx, a, nsplit, sk, s);
 }
 
-// split count for the store / residual epilogues: a launch costs ceil(tiles * ns / 256) rounds of K / ns, plus the reduce
-// pass over (ns + 1 or 2) images of C.  Constants from profiles/r01_gemm_x3_vs_f32.txt (1.45 us per k-tile and round,
-// ~3.5 TB/s for the reduce).
+// data-parallel form only: split count for the store / residual epilogues.  A launch costs ceil(tiles * ns / 256) rounds of
+// K / ns, plus the reduce pass over (ns + 1 or 2) images of C (1.45 us per k-tile and round, ~3.5 TB/s for the reduce).
 static int x3_pick_split(const vn_gemm_args& a, bool residual) {
     static const int forced_env = x3_env("VN_X3_SPLITK", -1);      // 0 / 1: off, 2 / 4: forced
     const int forced = g_x3_split != -2 ? g_x3_split : forced_env;
@@ -430,43 +504,36 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
     const double bytes = 6.0 * ((double)a.M * a.K + (double)a.N * a.K) +
                          ((EPI == VN_EPI_GEGLU && a.C16) ? 6.0 : 4.0) * (double)a.M * n_out * (EPI == VN_EPI_RESIDUAL ? 2 : 1);
     const int pi = vn_prof_pre(ctx, 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);       // algorithmic (fp32-equivalent) flops
+    int rc = VN_OK;
+    const bool sk = x3_sk();
+    bool done = false;
     if constexpr (EPI == VN_EPI_STORE) {
-        static const int abl_env = x3_env("VN_X3_ABL", 0) & 3;             // ablations (tuning only; results invalid)
+        static const int abl_env = x3_env("VN_X3_ABL", 0) & 7;             // ablations (tuning only; results invalid)
         const int abl = g_x3_abl >= 0 ? g_x3_abl : abl_env;
         if (abl) {
-            const int tiles_n = vn_cdiv(a.N, X3_BN);
-            if (x3_pipe() == 5) {
-                if (abl == 1) x3_go<VN_EPI_STORE, 4, 2, 1>(a, vn_cdiv(a.M, 256), tiles_n, 1, s);
-                else if (abl == 2) x3_go<VN_EPI_STORE, 4, 2, 2>(a, vn_cdiv(a.M, 256), tiles_n, 1, s);
-                else x3_go<VN_EPI_STORE, 4, 2, 3>(a, vn_cdiv(a.M, 256), tiles_n, 1, s);
-            } else {
-                if (abl == 1) x3_go<VN_EPI_STORE, 4, 1, 1>(a, vn_cdiv(a.M, 128), tiles_n, 1, s);
-                else if (abl == 2) x3_go<VN_EPI_STORE, 4, 1, 2>(a, vn_cdiv(a.M, 128), tiles_n, 1, s);
-                else x3_go<VN_EPI_STORE, 4, 1, 3>(a, vn_cdiv(a.M, 128), tiles_n, 1, s);
-            }
-            vn_prof_post(ctx, pi, s);
-            VN_LAUNCH_CHECK(ctx);
-            return VN_OK;
+            const bool big = x3_bm() == 256;
+            if (abl == 1) rc = big ? x3_go<VN_EPI_STORE, 2, 1>(ctx, a, 1, sk, s) : x3_go<VN_EPI_STORE, 1, 1>(ctx, a, 1, sk, s);
+            else if (abl == 2) rc = big ? x3_go<VN_EPI_STORE, 2, 2>(ctx, a, 1, sk, s) : x3_go<VN_EPI_STORE, 1, 2>(ctx, a, 1, sk, s);
+            else if (abl == 3) rc = big ? x3_go<VN_EPI_STORE, 2, 3>(ctx, a, 1, sk, s) : x3_go<VN_EPI_STORE, 1, 3>(ctx, a, 1, sk, s);
+            else rc = big ? x3_go<VN_EPI_STORE, 2, 4>(ctx, a, 1, sk, s) : x3_go<VN_EPI_STORE, 1, 4>(ctx, a, 1, sk, s);
+            done = true;
         }
     }
     if constexpr (EPI == VN_EPI_STORE || EPI == VN_EPI_RESIDUAL) {
-        const int ns = x3_pick_split(a, EPI == VN_EPI_RESIDUAL);
+        const int ns = (done || sk) ? 1 : x3_pick_split(a, EPI == VN_EPI_RESIDUAL);
         if (ns > 1) {
             if (!ctx->x3_ws) VN_HIP_CHECK(ctx, hipMalloc((void**)&ctx->x3_ws, (size_t)X3_WS_FLOATS * sizeof(float)));
             vn_gemm_args q = a;                       // every split stores its raw image [M][N] into the workspace
             q.C = ctx->x3_ws;
             q.ldc = a.N;
-            x3_go_pipe<VN_EPI_STORE>(q, ns, s);
-            VN_LAUNCH_CHECK(ctx);
-            const int rc = vn_launch_splitk_reduce(ctx, ctx->x3_ws, ns, a.C, a.M, a.N, a.ldc, EPI == VN_EPI_RESIDUAL, s);
-            vn_prof_post(ctx, pi, s);
-            return rc;
+            rc = x3_go_bm<VN_EPI_STORE>(ctx, q, ns, false, s);
+            if (rc == VN_OK) rc = vn_launch_splitk_reduce(ctx, ctx->x3_ws, ns, a.C, a.M, a.N, a.ldc, EPI == VN_EPI_RESIDUAL, s);
+            done = true;
         }
     }
-    x3_go_pipe<EPI>(a, 1, s);
+    if (!done) rc = x3_go_bm<EPI>(ctx, a, 1, sk, s);
     vn_prof_post(ctx, pi, s);
-    VN_LAUNCH_CHECK(ctx);
-    return VN_OK;
+    return rc;
 }
 
 template <typename K>
@@ -477,9 +544,15 @@ static int x3_attr(vn_ctx* ctx, K kernel, size_t bytes) {
 template <int EPI>
 static int x3_attrs(vn_ctx* ctx) {
     int rc;
-    if ((rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 3, 1>, (size_t)x3_geo<1>::STAGE * 8))) return rc;
-    if ((rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 4, 1>, (size_t)x3_geo<1>::STAGE * 12))) return rc;
-    return x3_attr(ctx, vn_gemm_x3_kernel<EPI, 4, 2>, (size_t)x3_geo<2>::STAGE * 8);
+    if ((rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 1, false>, x3_lds_bytes<1>()))) return rc;
+    if ((rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 1, true>, x3_lds_bytes<1>()))) return rc;
+    if ((rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 2, false>, x3_lds_bytes<2>()))) return rc;
+    return x3_attr(ctx, vn_gemm_x3_kernel<EPI, 2, true>, x3_lds_bytes<2>());
+}
+template <int MI, int ABL>
+static int x3_attrs_abl(vn_ctx* ctx) {
+    int rc = x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_STORE, MI, false, ABL>, x3_lds_bytes<MI>());
+    return rc ? rc : x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_STORE, MI, true, ABL>, x3_lds_bytes<MI>());
 }
 
 int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s) {
@@ -494,12 +567,9 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
         if ((rc = x3_attrs<VN_EPI_STORE>(ctx)) || (rc = x3_attrs<VN_EPI_BIAS>(ctx)) || (rc = x3_attrs<VN_EPI_RESIDUAL>(ctx)) ||
             (rc = x3_attrs<VN_EPI_GEGLU>(ctx)) || (rc = x3_attrs<VN_EPI_QKV>(ctx)))
             return rc;
-        if ((rc = x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_STORE, 4, 1, 1>, (size_t)x3_geo<1>::STAGE * 12)) ||
-            (rc = x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_STORE, 4, 1, 2>, (size_t)x3_geo<1>::STAGE * 12)) ||
-            (rc = x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_STORE, 4, 1, 3>, (size_t)x3_geo<1>::STAGE * 12)) ||
-            (rc = x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_STORE, 4, 2, 1>, (size_t)x3_geo<2>::STAGE * 8)) ||
-            (rc = x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_STORE, 4, 2, 2>, (size_t)x3_geo<2>::STAGE * 8)) ||
-            (rc = x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_STORE, 4, 2, 3>, (size_t)x3_geo<2>::STAGE * 8)))
+        if ((rc = x3_attrs_abl<1, 1>(ctx)) || (rc = x3_attrs_abl<1, 2>(ctx)) || (rc = x3_attrs_abl<1, 3>(ctx)) ||
+            (rc = x3_attrs_abl<2, 1>(ctx)) || (rc = x3_attrs_abl<2, 2>(ctx)) || (rc = x3_attrs_abl<2, 3>(ctx)) ||
+            (rc = x3_attrs_abl<1, 4>(ctx)) || (rc = x3_attrs_abl<2, 4>(ctx)))
             return rc;
         ctx->attr_mask |= VN_ATTR_GEMM_X3;
     }
