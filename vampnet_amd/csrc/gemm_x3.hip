@@ -137,8 +137,17 @@ __device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 
     }
 }
 
-// stream-K partition: block lb of G owns units [U lb / G, U (lb + 1) / G) of the U = tiles * nk k-tile units
-__device__ __host__ __forceinline__ long x3_unit0(long U, int lb, int G) { return U * lb / G; }
+// stream-K partition.  The walk of tiles (x3_tile_coords order) is cut into eight contiguous chunks, one per XCD (blocks with
+// blockIdx % 8 == x run on XCD x and share its L2).  Inside a chunk of n tiles the Gx = G / 8 blocks of that XCD take whole
+// tiles round-robin for floor(n / Gx) rounds — at any moment they work on ADJACENT tiles, which is what keeps the A / W panels
+// L2-resident (contiguous per-block ranges ran 35-45 % slower, profiles/r02_gemm_x3_streamk_v1_vs_dp.txt) — and the
+// remaining nt < Gx tiles are cut along k into Gx equal contiguous ranges of k-tile units ("tail").
+struct x3_chunk { int c0, n; };
+__device__ __host__ __forceinline__ x3_chunk x3_xcd_chunk(int ntiles, int xcd) {
+    const int q = ntiles >> 3, r = ntiles & 7;
+    return {xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, q + (xcd < r ? 1 : 0)};
+}
+__device__ __host__ __forceinline__ long x3_unit0(long U, int i, int Gx) { return U * i / Gx; }
 
 // slab = one tile's accumulators in fragment order: chunk c (16 bytes per lane) of wave w at ((w * 8 MI + c) * 64 + lane) * 4
 template <int MI>
@@ -178,24 +187,48 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
     const int aRow = (wm * 32 * MI + l31) * 16;
     const int bRow = (wn * 64 + l31) * 16;
 
-    // ---- this block's work: SK: a contiguous range of k-tile units; else one tile (and one k-split of it)
-    const int lb = x3_xcd_remap(blockIdx.x, gridDim.x);
-    long u = 0, u_end = 0;
+    // ---- this block's work.  SK: whole tiles of its XCD's chunk round-robin, then a k-range of the chunk's tail tiles;
+    // else one tile (and one k-split of it)
+    int sk_c0 = 0, sk_full = 0, sk_gx = 1, sk_i = 0, sk_slab = 0;
+    long tu = 0, tu_end = 0;                          // SK: this block's range of tail units
+    int seg = 0, nseg = 1;
     if constexpr (SK) {
-        const long U = (long)ntiles * nk_all;
-        u = x3_unit0(U, lb, gridDim.x);
-        u_end = x3_unit0(U, lb + 1, gridDim.x);
+        const int xcd = blockIdx.x & 7;
+        sk_i = blockIdx.x >> 3;
+        sk_gx = gridDim.x >> 3;
+        const x3_chunk ch = x3_xcd_chunk(ntiles, xcd);
+        sk_c0 = ch.c0;
+        sk_full = ch.n / sk_gx;
+        const long Ut = (long)(ch.n - sk_full * sk_gx) * nk_all;
+        tu = x3_unit0(Ut, sk_i, sk_gx);
+        tu_end = x3_unit0(Ut, sk_i + 1, sk_gx);
+        sk_slab = 2 * (xcd * sk_gx + sk_i);
+        nseg = sk_full + (tu_end > tu ? 2 : 0);       // upper bound; the loop stops when the tail range is used up
     } else {
-        u = (long)lb * nk_all + (long)nk_all * blockIdx.y / gridDim.y;
-        u_end = (long)lb * nk_all + (long)nk_all * (blockIdx.y + 1) / gridDim.y;
         if (gridDim.y > 1) p.C += (size_t)blockIdx.y * p.M * p.N;
     }
-    const long u_first = u;
+    const long tu_first = tu;
 
-    while (u < u_end) {
-        const int t = (int)(u / nk_all);
-        const int kb = (int)(u - (long)t * nk_all);
-        const int ke = (u_end - u) < (long)(nk_all - kb) ? kb + (int)(u_end - u) : nk_all;
+    for (; seg < nseg; ++seg) {
+        int t, kb, ke;
+        bool first_tail = false;
+        if constexpr (SK) {
+            if (seg < sk_full) {
+                t = sk_c0 + seg * sk_gx + sk_i; kb = 0; ke = nk_all;
+            } else {
+                if (tu >= tu_end) break;
+                const int tt = (int)(tu / nk_all);
+                kb = (int)(tu - (long)tt * nk_all);
+                ke = (tu_end - tu) < (long)(nk_all - kb) ? kb + (int)(tu_end - tu) : nk_all;
+                t = sk_c0 + sk_full * sk_gx + tt;
+                first_tail = tu == tu_first;
+                tu += ke - kb;
+            }
+        } else {
+            t = x3_xcd_remap(blockIdx.x, gridDim.x);
+            kb = (int)((long)nk_all * blockIdx.y / gridDim.y);
+            ke = (int)((long)nk_all * (blockIdx.y + 1) / gridDim.y);
+        }
         int tm, tn;
         x3_tile_coords(t, tiles_m, tiles_n, tm, tn);
         const int m0 = tm * G::BM, n0 = tn * X3_BN;
@@ -273,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         };
 
         const int nk = ke - kb;
-        if (u != u_first) X3_BARRIER();                     // the previous segment's last LDS reads have retired everywhere
+        if (seg) X3_BARRIER();                              // the previous segment's last LDS reads have retired everywhere
         if constexpr (MI == 1) {
             // three buffers; tile kt lives in buffer kt % 3.  Phase intervals I_j between consecutive barriers: group 0 loads
             // step i in I_2i and computes it in I_2i+1, group 1 one interval later.  Tile kt is read in I_4kt .. I_4kt+3 (every
@@ -366,46 +399,52 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             x3_epilogue<EPI, MI>(p, acc, m0, n0, wm, wn, lane);
         } else {
             // a shared tile: raw accumulators to this block's first / second slab (the fix-up kernel recomputes the same map)
-            x3_slab_store<MI>(slabs + (size_t)(2 * lb + (u != u_first ? 1 : 0)) * (G::BM * X3_BN), acc, wave, lane);
+            x3_slab_store<MI>(slabs + (size_t)(sk_slab + (first_tail ? 0 : 1)) * (G::BM * X3_BN), acc, wave, lane);
         }
-        u += nk;
     }
 }
 
 // stream-K pass 2: one block per output tile; tiles that one block computed whole were finished in pass 1 (exit); for a
-// shared tile add the slabs of the blocks whose ranges meet it, in k order, and run the epilogue.
+// tail tile add the slabs of the blocks of its XCD whose unit ranges meet it, in k order, and run the epilogue.
 template <int EPI, int MI>
 __global__ __launch_bounds__(512) void vn_gemm_x3_fixup_kernel(vn_gemm_args p, int tiles_m, int tiles_n, const float* slabs, int G) {
     const int t = blockIdx.x;
     const int nk = p.K / X3_KT;
-    const long U = (long)tiles_m * tiles_n * nk;
-    const long t0 = (long)t * nk, t1 = t0 + nk;
-    int lb = (int)(t0 * G / U);                          // block whose range holds unit t0 (+- 1 from the integer divisions)
-    while (lb > 0 && x3_unit0(U, lb, G) > t0) --lb;
-    while (lb + 1 < G && x3_unit0(U, lb + 1, G) <= t0) ++lb;
-    if (x3_unit0(U, lb + 1, G) >= t1) return;            // one block covered [t0, t1): done in pass 1
+    const int ntiles = tiles_m * tiles_n, Gx = G >> 3;
+    int xcd = 0;
+    x3_chunk ch = x3_xcd_chunk(ntiles, 0);
+    while (xcd < 7 && t >= ch.c0 + ch.n) ch = x3_xcd_chunk(ntiles, ++xcd);
+    const int full = ch.n / Gx;
+    const int tt = t - ch.c0 - full * Gx;              // index among the chunk's tail tiles
+    if (tt < 0) return;                                // a whole tile of the round-robin part: done in pass 1
+    const long Ut = (long)(ch.n - full * Gx) * nk;
+    const long t0 = (long)tt * nk, t1 = t0 + nk;
+    int i = (int)(t0 * Gx / Ut);                       // block whose range holds unit t0 (+- 1 from the integer divisions)
+    while (i > 0 && x3_unit0(Ut, i, Gx) > t0) --i;
+    while (i + 1 < Gx && x3_unit0(Ut, i + 1, Gx) <= t0) ++i;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int a = 0; a < MI; ++a)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    for (; lb < G; ++lb) {
-        const long b0 = x3_unit0(U, lb, G), b1 = x3_unit0(U, lb + 1, G);
+            for (int r = 0; r < 16; ++r) acc[a][j][r] = 0.0f;
+    for (; i < Gx; ++i) {
+        const long b0 = x3_unit0(Ut, i, Gx), b1 = x3_unit0(Ut, i + 1, Gx);
         if (b0 >= t1) break;
-        if (b1 <= b0) continue;                          // empty range (G > U)
+        if (b1 <= b0) continue;                          // empty range (fewer units than blocks)
+        if (b0 <= t0 && b1 >= t1) return;                // one block had the whole tile: finished in pass 1
         const long s0 = b0 > t0 ? b0 : t0;               // the block's segment inside this tile starts here
-        const float* slab = slabs + (size_t)(2 * lb + (s0 != b0 ? 1 : 0)) * (128 * MI * X3_BN);
+        const float* slab = slabs + (size_t)(2 * (xcd * Gx + i) + (s0 != b0 ? 1 : 0)) * (128 * MI * X3_BN);
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int a = 0; a < MI; ++a)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const f32x4 v = *(const f32x4*)(slab + ((size_t)(wave * 8 * MI + (i * 2 + j) * 4 + c) * 64 + lane) * 4);
-                    acc[i][j][4 * c] += v[0]; acc[i][j][4 * c + 1] += v[1]; acc[i][j][4 * c + 2] += v[2]; acc[i][j][4 * c + 3] += v[3];
+                    const f32x4 v = *(const f32x4*)(slab + ((size_t)(wave * 8 * MI + (a * 2 + j) * 4 + c) * 64 + lane) * 4);
+                    acc[a][j][4 * c] += v[0]; acc[a][j][4 * c + 1] += v[1]; acc[a][j][4 * c + 2] += v[2]; acc[a][j][4 * c + 3] += v[3];
                 }
     }
     int tm, tn;
@@ -456,15 +495,16 @@ template <int EPI, int MI, int ABL = 0>
 static int x3_go(vn_ctx* ctx, const vn_gemm_args& a, int nsplit, bool sk, hipStream_t s) {
     const int tiles_m = vn_cdiv(a.M, 128 * MI), tiles_n = vn_cdiv(a.N, X3_BN);
     if (sk) {
-        const long U = (long)tiles_m * tiles_n * (a.K / X3_KT);
-        const int cus = x3_num_cus(ctx);
-        const int G = U < cus ? (int)U : cus;
-        if ((size_t)2 * G * 128 * MI * X3_BN > (size_t)X3_WS_FLOATS) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: slab workspace too small%s", "");
+        const int ntiles = tiles_m * tiles_n;
+        const int G = x3_num_cus(ctx) & ~7;                  // one persistent block per CU, the same number on every XCD
+        if (G < 8 || (size_t)2 * G * 128 * MI * X3_BN > (size_t)X3_WS_FLOATS) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: slab workspace too small%s", "");
         if (!ctx->x3_ws) VN_HIP_CHECK(ctx, hipMalloc((void**)&ctx->x3_ws, (size_t)X3_WS_FLOATS * sizeof(float)));
         hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, MI, true, ABL>), dim3(G), dim3(512), x3_lds_bytes<MI>(), s, a, tiles_m, tiles_n, ctx->x3_ws);
         VN_LAUNCH_CHECK(ctx);
-        if (U % G != 0 || (U / G) % (a.K / X3_KT) != 0)      // some tile is shared between blocks
-            hipLaunchKernelGGL((vn_gemm_x3_fixup_kernel<EPI, MI>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, tiles_m, tiles_n, ctx->x3_ws, G);
+        bool tail = false;                                   // does any XCD chunk leave tiles to the k-split tail ?
+        for (int x = 0; x < 8; ++x) tail = tail || (x3_xcd_chunk(ntiles, x).n % (G >> 3)) != 0;
+        if (tail)
+            hipLaunchKernelGGL((vn_gemm_x3_fixup_kernel<EPI, MI>), dim3(ntiles), dim3(512), 0, s, a, tiles_m, tiles_n, ctx->x3_ws, G);
     } else {
         hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, MI, false, ABL>), dim3(tiles_m * tiles_n, nsplit), dim3(512), x3_lds_bytes<MI>(), s, a,
                            tiles_m, tiles_n, (float*)nullptr);
