@@ -209,6 +209,11 @@ int vn_gemm_bf16(vn_ctx* ctx, const void* A16, const void* W16, const float* bia
 int vn_gemm_bf16x3(vn_ctx* ctx, const void* A3, int64_t a_plane, const void* W3, int64_t w_plane, const float* bias,
                    float* C, int M, int N, int K, int epilogue, void* stream);
 
+/* The same op in the bf16x3 precision (attention_x3.hip: both products as six bf16-MFMA products of exact three-way operand
+ * splits, fp32 softmax): same arguments and output as vn_attention_f32.                                                  */
+int vn_attention_bf16x3(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                        float* out, int B, int H, int T, int num_buckets, int max_distance, void* stream);
+
 /* Self-attention core (transformer.py:229-254): q,k,v dev f32 [B][H][T][64];
  * rel_bias dev f32 [num_buckets][H]; out dev f32 [B][T][H*64].                                */
 int vn_attention_f32(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,

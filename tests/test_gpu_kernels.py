@@ -82,16 +82,41 @@ def _attention_ref(q, k, v, table):
     return out.permute(1, 2, 0, 3).reshape(B, T, H * 64)
 
 
-@pytest.mark.parametrize("B,H,T", [(1, 20, 575), (2, 20, 173), (3, 4, 64), (2, 2, 1), (1, 3, 65), (1, 2, 130), (2, 1, 600)])
-def test_attention(eng, B, H, T):
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("B,H,T", [(1, 20, 575), (2, 20, 173), (3, 4, 64), (2, 2, 1), (1, 3, 65), (1, 2, 130), (2, 1, 600),
+                                   (1, 2, 32), (1, 1, 33), (2, 3, 128), (1, 2, 129), (1, 1, 97)])
+def test_attention(eng, B, H, T, precision):
+    """both attention kernels (fp32-input MFMA; bf16x3 = six bf16-MFMA products of exact splits) at the SAME tolerance; the T
+    values put the end of the sequence at every position of a 32-key tile and of a 64 / 128-query block"""
     q, k, v = _rand((B, H, T, 64), 10), _rand((B, H, T, 64), 11), _rand((B, H, T, 64), 12)
     table = _rand((32, H), 13)
     ref = _attention_ref(q, k, v, table)
-    got = eng.attention(q.cuda(), k.cuda(), v.cuda(), table.cuda()).cpu()
+    got = eng.attention(q.cuda(), k.cuda(), v.cuda(), table.cuda(), precision=precision).cpu()
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-5, atol=3e-6)
 
 
-def test_attention_bias_buckets_exact(eng):
+def test_attention_bf16x3_forced_rescale_and_large_scores(eng):
+    """online-softmax edge cases of attention_x3.hip against float64: a key late in the sequence that dominates one query
+    (running max jumps at the last tiles: every earlier partial sum is rescaled by ~e^-40), scores of large magnitude, and
+    transpose-detecting structure (q, k, v asymmetric)."""
+    B, H, T = 1, 2, 200
+    g = torch.Generator().manual_seed(5)
+    q, k, v = (torch.randn(B, H, T, 64, generator=g) for _ in range(3))
+    k[0, 0, 190] = q[0, 0, 7] * 5.0                       # q7 . k190 / 8 ~ 40 above everything else
+    k[0, 1, 3] = q[0, 1, 150] * 4.0
+    q[0, 1, 20] *= 6.0
+    table = torch.randn(32, H, generator=g)
+    s = torch.einsum("bhld,bhtd->bhlt", q.double(), k.double()) / 8.0 + O.compute_bias(table, T).permute(1, 0, 2, 3).double()
+    ref = torch.einsum("bhlt,bhtd->bhld", torch.softmax(s, -1), v.double()).permute(0, 2, 1, 3).reshape(B, T, H * 64)
+    for precision in ("f32", "bf16x3"):
+        got = eng.attention(q.cuda(), k.cuda(), v.cuda(), table.cuda(), precision=precision).cpu().double()
+        err = (got - ref).abs().max().item()
+        print(f"{precision}: max |err| vs float64 = {err:.3e}")
+        assert err < 2e-5
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_attention_bias_buckets_exact(eng, precision):
     """q = 0 -> scores are the bias alone; v = one-hot(position) -> output row = softmax(bias) itself,
     which pins every bucket boundary (rel = -574..574) against the oracle table."""
     T, H = 575, 2
@@ -103,7 +128,7 @@ def test_attention_bias_buckets_exact(eng):
         v = torch.zeros(1, H, T, 64)
         n = min(64, T - blk)
         v[0, :, blk:blk + n, :n] = torch.eye(n)
-        got = eng.attention(q.cuda(), k.cuda(), v.cuda(), table.cuda()).cpu().reshape(T, H, 64)
+        got = eng.attention(q.cuda(), k.cuda(), v.cuda(), table.cuda(), precision=precision).cpu().reshape(T, H, 64)
         want = ref_soft[:, :, blk:blk + n].permute(1, 0, 2)
         np.testing.assert_allclose(got[:, :, :n].numpy(), want.numpy(), rtol=1e-5, atol=1e-7)
 

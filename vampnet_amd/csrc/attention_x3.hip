@@ -1,0 +1,227 @@
+// Self-attention with the shared T5 relative-position bias on the bf16 matrix cores at fp32 grade ("bf16x3"), for gfx950.
+//
+// Replaces MultiHeadRelativeAttention.forward's core (vampnet/modules/transformer.py:234-254) when the model runs in the
+// bf16x3 precision:  attn = einsum(q,k)/sqrt(64) + bias[h, bucket(k - q)] ; softmax(dim=keys) ; einsum(attn, v).
+// Same decomposition as attention_f32.hip (flash-style online softmax, both products computed transposed so that every
+// softmax quantity is lane-local, bias from a 2T-1 table in LDS), but both GEMMs run as SIX v_mfma_f32_32x32x16_bf16
+// products of exact three-way operand splits (gemm_x3.hip: x = x0 + x1 + x2 exactly, terms down to 2^-16 of the leading one
+// kept, fp32 accumulation): 6/16 of the fp32-input MFMA's matrix time at the same error class.
+//
+// Operands arrive as planes, written by the QKV GEMM's epilogues (gemm_x3.hip):
+//   q16, k16 : [3 planes][B][H][T][64] bf16 (q pre-multiplied by 1/8 = 1/sqrt(64): a power of two commutes with the split)
+//   vt16     : [3 planes][B][H][ceil(T/32)][64 d][32 keys] bf16 — V TRANSPOSED and blocked by 32-key tile, so that a tile is
+//              one contiguous 4 KiB block (whole cache lines for the LDS-DMA) whose rows are the MFMA A operand of O^T = V^T P^T;
+//              the buffer is zero-filled once, keys >= T of the last tile hold finite values and meet P = 0.
+// Softmax probabilities are split into their three planes in registers (P in [0, 1]: exact).
+//
+// Work decomposition: grid = (ceil(T / (32 NW)), H, B); block = NW waves; wave w owns 32 query columns.
+//   S^T[key][q] = K[key][:] . Q[q][:]      A = K tile rows (LDS), B = Q (registers, loaded once)
+//   O^T[d][q]   = V^T[d][key] . P^T[key][q]  A = V^T tile rows (LDS), B = P (the registers the softmax produced)
+// MFMA row rho of S^T is mapped to key swap_bits_2_3(rho) (the A operand simply reads that K row): a lane (query j = lane & 31,
+// half hh = lane >> 5) then holds keys 16 (r >> 3) + 8 hh + (r & 7), r = 0..15 — for each 16-key step of the second product
+// EIGHT CONSECUTIVE keys, i.e. exactly its k-slots of the B operand, and the V^T operand is one 16-byte LDS read.
+// K/V^T tiles (32 keys: 12 + 12 KiB for the three planes) are double-buffered by LDS-DMA (global_load_lds_dwordx4), one
+// barrier per tile.  LDS images are lane-linear, so the bank swizzles sit on the DMA source address:
+//   K rows are 128 B: slot s of row r lives at s ^ ((r >> 1) & 7);  V^T rows are 64 B: s ^ ((r >> 2) & 3)  (both give every
+//   16-lane ds_read_b128 group 16 distinct 16-byte slots of the 256-byte bank row).
+// Algorithmic FLOPs: 4*T*T*64 per (b,h); executed on the bf16 pipe: 6x that.
+#include "vn_common.h"
+
+#define AX_KT 32                          // keys per tile
+#define AX_PLANE_FLOATS 1024              // one plane tile of K (32 x 128 B) or V^T (64 x 64 B): 4 KiB
+#define AX_STAGE_FLOATS (6 * AX_PLANE_FLOATS)
+
+__device__ __forceinline__ int ax_swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void vn_attention_x3_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
+                                                                    long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
+                                                                    const float* __restrict__ bias_full, float* __restrict__ out,
+                                                                    uint16_t* __restrict__ out16, long plane16, int B, int H, int T) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* bt = smem + 2 * AX_STAGE_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int NT = (T + AX_KT - 1) / AX_KT;
+    const size_t head = (size_t)b * H + h;
+    const uint16_t* Qp = q16 + head * (size_t)T * VN_DHEAD;
+    const uint16_t* Kp = k16 + head * (size_t)T * VN_DHEAD;
+    const uint16_t* Vp = vt16 + head * (size_t)NT * (VN_DHEAD * AX_KT);
+    const int q0 = qb * (NW * 32) + wave * 32;
+    const bool active = q0 < T;                         // waves past the end only help with the DMA and the barriers
+    const int qrow = q0 + l31;
+    const int qrow_c = qrow < T ? qrow : T - 1;
+
+    const int nb = 2 * T - 1;
+    for (int i = tid; i < nb; i += NW * 64) bt[i] = bias_full[(size_t)h * nb + i];
+
+    // Q fragments (B operand of S^T = K Q^T): lane (j, hh) holds Q[q_j][16 step + 8 hh .. + 7] of every plane
+    bf16x8 qf[3][4];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            qf[p][s] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Qp + (size_t)p * plane_qk + (size_t)qrow_c * VN_DHEAD + 16 * s + 8 * hh));
+
+    // LDS-DMA: 24 wave-instructions of 1 KiB per stage (K: 3 planes x 4, each 8 rows x 128 B; V^T: 3 planes x 4, each 16 rows x 64 B)
+    auto stage = [&](int buf, int kt) {
+        float* base = smem + buf * AX_STAGE_FLOATS;
+        const int key0 = kt * AX_KT;
+#pragma unroll
+        for (int i = 0; i < 24 / NW; ++i) {
+            const int q = wave + i * NW;
+            const uint16_t* src;
+            if (q < 12) {
+                const int p = q >> 2, row = 8 * (q & 3) + (lane >> 3);
+                int key = key0 + row;
+                key = key < T ? key : T - 1;
+                src = Kp + (size_t)p * plane_qk + (size_t)key * VN_DHEAD + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+            } else {
+                const int q2 = q - 12;
+                const int p = q2 >> 2, row = 16 * (q2 & 3) + (lane >> 2);
+                src = Vp + (size_t)p * plane_vt + ((size_t)kt * VN_DHEAD + row) * AX_KT + ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(base + q * 256), 16, 0, 0);
+        }
+    };
+
+    const int kr = ax_swap23(l31);                      // K row feeding MFMA row l31
+    const int kOff = kr * 32, kSw = (kr >> 1) & 7;      // floats; 128-byte rows
+    const int vSw = (l31 >> 2) & 3;                     // rows d = 32 dt + l31: (d >> 2) & 3 == (l31 >> 2) & 3
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+
+    stage(0, 0);
+    for (int kt = 0; kt < NT; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of tile kt have landed
+        __syncthreads();                                        // all pieces landed; everybody is done with tile kt - 1
+        if (kt + 1 < NT) stage((kt + 1) & 1, kt + 1);
+        if (!active) continue;
+        const float* Ks = smem + (kt & 1) * AX_STAGE_FLOATS;
+        const float* Vs = Ks + 3 * AX_PLANE_FLOATS;
+
+        // ---- S^T = K . Q^T: four 16-wide d steps x six plane products (smallest terms first)
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 kf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                kf[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Ks + p * AX_PLANE_FLOATS + kOff + ((2 * s + hh) ^ kSw) * 4));
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[2][s], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[0][s], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[1][s], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[1][s], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[0][s], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][s], sacc, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+
+        // ---- online softmax over the tile's 32 keys; lane (j, hh) holds keys 32 kt + 16 (r >> 3) + 8 hh + (r & 7) of query j
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kt * AX_KT + 16 * (r >> 3) + 8 * hh + (r & 7);
+            const int key_c = key < T ? key : T - 1;
+            float x = sacc[r] + bt[key_c - qrow_c + (T - 1)];          // q was pre-scaled by 1/sqrt(64); += bias
+            x = key < T ? x : -INFINITY;
+            sacc[r] = x;
+            mx = fmaxf(mx, x);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);                          // finite: every tile has >= 1 valid key
+        const float alpha = vn_exp_neg(m_run - m_new);                 // first tile: exp(-inf) = 0
+        float lsum = 0.f;
+        bf16x8 pf[3][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x8 pe;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pe[e] = vn_exp_neg(sacc[8 * s + e] - m_new);
+                lsum += pe[e];
+            }
+            vn_split3_x8(pe, pf[0][s], pf[1][s], pf[2][s]);
+        }
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+        // ---- O^T += V^T . P^T: two 32-row d tiles x two 16-key steps x six plane products
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                bf16x8 vf[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    vf[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Vs + p * AX_PLANE_FLOATS + (32 * dt + l31) * 16 + ((2 * s + hh) ^ vSw) * 4));
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[2][s], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], pf[0][s], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf[1][s], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[1][s], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf[0][s], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[0][s], o[dt], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    // ---- finish: the two lanes of a query add their row sums; normalise; store.
+    // accumulator o[dt][r] = O[q_j][d = 32 dt + (r & 3) + 8 (r >> 2) + 4 hh]  (C/D map of the 32x32 MFMA)
+    float l_tot = l_run + __shfl_xor(l_run, 32);
+    if (active && qrow < T) {
+        const float inv = 1.0f / l_tot;
+        const size_t ooff = ((size_t)b * T + qrow) * ((size_t)H * VN_DHEAD) + h * VN_DHEAD + 4 * hh;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // the reference divides (softmax), it does not multiply by a reciprocal: keep the division per element
+                const f32x4 ov = {o[dt][4 * g] / l_tot, o[dt][4 * g + 1] / l_tot, o[dt][4 * g + 2] / l_tot, o[dt][4 * g + 3] / l_tot};
+                (void)inv;
+                const size_t off = ooff + 32 * dt + 8 * g;
+                if (out16) vn_store_bf16x4(out16 + off, plane16, ov);
+                else *(f32x4*)(out + off) = ov;
+            }
+    }
+}
+
+int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16, long plane_qk, const uint16_t* vt16, long plane_vt,
+                           const float* relbias_full, float* out, uint16_t* out16, long plane16, int B, int H, int T, hipStream_t s) {
+    if (B <= 0 || T <= 0) return VN_OK;
+    const size_t lds = (size_t)(2 * AX_STAGE_FLOATS + 2 * T - 1 + 3) * sizeof(float);
+    if (lds > 80 * 1024) return vn_fail(ctx, VN_ERR_INVALID, "attention_x3: T=%s%ld too long for two blocks per CU", "", T);
+    if (!(ctx->attr_mask & VN_ATTR_ATTN_X3)) {
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        ctx->attr_mask |= VN_ATTR_ATTN_X3;
+    }
+    const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
+    // waves per block: 4 (128 queries) unless the last block of every head would be mostly empty
+    static const int forced = [] { const char* e = getenv("VN_ATTN_X3_WAVES"); return e ? atoi(e) : 0; }();
+    int nw = forced == 2 || forced == 4 ? forced : ((T % 128) != 0 && (T % 128) <= 64 ? 2 : 4);
+    if (nw == 4)
+        hipLaunchKernelGGL(vn_attention_x3_kernel<4>, dim3(vn_cdiv(T, 128), H, B), dim3(256), lds, s, q16, k16, plane_qk, vt16, plane_vt,
+                           relbias_full, out, out16, plane16, B, H, T);
+    else
+        hipLaunchKernelGGL(vn_attention_x3_kernel<2>, dim3(vn_cdiv(T, 64), H, B), dim3(128), lds, s, q16, k16, plane_qk, vt16, plane_vt,
+                           relbias_full, out, out16, plane16, B, H, T);
+    vn_prof_post(ctx, pi, s);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}

@@ -185,6 +185,8 @@ extern "C" void vn_model_destroy(vn_model* m) {
     (void)hipFree(m->ksched);
     (void)hipFree(m->y16);
     (void)hipFree(m->g16);
+    (void)hipFree(m->qk16);
+    (void)hipFree(m->vt16);
     delete m;
 }
 
@@ -256,17 +258,38 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
         a.W = bf ? W16(id, layer) : W(m, id, layer);
         a.bf16 = gm; a.a_plane = a_plane; a.w_plane = m->w_plane;
     };
+    // bf16x3: attention on the bf16 matrix cores too (attention_x3.hip); VN_ATTN_X3=0 keeps the fp32-input MFMA kernel (A/B runs)
+    static const bool attn_x3 = [] { const char* e = getenv("VN_ATTN_X3"); return !(e && e[0] == '0'); }();
     for (int l = 0; l < m->L; ++l) {
         // y = RMSNorm(x) ; FiLM = identity (d_cond = 0, transformer.py:554)
         if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM1, l), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr, yp))) return rc;
-        vn_gemm_args a{};
-        operands(a, m->y, m->y16, yp, VN_W_QKV, l);
-        a.C = m->qkv; a.M = M; a.N = 3 * D; a.K = D; a.ldc = 3 * D;
-        a.T = T; a.H = H; a.qkv_plane = plane;
-        if ((rc = vn_launch_gemm_f32(ctx, a, VN_EPI_QKV, s))) return rc;
-        if ((rc = vn_launch_attention(ctx, m->qkv, m->qkv + plane, m->qkv + 2 * plane, m->bias_full, m->y, B, H, T, s,
-                                      bf ? m->y16 : nullptr, yp)))
-            return rc;
+        if (gm == 2 && attn_x3) {
+            // q (x 1/8) and k as split planes, head-major; V^T (blocked by 32-key tile) from the swapped product W_v . y^T
+            vn_gemm_args a{};
+            operands(a, m->y, m->y16, yp, VN_W_QKV, l);
+            a.C16 = m->qk16; a.c_plane = m->qk_plane; a.M = M; a.N = 2 * D; a.K = D; a.ldc = 2 * D;
+            a.T = T; a.H = H; a.qkv_plane = plane;
+            if ((rc = vn_launch_gemm_f32(ctx, a, VN_EPI_QK3, s))) return rc;
+            vn_gemm_args v{};
+            v.A = (const float*)(m->blob16 + vn_tensor_offset(&m->d, VN_W_QKV, l) + 2L * D * D);
+            v.W = (const float*)m->y16;
+            v.bf16 = 2; v.a_plane = m->w_plane; v.w_plane = yp;
+            v.C16 = m->vt16; v.c_plane = m->vt_plane; v.M = D; v.N = M; v.K = D; v.ldc = M;
+            v.T = T; v.H = H;
+            if ((rc = vn_launch_gemm_f32(ctx, v, VN_EPI_VT3, s))) return rc;
+            if ((rc = vn_launch_attention_x3(ctx, m->qk16, m->qk16 + plane, m->qk_plane, m->vt16, m->vt_plane, m->bias_full, nullptr,
+                                             m->y16, yp, B, H, T, s)))
+                return rc;
+        } else {
+            vn_gemm_args a{};
+            operands(a, m->y, m->y16, yp, VN_W_QKV, l);
+            a.C = m->qkv; a.M = M; a.N = 3 * D; a.K = D; a.ldc = 3 * D;
+            a.T = T; a.H = H; a.qkv_plane = plane;
+            if ((rc = vn_launch_gemm_f32(ctx, a, VN_EPI_QKV, s))) return rc;
+            if ((rc = vn_launch_attention(ctx, m->qkv, m->qkv + plane, m->qkv + 2 * plane, m->bias_full, m->y, B, H, T, s,
+                                          bf ? m->y16 : nullptr, yp)))
+                return rc;
+        }
         vn_gemm_args o{};
         operands(o, m->y, m->y16, yp, VN_W_WO, l);
         o.C = m->x; o.M = M; o.N = D; o.K = D; o.ldc = D;
@@ -389,6 +412,15 @@ static int set_bf16_planes(vn_model* m, const void* blob16_dev, long w_plane) {
     int rc;        // the bf16 A-operand images are sized for three planes in either mode (graphs keep pointing at them)
     if (!m->y16 && (rc = dev_alloc(m->ctx, &m->y16, (size_t)3 * m->max_rows * m->D))) return rc;
     if (!m->g16 && (rc = dev_alloc(m->ctx, &m->g16, (size_t)3 * m->max_rows * 2 * m->D))) return rc;
+    if (w_plane > 0 && !m->qk16) {        // bf16x3: attention operands as planes (attention_x3.hip)
+        m->qk_plane = 2 * m->max_rows * (long)m->D;
+        m->vt_plane = (long)m->d.max_batch * m->H * ((m->d.max_T + 31) / 32) * (VN_DHEAD * 32);
+        if ((rc = dev_alloc(m->ctx, &m->qk16, (size_t)3 * m->qk_plane + 32 * VN_DHEAD))) return rc;
+        if ((rc = dev_alloc(m->ctx, &m->vt16, (size_t)3 * m->vt_plane))) return rc;
+        // keys >= T of a head's last tile are multiplied by P = 0: they must be finite, so start from zeros
+        VN_HIP_CHECK(m->ctx, hipMemset(m->vt16, 0, (size_t)3 * m->vt_plane * sizeof(uint16_t)));
+        VN_HIP_CHECK(m->ctx, hipMemset(m->qk16, 0, ((size_t)3 * m->qk_plane + 32 * VN_DHEAD) * sizeof(uint16_t)));
+    }
     m->blob16 = (const uint16_t*)blob16_dev;
     m->w_plane = w_plane;
     return VN_OK;
@@ -552,6 +584,59 @@ extern "C" int vn_attention_bf16(vn_ctx* ctx, const float* q, const float* k, co
     (void)hipStreamSynchronize(s);
     (void)hipFree(full);
     (void)hipFree(lut_d);
+    return rc;
+}
+
+// bf16x3 attention as a single op (tests): fp32 q, k, v [B][H][T][64] are split / transposed here exactly as the QKV GEMM
+// epilogues do (q x 1/8; V^T blocked by 32-key tile), then attention_x3.hip runs; out fp32 [B][T][H*64]
+__global__ void vn_attn_x3_prep_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                       uint16_t* __restrict__ qk16, long plane_qk, uint16_t* __restrict__ vt16, long plane_vt,
+                                       long heads, int T) {
+    const long n = heads * T * VN_DHEAD;
+    const int nt = (T + 31) >> 5;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        const int d = (int)(i & 63);
+        const long ht = i >> 6;
+        const long hd = ht / T;
+        const int t = (int)(ht - hd * T);
+        uint16_t a, b, c;
+        vn_split3(q[i] * 0.125f, a, b, c);
+        qk16[i] = a; qk16[i + plane_qk] = b; qk16[i + 2 * plane_qk] = c;
+        vn_split3(k[i], a, b, c);
+        qk16[n + i] = a; qk16[n + i + plane_qk] = b; qk16[n + i + 2 * plane_qk] = c;
+        vn_split3(v[i], a, b, c);
+        const long o = ((hd * nt + (t >> 5)) * VN_DHEAD + d) * 32 + (t & 31);
+        vt16[o] = a; vt16[o + plane_vt] = b; vt16[o + 2 * plane_vt] = c;
+    }
+}
+
+extern "C" int vn_attention_bf16x3(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                                   float* out, int B, int H, int T, int num_buckets, int max_distance, void* stream) {
+    if (!ctx || !q || !k || !v || !rel_bias || !out || T <= 0 || H <= 0 || B <= 0) return VN_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const long heads = (long)B * H, n = heads * T * VN_DHEAD;
+    const long plane_qk = 2 * n, plane_vt = heads * ((T + 31) / 32) * (VN_DHEAD * 32);
+    float* full = nullptr;
+    int32_t* lut_d = nullptr;
+    uint16_t *qk16 = nullptr, *vt16 = nullptr;
+    const int nb = 2 * T - 1;
+    int rc = VN_OK;
+    if (hipMalloc((void**)&full, (size_t)H * nb * sizeof(float)) != hipSuccess || hipMalloc((void**)&lut_d, (size_t)nb * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void**)&qk16, ((size_t)3 * plane_qk + 32 * VN_DHEAD) * 2) != hipSuccess || hipMalloc((void**)&vt16, (size_t)3 * plane_vt * 2) != hipSuccess)
+        rc = vn_fail(ctx, VN_ERR_OOM, "attention_bf16x3: scratch allocation failed%s", "");
+    std::vector<int32_t> lut(nb);
+    vn_bucket_lut_host(T, num_buckets, max_distance, lut.data());
+    if (rc == VN_OK && hipMemcpy(lut_d, lut.data(), nb * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) rc = VN_ERR_HIP;
+    if (rc == VN_OK && (hipMemsetAsync(vt16, 0, (size_t)3 * plane_vt * 2, s) != hipSuccess ||
+                        hipMemsetAsync(qk16, 0, ((size_t)3 * plane_qk + 32 * VN_DHEAD) * 2, s) != hipSuccess))
+        rc = VN_ERR_HIP;
+    if (rc == VN_OK) rc = vn_launch_bias_expand(ctx, rel_bias, lut_d, full, H, T, s);
+    if (rc == VN_OK) {
+        hipLaunchKernelGGL(vn_attn_x3_prep_kernel, dim3(1024), dim3(256), 0, s, q, k, v, qk16, plane_qk, vt16, plane_vt, heads, T);
+        rc = vn_launch_attention_x3(ctx, qk16, qk16 + n, plane_qk, vt16, plane_vt, full, out, nullptr, 0, B, H, T, s);
+    }
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(full); (void)hipFree(lut_d); (void)hipFree(qk16); (void)hipFree(vt16);
     return rc;
 }
 

@@ -130,6 +130,26 @@ __device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 
                         const int hd = rem >> 6, d = rem & 63;
                         const int b = row / p.T, t = row - b * p.T;
                         p.C[which * p.qkv_plane + (((size_t)b * p.H + hd) * p.T + t) * VN_DHEAD + d] = v;
+                    } else if constexpr (EPI == VN_EPI_QK3) {
+                        // columns [0, D) = q (x 1/sqrt(64), exact), [D, 2D) = k: split planes, head-major [which][b][h][t][64]
+                        const int D = p.H * VN_DHEAD;
+                        const int which = col >= D ? 1 : 0, rem = col - which * D;
+                        const int hd = rem >> 6, d = rem & 63;
+                        const int b = row / p.T, t = row - b * p.T;
+                        uint16_t t0, t1, t2;
+                        vn_split3(which ? v : v * 0.125f, t0, t1, t2);
+                        uint16_t* dst = p.C16 + which * p.qkv_plane + (((size_t)b * p.H + hd) * p.T + t) * VN_DHEAD + d;
+                        dst[0] = t0; dst[p.c_plane] = t1; dst[2 * p.c_plane] = t2;
+                    } else if constexpr (EPI == VN_EPI_VT3) {
+                        // swapped product: row = feature (head hd, d), col = token (b, t) -> V^T blocked by 32-key tile:
+                        // [b][h][t / 32][d][t % 32]
+                        const int hd = row >> 6, d = row & 63;
+                        const int b = col / p.T, t = col - b * p.T;
+                        const int nt = (p.T + 31) >> 5;
+                        uint16_t t0, t1, t2;
+                        vn_split3(v, t0, t1, t2);
+                        uint16_t* dst = p.C16 + ((((size_t)b * p.H + hd) * nt + (t >> 5)) * VN_DHEAD + d) * 32 + (t & 31);
+                        dst[0] = t0; dst[p.c_plane] = t1; dst[2 * p.c_plane] = t2;
                     }
                 }
             }
@@ -460,14 +480,14 @@ static int x3_env(const char* name, int dflt) {
 }
 
 // tuning / test hooks (process-global): tile height 128 / 256, stream-K on / off, forced split-K of the data-parallel form,
-// ablation bits.  Defaults: VN_X3_BM (128), VN_X3_SK (1).
+// ablation bits.  Defaults: VN_X3_BM (128), VN_X3_SK (0: see the file header).
 static int g_x3_bm = 0, g_x3_sk = -1, g_x3_split = -2, g_x3_abl = -1;
 static int x3_bm() {
     static const int bm = x3_env("VN_X3_BM", 128) == 256 ? 256 : 128;
     return g_x3_bm ? g_x3_bm : bm;
 }
 static bool x3_sk() {
-    static const int sk = x3_env("VN_X3_SK", 1);
+    static const int sk = x3_env("VN_X3_SK", 0);
     return (g_x3_sk >= 0 ? g_x3_sk : sk) != 0;
 }
 extern "C" int vn_debug_x3_config(int bm, int stream_k, int splitk, int abl) {
@@ -598,14 +618,16 @@ static int x3_attrs_abl(vn_ctx* ctx) {
 int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: empty problem%s", "");
     if (a.K % X3_KT) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: K=%s%ld must be a multiple of 32", "", a.K);
-    if (a.N % 64) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: N=%s%ld must be a multiple of 64", "", a.N);
+    if (a.N % 64 && epilogue != VN_EPI_VT3)       // (columns >= N are clamped on load and masked on store; GEGLU pairs need 64)
+        return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: N=%s%ld must be a multiple of 64", "", a.N);
     if (a.a_plane <= 0 || a.w_plane <= 0 || (a.a_plane & 7) || (a.w_plane & 7))
         return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: plane strides must be positive multiples of 8 elements%s", "");
     if (((uintptr_t)a.A | (uintptr_t)a.W) & 15) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: operands must be 16-byte aligned%s", "");
     if (!(ctx->attr_mask & VN_ATTR_GEMM_X3)) {
         int rc;
         if ((rc = x3_attrs<VN_EPI_STORE>(ctx)) || (rc = x3_attrs<VN_EPI_BIAS>(ctx)) || (rc = x3_attrs<VN_EPI_RESIDUAL>(ctx)) ||
-            (rc = x3_attrs<VN_EPI_GEGLU>(ctx)) || (rc = x3_attrs<VN_EPI_QKV>(ctx)))
+            (rc = x3_attrs<VN_EPI_GEGLU>(ctx)) || (rc = x3_attrs<VN_EPI_QKV>(ctx)) || (rc = x3_attrs<VN_EPI_QK3>(ctx)) ||
+            (rc = x3_attrs<VN_EPI_VT3>(ctx)))
             return rc;
         if ((rc = x3_attrs_abl<1, 1>(ctx)) || (rc = x3_attrs_abl<1, 2>(ctx)) || (rc = x3_attrs_abl<1, 3>(ctx)) ||
             (rc = x3_attrs_abl<2, 1>(ctx)) || (rc = x3_attrs_abl<2, 2>(ctx)) || (rc = x3_attrs_abl<2, 3>(ctx)) ||
@@ -623,6 +645,10 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
             if (a.C16 && a.c_plane <= 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3/geglu: C16 needs c_plane%s", "");
             return x3_launch<VN_EPI_GEGLU>(ctx, a, s);
         case VN_EPI_QKV: return x3_launch<VN_EPI_QKV>(ctx, a, s);
+        case VN_EPI_QK3:
+        case VN_EPI_VT3:
+            if (!a.C16 || a.c_plane <= 0 || a.T <= 0 || a.H <= 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: plane epilogue needs C16 / c_plane / T / H%s", "");
+            return epilogue == VN_EPI_QK3 ? x3_launch<VN_EPI_QK3>(ctx, a, s) : x3_launch<VN_EPI_VT3>(ctx, a, s);
     }
     return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: unknown epilogue %s%ld", "", epilogue);
 }

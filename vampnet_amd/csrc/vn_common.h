@@ -12,12 +12,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// fp32 -> bf16, round to nearest even (what torch's .to(bfloat16) does); NaN not expected on this path
-__device__ __forceinline__ uint16_t vn_f32_to_bf16(float f) {
-    unsigned u = __builtin_bit_cast(unsigned, f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+// fp32 -> bf16, round to nearest even (what torch's .to(bfloat16) does): the native conversion, v_cvt_pk_bf16_f32 on gfx950
+// (a third of the integer-arithmetic form's instructions); NaN not expected on this path
+__device__ __forceinline__ uint16_t vn_f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 
 __device__ __forceinline__ float vn_bf16_to_f32(uint16_t b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
 
@@ -28,6 +27,13 @@ __device__ __forceinline__ void vn_split3(float x, uint16_t& p0, uint16_t& p1, u
     const float r1 = x - vn_bf16_to_f32(p0);
     p1 = vn_f32_to_bf16(r1);
     p2 = vn_f32_to_bf16(r1 - vn_bf16_to_f32(p1));
+}
+// eight values at once (the B operand of one MFMA k-step): planes as packed bf16x8
+__device__ __forceinline__ void vn_split3_x8(const f32x8& x, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+    p0 = __builtin_convertvector(x, bf16x8);
+    const f32x8 r1 = x - __builtin_convertvector(p0, f32x8);
+    p1 = __builtin_convertvector(r1, bf16x8);
+    p2 = __builtin_convertvector(r1 - __builtin_convertvector(p1, f32x8), bf16x8);
 }
 // four consecutive values -> one 8-byte store per plane; plane == 0: single bf16 plane (fast mode)
 __device__ __forceinline__ void vn_store_bf16x4(uint16_t* dst, long plane, const f32x4& o) {
@@ -150,7 +156,7 @@ struct vn_ctx {
     // process may hold contexts on several)
     unsigned attr_mask;
 };
-enum { VN_ATTR_ATTN = 1u, VN_ATTR_ATTN_TRAIN = 2u, VN_ATTR_REMASK = 4u, VN_ATTR_MT_JUMP = 8u, VN_ATTR_GEMM_X3 = 16u };
+enum { VN_ATTR_ATTN = 1u, VN_ATTR_ATTN_TRAIN = 2u, VN_ATTR_REMASK = 4u, VN_ATTR_MT_JUMP = 8u, VN_ATTR_GEMM_X3 = 16u, VN_ATTR_ATTN_X3 = 32u };
 
 // bracket a launch with events when profiling is on (no-ops otherwise)
 static inline int vn_prof_pre(vn_ctx* ctx, int cls, double flops, hipStream_t s, double bytes = 0.0) {
@@ -191,7 +197,9 @@ static inline int vn_fail(vn_ctx* ctx, int code, const char* fmt, const char* a 
 static inline int vn_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---- launchers implemented in the .hip files ------------------------------------------------
-enum { VN_EPI_STORE = 0, VN_EPI_BIAS = 1, VN_EPI_RESIDUAL = 2, VN_EPI_GEGLU = 3, VN_EPI_QKV = 4 };
+// QK3 / VT3 (gemm_x3.hip only): the operands of attention_x3.hip as split planes — q (x 1/8) and k head-major, V transposed
+// and blocked by 32-key tile (computed by the SWAPPED product W_v . y^T: output rows = features, columns = tokens)
+enum { VN_EPI_STORE = 0, VN_EPI_BIAS = 1, VN_EPI_RESIDUAL = 2, VN_EPI_GEGLU = 3, VN_EPI_QKV = 4, VN_EPI_QK3 = 5, VN_EPI_VT3 = 6 };
 
 struct vn_gemm_args {
     const float* A;      // [M][K] row-major, lda = K
@@ -220,6 +228,10 @@ int vn_launch_embed(vn_ctx* ctx, const int32_t* codes, const float* tables, cons
                     float* x, int B, int C, int T, int V1, int latent, int D, hipStream_t s);
 int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* relbias_full,
                         float* out, int B, int H, int T, hipStream_t s, uint16_t* out16 = nullptr, long plane16 = 0);
+// bf16x3 attention (attention_x3.hip): q16 / k16 planes [3][B][H][T][64] (plane_qk elements apart, q pre-scaled by 1/8),
+// vt16 planes [3][B][H][ceil(T/32)][64][32] (plane_vt apart); out fp32 [B][T][H*64] or out16 split planes (plane16 apart)
+int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16, long plane_qk, const uint16_t* vt16, long plane_vt,
+                           const float* relbias_full, float* out, uint16_t* out16, long plane16, int B, int H, int T, hipStream_t s);
 // expands [num_buckets][H] into per-head tables over rel = key - query in [-(T-1), T-1]: out[h][rel + T - 1]
 void vn_bucket_lut_host(int T, int num_buckets, int max_distance, int32_t* lut /* [2T-1] */);
 int vn_launch_bias_expand(vn_ctx* ctx, const float* rel_bias, const int32_t* lut_dev, float* out, int H, int T,
