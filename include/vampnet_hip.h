@@ -371,6 +371,9 @@ int vn_debug_gemm_config(int bm, int bn, int order);
  * data-parallel work distribution (-1 = VN_X3_SK / default 1); splitk (data-parallel form only) 0/1 off, 2/4 forced, -1 =
  * cost model; abl = ablation bits (tuning; results invalid), -1 = none                                                    */
 int vn_debug_x3_config(int bm, int stream_k, int splitk, int abl);
+/* average duration (us) of `iters` launches of the bf16x3 attention kernel alone (planes prepared outside the timed region) */
+int vn_debug_attention_x3_time(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias, float* out,
+                               int B, int H, int T, int iters, float* avg_us, void* stream);
 
 #ifdef __cplusplus
 }

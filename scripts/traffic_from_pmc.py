@@ -1,22 +1,31 @@
-"""profiles/r01_pmc_{fetch,write}_size.txt (rocprofv3 --pmc passes of `bench.py --steps 1`) -> profiles/r01_traffic.json:
-fabric bytes per launch of the dominant kernel family (vn_gemm_f32[_sk]_kernel), corrected as the MI355X guide
-prescribes: FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at half size (x2).
-These are L2-miss requests to the fabric: Infinity-Cache (MALL) hits are included, so this is an UPPER bound on HBM bytes."""
-import json, re, sys
-def parse(path):
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summaries of `python bench.py` (scripts/gpu_bench_prof.sh -> pmc_summary.py) ->
+profiles/<out>.json: fabric bytes per launch of the dominant kernel family, corrected as MI355X_MICROARCH.md prescribes
+(FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at half size: x2).  These are L2-miss
+requests to the fabric: Infinity-Cache (MALL) hits are included, so this is an UPPER bound on HBM bytes.
+usage: traffic_from_pmc.py <fetch_summary.txt> <write_summary.txt> <kernel substring> <out.json>"""
+import json
+import re
+import sys
+
+
+def parse(path, pat):
     tot, n = 0.0, 0
     for line in open(path):
         m = re.match(r"(.*?)\s+launches=\s*(\d+)\s+mean=\s*([\d.]+)\s+total=\s*([\d.]+)", line)
-        if m and "vn_gemm_f32" in m.group(1):
-            n += int(m.group(2)); tot += float(m.group(4))
+        if m and pat in m.group(1):
+            n += int(m.group(2))
+            tot += float(m.group(4))
     return tot, n
-f, nf = parse("profiles/r01_pmc_fetch_size.txt")
-w, nw = parse("profiles/r01_pmc_write_size.txt")
-assert nf == nw and nf > 0
-out = {"kernel": "vn_gemm_f32[_sk]_kernel", "launches": nf, "fetch_kib_raw": f, "write_kib_raw": w,
+
+
+fetch, write, pat, out_path = sys.argv[1:5]
+f, nf = parse(fetch, pat)
+w, nw = parse(write, pat)
+assert nf == nw and nf > 0, (nf, nw)
+out = {"kernel": pat, "launches": nf, "fetch_kib_raw": f, "write_kib_raw": w,
        "bytes_per_launch": (2 * f + w) * 1024 / nf, "read_bytes_per_launch": 2 * f * 1024 / nf,
        "write_bytes_per_launch": w * 1024 / nf,
-       "note": "L2->fabric traffic incl. Infinity-Cache hits (FETCH_SIZE x2 gfx950 correction); A+W+C of every GEMM of a "
-               "forward (<= 120 MB) fit the 256 MB Infinity Cache, so HBM traffic itself is close to algorithmic"}
-json.dump(out, open("profiles/r01_traffic.json", "w"), indent=1)
+       "note": "L2->fabric traffic incl. Infinity-Cache hits (FETCH_SIZE x2 gfx950 correction), averaged over the GEMM launches "
+               "of one vamp() step of `python bench.py`"}
+json.dump(out, open(out_path, "w"), indent=1)
 print(out)

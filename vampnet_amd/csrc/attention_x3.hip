@@ -34,7 +34,7 @@
 __device__ __forceinline__ int ax_swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64, 2) void vn_attention_x3_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
+__global__ __launch_bounds__(NW * 64, NW == 6 ? 3 : 2) void vn_attention_x3_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
                                                                     long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
                                                                     const float* __restrict__ bias_full, float* __restrict__ out,
                                                                     uint16_t* __restrict__ out16, long plane16, int B, int H, int T) {
@@ -130,14 +130,24 @@ __global__ __launch_bounds__(NW * 64, 2) void vn_attention_x3_kernel(const uint1
 
         // ---- online softmax over the tile's 32 keys; lane (j, hh) holds keys 32 kt + 16 (r >> 3) + 8 hh + (r & 7) of query j
         float mx = -INFINITY;
+        const float* brow = bt + (kt * AX_KT + 8 * hh - qrow_c + (T - 1));     // bias of key 32 kt + 8 hh for this query
+        if (kt + 1 < NT) {                                             // every key of the tile is < T
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kt * AX_KT + 16 * (r >> 3) + 8 * hh + (r & 7);
-            const int key_c = key < T ? key : T - 1;
-            float x = sacc[r] + bt[key_c - qrow_c + (T - 1)];          // q was pre-scaled by 1/sqrt(64); += bias
-            x = key < T ? x : -INFINITY;
-            sacc[r] = x;
-            mx = fmaxf(mx, x);
+            for (int r = 0; r < 16; ++r) {
+                const float x = sacc[r] + brow[16 * (r >> 3) + (r & 7)];   // q was pre-scaled by 1/sqrt(64); += bias
+                sacc[r] = x;
+                mx = fmaxf(mx, x);
+            }
+        } else {                                                       // last tile: keys >= T are masked out
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * AX_KT + 16 * (r >> 3) + 8 * hh + (r & 7);
+                const int key_c = key < T ? key : T - 1;
+                float x = sacc[r] + bt[key_c - qrow_c + (T - 1)];
+                x = key < T ? x : -INFINITY;
+                sacc[r] = x;
+                mx = fmaxf(mx, x);
+            }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);                          // finite: every tile has >= 1 valid key
@@ -156,10 +166,12 @@ __global__ __launch_bounds__(NW * 64, 2) void vn_attention_x3_kernel(const uint1
         }
         l_run = l_run * alpha + lsum;
         m_run = m_new;
+        if (!__all(alpha == 1.0f)) {                                   // exp(0) = 1 exactly: skipping the multiply changes no bit
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
 
         // ---- O^T += V^T . P^T: two 32-row d tiles x two 16-key steps x six plane products
         __builtin_amdgcn_s_setprio(1);
@@ -209,13 +221,32 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
     if (!(ctx->attr_mask & VN_ATTR_ATTN_X3)) {
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_x3_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         ctx->attr_mask |= VN_ATTR_ATTN_X3;
     }
     const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
-    // waves per block: 4 (128 queries) unless the last block of every head would be mostly empty
+    // waves per block (32 queries each).  Blocks per CU: LDS allows 3 (2 x 24 KiB stages + the bias table), registers allow 12
+    // waves.  Cost of a choice = rounds x waves per SIMD while a round runs; ties go to the larger block (fewer K / V^T reads).
+    // T = 575, B = 8: six waves = 3 blocks per head with no idle wave, 480 blocks = ONE round on 2 x 256 slots (four waves: 800
+    // blocks on 768 slots = two rounds).
     static const int forced = [] { const char* e = getenv("VN_ATTN_X3_WAVES"); return e ? atoi(e) : 0; }();
-    int nw = forced == 2 || forced == 4 ? forced : ((T % 128) != 0 && (T % 128) <= 64 ? 2 : 4);
-    if (nw == 4)
+    int nw = forced;
+    if (nw != 2 && nw != 4 && nw != 6) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) cus = 256;
+        long best = -1;
+        for (int c = 2; c <= 6; c += 2) {
+            const long blocks = (long)vn_cdiv(T, 32 * c) * H * B;
+            const int bpc = c == 6 ? 2 : 3;
+            const long per_cu = (blocks + cus - 1) / cus < bpc ? (blocks + cus - 1) / cus : bpc;
+            const long cost = ((blocks + (long)cus * bpc - 1) / ((long)cus * bpc)) * ((per_cu * c + 3) / 4);
+            if (best < 0 || cost <= best) { best = cost; nw = c; }
+        }
+    }
+    if (nw == 6)
+        hipLaunchKernelGGL(vn_attention_x3_kernel<6>, dim3(vn_cdiv(T, 192), H, B), dim3(384), lds, s, q16, k16, plane_qk, vt16, plane_vt,
+                           relbias_full, out, out16, plane16, B, H, T);
+    else if (nw == 4)
         hipLaunchKernelGGL(vn_attention_x3_kernel<4>, dim3(vn_cdiv(T, 128), H, B), dim3(256), lds, s, q16, k16, plane_qk, vt16, plane_vt,
                            relbias_full, out, out16, plane16, B, H, T);
     else

@@ -610,10 +610,9 @@ __global__ void vn_attn_x3_prep_kernel(const float* __restrict__ q, const float*
     }
 }
 
-extern "C" int vn_attention_bf16x3(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
-                                   float* out, int B, int H, int T, int num_buckets, int max_distance, void* stream) {
-    if (!ctx || !q || !k || !v || !rel_bias || !out || T <= 0 || H <= 0 || B <= 0) return VN_ERR_INVALID;
-    hipStream_t s = (hipStream_t)stream;
+// shared by the single-op entry and the timing hook: scratch, bias table, plane images; *launches of the kernel only
+static int attention_x3_run(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias, float* out, int B,
+                            int H, int T, int num_buckets, int max_distance, int iters, float* avg_us, hipStream_t s) {
     const long heads = (long)B * H, n = heads * T * VN_DHEAD;
     const long plane_qk = 2 * n, plane_vt = heads * ((T + 31) / 32) * (VN_DHEAD * 32);
     float* full = nullptr;
@@ -635,9 +634,36 @@ extern "C" int vn_attention_bf16x3(vn_ctx* ctx, const float* q, const float* k, 
         hipLaunchKernelGGL(vn_attn_x3_prep_kernel, dim3(1024), dim3(256), 0, s, q, k, v, qk16, plane_qk, vt16, plane_vt, heads, T);
         rc = vn_launch_attention_x3(ctx, qk16, qk16 + n, plane_qk, vt16, plane_vt, full, out, nullptr, 0, B, H, T, s);
     }
+    if (rc == VN_OK && iters > 0 && avg_us) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < iters && rc == VN_OK; ++i)
+            rc = vn_launch_attention_x3(ctx, qk16, qk16 + n, plane_qk, vt16, plane_vt, full, out, nullptr, 0, B, H, T, s);
+        (void)hipEventRecord(e1, s);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *avg_us = 1e3f * ms / iters;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
     (void)hipStreamSynchronize(s);
     (void)hipFree(full); (void)hipFree(lut_d); (void)hipFree(qk16); (void)hipFree(vt16);
     return rc;
+}
+
+extern "C" int vn_attention_bf16x3(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                                   float* out, int B, int H, int T, int num_buckets, int max_distance, void* stream) {
+    if (!ctx || !q || !k || !v || !rel_bias || !out || T <= 0 || H <= 0 || B <= 0) return VN_ERR_INVALID;
+    return attention_x3_run(ctx, q, k, v, rel_bias, out, B, H, T, num_buckets, max_distance, 0, nullptr, (hipStream_t)stream);
+}
+
+// tuning hook (scripts/attn_bench.py): average duration of `iters` back-to-back launches of the bf16x3 attention KERNEL
+// (operand planes prepared once, outside the timed region)
+extern "C" int vn_debug_attention_x3_time(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                                          float* out, int B, int H, int T, int iters, float* avg_us, void* stream) {
+    if (!ctx || !q || !k || !v || !rel_bias || !out || !avg_us || T <= 0 || H <= 0 || B <= 0 || iters <= 0) return VN_ERR_INVALID;
+    return attention_x3_run(ctx, q, k, v, rel_bias, out, B, H, T, 32, 128, iters, avg_us, (hipStream_t)stream);
 }
 
 extern "C" int vn_rmsnorm_f32(vn_ctx* ctx, const float* x, const float* w, float* y, int rows, int D, float eps,

@@ -32,13 +32,18 @@
 //   * Epilogues as in gemm_f32.hip (store / bias / residual / GEGLU gate / QKV head-major scatter); the GEGLU result is
 //     written as three planes again (it is only ever the A operand of the next GEMM).
 //   * rows >= M and columns >= N are clamped on load and masked on store.
-// Work distribution: "stream-K" (default).  The launch is one persistent block per CU; the tile x k-tile space, walked
-// tile after tile in an XCD-aware order (8-row tile groups, one contiguous eighth of the walk per XCD), is cut into 256
-// EQUAL contiguous ranges.  A block whose range covers a whole tile finishes it with the fused epilogue; the at most two
-// tiles it shares with its neighbours are stored as raw fp32 accumulator images ("slabs", fragment order, 16-byte
-// coalesced) and vn_gemm_x3_fixup_kernel adds a tile's slabs in k order and runs the same epilogue — deterministic, no
-// flags, no atomics.  This removes the round quantisation of a data-parallel launch (1080 tiles on 256 CUs = 5 rounds for
-// 4.2 rounds of work).  The data-parallel form (one block per tile) is kept for A/B runs (vn_debug_x3_config).
+// Work distribution, by shape (x3_sk below):
+//   * data-parallel: one block per output tile, XCD-aware tile walk (8-row tile groups, one contiguous eighth of the walk per
+//     XCD); the store / residual epilogues of badly filling shapes are split along K in two passes (split images to a
+//     workspace, vn_splitk_reduce_kernel adds them in fixed order).  Default for everything that fills the chip: with every
+//     CU busy the kernel sits at the chip's power limit (~1.75 GHz, GRBM_GUI_ACTIVE / duration), a partly filled last round
+//     runs at a higher clock, and an evenly balanced launch measured no faster (profiles/r02_gemm_x3_streamk_v2_vs_dp.txt).
+//   * "stream-K" for launches that leave more than a quarter of the CUs without a tile: one persistent block per CU; inside an
+//     XCD's chunk of the walk the blocks take whole tiles round-robin (so co-running blocks work on adjacent tiles and share
+//     the A / W panels in L2) and the left-over tiles are cut along k into equal contiguous ranges.  A block that covers a
+//     whole tile finishes it with the fused epilogue; partial tiles are stored as raw fp32 accumulator images ("slabs",
+//     fragment order, 16-byte coalesced) and vn_gemm_x3_fixup_kernel adds a tile's slabs in k order and runs the same
+//     epilogue — deterministic, no flags, no atomics.
 // On the GPU the result is within 7.5e-6 of float64 at 4600 x 3840 x 1280 (the fp32-input MFMA kernel: 9e-6).
 #include <stdlib.h>
 #include "vn_common.h"
@@ -480,15 +485,22 @@ static int x3_env(const char* name, int dflt) {
 }
 
 // tuning / test hooks (process-global): tile height 128 / 256, stream-K on / off, forced split-K of the data-parallel form,
-// ablation bits.  Defaults: VN_X3_BM (128), VN_X3_SK (0: see the file header).
+// ablation bits.  Defaults: VN_X3_BM (128), VN_X3_SK (-1: by shape).
 static int g_x3_bm = 0, g_x3_sk = -1, g_x3_split = -2, g_x3_abl = -1;
 static int x3_bm() {
     static const int bm = x3_env("VN_X3_BM", 128) == 256 ? 256 : 128;
     return g_x3_bm ? g_x3_bm : bm;
 }
-static bool x3_sk() {
-    static const int sk = x3_env("VN_X3_SK", 0);
-    return (g_x3_sk >= 0 ? g_x3_sk : sk) != 0;
+// Work distribution.  -1 (default) = by shape: stream-K where one data-parallel round would leave more than a quarter of the CUs
+// without a tile and the epilogue has no split-K form (the one- / two-sequence QKV, GEGLU and classifier GEMMs: 51 vs 59 us
+// on the B = 1 QKV shape); data-parallel (+ two-pass split-K for the store / residual epilogues) everywhere else — with every
+// CU busy the chip sits at its power limit and an evenly balanced launch gains nothing there
+// (profiles/r02_gemm_x3_streamk_v2_vs_dp.txt: QKV B = 8 246 vs 252 us, Wo / W1 / W2 slower by the fix-up pass).
+static bool x3_sk(int ntiles, int cus, bool has_splitk) {
+    static const int sk_env = x3_env("VN_X3_SK", -1);
+    const int sk = g_x3_sk >= 0 ? g_x3_sk : sk_env;
+    if (sk >= 0) return sk != 0;
+    return !has_splitk && 4 * ntiles < 3 * cus;
 }
 extern "C" int vn_debug_x3_config(int bm, int stream_k, int splitk, int abl) {
     if (bm != 0 && bm != 128 && bm != 256) return VN_ERR_INVALID;
@@ -565,7 +577,7 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
                          ((EPI == VN_EPI_GEGLU && a.C16) ? 6.0 : 4.0) * (double)a.M * n_out * (EPI == VN_EPI_RESIDUAL ? 2 : 1);
     const int pi = vn_prof_pre(ctx, 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);       // algorithmic (fp32-equivalent) flops
     int rc = VN_OK;
-    const bool sk = x3_sk();
+    const bool sk = x3_sk(vn_cdiv(a.M, x3_bm()) * vn_cdiv(a.N, X3_BN), x3_num_cus(ctx), EPI == VN_EPI_STORE || EPI == VN_EPI_RESIDUAL);
     bool done = false;
     if constexpr (EPI == VN_EPI_STORE) {
         static const int abl_env = x3_env("VN_X3_ABL", 0) & 7;             // ablations (tuning only; results invalid)
