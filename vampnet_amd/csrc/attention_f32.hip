@@ -40,7 +40,16 @@ __global__ __launch_bounds__(256) void vn_attention_kernel(const float* __restri
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
-    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // 1-D XCD-aware grid: every XCD (blockIdx % 8) walks a contiguous eighth of the (b, h, q-block) list, so the q-blocks of a
+    // head share its K / V in ONE L2 instead of fetching them on all eight
+    int lid;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int qq = nwg >> 3, rr = nwg & 7;
+        lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int nqb = (T + 63) / 64;
+    const int qb = lid % nqb, h = (lid / nqb) % H, b = lid / (nqb * H);
     const size_t headoff = ((size_t)b * H + h) * (size_t)T * VN_DHEAD;
     const float* Q = q + headoff;
     const float* K = k + headoff;
@@ -219,7 +228,16 @@ __global__ __launch_bounds__(256) void vn_attention_bf16_kernel(const float* __r
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
-    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // 1-D XCD-aware grid: every XCD (blockIdx % 8) walks a contiguous eighth of the (b, h, q-block) list, so the q-blocks of a
+    // head share its K / V in ONE L2 instead of fetching them on all eight
+    int lid;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int qq = nwg >> 3, rr = nwg & 7;
+        lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int nqb = (T + 63) / 64;
+    const int qb = lid % nqb, h = (lid / nqb) % H, b = lid / (nqb * H);
     const size_t headoff = ((size_t)b * H + h) * (size_t)T * VN_DHEAD;
     const float* Q = q + headoff;
     const float* K = k + headoff;
@@ -378,7 +396,7 @@ int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float
         ctx->attr_mask |= VN_ATTR_ATTN;
     }
     const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
-    const dim3 grid(vn_cdiv(T, 64), H, B);
+    const dim3 grid(vn_cdiv(T, 64) * H * B);
     static const bool bf16_attn = [] { const char* e = getenv("VN_ATTN_BF16"); return !(e && e[0] == '0'); }();
     if (out16 && bf16_attn && plane16 == 0) {        // fast mode: bf16 MFMA attention (VN_ATTN_BF16=0 keeps the fp32 kernel for A/B runs)
         const size_t lds16 = (size_t)(2 * ATT_KT * ATB_LDK) * sizeof(uint16_t) + (size_t)(2 * T - 1 + 3) * sizeof(float);

@@ -14,7 +14,7 @@
 //              the buffer is zero-filled once, keys >= T of the last tile hold finite values and meet P = 0.
 // Softmax probabilities are split into their three planes in registers (P in [0, 1]: exact).
 //
-// Work decomposition: grid = (ceil(T / (32 NW)), H, B); block = NW waves; wave w owns 32 query columns.
+// Work decomposition: one block per (b, h, q-block of 32 NW queries), XCD-aware 1-D walk; block = NW waves; wave w owns 32 query columns.
 //   S^T[key][q] = K[key][:] . Q[q][:]      A = K tile rows (LDS), B = Q (registers, loaded once)
 //   O^T[d][q]   = V^T[d][key] . P^T[key][q]  A = V^T tile rows (LDS), B = P (the registers the softmax produced)
 // MFMA row rho of S^T is mapped to key swap_bits_2_3(rho) (the A operand simply reads that K row): a lane (query j = lane & 31,
@@ -33,7 +33,8 @@
 
 __device__ __forceinline__ int ax_swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
-template <int NW>
+// ABL (tuning only, results invalid): bit 0 = no exp / split (P = bf16(S) in all planes), bit 1 = no S^T MFMAs, bit 2 = no O^T MFMAs
+template <int NW, int ABL = 0>
 __global__ __launch_bounds__(NW * 64, NW == 6 ? 3 : 2) void vn_attention_x3_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
                                                                     long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
                                                                     const float* __restrict__ bias_full, float* __restrict__ out,
@@ -43,7 +44,17 @@ __global__ __launch_bounds__(NW * 64, NW == 6 ? 3 : 2) void vn_attention_x3_kern
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
-    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // 1-D grid, XCD-aware: blocks with blockIdx % 8 == x run on XCD x; give every XCD a contiguous eighth of the (b, h, q-block)
+    // walk so that the q-blocks of a head run on ONE XCD and share its K / V^T tiles in that L2 (with the natural order a head's
+    // q-blocks went round-robin over the XCDs and every one of them fetched the head's planes from the fabric: 235 MB per launch)
+    const int nqb = (T + NW * 32 - 1) / (NW * 32);
+    int lid;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int qq = nwg >> 3, rr = nwg & 7;
+        lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int qb = lid % nqb, h = (lid / nqb) % H, b = lid / (nqb * H);
     const int NT = (T + AX_KT - 1) / AX_KT;
     const size_t head = (size_t)b * H + h;
     const uint16_t* Qp = q16 + head * (size_t)T * VN_DHEAD;
@@ -119,12 +130,16 @@ __global__ __launch_bounds__(NW * 64, NW == 6 ? 3 : 2) void vn_attention_x3_kern
 #pragma unroll
             for (int p = 0; p < 3; ++p)
                 kf[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Ks + p * AX_PLANE_FLOATS + kOff + ((2 * s + hh) ^ kSw) * 4));
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[2][s], sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[0][s], sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[1][s], sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[1][s], sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[0][s], sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][s], sacc, 0, 0, 0);
+            if constexpr (ABL & 2) {
+                sacc[s] += (float)kf[0][0] + (float)kf[1][1] + (float)kf[2][2];
+            } else {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[2][s], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[0][s], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[1][s], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[1][s], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[0][s], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][s], sacc, 0, 0, 0);
+            }
         }
         __builtin_amdgcn_s_setprio(0);
 
@@ -159,10 +174,11 @@ __global__ __launch_bounds__(NW * 64, NW == 6 ? 3 : 2) void vn_attention_x3_kern
             f32x8 pe;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                pe[e] = vn_exp_neg(sacc[8 * s + e] - m_new);
+                pe[e] = (ABL & 1) ? sacc[8 * s + e] - m_new : vn_exp_neg(sacc[8 * s + e] - m_new);
                 lsum += pe[e];
             }
-            vn_split3_x8(pe, pf[0][s], pf[1][s], pf[2][s]);
+            if constexpr (ABL & 1) pf[0][s] = pf[1][s] = pf[2][s] = __builtin_convertvector(pe, bf16x8);
+            else vn_split3_x8(pe, pf[0][s], pf[1][s], pf[2][s]);
         }
         l_run = l_run * alpha + lsum;
         m_run = m_new;
@@ -183,12 +199,16 @@ __global__ __launch_bounds__(NW * 64, NW == 6 ? 3 : 2) void vn_attention_x3_kern
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
                     vf[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Vs + p * AX_PLANE_FLOATS + (32 * dt + l31) * 16 + ((2 * s + hh) ^ vSw) * 4));
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[2][s], o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], pf[0][s], o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf[1][s], o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[1][s], o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf[0][s], o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[0][s], o[dt], 0, 0, 0);
+                if constexpr (ABL & 4) {
+                    o[dt][s] += (float)vf[0][0] * (float)pf[0][s][0] + (float)vf[1][1] * (float)pf[1][s][1] + (float)vf[2][2] * (float)pf[2][s][2];
+                } else {
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[2][s], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], pf[0][s], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf[1][s], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[1][s], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf[0][s], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[0][s], o[dt], 0, 0, 0);
+                }
             }
         __builtin_amdgcn_s_setprio(0);
     }
@@ -219,9 +239,12 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
     const size_t lds = (size_t)(2 * AX_STAGE_FLOATS + 2 * T - 1 + 3) * sizeof(float);
     if (lds > 80 * 1024) return vn_fail(ctx, VN_ERR_INVALID, "attention_x3: T=%s%ld too long for two blocks per CU", "", T);
     if (!(ctx->attr_mask & VN_ATTR_ATTN_X3)) {
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_x3_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<6, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         ctx->attr_mask |= VN_ATTR_ATTN_X3;
     }
     const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
@@ -244,13 +267,22 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
         }
     }
     if (nw == 6)
-        hipLaunchKernelGGL(vn_attention_x3_kernel<6>, dim3(vn_cdiv(T, 192), H, B), dim3(384), lds, s, q16, k16, plane_qk, vt16, plane_vt,
+        hipLaunchKernelGGL((vn_attention_x3_kernel<6, 0>), dim3(vn_cdiv(T, 192) * H * B), dim3(384), lds, s, q16, k16, plane_qk, vt16, plane_vt,
                            relbias_full, out, out16, plane16, B, H, T);
-    else if (nw == 4)
-        hipLaunchKernelGGL(vn_attention_x3_kernel<4>, dim3(vn_cdiv(T, 128), H, B), dim3(256), lds, s, q16, k16, plane_qk, vt16, plane_vt,
-                           relbias_full, out, out16, plane16, B, H, T);
+    else if (nw == 4) {
+        static const int abl = [] { const char* e = getenv("VN_ATTN_X3_ABL"); return e ? atoi(e) & 7 : 0; }();   // tuning only
+#define AX_GO(A) hipLaunchKernelGGL((vn_attention_x3_kernel<4, A>), dim3(vn_cdiv(T, 128) * H * B), dim3(256), lds, s, q16, k16, plane_qk, vt16, \
+                                    plane_vt, relbias_full, out, out16, plane16, B, H, T)
+        switch (abl) {
+            case 1: AX_GO(1); break;
+            case 6: AX_GO(6); break;
+            case 7: AX_GO(7); break;
+            default: AX_GO(0); break;
+        }
+#undef AX_GO
+    }
     else
-        hipLaunchKernelGGL(vn_attention_x3_kernel<2>, dim3(vn_cdiv(T, 64), H, B), dim3(128), lds, s, q16, k16, plane_qk, vt16, plane_vt,
+        hipLaunchKernelGGL((vn_attention_x3_kernel<2, 0>), dim3(vn_cdiv(T, 64) * H * B), dim3(128), lds, s, q16, k16, plane_qk, vt16, plane_vt,
                            relbias_full, out, out16, plane16, B, H, T);
     vn_prof_post(ctx, pi, s);
     VN_LAUNCH_CHECK(ctx);
