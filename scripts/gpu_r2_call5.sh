@@ -5,7 +5,7 @@ O=gpurun_out/r2c5
 mkdir -p $O
 timeout 300 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "attention" -x > $O/1_kernels.log 2>&1
 echo "attention tests rc=$?"; tail -3 $O/1_kernels.log
-for w in 0 2 4 6; do VN_ATTN_X3_WAVES=$w timeout 120 python scripts/attn_bench.py 2>/dev/null; done > $O/2_attn_bench.txt; cat $O/2_attn_bench.txt
+for w in 4; do timeout 120 python scripts/attn_bench.py 2>/dev/null; done > $O/2_attn_bench.txt; cat $O/2_attn_bench.txt
 timeout 400 python -m pytest tests/test_gpu_bf16x3.py -q -m gpu -x > $O/3_model_bf16x3.log 2>&1
 echo "bf16x3 model tests rc=$?"; tail -3 $O/3_model_bf16x3.log
 timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/4_bench.json 2> $O/4_bench.err

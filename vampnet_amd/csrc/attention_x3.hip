@@ -9,9 +9,12 @@
 //
 // Operands arrive as planes, written by the QKV GEMM's epilogues (gemm_x3.hip):
 //   q16, k16 : [3 planes][B][H][T][64] bf16 (q pre-multiplied by 1/8 = 1/sqrt(64): a power of two commutes with the split)
-//   vt16     : [3 planes][B][H][ceil(T/32)][64 d][32 keys] bf16 — V TRANSPOSED and blocked by 32-key tile, so that a tile is
-//              one contiguous 4 KiB block (whole cache lines for the LDS-DMA) whose rows are the MFMA A operand of O^T = V^T P^T;
-//              the buffer is zero-filled once, keys >= T of the last tile hold finite values and meet P = 0.
+//   vt16     : [3 planes][H][ceil(B T / 32)][64 d][32 tokens] bf16 — V TRANSPOSED and blocked by tiles of 32 GLOBAL token rows
+//              m = b T + t (the row index of the activations), so that a tile is one contiguous 4 KiB block (whole cache lines
+//              for the LDS-DMA) whose rows are the MFMA A operand of O^T = V^T P^T, and the producing GEMM writes 16-byte
+//              aligned runs whatever T is.  Key tiles are therefore aligned to m, not to t: an item's first and last tile
+//              also hold the neighbouring items' tokens, which are masked (P = 0; the buffer is zero-filled once, so every
+//              masked value is finite).
 // Softmax probabilities are split into their three planes in registers (P in [0, 1]: exact).
 //
 // Work decomposition: one block per (b, h, q-block of 32 NW queries), XCD-aware 1-D walk; block = NW waves; wave w owns 32 query columns.
@@ -35,7 +38,7 @@ __device__ __forceinline__ int ax_swap23(int r) { return (r & ~12) | ((r & 4) <<
 
 // ABL (tuning only, results invalid): bit 0 = no exp / split (P = bf16(S) in all planes), bit 1 = no S^T MFMAs, bit 2 = no O^T MFMAs
 template <int NW, int ABL = 0>
-__global__ __launch_bounds__(NW * 64, NW == 6 ? 3 : 2) void vn_attention_x3_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
+__global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
                                                                     long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
                                                                     const float* __restrict__ bias_full, float* __restrict__ out,
                                                                     uint16_t* __restrict__ out16, long plane16, int B, int H, int T) {
@@ -55,11 +58,14 @@ __global__ __launch_bounds__(NW * 64, NW == 6 ? 3 : 2) void vn_attention_x3_kern
         lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
     }
     const int qb = lid % nqb, h = (lid / nqb) % H, b = lid / (nqb * H);
-    const int NT = (T + AX_KT - 1) / AX_KT;
+    // key tiles of this item in global token rows: tile g holds tokens 32 g .. 32 g + 31, key index t = m - b T
+    const int m_lo = b * T;
+    const int g_lo = m_lo / AX_KT, NT = (m_lo + T - 1) / AX_KT - g_lo + 1;
+    const int MT = (B * T + AX_KT - 1) / AX_KT;
     const size_t head = (size_t)b * H + h;
     const uint16_t* Qp = q16 + head * (size_t)T * VN_DHEAD;
     const uint16_t* Kp = k16 + head * (size_t)T * VN_DHEAD;
-    const uint16_t* Vp = vt16 + head * (size_t)NT * (VN_DHEAD * AX_KT);
+    const uint16_t* Vp = vt16 + ((size_t)h * MT + g_lo) * (VN_DHEAD * AX_KT);
     const int q0 = qb * (NW * 32) + wave * 32;
     const bool active = q0 < T;                         // waves past the end only help with the DMA and the barriers
     const int qrow = q0 + l31;
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(NW * 64, NW == 6 ? 3 : 2) void vn_attention_x3_kern
     // LDS-DMA: 24 wave-instructions of 1 KiB per stage (K: 3 planes x 4, each 8 rows x 128 B; V^T: 3 planes x 4, each 16 rows x 64 B)
     auto stage = [&](int buf, int kt) {
         float* base = smem + buf * AX_STAGE_FLOATS;
-        const int key0 = kt * AX_KT;
+        const int key0 = (g_lo + kt) * AX_KT - m_lo;            // may be negative in the first tile
 #pragma unroll
         for (int i = 0; i < 24 / NW; ++i) {
             const int q = wave + i * NW;
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(NW * 64, NW == 6 ? 3 : 2) void vn_attention_x3_kern
             if (q < 12) {
                 const int p = q >> 2, row = 8 * (q & 3) + (lane >> 3);
                 int key = key0 + row;
-                key = key < T ? key : T - 1;
+                key = key < 0 ? 0 : (key < T ? key : T - 1);
                 src = Kp + (size_t)p * plane_qk + (size_t)key * VN_DHEAD + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
             } else {
                 const int q2 = q - 12;
@@ -145,21 +151,22 @@ __global__ __launch_bounds__(NW * 64, NW == 6 ? 3 : 2) void vn_attention_x3_kern
 
         // ---- online softmax over the tile's 32 keys; lane (j, hh) holds keys 32 kt + 16 (r >> 3) + 8 hh + (r & 7) of query j
         float mx = -INFINITY;
-        const float* brow = bt + (kt * AX_KT + 8 * hh - qrow_c + (T - 1));     // bias of key 32 kt + 8 hh for this query
-        if (kt + 1 < NT) {                                             // every key of the tile is < T
+        const int key0 = (g_lo + kt) * AX_KT - m_lo;                   // key index of the tile's first row
+        const float* brow = bt + (key0 + 8 * hh - qrow_c + (T - 1));   // bias of key key0 + 8 hh for this query
+        if (key0 >= 0 && key0 + AX_KT <= T) {                          // every key of the tile belongs to this item
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float x = sacc[r] + brow[16 * (r >> 3) + (r & 7)];   // q was pre-scaled by 1/sqrt(64); += bias
                 sacc[r] = x;
                 mx = fmaxf(mx, x);
             }
-        } else {                                                       // last tile: keys >= T are masked out
+        } else {                                                       // first / last tile: the neighbours' tokens are masked out
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = kt * AX_KT + 16 * (r >> 3) + 8 * hh + (r & 7);
-                const int key_c = key < T ? key : T - 1;
+                const int key = key0 + 16 * (r >> 3) + 8 * hh + (r & 7);
+                const int key_c = key < 0 ? 0 : (key < T ? key : T - 1);
                 float x = sacc[r] + bt[key_c - qrow_c + (T - 1)];
-                x = key < T ? x : -INFINITY;
+                x = (key >= 0 && key < T) ? x : -INFINITY;
                 sacc[r] = x;
                 mx = fmaxf(mx, x);
             }
@@ -240,50 +247,25 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
     if (lds > 80 * 1024) return vn_fail(ctx, VN_ERR_INVALID, "attention_x3: T=%s%ld too long for two blocks per CU", "", T);
     if (!(ctx->attr_mask & VN_ATTR_ATTN_X3)) {
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<6, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         ctx->attr_mask |= VN_ATTR_ATTN_X3;
     }
     const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
-    // waves per block (32 queries each).  Blocks per CU: LDS allows 3 (2 x 24 KiB stages + the bias table), registers allow 12
-    // waves.  Cost of a choice = rounds x waves per SIMD while a round runs; ties go to the larger block (fewer K / V^T reads).
-    // T = 575, B = 8: six waves = 3 blocks per head with no idle wave, 480 blocks = ONE round on 2 x 256 slots (four waves: 800
-    // blocks on 768 slots = two rounds).
-    static const int forced = [] { const char* e = getenv("VN_ATTN_X3_WAVES"); return e ? atoi(e) : 0; }();
-    int nw = forced;
-    if (nw != 2 && nw != 4 && nw != 6) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) cus = 256;
-        long best = -1;
-        for (int c = 2; c <= 6; c += 2) {
-            const long blocks = (long)vn_cdiv(T, 32 * c) * H * B;
-            const int bpc = c == 6 ? 2 : 3;
-            const long per_cu = (blocks + cus - 1) / cus < bpc ? (blocks + cus - 1) / cus : bpc;
-            const long cost = ((blocks + (long)cus * bpc - 1) / ((long)cus * bpc)) * ((per_cu * c + 3) / 4);
-            if (best < 0 || cost <= best) { best = cost; nw = c; }
-        }
-    }
-    if (nw == 6)
-        hipLaunchKernelGGL((vn_attention_x3_kernel<6, 0>), dim3(vn_cdiv(T, 192) * H * B), dim3(384), lds, s, q16, k16, plane_qk, vt16, plane_vt,
-                           relbias_full, out, out16, plane16, B, H, T);
-    else if (nw == 4) {
-        static const int abl = [] { const char* e = getenv("VN_ATTN_X3_ABL"); return e ? atoi(e) & 7 : 0; }();   // tuning only
+    // four waves (128 queries) per block, three blocks per CU (LDS: 2 x 24 KiB stages + the bias table; 168 VGPRs).  Measured
+    // alternatives (profiles/r02_attention_x3_kernel_times.txt): six waves (one round of 480 blocks at B = 8) 119 vs 112 us,
+    // two waves no better at any batch size.
+    static const int abl = [] { const char* e = getenv("VN_ATTN_X3_ABL"); return e ? atoi(e) & 7 : 0; }();   // tuning only
 #define AX_GO(A) hipLaunchKernelGGL((vn_attention_x3_kernel<4, A>), dim3(vn_cdiv(T, 128) * H * B), dim3(256), lds, s, q16, k16, plane_qk, vt16, \
                                     plane_vt, relbias_full, out, out16, plane16, B, H, T)
-        switch (abl) {
-            case 1: AX_GO(1); break;
-            case 6: AX_GO(6); break;
-            case 7: AX_GO(7); break;
-            default: AX_GO(0); break;
-        }
-#undef AX_GO
+    switch (abl) {
+        case 1: AX_GO(1); break;
+        case 6: AX_GO(6); break;
+        case 7: AX_GO(7); break;
+        default: AX_GO(0); break;
     }
-    else
-        hipLaunchKernelGGL((vn_attention_x3_kernel<2, 0>), dim3(vn_cdiv(T, 64) * H * B), dim3(128), lds, s, q16, k16, plane_qk, vt16, plane_vt,
-                           relbias_full, out, out16, plane16, B, H, T);
+#undef AX_GO
     vn_prof_post(ctx, pi, s);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;

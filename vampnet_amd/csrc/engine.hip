@@ -414,7 +414,7 @@ static int set_bf16_planes(vn_model* m, const void* blob16_dev, long w_plane) {
     if (!m->g16 && (rc = dev_alloc(m->ctx, &m->g16, (size_t)3 * m->max_rows * 2 * m->D))) return rc;
     if (w_plane > 0 && !m->qk16) {        // bf16x3: attention operands as planes (attention_x3.hip)
         m->qk_plane = 2 * m->max_rows * (long)m->D;
-        m->vt_plane = (long)m->d.max_batch * m->H * ((m->d.max_T + 31) / 32) * (VN_DHEAD * 32);
+        m->vt_plane = (long)m->H * ((m->max_rows + 31) / 32) * (VN_DHEAD * 32);
         if ((rc = dev_alloc(m->ctx, &m->qk16, (size_t)3 * m->qk_plane + 32 * VN_DHEAD))) return rc;
         if ((rc = dev_alloc(m->ctx, &m->vt16, (size_t)3 * m->vt_plane))) return rc;
         // keys >= T of a head's last tile are multiplied by P = 0: they must be finite, so start from zeros
@@ -591,21 +591,22 @@ extern "C" int vn_attention_bf16(vn_ctx* ctx, const float* q, const float* k, co
 // epilogues do (q x 1/8; V^T blocked by 32-key tile), then attention_x3.hip runs; out fp32 [B][T][H*64]
 __global__ void vn_attn_x3_prep_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                        uint16_t* __restrict__ qk16, long plane_qk, uint16_t* __restrict__ vt16, long plane_vt,
-                                       long heads, int T) {
+                                       long heads, int H, int T) {
     const long n = heads * T * VN_DHEAD;
-    const int nt = (T + 31) >> 5;
+    const long mt = ((heads / H) * T + 31) >> 5;          // tiles of 32 global token rows m = b T + t
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
         const int d = (int)(i & 63);
         const long ht = i >> 6;
-        const long hd = ht / T;
+        const long hd = ht / T;                           // = b H + h
         const int t = (int)(ht - hd * T);
+        const long mrow = (hd / H) * T + t;
         uint16_t a, b, c;
         vn_split3(q[i] * 0.125f, a, b, c);
         qk16[i] = a; qk16[i + plane_qk] = b; qk16[i + 2 * plane_qk] = c;
         vn_split3(k[i], a, b, c);
         qk16[n + i] = a; qk16[n + i + plane_qk] = b; qk16[n + i + 2 * plane_qk] = c;
         vn_split3(v[i], a, b, c);
-        const long o = ((hd * nt + (t >> 5)) * VN_DHEAD + d) * 32 + (t & 31);
+        const long o = (((hd % H) * mt + (mrow >> 5)) * VN_DHEAD + d) * 32 + (mrow & 31);
         vt16[o] = a; vt16[o + plane_vt] = b; vt16[o + 2 * plane_vt] = c;
     }
 }
@@ -614,7 +615,7 @@ __global__ void vn_attn_x3_prep_kernel(const float* __restrict__ q, const float*
 static int attention_x3_run(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias, float* out, int B,
                             int H, int T, int num_buckets, int max_distance, int iters, float* avg_us, hipStream_t s) {
     const long heads = (long)B * H, n = heads * T * VN_DHEAD;
-    const long plane_qk = 2 * n, plane_vt = heads * ((T + 31) / 32) * (VN_DHEAD * 32);
+    const long plane_qk = 2 * n, plane_vt = (long)H * (((long)B * T + 31) / 32) * (VN_DHEAD * 32);
     float* full = nullptr;
     int32_t* lut_d = nullptr;
     uint16_t *qk16 = nullptr, *vt16 = nullptr;
@@ -631,7 +632,7 @@ static int attention_x3_run(vn_ctx* ctx, const float* q, const float* k, const f
         rc = VN_ERR_HIP;
     if (rc == VN_OK) rc = vn_launch_bias_expand(ctx, rel_bias, lut_d, full, H, T, s);
     if (rc == VN_OK) {
-        hipLaunchKernelGGL(vn_attn_x3_prep_kernel, dim3(1024), dim3(256), 0, s, q, k, v, qk16, plane_qk, vt16, plane_vt, heads, T);
+        hipLaunchKernelGGL(vn_attn_x3_prep_kernel, dim3(1024), dim3(256), 0, s, q, k, v, qk16, plane_qk, vt16, plane_vt, heads, H, T);
         rc = vn_launch_attention_x3(ctx, qk16, qk16 + n, plane_qk, vt16, plane_vt, full, out, nullptr, 0, B, H, T, s);
     }
     if (rc == VN_OK && iters > 0 && avg_us) {

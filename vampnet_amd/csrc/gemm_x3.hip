@@ -146,16 +146,108 @@ __device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 
                         uint16_t* dst = p.C16 + which * p.qkv_plane + (((size_t)b * p.H + hd) * p.T + t) * VN_DHEAD + d;
                         dst[0] = t0; dst[p.c_plane] = t1; dst[2 * p.c_plane] = t2;
                     } else if constexpr (EPI == VN_EPI_VT3) {
-                        // swapped product: row = feature (head hd, d), col = token (b, t) -> V^T blocked by 32-key tile:
-                        // [b][h][t / 32][d][t % 32]
+                        // swapped product: row = feature (head hd, d), col = global token row m = b T + t -> V^T blocked by
+                        // tiles of 32 token rows: [h][m / 32][d][m % 32]
                         const int hd = row >> 6, d = row & 63;
-                        const int b = col / p.T, t = col - b * p.T;
-                        const int nt = (p.T + 31) >> 5;
+                        const int mt = (p.N + 31) >> 5;
                         uint16_t t0, t1, t2;
                         vn_split3(v, t0, t1, t2);
-                        uint16_t* dst = p.C16 + ((((size_t)b * p.H + hd) * nt + (t >> 5)) * VN_DHEAD + d) * 32 + (t & 31);
+                        uint16_t* dst = p.C16 + (((size_t)hd * mt + (col >> 5)) * VN_DHEAD + d) * 32 + (col & 31);
                         dst[0] = t0; dst[p.c_plane] = t1; dst[2 * p.c_plane] = t2;
                     }
+                }
+            }
+        }
+    }
+}
+
+// The same epilogues staged through LDS (free after the k-loop): every wave drops its accumulators into a row-major image
+// of 128 tile rows, then all 512 threads read the image back in 16-byte pieces and issue 16-byte global accesses.  The direct
+// epilogue above issues one 2- or 4-byte store per accumulator register (32 per MFMA tile, x3 for split planes), and the store
+// tail of a tile is ISSUE-bound (guide T21): the in-model GEMMs with plane epilogues ran 10-14 % below the fp32-store shapes
+// (profiles/r02_c6_bench_kernel_stats_last_vamp.txt).  One pass per 128-row half of a 256-row tile; every thread of the block must call it.
+//   fp32 kinds (store / bias / residual / QKV scatter): image [128][128] fp32 (64 KiB)
+//   GEGLU planes: image [3][128][64] bf16 (48 KiB);  QK3 / VT3 planes: [3][128][128] bf16 (96 KiB)
+template <int EPI, int MI>
+__device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const f32x16 (&acc)[MI][2], int m0, int n0, int wave, int lane,
+                                                   float* lds) {
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5, tid = wave * 64 + lane;
+    uint16_t* L16 = (uint16_t*)lds;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        __syncthreads();                  // k-loop reads / the previous pass's read-out are done in every wave
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int R = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;                 // image row; tile row = (R >> 5) * 32 MI + 32 i + (R & 31)
+            if constexpr (EPI == VN_EPI_GEGLU) {
+                const float o = acc[i][0][r] * vn_gelu_tanh(acc[i][1][r]);
+                uint16_t t0, t1, t2;
+                vn_split3(o, t0, t1, t2);
+                uint16_t* d = L16 + R * 64 + wn * 32 + l31;
+                d[0] = t0; d[128 * 64] = t1; d[2 * 128 * 64] = t2;
+            } else if constexpr (EPI == VN_EPI_QK3 || EPI == VN_EPI_VT3) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = wn * 64 + j * 32 + l31;
+                    float v = acc[i][j][r];
+                    if constexpr (EPI == VN_EPI_QK3) v = (n0 + c) < p.H * VN_DHEAD ? v * 0.125f : v;      // q columns: x 1/sqrt(64)
+                    uint16_t t0, t1, t2;
+                    vn_split3(v, t0, t1, t2);
+                    uint16_t* d = L16 + R * 128 + c;
+                    d[0] = t0; d[128 * 128] = t1; d[2 * 128 * 128] = t2;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) lds[R * 128 + wn * 64 + j * 32 + l31] = acc[i][j][r];
+            }
+        }
+        __syncthreads();
+        if constexpr (EPI == VN_EPI_GEGLU) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {                                           // 3 planes x 128 rows x 8 pieces of 8 columns
+                const int idx = tid + 512 * k;
+                const int q = idx >> 10, R = (idx >> 3) & 127, c8 = (idx & 7) * 8;
+                const int row = m0 + (R >> 5) * 32 * MI + 32 * i + (R & 31), ocol = n0 / 2 + c8;
+                if (row < p.M && 2 * ocol < p.N)
+                    *(u32x4*)(p.C16 + (size_t)q * p.c_plane + (size_t)row * p.ldc + ocol) = *(const u32x4*)(L16 + q * (128 * 64) + R * 64 + c8);
+            }
+        } else if constexpr (EPI == VN_EPI_QK3 || EPI == VN_EPI_VT3) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {                                          // 3 planes x 128 rows x 16 pieces of 8 columns
+                const int idx = tid + 512 * k;
+                const int q = idx >> 11, R = (idx >> 4) & 127, c8 = (idx & 15) * 8;
+                const int row = m0 + (R >> 5) * 32 * MI + 32 * i + (R & 31), col = n0 + c8;
+                if (row >= p.M || col >= p.N) continue;
+                const u32x4 v = *(const u32x4*)(L16 + q * (128 * 128) + R * 128 + c8);
+                size_t off;
+                if constexpr (EPI == VN_EPI_QK3) {
+                    const int D = p.H * VN_DHEAD;
+                    const int which = col >= D ? 1 : 0, rem = col - which * D;
+                    const int b = row / p.T, t = row - b * p.T;
+                    off = which * p.qkv_plane + (((size_t)b * p.H + (rem >> 6)) * p.T + t) * VN_DHEAD + (rem & 63);
+                } else {
+                    off = (((size_t)(row >> 6) * ((p.N + 31) >> 5) + (col >> 5)) * VN_DHEAD + (row & 63)) * 32 + (col & 31);
+                }
+                *(u32x4*)(p.C16 + (size_t)q * p.c_plane + off) = v;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {                                           // 128 rows x 32 pieces of 4 columns
+                const int idx = tid + 512 * k;
+                const int R = idx >> 5, c4 = (idx & 31) * 4;
+                const int row = m0 + (R >> 5) * 32 * MI + 32 * i + (R & 31), col = n0 + c4;
+                if (row >= p.M || col >= p.N) continue;
+                f32x4 v = *(const f32x4*)(lds + R * 128 + c4);
+                if constexpr (EPI == VN_EPI_QKV) {
+                    const int D = p.H * VN_DHEAD;
+                    const int which = col / D, rem = col - which * D;
+                    const int b = row / p.T, t = row - b * p.T;
+                    *(f32x4*)(p.C + which * p.qkv_plane + (((size_t)b * p.H + (rem >> 6)) * p.T + t) * VN_DHEAD + (rem & 63)) = v;
+                } else {
+                    float* c = p.C + (size_t)row * p.ldc + col;
+                    if constexpr (EPI == VN_EPI_BIAS) v += *(const f32x4*)(p.bias + col);
+                    if constexpr (EPI == VN_EPI_RESIDUAL) v += *(const f32x4*)c;
+                    *(f32x4*)c = v;
                 }
             }
         }
@@ -421,7 +513,8 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         }
 
         if (!SK || (kb == 0 && ke == nk_all)) {
-            x3_epilogue<EPI, MI>(p, acc, m0, n0, wm, wn, lane);
+            if (p.staged) x3_epilogue_staged<EPI, MI>(p, acc, m0, n0, wave, lane, lds);
+            else x3_epilogue<EPI, MI>(p, acc, m0, n0, wm, wn, lane);
         } else {
             // a shared tile: raw accumulators to this block's first / second slab (the fix-up kernel recomputes the same map)
             x3_slab_store<MI>(slabs + (size_t)(sk_slab + (first_tail ? 0 : 1)) * (G::BM * X3_BN), acc, wave, lane);
@@ -474,7 +567,9 @@ __global__ __launch_bounds__(512) void vn_gemm_x3_fixup_kernel(vn_gemm_args p, i
     }
     int tm, tn;
     x3_tile_coords(t, tiles_m, tiles_n, tm, tn);
-    x3_epilogue<EPI, MI>(p, acc, tm * 128 * MI, tn * X3_BN, wave >> 1, wave & 1, lane);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (p.staged) x3_epilogue_staged<EPI, MI>(p, acc, tm * 128 * MI, tn * X3_BN, wave, lane, lds);
+    else x3_epilogue<EPI, MI>(p, acc, tm * 128 * MI, tn * X3_BN, wave >> 1, wave & 1, lane);
 }
 
 #define X3_WS_FLOATS (32L << 20)          // 128 MiB: stream-K slabs (2 x 256 x 64 / 128 KiB) or split-K images; allocated once
@@ -523,8 +618,25 @@ static int x3_num_cus(vn_ctx* ctx) {
     return cus[d];
 }
 
+// may the epilogue go through LDS with 16-byte global accesses ?  (VN_X3_STAGED=0: never — A/B runs)
+template <int EPI>
+static int x3_staged_ok(const vn_gemm_args& a) {
+    static const bool on = x3_env("VN_X3_STAGED", 1) != 0;
+    if (!on) return 0;
+    auto al = [](const void* p, uintptr_t m) { return ((uintptr_t)p & (m - 1)) == 0; };
+    if (EPI == VN_EPI_GEGLU) return a.C16 && al(a.C16, 16) && !(a.ldc & 7) && !(a.c_plane & 7) && !(a.N & 15);
+    if (EPI == VN_EPI_QK3) return al(a.C16, 16) && !(a.c_plane & 7) && !(a.qkv_plane & 7) && !(a.N & 7);
+    if (EPI == VN_EPI_VT3) return al(a.C16, 16) && !(a.c_plane & 7) && !(a.M & 63);
+    if (!al(a.C, 16) || (a.N & 3)) return 0;
+    if (EPI == VN_EPI_QKV) return !(a.qkv_plane & 3);
+    if (EPI == VN_EPI_BIAS && !al(a.bias, 16)) return 0;
+    return !(a.ldc & 3);
+}
+
 template <int EPI, int MI, int ABL = 0>
-static int x3_go(vn_ctx* ctx, const vn_gemm_args& a, int nsplit, bool sk, hipStream_t s) {
+static int x3_go(vn_ctx* ctx, const vn_gemm_args& a_in, int nsplit, bool sk, hipStream_t s) {
+    vn_gemm_args a = a_in;
+    a.staged = x3_staged_ok<EPI>(a);
     const int tiles_m = vn_cdiv(a.M, 128 * MI), tiles_n = vn_cdiv(a.N, X3_BN);
     if (sk) {
         const int ntiles = tiles_m * tiles_n;
@@ -536,7 +648,7 @@ static int x3_go(vn_ctx* ctx, const vn_gemm_args& a, int nsplit, bool sk, hipStr
         bool tail = false;                                   // does any XCD chunk leave tiles to the k-split tail ?
         for (int x = 0; x < 8; ++x) tail = tail || (x3_xcd_chunk(ntiles, x).n % (G >> 3)) != 0;
         if (tail)
-            hipLaunchKernelGGL((vn_gemm_x3_fixup_kernel<EPI, MI>), dim3(ntiles), dim3(512), 0, s, a, tiles_m, tiles_n, ctx->x3_ws, G);
+            hipLaunchKernelGGL((vn_gemm_x3_fixup_kernel<EPI, MI>), dim3(ntiles), dim3(512), 96 * 1024, s, a, tiles_m, tiles_n, ctx->x3_ws, G);
     } else {
         hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, MI, false, ABL>), dim3(tiles_m * tiles_n, nsplit), dim3(512), x3_lds_bytes<MI>(), s, a,
                            tiles_m, tiles_n, (float*)nullptr);
@@ -619,6 +731,8 @@ static int x3_attrs(vn_ctx* ctx) {
     if ((rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 1, false>, x3_lds_bytes<1>()))) return rc;
     if ((rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 1, true>, x3_lds_bytes<1>()))) return rc;
     if ((rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 2, false>, x3_lds_bytes<2>()))) return rc;
+    if ((rc = x3_attr(ctx, vn_gemm_x3_fixup_kernel<EPI, 1>, 96 * 1024))) return rc;
+    if ((rc = x3_attr(ctx, vn_gemm_x3_fixup_kernel<EPI, 2>, 96 * 1024))) return rc;
     return x3_attr(ctx, vn_gemm_x3_kernel<EPI, 2, true>, x3_lds_bytes<2>());
 }
 template <int MI, int ABL>

@@ -214,6 +214,7 @@ struct vn_gemm_args {
     // QKV scatter: C = qkv base [3][B][H][T][64]; row m = b*T + t
     int T, H;
     long qkv_plane;      // B*H*T*64
+    int staged;          // gemm_x3.hip: epilogue through LDS with 16-byte global accesses (set by the launcher when alignment allows)
 };
 int vn_launch_gemm_f32(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);
 int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);      // a.bf16 == 2
@@ -229,7 +230,7 @@ int vn_launch_embed(vn_ctx* ctx, const int32_t* codes, const float* tables, cons
 int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* relbias_full,
                         float* out, int B, int H, int T, hipStream_t s, uint16_t* out16 = nullptr, long plane16 = 0);
 // bf16x3 attention (attention_x3.hip): q16 / k16 planes [3][B][H][T][64] (plane_qk elements apart, q pre-scaled by 1/8),
-// vt16 planes [3][B][H][ceil(T/32)][64][32] (plane_vt apart); out fp32 [B][T][H*64] or out16 split planes (plane16 apart)
+// vt16 planes [3][H][ceil(B T / 32)][64][32] over global token rows (plane_vt apart); out fp32 [B][T][H*64] or out16 split planes (plane16 apart)
 int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16, long plane_qk, const uint16_t* vt16, long plane_vt,
                            const float* relbias_full, float* out, uint16_t* out16, long plane16, int B, int H, int T, hipStream_t s);
 // expands [num_buckets][H] into per-head tables over rel = key - query in [-(T-1), T-1]: out[h][rel + T - 1]

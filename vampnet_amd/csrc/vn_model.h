@@ -18,7 +18,7 @@ struct vn_model {
     long w_plane;            // 0: single-plane bf16 fast mode
     uint16_t *y16, *g16;     // sized for three planes
     // bf16x3 attention operands (attention_x3.hip), written by the QKV GEMM epilogues: qk16 = q then k planes
-    // [3][2][max_rows * D]; vt16 = blocked V^T planes [3][max_batch * H * ceil(max_T / 32) * 64 * 32], zero-filled once
+    // [3][2][max_rows * D]; vt16 = blocked V^T planes [3][H * ceil(max_rows / 32) * 64 * 32], zero-filled once
     uint16_t *qk16, *vt16;
     long qk_plane, vt_plane;
     int bias_T;              // T the expanded bias table is currently built for (-1 = none)
