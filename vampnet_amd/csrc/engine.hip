@@ -264,19 +264,14 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
         // y = RMSNorm(x) ; FiLM = identity (d_cond = 0, transformer.py:554)
         if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM1, l), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr, yp))) return rc;
         if (gm == 2 && attn_x3) {
-            // q (x 1/8) and k as split planes, head-major; V^T (blocked by 32-key tile) from the swapped product W_v . y^T
+            // ONE QKV GEMM whose epilogue writes the attention operands as split planes: q (x 1/8) and k head-major, V^T blocked by
+            // tiles of 32 token rows (transposed through the epilogue's LDS image)
             vn_gemm_args a{};
             operands(a, m->y, m->y16, yp, VN_W_QKV, l);
-            a.C16 = m->qk16; a.c_plane = m->qk_plane; a.M = M; a.N = 2 * D; a.K = D; a.ldc = 2 * D;
+            a.C16 = m->qk16; a.c_plane = m->qk_plane; a.V16 = m->vt16; a.v_plane = m->vt_plane;
+            a.M = M; a.N = 3 * D; a.K = D; a.ldc = 3 * D;
             a.T = T; a.H = H; a.qkv_plane = plane;
-            if ((rc = vn_launch_gemm_f32(ctx, a, VN_EPI_QK3, s))) return rc;
-            vn_gemm_args v{};
-            v.A = (const float*)(m->blob16 + vn_tensor_offset(&m->d, VN_W_QKV, l) + 2L * D * D);
-            v.W = (const float*)m->y16;
-            v.bf16 = 2; v.a_plane = m->w_plane; v.w_plane = yp;
-            v.C16 = m->vt16; v.c_plane = m->vt_plane; v.M = D; v.N = M; v.K = D; v.ldc = M;
-            v.T = T; v.H = H;
-            if ((rc = vn_launch_gemm_f32(ctx, v, VN_EPI_VT3, s))) return rc;
+            if ((rc = vn_launch_gemm_f32(ctx, a, VN_EPI_QKV3, s))) return rc;
             if ((rc = vn_launch_attention_x3(ctx, m->qk16, m->qk16 + plane, m->qk_plane, m->vt16, m->vt_plane, m->bias_full, nullptr,
                                              m->y16, yp, B, H, T, s)))
                 return rc;

@@ -135,25 +135,22 @@ __device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 
                         const int hd = rem >> 6, d = rem & 63;
                         const int b = row / p.T, t = row - b * p.T;
                         p.C[which * p.qkv_plane + (((size_t)b * p.H + hd) * p.T + t) * VN_DHEAD + d] = v;
-                    } else if constexpr (EPI == VN_EPI_QK3) {
-                        // columns [0, D) = q (x 1/sqrt(64), exact), [D, 2D) = k: split planes, head-major [which][b][h][t][64]
+                    } else if constexpr (EPI == VN_EPI_QKV3) {
+                        // columns [0, D) = q (x 1/sqrt(64), exact), [D, 2D) = k: split planes, head-major [which][b][h][t][64];
+                        // [2D, 3D) = v -> V^T blocked by tiles of 32 token rows: [h][row / 32][d][row % 32]
                         const int D = p.H * VN_DHEAD;
-                        const int which = col >= D ? 1 : 0, rem = col - which * D;
+                        const int which = col / D, rem = col - which * D;
                         const int hd = rem >> 6, d = rem & 63;
-                        const int b = row / p.T, t = row - b * p.T;
                         uint16_t t0, t1, t2;
                         vn_split3(which ? v : v * 0.125f, t0, t1, t2);
-                        uint16_t* dst = p.C16 + which * p.qkv_plane + (((size_t)b * p.H + hd) * p.T + t) * VN_DHEAD + d;
-                        dst[0] = t0; dst[p.c_plane] = t1; dst[2 * p.c_plane] = t2;
-                    } else if constexpr (EPI == VN_EPI_VT3) {
-                        // swapped product: row = feature (head hd, d), col = global token row m = b T + t -> V^T blocked by
-                        // tiles of 32 token rows: [h][m / 32][d][m % 32]
-                        const int hd = row >> 6, d = row & 63;
-                        const int mt = (p.N + 31) >> 5;
-                        uint16_t t0, t1, t2;
-                        vn_split3(v, t0, t1, t2);
-                        uint16_t* dst = p.C16 + (((size_t)hd * mt + (col >> 5)) * VN_DHEAD + d) * 32 + (col & 31);
-                        dst[0] = t0; dst[p.c_plane] = t1; dst[2 * p.c_plane] = t2;
+                        if (which < 2) {
+                            const int b = row / p.T, t = row - b * p.T;
+                            uint16_t* dst = p.C16 + which * p.qkv_plane + (((size_t)b * p.H + hd) * p.T + t) * VN_DHEAD + d;
+                            dst[0] = t0; dst[p.c_plane] = t1; dst[2 * p.c_plane] = t2;
+                        } else {
+                            uint16_t* dst = p.V16 + (((size_t)hd * ((p.M + 31) >> 5) + (row >> 5)) * VN_DHEAD + d) * 32 + (row & 31);
+                            dst[0] = t0; dst[p.v_plane] = t1; dst[2 * p.v_plane] = t2;
+                        }
                     }
                 }
             }
@@ -167,7 +164,8 @@ __device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 
 // tail of a tile is ISSUE-bound (guide T21): the in-model GEMMs with plane epilogues ran 10-14 % below the fp32-store shapes
 // (profiles/r02_c6_bench_kernel_stats_last_vamp.txt).  One pass per 128-row half of a 256-row tile; every thread of the block must call it.
 //   fp32 kinds (store / bias / residual / QKV scatter): image [128][128] fp32 (64 KiB)
-//   GEGLU planes: image [3][128][64] bf16 (48 KiB);  QK3 / VT3 planes: [3][128][128] bf16 (96 KiB)
+//   GEGLU planes: image [3][128][64] bf16 (48 KiB);  QKV3 planes: [3][128][128] bf16 (96 KiB) for the q / k tiles, TRANSPOSED
+//   [3][128 columns][136] bf16 (102 KiB) for the v tiles (a tile is all q, all k or all v: D % 128 == 0)
 template <int EPI, int MI>
 __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const f32x16 (&acc)[MI][2], int m0, int n0, int wave, int lane,
                                                    float* lds) {
@@ -185,16 +183,29 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
                 vn_split3(o, t0, t1, t2);
                 uint16_t* d = L16 + R * 64 + wn * 32 + l31;
                 d[0] = t0; d[128 * 64] = t1; d[2 * 128 * 64] = t2;
-            } else if constexpr (EPI == VN_EPI_QK3 || EPI == VN_EPI_VT3) {
+            } else if constexpr (EPI == VN_EPI_QKV3) {
+                if (n0 < 2 * p.H * VN_DHEAD) {                                      // q / k tile: row-major image
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int c = wn * 64 + j * 32 + l31;
-                    float v = acc[i][j][r];
-                    if constexpr (EPI == VN_EPI_QK3) v = (n0 + c) < p.H * VN_DHEAD ? v * 0.125f : v;      // q columns: x 1/sqrt(64)
-                    uint16_t t0, t1, t2;
-                    vn_split3(v, t0, t1, t2);
-                    uint16_t* d = L16 + R * 128 + c;
-                    d[0] = t0; d[128 * 128] = t1; d[2 * 128 * 128] = t2;
+                    for (int j = 0; j < 2; ++j) {
+                        const int c = wn * 64 + j * 32 + l31;
+                        uint16_t t0, t1, t2;
+                        vn_split3(n0 < p.H * VN_DHEAD ? acc[i][j][r] * 0.125f : acc[i][j][r], t0, t1, t2);      // q: x 1/sqrt(64)
+                        uint16_t* d = L16 + R * 128 + c;
+                        d[0] = t0; d[128 * 128] = t1; d[2 * 128 * 128] = t2;
+                    }
+                } else if ((r & 3) == 0) {                                          // v tile: transposed image [column][row], pitch 136
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int c = wn * 64 + j * 32 + l31;
+                        uint16_t t[3][4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vn_split3(acc[i][j][r + e], t[0][e], t[1][e], t[2][e]);
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            uint2 pk = {t[q][0] | ((unsigned)t[q][1] << 16), t[q][2] | ((unsigned)t[q][3] << 16)};
+                            *(uint2*)(L16 + q * (128 * 136) + c * 136 + R) = pk;    // rows R .. R + 3 (r & 3 = 0 .. 3)
+                        }
+                    }
                 }
             } else {
 #pragma unroll
@@ -211,24 +222,25 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
                 if (row < p.M && 2 * ocol < p.N)
                     *(u32x4*)(p.C16 + (size_t)q * p.c_plane + (size_t)row * p.ldc + ocol) = *(const u32x4*)(L16 + q * (128 * 64) + R * 64 + c8);
             }
-        } else if constexpr (EPI == VN_EPI_QK3 || EPI == VN_EPI_VT3) {
+        } else if constexpr (EPI == VN_EPI_QKV3) {
+            const int D = p.H * VN_DHEAD;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) {                                          // 3 planes x 128 rows x 16 pieces of 8 columns
+            for (int k = 0; k < 12; ++k) {                                          // 3 planes x 128 x 16 pieces of 8 elements
                 const int idx = tid + 512 * k;
-                const int q = idx >> 11, R = (idx >> 4) & 127, c8 = (idx & 15) * 8;
-                const int row = m0 + (R >> 5) * 32 * MI + 32 * i + (R & 31), col = n0 + c8;
-                if (row >= p.M || col >= p.N) continue;
-                const u32x4 v = *(const u32x4*)(L16 + q * (128 * 128) + R * 128 + c8);
-                size_t off;
-                if constexpr (EPI == VN_EPI_QK3) {
-                    const int D = p.H * VN_DHEAD;
+                const int q = idx >> 11, a = (idx >> 4) & 127, b8 = (idx & 15) * 8;
+                if (n0 < 2 * D) {                                                   // a = image row, b8 = first of 8 columns
+                    const int row = m0 + (a >> 5) * 32 * MI + 32 * i + (a & 31), col = n0 + b8;
+                    if (row >= p.M || col >= p.N) continue;
                     const int which = col >= D ? 1 : 0, rem = col - which * D;
                     const int b = row / p.T, t = row - b * p.T;
-                    off = which * p.qkv_plane + (((size_t)b * p.H + (rem >> 6)) * p.T + t) * VN_DHEAD + (rem & 63);
-                } else {
-                    off = (((size_t)(row >> 6) * ((p.N + 31) >> 5) + (col >> 5)) * VN_DHEAD + (row & 63)) * 32 + (col & 31);
+                    *(u32x4*)(p.C16 + (size_t)q * p.c_plane + which * p.qkv_plane + (((size_t)b * p.H + (rem >> 6)) * p.T + t) * VN_DHEAD + (rem & 63)) =
+                        *(const u32x4*)(L16 + q * (128 * 128) + a * 128 + b8);
+                } else {                                                            // a = column (feature), b8 = first of 8 image rows (tokens)
+                    const int row = m0 + (b8 >> 5) * 32 * MI + 32 * i + (b8 & 31), f = n0 + a - 2 * D;
+                    if (row >= p.M || n0 + a >= p.N) continue;
+                    *(u32x4*)(p.V16 + (size_t)q * p.v_plane + (((size_t)(f >> 6) * ((p.M + 31) >> 5) + (row >> 5)) * VN_DHEAD + (f & 63)) * 32 + (row & 31)) =
+                        *(const u32x4*)(L16 + q * (128 * 136) + a * 136 + b8);
                 }
-                *(u32x4*)(p.C16 + (size_t)q * p.c_plane + off) = v;
             }
         } else {
 #pragma unroll
@@ -625,8 +637,8 @@ static int x3_staged_ok(const vn_gemm_args& a) {
     if (!on) return 0;
     auto al = [](const void* p, uintptr_t m) { return ((uintptr_t)p & (m - 1)) == 0; };
     if (EPI == VN_EPI_GEGLU) return a.C16 && al(a.C16, 16) && !(a.ldc & 7) && !(a.c_plane & 7) && !(a.N & 15);
-    if (EPI == VN_EPI_QK3) return al(a.C16, 16) && !(a.c_plane & 7) && !(a.qkv_plane & 7) && !(a.N & 7);
-    if (EPI == VN_EPI_VT3) return al(a.C16, 16) && !(a.c_plane & 7) && !(a.M & 63);
+    if (EPI == VN_EPI_QKV3)
+        return al(a.C16, 16) && al(a.V16, 16) && !(a.c_plane & 7) && !(a.v_plane & 7) && !(a.qkv_plane & 7) && !((a.H * VN_DHEAD) & 127);
     if (!al(a.C, 16) || (a.N & 3)) return 0;
     if (EPI == VN_EPI_QKV) return !(a.qkv_plane & 3);
     if (EPI == VN_EPI_BIAS && !al(a.bias, 16)) return 0;
@@ -648,7 +660,7 @@ static int x3_go(vn_ctx* ctx, const vn_gemm_args& a_in, int nsplit, bool sk, hip
         bool tail = false;                                   // does any XCD chunk leave tiles to the k-split tail ?
         for (int x = 0; x < 8; ++x) tail = tail || (x3_xcd_chunk(ntiles, x).n % (G >> 3)) != 0;
         if (tail)
-            hipLaunchKernelGGL((vn_gemm_x3_fixup_kernel<EPI, MI>), dim3(ntiles), dim3(512), 96 * 1024, s, a, tiles_m, tiles_n, ctx->x3_ws, G);
+            hipLaunchKernelGGL((vn_gemm_x3_fixup_kernel<EPI, MI>), dim3(ntiles), dim3(512), 104 * 1024, s, a, tiles_m, tiles_n, ctx->x3_ws, G);
     } else {
         hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, MI, false, ABL>), dim3(tiles_m * tiles_n, nsplit), dim3(512), x3_lds_bytes<MI>(), s, a,
                            tiles_m, tiles_n, (float*)nullptr);
@@ -731,8 +743,8 @@ static int x3_attrs(vn_ctx* ctx) {
     if ((rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 1, false>, x3_lds_bytes<1>()))) return rc;
     if ((rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 1, true>, x3_lds_bytes<1>()))) return rc;
     if ((rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 2, false>, x3_lds_bytes<2>()))) return rc;
-    if ((rc = x3_attr(ctx, vn_gemm_x3_fixup_kernel<EPI, 1>, 96 * 1024))) return rc;
-    if ((rc = x3_attr(ctx, vn_gemm_x3_fixup_kernel<EPI, 2>, 96 * 1024))) return rc;
+    if ((rc = x3_attr(ctx, vn_gemm_x3_fixup_kernel<EPI, 1>, 104 * 1024))) return rc;
+    if ((rc = x3_attr(ctx, vn_gemm_x3_fixup_kernel<EPI, 2>, 104 * 1024))) return rc;
     return x3_attr(ctx, vn_gemm_x3_kernel<EPI, 2, true>, x3_lds_bytes<2>());
 }
 template <int MI, int ABL>
@@ -744,16 +756,14 @@ static int x3_attrs_abl(vn_ctx* ctx) {
 int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: empty problem%s", "");
     if (a.K % X3_KT) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: K=%s%ld must be a multiple of 32", "", a.K);
-    if (a.N % 64 && epilogue != VN_EPI_VT3)       // (columns >= N are clamped on load and masked on store; GEGLU pairs need 64)
-        return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: N=%s%ld must be a multiple of 64", "", a.N);
+    if (a.N % 64) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: N=%s%ld must be a multiple of 64", "", a.N);
     if (a.a_plane <= 0 || a.w_plane <= 0 || (a.a_plane & 7) || (a.w_plane & 7))
         return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: plane strides must be positive multiples of 8 elements%s", "");
     if (((uintptr_t)a.A | (uintptr_t)a.W) & 15) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: operands must be 16-byte aligned%s", "");
     if (!(ctx->attr_mask & VN_ATTR_GEMM_X3)) {
         int rc;
         if ((rc = x3_attrs<VN_EPI_STORE>(ctx)) || (rc = x3_attrs<VN_EPI_BIAS>(ctx)) || (rc = x3_attrs<VN_EPI_RESIDUAL>(ctx)) ||
-            (rc = x3_attrs<VN_EPI_GEGLU>(ctx)) || (rc = x3_attrs<VN_EPI_QKV>(ctx)) || (rc = x3_attrs<VN_EPI_QK3>(ctx)) ||
-            (rc = x3_attrs<VN_EPI_VT3>(ctx)))
+            (rc = x3_attrs<VN_EPI_GEGLU>(ctx)) || (rc = x3_attrs<VN_EPI_QKV>(ctx)) || (rc = x3_attrs<VN_EPI_QKV3>(ctx)))
             return rc;
         if ((rc = x3_attrs_abl<1, 1>(ctx)) || (rc = x3_attrs_abl<1, 2>(ctx)) || (rc = x3_attrs_abl<1, 3>(ctx)) ||
             (rc = x3_attrs_abl<2, 1>(ctx)) || (rc = x3_attrs_abl<2, 2>(ctx)) || (rc = x3_attrs_abl<2, 3>(ctx)) ||
@@ -771,10 +781,10 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
             if (a.C16 && a.c_plane <= 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3/geglu: C16 needs c_plane%s", "");
             return x3_launch<VN_EPI_GEGLU>(ctx, a, s);
         case VN_EPI_QKV: return x3_launch<VN_EPI_QKV>(ctx, a, s);
-        case VN_EPI_QK3:
-        case VN_EPI_VT3:
-            if (!a.C16 || a.c_plane <= 0 || a.T <= 0 || a.H <= 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: plane epilogue needs C16 / c_plane / T / H%s", "");
-            return epilogue == VN_EPI_QK3 ? x3_launch<VN_EPI_QK3>(ctx, a, s) : x3_launch<VN_EPI_VT3>(ctx, a, s);
+        case VN_EPI_QKV3:
+            if (!a.C16 || !a.V16 || a.c_plane <= 0 || a.v_plane <= 0 || a.T <= 0 || a.H <= 0 || a.N != 3 * a.H * VN_DHEAD)
+                return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: QKV plane epilogue needs C16 / V16 / plane strides / T / H and N = 3 H 64%s", "");
+            return x3_launch<VN_EPI_QKV3>(ctx, a, s);
     }
     return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: unknown epilogue %s%ld", "", epilogue);
 }

@@ -197,9 +197,9 @@ static inline int vn_fail(vn_ctx* ctx, int code, const char* fmt, const char* a 
 static inline int vn_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---- launchers implemented in the .hip files ------------------------------------------------
-// QK3 / VT3 (gemm_x3.hip only): the operands of attention_x3.hip as split planes — q (x 1/8) and k head-major, V transposed
-// and blocked by 32-key tile (computed by the SWAPPED product W_v . y^T: output rows = features, columns = tokens)
-enum { VN_EPI_STORE = 0, VN_EPI_BIAS = 1, VN_EPI_RESIDUAL = 2, VN_EPI_GEGLU = 3, VN_EPI_QKV = 4, VN_EPI_QK3 = 5, VN_EPI_VT3 = 6 };
+// QKV3 (gemm_x3.hip only): the operands of attention_x3.hip as split planes from ONE QKV GEMM — q (x 1/8) and k head-major,
+// V TRANSPOSED (through the epilogue's LDS image) and blocked by tiles of 32 global token rows
+enum { VN_EPI_STORE = 0, VN_EPI_BIAS = 1, VN_EPI_RESIDUAL = 2, VN_EPI_GEGLU = 3, VN_EPI_QKV = 4, VN_EPI_QKV3 = 5 };
 
 struct vn_gemm_args {
     const float* A;      // [M][K] row-major, lda = K
@@ -214,6 +214,8 @@ struct vn_gemm_args {
     // QKV scatter: C = qkv base [3][B][H][T][64]; row m = b*T + t
     int T, H;
     long qkv_plane;      // B*H*T*64
+    uint16_t* V16;       // QKV3 epilogue: V^T planes [3][H][ceil(M / 32)][64][32], v_plane elements apart (C16 = q then k planes)
+    long v_plane;
     int staged;          // gemm_x3.hip: epilogue through LDS with 16-byte global accesses (set by the launcher when alignment allows)
 };
 int vn_launch_gemm_f32(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);
