@@ -592,11 +592,19 @@ static int x3_env(const char* name, int dflt) {
 }
 
 // tuning / test hooks (process-global): tile height 128 / 256, stream-K on / off, forced split-K of the data-parallel form,
-// ablation bits.  Defaults: VN_X3_BM (128), VN_X3_SK (-1: by shape).
+// ablation bits.  Defaults: VN_X3_BM (0: by shape), VN_X3_SK (-1: by shape).
 static int g_x3_bm = 0, g_x3_sk = -1, g_x3_split = -2, g_x3_abl = -1;
-static int x3_bm() {
-    static const int bm = x3_env("VN_X3_BM", 128) == 256 ? 256 : 128;
-    return g_x3_bm ? g_x3_bm : bm;
+// tile height: 0 (default) = by shape.  The 256 x 128 tile moves 25 % fewer operand bytes per flop (fewer DMA and LDS reads
+// at the chip's power limit) but its rounds are twice as coarse: it wins where it still fills whole rounds (W1 + GEGLU at
+// B = 8: 720 tiles = 2.8 rounds, 305 vs 319 us) and loses elsewhere (QKV 540 tiles = 2.1 rounds: 283 vs 251 us;
+// profiles/r02_gemm_x3_staged_epilogue_shapes.txt).
+static int x3_bm(const vn_gemm_args& a, int cus) {
+    static const int bm_env = x3_env("VN_X3_BM", 0);
+    const int bm = g_x3_bm ? g_x3_bm : bm_env;
+    if (bm == 128 || bm == 256) return bm;
+    const long t256 = (long)vn_cdiv(a.M, 256) * vn_cdiv(a.N, X3_BN);
+    const long rounds = (t256 + cus - 1) / cus;
+    return (rounds >= 2 && 10 * t256 >= 9 * rounds * cus) ? 256 : 128;
 }
 // Work distribution.  -1 (default) = by shape: stream-K where one data-parallel round would leave more than a quarter of the CUs
 // without a tile and the epilogue has no split-K form (the one- / two-sequence QKV, GEGLU and classifier GEMMs: 51 vs 59 us
@@ -669,16 +677,15 @@ static int x3_go(vn_ctx* ctx, const vn_gemm_args& a_in, int nsplit, bool sk, hip
     return VN_OK;
 }
 template <int EPI>
-static int x3_go_bm(vn_ctx* ctx, const vn_gemm_args& a, int nsplit, bool sk, hipStream_t s) {
-    return x3_bm() == 256 ? x3_go<EPI, 2>(ctx, a, nsplit, sk, s) : x3_go<EPI, 1>(ctx, a, nsplit, sk, s);
+static int x3_go_bm(vn_ctx* ctx, const vn_gemm_args& a, int nsplit, bool sk, int bm, hipStream_t s) {
+    return bm == 256 ? x3_go<EPI, 2>(ctx, a, nsplit, sk, s) : x3_go<EPI, 1>(ctx, a, nsplit, sk, s);
 }
 
 // data-parallel form only: split count for the store / residual epilogues.  A launch costs ceil(tiles * ns / 256) rounds of
 // K / ns, plus the reduce pass over (ns + 1 or 2) images of C (1.45 us per k-tile and round, ~3.5 TB/s for the reduce).
-static int x3_pick_split(const vn_gemm_args& a, bool residual) {
+static int x3_pick_split(const vn_gemm_args& a, bool residual, int bm) {
     static const int forced_env = x3_env("VN_X3_SPLITK", -1);      // 0 / 1: off, 2 / 4: forced
     const int forced = g_x3_split != -2 ? g_x3_split : forced_env;
-    const int bm = x3_bm();
     const int tiles = vn_cdiv(a.M, bm) * vn_cdiv(a.N, X3_BN), nk = a.K / X3_KT;
     if (forced == 0 || forced == 1 || (a.N & 3) || (a.ldc & 3)) return 1;
     int best = 1;
@@ -701,13 +708,14 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
                          ((EPI == VN_EPI_GEGLU && a.C16) ? 6.0 : 4.0) * (double)a.M * n_out * (EPI == VN_EPI_RESIDUAL ? 2 : 1);
     const int pi = vn_prof_pre(ctx, 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);       // algorithmic (fp32-equivalent) flops
     int rc = VN_OK;
-    const bool sk = x3_sk(vn_cdiv(a.M, x3_bm()) * vn_cdiv(a.N, X3_BN), x3_num_cus(ctx), EPI == VN_EPI_STORE || EPI == VN_EPI_RESIDUAL);
+    const int bm = x3_bm(a, x3_num_cus(ctx));
+    const bool sk = x3_sk(vn_cdiv(a.M, bm) * vn_cdiv(a.N, X3_BN), x3_num_cus(ctx), EPI == VN_EPI_STORE || EPI == VN_EPI_RESIDUAL);
     bool done = false;
     if constexpr (EPI == VN_EPI_STORE) {
         static const int abl_env = x3_env("VN_X3_ABL", 0) & 7;             // ablations (tuning only; results invalid)
         const int abl = g_x3_abl >= 0 ? g_x3_abl : abl_env;
         if (abl) {
-            const bool big = x3_bm() == 256;
+            const bool big = bm == 256;
             if (abl == 1) rc = big ? x3_go<VN_EPI_STORE, 2, 1>(ctx, a, 1, sk, s) : x3_go<VN_EPI_STORE, 1, 1>(ctx, a, 1, sk, s);
             else if (abl == 2) rc = big ? x3_go<VN_EPI_STORE, 2, 2>(ctx, a, 1, sk, s) : x3_go<VN_EPI_STORE, 1, 2>(ctx, a, 1, sk, s);
             else if (abl == 3) rc = big ? x3_go<VN_EPI_STORE, 2, 3>(ctx, a, 1, sk, s) : x3_go<VN_EPI_STORE, 1, 3>(ctx, a, 1, sk, s);
@@ -716,18 +724,18 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
         }
     }
     if constexpr (EPI == VN_EPI_STORE || EPI == VN_EPI_RESIDUAL) {
-        const int ns = (done || sk) ? 1 : x3_pick_split(a, EPI == VN_EPI_RESIDUAL);
+        const int ns = (done || sk) ? 1 : x3_pick_split(a, EPI == VN_EPI_RESIDUAL, bm);
         if (ns > 1) {
             if (!ctx->x3_ws) VN_HIP_CHECK(ctx, hipMalloc((void**)&ctx->x3_ws, (size_t)X3_WS_FLOATS * sizeof(float)));
             vn_gemm_args q = a;                       // every split stores its raw image [M][N] into the workspace
             q.C = ctx->x3_ws;
             q.ldc = a.N;
-            rc = x3_go_bm<VN_EPI_STORE>(ctx, q, ns, false, s);
+            rc = x3_go_bm<VN_EPI_STORE>(ctx, q, ns, false, bm, s);
             if (rc == VN_OK) rc = vn_launch_splitk_reduce(ctx, ctx->x3_ws, ns, a.C, a.M, a.N, a.ldc, EPI == VN_EPI_RESIDUAL, s);
             done = true;
         }
     }
-    if (!done) rc = x3_go_bm<EPI>(ctx, a, 1, sk, s);
+    if (!done) rc = x3_go_bm<EPI>(ctx, a, 1, sk, bm, s);
     vn_prof_post(ctx, pi, s);
     return rc;
 }

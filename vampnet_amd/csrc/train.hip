@@ -233,7 +233,8 @@ static vn_drop make_drop(const vn_train_params* p, int layer, int site, long row
     return d;
 }
 
-// STAGED (round 2; VN_TRAIN_X3=1, not yet run on a GPU): route every GEMM of the training step — forward, dX and dW —
+// Opt-in (VN_TRAIN_X3=1; parity-green on MI355X, tests/test_gpu_train.py::test_training_step_on_bf16x3_gemms; 102.5 vs 99.6 ms
+// per step, so not the default): route every GEMM of the training step — forward, dX and dW —
 // through the bf16x3 kernel (gemm_x3.hip, verified on the inference path).  Both fp32 operands are split into their three
 // exact bf16 planes on the fly (vn_split3_f32: two extra HBM passes per GEMM, ~10 % of its time), so nothing else in
 // the step changes; bf16 keeps fp32's exponent range, which the tiny dlogits / dY magnitudes of the backward pass need
