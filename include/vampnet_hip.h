@@ -367,10 +367,9 @@ int vn_debug_graph_replays(const vn_model* model, int64_t* count);
 /* tuning hook (scripts/gemm_sweep.py): force the GEMM block tile (bm x bn in {128,64}^2; 0,0 = automatic) and the
  * tile walk order (0 column-major, 1 grouped 8-row patches, -1 keep).  Process-global; not for production use.   */
 int vn_debug_gemm_config(int bm, int bn, int order);
-/* same for the bf16x3 GEMM (gemm_x3.hip): bm = tile height 128 / 256 (0 = VN_X3_BM / default); stream_k 1 / 0 = stream-K or
- * data-parallel work distribution (-1 = VN_X3_SK / default 1); splitk (data-parallel form only) 0/1 off, 2/4 forced, -1 =
- * cost model; abl = ablation bits (tuning; results invalid), -1 = none                                                    */
-int vn_debug_x3_config(int bm, int stream_k, int splitk, int abl);
+/* same for the bf16x3 GEMM (gemm_x3.hip): bm = tile height 128 / 256 (0 = VN_X3_BM / by shape); splitk 0/1 off, 2/4 forced,
+ * -1 = cost model; abl = ablation bits (tuning; results invalid), -1 = none                                              */
+int vn_debug_x3_config(int bm, int splitk, int abl);
 /* average duration (us) of `iters` launches of the bf16x3 attention kernel alone (planes prepared outside the timed region) */
 int vn_debug_attention_x3_time(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias, float* out,
                                int B, int H, int T, int iters, float* avg_us, void* stream);

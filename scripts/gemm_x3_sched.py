@@ -1,4 +1,4 @@
-"""bf16x3 GEMM: tile height (128 / 256) x work distribution (stream-K / data-parallel + split-K) on the model's shapes,
+"""bf16x3 GEMM: tile height (128 / 256 / by shape) on the model's shapes,
 interleaved rounds in ONE process (median of ROUNDS), real split planes of N(0,1) operands.  TF-eq = 2MNK / t
 (fp32-equivalent); the matrix pipe executes 6x that.  Second table: ablations of the kernels (results invalid)."""
 import statistics
@@ -16,7 +16,7 @@ SHAPES = [("qkv B8", 4600, 3840, 1280, _lib.EPI_STORE), ("wo  B8", 4600, 1280, 1
           ("cls B8", 4600, 4096, 1280, _lib.EPI_BIAS), ("qkv c2f", 1384, 3840, 1280, _lib.EPI_STORE),
           ("w2  c2f", 1384, 1280, 2560, _lib.EPI_RESIDUAL), ("qkv B1", 575, 3840, 1280, _lib.EPI_STORE),
           ("sq 4096", 4096, 4096, 4096, _lib.EPI_STORE), ("sq 8192", 8192, 8192, 8192, _lib.EPI_STORE)]
-PIPES = [(128, 1), (256, 1), (128, 0), (256, 0)]
+PIPES = [128, 256, 0]
 ROUNDS = 5
 
 
@@ -32,12 +32,12 @@ def timeit(fn, n=10):
     return a.elapsed_time(b) / n * 1e-3
 
 
-def cfg(p=(0, -1), split=-1, abl=-1):
-    eng.check(eng.lib.vn_debug_x3_config(p[0], p[1], split, abl), "vn_debug_x3_config")
+def cfg(p=0, split=-1, abl=-1):
+    eng.check(eng.lib.vn_debug_x3_config(p, split, abl), "vn_debug_x3_config")
 
 
 def name_of(p):
-    return ("sk" if p[1] else "dp") + str(p[0])
+    return "bm" + (str(p) if p else "auto")
 
 
 print(f"{'shape':10s} " + " ".join(f"{name_of(p) + ' us':>10s} {'TF-eq':>6s} {'%pipe':>6s}" for p in PIPES))
@@ -68,7 +68,7 @@ for name, M, N, K in [("qkv B8", 4600, 3840, 1280), ("sq 4096", 4096, 4096, 4096
     a3 = eng.split3(torch.randn(M, K, device="cuda", generator=g))
     w3 = eng.split3(torch.randn(N, K, device="cuda", generator=g) / K ** 0.5)
     out = torch.zeros(M, N, device="cuda")
-    for p in ((128, 0), (256, 0)):
+    for p in (128, 256):
         row = f"{name:8s} {name_of(p)}: "
         for abl in (0, 1, 2, 3, 4):
             cfg(p, 1, abl)

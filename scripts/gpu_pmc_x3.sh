@@ -2,10 +2,10 @@
 # PMC counters for the bf16x3 GEMM kernel (one counter group per pass; no trace domains).  $1 = tile height (128 / 256),
 # $2 = 1 stream-K / 0 data-parallel.  Output: gpurun_out/pmc_x3_bm$1_sk$2/
 BM=${1:-128}
-SK=${2:-1}
-O=gpurun_out/pmc_x3_bm${BM}_sk$SK
+
+O=gpurun_out/pmc_x3_bm${BM}
 mkdir -p $O
-export TMPDIR=/tmp VN_X3_BM=$BM VN_X3_SK=$SK
+export TMPDIR=/tmp VN_X3_BM=$BM
 R=$GRAFT_REPO_ROOT
 cd /tmp
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INST_LEVEL_VMEM" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do

@@ -509,96 +509,3 @@ def test_split_plane_gemm_lds_addressing():
 
     assert check(1, 3) == (48 * 1024, 6)          # gemm_x3.hip, 128 x 128
     assert check(2, 3) == (72 * 1024, 9)          # gemm_x3.hip, 256 x 128 (ping-pong)
-
-
-def test_stream_k_partition_and_fixup_slab_map():
-    """Model of gemm_x3.hip's stream-K work distribution: the tile walk is cut into eight per-XCD chunks; inside a chunk the
-    Gx blocks of that XCD take whole tiles round-robin and the left-over nt < Gx tiles are cut along k into Gx contiguous
-    unit ranges.  Replays the kernel's segment walk (which segment is finished in place, which goes to the block's slab 0 /
-    1) and the fix-up kernel's search (which slabs a tile adds, in which order) for many shapes: every k-tile unit of every
-    tile is multiplied exactly once, a tile is either finished in pass 1 or rebuilt in pass 2 from exactly the slabs pass 1
-    wrote for it, in ascending k order, and no slab is written twice."""
-    def chunk(ntiles, xcd):
-        q, r = ntiles >> 3, ntiles & 7
-        return (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q), q + (1 if xcd < r else 0)
-
-    def unit0(U, i, Gx):
-        return U * i // Gx
-
-    def check(ntiles, nk, G):
-        Gx = G >> 3
-        done_in_pass1, slab_of = set(), {}                  # slab index -> (tile, kb, ke)
-        covered = [[0] * nk for _ in range(ntiles)]
-        for bid in range(G):
-            xcd, i = bid & 7, bid >> 3
-            c0, n = chunk(ntiles, xcd)
-            full = n // Gx
-            Ut = (n - full * Gx) * nk
-            tu, tu_end = unit0(Ut, i, Gx), unit0(Ut, i + 1, Gx)
-            tu_first = tu
-            for seg in range(full + (2 if tu_end > tu else 0)):
-                if seg < full:
-                    t, kb, ke = c0 + seg * Gx + i, 0, nk
-                else:
-                    if tu >= tu_end:
-                        break
-                    tt = tu // nk
-                    kb = tu - tt * nk
-                    ke = kb + (tu_end - tu) if (tu_end - tu) < (nk - kb) else nk
-                    t = c0 + full * Gx + tt
-                    first_tail = tu == tu_first
-                    tu += ke - kb
-                for k in range(kb, ke):
-                    covered[t][k] += 1
-                if kb == 0 and ke == nk:
-                    done_in_pass1.add(t)
-                else:
-                    idx = 2 * (xcd * Gx + i) + (0 if first_tail else 1)
-                    assert idx not in slab_of and idx < 2 * G
-                    slab_of[idx] = (t, kb, ke)
-            assert tu == tu_end
-        assert covered == [[1] * nk for _ in range(ntiles)]
-        tail = any(chunk(ntiles, x)[1] % Gx for x in range(8))
-        assert tail or not slab_of
-        for t in range(ntiles):
-            xcd = 0
-            c0, n = chunk(ntiles, 0)
-            while xcd < 7 and t >= c0 + n:
-                xcd += 1
-                c0, n = chunk(ntiles, xcd)
-            full = n // Gx
-            tt = t - c0 - full * Gx
-            if tt < 0:
-                assert t in done_in_pass1
-                continue
-            Ut = (n - full * Gx) * nk
-            t0, t1 = tt * nk, (tt + 1) * nk
-            i = t0 * Gx // Ut
-            while i > 0 and unit0(Ut, i, Gx) > t0:
-                i -= 1
-            while i + 1 < Gx and unit0(Ut, i + 1, Gx) <= t0:
-                i += 1
-            got, whole = [], False
-            while i < Gx:
-                b0, b1 = unit0(Ut, i, Gx), unit0(Ut, i + 1, Gx)
-                if b0 >= t1:
-                    break
-                if b1 > b0:
-                    if b0 <= t0 and b1 >= t1:
-                        whole = True
-                        break
-                    s0 = max(b0, t0)
-                    got.append(slab_of.pop(2 * (xcd * Gx + i) + (1 if s0 != b0 else 0)))
-                i += 1
-            if whole:
-                assert t in done_in_pass1 and not got
-                continue
-            assert t not in done_in_pass1
-            assert [g[0] for g in got] == [t] * len(got) and len(got) >= 2
-            assert got[0][1] == 0 and got[-1][2] == nk and all(a[2] == b[1] for a, b in zip(got, got[1:]))
-        assert not slab_of                                  # every slab written in pass 1 was consumed exactly once
-
-    for ntiles, nk in [(1080, 40), (360, 40), (360, 80), (2880, 40), (1152, 40), (540, 40), (150, 40), (50, 80), (1, 1), (2, 2),
-                       (4, 1), (1, 3), (6, 5), (256, 40), (512, 40), (257, 3), (1024, 128), (9, 2), (17, 7), (255, 1)]:
-        for G in (256, 304, 8, 16):
-            check(ntiles, nk, G)

@@ -258,8 +258,13 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
         a.W = bf ? W16(id, layer) : W(m, id, layer);
         a.bf16 = gm; a.a_plane = a_plane; a.w_plane = m->w_plane;
     };
-    // bf16x3: attention on the bf16 matrix cores too (attention_x3.hip); VN_ATTN_X3=0 keeps the fp32-input MFMA kernel (A/B runs)
-    static const bool attn_x3 = [] { const char* e = getenv("VN_ATTN_X3"); return !(e && e[0] == '0'); }();
+    // bf16x3: attention on the bf16 matrix cores too (attention_x3.hip) once there are enough 128-query blocks to fill the chip
+    // (>= 1.5 per CU); below that (one or two sequences) the 64-query blocks of the fp32-input MFMA kernel fill it better
+    // (B = 1, coarse: 55.6 vs 57.8 ms per clip, profiles/r02_c10_3_cfg1_*.json).  VN_ATTN_X3 = 0 / 1 forces one of them (A/B runs).
+    static const int attn_x3_env = [] { const char* e = getenv("VN_ATTN_X3"); return e ? atoi(e) : -1; }();
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const bool attn_x3 = attn_x3_env >= 0 ? attn_x3_env != 0 : 2L * B * H * ((T + 127) / 128) >= 3L * cus;
     for (int l = 0; l < m->L; ++l) {
         // y = RMSNorm(x) ; FiLM = identity (d_cond = 0, transformer.py:554)
         if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM1, l), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr, yp))) return rc;

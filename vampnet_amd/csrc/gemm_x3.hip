@@ -32,18 +32,13 @@
 //   * Epilogues as in gemm_f32.hip (store / bias / residual / GEGLU gate / QKV head-major scatter); the GEGLU result is
 //     written as three planes again (it is only ever the A operand of the next GEMM).
 //   * rows >= M and columns >= N are clamped on load and masked on store.
-// Work distribution, by shape (x3_sk below):
-//   * data-parallel: one block per output tile, XCD-aware tile walk (8-row tile groups, one contiguous eighth of the walk per
-//     XCD); the store / residual epilogues of badly filling shapes are split along K in two passes (split images to a
-//     workspace, vn_splitk_reduce_kernel adds them in fixed order).  Default for everything that fills the chip: with every
-//     CU busy the kernel sits at the chip's power limit (~1.75 GHz, GRBM_GUI_ACTIVE / duration), a partly filled last round
-//     runs at a higher clock, and an evenly balanced launch measured no faster (profiles/r02_gemm_x3_streamk_v2_vs_dp.txt).
-//   * "stream-K" for launches that leave more than a quarter of the CUs without a tile: one persistent block per CU; inside an
-//     XCD's chunk of the walk the blocks take whole tiles round-robin (so co-running blocks work on adjacent tiles and share
-//     the A / W panels in L2) and the left-over tiles are cut along k into equal contiguous ranges.  A block that covers a
-//     whole tile finishes it with the fused epilogue; partial tiles are stored as raw fp32 accumulator images ("slabs",
-//     fragment order, 16-byte coalesced) and vn_gemm_x3_fixup_kernel adds a tile's slabs in k order and runs the same
-//     epilogue — deterministic, no flags, no atomics.
+// Work distribution: data-parallel, one block per output tile, XCD-aware tile walk (8-row tile groups, one contiguous eighth
+// of the walk per XCD); the store / residual epilogues of badly filling shapes are split along K in two passes (split images
+// to a workspace, vn_splitk_reduce_kernel adds them in fixed order).  A persistent stream-K distribution (per-XCD round-robin
+// whole tiles + k-split tail, deterministic two-pass fix-up) was built, verified and measured in round 2 and removed again:
+// with every CU busy the kernel sits at the chip's power limit (~1.75 GHz, GRBM_GUI_ACTIVE / duration) while a partly filled
+// last round runs at a higher clock, so the evenly balanced launch gained <= 2.5 % on the QKV shape, lost to its fix-up pass on
+// Wo / W1 / W2 and lost 3 ms of 55 on the B = 1 path (profiles/r02_gemm_x3_streamk_v2_vs_dp.txt, r02_c10_3_cfg1_*.json).
 // On the GPU the result is within 7.5e-6 of float64 at 4600 x 3840 x 1280 (the fp32-input MFMA kernel: 9e-6).
 #include <stdlib.h>
 #include "vn_common.h"
@@ -266,38 +261,11 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
     }
 }
 
-// stream-K partition.  The walk of tiles (x3_tile_coords order) is cut into eight contiguous chunks, one per XCD (blocks with
-// blockIdx % 8 == x run on XCD x and share its L2).  Inside a chunk of n tiles the Gx = G / 8 blocks of that XCD take whole
-// tiles round-robin for floor(n / Gx) rounds — at any moment they work on ADJACENT tiles, which is what keeps the A / W panels
-// L2-resident (contiguous per-block ranges ran 35-45 % slower, profiles/r02_gemm_x3_streamk_v1_vs_dp.txt) — and the
-// remaining nt < Gx tiles are cut along k into Gx equal contiguous ranges of k-tile units ("tail").
-struct x3_chunk { int c0, n; };
-__device__ __host__ __forceinline__ x3_chunk x3_xcd_chunk(int ntiles, int xcd) {
-    const int q = ntiles >> 3, r = ntiles & 7;
-    return {xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, q + (xcd < r ? 1 : 0)};
-}
-__device__ __host__ __forceinline__ long x3_unit0(long U, int i, int Gx) { return U * i / Gx; }
-
-// slab = one tile's accumulators in fragment order: chunk c (16 bytes per lane) of wave w at ((w * 8 MI + c) * 64 + lane) * 4
-template <int MI>
-__device__ __forceinline__ void x3_slab_store(float* slab, const f32x16 (&acc)[MI][2], int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x4 v = {acc[i][j][4 * c], acc[i][j][4 * c + 1], acc[i][j][4 * c + 2], acc[i][j][4 * c + 3]};
-                *(f32x4*)(slab + ((size_t)(wave * 8 * MI + (i * 2 + j) * 4 + c) * 64 + lane) * 4) = v;
-            }
-}
-
-// SK = false: data-parallel, one block per output tile (gridDim.y > 1: split-K images, store epilogue only).
-// SK = true : stream-K, see the file header.  slabs: [2 G] images of (128 MI x 128) floats.
+// one block per output tile (gridDim.y > 1: split-K images, store epilogue only)
 // ABL (tuning only, results invalid): bit 0 = no DMA inside the k-loop, bit 1 = no fragment reads inside the k-loop, bit 2 =
 // every DMA instruction fetches 8 rows x 128 B (whole cache lines, same volume) instead of 16 rows x 64 B
-template <int EPI, int MI, bool SK, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int tiles_m, int tiles_n, float* slabs) {
+template <int EPI, int MI, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int tiles_m, int tiles_n) {
     using G = x3_geo<MI>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -316,48 +284,11 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
     const int aRow = (wm * 32 * MI + l31) * 16;
     const int bRow = (wn * 64 + l31) * 16;
 
-    // ---- this block's work.  SK: whole tiles of its XCD's chunk round-robin, then a k-range of the chunk's tail tiles;
-    // else one tile (and one k-split of it)
-    int sk_c0 = 0, sk_full = 0, sk_gx = 1, sk_i = 0, sk_slab = 0;
-    long tu = 0, tu_end = 0;                          // SK: this block's range of tail units
-    int seg = 0, nseg = 1;
-    if constexpr (SK) {
-        const int xcd = blockIdx.x & 7;
-        sk_i = blockIdx.x >> 3;
-        sk_gx = gridDim.x >> 3;
-        const x3_chunk ch = x3_xcd_chunk(ntiles, xcd);
-        sk_c0 = ch.c0;
-        sk_full = ch.n / sk_gx;
-        const long Ut = (long)(ch.n - sk_full * sk_gx) * nk_all;
-        tu = x3_unit0(Ut, sk_i, sk_gx);
-        tu_end = x3_unit0(Ut, sk_i + 1, sk_gx);
-        sk_slab = 2 * (xcd * sk_gx + sk_i);
-        nseg = sk_full + (tu_end > tu ? 2 : 0);       // upper bound; the loop stops when the tail range is used up
-    } else {
-        if (gridDim.y > 1) p.C += (size_t)blockIdx.y * p.M * p.N;
-    }
-    const long tu_first = tu;
-
-    for (; seg < nseg; ++seg) {
-        int t, kb, ke;
-        bool first_tail = false;
-        if constexpr (SK) {
-            if (seg < sk_full) {
-                t = sk_c0 + seg * sk_gx + sk_i; kb = 0; ke = nk_all;
-            } else {
-                if (tu >= tu_end) break;
-                const int tt = (int)(tu / nk_all);
-                kb = (int)(tu - (long)tt * nk_all);
-                ke = (tu_end - tu) < (long)(nk_all - kb) ? kb + (int)(tu_end - tu) : nk_all;
-                t = sk_c0 + sk_full * sk_gx + tt;
-                first_tail = tu == tu_first;
-                tu += ke - kb;
-            }
-        } else {
-            t = x3_xcd_remap(blockIdx.x, gridDim.x);
-            kb = (int)((long)nk_all * blockIdx.y / gridDim.y);
-            ke = (int)((long)nk_all * (blockIdx.y + 1) / gridDim.y);
-        }
+    // ---- this block's tile (and, for split-K launches, its k-range)
+    if (gridDim.y > 1) p.C += (size_t)blockIdx.y * p.M * p.N;
+    {
+        const int t = x3_xcd_remap(blockIdx.x, gridDim.x);
+        const int kb = (int)((long)nk_all * blockIdx.y / gridDim.y), ke = (int)((long)nk_all * (blockIdx.y + 1) / gridDim.y);
         int tm, tn;
         x3_tile_coords(t, tiles_m, tiles_n, tm, tn);
         const int m0 = tm * G::BM, n0 = tn * X3_BN;
@@ -435,7 +366,6 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         };
 
         const int nk = ke - kb;
-        if (seg) X3_BARRIER();                              // the previous segment's last LDS reads have retired everywhere
         if constexpr (MI == 1) {
             // three buffers; tile kt lives in buffer kt % 3.  Phase intervals I_j between consecutive barriers: group 0 loads
             // step i in I_2i and computes it in I_2i+1, group 1 one interval later.  Tile kt is read in I_4kt .. I_4kt+3 (every
@@ -524,76 +454,20 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             }
         }
 
-        if (!SK || (kb == 0 && ke == nk_all)) {
-            if (p.staged) x3_epilogue_staged<EPI, MI>(p, acc, m0, n0, wave, lane, lds);
-            else x3_epilogue<EPI, MI>(p, acc, m0, n0, wm, wn, lane);
-        } else {
-            // a shared tile: raw accumulators to this block's first / second slab (the fix-up kernel recomputes the same map)
-            x3_slab_store<MI>(slabs + (size_t)(sk_slab + (first_tail ? 0 : 1)) * (G::BM * X3_BN), acc, wave, lane);
-        }
+        if (p.staged) x3_epilogue_staged<EPI, MI>(p, acc, m0, n0, wave, lane, lds);
+        else x3_epilogue<EPI, MI>(p, acc, m0, n0, wm, wn, lane);
     }
 }
 
-// stream-K pass 2: one block per output tile; tiles that one block computed whole were finished in pass 1 (exit); for a
-// tail tile add the slabs of the blocks of its XCD whose unit ranges meet it, in k order, and run the epilogue.
-template <int EPI, int MI>
-__global__ __launch_bounds__(512) void vn_gemm_x3_fixup_kernel(vn_gemm_args p, int tiles_m, int tiles_n, const float* slabs, int G) {
-    const int t = blockIdx.x;
-    const int nk = p.K / X3_KT;
-    const int ntiles = tiles_m * tiles_n, Gx = G >> 3;
-    int xcd = 0;
-    x3_chunk ch = x3_xcd_chunk(ntiles, 0);
-    while (xcd < 7 && t >= ch.c0 + ch.n) ch = x3_xcd_chunk(ntiles, ++xcd);
-    const int full = ch.n / Gx;
-    const int tt = t - ch.c0 - full * Gx;              // index among the chunk's tail tiles
-    if (tt < 0) return;                                // a whole tile of the round-robin part: done in pass 1
-    const long Ut = (long)(ch.n - full * Gx) * nk;
-    const long t0 = (long)tt * nk, t1 = t0 + nk;
-    int i = (int)(t0 * Gx / Ut);                       // block whose range holds unit t0 (+- 1 from the integer divisions)
-    while (i > 0 && x3_unit0(Ut, i, Gx) > t0) --i;
-    while (i + 1 < Gx && x3_unit0(Ut, i + 1, Gx) <= t0) ++i;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x16 acc[MI][2];
-#pragma unroll
-    for (int a = 0; a < MI; ++a)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][j][r] = 0.0f;
-    for (; i < Gx; ++i) {
-        const long b0 = x3_unit0(Ut, i, Gx), b1 = x3_unit0(Ut, i + 1, Gx);
-        if (b0 >= t1) break;
-        if (b1 <= b0) continue;                          // empty range (fewer units than blocks)
-        if (b0 <= t0 && b1 >= t1) return;                // one block had the whole tile: finished in pass 1
-        const long s0 = b0 > t0 ? b0 : t0;               // the block's segment inside this tile starts here
-        const float* slab = slabs + (size_t)(2 * (xcd * Gx + i) + (s0 != b0 ? 1 : 0)) * (128 * MI * X3_BN);
-#pragma unroll
-        for (int a = 0; a < MI; ++a)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const f32x4 v = *(const f32x4*)(slab + ((size_t)(wave * 8 * MI + (a * 2 + j) * 4 + c) * 64 + lane) * 4);
-                    acc[a][j][4 * c] += v[0]; acc[a][j][4 * c + 1] += v[1]; acc[a][j][4 * c + 2] += v[2]; acc[a][j][4 * c + 3] += v[3];
-                }
-    }
-    int tm, tn;
-    x3_tile_coords(t, tiles_m, tiles_n, tm, tn);
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    if (p.staged) x3_epilogue_staged<EPI, MI>(p, acc, tm * 128 * MI, tn * X3_BN, wave, lane, lds);
-    else x3_epilogue<EPI, MI>(p, acc, tm * 128 * MI, tn * X3_BN, wave >> 1, wave & 1, lane);
-}
-
-#define X3_WS_FLOATS (32L << 20)          // 128 MiB: stream-K slabs (2 x 256 x 64 / 128 KiB) or split-K images; allocated once
+#define X3_WS_FLOATS (32L << 20)          // 128 MiB of split-K partial images, allocated once (graph-safe: never re-allocated)
 
 static int x3_env(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
 }
 
-// tuning / test hooks (process-global): tile height 128 / 256, stream-K on / off, forced split-K of the data-parallel form,
-// ablation bits.  Defaults: VN_X3_BM (0: by shape), VN_X3_SK (-1: by shape).
-static int g_x3_bm = 0, g_x3_sk = -1, g_x3_split = -2, g_x3_abl = -1;
+// tuning / test hooks (process-global): tile height 128 / 256, forced split-K, ablation bits
+static int g_x3_bm = 0, g_x3_split = -2, g_x3_abl = -1;
 // tile height: 0 (default) = by shape.  The 256 x 128 tile moves 25 % fewer operand bytes per flop (fewer DMA and LDS reads
 // at the chip's power limit) but its rounds are twice as coarse: it wins where it still fills whole rounds (W1 + GEGLU at
 // B = 8: 720 tiles = 2.8 rounds, 305 vs 319 us) and loses elsewhere (QKV 540 tiles = 2.1 rounds: 283 vs 251 us;
@@ -606,20 +480,9 @@ static int x3_bm(const vn_gemm_args& a, int cus) {
     const long rounds = (t256 + cus - 1) / cus;
     return (rounds >= 2 && 10 * t256 >= 9 * rounds * cus) ? 256 : 128;
 }
-// Work distribution.  -1 (default) = by shape: stream-K where one data-parallel round would leave more than a quarter of the CUs
-// without a tile and the epilogue has no split-K form (the one- / two-sequence QKV, GEGLU and classifier GEMMs: 51 vs 59 us
-// on the B = 1 QKV shape); data-parallel (+ two-pass split-K for the store / residual epilogues) everywhere else — with every
-// CU busy the chip sits at its power limit and an evenly balanced launch gains nothing there
-// (profiles/r02_gemm_x3_streamk_v2_vs_dp.txt: QKV B = 8 246 vs 252 us, Wo / W1 / W2 slower by the fix-up pass).
-static bool x3_sk(int ntiles, int cus, bool has_splitk) {
-    static const int sk_env = x3_env("VN_X3_SK", -1);
-    const int sk = g_x3_sk >= 0 ? g_x3_sk : sk_env;
-    if (sk >= 0) return sk != 0;
-    return !has_splitk && 4 * ntiles < 3 * cus;
-}
-extern "C" int vn_debug_x3_config(int bm, int stream_k, int splitk, int abl) {
+extern "C" int vn_debug_x3_config(int bm, int splitk, int abl) {
     if (bm != 0 && bm != 128 && bm != 256) return VN_ERR_INVALID;
-    g_x3_bm = bm; g_x3_sk = stream_k < 0 ? -1 : (stream_k != 0); g_x3_split = splitk < 0 ? -2 : splitk;
+    g_x3_bm = bm; g_x3_split = splitk < 0 ? -2 : splitk;
     g_x3_abl = abl < 0 ? -1 : (abl & 7);
     return VN_OK;
 }
@@ -654,34 +517,20 @@ static int x3_staged_ok(const vn_gemm_args& a) {
 }
 
 template <int EPI, int MI, int ABL = 0>
-static int x3_go(vn_ctx* ctx, const vn_gemm_args& a_in, int nsplit, bool sk, hipStream_t s) {
+static int x3_go(vn_ctx* ctx, const vn_gemm_args& a_in, int nsplit, hipStream_t s) {
     vn_gemm_args a = a_in;
     a.staged = x3_staged_ok<EPI>(a);
     const int tiles_m = vn_cdiv(a.M, 128 * MI), tiles_n = vn_cdiv(a.N, X3_BN);
-    if (sk) {
-        const int ntiles = tiles_m * tiles_n;
-        const int G = x3_num_cus(ctx) & ~7;                  // one persistent block per CU, the same number on every XCD
-        if (G < 8 || (size_t)2 * G * 128 * MI * X3_BN > (size_t)X3_WS_FLOATS) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: slab workspace too small%s", "");
-        if (!ctx->x3_ws) VN_HIP_CHECK(ctx, hipMalloc((void**)&ctx->x3_ws, (size_t)X3_WS_FLOATS * sizeof(float)));
-        hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, MI, true, ABL>), dim3(G), dim3(512), x3_lds_bytes<MI>(), s, a, tiles_m, tiles_n, ctx->x3_ws);
-        VN_LAUNCH_CHECK(ctx);
-        bool tail = false;                                   // does any XCD chunk leave tiles to the k-split tail ?
-        for (int x = 0; x < 8; ++x) tail = tail || (x3_xcd_chunk(ntiles, x).n % (G >> 3)) != 0;
-        if (tail)
-            hipLaunchKernelGGL((vn_gemm_x3_fixup_kernel<EPI, MI>), dim3(ntiles), dim3(512), 104 * 1024, s, a, tiles_m, tiles_n, ctx->x3_ws, G);
-    } else {
-        hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, MI, false, ABL>), dim3(tiles_m * tiles_n, nsplit), dim3(512), x3_lds_bytes<MI>(), s, a,
-                           tiles_m, tiles_n, (float*)nullptr);
-    }
+    hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, MI, ABL>), dim3(tiles_m * tiles_n, nsplit), dim3(512), x3_lds_bytes<MI>(), s, a, tiles_m, tiles_n);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
 }
 template <int EPI>
-static int x3_go_bm(vn_ctx* ctx, const vn_gemm_args& a, int nsplit, bool sk, int bm, hipStream_t s) {
-    return bm == 256 ? x3_go<EPI, 2>(ctx, a, nsplit, sk, s) : x3_go<EPI, 1>(ctx, a, nsplit, sk, s);
+static int x3_go_bm(vn_ctx* ctx, const vn_gemm_args& a, int nsplit, int bm, hipStream_t s) {
+    return bm == 256 ? x3_go<EPI, 2>(ctx, a, nsplit, s) : x3_go<EPI, 1>(ctx, a, nsplit, s);
 }
 
-// data-parallel form only: split count for the store / residual epilogues.  A launch costs ceil(tiles * ns / 256) rounds of
+// split count for the store / residual epilogues.  A launch costs ceil(tiles * ns / 256) rounds of
 // K / ns, plus the reduce pass over (ns + 1 or 2) images of C (1.45 us per k-tile and round, ~3.5 TB/s for the reduce).
 static int x3_pick_split(const vn_gemm_args& a, bool residual, int bm) {
     static const int forced_env = x3_env("VN_X3_SPLITK", -1);      // 0 / 1: off, 2 / 4: forced
@@ -709,33 +558,32 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
     const int pi = vn_prof_pre(ctx, 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);       // algorithmic (fp32-equivalent) flops
     int rc = VN_OK;
     const int bm = x3_bm(a, x3_num_cus(ctx));
-    const bool sk = x3_sk(vn_cdiv(a.M, bm) * vn_cdiv(a.N, X3_BN), x3_num_cus(ctx), EPI == VN_EPI_STORE || EPI == VN_EPI_RESIDUAL);
     bool done = false;
     if constexpr (EPI == VN_EPI_STORE) {
         static const int abl_env = x3_env("VN_X3_ABL", 0) & 7;             // ablations (tuning only; results invalid)
         const int abl = g_x3_abl >= 0 ? g_x3_abl : abl_env;
         if (abl) {
             const bool big = bm == 256;
-            if (abl == 1) rc = big ? x3_go<VN_EPI_STORE, 2, 1>(ctx, a, 1, sk, s) : x3_go<VN_EPI_STORE, 1, 1>(ctx, a, 1, sk, s);
-            else if (abl == 2) rc = big ? x3_go<VN_EPI_STORE, 2, 2>(ctx, a, 1, sk, s) : x3_go<VN_EPI_STORE, 1, 2>(ctx, a, 1, sk, s);
-            else if (abl == 3) rc = big ? x3_go<VN_EPI_STORE, 2, 3>(ctx, a, 1, sk, s) : x3_go<VN_EPI_STORE, 1, 3>(ctx, a, 1, sk, s);
-            else rc = big ? x3_go<VN_EPI_STORE, 2, 4>(ctx, a, 1, sk, s) : x3_go<VN_EPI_STORE, 1, 4>(ctx, a, 1, sk, s);
+            if (abl == 1) rc = big ? x3_go<VN_EPI_STORE, 2, 1>(ctx, a, 1, s) : x3_go<VN_EPI_STORE, 1, 1>(ctx, a, 1, s);
+            else if (abl == 2) rc = big ? x3_go<VN_EPI_STORE, 2, 2>(ctx, a, 1, s) : x3_go<VN_EPI_STORE, 1, 2>(ctx, a, 1, s);
+            else if (abl == 3) rc = big ? x3_go<VN_EPI_STORE, 2, 3>(ctx, a, 1, s) : x3_go<VN_EPI_STORE, 1, 3>(ctx, a, 1, s);
+            else rc = big ? x3_go<VN_EPI_STORE, 2, 4>(ctx, a, 1, s) : x3_go<VN_EPI_STORE, 1, 4>(ctx, a, 1, s);
             done = true;
         }
     }
     if constexpr (EPI == VN_EPI_STORE || EPI == VN_EPI_RESIDUAL) {
-        const int ns = (done || sk) ? 1 : x3_pick_split(a, EPI == VN_EPI_RESIDUAL, bm);
+        const int ns = done ? 1 : x3_pick_split(a, EPI == VN_EPI_RESIDUAL, bm);
         if (ns > 1) {
             if (!ctx->x3_ws) VN_HIP_CHECK(ctx, hipMalloc((void**)&ctx->x3_ws, (size_t)X3_WS_FLOATS * sizeof(float)));
             vn_gemm_args q = a;                       // every split stores its raw image [M][N] into the workspace
             q.C = ctx->x3_ws;
             q.ldc = a.N;
-            rc = x3_go_bm<VN_EPI_STORE>(ctx, q, ns, false, bm, s);
+            rc = x3_go_bm<VN_EPI_STORE>(ctx, q, ns, bm, s);
             if (rc == VN_OK) rc = vn_launch_splitk_reduce(ctx, ctx->x3_ws, ns, a.C, a.M, a.N, a.ldc, EPI == VN_EPI_RESIDUAL, s);
             done = true;
         }
     }
-    if (!done) rc = x3_go_bm<EPI>(ctx, a, 1, sk, bm, s);
+    if (!done) rc = x3_go_bm<EPI>(ctx, a, 1, bm, s);
     vn_prof_post(ctx, pi, s);
     return rc;
 }
@@ -747,18 +595,12 @@ static int x3_attr(vn_ctx* ctx, K kernel, size_t bytes) {
 }
 template <int EPI>
 static int x3_attrs(vn_ctx* ctx) {
-    int rc;
-    if ((rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 1, false>, x3_lds_bytes<1>()))) return rc;
-    if ((rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 1, true>, x3_lds_bytes<1>()))) return rc;
-    if ((rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 2, false>, x3_lds_bytes<2>()))) return rc;
-    if ((rc = x3_attr(ctx, vn_gemm_x3_fixup_kernel<EPI, 1>, 104 * 1024))) return rc;
-    if ((rc = x3_attr(ctx, vn_gemm_x3_fixup_kernel<EPI, 2>, 104 * 1024))) return rc;
-    return x3_attr(ctx, vn_gemm_x3_kernel<EPI, 2, true>, x3_lds_bytes<2>());
+    int rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 1>, x3_lds_bytes<1>());
+    return rc ? rc : x3_attr(ctx, vn_gemm_x3_kernel<EPI, 2>, x3_lds_bytes<2>());
 }
 template <int MI, int ABL>
 static int x3_attrs_abl(vn_ctx* ctx) {
-    int rc = x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_STORE, MI, false, ABL>, x3_lds_bytes<MI>());
-    return rc ? rc : x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_STORE, MI, true, ABL>, x3_lds_bytes<MI>());
+    return x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_STORE, MI, ABL>, x3_lds_bytes<MI>());
 }
 
 int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s) {
