@@ -262,8 +262,9 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
     // (>= 1.5 per CU); below that (one or two sequences) the 64-query blocks of the fp32-input MFMA kernel fill it better
     // (B = 1, coarse: 55.6 vs 57.8 ms per clip, profiles/r02_c10_3_cfg1_*.json).  VN_ATTN_X3 = 0 / 1 forces one of them (A/B runs).
     static const int attn_x3_env = [] { const char* e = getenv("VN_ATTN_X3"); return e ? atoi(e) : -1; }();
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    static int cus_of[64] = {0};                      // queried once per device, outside any stream capture (first forward is eager)
+    int& cus = cus_of[ctx->device & 63];
+    if (!cus && (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0)) cus = 256;
     const bool attn_x3 = attn_x3_env >= 0 ? attn_x3_env != 0 : 2L * B * H * ((T + 127) / 128) >= 3L * cus;
     for (int l = 0; l < m->L; ++l) {
         // y = RMSNorm(x) ; FiLM = identity (d_cond = 0, transformer.py:554)
