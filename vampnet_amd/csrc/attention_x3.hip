@@ -37,6 +37,8 @@
 __device__ __forceinline__ int ax_swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
 // ABL (tuning only, results invalid): bit 0 = no exp / split (P = bf16(S) in all planes), bit 1 = no S^T MFMAs, bit 2 = no O^T MFMAs
+// (Tried and dropped, profiles/r02_attention_x3_phase_order_ab.txt: one VALU phase + one 48-MFMA phase per tile with K staged a
+// tile ahead of V^T — 125 vs 119 us; six- and two-wave blocks; see also r02_attention_x3_kernel_times.txt.)
 template <int NW, int ABL = 0>
 __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
                                                                     long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
@@ -83,9 +85,8 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
             qf[p][s] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Qp + (size_t)p * plane_qk + (size_t)qrow_c * VN_DHEAD + 16 * s + 8 * hh));
 
     // LDS-DMA: 24 wave-instructions of 1 KiB per stage (K: 3 planes x 4, each 8 rows x 128 B; V^T: 3 planes x 4, each 16 rows x 64 B)
-    auto stage = [&](int buf, int kt) {
-        float* base = smem + buf * AX_STAGE_FLOATS;
-        const int key0 = (g_lo + kt) * AX_KT - m_lo;            // may be negative in the first tile
+    auto stage = [&](int kbuf, int ktk, int vbuf, int ktv) {   // K tile ktk -> K half of stage kbuf, V^T tile ktv -> V half of stage vbuf
+        const int key0 = (g_lo + ktk) * AX_KT - m_lo;           // may be negative in the first tile
 #pragma unroll
         for (int i = 0; i < 24 / NW; ++i) {
             const int q = wave + i * NW;
@@ -98,8 +99,10 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
             } else {
                 const int q2 = q - 12;
                 const int p = q2 >> 2, row = 16 * (q2 & 3) + (lane >> 2);
-                src = Vp + (size_t)p * plane_vt + ((size_t)kt * VN_DHEAD + row) * AX_KT + ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+                src = Vp + (size_t)p * plane_vt + ((size_t)ktv * VN_DHEAD + row) * AX_KT + ((lane & 3) ^ ((row >> 2) & 3)) * 8;
             }
+            if ((q < 12 ? ktk : ktv) >= NT) continue;          // nothing left to fetch for this half
+            float* base = smem + (q < 12 ? kbuf : vbuf) * AX_STAGE_FLOATS;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(base + q * 256), 16, 0, 0);
         }
@@ -116,17 +119,11 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
 
-    stage(0, 0);
-    for (int kt = 0; kt < NT; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of tile kt have landed
-        __syncthreads();                                        // all pieces landed; everybody is done with tile kt - 1
-        if (kt + 1 < NT) stage((kt + 1) & 1, kt + 1);
-        if (!active) continue;
-        const float* Ks = smem + (kt & 1) * AX_STAGE_FLOATS;
-        const float* Vs = Ks + 3 * AX_PLANE_FLOATS;
-
-        // ---- S^T = K . Q^T: four 16-wide d steps x six plane products (smallest terms first)
-        f32x16 sacc;
+    f32x16 sacc;
+    bf16x8 pf[3][2];
+    // ---- S^T = K . Q^T for the tile in stage `kb`: four 16-wide d steps x six plane products (smallest terms first)
+    auto qk_phase = [&](int kb) {
+        const float* Ks = smem + kb * AX_STAGE_FLOATS;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
         __builtin_amdgcn_s_setprio(1);
@@ -148,8 +145,9 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
             }
         }
         __builtin_amdgcn_s_setprio(0);
-
-        // ---- online softmax over the tile's 32 keys; lane (j, hh) holds keys 32 kt + 16 (r >> 3) + 8 hh + (r & 7) of query j
+    };
+    // ---- online softmax of tile kt (scores in sacc): P planes -> pf, running max / sum, O rescaled
+    auto softmax_phase = [&](int kt) {
         float mx = -INFINITY;
         const int key0 = (g_lo + kt) * AX_KT - m_lo;                   // key index of the tile's first row
         const float* brow = bt + (key0 + 8 * hh - qrow_c + (T - 1));   // bias of key key0 + 8 hh for this query
@@ -175,7 +173,6 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
         const float m_new = fmaxf(m_run, mx);                          // finite: every tile has >= 1 valid key
         const float alpha = vn_exp_neg(m_run - m_new);                 // first tile: exp(-inf) = 0
         float lsum = 0.f;
-        bf16x8 pf[3][2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f32x8 pe;
@@ -195,8 +192,10 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         }
-
-        // ---- O^T += V^T . P^T: two 32-row d tiles x two 16-key steps x six plane products
+    };
+    // ---- O^T += V^T . P^T for the tile in stage `vb`: two 32-row d tiles x two 16-key steps x six plane products
+    auto pv_phase = [&](int vb) {
+        const float* Vs = smem + vb * AX_STAGE_FLOATS + 3 * AX_PLANE_FLOATS;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -218,6 +217,17 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
                 }
             }
         __builtin_amdgcn_s_setprio(0);
+    };
+
+    stage(0, 0, 0, 0);
+    for (int kt = 0; kt < NT; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of tile kt have landed
+        __syncthreads();                                        // all pieces landed; everybody is done with tile kt - 1
+        stage((kt + 1) & 1, kt + 1, (kt + 1) & 1, kt + 1);
+        if (!active) continue;
+        qk_phase(kt & 1);
+        softmax_phase(kt);
+        pv_phase(kt & 1);
     }
 
     // ---- finish: the two lanes of a query add their row sums; normalise; store.
