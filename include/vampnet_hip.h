@@ -311,6 +311,14 @@ int  vn_train_forward(vn_train* tr, const int64_t* z_masked, int B, int T, const
 int  vn_train_eval(vn_train* tr, const int64_t* z_masked, const int64_t* target, int B, int T, float label_smoothing,
                    float* row_loss, int32_t* rank, void* stream);
 /* *grad_norm_dev = || grads / world_size ||_2 ; clip ; AdamW on every trainable element ; vn_train_sync.             */
+/* ZeRO-1 (train.py:588-590, ZeroRedundancyOptimizer): the optimiser state is sharded over the ranks — rank r keeps Adam moments
+ * for elements [lo, hi) of the train vector only.  vn_train_grad_sumsq: *sumsq_dev = sum of squares (double) of n gradient
+ * elements (the ranks add theirs, the root x 1/world_size is the global norm).  vn_train_update_shard: clip by *grad_norm_dev and
+ * AdamW on the trainable elements inside [lo, hi); grads_shard (SUM over ranks) / mom_shard / var_shard are indexed from lo.
+ * The caller all-gathers the parameter slices and then calls vn_train_sync.                                              */
+int  vn_train_grad_sumsq(vn_train* tr, const float* grads, int64_t n, double* sumsq_dev, void* stream);
+int  vn_train_update_shard(vn_train* tr, const float* grads_shard, float* mom_shard, float* var_shard, const vn_train_params* p,
+                           int64_t lo, int64_t hi, const float* grad_norm_dev, void* stream);
 int  vn_train_update(vn_train* tr, const float* grads, float* adam_m, float* adam_v, const vn_train_params* p,
                      float* grad_norm_dev, void* stream);
 /* LoRA-only fine-tuning: train.py:696 `lora.mark_only_lora_as_trainable(model)` on loralib `Linear(r=8, lora_alpha=1)`

@@ -1,6 +1,7 @@
 """CPU tests of vampnet_amd/checkpoint.py — the reader behind `VampNet.load` / `DAC.load` (interface.py:27-50,70; audiotools
 `BaseModel.load`: torch.package archive first, `{"state_dict", "metadata": {"kwargs"}}` dict second) — of the trust rule for
 files that execute code, and of the codec kwargs / state_dict validation."""
+import os
 import pathlib
 
 import pytest
@@ -106,3 +107,44 @@ def test_codec_kwargs_and_state_dict_validation():
         validate_codec_state_dict(sd, dict(DEFAULT_CFG, **dict(tiny, encoder_dim=2 * tiny["encoder_dim"])))
     with pytest.raises(ValueError, match="not a DAC-family"):
         validate_codec_state_dict(_sd(), dict(DEFAULT_CFG, **tiny))
+
+
+@pytest.mark.filterwarnings("ignore::UserWarning")
+def test_parity_script_on_synthetic_checkpoints(tmp_path):
+    """scripts/parity_real_ckpt.py (BASELINE configs[0] against the reference on real checkpoints) end to end on stand-ins: a
+    torch.package coarse checkpoint + a LoRA file, a dict c2f checkpoint, a codec dict checkpoint, tokens from an npy file; the
+    engine side replaced by the oracle (dry run).  Also pins merge_lora_state_dict against the oracle's own forward."""
+    import importlib.util
+    import numpy as np
+    from torch import package
+    from oracle import dac_oracle as D, vampnet_oracle as O
+    from tests import pkg_model
+    from vampnet_amd.checkpoint import merge_lora_state_dict
+    csd, fsd = W.synth_state_dict(W.TINY_COARSE_DIMS, 0), W.synth_state_dict(W.TINY_C2F_DIMS, 1)
+    model = pkg_model.VampNet(csd, **model_kwargs(W.TINY_COARSE_DIMS))
+    with package.PackageExporter(str(tmp_path / "coarse.pth")) as pe:
+        pe.extern(["torch.**"])
+        pe.intern("tests.**")
+        pe.save_pickle("VampNet", "VampNet.pth", model)
+        pe.save_pickle("VampNet", "VampNet.metadata", {"kwargs": model_kwargs(W.TINY_COARSE_DIMS)})
+    torch.save({"state_dict": fsd, "metadata": {"kwargs": model_kwargs(W.TINY_C2F_DIMS)}}, tmp_path / "c2f.pth")
+    g = torch.Generator().manual_seed(3)
+    key = "transformer.layers.1.feed_forward.w_2"
+    lora = {key + ".lora_A": torch.randn(8, csd[key + ".weight"].shape[1], generator=g) * 0.05,
+            key + ".lora_B": torch.randn(csd[key + ".weight"].shape[0], 8, generator=g) * 0.05}
+    torch.save(lora, tmp_path / "lora.pth")
+    merged = merge_lora_state_dict({**csd, **lora})
+    assert not any("lora_" in k for k in merged)
+    assert torch.equal(merged[key + ".weight"], csd[key + ".weight"] + (lora[key + ".lora_B"] @ lora[key + ".lora_A"]) / 8.0)
+    assert all(torch.equal(merged[k], v) for k, v in csd.items() if k != key + ".weight")
+    cfg = dict(D.DAC_TINY_CFG, n_codebooks=14)
+    torch.save({"state_dict": D.synth_dac_state_dict(cfg, 1), "metadata": {"kwargs": cfg}}, tmp_path / "codec.pth")
+    np.save(tmp_path / "z.npy", W.synth_codes(1, 14, 90, seed=4).numpy())
+    spec = importlib.util.spec_from_file_location("parity_real_ckpt", os.path.join(os.path.dirname(__file__), "..", "scripts", "parity_real_ckpt.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = ["--coarse", str(tmp_path / "coarse.pth"), "--coarse-lora", str(tmp_path / "lora.pth"), "--c2f", str(tmp_path / "c2f.pth"),
+            "--codec", str(tmp_path / "codec.pth"), "--tokens", str(tmp_path / "z.npy"), "--engine", "oracle", "--steps", "3", "--seeds", "0", "1"]
+    with pytest.raises(PermissionError):
+        mod.main(argv)                                     # the torch.package checkpoint needs --trusted
+    assert mod.main(argv + ["--trusted"]) == 0

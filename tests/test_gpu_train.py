@@ -365,6 +365,84 @@ def test_checkpoint_resume_and_interface_load(engine, tmp_path, only_lora):
     assert (inf.forward_codes(zm) - tr3.model.forward_codes(zm)).abs().max().item() < 2e-5
 
 
+def test_zero1_shard_update_equals_full_update(engine):
+    """vn_train_update_shard over a partition of the train vector == vn_train_update, bit for bit (same AdamW kernel on the
+    same elements, same clip norm), with shard-local moment buffers; vn_train_grad_sumsq of the slices adds up to the norm."""
+    import ctypes as C
+    dims = W.TINY_COARSE_DIMS
+    sd, cb = W.synth_state_dict(dims, 0), W.synth_codebooks()
+    kw = dict(max_batch=2, max_T=32, dropout=0.0, seed=5, use_noam=False, lr=1e-3)
+    full, sh = _trainer(engine, dims, sd, cb, **kw), _trainer(engine, dims, sd, cb, **kw)
+    z = W.synth_codes(2, 4, 32, seed=9)
+    mask = TO.make_training_mask(z, torch.tensor([0.4, 0.8]), 0, generator=torch.Generator().manual_seed(2))
+    n = full.n_total
+    cuts = [0, (n // 3) & ~3, (2 * n // 3 + 8) & ~3, n]                     # three slices, 16-byte multiples
+    ms = [torch.zeros(b - a, device="cuda") for a, b in zip(cuts, cuts[1:])]
+    vs = [torch.zeros(b - a, device="cuda") for a, b in zip(cuts, cuts[1:])]
+    for step in (1, 2):
+        zm, tg = full.make_batch(z, mask=mask)
+        full.forward_backward(zm, tg, step=step)
+        sh.forward_backward(zm, tg, step=step)
+        assert torch.equal(full.grads, sh.grads)
+        full._apply_update(step, 1e-3)
+        st = engine.stream()
+        tot = torch.zeros(1, dtype=torch.float64, device="cuda")
+        one = torch.zeros(1, dtype=torch.float64, device="cuda")
+        for a, b in zip(cuts, cuts[1:]):
+            engine.check(engine.lib.vn_train_grad_sumsq(sh.handle, sh.grads[a:b].data_ptr(), b - a, one.data_ptr(), st), "sumsq")
+            tot += one
+        norm = tot.sqrt().float()
+        assert abs(norm.item() - full.grad_norm.item()) <= 2e-6 * full.grad_norm.item()
+        tp = sh._tp(step, lr=1e-3)
+        for (a, b), m_, v_ in zip(zip(cuts, cuts[1:]), ms, vs):
+            g = sh.grads[a:b].clone()                                        # shard-local buffers, indexed from a
+            engine.check(engine.lib.vn_train_update_shard(sh.handle, g.data_ptr(), m_.data_ptr(), v_.data_ptr(), C.byref(tp), a, b,
+                                                          full.grad_norm.data_ptr(), st), "vn_train_update_shard")
+        engine.check(engine.lib.vn_train_sync(sh.handle, st), "vn_train_sync")
+        assert torch.equal(sh.params, full.params)
+        assert torch.equal(torch.cat(ms), full.adam_m) and torch.equal(torch.cat(vs), full.adam_v)
+
+
+def test_zero1_trainer_step_on_a_one_rank_rccl_group(engine):
+    """Trainer(zero1=True) through reduce_scatter_tensor / all_gather_into_tensor on RCCL (one-rank group on this GPU: the
+    collectives are identities, the code path is the multi-GPU one): same losses, parameters and consolidated optimizer state
+    as the replicated trainer."""
+    import os
+    import socket
+    import torch.distributed as dist
+    dims = W.TINY_COARSE_DIMS
+    sd, cb = W.synth_state_dict(dims, 0), W.synth_codebooks()
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        kw = dict(max_batch=2, max_T=32, dropout=0.1, seed=5)
+        tr = _trainer(engine, dims, sd, cb, process_group=dist.group.WORLD, zero1=True, **kw)
+        ref = _trainer(engine, dims, sd, cb, **kw)
+        assert tr.zero1 and not tr.overlap and tr.adam_m.numel() == tr.shard_len
+        z = W.synth_codes(2, 4, 32, seed=9)
+        mask = TO.make_training_mask(z, torch.tensor([0.4, 0.8]), 0, generator=torch.Generator().manual_seed(2))
+        for _ in range(3):
+            o1, o2 = tr.step(z, mask=mask), ref.step(z, mask=mask)
+            assert o1["loss"].item() == o2["loss"].item()
+            assert abs(o1["other/grad_norm"].item() - o2["other/grad_norm"].item()) <= 2e-6 * o2["other/grad_norm"].item()
+        for k, v in ref.state_dict().items():
+            assert (tr.state_dict()[k] - v).abs().max().item() < 1e-7, k
+        a, b = tr.optimizer_state_dict(), ref.optimizer_state_dict()
+        assert a["param_groups"] == b["param_groups"] and set(a["state"]) == set(b["state"])
+        for i in b["state"]:
+            assert (a["state"][i]["exp_avg"] - b["state"][i]["exp_avg"]).abs().max().item() < 1e-9, i
+        tr2 = _trainer(engine, dims, sd, cb, process_group=dist.group.WORLD, zero1=True, **kw)
+        tr2.load_state_dict(tr.state_dict())
+        tr2.load_optimizer_state_dict(a)                                     # resume into the sharded layout
+        assert tr2.steps == 3 and torch.equal(tr2.adam_m, tr.adam_m)
+    finally:
+        if own_pg:
+            dist.destroy_process_group()
+
+
 def test_staged_backward_with_overlapped_allreduce(engine):
     """The data-parallel step with the gradient exchange overlapped with the backward pass (one-rank RCCL group on this
     GPU: the collectives are identities, everything else is the real code path): same loss and gradients as the

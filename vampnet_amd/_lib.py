@@ -80,6 +80,8 @@ SYMBOLS = {
     "vn_train_backward": (C.c_int, [_P, C.POINTER(vn_train_params), _P, C.c_int, C.c_int, _P]),
     "vn_train_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(vn_train_params), _P, _P]),
     "vn_train_eval": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_float, _P, _P, _P]),
+    "vn_train_grad_sumsq": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
+    "vn_train_update_shard": (C.c_int, [_P, _P, _P, _P, C.POINTER(vn_train_params), C.c_int64, C.c_int64, _P, _P]),
     "vn_train_update": (C.c_int, [_P, _P, _P, _P, C.POINTER(vn_train_params), _P, _P]),
     "vn_lora_param_size": (C.c_int, [C.POINTER(vn_dims), C.POINTER(C.c_int64)]),
     "vn_lora_param_offset": (C.c_int, [C.POINTER(vn_dims), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

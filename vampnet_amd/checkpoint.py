@@ -93,3 +93,23 @@ def load_tensor_dict(path, *, trusted: bool = False) -> dict:
             raise PermissionError(f"{path} cannot be read with weights_only=True ({type(e).__name__}: {e}); pass trusted=True "
                                   "or set VN_TRUST_CHECKPOINTS=1 for files you trust") from e
         return torch.load(path, map_location="cpu", weights_only=False)
+
+
+LORA_SCALING = 1.0 / 8.0      # loralib: lora_alpha (1) / r (8), transformer.py:22 LORA_R
+
+
+def merge_lora_state_dict(sd: dict) -> dict:
+    """What loralib's `Linear.eval()` computes once for every adapter pair: W_eff = W + (lora_B @ lora_A) * alpha / r
+    (SURVEY.md App. C).  Returns a state_dict WITHOUT lora_A / lora_B keys whose weights are the merged ones — the form both
+    the engine's packer and a plain `nn.Linear` model (the reference under the import shim) load."""
+    out = {}
+    for k, v in sd.items():
+        if k.endswith(".lora_A") or k.endswith(".lora_B"):
+            continue
+        if k.endswith(".weight"):
+            stem = k[:-len(".weight")]
+            a, b = sd.get(stem + ".lora_A"), sd.get(stem + ".lora_B")
+            if a is not None and b is not None:
+                v = v.float() + (b.float() @ a.float()) * LORA_SCALING
+        out[k] = v
+    return out

@@ -276,7 +276,6 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
     const uint16_t* A16 = (const uint16_t*)p.A;
     const uint16_t* W16 = (const uint16_t*)p.W;
     const int nk_all = p.K / X3_KT;
-    const int ntiles = tiles_m * tiles_n;
     const int drow = (ABL & 4) ? lane >> 3 : lane >> 2;
     const int dslot = (ABL & 4) ? lane & 7 : (lane & 3) ^ ((lane >> 4) & 3);     // (row >> 2) & 3 == (lane >> 4) & 3
     // fragment offsets (floats) inside a plane tile: row * 16 + ((2 s + h) ^ ((row >> 2) & 3)) * 4

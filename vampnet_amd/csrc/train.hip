@@ -628,6 +628,54 @@ extern "C" int vn_train_update(vn_train* t, const float* grads, float* mom, floa
     return vn_train_sync(t, stream);
 }
 
+// ---- ZeRO-1 (train.py:588-590: ZeroRedundancyOptimizer(model.parameters(), AdamW) when world_size > 1) ------------------
+// Each rank owns elements [lo, hi) of the flat train vector and keeps Adam moments for that slice only.  Per step:
+//   reduce-scatter(sum) of the gradient vector -> the rank's slice ; vn_train_grad_sumsq on the slice ; all-reduce(sum) of the
+//   doubles -> global norm ; vn_train_update_shard ; all-gather of the parameter slices ; vn_train_sync.
+extern "C" int vn_train_grad_sumsq(vn_train* t, const float* grads, int64_t n, double* sumsq_dev, void* stream) {
+    if (!t || !grads || !sumsq_dev || n <= 0) return VN_ERR_INVALID;
+    return vn_launch_grad_sumsq(t->m->ctx, grads, (long)n, t->npartial, sumsq_dev, (hipStream_t)stream);
+}
+
+// AdamW on the trainable elements inside [lo, hi): grads_shard / mom_shard / var_shard are indexed from lo (element i of the train
+// vector <-> shard[i - lo]) and grads_shard holds the SUM over ranks; *grad_norm_dev = || sum / world_size ||_2 over the WHOLE
+// vector (computed by the caller from the ranks' vn_train_grad_sumsq).  Parameters are updated in place in the trainer's full
+// vector; the caller all-gathers the slices and then calls vn_train_sync.
+extern "C" int vn_train_update_shard(vn_train* t, const float* grads_shard, float* mom_shard, float* var_shard,
+                                     const vn_train_params* p, int64_t lo, int64_t hi, const float* grad_norm_dev, void* stream) {
+    if (!t || !grads_shard || !mom_shard || !var_shard || !grad_norm_dev) return VN_ERR_INVALID;
+    vn_model* m = t->m;
+    vn_ctx* ctx = m->ctx;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = params_ok(ctx, p);
+    if (rc) return rc;
+    if (t->lora) return vn_fail(ctx, VN_ERR_UNSUPPORTED, "update_shard: LoRA-only training keeps a replicated optimiser (2.9 M parameters)%s", "");
+    if (lo < 0 || hi > t->n_total || lo > hi) return vn_fail(ctx, VN_ERR_INVALID, "update_shard: bad range [%s%ld, %ld)", "", (long)lo, (long)hi);
+    vn_adamw_args a;
+    a.lr = p->lr; a.beta1 = p->beta1; a.beta2 = p->beta2; a.eps = p->eps; a.weight_decay = p->weight_decay;
+    a.bc1 = (float)(1.0 - pow((double)p->beta1, (double)p->step));
+    a.bc2 = (float)(1.0 - pow((double)p->beta2, (double)p->step));
+    a.gscale = 1.0f / (float)p->world_size;
+    a.clip = p->grad_clip;
+    auto range = [&](long r0, long r1) {
+        r0 = r0 > lo ? r0 : (long)lo;
+        r1 = r1 < hi ? r1 : (long)hi;
+        if (r1 <= r0) return (int)VN_OK;
+        return vn_launch_adamw(ctx, t->params + r0, grads_shard + (r0 - lo), mom_shard + (r0 - lo), var_shard + (r0 - lo), r1 - r0, a,
+                               grad_norm_dev, s);
+    };
+    const vn_dims& d = m->d;
+    const long V1 = d.vocab + 1, ld = d.latent_dim;
+    const long tab = vn_tensor_offset(&d, VN_W_EMB_TABLES, 0);
+    for (int c = 0; c < d.n_codebooks; ++c) {      // embedding.special.MASK rows; the codec codebooks are not parameters
+        const long r0 = tab + ((long)c * V1 + d.vocab) * ld;
+        if ((rc = range(r0, r0 + ld))) return rc;
+    }
+    if ((rc = range(vn_tensor_offset(&d, VN_W_EMB_WT, 0), vn_tensor_offset(&d, VN_W_CLS_W, 0)))) return rc;
+    if ((rc = range(vn_tensor_offset(&d, VN_W_CLS_B, 0), t->wsize))) return rc;
+    return range(t->off_g, t->n_total);
+}
+
 extern "C" int vn_dropout_keep_mask(vn_ctx* ctx, uint64_t seed, int64_t step, int layer, int site, float p, int64_t row0,
                                     int64_t rows, int cols, uint8_t* out, void* stream) {
     if (!ctx || !out || site < 0 || site > 3) return VN_ERR_INVALID;

@@ -650,6 +650,26 @@ __global__ __launch_bounds__(1024) void vn_sumsq_finish_kernel(const double* __r
     if (threadIdx.x == 0) *norm_out = (float)(sqrt(red[0]) * (double)gscale);
 }
 
+__global__ __launch_bounds__(1024) void vn_sumsq_finish_f64_kernel(const double* __restrict__ partial, int n, double* __restrict__ out) {
+    __shared__ double red[1024];
+    red[threadIdx.x] = (int)threadIdx.x < n ? partial[threadIdx.x] : 0.0;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+
+// sum of squares in double (the ranks of a ZeRO-1 job add these before taking the root)
+int vn_launch_grad_sumsq(vn_ctx* ctx, const float* g, long n, double* partial, double* out, hipStream_t s) {
+    if (n % 4) return vn_fail(ctx, VN_ERR_INVALID, "grad_sumsq: length %s%ld must be a multiple of 4", "", n);
+    hipLaunchKernelGGL(vn_sumsq_partial_kernel, dim3(VN_NORM_BLOCKS), dim3(256), 0, s, g, n / 4, partial);
+    hipLaunchKernelGGL(vn_sumsq_finish_f64_kernel, dim3(1), dim3(1024), 0, s, partial, VN_NORM_BLOCKS, out);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
 int vn_launch_grad_norm(vn_ctx* ctx, const float* g, long n, float gscale, double* partial, float* norm_out, hipStream_t s) {
     if (n % 4) return vn_fail(ctx, VN_ERR_INVALID, "grad_norm: length %s%ld must be a multiple of 4", "", n);
     hipLaunchKernelGGL(vn_sumsq_partial_kernel, dim3(VN_NORM_BLOCKS), dim3(256), 0, s, g, n / 4, partial);

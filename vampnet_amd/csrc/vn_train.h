@@ -30,6 +30,7 @@ int vn_embed_bwd_partial_floats(int B, int T, int C, int ld, int D);
 int vn_launch_embed_bwd(vn_ctx* ctx, const float* dx, const int32_t* z, const float* tables, const float* wt, float* dtables,
                         float* dwt, float* db, float* partial, float* dlat, int B, int C, int T, int V1, int ld, int D,
                         hipStream_t s);
+int vn_launch_grad_sumsq(vn_ctx* ctx, const float* g, long n, double* partial, double* out, hipStream_t s);
 int vn_launch_grad_norm(vn_ctx* ctx, const float* g, long n, float gscale, double* partial, float* norm_out, hipStream_t s);
 int vn_launch_adamw(vn_ctx* ctx, float* p, const float* g, float* m, float* v, long n, const vn_adamw_args& a,
                     const float* norm, hipStream_t s);

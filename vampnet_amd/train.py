@@ -37,7 +37,7 @@ class Trainer:
                  n_conditioning_codebooks=0, latent_dim=8, embedding_dim=1280, vocab_size=1024, max_batch=8, max_T=575,
                  lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_clip=5.0, label_smoothing=0.1,
                  dropout=0.1, noam_factor=2.0, noam_warmup=10000, use_noam=True, seed=0, process_group=None,
-                 batch_offset=0, only_lora=False, overlap_allreduce=True, layers_per_bucket=4, **_ignored):
+                 batch_offset=0, only_lora=False, overlap_allreduce=True, layers_per_bucket=4, zero1=False, **_ignored):
         self.engine, self.lib = engine, engine.lib
         self.dims = vn_dims(n_layers, n_heads, embedding_dim, n_codebooks, n_conditioning_codebooks, vocab_size,
                             latent_dim, 32, 128, 1e-6, max_batch, max_T)
@@ -49,7 +49,10 @@ class Trainer:
         self.noam = (noam_factor, noam_warmup) if use_noam else None
         self.seed, self.pg, self.batch_offset = seed, process_group, batch_offset
         self.steps = 0
-        self.overlap = bool(overlap_allreduce) and process_group is not None and not only_lora
+        # ZeRO-1 (train.py:588-590: ZeroRedundancyOptimizer when world_size > 1): Adam moments sharded over the ranks, gradients
+        # reduce-scattered, parameters all-gathered after the update; the LoRA optimiser (2.9 M parameters) stays replicated
+        self.zero1 = bool(zero1) and process_group is not None and not only_lora
+        self.overlap = bool(overlap_allreduce) and process_group is not None and not only_lora and not self.zero1
         self.layers_per_bucket = max(1, int(layers_per_bucket))
         self._reduced = False
         n = C.c_int64()
@@ -84,16 +87,30 @@ class Trainer:
         host[og:og + g.numel()] = g
         host[ov:ov + v.numel()] = v
         dev = engine.device
-        self.params = host.to(dev)
+        if self.zero1:
+            import torch.distributed as dist
+            self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+            self.shard_len = -(-self.n_total // (4 * self.world)) * 4           # equal slices, 16-byte multiples
+            pad = torch.zeros(self.shard_len * self.world, dtype=torch.float32, device=dev)
+            pad[:self.n_total] = host.to(dev)
+            self._params_pad = pad
+            self.params = pad[:self.n_total]                                    # the engine's view: same storage
+        else:
+            self.params = host.to(dev)
         if only_lora:
             # train.py:696 lora.mark_only_lora_as_trainable: the optimiser state covers the adapters only
             self._base_sd = {k: v.detach().cpu().clone() for k, v in sd.items() if "lora_" not in k}
             self.lora = self.pack_lora(sd).to(dev)
             self.grads = torch.zeros_like(self.lora)
+        elif self.zero1:
+            self._grads_pad = torch.zeros_like(self._params_pad)
+            self.grads = self._grads_pad[:self.n_total]
+            self._gshard = torch.zeros(self.shard_len, dtype=torch.float32, device=dev)
+            self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
         else:
             self.grads = torch.zeros_like(self.params)
-        self.adam_m = torch.zeros_like(self.grads)
-        self.adam_v = torch.zeros_like(self.grads)
+        self.adam_m = torch.zeros_like(self._gshard if self.zero1 else self.grads)
+        self.adam_v = torch.zeros_like(self.adam_m)
         self.loss = torch.zeros(1, device=dev)
         self.grad_norm = torch.zeros(1, device=dev)
         # inference view of the same weights (generate / forward share the blob the optimiser updates)
@@ -227,8 +244,86 @@ class Trainer:
                                                     self.engine.stream()), "vn_train_forward")
         return logits.permute(0, 3, 1, 2).reshape(B, self.vocab, T * self.Cp)
 
+    # ---- ZeRO-1 ---------------------------------------------------------------------------------------
+    def shard_range(self, rank=None):
+        """[lo, hi) of the train vector whose optimiser state rank `rank` owns"""
+        r = self.rank if rank is None else rank
+        lo = min(r * self.shard_len, self.n_total)
+        return lo, min(lo + self.shard_len, self.n_total)
+
+    def _reduce_scatter_grads(self):
+        """self._gshard <- SUM over ranks of this rank's slice of the (zero-padded) gradient vector"""
+        import torch.distributed as dist
+        lo = self.rank * self.shard_len
+        if dist.get_backend(self.pg) == "gloo":            # gloo has no reduce-scatter: all-reduce, keep the slice (CPU tests)
+            dist.all_reduce(self._grads_pad, group=self.pg)
+            self._gshard.copy_(self._grads_pad[lo:lo + self.shard_len])
+        else:
+            dist.reduce_scatter_tensor(self._gshard, self._grads_pad, group=self.pg)
+
+    def _all_gather_params(self):
+        import torch.distributed as dist
+        lo = self.rank * self.shard_len
+        mine = self._params_pad[lo:lo + self.shard_len]
+        if dist.get_backend(self.pg) == "gloo":
+            parts = [self._params_pad[r * self.shard_len:(r + 1) * self.shard_len] for r in range(self.world)]
+            tmp = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(tmp, mine.clone(), group=self.pg)
+            for dst, src in zip(parts, tmp):
+                dst.copy_(src)
+        else:
+            dist.all_gather_into_tensor(self._params_pad, mine, group=self.pg)      # in place: `mine` is its own slot of the output
+
+    def _shard_sumsq(self):
+        """sum of squares (float64, 1 element) of the reduced gradient slice"""
+        self.engine.check(self.lib.vn_train_grad_sumsq(self.handle, self._gshard.data_ptr(), self.shard_len, self._sumsq.data_ptr(),
+                                                       self.engine.stream()), "vn_train_grad_sumsq")
+        return self._sumsq
+
+    def _apply_update_shard(self, step, lr, lo, hi):
+        tp = self._tp(step, lr=lr)
+        self.engine.check(self.lib.vn_train_update_shard(self.handle, self._gshard.data_ptr(), self.adam_m.data_ptr(),
+                                                         self.adam_v.data_ptr(), C.byref(tp), lo, hi, self.grad_norm.data_ptr(),
+                                                         self.engine.stream()), "vn_train_update_shard")
+
+    def _sync_derived(self):
+        self.engine.check(self.lib.vn_train_sync(self.handle, self.engine.stream()), "vn_train_sync")
+
+    def _update_zero1(self, step, lr):
+        """reduce-scatter -> global norm from the slices' sums of squares -> clip + AdamW on the own slice -> all-gather."""
+        import torch.distributed as dist
+        self._reduce_scatter_grads()
+        sumsq = self._shard_sumsq()
+        dist.all_reduce(sumsq, group=self.pg)
+        self.grad_norm.copy_((sumsq.sqrt() / self.world).to(torch.float32))     # || sum / world ||, as vn_train_update computes it
+        lo, hi = self.shard_range()
+        self._apply_update_shard(step, lr, lo, hi)
+        self._all_gather_params()
+        self._sync_derived()
+
+    def consolidate_state(self):
+        """ZeroRedundancyOptimizer.consolidate_state_dict (train.py:376-378): every rank receives the full moment vectors
+        (returned as (m, v) of length n_total; the sharded buffers stay as they are)."""
+        import torch.distributed as dist
+        out = []
+        for buf in (self.adam_m, self.adam_v):
+            parts = [torch.empty_like(buf) for _ in range(self.world)]
+            dist.all_gather(parts, buf, group=self.pg)
+            out.append(torch.cat(parts)[:self.n_total])
+        return tuple(out)
+
     def update(self):
         """(all-reduce) -> clip -> AdamW -> scheduler.step(); advances self.steps."""
+        if getattr(self, "zero1", False):
+            import torch.distributed as dist
+            dist.all_reduce(self.loss, group=self.pg)
+            self.loss /= self.world
+            step = self.steps + 1
+            lr = noam_lr(step, self.D, *self.noam) if self.noam else self.hp["lr"]
+            self._update_zero1(step, lr)
+            self.steps = step
+            self.last_lr = lr
+            return self.grad_norm
         if self.pg is not None:
             import torch.distributed as dist
             if not self._reduced:
@@ -311,7 +406,10 @@ class Trainer:
         reference has after mark_only_lora_as_trainable), full mode for every non-adapter parameter.  `lr` is what the
         reference's param group holds after N steps: NoamScheduler has already stepped to N + 1 (train.py:596)."""
         exp = self.export_lora if self.only_lora else self.export
-        m, v = exp(self.adam_m), exp(self.adam_v)
+        if getattr(self, "zero1", False):                  # sharded moments: gather them first (every rank must call this)
+            m, v = (exp(t) for t in self.consolidate_state())
+        else:
+            m, v = exp(self.adam_m), exp(self.adam_v)
         index = {k: i for i, k in enumerate(self._all_param_names())}
         state = {}
         if self.steps > 0:
@@ -357,6 +455,12 @@ class Trainer:
         if self.only_lora:
             self.adam_m.copy_(self.pack_lora(m, init_missing=False))
             self.adam_v.copy_(self.pack_lora(v, init_missing=False))
+        elif getattr(self, "zero1", False):                # keep this rank's slice of the full moment vectors
+            lo = self.rank * self.shard_len
+            for dst, full in ((self.adam_m, self.pack(m)), (self.adam_v, self.pack(v))):
+                dst.zero_()
+                n = max(0, min(self.shard_len, self.n_total - lo))
+                dst[:n].copy_(full[lo:lo + n])
         else:
             self.adam_m.copy_(self.pack(m)); self.adam_v.copy_(self.pack(v))
         self.steps = int(float(st[index[have[0]]]["step"]))
