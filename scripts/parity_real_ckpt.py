@@ -94,7 +94,11 @@ def main(argv=None):
     ap.add_argument("--precision", choices=["f32", "bf16x3"], default="bf16x3")
     ap.add_argument("--trusted", action="store_true", help="allow torch.package archives / full unpickling (they execute code)")
     args = ap.parse_args(argv)
-    torch.set_grad_enabled(False)
+    with torch.no_grad():
+        return _run(args)
+
+
+def _run(args):
     models = load_models(args)
     elabel, itf, eng_vamp = engine_side(args, models)
     if args.tokens:

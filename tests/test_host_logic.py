@@ -509,3 +509,54 @@ def test_split_plane_gemm_lds_addressing():
 
     assert check(1, 3) == (48 * 1024, 6)          # gemm_x3.hip, 128 x 128
     assert check(2, 3) == (72 * 1024, 9)          # gemm_x3.hip, 256 x 128 (ping-pong)
+
+
+def test_attention_x3_lds_addressing():
+    """Model of attention_x3.hip's LDS images (K plane tile: 32 rows x 128 B, V^T plane tile: 64 rows x 64 B): replay the per-lane
+    LDS-DMA destinations and source-side swizzles, then check that every ds_read_b128 of the two MFMA A operands fetches the
+    (row, 8-element slot) it feeds to the matrix core — K rows through the swap-bits-2-3 key map — and that each of its four
+    16-lane groups touches 16 distinct 16-byte slots of the 256-byte bank row (conflict-free)."""
+    def swap23(r):
+        return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1)
+
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[l + 32 for l in g] for g in groups]
+    lds = {}
+    for q in range(4):                                   # K: instruction q = 8 rows x 128 B
+        for lane in range(64):
+            row, phys = 8 * q + (lane >> 3), lane & 7
+            lds[q * 1024 + lane * 16] = (row, phys ^ ((row >> 1) & 7))
+    assert sorted(lds.values()) == [(r, s) for r in range(32) for s in range(8)]
+    keys_of = {}
+    for s in range(4):                                   # 16-wide d step s; lane (l31, hh) needs row swap23(l31), slot 2 s + hh
+        for g in groups:
+            slots = set()
+            for l in g:
+                l31, hh = l & 31, l >> 5
+                kr = swap23(l31)
+                byte = kr * 128 + ((2 * s + hh) ^ ((kr >> 1) & 7)) * 16
+                assert lds[byte] == (kr, 2 * s + hh)
+                slots.add((byte // 16) % 16)
+                keys_of[l31] = kr
+            assert len(slots) == 16
+    # the key map: accumulator register r of lane half hh holds MFMA row (r & 3) + 8 (r >> 2) + 4 hh = key 16 (r >> 3) + 8 hh + (r & 7)
+    for hh in range(2):
+        for r in range(16):
+            assert keys_of[(r & 3) + 8 * (r >> 2) + 4 * hh] == 16 * (r >> 3) + 8 * hh + (r & 7)
+    lds = {}
+    for q in range(4):                                   # V^T: instruction q = 16 rows x 64 B
+        for lane in range(64):
+            row, phys = 16 * q + (lane >> 2), lane & 3
+            lds[q * 1024 + lane * 16] = (row, phys ^ ((row >> 2) & 3))
+    assert sorted(lds.values()) == [(r, s) for r in range(64) for s in range(4)]
+    for s in range(2):                                   # 16-key step s: lane (d = 32 dt + l31, hh) needs keys 16 s + 8 hh .. + 7 = slot 2 s + hh
+        for dt in range(2):
+            for g in groups:
+                slots = set()
+                for l in g:
+                    l31, hh = l & 31, l >> 5
+                    d = 32 * dt + l31
+                    byte = d * 64 + ((2 * s + hh) ^ ((l31 >> 2) & 3)) * 16
+                    assert lds[byte] == (d, 2 * s + hh)
+                    slots.add((byte // 16) % 16)
+                assert len(slots) == 16
