@@ -343,11 +343,16 @@ def test_checkpoint_resume_and_interface_load(engine, tmp_path, only_lora):
 
     # the optimizer file is a torch.optim.AdamW state_dict over the same parameter list
     import os
-    names = tr._param_names()
+    # (indexed over ALL of the reference model's parameters(), train.py:588-590; state only for the trained subset)
+    names = tr._all_param_names()
     ps = [torch.nn.Parameter(torch.zeros(tr._sd_template[k][0])) for k in names]
     opt = torch.optim.AdamW(ps, lr=1e-3)
     opt.load_state_dict(torch.load(os.path.join(folder, "optimizer.pth")))
-    assert float(opt.state[ps[0]]["step"]) == 3.0
+    trained = set(tr._param_names())
+    for k, prm in zip(names, ps):
+        assert (prm in opt.state) == (k in trained), k
+        if k in trained:
+            assert float(opt.state[prm]["step"]) == 3.0
     assert os.path.exists(os.path.join(folder, "lora.pth")) == only_lora
 
     # inference twin reads the same files
