@@ -378,6 +378,10 @@ int vn_debug_gemm_config(int bm, int bn, int order);
 /* same for the bf16x3 GEMM (gemm_x3.hip): bm = tile height 128 / 256 (0 = VN_X3_BM / by shape); splitk 0/1 off, 2/4 forced,
  * -1 = cost model; abl = ablation bits (tuning; results invalid), -1 = none                                              */
 int vn_debug_x3_config(int bm, int splitk, int abl);
+/* a RESIDUAL bf16x3 GEMM that is split along K runs the RMSNorm that follows it in the layer inside its reduce pass
+ * (vn_splitk_reduce_rmsnorm_kernel); 0 = keep the two kernels apart (A/B tests: both forms are bitwise equal), 1 = fuse,
+ * -1 = VN_X3_FUSE_NORM / default (on).  Process-global.                                                             */
+int vn_debug_x3_fuse_norm(int on);
 /* average duration (us) of `iters` launches of the bf16x3 attention kernel alone (planes prepared outside the timed region) */
 int vn_debug_attention_x3_time(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias, float* out,
                                int B, int H, int T, int iters, float* avg_us, void* stream);

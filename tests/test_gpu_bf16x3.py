@@ -83,3 +83,37 @@ def test_forward_full_size_vs_reference_probe(eng, name, dims, T, seed, monkeypa
     d = (a - b).abs().max().item()
     print(f"{name}: max |logit(bf16x3) - logit(f32 mfma)| = {d:.3e}")
     assert d <= TM.LOGIT_ATOL_FULL
+
+
+@pytest.mark.parametrize("dims,T,B", [(W.TINY_COARSE_DIMS, 200, 3), (W.TINY_C2F_DIMS, 173, 2)])
+def test_fused_splitk_reduce_rmsnorm_is_bitwise_the_two_kernel_form(eng, dims, T, B):
+    """A RESIDUAL GEMM that is split along K runs the next RMSNorm inside its reduce pass (vn_splitk_reduce_rmsnorm_kernel): the
+    logits must not move by a bit against the reduce kernel followed by the norm kernel (same summation order, same row math).
+    Split-K forced to 2 so that the small shapes take the path the B = 8 model shapes take by the cost model."""
+    from vampnet_amd.engine import VampNetModel
+    cb = W.synth_codebooks()
+    m = VampNetModel(eng, W.synth_state_dict(dims, 3), cb, max_batch=4, max_T=256, precision="bf16x3", **model_kwargs(dims))
+    codes = W.synth_codes(B, dims["n_codebooks"], T, seed=5)
+    codes[:, dims["n_cond"]:, ::3] = 1024
+    lib = eng.lib
+    try:
+        lib.vn_debug_x3_config(0, 2, -1)
+        lib.vn_debug_x3_fuse_norm(1)
+        a = m.forward_codes(codes, layout="native").clone()
+        lib.vn_debug_x3_fuse_norm(0)
+        b = m.forward_codes(codes, layout="native").clone()
+        lib.vn_debug_x3_config(0, 0, -1)            # no split at all: the residual epilogue + the stand-alone norm
+        c = m.forward_codes(codes, layout="native").clone()
+    finally:
+        lib.vn_debug_x3_config(0, -1, -1)
+        lib.vn_debug_x3_fuse_norm(-1)
+    assert torch.equal(a, b)
+    assert (a - c).abs().max().item() <= 2e-5       # split vs unsplit k-order: fp32 re-association only
+    sd = W.synth_state_dict(dims, 3)
+    ref = O.forward(sd, dims, O.from_codes(sd, cb, codes))
+    lib.vn_debug_x3_config(0, 2, -1)
+    try:
+        got = m.forward_codes(codes).cpu()          # reference layout, fused form
+    finally:
+        lib.vn_debug_x3_config(0, -1, -1)
+    assert (got - ref).abs().max().item() <= TM.LOGIT_ATOL_TINY

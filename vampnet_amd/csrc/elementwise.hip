@@ -6,21 +6,14 @@
 // One 64-lane wave per row, float4 loads (coalesced 1 KiB per wave instruction), shuffle reduce.
 // Algorithmic bytes: 8*D per row (read x, write y) + D*4 weights (L2 resident).
 // ---------------------------------------------------------------------------------------------
-template <int VEC>   // VEC = float4 per lane = D / 256
-__global__ __launch_bounds__(256) void vn_rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                         float* __restrict__ y, uint16_t* __restrict__ y16, long plane16,
-                                                         int rows, int D, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const f32x4* xr = (const f32x4*)(x + (size_t)row * D);
-    f32x4 v[VEC];
+// the row math shared by the stand-alone kernel and the fused split-K reduce below (one expression tree -> the same contraction
+// into FMAs in both, so the two paths are bitwise equal): v = the lane's VEC float4 of row `row` (element 4 (lane + 64 i) + e)
+template <int VEC>
+__device__ __forceinline__ void vn_rmsnorm_row(const f32x4 (&v)[VEC], const float* __restrict__ w, float* __restrict__ y,
+                                               uint16_t* __restrict__ y16, long plane16, int row, int D, float eps, int lane) {
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        v[i] = xr[lane + 64 * i];
-        ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
-    }
+    for (int i = 0; i < VEC; ++i) ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     const float rstd = 1.0f / sqrtf(ss / (float)D + eps);   // exact div+sqrt == torch.rsqrt on CPU
@@ -40,6 +33,49 @@ __global__ __launch_bounds__(256) void vn_rmsnorm_kernel(const float* __restrict
             yr[lane + 64 * i] = o;
         }
     }
+}
+
+template <int VEC>   // VEC = float4 per lane = D / 256
+__global__ __launch_bounds__(256) void vn_rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         float* __restrict__ y, uint16_t* __restrict__ y16, long plane16,
+                                                         int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const f32x4* xr = (const f32x4*)(x + (size_t)row * D);
+    f32x4 v[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = xr[lane + 64 * i];
+    vn_rmsnorm_row<VEC>(v, w, y, y16, plane16, row, D, eps, lane);
+}
+
+// Split-K reduce of a RESIDUAL GEMM fused with the RMSNorm that follows it in the layer (x += sum of the split images, in the
+// fixed order of vn_splitk_reduce_kernel; y = RMSNorm(x)): one wave per row, the row never leaves the registers between the two.
+// Saves the norm kernel's read of x and one launch boundary per (Wo, norm_3) / (W2, next norm_1) pair.
+template <int VEC>
+__global__ __launch_bounds__(256) void vn_splitk_reduce_rmsnorm_kernel(const float* __restrict__ partial, int nsplit, float* __restrict__ x,
+                                                                       const float* __restrict__ w, float* __restrict__ y,
+                                                                       uint16_t* __restrict__ y16, long plane16, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long plane4 = (long)rows * (D >> 2);
+    const f32x4* pr = (const f32x4*)partial + (size_t)row * (D >> 2);
+    f32x4* xr = (f32x4*)(x + (size_t)row * D);
+    f32x4 v[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        f32x4 a = pr[lane + 64 * i];
+        for (int sp = 1; sp < nsplit; ++sp) {
+            const f32x4 b = pr[lane + 64 * i + sp * plane4];
+            a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+        }
+        const f32x4 r = xr[lane + 64 * i];
+        a[0] += r[0]; a[1] += r[1]; a[2] += r[2]; a[3] += r[3];
+        xr[lane + 64 * i] = a;
+        v[i] = a;
+    }
+    vn_rmsnorm_row<VEC>(v, w, y, y16, plane16, row, D, eps, lane);
 }
 
 // generic fallback (any D multiple of 4): strided loop, two passes over the row (second from L1/L2)
@@ -81,6 +117,18 @@ int vn_launch_rmsnorm(vn_ctx* ctx, const float* x, const float* w, float* y, int
     else if (D == 256) hipLaunchKernelGGL(vn_rmsnorm_kernel<1>, grid, block, 0, s, x, w, y, y16, plane16, rows, D, eps);
     else if (y16) return vn_fail(ctx, VN_ERR_UNSUPPORTED, "rmsnorm: bf16 output needs D in {256, 1280}%s", "");
     else hipLaunchKernelGGL(vn_rmsnorm_generic_kernel, grid, block, 0, s, x, w, y, rows, D, eps);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// fused split-K reduce (+ residual) + RMSNorm; D in {256, 1280} (the models' widths), C row stride == D
+int vn_launch_splitk_reduce_rmsnorm(vn_ctx* ctx, const float* partial, int nsplit, float* x, const float* w, float* y, uint16_t* y16,
+                                    long plane16, int rows, int D, float eps, hipStream_t s) {
+    if (rows <= 0) return VN_OK;
+    const dim3 grid(vn_cdiv(rows, 4)), block(256);
+    if (D == 1280) hipLaunchKernelGGL(vn_splitk_reduce_rmsnorm_kernel<5>, grid, block, 0, s, partial, nsplit, x, w, y, y16, plane16, rows, D, eps);
+    else if (D == 256) hipLaunchKernelGGL(vn_splitk_reduce_rmsnorm_kernel<1>, grid, block, 0, s, partial, nsplit, x, w, y, y16, plane16, rows, D, eps);
+    else return vn_fail(ctx, VN_ERR_UNSUPPORTED, "splitk_reduce_rmsnorm: D=%s%ld must be 256 or 1280", "", D);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
 }

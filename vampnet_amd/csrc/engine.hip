@@ -266,9 +266,16 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
     int& cus = cus_of[ctx->device & 63];
     if (!cus && (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0)) cus = 256;
     const bool attn_x3 = attn_x3_env >= 0 ? attn_x3_env != 0 : 2L * B * H * ((T + 127) / 128) >= 3L * cus;
+    // a RESIDUAL GEMM that gets split along K runs the RMSNorm that follows it inside its reduce pass (gemm_x3.hip)
+    int normed = 0;
+    auto with_norm = [&](vn_gemm_args& a, const float* w) {
+        a.norm_w = w; a.norm_y = m->y; a.norm_y16 = bf ? m->y16 : nullptr; a.norm_plane = yp; a.norm_eps = m->d.eps;
+        a.norm_done = &normed;
+        normed = 0;
+    };
     for (int l = 0; l < m->L; ++l) {
         // y = RMSNorm(x) ; FiLM = identity (d_cond = 0, transformer.py:554)
-        if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM1, l), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr, yp))) return rc;
+        if (!normed && (rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM1, l), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr, yp))) return rc;
         if (gm == 2 && attn_x3) {
             // ONE QKV GEMM whose epilogue writes the attention operands as split planes: q (x 1/8) and k head-major, V^T blocked by
             // tiles of 32 token rows (transposed through the epilogue's LDS image)
@@ -294,8 +301,9 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
         vn_gemm_args o{};
         operands(o, m->y, m->y16, yp, VN_W_WO, l);
         o.C = m->x; o.M = M; o.N = D; o.K = D; o.ldc = D;
+        with_norm(o, W(m, VN_W_NORM3, l));
         if ((rc = vn_launch_gemm_f32(ctx, o, VN_EPI_RESIDUAL, s))) return rc;           // x = x + attn
-        if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM3, l), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr, yp))) return rc;
+        if (!normed && (rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM3, l), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr, yp))) return rc;
         vn_gemm_args f1{};
         operands(f1, m->y, m->y16, yp, VN_W_W1, l);
         f1.C = m->g; f1.C16 = bf ? m->g16 : nullptr; f1.c_plane = gp; f1.M = M; f1.N = 4 * D; f1.K = D; f1.ldc = 2 * D;
@@ -303,9 +311,10 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
         vn_gemm_args f2{};
         operands(f2, m->g, m->g16, gp, VN_W_W2, l);
         f2.C = m->x; f2.M = M; f2.N = D; f2.K = 2 * D; f2.ldc = D;
+        with_norm(f2, l + 1 < m->L ? W(m, VN_W_NORM1, l + 1) : W(m, VN_W_FINAL_NORM));   // the next layer's norm_1 / the final norm
         if ((rc = vn_launch_gemm_f32(ctx, f2, VN_EPI_RESIDUAL, s))) return rc;          // x = x + ffn
     }
-    if ((rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_FINAL_NORM), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr, yp))) return rc;
+    if (!normed && (rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_FINAL_NORM), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr, yp))) return rc;
     vn_gemm_args c{};
     operands(c, m->y, m->y16, yp, VN_W_CLS_W, 0);
     c.bias = W(m, VN_W_CLS_B); c.C = logits; c.M = M;

@@ -531,6 +531,13 @@ static int x3_go_bm(vn_ctx* ctx, const vn_gemm_args& a, int nsplit, int bm, hipS
 
 // split count for the store / residual epilogues.  A launch costs ceil(tiles * ns / 256) rounds of
 // K / ns, plus the reduce pass over (ns + 1 or 2) images of C (1.45 us per k-tile and round, ~3.5 TB/s for the reduce).
+static int g_x3_fuse_norm = -1;                  // test hook: -1 = VN_X3_FUSE_NORM (default on), 0 / 1 forced
+extern "C" int vn_debug_x3_fuse_norm(int on) { g_x3_fuse_norm = on < 0 ? -1 : (on != 0); return VN_OK; }
+static bool x3_norm_fusable(const vn_gemm_args& a) {
+    static const bool fuse_env = x3_env("VN_X3_FUSE_NORM", 1) != 0;
+    const bool fuse_norm = g_x3_fuse_norm >= 0 ? g_x3_fuse_norm != 0 : fuse_env;
+    return fuse_norm && a.norm_w && a.norm_done && a.ldc == a.N && (a.N == 1280 || a.N == 256);
+}
 static int x3_pick_split(const vn_gemm_args& a, bool residual, int bm) {
     static const int forced_env = x3_env("VN_X3_SPLITK", -1);      // 0 / 1: off, 2 / 4: forced
     const int forced = g_x3_split != -2 ? g_x3_split : forced_env;
@@ -543,6 +550,8 @@ static int x3_pick_split(const vn_gemm_args& a, bool residual, int bm) {
         if (forced > 1 && ns != forced && ns != 1) continue;
         double cost = ceil(tiles * ns / 256.0) * (nk / (double)ns) * 1.45 * (bm / 128);
         if (ns > 1) cost += (ns + (residual ? 2 : 1)) * 4.0 * a.M * (double)a.N / 3.5e6;
+        // the reduce pass of a split launch also runs the RMSNorm that follows: that norm's read of x and a launch boundary are saved
+        if (ns > 1 && residual && x3_norm_fusable(a)) cost -= 4.0 * a.M * (double)a.N / 3.5e6 + 1.5;
         if (forced > 1 && ns == forced) cost = 0;
         if (cost < best_cost) { best_cost = cost; best = ns; }
     }
@@ -578,7 +587,14 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
             q.C = ctx->x3_ws;
             q.ldc = a.N;
             rc = x3_go_bm<VN_EPI_STORE>(ctx, q, ns, bm, s);
-            if (rc == VN_OK) rc = vn_launch_splitk_reduce(ctx, ctx->x3_ws, ns, a.C, a.M, a.N, a.ldc, EPI == VN_EPI_RESIDUAL, s);
+            if (EPI == VN_EPI_RESIDUAL && x3_norm_fusable(a)) {
+                if (rc == VN_OK)
+                    rc = vn_launch_splitk_reduce_rmsnorm(ctx, ctx->x3_ws, ns, a.C, a.norm_w, a.norm_y, a.norm_y16, a.norm_plane, a.M, a.N,
+                                                         a.norm_eps, s);
+                if (rc == VN_OK) *a.norm_done = 1;
+            } else if (rc == VN_OK) {
+                rc = vn_launch_splitk_reduce(ctx, ctx->x3_ws, ns, a.C, a.M, a.N, a.ldc, EPI == VN_EPI_RESIDUAL, s);
+            }
             done = true;
         }
     }

@@ -217,12 +217,25 @@ struct vn_gemm_args {
     uint16_t* V16;       // QKV3 epilogue: V^T planes [3][H][ceil(M / 32)][64][32], v_plane elements apart (C16 = q then k planes)
     long v_plane;
     int staged;          // gemm_x3.hip: epilogue through LDS with 16-byte global accesses (set by the launcher when alignment allows)
+    // RESIDUAL epilogue only, optional: the RMSNorm that follows this GEMM in the layer (y = RMSNorm(C) with weight norm_w).  A launch
+    // that is split along K runs it inside its reduce pass (vn_splitk_reduce_rmsnorm_kernel) and sets *norm_done = 1; otherwise the
+    // caller launches the norm itself.  norm_y16 / norm_plane as vn_launch_rmsnorm's y16 / plane16.
+    const float* norm_w;
+    float* norm_y;
+    uint16_t* norm_y16;
+    long norm_plane;
+    float norm_eps;
+    int* norm_done;
 };
 int vn_launch_gemm_f32(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);
 int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);      // a.bf16 == 2
 // C[M][N] (row stride ldc) (+)= sum over the nsplit partial images partial[s][M][N], in fixed order (gemm_f32.hip)
 int vn_launch_splitk_reduce(vn_ctx* ctx, const float* partial, int nsplit, float* C, int M, int N, int ldc, bool residual,
                             hipStream_t s);
+
+// x[rows][D] += sum of the nsplit images partial[s][rows][D] (fixed order), then y = RMSNorm(x) from the same registers (elementwise.hip)
+int vn_launch_splitk_reduce_rmsnorm(vn_ctx* ctx, const float* partial, int nsplit, float* x, const float* w, float* y, uint16_t* y16,
+                                    long plane16, int rows, int D, float eps, hipStream_t s);
 
 // y16 / out16: bf16 image of the output for the next GEMM; plane16 == 0 one plane, > 0 three split planes that far apart
 int vn_launch_rmsnorm(vn_ctx* ctx, const float* x, const float* w, float* y, int rows, int D, float eps, hipStream_t s,
