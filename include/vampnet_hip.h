@@ -386,6 +386,11 @@ int vn_debug_x3_fuse_norm(int on);
 int vn_debug_attention_x3_time(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias, float* out,
                                int B, int H, int T, int iters, float* avg_us, void* stream);
 
+/* tuning hook of the bf16x3 attention kernel (scripts/attn_probe.py; process-global): abl = variant bits (-1 = VN_ATTN_X3_ABL),
+ * lds_bytes = dynamic-LDS override (0 = natural; sets the blocks per CU), stagger = start delay per SIMD wave slot in units of 64
+ * cycles (-1 = VN_ATTN_X3_STAGGER), trace_dev = uint32 [blocks / 16][8] phase-cycle sums for abl = 16 (NULL = none)            */
+int vn_debug_attention_x3_config(int abl, int lds_bytes, int stagger, void* trace_dev);
+
 #ifdef __cplusplus
 }
 #endif

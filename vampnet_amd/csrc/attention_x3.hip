@@ -36,14 +36,19 @@
 
 __device__ __forceinline__ int ax_swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
-// ABL (tuning only, results invalid): bit 0 = no exp / split (P = bf16(S) in all planes), bit 1 = no S^T MFMAs, bit 2 = no O^T MFMAs
+// ABL (tuning only): bit 0 = no exp / split (P = bf16(S) in all planes), bit 1 = no S^T MFMAs, bit 2 = no O^T MFMAs (results invalid
+// with bits 0-2); bit 3 = no s_setprio around the MFMA phases; bit 4 = phase trace: wave 0 of every 16th block accumulates
+// s_memtime deltas per phase over its tiles into trace[block / 16][8] = {wait, barrier, dma issue, qk, softmax, pv, total, hw_id}.
+// stagger (any variant): a block whose waves sit in SIMD wave slot w starts (w % 3) * stagger * 64 cycles late, so that the blocks
+// sharing a CU do not run the same phase at the same time.
 // (Tried and dropped, profiles/r02_attention_x3_phase_order_ab.txt: one VALU phase + one 48-MFMA phase per tile with K staged a
 // tile ahead of V^T — 125 vs 119 us; six- and two-wave blocks; see also r02_attention_x3_kernel_times.txt.)
 template <int NW, int ABL = 0>
 __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
                                                                     long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
                                                                     const float* __restrict__ bias_full, float* __restrict__ out,
-                                                                    uint16_t* __restrict__ out16, long plane16, int B, int H, int T) {
+                                                                    uint16_t* __restrict__ out16, long plane16, int B, int H, int T,
+                                                                    int stagger, unsigned* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* bt = smem + 2 * AX_STAGE_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
         const float* Ks = smem + kb * AX_STAGE_FLOATS;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             bf16x8 kf[3];
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][s], sacc, 0, 0, 0);
             }
         }
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
     };
     // ---- online softmax of tile kt (scores in sacc): P planes -> pf, running max / sum, O rescaled
     auto softmax_phase = [&](int kt) {
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
     // ---- O^T += V^T . P^T for the tile in stage `vb`: two 32-row d tiles x two 16-key steps x six plane products
     auto pv_phase = [&](int vb) {
         const float* Vs = smem + vb * AX_STAGE_FLOATS + 3 * AX_PLANE_FLOATS;
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -216,18 +221,51 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[0][s], o[dt], 0, 0, 0);
                 }
             }
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
     };
 
+    if (stagger > 0) {                                      // de-phase the blocks that share this CU
+        const int slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) % 3;         // HW_REG_HW_ID bits [3:0]: wave slot in the SIMD
+        for (int i = 0; i < slot * stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+    unsigned long long tr_t = 0;
+    unsigned tr_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tr_start = 0;
+    const bool tracing = (ABL & 16) && trace && wave == 0 && (lid & 15) == 0;
+    auto tick = [&](int slot) {
+        if constexpr (ABL & 16) {
+            if (tracing) {
+                const unsigned long long now = __builtin_readcyclecounter();
+                tr_acc[slot] += (unsigned)(now - tr_t);
+                tr_t = now;
+            }
+        }
+    };
+    if constexpr (ABL & 16) { tr_t = tr_start = __builtin_readcyclecounter(); }
     stage(0, 0, 0, 0);
     for (int kt = 0; kt < NT; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of tile kt have landed
+        tick(0);
         __syncthreads();                                        // all pieces landed; everybody is done with tile kt - 1
+        tick(1);
         stage((kt + 1) & 1, kt + 1, (kt + 1) & 1, kt + 1);
+        tick(2);
         if (!active) continue;
         qk_phase(kt & 1);
+        tick(3);
         softmax_phase(kt);
+        tick(4);
         pv_phase(kt & 1);
+        tick(5);
+    }
+    if constexpr (ABL & 16) {
+        if (tracing && lane == 0) {
+            unsigned* t = trace + (lid >> 4) * 8;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t[i] = tr_acc[i];
+            t[6] = (unsigned)(__builtin_readcyclecounter() - tr_start);
+            t[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        }
     }
 
     // ---- finish: the two lanes of a query add their row sums; normalise; store.
@@ -250,29 +288,46 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
     }
 }
 
+// tuning hooks (process-global; scripts/attn_probe.py): ablation / variant bits, dynamic-LDS override (occupancy: > 80 KiB = one block
+// per CU, > 53.3 KiB = two), start stagger, phase-trace buffer
+static int g_ax_abl = -1, g_ax_lds = 0, g_ax_stagger = -1;
+static unsigned* g_ax_trace = nullptr;
+extern "C" int vn_debug_attention_x3_config(int abl, int lds_bytes, int stagger, void* trace_dev) {
+    g_ax_abl = abl; g_ax_lds = lds_bytes; g_ax_stagger = stagger; g_ax_trace = (unsigned*)trace_dev;
+    return VN_OK;
+}
+
 int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16, long plane_qk, const uint16_t* vt16, long plane_vt,
                            const float* relbias_full, float* out, uint16_t* out16, long plane16, int B, int H, int T, hipStream_t s) {
     if (B <= 0 || T <= 0) return VN_OK;
-    const size_t lds = (size_t)(2 * AX_STAGE_FLOATS + 2 * T - 1 + 3) * sizeof(float);
+    size_t lds = (size_t)(2 * AX_STAGE_FLOATS + 2 * T - 1 + 3) * sizeof(float);
     if (lds > 80 * 1024) return vn_fail(ctx, VN_ERR_INVALID, "attention_x3: T=%s%ld too long for two blocks per CU", "", T);
+    if (g_ax_lds > (int)lds && g_ax_lds <= 160 * 1024) lds = g_ax_lds;
     if (!(ctx->attr_mask & VN_ATTR_ATTN_X3)) {
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->attr_mask |= VN_ATTR_ATTN_X3;
     }
     const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
     // four waves (128 queries) per block, three blocks per CU (LDS: 2 x 24 KiB stages + the bias table; 168 VGPRs).  Measured
     // alternatives (profiles/r02_attention_x3_kernel_times.txt): six waves (one round of 480 blocks at B = 8) 119 vs 112 us,
     // two waves no better at any batch size.
-    static const int abl = [] { const char* e = getenv("VN_ATTN_X3_ABL"); return e ? atoi(e) & 7 : 0; }();   // tuning only
+    static const int abl_env = [] { const char* e = getenv("VN_ATTN_X3_ABL"); return e ? atoi(e) & 31 : 0; }();   // tuning only
+    static const int stagger_env = [] { const char* e = getenv("VN_ATTN_X3_STAGGER"); return e ? atoi(e) : 0; }();
+    const int abl = g_ax_abl >= 0 ? g_ax_abl : abl_env;
+    const int stagger = g_ax_stagger >= 0 ? g_ax_stagger : stagger_env;
 #define AX_GO(A) hipLaunchKernelGGL((vn_attention_x3_kernel<4, A>), dim3(vn_cdiv(T, 128) * H * B), dim3(256), lds, s, q16, k16, plane_qk, vt16, \
-                                    plane_vt, relbias_full, out, out16, plane16, B, H, T)
+                                    plane_vt, relbias_full, out, out16, plane16, B, H, T, stagger, g_ax_trace)
     switch (abl) {
         case 1: AX_GO(1); break;
         case 6: AX_GO(6); break;
         case 7: AX_GO(7); break;
+        case 8: AX_GO(8); break;
+        case 16: AX_GO(16); break;
         default: AX_GO(0); break;
     }
 #undef AX_GO
