@@ -369,6 +369,15 @@ int vn_mt19937_generate_chunks(vn_ctx* ctx, const uint32_t* states, int n_chunks
 int vn_torch_exponential_f32(vn_ctx* ctx, const uint32_t* raw, float* out, int64_t n, void* stream);
 int vn_torch_uniform_f32(vn_ctx* ctx, const uint32_t* raw, float* out, int64_t n, float lo, float hi, void* stream);
 
+/* Interface.build_mask on the device, RNG-exact (vampnet/interface.py:454-489, vampnet/mask.py:56-173): `raw` = the words of
+ * torch's CPU mt19937 stream that the reference's draws consume, produced by vn_mt19937_generate — [0, B*C*T) linear_random's
+ * bernoulli (one word per element), then the always-heads coins of periodic_mask (values unused), `roll_word` = index of the
+ * randint word of the roll (-1: period == 0), `drop_word` = index of the first of the n_drop randint words of dropout.  onset:
+ * optional [B][C][T] int64 mask to AND in (host-computed).  ncc / upper already normalised to [0, C].  mask: [B][C][T] int64.  */
+int vn_build_mask(vn_ctx* ctx, const uint32_t* raw, const int64_t* onset, int64_t* mask, int B, int C, int T, float intensity,
+                  int n_prefix, int n_suffix, int period, int width, int64_t roll_word, int64_t drop_word, int n_drop,
+                  int ncc, int upper, void* stream);
+
 /* number of forward passes of this model that were served by replaying a captured hipGraph (tests)               */
 int vn_debug_graph_replays(const vn_model* model, int64_t* count);
 
@@ -382,6 +391,10 @@ int vn_debug_x3_config(int bm, int splitk, int abl);
  * (vn_splitk_reduce_rmsnorm_kernel); 0 = keep the two kernels apart (A/B tests: both forms are bitwise equal), 1 = fuse,
  * -1 = VN_X3_FUSE_NORM / default (on).  Process-global.                                                             */
 int vn_debug_x3_fuse_norm(int on);
+/* the two forms as single ops (tests): x[rows][D] += sum of partial[s][rows][D], y16 = three split planes (plane16 elements
+ * apart) of RMSNorm(x) with weight w; fused != 0 = one kernel, 0 = reduce kernel then norm kernel                      */
+int vn_debug_splitk_reduce_rmsnorm(vn_ctx* ctx, const float* partial, int nsplit, float* x, const float* w, void* y16,
+                                   int64_t plane16, int rows, int D, float eps, int fused, void* stream);
 /* average duration (us) of `iters` launches of the bf16x3 attention kernel alone (planes prepared outside the timed region) */
 int vn_debug_attention_x3_time(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias, float* out,
                                int B, int H, int T, int iters, float* avg_us, void* stream);

@@ -30,6 +30,35 @@ def test_rmsnorm(eng, rows, D):
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("rows,D,ns", [(4600, 1280, 2), (575, 1280, 4), (601, 256, 2), (3, 256, 3), (1, 1280, 2)])
+def test_splitk_reduce_rmsnorm_fused_vs_two_kernels(eng, rows, D, ns):
+    """vn_splitk_reduce_rmsnorm_kernel (the reduce pass of a split RESIDUAL GEMM that also runs the next RMSNorm) against the
+    reduce kernel followed by the norm kernel: x and the three y planes bitwise; and against torch within fp32 rounding."""
+    part, x0, w = _rand((ns, rows, D), 11, 0.7), _rand((rows, D), 12, 2.0), 1 + _rand((D,), 13, 0.1)
+    outs = []
+    for fused in (1, 0):
+        x = x0.cuda().clone()
+        y16 = torch.zeros(3, rows, D, dtype=torch.bfloat16, device="cuda")
+        eng.check(eng.lib.vn_debug_splitk_reduce_rmsnorm(eng.handle, part.cuda().data_ptr(), ns, x.data_ptr(), w.cuda().data_ptr(),
+                                                         y16.data_ptr(), rows * D, rows, D, 1e-6, fused, eng.stream()), "reduce_rmsnorm")
+        outs.append((x.cpu(), y16.cpu()))
+    (xf, yf), (xs, ys) = outs
+    dx = (xf - xs).abs().max().item()
+    dy = (yf.float().sum(0) - ys.float().sum(0)).abs().max().item()
+    print(f"fused vs two kernels: max |dx| = {dx:.3e}, max |dy| = {dy:.3e}")
+    assert torch.equal(xf, xs)
+    assert torch.equal(yf.view(torch.int16), ys.view(torch.int16))
+    xr = x0.clone()
+    acc = part[0].clone()
+    for sp in range(1, ns):
+        acc += part[sp]
+    xr = acc + xr                                  # the reduce's order: images first, then the residual
+    assert torch.equal(xf, xr)
+    yr = O.rmsnorm(xr, w)
+    np.testing.assert_allclose(yf.float().sum(0).numpy(), yr.numpy(), rtol=2e-6, atol=1e-6)
+    assert torch.equal(yf.double().sum(0).float(), yf.float().sum(0))       # planes: exact three-way split of an fp32 value
+
+
 GEMM_SHAPES = [(575, 1280, 1280), (4600, 3840, 1280), (4600, 1280, 2560), (1384, 10240, 1280),
                (50, 256, 256), (1, 128, 64), (129, 192, 96), (64, 64, 32), (700, 4096, 256)]
 

@@ -638,3 +638,51 @@ def test_torch_device_rng_mode_equals_host_replay(tiny):
         outs[mode] = (itf.vamp(z14, m14, batch_size=2, seed=1, _sampling_steps=4).cpu(), torch.rand(64))
     assert torch.equal(outs["torch"][0], outs["torch_device"][0])
     assert torch.equal(outs["torch"][1], outs["torch_device"][1])
+
+
+BUILD_MASK_CASES = [
+    dict(),                                                            # hello.py / BASELINE configs[0]: periodic 7, upper 3
+    dict(rand_mask_intensity=0.7, periodic_prompt=5, periodic_prompt_width=3),
+    dict(prefix_s=0.5, suffix_s=0.8, periodic_prompt=13, periodic_prompt_width=5, upper_codebook_mask=6, ncc=2),
+    dict(periodic_prompt=0, _dropout=0.3, upper_codebook_mask=14),
+    dict(rand_mask_intensity=0.35, periodic_prompt=3, periodic_prompt_width=8, _dropout=0.05, ncc=1, upper_codebook_mask=9),
+    dict(periodic_prompt=700, periodic_prompt_width=1, upper_codebook_mask=0),     # period > T: one centre, roll < 700
+]
+
+
+@pytest.mark.parametrize("B,T", [(1, 575), (3, 173), (2, 64)])
+@pytest.mark.parametrize("case", range(len(BUILD_MASK_CASES)))
+def test_build_mask_on_device(itf, B, T, case):
+    """Interface.build_mask with the draws and the composition on the GPU (vn_build_mask_kernel over torch's CPU mt19937 stream
+    continued on the device) == the host twin of vampnet/mask.py, which the CPU tests pin bitwise to the reference: same mask,
+    same generator position afterwards.  Also with an onset-style mask ANDed in."""
+    from vampnet_amd import masks
+    kw = BUILD_MASK_CASES[case]
+    z = W.synth_codes(B, 14, T, seed=20 + case).cuda()
+    onset = None
+    if case in (1, 4):
+        onset = (torch.rand(1, 1, T, generator=torch.Generator().manual_seed(case)) < 0.8).long().expand(B, 14, T)
+    args = dict(rand_mask_intensity=kw.get("rand_mask_intensity", 1.0), n_prefix=itf.s2t(kw.get("prefix_s", 0.0)),
+                n_suffix=itf.s2t(kw.get("suffix_s", 0.0)), periodic_prompt=kw.get("periodic_prompt", 7),
+                periodic_prompt_width=kw.get("periodic_prompt_width", 1), onset_mask=onset, dropout=kw.get("_dropout", 0.0),
+                upper_codebook_mask=kw.get("upper_codebook_mask", 3), ncc=kw.get("ncc", 0))
+    torch.manual_seed(1000 + case)
+    _ = torch.rand(37)                                  # a generator position inside a 624-word block
+    ref = masks.build_mask(z, **args)
+    state_ref = torch.get_rng_state()
+    torch.manual_seed(1000 + case)
+    _ = torch.rand(37)
+    got = masks.build_mask_device(itf.engine, z, **args)
+    assert got.device == z.device and got.dtype == torch.long
+    assert torch.equal(got.cpu(), ref.cpu())
+    assert torch.equal(torch.get_rng_state(), state_ref)
+    if onset is None:                                   # the Interface entry point routes to the same kernel
+        old = itf.mask_on_device
+        try:
+            itf.mask_on_device = True
+            torch.manual_seed(1000 + case)
+            _ = torch.rand(37)
+            assert torch.equal(itf.build_mask(z, **kw).cpu(), ref.cpu())
+            assert torch.equal(torch.get_rng_state(), state_ref)
+        finally:
+            itf.mask_on_device = old

@@ -560,3 +560,54 @@ def test_attention_x3_lds_addressing():
                     assert lds[byte] == (d, 2 * s + hh)
                     slots.add((byte // 16) % 16)
                 assert len(slots) == 16
+
+
+def test_build_mask_device_word_ledger_and_kernel_arithmetic():
+    """The device build_mask (csrc/elementwise.hip: vn_build_mask_kernel, masks.build_mask_device) restated in numpy over the raw
+    mt19937 words — the same ledger (masks.mask_word_ledger), the same 24-bit bernoulli, `% period` roll, `% T` dropout columns,
+    nearest-centre window test — against the host twin of vampnet/mask.py (itself pinned bitwise to the reference), including
+    the generator position after the call.  The GPU test holds the kernel to the same masks."""
+    import numpy as np
+    from vampnet_amd import masks
+
+    def model(raw, B, C, T, rand_mask_intensity=1.0, n_prefix=0, n_suffix=0, periodic_prompt=7, periodic_prompt_width=1,
+              onset_mask=None, dropout=0.0, upper_codebook_mask=3, ncc=0):
+        period, width = periodic_prompt, periodic_prompt_width
+        roll_word, drop_word, n_drop, n_words = masks.mask_word_ledger(B, C, T, period, width, dropout)
+        n_lin = B * C * T
+        u = (raw[:n_lin] & np.uint64(0xFFFFFF)).astype(np.float32) * np.float32(2.0 ** -24)
+        m = (u < np.float32(rand_mask_intensity)).astype(np.int64).reshape(B, C, T)
+        t = np.arange(T)
+        m[:, :, (t < n_prefix) | (t >= T - n_suffix)] = 0
+        if period > 0:
+            off = int(raw[roll_word] % np.uint64(period))
+            ts = (t - off % T) % T
+            hw, c0 = width // 2, (ts // period) * period
+            c1 = c0 + period
+            m[:, :, ((ts - c0) <= hw) | ((c1 < T) & ((c1 - ts) <= hw))] = 0
+        if onset_mask is not None:
+            m[onset_mask.numpy() == 0] = 0
+        for j in range(n_drop):
+            m[:, :, int(raw[drop_word + j] % np.uint64(T))] = 1
+        m[:, :(0 if ncc is None else masks._slice_start(ncc, C)), :] = 0
+        m[:, masks._slice_start(upper_codebook_mask, C):, :] = 1
+        return m, n_words
+
+    cases = [dict(), dict(rand_mask_intensity=0.7, periodic_prompt=5, periodic_prompt_width=3),
+             dict(n_prefix=44, n_suffix=69, periodic_prompt=13, periodic_prompt_width=5, upper_codebook_mask=6, ncc=2),
+             dict(periodic_prompt=0, dropout=0.3, upper_codebook_mask=14),
+             dict(rand_mask_intensity=0.35, periodic_prompt=3, periodic_prompt_width=8, dropout=0.05, ncc=1, upper_codebook_mask=9),
+             dict(periodic_prompt=700, upper_codebook_mask=0), dict(upper_codebook_mask=-2, ncc=-13), dict(n_prefix=600), dict(ncc=None)]
+    for ci, kw in enumerate(cases):
+        for (B, T) in [(1, 575), (3, 173), (2, 64)]:
+            z = torch.zeros(B, 14, T, dtype=torch.long)
+            onset = None
+            if ci in (1, 4):
+                onset = (torch.rand(1, 1, T, generator=torch.Generator().manual_seed(ci)) < 0.8).long().expand(B, 14, T)
+            torch.manual_seed(50 + ci)
+            raw = _mt_raw(50 + ci, B * 14 * T + 4 * B * T + 700)
+            ref = masks.build_mask(z, onset_mask=onset, **kw)
+            got, n_words = model(raw, B, 14, T, onset_mask=onset, **kw)
+            assert np.array_equal(got, ref.numpy()), (ci, B, T)
+            nxt = torch.empty(1).uniform_(0, 1).item()                 # the generator stands n_words further
+            assert nxt == float(np.float32(int(raw[n_words]) & 0xFFFFFF) * np.float32(2.0 ** -24)), (ci, B, T)

@@ -133,6 +133,17 @@ int vn_launch_splitk_reduce_rmsnorm(vn_ctx* ctx, const float* partial, int nspli
     return VN_OK;
 }
 
+// test hook: x += sum of the split images, y16 = split planes of RMSNorm(x), as ONE kernel (fused != 0) or as the reduce kernel
+// followed by the norm kernel — tests/test_gpu_kernels.py holds the two forms to bitwise equality
+extern "C" int vn_debug_splitk_reduce_rmsnorm(vn_ctx* ctx, const float* partial, int nsplit, float* x, const float* w, void* y16,
+                                              int64_t plane16, int rows, int D, float eps, int fused, void* stream) {
+    if (!ctx || !partial || !x || !w || !y16 || nsplit < 1 || rows <= 0 || plane16 < (int64_t)rows * D) return VN_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (fused) return vn_launch_splitk_reduce_rmsnorm(ctx, partial, nsplit, x, w, nullptr, (uint16_t*)y16, plane16, rows, D, eps, s);
+    const int rc = vn_launch_splitk_reduce(ctx, partial, nsplit, x, rows, D, D, true, s);
+    return rc ? rc : vn_launch_rmsnorm(ctx, x, w, nullptr, rows, D, eps, s, (uint16_t*)y16, plane16);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Codebook embedding (vampnet/modules/layers.py:134-163): per codebook c gather the latent row
 // tables[c][code] (row `vocab` = MASK special), concatenate (8C values) and apply the 1x1 conv
@@ -278,6 +289,57 @@ int vn_launch_apply_mask(vn_ctx* ctx, const int64_t* tokens, const int64_t* mask
     if (n <= 0) return VN_OK;
     hipLaunchKernelGGL(vn_apply_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tokens, mask, z,
                        count, n, V);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Interface.build_mask on the device (vampnet/interface.py:454-489 over vampnet/mask.py), RNG-exact: the words of torch's CPU
+// generator that the reference's draws consume are produced on the device (torch_rng.hip) and handed in as `raw`:
+//   raw[0 .. B C T)        linear_random  (mask.py:70):  bernoulli(p) = ((w & 0xFFFFFF) * 2^-24 < p), one word per element
+//   raw[.. + B * sum w)    periodic_mask's always-heads coins (mask.py:120): consumed, values unused
+//   raw[roll_word]         the roll offset  randint(0, period, (1,)) = w % period  (mask.py:128), absent when period == 0
+//   raw[drop_word ..+n_drop) dropout's randint(0, T, (n_drop,)) = w % T  (mask.py:170)
+// One thread per element: random & inpaint (mask.py:75-99) & periodic, rolled (mask.py:101-131) & onset (host-computed, optional);
+// dropout columns -> 1; conditioning codebooks -> 0 (mask.py:133-142); codebooks >= upper -> 1 (mask.py:144-146).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vn_build_mask_kernel(const uint32_t* __restrict__ raw, const int64_t* __restrict__ onset,
+                                                            int64_t* __restrict__ mask, int B, int C, int T, float intensity,
+                                                            int n_prefix, int n_suffix, int period, int width, long roll_word,
+                                                            long drop_word, int n_drop, int ncc, int upper) {
+    const long n = (long)B * C * T;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int t = (int)(i % T), c = (int)((i / T) % C);
+    const float u = (float)(raw[i] & 0xFFFFFFu) * 5.9604644775390625e-08f;          // at::uniform_real_distribution<float>: 24 bits
+    int m = u < intensity ? 1 : 0;
+    if (t < n_prefix || t >= T - n_suffix) m = 0;
+    if (period > 0) {
+        const int off = roll_word >= 0 ? (int)(raw[roll_word] % (uint32_t)period) : 0;
+        int ts = t - off % T;                                                        // torch.roll: out[t] = in[(t - off) mod T]
+        if (ts < 0) ts += T;
+        const int hw = width / 2, k = ts / period;
+        const int c0 = k * period, c1 = c0 + period;                                 // centres j % period == 0, j < T
+        if (ts - c0 <= hw || (c1 < T && c1 - ts <= hw)) m = 0;
+    }
+    if (onset && onset[i] == 0) m = 0;
+    for (int j = 0; j < n_drop; ++j)
+        if ((int)(raw[drop_word + j] % (uint32_t)T) == t) m = 1;
+    if (c < ncc) m = 0;
+    if (c >= upper) m = 1;
+    mask[i] = m;
+}
+
+extern "C" int vn_build_mask(vn_ctx* ctx, const uint32_t* raw, const int64_t* onset, int64_t* mask, int B, int C, int T, float intensity,
+                             int n_prefix, int n_suffix, int period, int width, int64_t roll_word, int64_t drop_word, int n_drop,
+                             int ncc, int upper, void* stream) {
+    if (!ctx || !raw || !mask || B <= 0 || C <= 0 || T <= 0) return VN_ERR_INVALID;
+    if (!(intensity >= 0.f && intensity <= 1.f)) return vn_fail(ctx, VN_ERR_INVALID, "build_mask: intensity must be in [0, 1]%s", "");
+    if (period < 0 || width < 0 || n_prefix < 0 || n_suffix < 0 || n_drop < 0 || ncc < 0 || upper < 0 || (n_drop > 0 && drop_word < 0))
+        return vn_fail(ctx, VN_ERR_INVALID, "build_mask: negative argument%s", "");
+    const long n = (long)B * C * T;
+    hipLaunchKernelGGL(vn_build_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, raw, onset, mask, B, C, T,
+                       intensity, n_prefix, n_suffix, period, width, (long)roll_word, (long)drop_word, n_drop, ncc, upper);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
 }

@@ -16,6 +16,7 @@ Additions that the reference does not have (all optional, defaults reproduce the
 """
 import functools
 import math
+import os
 from pathlib import Path
 
 import torch
@@ -134,6 +135,9 @@ class Interface:
         self._in_stream = False
         self.loudness = -24.0
         self.beat_tracker = None
+        # build_mask on the GPU (draws included, RNG-exact: masks.build_mask_device) instead of the host twin of vampnet/mask.py;
+        # both give the same mask and leave torch's CPU generator at the same position
+        self.mask_on_device = os.environ.get("VN_MASK_ON_DEVICE", "0") != "0"
         self.rng = rng
         self.max_batch = max_batch
         self.pg = process_group
@@ -281,6 +285,11 @@ class Interface:
         if onset_mask_width > 0:
             assert sig is not None, "must provide a signal to use onset mask"
             onset = masks.onset_mask(sig, z, self, width=onset_mask_width)
+        if getattr(self, "mask_on_device", False):   # same mask, same generator position, no host loop (csrc/elementwise.hip: vn_build_mask_kernel)
+            return masks.build_mask_device(self.engine, z, rand_mask_intensity=rand_mask_intensity, n_prefix=self.s2t(prefix_s),
+                                           n_suffix=self.s2t(suffix_s), periodic_prompt=periodic_prompt,
+                                           periodic_prompt_width=periodic_prompt_width, onset_mask=onset, dropout=_dropout,
+                                           upper_codebook_mask=upper_codebook_mask, ncc=ncc)
         return masks.build_mask(z, rand_mask_intensity=rand_mask_intensity, n_prefix=self.s2t(prefix_s),
                                 n_suffix=self.s2t(suffix_s), periodic_prompt=periodic_prompt,
                                 periodic_prompt_width=periodic_prompt_width, onset_mask=onset, dropout=_dropout,

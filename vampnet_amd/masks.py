@@ -154,6 +154,65 @@ def build_mask(z: torch.Tensor, *, rand_mask_intensity=1.0, n_prefix=0, n_suffix
     return m.to(z.device)
 
 
+def _slice_start(v, C):
+    """python slice semantics of mask[:, v:, :] / mask[:, :v, :] for an int bound -> index in [0, C]."""
+    v = int(v)
+    return max(C + v, 0) if v < 0 else min(v, C)
+
+
+def mask_word_ledger(B: int, C: int, T: int, period: int, width: int, dropout: float):
+    """Where the reference's build_mask draws sit in torch's CPU mt19937 stream, in 32-bit words from the current position:
+    [0, B C T) linear_random's bernoulli; then one word per always-heads coin of periodic_mask (B items x the clipped windows);
+    then the roll's randint (absent when period == 0); then dropout's int(T p) randints.
+    -> (roll_word or -1, drop_word, n_drop, n_words)."""
+    n_lin = B * C * T
+    n_coin = 0
+    if period > 0:
+        centers = torch.arange(0, T, period)
+        lo = (centers - width // 2).clamp(min=0)
+        hi = (centers + width // 2).clamp(max=T - 1) + 1
+        n_coin = B * int((hi - lo).sum())
+    roll_word = n_lin + n_coin if period > 0 else -1
+    n_drop = int(T * dropout)
+    drop_word = n_lin + n_coin + (1 if period > 0 else 0)
+    return roll_word, drop_word, n_drop, drop_word + n_drop
+
+
+def build_mask_device(engine, z: torch.Tensor, *, rand_mask_intensity=1.0, n_prefix=0, n_suffix=0, periodic_prompt=7,
+                      periodic_prompt_width=1, onset_mask=None, dropout=0.0, upper_codebook_mask=3, ncc=0) -> torch.Tensor:
+    """build_mask with every draw and the whole composition on the GPU (csrc/elementwise.hip: vn_build_mask_kernel): torch's CPU
+    generator is handed to the device (vampnet_amd/torch_rng.py), the words the reference's draws consume — B C T for
+    linear_random, one per always-heads coin of periodic_mask, one for the roll, int(T p) for dropout — are produced there, and
+    the advanced generator is written back, so the mask AND the generator position equal the host path's / the reference's
+    (tests/test_gpu_model.py::test_build_mask_on_device).  `onset_mask`, when given, is the host-computed onset mask."""
+    import ctypes as C_
+    B, C, T = (int(v) for v in z.shape)
+    dev = engine.device
+    period, width = int(periodic_prompt), int(periodic_prompt_width)
+    if period < 0 or width < 0:
+        raise ValueError("periodic_prompt and periodic_prompt_width must be >= 0")
+    p = float(torch.tensor(float(rand_mask_intensity), dtype=torch.float32))
+    if not 0.0 <= p <= 1.0:
+        raise RuntimeError("Expected p_in >= 0 && p_in <= 1")                 # torch.bernoulli's own check
+    roll_word, drop_word, n_drop, n_words = mask_word_ledger(B, C, T, period, width, dropout)
+    rng = engine.torch_rng()
+    rng._producer = torch.cuda.current_stream(dev)
+    rng.load_from_torch()
+    raw = torch.empty(n_words, dtype=torch.int32, device=dev)
+    rng._gen(raw.data_ptr(), n_words)
+    onset = None
+    if onset_mask is not None:
+        onset = onset_mask.to(dev, torch.int64).expand(B, C, T).contiguous()
+    mask = torch.empty(B, C, T, dtype=torch.int64, device=dev)
+    C_up = _slice_start(upper_codebook_mask, C)
+    C_ncc = 0 if ncc is None else _slice_start(ncc, C)
+    engine.check(engine.lib.vn_build_mask(engine.handle, raw.data_ptr(), onset.data_ptr() if onset is not None else None,
+                                          mask.data_ptr(), B, C, T, C_.c_float(p), int(n_prefix), int(n_suffix), period, width,
+                                          roll_word, drop_word, n_drop, C_ncc, C_up, engine.stream()), "vn_build_mask")
+    rng.store_to_torch()
+    return mask if z.device == mask.device else mask.to(z.device)
+
+
 # ---- the reference module's own names and signatures (vampnet/mask.py), so that `from vampnet_amd import masks as pmask` serves
 # its callers (app.py:206-217, scripts/exp/train.py:250-254).  Same arithmetic, same torch-CPU RNG consumption; pinned against
 # the reference in tests/test_oracle_vs_reference.py::test_mask_module_names_bitwise.

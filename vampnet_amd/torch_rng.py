@@ -59,9 +59,40 @@ class DeviceTorchRng:
             self._raw = torch.empty(n_words, dtype=torch.int32, device=self.engine.device)
         return self._raw
 
+    def self_check(self):
+        """Once per process: the device continuation rests on three facts about THIS torch build's CPU generator — exponential_
+        = float(-log1p(-u53)) of consecutive word pairs, uniform_ / bernoulli = the 24-bit formula of one word, randint = word %
+        range, all strictly sequential (tests/test_host_logic.py pins them where the CPU suite runs).  A build that vectorises
+        one of them differently (e.g. an MKL/VSL path) would silently part from the reference, so compare a few dozen device
+        samples with torch's own from a copy of the current generator and refuse to continue on a mismatch."""
+        if DeviceTorchRng._checked:
+            return
+        blob = torch.get_rng_state()
+        g = torch.Generator()
+        g.set_state(blob)
+        want_e = torch.empty(48).exponential_(1, generator=g)
+        want_u = torch.empty(48).uniform_(1e-20, 1.0, generator=g)
+        state, pos = parse_torch_rng_state(blob)
+        keep_state, keep_pos = self.state.clone(), self.pos.clone()
+        try:
+            self.state.copy_(torch.from_numpy(state.view(np.int32)))
+            self.pos.fill_(pos)
+            got_e = self.exponential_(torch.empty(48, device=self.engine.device)).cpu()
+            got_u = self.uniform_(torch.empty(48, device=self.engine.device), 1e-20, 1.0).cpu()
+        finally:
+            self.state.copy_(keep_state)
+            self.pos.copy_(keep_pos)
+        if not (torch.equal(got_e, want_e) and torch.equal(got_u, want_u)):
+            raise RuntimeError("this torch build's CPU generator does not follow the sequential mt19937 formulas the device RNG "
+                               "continues (exponential_ / uniform_ differ): use rng='torch' (host-drawn noise) instead of 'torch_device'")
+        DeviceTorchRng._checked = True
+
+    _checked = False
+
     def load_from_torch(self):
         if getattr(self, "_producer", None) is None:
             self._producer = torch.cuda.current_stream(self.engine.device)
+        self.self_check()
         self._blob = torch.get_rng_state()
         state, pos = parse_torch_rng_state(self._blob)
         self.state.copy_(torch.from_numpy(state.view(np.int32)))
