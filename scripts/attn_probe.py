@@ -32,12 +32,16 @@ def run(B, H, T, abl=0, lds=0, stagger=0, trace=None, iters=30):
 
 
 H = 20
-for (B, T) in [(8, 575), (4, 575), (2, 575), (32, 173)]:
+QUICK = os.environ.get("ATTN_PROBE_QUICK") == "1"
+for (B, T) in ([(8, 575), (32, 173), (2, 575)] if QUICK else [(8, 575), (4, 575), (2, 575), (32, 173)]):
     fl = 4.0 * T * T * 64 * H * B
-    for name, kw in [("3 blocks/CU (shipped)", {}), ("2 blocks/CU", dict(lds=60 * 1024)), ("1 block/CU", dict(lds=90 * 1024)),
-                     ("no setprio", dict(abl=8)), ("no setprio, 2/CU", dict(abl=8, lds=60 * 1024))] + \
+    variants = [("3 blocks/CU (shipped)", {}), ("2 blocks/CU", dict(lds=60 * 1024)), ("1 block/CU", dict(lds=90 * 1024)),
+                ("no setprio", dict(abl=8))]
+    if not QUICK:
+        variants += [("no setprio, 2/CU", dict(abl=8, lds=60 * 1024))] + \
                     [(f"stagger {s} x 64 cyc", dict(stagger=s)) for s in (4, 8, 16, 24, 32, 48, 64)] + \
-                    [(f"stagger {s} x 64 cyc, 2/CU", dict(stagger=s, lds=60 * 1024)) for s in (16, 32, 48)]:
+                    [(f"stagger {s} x 64 cyc, 2/CU", dict(stagger=s, lds=60 * 1024)) for s in (16, 32, 48)]
+    for name, kw in variants:
         us = run(B, H, T, **kw)
         print(f"B={B:2d} T={T}: {name:28s} {us:8.1f} us  {fl / us / 1e6:6.1f} TF-eq", flush=True)
 

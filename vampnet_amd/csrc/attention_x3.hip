@@ -28,6 +28,7 @@
 //   K rows are 128 B: slot s of row r lives at s ^ ((r >> 1) & 7);  V^T rows are 64 B: s ^ ((r >> 2) & 3)  (both give every
 //   16-lane ds_read_b128 group 16 distinct 16-byte slots of the 256-byte bank row).
 // Algorithmic FLOPs: 4*T*T*64 per (b,h); executed on the bf16 pipe: 6x that.
+#include <type_traits>
 #include "vn_common.h"
 
 #define AX_KT 32                          // keys per tile
@@ -89,27 +90,28 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
         for (int s = 0; s < 4; ++s)
             qf[p][s] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Qp + (size_t)p * plane_qk + (size_t)qrow_c * VN_DHEAD + 16 * s + 8 * hh));
 
-    // LDS-DMA: 24 wave-instructions of 1 KiB per stage (K: 3 planes x 4, each 8 rows x 128 B; V^T: 3 planes x 4, each 16 rows x 64 B)
-    auto stage = [&](int kbuf, int ktk, int vbuf, int ktv) {   // K tile ktk -> K half of stage kbuf, V^T tile ktv -> V half of stage vbuf
-        const int key0 = (g_lo + ktk) * AX_KT - m_lo;           // may be negative in the first tile
+    // LDS-DMA: 24 wave-instructions of 1 KiB per stage (K: 3 planes x 4, each 8 rows x 128 B; V^T: 3 planes x 4, each 16 rows x 64 B);
+    // wave w issues piece w of every plane tile.  A piece's source is (uniform plane / tile base) + (a per-lane offset that is the
+    // same for every plane and tile), so a tile costs six scalar adds and no vector address arithmetic.  K rows are NOT clamped to
+    // the item: the rows of a first / last tile that belong to the neighbouring items (or to the q planes in front of / the
+    // 32-row padding behind the k planes) are read as they are and masked to -inf before the softmax.
+    static_assert(NW == 4, "one piece of every plane tile per wave");
+    const int krow = 8 * wave + (lane >> 3), vrow = 16 * wave + (lane >> 2);
+    const unsigned kvoff = (unsigned)(krow * VN_DHEAD + ((lane & 7) ^ ((krow >> 1) & 7)) * 8) * 2u;      // bytes inside a K tile
+    const unsigned vvoff = (unsigned)(vrow * AX_KT + ((lane & 3) ^ ((vrow >> 2) & 3)) * 8) * 2u;         // bytes inside a V^T tile
+    const char* kbase = (const char*)(Kp + (long)(g_lo * AX_KT - m_lo) * VN_DHEAD);                       // tile 0, plane 0 (key0 <= 0)
+    const char* vbase = (const char*)Vp;
+    auto stage = [&](int buf, int kt) {                       // tile kt -> stage buf
+        if (kt >= NT) return;
+        float* base = smem + buf * AX_STAGE_FLOATS + wave * 256;
 #pragma unroll
-        for (int i = 0; i < 24 / NW; ++i) {
-            const int q = wave + i * NW;
-            const uint16_t* src;
-            if (q < 12) {
-                const int p = q >> 2, row = 8 * (q & 3) + (lane >> 3);
-                int key = key0 + row;
-                key = key < 0 ? 0 : (key < T ? key : T - 1);
-                src = Kp + (size_t)p * plane_qk + (size_t)key * VN_DHEAD + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
-            } else {
-                const int q2 = q - 12;
-                const int p = q2 >> 2, row = 16 * (q2 & 3) + (lane >> 2);
-                src = Vp + (size_t)p * plane_vt + ((size_t)ktv * VN_DHEAD + row) * AX_KT + ((lane & 3) ^ ((row >> 2) & 3)) * 8;
-            }
-            if ((q < 12 ? ktk : ktv) >= NT) continue;          // nothing left to fetch for this half
-            float* base = smem + (q < 12 ? kbuf : vbuf) * AX_STAGE_FLOATS;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(base + q * 256), 16, 0, 0);
+        for (int p = 0; p < 3; ++p) {
+            const char* ks = kbase + ((size_t)p * plane_qk * 2 + (size_t)kt * (AX_KT * VN_DHEAD * 2));
+            const char* vs = vbase + ((size_t)p * plane_vt * 2 + (size_t)kt * (VN_DHEAD * AX_KT * 2));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ks + kvoff),
+                                             (__attribute__((address_space(3))) void*)(base + (4 * p) * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vs + vvoff),
+                                             (__attribute__((address_space(3))) void*)(base + (12 + 4 * p) * 256), 16, 0, 0);
         }
     };
 
@@ -156,7 +158,8 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
         float mx = -INFINITY;
         const int key0 = (g_lo + kt) * AX_KT - m_lo;                   // key index of the tile's first row
         const float* brow = bt + (key0 + 8 * hh - qrow_c + (T - 1));   // bias of key key0 + 8 hh for this query
-        if (key0 >= 0 && key0 + AX_KT <= T) {                          // every key of the tile belongs to this item
+        const bool full = key0 >= 0 && key0 + AX_KT <= T;              // every key of the tile belongs to this item (uniform)
+        if (full) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float x = sacc[r] + brow[16 * (r >> 3) + (r & 7)];   // q was pre-scaled by 1/sqrt(64); += bias
@@ -178,17 +181,21 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
         const float m_new = fmaxf(m_run, mx);                          // finite: every tile has >= 1 valid key
         const float alpha = vn_exp_neg(m_run - m_new);                 // first tile: exp(-inf) = 0
         float lsum = 0.f;
+        auto probs = [&](auto finite) {        // a full tile has no -inf score: exp without the clamp (same value for finite arguments)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            f32x8 pe;
+            for (int s = 0; s < 2; ++s) {
+                f32x8 pe;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                pe[e] = (ABL & 1) ? sacc[8 * s + e] - m_new : vn_exp_neg(sacc[8 * s + e] - m_new);
-                lsum += pe[e];
+                for (int e = 0; e < 8; ++e) {
+                    pe[e] = (ABL & 1) ? sacc[8 * s + e] - m_new : vn_exp_neg<decltype(finite)::value>(sacc[8 * s + e] - m_new);
+                    lsum += pe[e];
+                }
+                if constexpr (ABL & 1) pf[0][s] = pf[1][s] = pf[2][s] = __builtin_convertvector(pe, bf16x8);
+                else vn_split3_x8(pe, pf[0][s], pf[1][s], pf[2][s]);
             }
-            if constexpr (ABL & 1) pf[0][s] = pf[1][s] = pf[2][s] = __builtin_convertvector(pe, bf16x8);
-            else vn_split3_x8(pe, pf[0][s], pf[1][s], pf[2][s]);
-        }
+        };
+        if (full) probs(std::true_type{});
+        else probs(std::false_type{});
         l_run = l_run * alpha + lsum;
         m_run = m_new;
         if (!__all(alpha == 1.0f)) {                                   // exp(0) = 1 exactly: skipping the multiply changes no bit
@@ -242,13 +249,13 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
         }
     };
     if constexpr (ABL & 16) { tr_t = tr_start = __builtin_readcyclecounter(); }
-    stage(0, 0, 0, 0);
+    stage(0, 0);
     for (int kt = 0; kt < NT; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of tile kt have landed
         tick(0);
         __syncthreads();                                        // all pieces landed; everybody is done with tile kt - 1
         tick(1);
-        stage((kt + 1) & 1, kt + 1, (kt + 1) & 1, kt + 1);
+        stage((kt + 1) & 1, kt + 1);
         tick(2);
         if (!active) continue;
         qk_phase(kt & 1);

@@ -85,8 +85,10 @@ __device__ __forceinline__ float vn_gelu_tanh(float x) {
 // exp(x) for x <= 0 with fp32-level accuracy at a third of ocml expf's instruction count: x*log2(e) is split into a
 // rounded product and its exact fma remainder (plus the constant's low part), v_exp_f32 evaluates 2^hi (1 ulp) and the
 // remainder is applied to first order (|lo| < 2^-22, so the dropped term is < 2^-45 relative).
+template <bool FINITE = false>
 __device__ __forceinline__ float vn_exp_neg(float x) {
-    x = fmaxf(x, -104.0f);                                     // -inf (masked key / first tile) -> exp2(-150) = 0, no NaN
+    if constexpr (!FINITE) x = fmaxf(x, -104.0f);              // -inf (masked key / first tile) -> exp2(-150) = 0, no NaN
+    // FINITE: the caller guarantees x > -inf (then hi, lo are finite whatever x is and exp2 flushes to 0 by itself)
     const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f;
     const float hi = x * L2E_HI;
     const float lo = fmaf(x, L2E_HI, -hi) + x * L2E_LO;
