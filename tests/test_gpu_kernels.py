@@ -36,10 +36,11 @@ def test_splitk_reduce_rmsnorm_fused_vs_two_kernels(eng, rows, D, ns):
     reduce kernel followed by the norm kernel: x and the three y planes bitwise; and against torch within fp32 rounding."""
     part, x0, w = _rand((ns, rows, D), 11, 0.7), _rand((rows, D), 12, 2.0), 1 + _rand((D,), 13, 0.1)
     outs = []
+    part_d, w_d = part.cuda(), w.cuda()             # keep the device copies alive across the launches
     for fused in (1, 0):
         x = x0.cuda().clone()
         y16 = torch.zeros(3, rows, D, dtype=torch.bfloat16, device="cuda")
-        eng.check(eng.lib.vn_debug_splitk_reduce_rmsnorm(eng.handle, part.cuda().data_ptr(), ns, x.data_ptr(), w.cuda().data_ptr(),
+        eng.check(eng.lib.vn_debug_splitk_reduce_rmsnorm(eng.handle, part_d.data_ptr(), ns, x.data_ptr(), w_d.data_ptr(),
                                                          y16.data_ptr(), rows * D, rows, D, 1e-6, fused, eng.stream()), "reduce_rmsnorm")
         outs.append((x.cpu(), y16.cpu()))
     (xf, yf), (xs, ys) = outs

@@ -6,14 +6,19 @@
 // One 64-lane wave per row, float4 loads (coalesced 1 KiB per wave instruction), shuffle reduce.
 // Algorithmic bytes: 8*D per row (read x, write y) + D*4 weights (L2 resident).
 // ---------------------------------------------------------------------------------------------
-// the row math shared by the stand-alone kernel and the fused split-K reduce below (one expression tree -> the same contraction
-// into FMAs in both, so the two paths are bitwise equal): v = the lane's VEC float4 of row `row` (element 4 (lane + 64 i) + e)
+// the row math shared by the stand-alone kernel and the fused split-K reduce below (explicit fma chain for the sum of squares, no
+// other contractible expression: the two paths are bitwise equal, tests/test_gpu_kernels.py): v = the lane's VEC float4 of row `row` (element 4 (lane + 64 i) + e)
 template <int VEC>
 __device__ __forceinline__ void vn_rmsnorm_row(const f32x4 (&v)[VEC], const float* __restrict__ w, float* __restrict__ y,
                                                uint16_t* __restrict__ y16, long plane16, int row, int D, float eps, int lane) {
-    float ss = 0.f;
+    float ss = 0.f;           // explicit fma chain: nothing is left to the compiler's contraction choices, which differ between kernels
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    for (int i = 0; i < VEC; ++i) {
+        ss = fmaf(v[i][0], v[i][0], ss);
+        ss = fmaf(v[i][1], v[i][1], ss);
+        ss = fmaf(v[i][2], v[i][2], ss);
+        ss = fmaf(v[i][3], v[i][3], ss);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     const float rstd = 1.0f / sqrtf(ss / (float)D + eps);   // exact div+sqrt == torch.rsqrt on CPU

@@ -587,7 +587,9 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
             q.C = ctx->x3_ws;
             q.ldc = a.N;
             rc = x3_go_bm<VN_EPI_STORE>(ctx, q, ns, bm, s);
-            if (EPI == VN_EPI_RESIDUAL && x3_norm_fusable(a)) {
+            // while launches are being event-bracketed (pi >= 0) the two-kernel form runs, so that the GEMM's bracket holds the GEMM's
+            // own work (split images + reduce) and nothing of the norm — the bitwise same result (tests/test_gpu_kernels.py)
+            if (EPI == VN_EPI_RESIDUAL && x3_norm_fusable(a) && pi < 0) {
                 if (rc == VN_OK)
                     rc = vn_launch_splitk_reduce_rmsnorm(ctx, ctx->x3_ws, ns, a.C, a.norm_w, a.norm_y, a.norm_y16, a.norm_plane, a.M, a.N,
                                                          a.norm_eps, s);
