@@ -35,9 +35,8 @@ H = 20
 QUICK = os.environ.get("ATTN_PROBE_QUICK") == "1"
 for (B, T) in ([(8, 575), (32, 173), (2, 575)] if QUICK else [(8, 575), (4, 575), (2, 575), (32, 173)]):
     fl = 4.0 * T * T * 64 * H * B
-    variants = [("pipelined (2 blocks/CU)", dict(abl=32)), ("pipelined, 1 block/CU", dict(abl=32, lds=90 * 1024)),
-                ("plain loop, 3 blocks/CU", dict(abl=64)), ("plain loop, 2 blocks/CU", dict(abl=64, lds=60 * 1024)),
-                ("plain loop, 1 block/CU", dict(abl=64, lds=90 * 1024)), ("plain loop, no setprio", dict(abl=8))]
+    variants = [("3 blocks/CU (shipped)", {}), ("2 blocks/CU", dict(lds=60 * 1024)), ("1 block/CU", dict(lds=90 * 1024)),
+                ("with s_setprio 1 around the MFMA phases", dict(abl=8))]
     if not QUICK:
         variants += [("no setprio, 2/CU", dict(abl=8, lds=60 * 1024))] + \
                     [(f"stagger {s} x 64 cyc", dict(stagger=s)) for s in (4, 8, 16, 24, 32, 48, 64)] + \

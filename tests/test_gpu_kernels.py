@@ -125,25 +125,6 @@ def test_attention(eng, B, H, T, precision):
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-5, atol=3e-6)
 
 
-@pytest.mark.parametrize("B,H,T", [(1, 20, 575), (8, 2, 575), (2, 20, 173), (3, 4, 64), (2, 2, 1), (1, 3, 65), (2, 1, 600), (1, 2, 32),
-                                   (1, 1, 33), (1, 2, 129), (1, 1, 97), (5, 3, 200)])
-def test_attention_bf16x3_pipelined_equals_plain_loop(eng, B, H, T):
-    """The software-pipelined main loop of attention_x3.hip (S of the next tile and half of PV beside the softmax's VALU work) does
-    the plain loop's arithmetic in the plain loop's order: outputs bitwise equal, at sequence ends on every tile / block position."""
-    q, k, v = _rand((B, H, T, 64), 20), _rand((B, H, T, 64), 21), _rand((B, H, T, 64), 22)
-    k[0, 0, T // 2] = q[0, 0, 0] * 4.0                      # a late running-max jump for one query
-    table = _rand((32, H), 23)
-    outs = []
-    try:
-        for abl in (32, 64):                                # 32 = pipelined, 64 = plain loop
-            eng.lib.vn_debug_attention_x3_config(abl, 0, 0, None)
-            outs.append(eng.attention(q.cuda(), k.cuda(), v.cuda(), table.cuda(), precision="bf16x3").cpu())
-    finally:
-        eng.lib.vn_debug_attention_x3_config(-1, 0, -1, None)
-    assert torch.equal(outs[0], outs[1])
-    np.testing.assert_allclose(outs[0].numpy(), _attention_ref(q, k, v, table).numpy(), rtol=2e-5, atol=3e-6)
-
-
 def test_attention_bf16x3_forced_rescale_and_large_scores(eng):
     """online-softmax edge cases of attention_x3.hip against float64: a key late in the sequence that dominates one query
     (running max jumps at the last tiles: every earlier partial sum is rescaled by ~e^-40), scores of large magnitude, and

@@ -38,17 +38,26 @@
 __device__ __forceinline__ int ax_swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
 // ABL (tuning only): bit 0 = no exp / split (P = bf16(S) in all planes), bit 1 = no S^T MFMAs, bit 2 = no O^T MFMAs (results invalid
-// with bits 0-2); bit 3 = no s_setprio around the MFMA phases; bit 4 = phase trace: wave 0 of every 16th block accumulates
+// with bits 0-2); bit 3 = s_setprio 1 around the MFMA phases (off by default: 110.7 vs 112.5 us at B = 8); bit 4 = phase trace: wave 0 of every 16th block accumulates
 // s_memtime deltas per phase over its tiles into trace[block / 16][8] = {wait, barrier, dma issue, qk, softmax, pv, total, hw_id}.
 // stagger (any variant): a block whose waves sit in SIMD wave slot w starts (w % 3) * stagger * 64 cycles late, so that the blocks
 // sharing a CU do not run the same phase at the same time.
 // (Tried and dropped, profiles/r02_attention_x3_phase_order_ab.txt: one VALU phase + one 48-MFMA phase per tile with K staged a
-// tile ahead of V^T — 125 vs 119 us; six- and two-wave blocks; see also r02_attention_x3_kernel_times.txt.)
-template <int NW, int ABL, bool PIPE>
-__device__ __forceinline__ void ax_body(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16, long plane_qk,
-                                        const uint16_t* __restrict__ vt16, long plane_vt, const float* __restrict__ bias_full,
-                                        float* __restrict__ out, uint16_t* __restrict__ out16, long plane16, int B, int H, int T,
-                                        int stagger, unsigned* __restrict__ trace) {
+// tile ahead of V^T — 125 vs 119 us; six- and two-wave blocks; see also r02_attention_x3_kernel_times.txt.
+// Round 2, second half (profiles/r02_attention_x3_probe_*.txt, r02_ubench_mfma_valu_coissue.txt): the phase trace shows a tile
+// costing one wave ~4500 cycles alone (MFMA 1536, ~280 VALU instructions ~1400, LDS / DMA / barrier waits the rest) and ~7400 with
+// three blocks per CU, i.e. the matrix pipe and the VALU are about equally loaded and overlap only partly — the micro-benchmark
+// puts the overlap the hardware gives at <= 4 plain VALU instructions per MFMA and wave for free, ~5 cycles each beyond that.
+// A software-pipelined main loop (S of the next tile and half of PV in the same basic block as the softmax, bitwise equal to
+// this loop, commit 491c2d5) ran 115.5 vs 112.5 us at two blocks per CU (256 VGPRs) and was removed; start staggers by SIMD wave
+// slot change nothing (117.8-118.9 vs 119.9 us); 2 blocks per CU 114.8, 1 block 145 us.  What did pay: DMA sources as a uniform tile
+// base + a fixed per-lane offset (-5 %), no s_setprio (-1.6 %).)
+template <int NW, int ABL = 0>
+__global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
+                                                                    long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
+                                                                    const float* __restrict__ bias_full, float* __restrict__ out,
+                                                                    uint16_t* __restrict__ out16, long plane16, int B, int H, int T,
+                                                                    int stagger, unsigned* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* bt = smem + 2 * AX_STAGE_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -132,7 +141,7 @@ __device__ __forceinline__ void ax_body(const uint16_t* __restrict__ q16, const 
         const float* Ks = smem + kb * AX_STAGE_FLOATS;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);
+        if constexpr (ABL & 8) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             bf16x8 kf[3];
@@ -150,7 +159,7 @@ __device__ __forceinline__ void ax_body(const uint16_t* __restrict__ q16, const 
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][s], sacc, 0, 0, 0);
             }
         }
-        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
+        if constexpr (ABL & 8) __builtin_amdgcn_s_setprio(0);
     };
     // ---- online softmax of tile kt (scores in sacc): P planes -> pf, running max / sum, O rescaled
     auto softmax_phase = [&](int kt) {
@@ -207,7 +216,7 @@ __device__ __forceinline__ void ax_body(const uint16_t* __restrict__ q16, const 
     // ---- O^T += V^T . P^T for the tile in stage `vb`: two 32-row d tiles x two 16-key steps x six plane products
     auto pv_phase = [&](int vb) {
         const float* Vs = smem + vb * AX_STAGE_FLOATS + 3 * AX_PLANE_FLOATS;
-        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);
+        if constexpr (ABL & 8) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -227,7 +236,7 @@ __device__ __forceinline__ void ax_body(const uint16_t* __restrict__ q16, const 
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[0][s], o[dt], 0, 0, 0);
                 }
             }
-        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
+        if constexpr (ABL & 8) __builtin_amdgcn_s_setprio(0);
     };
 
     if (stagger > 0) {                                      // de-phase the blocks that share this CU
@@ -248,139 +257,6 @@ __device__ __forceinline__ void ax_body(const uint16_t* __restrict__ q16, const 
         }
     };
     if constexpr (ABL & 16) { tr_t = tr_start = __builtin_readcyclecounter(); }
-    if constexpr (PIPE) {
-        // ---- software pipeline over the key tiles: while the VALU runs the softmax of tile i (~300 instructions), the matrix pipe
-        // runs S(i+1) = K(i+1) Q^T (independent of it), then the first half of O += V^T(i) P(i) beside the second half of the
-        // exponentials — so ONE wave keeps both pipes busy.  (The plain loop below runs QK, softmax and PV back to back: each pipe
-        // idles while the other works, and three co-resident blocks recover only part of it — profiles/r02_attention_x3_probe.txt.)
-        // The arithmetic per element is the plain loop's, in the same order: the two forms are bitwise equal (tests/test_gpu_kernels.py).
-        // Stage j & 1 holds K(j) and V^T(j); iteration i reads K(i+1) and V^T(i) and issues the DMA of K(i+2) and V^T(i+1).
-        f32x16 sA, sB;
-        auto dma = [&](int kt, bool want_k, bool want_v) {      // tile kt -> stage kt & 1 (K and / or V^T half)
-            if (kt >= NT) return;
-            float* base = smem + (kt & 1) * AX_STAGE_FLOATS + wave * 256;
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                if (want_k) {
-                    const char* ks = kbase + ((size_t)p * plane_qk * 2 + (size_t)kt * (AX_KT * VN_DHEAD * 2));
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ks + kvoff),
-                                                     (__attribute__((address_space(3))) void*)(base + (4 * p) * 256), 16, 0, 0);
-                }
-                if (want_v) {
-                    const char* vs = vbase + ((size_t)p * plane_vt * 2 + (size_t)kt * (VN_DHEAD * AX_KT * 2));
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vs + vvoff),
-                                                     (__attribute__((address_space(3))) void*)(base + (12 + 4 * p) * 256), 16, 0, 0);
-                }
-            }
-        };
-        constexpr int QA[6] = {0, 2, 1, 0, 1, 0}, QB[6] = {2, 0, 1, 1, 0, 0};               // plane pairs, smallest terms first
-        // one iteration as ONE basic block (no branch inside): the compiler's scheduler interleaves the three streams
-        auto iter = [&](auto qk_c, auto masked_c, int i, f32x16& s_cur, f32x16& s_nxt) {
-            constexpr bool DO_QK = decltype(qk_c)::value, MASKED = decltype(masked_c)::value;
-            const float* Ks = smem + ((i + 1) & 1) * AX_STAGE_FLOATS;
-            const float* Vs = smem + (i & 1) * AX_STAGE_FLOATS + 3 * AX_PLANE_FLOATS;
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- matrix pipe: S(i+1)
-            if constexpr (DO_QK) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s_nxt[r] = 0.f;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    bf16x8 kf[3];
-#pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        kf[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Ks + p * AX_PLANE_FLOATS + kOff + ((2 * s + hh) ^ kSw) * 4));
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) s_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[QA[t]], qf[QB[t]][s], s_nxt, 0, 0, 0);
-                }
-            }
-            // ---- VALU: scores + bias, running max, rescale factor
-            float mx = -INFINITY;
-            const int key0 = (g_lo + i) * AX_KT - m_lo;
-            if constexpr (!MASKED) {
-                const float* brow = bt + (key0 + 8 * hh - qrow_c + (T - 1));
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float x = s_cur[r] + brow[16 * (r >> 3) + (r & 7)];
-                    s_cur[r] = x;
-                    mx = fmaxf(mx, x);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = key0 + 16 * (r >> 3) + 8 * hh + (r & 7);
-                    const int key_c = key < 0 ? 0 : (key < T ? key : T - 1);
-                    float x = s_cur[r] + bt[key_c - qrow_c + (T - 1)];
-                    x = (key >= 0 && key < T) ? x : -INFINITY;
-                    s_cur[r] = x;
-                    mx = fmaxf(mx, x);
-                }
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = vn_exp_neg(m_run - m_new);
-            // O of the tiles before this one (x 1.0 is exact: the plain loop skips the multiply then, same bits)
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-            // ---- per 16-key step: probabilities (VALU), then their six plane products into both O chains (matrix pipe)
-            float lsum = 0.f;
-#pragma unroll
-            for (int sv = 0; sv < 2; ++sv) {
-                f32x8 pe;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    pe[e] = vn_exp_neg<!MASKED>(s_cur[8 * sv + e] - m_new);
-                    lsum += pe[e];
-                }
-                bf16x8 pp[3];
-                vn_split3_x8(pe, pp[0], pp[1], pp[2]);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    bf16x8 vf[3];
-#pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        vf[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Vs + p * AX_PLANE_FLOATS + (32 * dt + l31) * 16 + ((2 * sv + hh) ^ vSw) * 4));
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[QA[t]], pp[QB[t]], o[dt], 0, 0, 0);
-                }
-            }
-            l_run = l_run * alpha + lsum;
-            m_run = m_new;
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto dispatch = [&](int i, f32x16& s_cur, f32x16& s_nxt) {
-            const int key0 = (g_lo + i) * AX_KT - m_lo;
-            const bool full = key0 >= 0 && key0 + AX_KT <= T;
-            using Tt = std::true_type;
-            using Ft = std::false_type;
-            if (i + 1 < NT) {
-                if (full) iter(Tt{}, Ft{}, i, s_cur, s_nxt);
-                else iter(Tt{}, Tt{}, i, s_cur, s_nxt);
-            } else {
-                if (full) iter(Ft{}, Ft{}, i, s_cur, s_nxt);
-                else iter(Ft{}, Tt{}, i, s_cur, s_nxt);
-            }
-        };
-        dma(0, true, true);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        dma(1, true, false);                                    // K(1) in flight while S(0) = K(0) Q^T
-        if (active) {
-            qk_phase(0);
-            sA = sacc;
-        }
-        for (int i = 0; i < NT; ++i) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of K(i+1) / V^T(i) have landed
-            __syncthreads();                                    // ... everybody's; and everybody is done with iteration i - 1
-            dma(i + 2, true, false);
-            dma(i + 1, false, true);
-            if (!active) continue;
-            if (i & 1) dispatch(i, sB, sA);
-            else dispatch(i, sA, sB);
-        }
-    } else {
     stage(0, 0);
     for (int kt = 0; kt < NT; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of tile kt have landed
@@ -396,7 +272,6 @@ __device__ __forceinline__ void ax_body(const uint16_t* __restrict__ q16, const 
         tick(4);
         pv_phase(kt & 1);
         tick(5);
-    }
     }
     if constexpr (ABL & 16) {
         if (tracing && lane == 0) {
@@ -428,24 +303,6 @@ __device__ __forceinline__ void ax_body(const uint16_t* __restrict__ q16, const 
     }
 }
 
-template <int NW, int ABL = 0>
-__global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
-                                                                    long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
-                                                                    const float* __restrict__ bias_full, float* __restrict__ out,
-                                                                    uint16_t* __restrict__ out16, long plane16, int B, int H, int T,
-                                                                    int stagger, unsigned* __restrict__ trace) {
-    ax_body<NW, ABL, false>(q16, k16, plane_qk, vt16, plane_vt, bias_full, out, out16, plane16, B, H, T, stagger, trace);
-}
-// the software-pipelined form (two waves per SIMD: the second set of score / probability registers)
-template <int NW, int ABL = 0>
-__global__ __launch_bounds__(NW * 64, 2) void vn_attention_x3p_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
-                                                                     long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
-                                                                     const float* __restrict__ bias_full, float* __restrict__ out,
-                                                                     uint16_t* __restrict__ out16, long plane16, int B, int H, int T,
-                                                                     int stagger, unsigned* __restrict__ trace) {
-    ax_body<NW, ABL, true>(q16, k16, plane_qk, vt16, plane_vt, bias_full, out, out16, plane16, B, H, T, stagger, trace);
-}
-
 // tuning hooks (process-global; scripts/attn_probe.py): ablation / variant bits, dynamic-LDS override (occupancy: > 80 KiB = one block
 // per CU, > 53.3 KiB = two), start stagger, phase-trace buffer
 static int g_ax_abl = -1, g_ax_lds = 0, g_ax_stagger = -1;
@@ -468,28 +325,18 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3p_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->attr_mask |= VN_ATTR_ATTN_X3;
     }
     const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
     // four waves (128 queries) per block, three blocks per CU (LDS: 2 x 24 KiB stages + the bias table; 168 VGPRs).  Measured
     // alternatives (profiles/r02_attention_x3_kernel_times.txt): six waves (one round of 480 blocks at B = 8) 119 vs 112 us,
     // two waves no better at any batch size.
-    static const int abl_env = [] { const char* e = getenv("VN_ATTN_X3_ABL"); return e ? atoi(e) & 127 : 0; }();   // tuning only
+    static const int abl_env = [] { const char* e = getenv("VN_ATTN_X3_ABL"); return e ? atoi(e) & 31 : 0; }();   // tuning only
     static const int stagger_env = [] { const char* e = getenv("VN_ATTN_X3_STAGGER"); return e ? atoi(e) : 0; }();
     const int abl = g_ax_abl >= 0 ? g_ax_abl : abl_env;
     const int stagger = g_ax_stagger >= 0 ? g_ax_stagger : stagger_env;
 #define AX_GO(A) hipLaunchKernelGGL((vn_attention_x3_kernel<4, A>), dim3(vn_cdiv(T, 128) * H * B), dim3(256), lds, s, q16, k16, plane_qk, vt16, \
                                     plane_vt, relbias_full, out, out16, plane16, B, H, T, stagger, g_ax_trace)
-    static const int pipe_env = [] { const char* e = getenv("VN_ATTN_X3_PIPE"); return e ? atoi(e) : 1; }();
-    const bool pipe = abl == 32 || (abl == 0 && pipe_env != 0);        // abl 64: the plain loop (A/B against the pipelined form)
-    if (pipe) {
-        hipLaunchKernelGGL((vn_attention_x3p_kernel<4, 0>), dim3(vn_cdiv(T, 128) * H * B), dim3(256), lds, s, q16, k16, plane_qk, vt16, plane_vt,
-                           relbias_full, out, out16, plane16, B, H, T, stagger, g_ax_trace);
-        vn_prof_post(ctx, pi, s);
-        VN_LAUNCH_CHECK(ctx);
-        return VN_OK;
-    }
     switch (abl) {
         case 1: AX_GO(1); break;
         case 6: AX_GO(6); break;
