@@ -44,12 +44,20 @@ template <int N, int DEP, int KIND>
 static void run(int threads, const char* kind) {
     float* out; unsigned long long* cyc;
     hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 8);
-    const int iters = 2000;
+    const int iters = 20000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL((k<N, DEP, KIND>), dim3(256), dim3(threads), 0, 0, out, cyc, iters);
+    hipEventRecord(e0, 0);
     hipLaunchKernelGGL((k<N, DEP, KIND>), dim3(256), dim3(threads), 0, 0, out, cyc, iters);
+    hipEventRecord(e1, 0);
     hipDeviceSynchronize();
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
     unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-    printf("waves/SIMD %d  %-10s dep %d  VALU per MFMA %2d : %6.1f cycles per (MFMA + VALU group)\n", threads / 256, kind, DEP, N, (double)c / (iters * 4.0));
+    const double nm = iters * 4.0, waves = 256.0 * threads / 64;
+    printf("waves/SIMD %d  %-10s dep %d  VALU per MFMA %2d : %6.1f s_memtime ticks per (MFMA + VALU group) per wave; kernel %.3f ms -> %.0f TF bf16, "
+           "%.2f ns per tick\n", threads / 256, kind, DEP, N, (double)c / nm, ms, waves * nm * 32768.0 / (ms * 1e-3) / 1e12, ms * 1e6 / (double)c);
     hipFree(out); hipFree(cyc);
 }
 #define SWEEP(DEP, KIND, NAME) \

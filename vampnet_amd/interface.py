@@ -137,7 +137,7 @@ class Interface:
         self.beat_tracker = None
         # build_mask on the GPU (draws included, RNG-exact: masks.build_mask_device) instead of the host twin of vampnet/mask.py;
         # both give the same mask and leave torch's CPU generator at the same position
-        self.mask_on_device = os.environ.get("VN_MASK_ON_DEVICE", "0") != "0"
+        self.mask_on_device = os.environ.get("VN_MASK_ON_DEVICE", "1") != "0"     # VN_MASK_ON_DEVICE=0: the host twin (A/B)
         self.rng = rng
         self.max_batch = max_batch
         self.pg = process_group
