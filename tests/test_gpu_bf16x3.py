@@ -122,3 +122,34 @@ def test_fused_splitk_reduce_rmsnorm_is_bitwise_the_two_kernel_form(eng, dims, T
     finally:
         lib.vn_debug_x3_config(0, -1, -1)
     assert (got - ref).abs().max().item() <= TM.LOGIT_ATOL_TINY
+
+
+@pytest.mark.parametrize("dims,B,T", [(W.TINY_COARSE_DIMS, 3, 200), (W.TINY_C2F_DIMS, 2, 173), (W.TINY_COARSE_DIMS, 1, 33)])
+def test_split_plane_attention_path_at_every_tile_height(eng, dims, B, T):
+    """The QKV GEMM with the plane epilogue (q x 1/8 and k planes head-major, V^T transposed through the LDS image into the blocked
+    layout) + attention_x3.hip, forced on for a small model, at the three tile heights of gemm_x3.hip (192 rows: 2 x 4 wave
+    grid, 64-row epilogue images): logits bitwise equal across the heights, equal to the oracle at the tiny-model tolerance, and
+    within fp32 noise of the fp32-attention path."""
+    from vampnet_amd.engine import VampNetModel
+    cb = W.synth_codebooks()
+    sd = W.synth_state_dict(dims, 4)
+    m = VampNetModel(eng, sd, cb, max_batch=4, max_T=256, precision="bf16x3", **model_kwargs(dims))
+    codes = W.synth_codes(B, dims["n_codebooks"], T, seed=6)
+    codes[:, dims["n_cond"]:, ::2] = 1024
+    lib = eng.lib
+    outs = {}
+    try:
+        lib.vn_debug_attention_x3_force(1)
+        for bm in (128, 192, 256):
+            lib.vn_debug_x3_config(bm, -1, -1)
+            outs[bm] = m.forward_codes(codes).clone()
+        lib.vn_debug_attention_x3_force(0)
+        lib.vn_debug_x3_config(0, -1, -1)
+        plain = m.forward_codes(codes).clone()
+    finally:
+        lib.vn_debug_attention_x3_force(-1)
+        lib.vn_debug_x3_config(0, -1, -1)
+    assert torch.equal(outs[128], outs[192]) and torch.equal(outs[128], outs[256])
+    ref = O.forward(sd, dims, O.from_codes(sd, cb, codes))
+    assert (outs[192].cpu() - ref).abs().max().item() <= TM.LOGIT_ATOL_TINY
+    assert (outs[192] - plain).abs().max().item() <= TM.LOGIT_ATOL_TINY

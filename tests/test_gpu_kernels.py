@@ -368,16 +368,16 @@ def test_split3_is_exact(eng):
     assert torch.equal(p[0], x.to(torch.bfloat16).float())          # plane 0 = RNE bf16 of x (== torch's cast)
 
 
-X3_CONFIGS = [128, 256, 0]
+X3_CONFIGS = [128, 192, 256, 0]
 
 
 def _x3_cfg(eng, bm=0, split=-1, abl=-1):
     eng.check(eng.lib.vn_debug_x3_config(bm, split, abl), "vn_debug_x3_config")
 
 
-@pytest.fixture(params=X3_CONFIGS, ids=["bm128", "bm256", "auto"])
+@pytest.fixture(params=X3_CONFIGS, ids=["bm128", "bm192", "bm256", "auto"])
 def x3_pipe(eng, request):
-    """both tile heights of gemm_x3.hip (and the by-shape default) through the same bodies (process-global tuning hook; reset afterwards)"""
+    """the three tile heights of gemm_x3.hip (and the by-shape default) through the same bodies (process-global tuning hook; reset afterwards)"""
     _x3_cfg(eng, request.param)
     yield request.param
     _x3_cfg(eng)
@@ -409,7 +409,7 @@ def test_gemm_bf16x3_fp32_grade(eng, x3_pipe, M, N, K):
 
 
 def test_gemm_bf16x3_tiles_agree_bitwise_and_are_race_free(eng):
-    """Both tile heights add the same products in the same order: bitwise-equal outputs, through the direct and the LDS-staged
+    """All tile heights add the same products in the same order: bitwise-equal outputs, through the direct and the LDS-staged
     epilogue alike; 20 back-to-back launches of each under a concurrently streaming kernel reproduce the same bits (LDS-DMA /
     barrier protocol of the ping-pong schedule, LDS image of the staged epilogue)."""
     M, N, K = 4600, 3840, 1280
@@ -417,7 +417,7 @@ def test_gemm_bf16x3_tiles_agree_bitwise_and_are_race_free(eng):
     outs = {}
     junk = torch.empty(64 << 20, device="cuda")
     side = torch.cuda.Stream()
-    for bm in (128, 256):
+    for bm in (128, 192, 256):
         _x3_cfg(eng, bm, 1)
         outs[bm] = eng.gemm_bf16x3(a3, w3).clone()
         for it in range(20):
@@ -427,7 +427,7 @@ def test_gemm_bf16x3_tiles_agree_bitwise_and_are_race_free(eng):
             assert torch.equal(again, outs[bm]), (bm, it)
     _x3_cfg(eng)
     torch.cuda.synchronize()
-    assert torch.equal(outs[128], outs[256])
+    assert torch.equal(outs[128], outs[256]) and torch.equal(outs[128], outs[192])
     odd = torch.empty(M * N + 1, device="cuda")[1:].view(M, N)       # base 4 bytes off a 16-byte boundary -> the direct epilogue
     eng.gemm_bf16x3(a3, w3, out=odd)
     assert torch.equal(odd, outs[128])

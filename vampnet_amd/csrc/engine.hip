@@ -235,6 +235,11 @@ int vn_model_ensure_bias(vn_model* m, int T, hipStream_t s) {
     return rc;
 }
 
+// test hook (process-global): 1 / 0 = bf16x3 models use / do not use the split-plane attention path (QKV3 epilogue + attention_x3.hip)
+// whatever the batch size, -1 = by occupancy (VN_ATTN_X3 / default)
+static int g_attn_x3_force = -1;
+extern "C" int vn_debug_attention_x3_force(int on) { g_attn_x3_force = on < 0 ? -1 : (on != 0); return VN_OK; }
+
 // forward on the int32 token buffer m->z -> m->logits   (layers.py:134-163 + transformer.py:617-639)
 static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logits, hipStream_t s) {
     vn_ctx* ctx = m->ctx;
@@ -261,7 +266,8 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
     // bf16x3: attention on the bf16 matrix cores too (attention_x3.hip) once there are enough 128-query blocks to fill the chip
     // (>= 1.5 per CU); below that (one or two sequences) the 64-query blocks of the fp32-input MFMA kernel fill it better
     // (B = 1, coarse: 55.6 vs 57.8 ms per clip, profiles/r02_c10_3_cfg1_*.json).  VN_ATTN_X3 = 0 / 1 forces one of them (A/B runs).
-    static const int attn_x3_env = [] { const char* e = getenv("VN_ATTN_X3"); return e ? atoi(e) : -1; }();
+    static const int attn_x3_envv = [] { const char* e = getenv("VN_ATTN_X3"); return e ? atoi(e) : -1; }();
+    const int attn_x3_env = g_attn_x3_force >= 0 ? g_attn_x3_force : attn_x3_envv;
     static int cus_of[64] = {0};                      // queried once per device, outside any stream capture (first forward is eager)
     int& cus = cus_of[ctx->device & 63];
     if (!cus && (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0)) cus = 256;

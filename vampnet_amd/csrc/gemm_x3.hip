@@ -47,15 +47,24 @@
 #define X3_KT 32                                  // bf16 per k-tile
 #define X3_BPLANE (128 * 16)                      // floats of one W plane tile: 128 rows x 64 B
 
-// Geometry by tile height BM = 128 MI.  A stage = three A plane tiles (BM rows x 64 B) then three W plane tiles.
-template <int MI>
+// Geometry by tile configuration CFG: BM x 128 output tile, eight waves as WR x WC, a wave owns RI x CJ MFMA tiles of 32 x 32.
+//   CFG 1: 128 x 128, waves 4 x 2, wave tile 32 x 64     CFG 2: 256 x 128, waves 4 x 2, wave tile 64 x 64
+//   CFG 3: 192 x 128, waves 2 x 4, wave tile 96 x 32 — the height that fills whole rounds of 256 CUs on the model's shapes at
+//          B = 8 (M = 4600 = 23.96 x 192: QKV 720 tiles = 2.8 rounds, Wo / W2 240 tiles = one round WITHOUT a k-split, classifier
+//          768 tiles = 3.0 rounds) where 128 rows leave the last of 5 / 2 rounds mostly empty and 256 rows quantise worse still.
+// A stage = three A plane tiles (BM rows x 64 B) then three W plane tiles (128 rows x 64 B).
+template <int CFG>
 struct x3_geo {
-    static constexpr int BM = 128 * MI;
+    static constexpr int RI = CFG == 3 ? 3 : CFG, CJ = CFG == 3 ? 1 : 2, WR = CFG == 3 ? 2 : 4, WC = CFG == 3 ? 4 : 2;
+    static constexpr int BM = 32 * RI * WR;
     static constexpr int APLANE = BM * 16;                          // floats
-    static constexpr int STAGE = 3 * (APLANE + X3_BPLANE);          // floats: 48 KiB (MI 1) / 72 KiB (MI 2)
-    static constexpr int NQ = 3 * (BM + 128) / 16;                  // 1 KiB DMA wave-instructions per stage
-    static constexpr int NPW = NQ / 8;                              // per wave: 6 / 9
+    static constexpr int STAGE = 3 * (APLANE + X3_BPLANE);          // floats: 48 / 72 / 60 KiB
+    static constexpr int NQ = 3 * (BM + 128) / 16;                  // 1 KiB DMA wave-instructions per stage: 48 / 72 / 60
+    static constexpr int NPW = (NQ + 7) / 8;                        // per wave: 6 / 9 / 8 (CFG 3: the last one only in waves 0-3)
+    static constexpr int NBUF = CFG == 1 ? 3 : 2;                   // resident stages
+    static constexpr int RP = 32 * WR;                              // rows of one pass of the staged epilogue's LDS image
 };
+static_assert(x3_geo<1>::BM == 128 && x3_geo<2>::BM == 256 && x3_geo<3>::BM == 192, "tile heights");
 
 __device__ __forceinline__ int x3_xcd_remap(int bid, int nwg) {
     const int xcd = bid & 7, idx = bid >> 3;
@@ -85,24 +94,26 @@ __device__ __forceinline__ void x3_tile_coords(int t, int tiles_m, int tiles_n, 
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
 
-// epilogue of one output tile from the accumulators in MFMA layout (shared by the GEMM kernel and the stream-K fix-up).
+// epilogue of one output tile from the accumulators in MFMA layout.
 // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-template <int EPI, int MI>
-__device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 (&acc)[MI][2], int m0, int n0, int wm, int wn,
-                                            int lane) {
+template <int EPI, int CFG>
+__device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 (&acc)[x3_geo<CFG>::RI][x3_geo<CFG>::CJ], int m0, int n0,
+                                            int wm, int wn, int lane) {
+    using G = x3_geo<CFG>;
+    static_assert(EPI != VN_EPI_GEGLU || G::CJ == 2, "GEGLU pairs the wave's two column tiles (value, gate)");
     const int l31 = lane & 31, h = lane >> 5;
-    const int colw = n0 + wn * 64 + l31;
+    const int colw = n0 + wn * 32 * G::CJ + l31;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+    for (int i = 0; i < G::RI; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int row = m0 + wm * 32 * G::RI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (row >= p.M) continue;
             if constexpr (EPI == VN_EPI_GEGLU) {
                 // wave tile = 64 packed columns = 32 value (j = 0) + 32 gate (j = 1), interleaved at pack time
                 const int ocol = (n0 + wn * 64) / 2 + l31;
                 if (2 * ocol >= p.N) continue;
-                const float o = acc[i][0][r] * vn_gelu_tanh(acc[i][1][r]);
+                const float o = acc[i][0][r] * vn_gelu_tanh(acc[i][G::CJ - 1][r]);
                 if (p.C16) {
                     uint16_t t0, t1, t2;
                     vn_split3(o, t0, t1, t2);
@@ -113,7 +124,7 @@ __device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < G::CJ; ++j) {
                     const int col = colw + j * 32;
                     if (col >= p.N) continue;
                     const float v = acc[i][j][r];
@@ -154,95 +165,104 @@ __device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 
 }
 
 // The same epilogues staged through LDS (free after the k-loop): every wave drops its accumulators into a row-major image
-// of 128 tile rows, then all 512 threads read the image back in 16-byte pieces and issue 16-byte global accesses.  The direct
-// epilogue above issues one 2- or 4-byte store per accumulator register (32 per MFMA tile, x3 for split planes), and the store
-// tail of a tile is ISSUE-bound (guide T21): the in-model GEMMs with plane epilogues ran 10-14 % below the fp32-store shapes
-// (profiles/r02_c6_bench_kernel_stats_last_vamp.txt).  One pass per 128-row half of a 256-row tile; every thread of the block must call it.
-//   fp32 kinds (store / bias / residual / QKV scatter): image [128][128] fp32 (64 KiB)
-//   GEGLU planes: image [3][128][64] bf16 (48 KiB);  QKV3 planes: [3][128][128] bf16 (96 KiB) for the q / k tiles, TRANSPOSED
-//   [3][128 columns][136] bf16 (102 KiB) for the v tiles (a tile is all q, all k or all v: D % 128 == 0)
-template <int EPI, int MI>
-__device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const f32x16 (&acc)[MI][2], int m0, int n0, int wave, int lane,
-                                                   float* lds) {
-    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5, tid = wave * 64 + lane;
+// of RP = 32 WR tile rows (the i-th 32-row block of every wave row), then all 512 threads read the image back in 16-byte pieces
+// and issue 16-byte global accesses.  The direct epilogue above issues one 2- or 4-byte store per accumulator register (32 per
+// MFMA tile, x3 for split planes), and the store tail of a tile is ISSUE-bound (guide T21): the in-model GEMMs with plane
+// epilogues ran 10-14 % below the fp32-store shapes (profiles/r02_c6_bench_kernel_stats_last_vamp.txt).  RI passes; every
+// thread of the block must call it.
+//   fp32 kinds (store / bias / residual / QKV scatter): image [RP][128] fp32 (64 / 32 KiB)
+//   GEGLU planes: image [3][RP][64] bf16;  QKV3 planes: [3][RP][128] bf16 for the q / k tiles, TRANSPOSED [3][128 columns][RP + 8]
+//   bf16 for the v tiles (a tile is all q, all k or all v: D % 128 == 0)
+template <int EPI, int CFG>
+__device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const f32x16 (&acc)[x3_geo<CFG>::RI][x3_geo<CFG>::CJ], int m0, int n0,
+                                                   int wave, int lane, float* lds) {
+    using G = x3_geo<CFG>;
+    constexpr int RI = G::RI, CJ = G::CJ, RP = G::RP, VP = RP + 8;          // VP: pitch of the transposed v image
+    static_assert(EPI != VN_EPI_GEGLU || CJ == 2, "GEGLU pairs the wave's two column tiles (value, gate)");
+    const int wm = wave / G::WC, wn = wave % G::WC, l31 = lane & 31, h = lane >> 5, tid = wave * 64 + lane;
     uint16_t* L16 = (uint16_t*)lds;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+    for (int i = 0; i < RI; ++i) {
         __syncthreads();                  // k-loop reads / the previous pass's read-out are done in every wave
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int R = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;                 // image row; tile row = (R >> 5) * 32 MI + 32 i + (R & 31)
+            const int R = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;                 // image row; tile row = (R >> 5) * 32 RI + 32 i + (R & 31)
             if constexpr (EPI == VN_EPI_GEGLU) {
-                const float o = acc[i][0][r] * vn_gelu_tanh(acc[i][1][r]);
+                const float o = acc[i][0][r] * vn_gelu_tanh(acc[i][CJ - 1][r]);
                 uint16_t t0, t1, t2;
                 vn_split3(o, t0, t1, t2);
                 uint16_t* d = L16 + R * 64 + wn * 32 + l31;
-                d[0] = t0; d[128 * 64] = t1; d[2 * 128 * 64] = t2;
+                d[0] = t0; d[RP * 64] = t1; d[2 * RP * 64] = t2;
             } else if constexpr (EPI == VN_EPI_QKV3) {
                 if (n0 < 2 * p.H * VN_DHEAD) {                                      // q / k tile: row-major image
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int c = wn * 64 + j * 32 + l31;
+                    for (int j = 0; j < CJ; ++j) {
+                        const int c = wn * 32 * CJ + j * 32 + l31;
                         uint16_t t0, t1, t2;
                         vn_split3(n0 < p.H * VN_DHEAD ? acc[i][j][r] * 0.125f : acc[i][j][r], t0, t1, t2);      // q: x 1/sqrt(64)
                         uint16_t* d = L16 + R * 128 + c;
-                        d[0] = t0; d[128 * 128] = t1; d[2 * 128 * 128] = t2;
+                        d[0] = t0; d[RP * 128] = t1; d[2 * RP * 128] = t2;
                     }
-                } else if ((r & 3) == 0) {                                          // v tile: transposed image [column][row], pitch 136
+                } else if ((r & 3) == 0) {                                          // v tile: transposed image [column][row], pitch VP
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int c = wn * 64 + j * 32 + l31;
+                    for (int j = 0; j < CJ; ++j) {
+                        const int c = wn * 32 * CJ + j * 32 + l31;
                         uint16_t t[3][4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) vn_split3(acc[i][j][r + e], t[0][e], t[1][e], t[2][e]);
 #pragma unroll
                         for (int q = 0; q < 3; ++q) {
                             uint2 pk = {t[q][0] | ((unsigned)t[q][1] << 16), t[q][2] | ((unsigned)t[q][3] << 16)};
-                            *(uint2*)(L16 + q * (128 * 136) + c * 136 + R) = pk;    // rows R .. R + 3 (r & 3 = 0 .. 3)
+                            *(uint2*)(L16 + q * (128 * VP) + c * VP + R) = pk;      // rows R .. R + 3 (r & 3 = 0 .. 3)
                         }
                     }
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) lds[R * 128 + wn * 64 + j * 32 + l31] = acc[i][j][r];
+                for (int j = 0; j < CJ; ++j) lds[R * 128 + wn * 32 * CJ + j * 32 + l31] = acc[i][j][r];
             }
         }
         __syncthreads();
         if constexpr (EPI == VN_EPI_GEGLU) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {                                           // 3 planes x 128 rows x 8 pieces of 8 columns
+            for (int k = 0; k < 3 * RP * 8 / 512; ++k) {                            // 3 planes x RP rows x 8 pieces of 8 columns
                 const int idx = tid + 512 * k;
-                const int q = idx >> 10, R = (idx >> 3) & 127, c8 = (idx & 7) * 8;
-                const int row = m0 + (R >> 5) * 32 * MI + 32 * i + (R & 31), ocol = n0 / 2 + c8;
+                const int q = idx / (RP * 8), R = (idx >> 3) % RP, c8 = (idx & 7) * 8;
+                const int row = m0 + (R >> 5) * 32 * RI + 32 * i + (R & 31), ocol = n0 / 2 + c8;
                 if (row < p.M && 2 * ocol < p.N)
-                    *(u32x4*)(p.C16 + (size_t)q * p.c_plane + (size_t)row * p.ldc + ocol) = *(const u32x4*)(L16 + q * (128 * 64) + R * 64 + c8);
+                    *(u32x4*)(p.C16 + (size_t)q * p.c_plane + (size_t)row * p.ldc + ocol) = *(const u32x4*)(L16 + q * (RP * 64) + R * 64 + c8);
             }
         } else if constexpr (EPI == VN_EPI_QKV3) {
             const int D = p.H * VN_DHEAD;
+            if (n0 < 2 * D) {
 #pragma unroll
-            for (int k = 0; k < 12; ++k) {                                          // 3 planes x 128 x 16 pieces of 8 elements
-                const int idx = tid + 512 * k;
-                const int q = idx >> 11, a = (idx >> 4) & 127, b8 = (idx & 15) * 8;
-                if (n0 < 2 * D) {                                                   // a = image row, b8 = first of 8 columns
-                    const int row = m0 + (a >> 5) * 32 * MI + 32 * i + (a & 31), col = n0 + b8;
+                for (int k = 0; k < 3 * RP * 16 / 512; ++k) {                       // 3 planes x RP rows x 16 pieces of 8 columns
+                    const int idx = tid + 512 * k;
+                    const int q = idx / (RP * 16), a = (idx >> 4) % RP, b8 = (idx & 15) * 8;
+                    const int row = m0 + (a >> 5) * 32 * RI + 32 * i + (a & 31), col = n0 + b8;
                     if (row >= p.M || col >= p.N) continue;
                     const int which = col >= D ? 1 : 0, rem = col - which * D;
                     const int b = row / p.T, t = row - b * p.T;
                     *(u32x4*)(p.C16 + (size_t)q * p.c_plane + which * p.qkv_plane + (((size_t)b * p.H + (rem >> 6)) * p.T + t) * VN_DHEAD + (rem & 63)) =
-                        *(const u32x4*)(L16 + q * (128 * 128) + a * 128 + b8);
-                } else {                                                            // a = column (feature), b8 = first of 8 image rows (tokens)
-                    const int row = m0 + (b8 >> 5) * 32 * MI + 32 * i + (b8 & 31), f = n0 + a - 2 * D;
+                        *(const u32x4*)(L16 + q * (RP * 128) + a * 128 + b8);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3 * 128 * (RP / 8) / 512; ++k) {                // 3 planes x 128 columns x RP / 8 pieces of 8 rows
+                    const int idx = tid + 512 * k;
+                    const int q = idx / (128 * (RP / 8)), a = (idx / (RP / 8)) & 127, b8 = (idx % (RP / 8)) * 8;     // a = column (feature)
+                    const int row = m0 + (b8 >> 5) * 32 * RI + 32 * i + (b8 & 31), f = n0 + a - 2 * D;
                     if (row >= p.M || n0 + a >= p.N) continue;
                     *(u32x4*)(p.V16 + (size_t)q * p.v_plane + (((size_t)(f >> 6) * ((p.M + 31) >> 5) + (row >> 5)) * VN_DHEAD + (f & 63)) * 32 + (row & 31)) =
-                        *(const u32x4*)(L16 + q * (128 * 136) + a * 136 + b8);
+                        *(const u32x4*)(L16 + q * (128 * VP) + a * VP + b8);
                 }
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {                                           // 128 rows x 32 pieces of 4 columns
+            for (int k = 0; k < RP * 32 / 512; ++k) {                               // RP rows x 32 pieces of 4 columns
                 const int idx = tid + 512 * k;
                 const int R = idx >> 5, c4 = (idx & 31) * 4;
-                const int row = m0 + (R >> 5) * 32 * MI + 32 * i + (R & 31), col = n0 + c4;
+                const int row = m0 + (R >> 5) * 32 * RI + 32 * i + (R & 31), col = n0 + c4;
                 if (row >= p.M || col >= p.N) continue;
                 f32x4 v = *(const f32x4*)(lds + R * 128 + c4);
                 if constexpr (EPI == VN_EPI_QKV) {
@@ -264,14 +284,15 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
 // one block per output tile (gridDim.y > 1: split-K images, store epilogue only)
 // ABL (tuning only, results invalid): bit 0 = no DMA inside the k-loop, bit 1 = no fragment reads inside the k-loop, bit 2 =
 // every DMA instruction fetches 8 rows x 128 B (whole cache lines, same volume) instead of 16 rows x 64 B
-template <int EPI, int MI, int ABL = 0>
+template <int EPI, int CFG, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int tiles_m, int tiles_n) {
-    using G = x3_geo<MI>;
+    using G = x3_geo<CFG>;
+    constexpr int RI = G::RI, CJ = G::CJ;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / G::WC, wn = wave % G::WC;
     const int grp = wave >> 2;                        // waves w and w + 4 share a SIMD: one of each group per SIMD
     const uint16_t* A16 = (const uint16_t*)p.A;
     const uint16_t* W16 = (const uint16_t*)p.W;
@@ -280,8 +301,8 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
     const int dslot = (ABL & 4) ? lane & 7 : (lane & 3) ^ ((lane >> 4) & 3);     // (row >> 2) & 3 == (lane >> 4) & 3
     // fragment offsets (floats) inside a plane tile: row * 16 + ((2 s + h) ^ ((row >> 2) & 3)) * 4
     const int l31 = lane & 31, h = lane >> 5, sw = (lane >> 2) & 3;
-    const int aRow = (wm * 32 * MI + l31) * 16;
-    const int bRow = (wn * 64 + l31) * 16;
+    const int aRow = (wm * 32 * RI + l31) * 16;
+    const int bRow = (wn * 32 * CJ + l31) * 16;
 
     // ---- this block's tile (and, for split-K launches, its k-range)
     if (gridDim.y > 1) p.C += (size_t)blockIdx.y * p.M * p.N;
@@ -292,18 +313,21 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         x3_tile_coords(t, tiles_m, tiles_n, tm, tn);
         const int m0 = tm * G::BM, n0 = tn * X3_BN;
 
-        // per-lane DMA sources: instruction q = wave * NPW + j fills 16 rows of one plane tile (A: q < 24 MI, plane q / (8 MI))
+        // per-lane DMA sources: instruction q fills 16 rows of one plane tile at LDS offset q KiB of the stage (A planes first: q <
+        // 3 BM / 16, plane q / (BM / 16)).  CFG 1 / 2: a wave owns NPW consecutive instructions; CFG 3 (60 instructions): instruction
+        // 8 j + wave, so waves 0-3 issue eight and waves 4-7 seven
+        auto piece_q = [&](int j) { return CFG == 3 ? 8 * j + wave : wave * G::NPW + j; };
         const uint16_t* src[G::NPW];
 #pragma unroll
         for (int j = 0; j < G::NPW; ++j) {
-            const int q = wave * G::NPW + j;
-            if (q < 24 * MI) {
-                const int pt = q / (8 * MI), row = (q % (8 * MI)) * 16 + drow;
+            const int q = piece_q(j);
+            if (q < 3 * (G::BM / 16)) {
+                const int pt = q / (G::BM / 16), row = (q % (G::BM / 16)) * 16 + drow;
                 int g = m0 + row;
                 g = g < p.M ? g : p.M - 1;
                 src[j] = A16 + (size_t)pt * p.a_plane + (size_t)g * p.K + dslot * 8 + kb * X3_KT;
             } else {
-                const int qb = q - 24 * MI;
+                const int qb = (q - 3 * (G::BM / 16)) % 24;             // (CFG 3, j = 7, waves 4-7: q >= NQ — never issued)
                 const int pt = qb >> 3, row = (qb & 7) * 16 + drow;
                 int g = n0 + row;
                 g = g < p.N ? g : p.N - 1;
@@ -312,24 +336,27 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         }
         auto stage_piece = [&](int buf, int k0, int j) {
             if constexpr (ABL & 4) k0 = (2 * k0) % p.K;     // a fresh 128-byte line per k-tile (probe: K % 64 == 0, data-parallel form)
-            float* base = lds + buf * G::STAGE + wave * (G::NPW * 256);
+            if constexpr (CFG == 3) {
+                if (j == G::NPW - 1 && wave >= 4) return;   // 60 = 4 x 8 + 4 x 7 instructions
+            }
+            float* base = lds + buf * G::STAGE + piece_q(j) * 256;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
-                                             (__attribute__((address_space(3))) void*)(base + j * 256), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)base, 16, 0, 0);
         };
         auto stage = [&](int buf, int k0) {
 #pragma unroll
             for (int j = 0; j < G::NPW; ++j) stage_piece(buf, k0, j);
         };
 
-        f32x16 acc[MI][2];
+        f32x16 acc[RI][CJ];
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < RI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < CJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-        struct Frags { bf16x8 a[3][MI], b[3][2]; };
+        struct Frags { bf16x8 a[3][RI], b[3][CJ]; };
         auto load_frags = [&](Frags& f, int buf, int s) {
             const float* sA = lds + buf * G::STAGE;
             const float* sB = sA + 3 * G::APLANE;
@@ -337,10 +364,10 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < RI; ++i)
                     f.a[q][i] = __builtin_bit_cast(bf16x8, *(const f32x4*)(sA + q * G::APLANE + aRow + i * 32 * 16 + off));
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < CJ; ++j)
                     f.b[q][j] = __builtin_bit_cast(bf16x8, *(const f32x4*)(sB + q * X3_BPLANE + bRow + j * 32 * 16 + off));
             }
         };
@@ -349,9 +376,9 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         auto mac_prod = [&](const Frags& f, int t) {
             const int qa = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0, qb = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < RI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < CJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[qa][i], f.b[qb][j], acc[i][j], 0, 0, 0);
         };
         Frags f;
@@ -365,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         };
 
         const int nk = ke - kb;
-        if constexpr (MI == 1) {
+        if constexpr (CFG == 1) {
             // three buffers; tile kt lives in buffer kt % 3.  Phase intervals I_j between consecutive barriers: group 0 loads
             // step i in I_2i and computes it in I_2i+1, group 1 one interval later.  Tile kt is read in I_4kt .. I_4kt+3 (every
             // load phase ends with lgkmcnt(0) BEFORE its barrier, so those reads have retired when I_4kt+4 starts), tile
@@ -409,12 +436,13 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                 b = b == 2 ? 0 : b + 1;
             }
         } else {
-            // two buffers of 72 KiB; tile kt lives in buffer kt & 1.  Tile kt + 1 goes into the buffer tile kt - 1 used (last
-            // read in I_4kt-1, retired before that interval's barrier) and is first read in I_4kt+4: each wave issues five
-            // of its nine pieces in the first load phase of tile kt and four between the products of its first compute phase
+            // two buffers (72 / 60 KiB); tile kt lives in buffer kt & 1.  Tile kt + 1 goes into the buffer tile kt - 1 used (last
+            // read in I_4kt-1, retired before that interval's barrier) and is first read in I_4kt+4: each wave issues NA of its
+            // pieces in the first load phase of tile kt and the other four between the products of its first compute phase
             // (group 0: I_4kt, I_4kt+1; group 1: I_4kt+1, I_4kt+2) and waits for them at the last point that still has a
             // barrier between it and the first read: group 0 at the end of its second compute phase (I_4kt+3), group 1 at
             // the end of its second load phase (I_4kt+3).
+            constexpr int NA = G::NPW - 4;                  // 5 (CFG 2) / 4 (CFG 3)
             stage(0, 0);
             X3_VMCNT(0);
             X3_BARRIER();
@@ -429,7 +457,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                 if constexpr (!(ABL & 2)) load_frags(f, b, 0);
                 if (more) {
 #pragma unroll
-                    for (int j = 0; j < 5; ++j) stage_piece(b ^ 1, k1, j);
+                    for (int j = 0; j < NA; ++j) stage_piece(b ^ 1, k1, j);
                 }
                 X3_LGKM0();
                 X3_BARRIER();
@@ -437,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
 #pragma unroll
                 for (int t = 0; t < 6; ++t) {
                     mac_prod(f, t);
-                    if (t < 4 && more) stage_piece(b ^ 1, k1, 5 + t);
+                    if (t < 4 && more) stage_piece(b ^ 1, k1, NA + t);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_s_setprio(0);
@@ -453,8 +481,8 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             }
         }
 
-        if (p.staged) x3_epilogue_staged<EPI, MI>(p, acc, m0, n0, wave, lane, lds);
-        else x3_epilogue<EPI, MI>(p, acc, m0, n0, wm, wn, lane);
+        if (p.staged) x3_epilogue_staged<EPI, CFG>(p, acc, m0, n0, wave, lane, lds);
+        else x3_epilogue<EPI, CFG>(p, acc, m0, n0, wm, wn, lane);
     }
 }
 
@@ -465,29 +493,17 @@ static int x3_env(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-// tuning / test hooks (process-global): tile height 128 / 256, forced split-K, ablation bits
+// tuning / test hooks (process-global): tile height 128 / 192 / 256, forced split-K, ablation bits
 static int g_x3_bm = 0, g_x3_split = -2, g_x3_abl = -1;
-// tile height: 0 (default) = by shape.  The 256 x 128 tile moves 25 % fewer operand bytes per flop (fewer DMA and LDS reads
-// at the chip's power limit) but its rounds are twice as coarse: it wins where it still fills whole rounds (W1 + GEGLU at
-// B = 8: 720 tiles = 2.8 rounds, 305 vs 319 us) and loses elsewhere (QKV 540 tiles = 2.1 rounds: 283 vs 251 us;
-// profiles/r02_gemm_x3_staged_epilogue_shapes.txt).
-static int x3_bm(const vn_gemm_args& a, int cus) {
-    static const int bm_env = x3_env("VN_X3_BM", 0);
-    const int bm = g_x3_bm ? g_x3_bm : bm_env;
-    if (bm == 128 || bm == 256) return bm;
-    const long t256 = (long)vn_cdiv(a.M, 256) * vn_cdiv(a.N, X3_BN);
-    const long rounds = (t256 + cus - 1) / cus;
-    return (rounds >= 2 && 10 * t256 >= 9 * rounds * cus) ? 256 : 128;
-}
 extern "C" int vn_debug_x3_config(int bm, int splitk, int abl) {
-    if (bm != 0 && bm != 128 && bm != 256) return VN_ERR_INVALID;
+    if (bm != 0 && bm != 128 && bm != 192 && bm != 256) return VN_ERR_INVALID;
     g_x3_bm = bm; g_x3_split = splitk < 0 ? -2 : splitk;
     g_x3_abl = abl < 0 ? -1 : (abl & 7);
     return VN_OK;
 }
 
-template <int MI>
-static constexpr size_t x3_lds_bytes() { return (size_t)x3_geo<MI>::STAGE * 4 * (MI == 1 ? 3 : 2); }
+template <int CFG>
+static constexpr size_t x3_lds_bytes() { return (size_t)x3_geo<CFG>::STAGE * 4 * x3_geo<CFG>::NBUF; }
 
 static int x3_num_cus(vn_ctx* ctx) {
     static int cus[64] = {0};
@@ -515,22 +531,23 @@ static int x3_staged_ok(const vn_gemm_args& a) {
     return !(a.ldc & 3);
 }
 
-template <int EPI, int MI, int ABL = 0>
+template <int EPI, int CFG, int ABL = 0>
 static int x3_go(vn_ctx* ctx, const vn_gemm_args& a_in, int nsplit, hipStream_t s) {
     vn_gemm_args a = a_in;
     a.staged = x3_staged_ok<EPI>(a);
-    const int tiles_m = vn_cdiv(a.M, 128 * MI), tiles_n = vn_cdiv(a.N, X3_BN);
-    hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, MI, ABL>), dim3(tiles_m * tiles_n, nsplit), dim3(512), x3_lds_bytes<MI>(), s, a, tiles_m, tiles_n);
+    const int tiles_m = vn_cdiv(a.M, x3_geo<CFG>::BM), tiles_n = vn_cdiv(a.N, X3_BN);
+    hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, CFG, ABL>), dim3(tiles_m * tiles_n, nsplit), dim3(512), x3_lds_bytes<CFG>(), s, a, tiles_m, tiles_n);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
 }
 template <int EPI>
 static int x3_go_bm(vn_ctx* ctx, const vn_gemm_args& a, int nsplit, int bm, hipStream_t s) {
+    if constexpr (EPI != VN_EPI_GEGLU) {
+        if (bm == 192) return x3_go<EPI, 3>(ctx, a, nsplit, s);
+    }
     return bm == 256 ? x3_go<EPI, 2>(ctx, a, nsplit, s) : x3_go<EPI, 1>(ctx, a, nsplit, s);
 }
 
-// split count for the store / residual epilogues.  A launch costs ceil(tiles * ns / 256) rounds of
-// K / ns, plus the reduce pass over (ns + 1 or 2) images of C (1.45 us per k-tile and round, ~3.5 TB/s for the reduce).
 static int g_x3_fuse_norm = -1;                  // test hook: -1 = VN_X3_FUSE_NORM (default on), 0 / 1 forced
 extern "C" int vn_debug_x3_fuse_norm(int on) { g_x3_fuse_norm = on < 0 ? -1 : (on != 0); return VN_OK; }
 static bool x3_norm_fusable(const vn_gemm_args& a) {
@@ -538,22 +555,47 @@ static bool x3_norm_fusable(const vn_gemm_args& a) {
     const bool fuse_norm = g_x3_fuse_norm >= 0 ? g_x3_fuse_norm != 0 : fuse_env;
     return fuse_norm && a.norm_w && a.norm_done && a.ldc == a.N && (a.N == 1280 || a.N == 256);
 }
-static int x3_pick_split(const vn_gemm_args& a, bool residual, int bm) {
-    static const int forced_env = x3_env("VN_X3_SPLITK", -1);      // 0 / 1: off, 2 / 4: forced
-    const int forced = g_x3_split != -2 ? g_x3_split : forced_env;
-    const int tiles = vn_cdiv(a.M, bm) * vn_cdiv(a.N, X3_BN), nk = a.K / X3_KT;
-    if (forced == 0 || forced == 1 || (a.N & 3) || (a.ldc & 3)) return 1;
-    int best = 1;
+
+// Tile height and k-split of a launch, by a cost model in microseconds calibrated on the model's shapes (scripts/gemm_x3_plan_sweep.py,
+// profiles/r02_gemm_x3_plan_sweep.txt): a launch runs ceil(tiles ns / CUs) rounds of K / ns k-tiles; a k-tile of a 128-row tile
+// costs 1.45 us when every CU is busy, taller tiles proportionally more minus what their smaller operand traffic per flop gives
+// back (192 rows: -17 % DMA bytes per flop, 256 rows: -25 %); a split launch adds its reduce pass over (ns + 1 or 2) images of C
+// at ~3.5 TB/s, minus the RMSNorm read it absorbs when the norm is fused into that pass.  The 192-row tile is what fills whole
+// rounds at B = 8 (M = 4600): QKV 720 tiles = 2.8 rounds (128 rows: 4.2 -> 5), Wo / W2 240 tiles = ONE round without a split,
+// classifier 768 = 3.0 rounds; 256 rows stay best for W1 + GEGLU (720 tiles = 2.8 rounds; the GEGLU epilogue needs the 64-wide
+// wave tile); one or two sequences keep 128 rows (more tiles) and split the N = 1280 projections.
+struct x3_plan { int bm, ns; };
+template <int EPI>
+static x3_plan x3_choose(const vn_gemm_args& a, int cus) {
+    static const int bm_env = x3_env("VN_X3_BM", 0), split_env = x3_env("VN_X3_SPLITK", -1);      // split: 0 / 1 off, 2 / 4 forced
+    const int bm_forced = g_x3_bm ? g_x3_bm : bm_env;
+    const int split_forced = g_x3_split != -2 ? g_x3_split : split_env;
+    constexpr bool can_split = EPI == VN_EPI_STORE || EPI == VN_EPI_RESIDUAL;
+    constexpr bool residual = EPI == VN_EPI_RESIDUAL;
+    const int nk = a.K / X3_KT;
+    x3_plan best{128, 1};
     double best_cost = 1e300;
-    for (int ns = 1; ns <= 4; ns *= 2) {
-        if (ns > 1 && (nk / ns < 8 || (double)ns * a.M * a.N > (double)X3_WS_FLOATS)) continue;
-        if (forced > 1 && ns != forced && ns != 1) continue;
-        double cost = ceil(tiles * ns / 256.0) * (nk / (double)ns) * 1.45 * (bm / 128);
-        if (ns > 1) cost += (ns + (residual ? 2 : 1)) * 4.0 * a.M * (double)a.N / 3.5e6;
-        // the reduce pass of a split launch also runs the RMSNorm that follows: that norm's read of x and a launch boundary are saved
-        if (ns > 1 && residual && x3_norm_fusable(a)) cost -= 4.0 * a.M * (double)a.N / 3.5e6 + 1.5;
-        if (forced > 1 && ns == forced) cost = 0;
-        if (cost < best_cost) { best_cost = cost; best = ns; }
+    static const int heights[3] = {128, 192, 256};
+    static const double rel[3] = {1.0, 1.5 * 0.97, 2.0 * 0.95};
+    for (int hi = 0; hi < 3; ++hi) {
+        const int bm = heights[hi];
+        if (bm == 192 && EPI == VN_EPI_GEGLU) continue;
+        if (bm_forced && bm != bm_forced && !(bm_forced == 192 && EPI == VN_EPI_GEGLU && bm == 128)) continue;
+        const long tiles = (long)vn_cdiv(a.M, bm) * vn_cdiv(a.N, X3_BN);
+        for (int ns = 1; ns <= (can_split ? 4 : 1); ns *= 2) {
+            if (ns > 1) {
+                if (split_forced == 0 || split_forced == 1 || (a.N & 3) || (a.ldc & 3)) continue;
+                if (nk / ns < 8 || (double)ns * a.M * a.N > (double)X3_WS_FLOATS) continue;
+            }
+            if (split_forced > 1 && ns != split_forced && ns != 1) continue;
+            double cost = (double)((tiles * ns + cus - 1) / cus) * (nk / (double)ns) * 1.45 * rel[hi];
+            if (ns > 1) {
+                cost += (ns + (residual ? 2 : 1)) * 4.0 * a.M * (double)a.N / 3.5e6;
+                if (residual && x3_norm_fusable(a)) cost -= 4.0 * a.M * (double)a.N / 3.5e6 + 1.5;
+                if (split_forced > 1 && ns == split_forced) cost = -1.0 + 1e-3 * hi;       // forced split: keep the height order
+            }
+            if (cost < best_cost) { best_cost = cost; best = x3_plan{bm, ns}; }
+        }
     }
     return best;
 }
@@ -565,7 +607,8 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
                          ((EPI == VN_EPI_GEGLU && a.C16) ? 6.0 : 4.0) * (double)a.M * n_out * (EPI == VN_EPI_RESIDUAL ? 2 : 1);
     const int pi = vn_prof_pre(ctx, 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);       // algorithmic (fp32-equivalent) flops
     int rc = VN_OK;
-    const int bm = x3_bm(a, x3_num_cus(ctx));
+    const x3_plan plan = x3_choose<EPI>(a, x3_num_cus(ctx));
+    const int bm = plan.bm;
     bool done = false;
     if constexpr (EPI == VN_EPI_STORE) {
         static const int abl_env = x3_env("VN_X3_ABL", 0) & 7;             // ablations (tuning only; results invalid)
@@ -580,7 +623,7 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
         }
     }
     if constexpr (EPI == VN_EPI_STORE || EPI == VN_EPI_RESIDUAL) {
-        const int ns = done ? 1 : x3_pick_split(a, EPI == VN_EPI_RESIDUAL, bm);
+        const int ns = done ? 1 : plan.ns;
         if (ns > 1) {
             if (!ctx->x3_ws) VN_HIP_CHECK(ctx, hipMalloc((void**)&ctx->x3_ws, (size_t)X3_WS_FLOATS * sizeof(float)));
             vn_gemm_args q = a;                       // every split stores its raw image [M][N] into the workspace
@@ -613,7 +656,11 @@ static int x3_attr(vn_ctx* ctx, K kernel, size_t bytes) {
 template <int EPI>
 static int x3_attrs(vn_ctx* ctx) {
     int rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 1>, x3_lds_bytes<1>());
-    return rc ? rc : x3_attr(ctx, vn_gemm_x3_kernel<EPI, 2>, x3_lds_bytes<2>());
+    if (!rc) rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 2>, x3_lds_bytes<2>());
+    if constexpr (EPI != VN_EPI_GEGLU) {
+        if (!rc) rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 3>, x3_lds_bytes<3>());
+    }
+    return rc;
 }
 template <int MI, int ABL>
 static int x3_attrs_abl(vn_ctx* ctx) {
