@@ -446,69 +446,79 @@ def test_split_plane_gemm_lds_addressing():
     """Model of the LDS layout of csrc/gemm_x3.hip (3 bf16 planes, verified on the GPU): replay the per-lane LDS-DMA destinations and source swizzle, then check that every
     ds_read_b128 fragment read fetches the (operand, plane, row, k) it feeds to the MFMA and that each of its four 16-lane
     groups touches 16 distinct 16-byte slots of the 256-byte bank row (conflict-free)."""
-    def check(MI, planes):
-        BM = 128 * MI
+    def check(cfg, planes=3):
+        RI, CJ, WR, WC = {1: (1, 2, 4, 2), 2: (2, 2, 4, 2), 3: (3, 1, 2, 4)}[cfg]       # x3_geo<CFG>
+        BM = 32 * RI * WR
         APLANE = BM * 16            # floats
         BPLANE = 128 * 16
         STAGE = planes * APLANE + planes * BPLANE
         NQ = (planes * BM + planes * 128) // 16
-        NPW = NQ // 8
-        assert NQ % 8 == 0
+        NPW = (NQ + 7) // 8
         lds = {}                    # half index -> (op, plane, row, k)
+        issued = 0
         for wave in range(8):
             for j in range(NPW):
-                q = wave * NPW + j
+                q = 8 * j + wave if cfg == 3 else wave * NPW + j     # CFG 3: 60 instructions = 8 for waves 0-3, 7 for waves 4-7
+                if cfg == 3 and j == NPW - 1 and wave >= 4:
+                    continue
+                assert q < NQ
+                issued += 1
                 for lane in range(64):
                     drow, dslot = lane >> 2, (lane & 3) ^ ((lane >> 4) & 3)
-                    if q < planes * 8 * MI:
-                        plane, row = q // (8 * MI), (q % (8 * MI)) * 16 + drow
+                    if q < planes * (BM // 16):
+                        plane, row = q // (BM // 16), (q % (BM // 16)) * 16 + drow
                         op = "A"
                     else:
-                        qb = q - planes * 8 * MI
+                        qb = q - planes * (BM // 16)
                         plane, row = qb >> 3, (qb & 7) * 16 + drow
                         op = "W"
                     base = (q * 256 + lane * 4) * 2
                     for e in range(8):
                         assert base + e not in lds
                         lds[base + e] = (op, plane, row, dslot * 8 + e)
-        assert len(lds) == STAGE * 2, (len(lds), STAGE * 2)
+        assert issued == NQ and len(lds) == STAGE * 2, (issued, len(lds), STAGE * 2)
         # bank conflicts of the ds_read_b128 groups
         groups = [[0,1,2,3,12,13,14,15,20,21,22,23,24,25,26,27], [4,5,6,7,8,9,10,11,16,17,18,19,28,29,30,31]]
         groups += [[l + 32 for l in g] for g in groups]
+        covered_a, covered_w = set(), set()
         for wave in range(8):
-            wm, wn = wave >> 1, wave & 1
+            wm, wn = wave // WC, wave % WC
             for s in range(2):
                 for q in range(planes):
-                    for i in range(MI):
+                    for i in range(RI):
                         addrs = {}
                         for lane in range(64):
                             l31, h, sw = lane & 31, lane >> 5, (lane >> 2) & 3
-                            aRow = (wm * 32 * MI + l31) * 16
+                            aRow = (wm * 32 * RI + l31) * 16
                             off = ((2 * s + h) ^ sw) * 4
                             fo = q * APLANE + aRow + i * 32 * 16 + off
                             addrs[lane] = fo * 4
+                            covered_a.add(wm * 32 * RI + i * 32 + l31)
                             for e in range(8):
-                                assert lds[fo * 2 + e] == ("A", q, wm * 32 * MI + i * 32 + l31, (2 * s + h) * 8 + e), (MI, wave, lane)
+                                assert lds[fo * 2 + e] == ("A", q, wm * 32 * RI + i * 32 + l31, (2 * s + h) * 8 + e), (cfg, wave, lane)
                         for g in groups:
                             slots = {(addrs[l] // 16) % 16 for l in g}
-                            assert len(slots) == 16, ("bank conflict A", MI, wave, s, q, i)
-                    for j in range(2):
+                            assert len(slots) == 16, ("bank conflict A", cfg, wave, s, q, i)
+                    for j in range(CJ):
                         addrs = {}
                         for lane in range(64):
                             l31, h, sw = lane & 31, lane >> 5, (lane >> 2) & 3
-                            bRow = (wn * 64 + l31) * 16
+                            bRow = (wn * 32 * CJ + l31) * 16
                             off = ((2 * s + h) ^ sw) * 4
                             fo = planes * APLANE + q * BPLANE + bRow + j * 32 * 16 + off
                             addrs[lane] = fo * 4
+                            covered_w.add(wn * 32 * CJ + j * 32 + l31)
                             for e in range(8):
-                                assert lds[fo * 2 + e] == ("W", q, wn * 64 + j * 32 + l31, (2 * s + h) * 8 + e), (MI, wave, lane)
+                                assert lds[fo * 2 + e] == ("W", q, wn * 32 * CJ + j * 32 + l31, (2 * s + h) * 8 + e), (cfg, wave, lane)
                         for g in groups:
                             assert len({(addrs[l] // 16) % 16 for l in g}) == 16, ("bank conflict W",)
+        assert covered_a == set(range(BM)) and covered_w == set(range(128))      # the eight wave tiles tile BM x 128
         return STAGE * 4, NPW
 
 
-    assert check(1, 3) == (48 * 1024, 6)          # gemm_x3.hip, 128 x 128
-    assert check(2, 3) == (72 * 1024, 9)          # gemm_x3.hip, 256 x 128 (ping-pong)
+    assert check(1) == (48 * 1024, 6)          # gemm_x3.hip, 128 x 128 (waves 4 x 2)
+    assert check(2) == (72 * 1024, 9)          # gemm_x3.hip, 256 x 128 (waves 4 x 2)
+    assert check(3) == (60 * 1024, 8)          # gemm_x3.hip, 192 x 128 (waves 2 x 4; 60 DMA instructions per stage)
 
 
 def test_attention_x3_lds_addressing():
