@@ -33,10 +33,10 @@ def run(B, H, T, abl=0, lds=0, stagger=0, trace=None, iters=30):
 
 H = 20
 QUICK = os.environ.get("ATTN_PROBE_QUICK") == "1"
-for (B, T) in ([(8, 575), (32, 173), (4, 575), (16, 173), (2, 575)] if QUICK else [(8, 575), (4, 575), (2, 575), (32, 173)]):
+for (B, T) in ([(8, 575), (32, 173), (2, 575)] if QUICK else [(8, 575), (4, 575), (2, 575), (32, 173)]):
     fl = 4.0 * T * T * 64 * H * B
-    variants = [("by shape (shipped)", {}), ("96-query blocks, 4 per CU", dict(abl=32)), ("128-query blocks, 3 per CU", dict(abl=64)),
-                ("96-query blocks, 3 per CU", dict(abl=32, lds=50 * 1024)), ("128-query blocks, 2 per CU", dict(abl=64, lds=60 * 1024))]
+    variants = [("3 blocks/CU (shipped)", {}), ("2 blocks/CU", dict(lds=60 * 1024)), ("1 block/CU", dict(lds=90 * 1024)),
+                ("with s_setprio 1 around the MFMA phases", dict(abl=8))]
     if not QUICK:
         variants += [("no setprio, 2/CU", dict(abl=8, lds=60 * 1024))] + \
                     [(f"stagger {s} x 64 cyc", dict(stagger=s)) for s in (4, 8, 16, 24, 32, 48, 64)] + \
@@ -48,10 +48,10 @@ for (B, T) in ([(8, 575), (32, 173), (4, 575), (16, 173), (2, 575)] if QUICK els
 # phase trace: cycles summed over the tiles of wave 0 of every 16th block
 names = ["wait dma", "barrier", "dma issue", "qk", "softmax", "pv"]
 for (B, T) in [(8, 575), (2, 575)]:
-    for name, kw in [("128-q 3/CU", dict(abl64=True)), ("96-q 4/CU", dict(abl32=True))]:
-        nblk = ((T + 95) // 96) * H * B
+    for name, kw in [("3/CU", {}), ("1/CU", dict(lds=90 * 1024))]:
+        nblk = ((T + 127) // 128) * H * B
         tr = torch.zeros((nblk + 15) // 16, 8, dtype=torch.int32, device="cuda")
-        us = run(B, H, T, abl=16 + (32 if kw.get("abl32") else 64), trace=tr, iters=3)
+        us = run(B, H, T, abl=16, trace=tr, iters=3, **kw)
         t = tr.cpu().to(torch.int64) & 0xFFFFFFFF
         t = t[t[:, 6] > 0]
         ntile = (T + 31) // 32 + 1

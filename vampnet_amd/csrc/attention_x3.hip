@@ -51,25 +51,21 @@ __device__ __forceinline__ int ax_swap23(int r) { return (r & ~12) | ((r & 4) <<
 // A software-pipelined main loop (S of the next tile and half of PV in the same basic block as the softmax, bitwise equal to
 // this loop, commit 491c2d5) ran 115.5 vs 112.5 us at two blocks per CU (256 VGPRs) and was removed; start staggers by SIMD wave
 // slot change nothing (117.8-118.9 vs 119.9 us); 2 blocks per CU 114.8, 1 block 145 us.  What did pay: DMA sources as a uniform tile
-// base + a fixed per-lane offset (-5 %), no s_setprio (-1.6 %).)
-// Two block shapes share this body:
-//   NW = 4 (128 queries): K and V^T tiles double-buffered (2 x 24 KiB) + the whole 2T-1 bias table: 52.5 KiB, three blocks per CU.
-//   NW = 3 ( 96 queries): K double-buffered, V^T single-buffered (36 KiB) + the T+95 entries of the bias table this q-block can
-//          touch: 38.6 KiB at T = 575, FOUR blocks per CU = the same twelve waves, but 1024 block slots and no idle wave: T = 575 is
-//          18 wave tiles = six blocks per (item, head) exactly, 960 blocks in ONE round, where the 128-query shape needs 800 blocks
-//          (five per head, the fifth with two idle waves) on 768 slots — 110.7 us against 88.1 us for the 760 blocks of 19 heads
-//          (profiles/r02_attention_x3_tail_round_probe.txt).  Price: a second barrier per tile (V^T of tile kt is fetched into
-//          the single buffer once every wave is done with tile kt-1 and must be visible before the second product) and a third
-//          more K / V^T traffic per query.
-template <int NW, int ABL>
-__device__ __forceinline__ void ax_body(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16, long plane_qk,
-                                        const uint16_t* __restrict__ vt16, long plane_vt, const float* __restrict__ bias_full,
-                                        float* __restrict__ out, uint16_t* __restrict__ out16, long plane16, int B, int H, int T,
-                                        int stagger, unsigned* __restrict__ trace) {
-    static_assert(NW == 4 || NW == 3, "block shapes");
-    constexpr bool V1 = NW == 3;                                  // single V^T buffer + bias window
+// base + a fixed per-lane offset (-5 %), no s_setprio (-1.6 %).
+// The tail round (800 blocks of 128 queries on 768 slots: 110.7 us against 88.1 us for the 760 blocks of 19 heads,
+// profiles/r02_attention_x3_tail_round_probe.txt) was attacked with a 96-query block shape (three waves, V^T single-buffered + the
+// T+95-entry window of the bias table = 38.6 KiB, FOUR blocks per CU, 960 blocks = one round, no idle wave; bitwise equal to this
+// shape, commit "96-query block shape"): 104.7 vs 109.6 us kernel-only, but a tile costs a wave 8200 instead of 7200 cycles (second
+// barrier per tile, a third more K / V^T traffic per query) and inside the model it came out even to slower (271.0 vs 269.3 ms per
+// step, profiles/r02_attention_x3_probe_96_vs_128_query_blocks.txt) — removed.)
+template <int NW, int ABL = 0>
+__global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
+                                                                    long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
+                                                                    const float* __restrict__ bias_full, float* __restrict__ out,
+                                                                    uint16_t* __restrict__ out16, long plane16, int B, int H, int T,
+                                                                    int stagger, unsigned* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* bt = smem + (V1 ? 9 : 12) * AX_PLANE_FLOATS;
+    float* bt = smem + 2 * AX_STAGE_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
@@ -98,13 +94,7 @@ __device__ __forceinline__ void ax_body(const uint16_t* __restrict__ q16, const 
     const int qrow_c = qrow < T ? qrow : T - 1;
 
     const int nb = 2 * T - 1;
-    // V1: only the entries key - query + T - 1 this q-block can touch, [ws, ws + T + NW 32 - 1)
-    const int ws = V1 ? (T - qb * (NW * 32) - NW * 32 > 0 ? T - qb * (NW * 32) - NW * 32 : 0) : 0;
-    {
-        const int cnt = V1 ? (nb - ws < T + NW * 32 - 1 ? nb - ws : T + NW * 32 - 1) : nb;
-        for (int i = tid; i < cnt; i += NW * 64) bt[i] = bias_full[(size_t)h * nb + ws + i];
-    }
-    const int boff = T - 1 - ws;                        // bias of (key, query) = bt[key - query + boff]
+    for (int i = tid; i < nb; i += NW * 64) bt[i] = bias_full[(size_t)h * nb + i];
 
     // Q fragments (B operand of S^T = K Q^T): lane (j, hh) holds Q[q_j][16 step + 8 hh .. + 7] of every plane
     bf16x8 qf[3][4];
@@ -119,44 +109,13 @@ __device__ __forceinline__ void ax_body(const uint16_t* __restrict__ q16, const 
     // same for every plane and tile), so a tile costs six scalar adds and no vector address arithmetic.  K rows are NOT clamped to
     // the item: the rows of a first / last tile that belong to the neighbouring items (or to the q planes in front of / the
     // 32-row padding behind the k planes) are read as they are and masked to -inf before the softmax.
-    // NW = 4: wave w issues piece w of every plane tile.  NW = 3: the twelve pieces of the K (V^T) tile go round the three waves:
-    // wave w issues pieces w, w + 3, w + 6, w + 9 (piece = 4 plane + sub); the lane offset depends on the sub-piece only through its
-    // first row (linear) and, for K, the parity of sub in the bank swizzle.
+    static_assert(NW == 4, "one piece of every plane tile per wave");
+    const int krow = 8 * wave + (lane >> 3), vrow = 16 * wave + (lane >> 2);
+    const unsigned kvoff = (unsigned)(krow * VN_DHEAD + ((lane & 7) ^ ((krow >> 1) & 7)) * 8) * 2u;      // bytes inside a K tile
+    const unsigned vvoff = (unsigned)(vrow * AX_KT + ((lane & 3) ^ ((vrow >> 2) & 3)) * 8) * 2u;         // bytes inside a V^T tile
     const char* kbase = (const char*)(Kp + (long)(g_lo * AX_KT - m_lo) * VN_DHEAD);                       // tile 0, plane 0 (key0 <= 0)
     const char* vbase = (const char*)Vp;
-    auto k_lane_off = [&](int sub) {
-        const int krow = 8 * sub + (lane >> 3);
-        return (unsigned)(krow * VN_DHEAD + ((lane & 7) ^ ((krow >> 1) & 7)) * 8) * 2u;                    // bytes inside a K tile
-    };
-    auto v_lane_off = [&](int sub) {
-        const int vrow = 16 * sub + (lane >> 2);
-        return (unsigned)(vrow * AX_KT + ((lane & 3) ^ ((vrow >> 2) & 3)) * 8) * 2u;                       // bytes inside a V^T tile
-    };
-    const unsigned kvoff = k_lane_off(wave), vvoff = v_lane_off(wave);                                    // NW = 4
-    const unsigned kvoff_e = k_lane_off(0), kvoff_o = k_lane_off(1) - 1024u, vvoff_0 = v_lane_off(0);     // NW = 3: + 1024 sub
-    auto issue_k = [&](float* kdst, int kt) {                 // K tile kt -> the 12 KiB at kdst (this wave's pieces)
-        if (kt >= NT) return;
-#pragma unroll
-        for (int i = 0; i < 12 / NW; ++i) {
-            const int q = NW == 4 ? 4 * i + wave : wave + NW * i, p = q >> 2, sub = q & 3;
-            const char* ks = kbase + ((size_t)p * plane_qk * 2 + (size_t)kt * (AX_KT * VN_DHEAD * 2));
-            const unsigned off = NW == 4 ? kvoff : ((sub & 1) ? kvoff_o : kvoff_e) + 1024u * sub;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ks + off),
-                                             (__attribute__((address_space(3))) void*)(kdst + q * 256), 16, 0, 0);
-        }
-    };
-    auto issue_v = [&](float* vdst, int kt) {                 // V^T tile kt -> the 12 KiB at vdst
-        if (kt >= NT) return;
-#pragma unroll
-        for (int i = 0; i < 12 / NW; ++i) {
-            const int q = NW == 4 ? 4 * i + wave : wave + NW * i, p = q >> 2, sub = q & 3;
-            const char* vs = vbase + ((size_t)p * plane_vt * 2 + (size_t)kt * (VN_DHEAD * AX_KT * 2));
-            const unsigned off = NW == 4 ? vvoff : vvoff_0 + 1024u * sub;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vs + off),
-                                             (__attribute__((address_space(3))) void*)(vdst + q * 256), 16, 0, 0);
-        }
-    };
-    auto stage = [&](int buf, int kt) {                       // NW = 4: tile kt -> stage buf (K then V^T, as issued before: K, V per plane)
+    auto stage = [&](int buf, int kt) {                       // tile kt -> stage buf
         if (kt >= NT) return;
         float* base = smem + buf * AX_STAGE_FLOATS + wave * 256;
 #pragma unroll
@@ -184,7 +143,8 @@ __device__ __forceinline__ void ax_body(const uint16_t* __restrict__ q16, const 
     f32x16 sacc;
     bf16x8 pf[3][2];
     // ---- S^T = K . Q^T for the tile in stage `kb`: four 16-wide d steps x six plane products (smallest terms first)
-    auto qk_phase = [&](const float* Ks) {
+    auto qk_phase = [&](int kb) {
+        const float* Ks = smem + kb * AX_STAGE_FLOATS;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
         if constexpr (ABL & 8) __builtin_amdgcn_s_setprio(1);
@@ -211,7 +171,7 @@ __device__ __forceinline__ void ax_body(const uint16_t* __restrict__ q16, const 
     auto softmax_phase = [&](int kt) {
         float mx = -INFINITY;
         const int key0 = (g_lo + kt) * AX_KT - m_lo;                   // key index of the tile's first row
-        const float* brow = bt + (key0 + 8 * hh - qrow_c + boff);      // bias of key key0 + 8 hh for this query
+        const float* brow = bt + (key0 + 8 * hh - qrow_c + (T - 1));   // bias of key key0 + 8 hh for this query
         const bool full = key0 >= 0 && key0 + AX_KT <= T;              // every key of the tile belongs to this item (uniform)
         if (full) {
 #pragma unroll
@@ -225,7 +185,7 @@ __device__ __forceinline__ void ax_body(const uint16_t* __restrict__ q16, const 
             for (int r = 0; r < 16; ++r) {
                 const int key = key0 + 16 * (r >> 3) + 8 * hh + (r & 7);
                 const int key_c = key < 0 ? 0 : (key < T ? key : T - 1);
-                float x = sacc[r] + bt[key_c - qrow_c + boff];
+                float x = sacc[r] + bt[key_c - qrow_c + (T - 1)];
                 x = (key >= 0 && key < T) ? x : -INFINITY;
                 sacc[r] = x;
                 mx = fmaxf(mx, x);
@@ -260,7 +220,8 @@ __device__ __forceinline__ void ax_body(const uint16_t* __restrict__ q16, const 
         }
     };
     // ---- O^T += V^T . P^T for the tile in stage `vb`: two 32-row d tiles x two 16-key steps x six plane products
-    auto pv_phase = [&](const float* Vs) {
+    auto pv_phase = [&](int vb) {
+        const float* Vs = smem + vb * AX_STAGE_FLOATS + 3 * AX_PLANE_FLOATS;
         if constexpr (ABL & 8) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -302,36 +263,6 @@ __device__ __forceinline__ void ax_body(const uint16_t* __restrict__ q16, const 
         }
     };
     if constexpr (ABL & 16) { tr_t = tr_start = __builtin_readcyclecounter(); }
-    if constexpr (V1) {
-        // K(kt) lives in K buffer kt & 1, V^T(kt) in the one V^T buffer.  Iteration kt: every wave has waited for its pieces of K(kt)
-        // -> barrier (K(kt) visible; everybody is done with V^T(kt-1) and K(kt-1)) -> issue V^T(kt), then K(kt+1) -> first product,
-        // softmax -> wait for the V^T pieces only (the four younger K pieces stay in flight) -> barrier -> second product.
-        float* Kb = smem;                                       // 2 x 3 planes
-        float* Vb = smem + 6 * AX_PLANE_FLOATS;                 // 3 planes
-        issue_k(Kb, 0);
-        for (int kt = 0; kt < NT; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            tick(0);
-            __syncthreads();
-            tick(1);
-            issue_v(Vb, kt);
-            issue_k(Kb + ((kt + 1) & 1) * 3 * AX_PLANE_FLOATS, kt + 1);
-            tick(2);
-            if (active) {
-                qk_phase(Kb + (kt & 1) * 3 * AX_PLANE_FLOATS);
-                tick(3);
-                softmax_phase(kt);
-                tick(4);
-            }
-            if (kt + 1 < NT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // V^T(kt) landed; K(kt+1) (4 pieces, issued later) may fly
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (active) {
-                pv_phase(Vb);
-                tick(5);
-            }
-        }
-    } else {
     stage(0, 0);
     for (int kt = 0; kt < NT; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of tile kt have landed
@@ -341,13 +272,12 @@ __device__ __forceinline__ void ax_body(const uint16_t* __restrict__ q16, const 
         stage((kt + 1) & 1, kt + 1);
         tick(2);
         if (!active) continue;
-        qk_phase(smem + (kt & 1) * AX_STAGE_FLOATS);
+        qk_phase(kt & 1);
         tick(3);
         softmax_phase(kt);
         tick(4);
-        pv_phase(smem + (kt & 1) * AX_STAGE_FLOATS + 3 * AX_PLANE_FLOATS);
+        pv_phase(kt & 1);
         tick(5);
-    }
     }
     if constexpr (ABL & 16) {
         if (tracing && lane == 0) {
@@ -379,15 +309,6 @@ __device__ __forceinline__ void ax_body(const uint16_t* __restrict__ q16, const 
     }
 }
 
-template <int NW, int ABL = 0>
-__global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
-                                                                    long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
-                                                                    const float* __restrict__ bias_full, float* __restrict__ out,
-                                                                    uint16_t* __restrict__ out16, long plane16, int B, int H, int T,
-                                                                    int stagger, unsigned* __restrict__ trace) {
-    ax_body<NW, ABL>(q16, k16, plane_qk, vt16, plane_vt, bias_full, out, out16, plane16, B, H, T, stagger, trace);
-}
-
 // tuning hooks (process-global; scripts/attn_probe.py): ablation / variant bits, dynamic-LDS override (occupancy: > 80 KiB = one block
 // per CU, > 53.3 KiB = two), start stagger, phase-trace buffer
 static int g_ax_abl = -1, g_ax_lds = 0, g_ax_stagger = -1;
@@ -400,10 +321,9 @@ extern "C" int vn_debug_attention_x3_config(int abl, int lds_bytes, int stagger,
 int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16, long plane_qk, const uint16_t* vt16, long plane_vt,
                            const float* relbias_full, float* out, uint16_t* out16, long plane16, int B, int H, int T, hipStream_t s) {
     if (B <= 0 || T <= 0) return VN_OK;
-    size_t lds = (size_t)(2 * AX_STAGE_FLOATS + 2 * T - 1 + 3) * sizeof(float);                       // 128-query blocks
-    size_t lds3 = (size_t)(9 * AX_PLANE_FLOATS + T + 3 * 32 + 3) * sizeof(float);                     //  96-query blocks
+    size_t lds = (size_t)(2 * AX_STAGE_FLOATS + 2 * T - 1 + 3) * sizeof(float);
     if (lds > 80 * 1024) return vn_fail(ctx, VN_ERR_INVALID, "attention_x3: T=%s%ld too long for two blocks per CU", "", T);
-    if (g_ax_lds > (int)lds && g_ax_lds <= 160 * 1024) lds = lds3 = g_ax_lds;
+    if (g_ax_lds > (int)lds && g_ax_lds <= 160 * 1024) lds = g_ax_lds;
     if (!(ctx->attr_mask & VN_ATTR_ATTN_X3)) {
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -411,37 +331,16 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<3, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<3, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->attr_mask |= VN_ATTR_ATTN_X3;
     }
     const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
-    static const int abl_env = [] { const char* e = getenv("VN_ATTN_X3_ABL"); return e ? atoi(e) & 127 : 0; }();   // tuning only
+    // four waves (128 queries) per block, three blocks per CU (LDS: 2 x 24 KiB stages + the bias table; 168 VGPRs).  Measured
+    // alternatives (profiles/r02_attention_x3_kernel_times.txt): six waves (one round of 480 blocks at B = 8) 119 vs 112 us,
+    // two waves no better at any batch size.
+    static const int abl_env = [] { const char* e = getenv("VN_ATTN_X3_ABL"); return e ? atoi(e) & 31 : 0; }();   // tuning only
     static const int stagger_env = [] { const char* e = getenv("VN_ATTN_X3_STAGGER"); return e ? atoi(e) : 0; }();
-    static const int nw_env = [] { const char* e = getenv("VN_ATTN_X3_NW"); return e ? atoi(e) : 0; }();           // 3 / 4 forced, 0 by shape
-    int abl = g_ax_abl >= 0 ? g_ax_abl : abl_env;
+    const int abl = g_ax_abl >= 0 ? g_ax_abl : abl_env;
     const int stagger = g_ax_stagger >= 0 ? g_ax_stagger : stagger_env;
-    // block shape: 96-query blocks (four per CU) when they take fewer rounds x block length than 128-query blocks (three per CU);
-    // abl bit 5 / 6 force 96 / 128 (A/B), the other variant bits exist for 128-query blocks only
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) cus = 256;
-    const long b4 = (long)vn_cdiv(T, 128) * H * B, b3 = (long)vn_cdiv(T, 96) * H * B;
-    const long cost4 = ((b4 + 3L * cus - 1) / (3L * cus)) * 128, cost3 = ((b3 + 4L * cus - 1) / (4L * cus)) * 96;
-    bool three = lds3 <= 40 * 1024 && cost3 < cost4;
-    if (nw_env == 3 || (abl & 32)) three = lds3 <= 80 * 1024;
-    if (nw_env == 4 || (abl & 64)) three = false;
-    abl &= 31;
-    if (three && (abl == 0 || abl == 16)) {
-        if (abl == 16)
-            hipLaunchKernelGGL((vn_attention_x3_kernel<3, 16>), dim3((unsigned)b3), dim3(192), lds3, s, q16, k16, plane_qk, vt16, plane_vt, relbias_full,
-                               out, out16, plane16, B, H, T, stagger, g_ax_trace);
-        else
-            hipLaunchKernelGGL((vn_attention_x3_kernel<3, 0>), dim3((unsigned)b3), dim3(192), lds3, s, q16, k16, plane_qk, vt16, plane_vt, relbias_full,
-                               out, out16, plane16, B, H, T, stagger, g_ax_trace);
-        vn_prof_post(ctx, pi, s);
-        VN_LAUNCH_CHECK(ctx);
-        return VN_OK;
-    }
 #define AX_GO(A) hipLaunchKernelGGL((vn_attention_x3_kernel<4, A>), dim3(vn_cdiv(T, 128) * H * B), dim3(256), lds, s, q16, k16, plane_qk, vt16, \
                                     plane_vt, relbias_full, out, out16, plane16, B, H, T, stagger, g_ax_trace)
     switch (abl) {
