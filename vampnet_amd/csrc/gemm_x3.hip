@@ -615,7 +615,13 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
         const int abl = g_x3_abl >= 0 ? g_x3_abl : abl_env;
         if (abl) {
             const bool big = bm == 256;
-            if (abl == 1) rc = big ? x3_go<VN_EPI_STORE, 2, 1>(ctx, a, 1, s) : x3_go<VN_EPI_STORE, 1, 1>(ctx, a, 1, s);
+            if (bm == 192) {
+                if (abl == 1) rc = x3_go<VN_EPI_STORE, 3, 1>(ctx, a, 1, s);
+                else if (abl == 2) rc = x3_go<VN_EPI_STORE, 3, 2>(ctx, a, 1, s);
+                else if (abl == 3) rc = x3_go<VN_EPI_STORE, 3, 3>(ctx, a, 1, s);
+                else rc = x3_go<VN_EPI_STORE, 3, 4>(ctx, a, 1, s);
+            }
+            else if (abl == 1) rc = big ? x3_go<VN_EPI_STORE, 2, 1>(ctx, a, 1, s) : x3_go<VN_EPI_STORE, 1, 1>(ctx, a, 1, s);
             else if (abl == 2) rc = big ? x3_go<VN_EPI_STORE, 2, 2>(ctx, a, 1, s) : x3_go<VN_EPI_STORE, 1, 2>(ctx, a, 1, s);
             else if (abl == 3) rc = big ? x3_go<VN_EPI_STORE, 2, 3>(ctx, a, 1, s) : x3_go<VN_EPI_STORE, 1, 3>(ctx, a, 1, s);
             else rc = big ? x3_go<VN_EPI_STORE, 2, 4>(ctx, a, 1, s) : x3_go<VN_EPI_STORE, 1, 4>(ctx, a, 1, s);
@@ -681,7 +687,8 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
             return rc;
         if ((rc = x3_attrs_abl<1, 1>(ctx)) || (rc = x3_attrs_abl<1, 2>(ctx)) || (rc = x3_attrs_abl<1, 3>(ctx)) ||
             (rc = x3_attrs_abl<2, 1>(ctx)) || (rc = x3_attrs_abl<2, 2>(ctx)) || (rc = x3_attrs_abl<2, 3>(ctx)) ||
-            (rc = x3_attrs_abl<1, 4>(ctx)) || (rc = x3_attrs_abl<2, 4>(ctx)))
+            (rc = x3_attrs_abl<1, 4>(ctx)) || (rc = x3_attrs_abl<2, 4>(ctx)) || (rc = x3_attrs_abl<3, 1>(ctx)) ||
+            (rc = x3_attrs_abl<3, 2>(ctx)) || (rc = x3_attrs_abl<3, 3>(ctx)) || (rc = x3_attrs_abl<3, 4>(ctx)))
             return rc;
         ctx->attr_mask |= VN_ATTR_GEMM_X3;
     }

@@ -235,7 +235,7 @@ int vn_launch_sample(vn_ctx* ctx, const vn_sample_args& a, hipStream_t s) {
 //   mask_n = conf_n < sorted(conf)[k]   <=>   #{ j : conf_j <= conf_n } <= k      (strict '<', ties stay)
 // The count form needs no sort and reproduces torch's tie semantics exactly; only currently-masked
 // positions can be re-masked (conf = +inf elsewhere), so only those are ranked: O(N * N_masked) LDS
-// broadcast reads, N <= 2300 (coarse) / 1730 (c2f).
+// broadcast reads, N <= 2300 (coarse) / 1730 (c2f); up to four blocks per item, each deciding a slice of the positions.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void vn_remask_kernel(vn_remask_args a) {
     extern __shared__ __attribute__((aligned(16))) float conf[];
@@ -276,7 +276,11 @@ __global__ __launch_bounds__(1024) void vn_remask_kernel(vn_remask_args a) {
     if (k > N - 1) k = N - 1;
     if (k < 0) k = 0;
 
-    for (int n = tid; n < N; n += 1024) {
+    // gridDim.y blocks share an item: every block ranks against the whole conf[] (recomputed per block: N cheap evaluations) but
+    // decides only its own slice of positions — the O(N^2) counting is what takes the time and one block per item left 248 CUs idle
+    const int chunk = (N + gridDim.y - 1) / gridDim.y;
+    const int n_lo = blockIdx.y * chunk, n_hi = n_lo + chunk < N ? n_lo + chunk : N;
+    for (int n = n_lo + tid; n < n_hi; n += 1024) {
         const float cn = conf[n];
         const int t = n / Cp, c = n - t * Cp;
         const size_t zi = ((size_t)b * a.C + a.n_cond + c) * a.T + t;
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(1024) void vn_remask_kernel(vn_remask_args a) {
         a.z[zi] = remask ? a.V : tok;
         if (a.out_sampled) a.out_sampled[zi] = tok;
     }
-    if (a.out_sampled && a.n_cond > 0) {
+    if (a.out_sampled && a.n_cond > 0 && blockIdx.y == 0) {
         const int nc = a.n_cond * a.T;
         for (int i = tid; i < nc; i += 1024) {
             const size_t zi = (size_t)b * a.C * a.T + i;
@@ -309,7 +313,8 @@ int vn_launch_remask(vn_ctx* ctx, const vn_remask_args& a, hipStream_t s) {
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
         ctx->attr_mask |= VN_ATTR_REMASK;
     }
-    hipLaunchKernelGGL(vn_remask_kernel, dim3(a.B), dim3(1024), lds, s, a);
+    const int slices = N >= 2048 ? 4 : (N >= 512 ? 2 : 1);          // <= 1024 positions per block: one per thread
+    hipLaunchKernelGGL(vn_remask_kernel, dim3(a.B, slices), dim3(1024), lds, s, a);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
 }
