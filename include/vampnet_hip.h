@@ -384,7 +384,7 @@ int vn_debug_graph_replays(const vn_model* model, int64_t* count);
 /* tuning hook (scripts/gemm_sweep.py): force the GEMM block tile (bm x bn in {128,64}^2; 0,0 = automatic) and the
  * tile walk order (0 column-major, 1 grouped 8-row patches, -1 keep).  Process-global; not for production use.   */
 int vn_debug_gemm_config(int bm, int bn, int order);
-/* same for the bf16x3 GEMM (gemm_x3.hip): bm = tile height 128 / 192 / 256 (0 = VN_X3_BM / by shape); splitk 0/1 off, 2/4 forced,
+/* same for the bf16x3 GEMM (gemm_x3.hip): bm = tile height 128 / 192 / 256 (0 = VN_X3_BM / by shape; the GEGLU epilogue has no 192-row form and takes 128 then); splitk 0/1 off, 2/4 forced,
  * -1 = cost model; abl = ablation bits (tuning; results invalid), -1 = none                                              */
 int vn_debug_x3_config(int bm, int splitk, int abl);
 /* bf16x3 models: 1 / 0 = always / never take the split-plane attention path (QKV GEMM with the plane epilogue + attention_x3.hip),
