@@ -185,6 +185,7 @@ extern "C" void vn_model_destroy(vn_model* m) {
     (void)hipFree(m->ksched);
     (void)hipFree(m->y16);
     (void)hipFree(m->g16);
+    (void)hipFree(m->w_tiled);
     (void)hipFree(m->qk16);
     (void)hipFree(m->vt16);
     delete m;
@@ -262,6 +263,11 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
         a.A = bf ? (const float*)A16 : A32;
         a.W = bf ? W16(id, layer) : W(m, id, layer);
         a.bf16 = gm; a.a_plane = a_plane; a.w_plane = m->w_plane;
+        static const bool w_tiled_on = [] { const char* e = getenv("VN_X3_WTILED"); return !(e && e[0] == '0'); }();   // A/B runs
+        if (gm == 2 && m->w_tiled && w_tiled_on) {      // bf16x3: the tiled image of the same weight planes
+            a.W = (const float*)(m->w_tiled + 3 * vn_tensor_offset(&m->d, id, layer));
+            a.w_tiled = 1;
+        }
     };
     // bf16x3: attention on the bf16 matrix cores too (attention_x3.hip) once there are enough 128-query blocks to fill the chip
     // (>= 1.5 per CU); below that (one or two sequences) the 64-query blocks of the fp32-input MFMA kernel fill it better
@@ -436,6 +442,26 @@ static int set_bf16_planes(vn_model* m, const void* blob16_dev, long w_plane) {
         // keys >= T of a head's last tile are multiplied by P = 0: they must be finite, so start from zeros
         VN_HIP_CHECK(m->ctx, hipMemset(m->vt16, 0, (size_t)3 * m->vt_plane * sizeof(uint16_t)));
         VN_HIP_CHECK(m->ctx, hipMemset(m->qk16, 0, ((size_t)3 * m->qk_plane + 32 * VN_DHEAD) * sizeof(uint16_t)));
+    }
+    if (w_plane > 0) {
+        // the GEMM weight tensors once more as tiled planes (gemm_x3.hip's LDS-DMA then fetches whole cache lines): a setup call,
+        // so simply fence it against whatever stream produced the caller's planes and whatever stream runs the model next
+        int64_t n = 0;
+        vn_weights_size(&m->d, &n);
+        if (!m->w_tiled && (rc = dev_alloc(m->ctx, &m->w_tiled, (size_t)3 * n))) return rc;
+        VN_HIP_CHECK(m->ctx, hipDeviceSynchronize());
+        const uint16_t* planes = (const uint16_t*)blob16_dev;
+        const long D = m->D;
+        auto tile = [&](int id, int layer, long rows, int K) {
+            const long off = vn_tensor_offset(&m->d, id, layer);
+            return vn_launch_tile_planes(m->ctx, planes + off, w_plane, m->w_tiled + 3 * off, rows, K, nullptr);
+        };
+        for (int l = 0; l < m->L; ++l)
+            if ((rc = tile(VN_W_QKV, l, 3 * D, (int)D)) || (rc = tile(VN_W_WO, l, D, (int)D)) || (rc = tile(VN_W_W1, l, 4 * D, (int)D)) ||
+                (rc = tile(VN_W_W2, l, D, (int)(2 * D))))
+                return rc;
+        if ((rc = tile(VN_W_CLS_W, 0, (long)m->Cp * m->d.vocab, (int)D))) return rc;
+        VN_HIP_CHECK(m->ctx, hipDeviceSynchronize());
     }
     m->blob16 = (const uint16_t*)blob16_dev;
     m->w_plane = w_plane;

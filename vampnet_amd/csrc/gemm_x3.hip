@@ -318,9 +318,11 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         // 8 j + wave, so waves 0-3 issue eight and waves 4-7 seven
         auto piece_q = [&](int j) { return CFG == 3 ? 8 * j + wave : wave * G::NPW + j; };
         const uint16_t* src[G::NPW];
+        int kadv[G::NPW];                                   // elements per k-tile: 32 along a planar row, 3 x 512 between tiled pieces
 #pragma unroll
         for (int j = 0; j < G::NPW; ++j) {
             const int q = piece_q(j);
+            kadv[j] = X3_KT;
             if (q < 3 * (G::BM / 16)) {
                 const int pt = q / (G::BM / 16), row = (q % (G::BM / 16)) * 16 + drow;
                 int g = m0 + row;
@@ -331,11 +333,17 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                 const int pt = qb >> 3, row = (qb & 7) * 16 + drow;
                 int g = n0 + row;
                 g = g < p.N ? g : p.N - 1;
-                src[j] = W16 + (size_t)pt * p.w_plane + (size_t)g * p.K + dslot * 8 + kb * X3_KT;
+                if (p.w_tiled && !(ABL & 4)) {          // piece = the contiguous 1 KiB of (row block g / 16, k-tile, plane pt)
+                    src[j] = W16 + (((size_t)(g >> 4) * nk_all + kb) * 3 + pt) * 512 + (g & 15) * 32 + dslot * 8;
+                    kadv[j] = 3 * 512;
+                } else {
+                    src[j] = W16 + (size_t)pt * p.w_plane + (size_t)g * p.K + dslot * 8 + kb * X3_KT;
+                }
             }
         }
-        auto stage_piece = [&](int buf, int k0, int j) {
+        auto stage_piece = [&](int buf, int k0, int j) {       // k0 = 32 x the k-tile index relative to kb
             if constexpr (ABL & 4) k0 = (2 * k0) % p.K;     // a fresh 128-byte line per k-tile (probe: K % 64 == 0, data-parallel form)
+            else k0 = (k0 / X3_KT) * kadv[j];
             if constexpr (CFG == 3) {
                 if (j == G::NPW - 1 && wave >= 4) return;   // 60 = 4 x 8 + 4 x 7 instructions
             }
@@ -708,6 +716,28 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
             return x3_launch<VN_EPI_QKV3>(ctx, a, s);
     }
     return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: unknown epilogue %s%ld", "", epilogue);
+}
+
+// ---- planar planes -> tiled planes (weights at load time): one thread per 16-byte run of a piece row
+__global__ __launch_bounds__(256) void vn_tile_planes_kernel(const uint16_t* __restrict__ planes, long plane, uint16_t* __restrict__ tiled,
+                                                             long rows, int K) {
+    const long n16 = 3L * rows * (K >> 3);                  // 16-byte runs of the output
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n16; i += (long)gridDim.x * 256L) {
+        const long piece = i >> 6;                          // 64 runs per 1 KiB piece
+        const int in_piece = (int)(i & 63), r = in_piece >> 2, slot = in_piece & 3;
+        const int pt = (int)(piece % 3);
+        const long bk = piece / 3, kt = bk % (K >> 5), rb = bk / (K >> 5);
+        *(u32x4*)(tiled + i * 8) = *(const u32x4*)(planes + (size_t)pt * plane + (size_t)(rb * 16 + r) * K + kt * 32 + slot * 8);
+    }
+}
+int vn_launch_tile_planes(vn_ctx* ctx, const uint16_t* planes, long plane, uint16_t* tiled, long rows, int K, hipStream_t s) {
+    if (rows <= 0 || K <= 0 || (rows & 15) || (K & 31) || (plane & 7))
+        return vn_fail(ctx, VN_ERR_INVALID, "tile_planes: rows %% 16, K %% 32, plane %% 8 must be 0 (rows=%s%ld, K=%ld)", "", rows, K);
+    const long n16 = 3L * rows * (K >> 3);
+    const int blocks = (int)((n16 + 255) / 256 < 8192 ? (n16 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(vn_tile_planes_kernel, dim3(blocks), dim3(256), 0, s, planes, plane, tiled, rows, K);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
 }
 
 // ---- plane builder (weights at load time, tests): dst[q][i] = q-th split term of src[i]

@@ -219,6 +219,10 @@ struct vn_gemm_args {
     uint16_t* V16;       // QKV3 epilogue: V^T planes [3][H][ceil(M / 32)][64][32], v_plane elements apart (C16 = q then k planes)
     long v_plane;
     int staged;          // gemm_x3.hip: epilogue through LDS with 16-byte global accesses (set by the launcher when alignment allows)
+    // gemm_x3.hip: W given as TILED planes (vn_launch_tile_planes): the 16-row x 32-k block of each plane is one contiguous 1 KiB piece,
+    // [row / 16][k / 32][plane][row % 16][k % 32] — an LDS-DMA instruction then fetches eight whole cache lines instead of sixteen
+    // half lines (w_plane is ignored)
+    int w_tiled;
     // RESIDUAL epilogue only, optional: the RMSNorm that follows this GEMM in the layer (y = RMSNorm(C) with weight norm_w).  A launch
     // that is split along K runs it inside its reduce pass (vn_splitk_reduce_rmsnorm_kernel) and sets *norm_done = 1; otherwise the
     // caller launches the norm itself.  norm_y16 / norm_plane as vn_launch_rmsnorm's y16 / plane16.
@@ -231,6 +235,8 @@ struct vn_gemm_args {
 };
 int vn_launch_gemm_f32(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);
 int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);      // a.bf16 == 2
+// planar split planes [3][rows][K] (plane elements apart) -> tiled planes [rows / 16][K / 32][3][16][32]; rows % 16 == 0, K % 32 == 0
+int vn_launch_tile_planes(vn_ctx* ctx, const uint16_t* planes, long plane, uint16_t* tiled, long rows, int K, hipStream_t s);
 // C[M][N] (row stride ldc) (+)= sum over the nsplit partial images partial[s][M][N], in fixed order (gemm_f32.hip)
 int vn_launch_splitk_reduce(vn_ctx* ctx, const float* partial, int nsplit, float* C, int M, int N, int ldc, bool residual,
                             hipStream_t s);

@@ -17,6 +17,8 @@ struct vn_model {
     const uint16_t* blob16;
     long w_plane;            // 0: single-plane bf16 fast mode
     uint16_t *y16, *g16;     // sized for three planes
+    // bf16x3: the GEMM weight tensors of blob16 once more as TILED planes (tensor at blob offset o -> 3 o; gemm_x3.hip reads these)
+    uint16_t* w_tiled;
     // bf16x3 attention operands (attention_x3.hip), written by the QKV GEMM epilogues: qk16 = q then k planes
     // [3][2][max_rows * D]; vt16 = blocked V^T planes [3][H * ceil(max_rows / 32) * 64 * 32], zero-filled once
     uint16_t *qk16, *vt16;
