@@ -205,7 +205,11 @@ int vn_gemm_bf16(vn_ctx* ctx, const void* A16, const void* W16, const float* bia
                  int epilogue, void* stream);
 
 /* bf16x3 GEMM as a single op (tests / tuning): A3 [3][M][K] and W3 [3][N][K] split planes (plane strides in elements),
- * fp32 C; epilogues 0..3 as vn_gemm_f32; K % 32 == 0, N % 64 == 0                                                     */
+ * fp32 C; epilogues 0..3 as vn_gemm_f32; K % 32 == 0, N % 64 == 0.  A plane stride of -1 says that operand is given in the
+ * TILED layout the model path uses for weights and activations — [row / 16][k / 32][plane][row % 16][k % 32] bf16, rows padded to
+ * a multiple of 16: the 16-row x 32-k block of a plane is one contiguous 1 KiB piece, i.e. one LDS-DMA instruction of whole
+ * cache lines (vn_model_set_bf16x3 re-lays the weight planes it is given this way; the engine's norm / attention / GEGLU
+ * producers write it directly).                                                                                         */
 int vn_gemm_bf16x3(vn_ctx* ctx, const void* A3, int64_t a_plane, const void* W3, int64_t w_plane, const float* bias,
                    float* C, int M, int N, int K, int epilogue, void* stream);
 

@@ -57,6 +57,16 @@ def test_splitk_reduce_rmsnorm_fused_vs_two_kernels(eng, rows, D, ns):
     assert torch.equal(xf, xr)
     yr = O.rmsnorm(xr, w)
     np.testing.assert_allclose(yf.float().sum(0).numpy(), yr.numpy(), rtol=2e-6, atol=1e-6)
+    if D % 32 == 0:                                    # the tiled plane layout of the model path: the same planes, re-laid
+        for fused in (1, 0):
+            x = x0.cuda().clone()
+            yt = torch.zeros(3 * ((rows + 15) // 16 * 16) * D, dtype=torch.bfloat16, device="cuda")
+            eng.check(eng.lib.vn_debug_splitk_reduce_rmsnorm(eng.handle, part_d.data_ptr(), ns, x.data_ptr(), w_d.data_ptr(),
+                                                             yt.data_ptr(), -1, rows, D, 1e-6, fused, eng.stream()), "reduce_rmsnorm tiled")
+            want = eng.tile3(yf.cuda()).reshape(-1).view(torch.int16)
+            got = yt.view(torch.int16)
+            live = eng.tile3(torch.ones(3, rows, D, dtype=torch.bfloat16, device="cuda")).reshape(-1) != 0     # padded rows are not written
+            assert torch.equal(got[live], want[live])
     assert torch.equal(yf.double().sum(0).float(), yf.float().sum(0))       # planes: exact three-way split of an fp32 value
 
 
@@ -431,6 +441,25 @@ def test_gemm_bf16x3_tiles_agree_bitwise_and_are_race_free(eng):
     odd = torch.empty(M * N + 1, device="cuda")[1:].view(M, N)       # base 4 bytes off a 16-byte boundary -> the direct epilogue
     eng.gemm_bf16x3(a3, w3, out=odd)
     assert torch.equal(odd, outs[128])
+
+
+@pytest.mark.parametrize("M,N,K", [(4600, 3840, 1280), (575, 1280, 2560), (130, 256, 64), (1, 128, 32), (300, 192, 96), (257, 128, 160)])
+def test_gemm_bf16x3_tiled_operands_equal_planar(eng, x3_pipe, M, N, K):
+    """The tiled operand layout ([row / 16][k / 32][plane][16][32]: one LDS-DMA instruction = one contiguous 1 KiB piece; what the
+    model path uses for weights and activations) feeds the same products in the same order as the planar planes: bitwise equal
+    outputs at every tile height, store / bias / residual epilogues."""
+    from vampnet_amd import _lib
+    a3, w3 = eng.split3(_rand((M, K), 3).cuda()), eng.split3((_rand((N, K), 4) / np.sqrt(K)).cuda())
+    at, wt = eng.tile3(a3), eng.tile3(w3)
+    b = _rand((N,), 5).cuda()
+    assert torch.equal(eng.gemm_bf16x3(at, wt, tiled_shape=(M, N, K)), eng.gemm_bf16x3(a3, w3))
+    assert torch.equal(eng.gemm_bf16x3(at, wt, bias=b, epilogue=_lib.EPI_BIAS, tiled_shape=(M, N, K)),
+                       eng.gemm_bf16x3(a3, w3, bias=b, epilogue=_lib.EPI_BIAS))
+    c0 = _rand((M, N), 6).cuda()
+    o1, o2 = c0.clone(), c0.clone()
+    eng.gemm_bf16x3(at, wt, epilogue=_lib.EPI_RESIDUAL, out=o1, tiled_shape=(M, N, K))
+    eng.gemm_bf16x3(a3, w3, epilogue=_lib.EPI_RESIDUAL, out=o2)
+    assert torch.equal(o1, o2)
 
 
 def test_gemm_bf16x3_identity_and_geglu(eng, x3_pipe):

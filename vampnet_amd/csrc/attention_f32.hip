@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void vn_attention_kernel(const float* __restri
             ov[2] = o[2][r] / l_tot;
             ov[3] = o[3][r] / l_tot;
             if (out16) {   // bf16 / bf16x3 modes: the attention output is only the A operand of the fc GEMM
-                vn_store_bf16x4(out16 + ooff + 4 * r, plane16, ov);
+                vn_store_planes4(out16, plane16, (long)b * T + qrow, h * VN_DHEAD + 16 * g + 4 * r, H * VN_DHEAD, ov);
             } else {
                 *(f32x4*)(out + ooff + 4 * r) = ov;
             }

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
                 const f32x4 ov = {o[dt][4 * g] / l_tot, o[dt][4 * g + 1] / l_tot, o[dt][4 * g + 2] / l_tot, o[dt][4 * g + 3] / l_tot};
                 (void)inv;
                 const size_t off = ooff + 32 * dt + 8 * g;
-                if (out16) vn_store_bf16x4(out16 + off, plane16, ov);
+                if (out16) vn_store_planes4(out16, plane16, (long)b * T + qrow, h * VN_DHEAD + 4 * hh + 32 * dt + 8 * g, H * VN_DHEAD, ov);
                 else *(f32x4*)(out + off) = ov;
             }
     }

@@ -257,7 +257,10 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
     // bf16x3 mode: the same four operands as three exact split planes each, multiplied on the bf16 matrix cores with
     // fp32-grade accuracy (gemm_x3.hip); everything else is the fp32 path.
     const int gm = bf ? (m->w_plane ? 2 : 1) : 0;                       // vn_gemm_args::bf16
-    const long yp = gm == 2 ? m->max_rows * (long)D : 0, gp = 2 * yp;   // plane strides of y16 / g16
+    // plane strides of y16 / g16: bf16x3 = the tiled layout (whole-line LDS-DMA in gemm_x3.hip), fast mode = one plane
+    static const bool a_tiled_on = [] { const char* e = getenv("VN_X3_ATILED"); return !(e && e[0] == '0'); }();   // A/B runs
+    const long yp = gm == 2 ? (a_tiled_on ? VN_PLANES_TILED : m->max_rows * (long)D) : 0;
+    const long gp = gm == 2 ? (a_tiled_on ? VN_PLANES_TILED : 2 * m->max_rows * (long)D) : 0;
     auto W16 = [&](int id, int layer) { return (const float*)(m->blob16 + vn_tensor_offset(&m->d, id, layer)); };
     auto operands = [&](vn_gemm_args& a, const float* A32, const uint16_t* A16, long a_plane, int id, int layer) {
         a.A = bf ? (const float*)A16 : A32;
@@ -432,8 +435,9 @@ static int set_bf16_planes(vn_model* m, const void* blob16_dev, long w_plane) {
     if (!blob16_dev) { m->blob16 = nullptr; m->w_plane = 0; return VN_OK; }          // back to exact fp32 MFMA
     if (m->D % 64) return vn_fail(m->ctx, VN_ERR_UNSUPPORTED, "bf16 modes need d_model %% 64 == 0%s", "");
     int rc;        // the bf16 A-operand images are sized for three planes in either mode (graphs keep pointing at them)
-    if (!m->y16 && (rc = dev_alloc(m->ctx, &m->y16, (size_t)3 * m->max_rows * m->D))) return rc;
-    if (!m->g16 && (rc = dev_alloc(m->ctx, &m->g16, (size_t)3 * m->max_rows * 2 * m->D))) return rc;
+    const size_t rows16 = ((size_t)m->max_rows + 15) / 16 * 16;        // the tiled layout addresses rows in blocks of 16
+    if (!m->y16 && (rc = dev_alloc(m->ctx, &m->y16, (size_t)3 * rows16 * m->D))) return rc;
+    if (!m->g16 && (rc = dev_alloc(m->ctx, &m->g16, (size_t)3 * rows16 * 2 * m->D))) return rc;
     if (w_plane > 0 && !m->qk16) {        // bf16x3: attention operands as planes (attention_x3.hip)
         m->qk_plane = 2 * m->max_rows * (long)m->D;
         m->vt_plane = (long)m->H * ((m->max_rows + 31) / 32) * (VN_DHEAD * 32);

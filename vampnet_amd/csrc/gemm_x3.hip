@@ -117,8 +117,10 @@ __device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 
                 if (p.C16) {
                     uint16_t t0, t1, t2;
                     vn_split3(o, t0, t1, t2);
-                    uint16_t* d = p.C16 + (size_t)row * p.ldc + ocol;
-                    d[0] = t0; d[p.c_plane] = t1; d[2 * p.c_plane] = t2;
+                    const bool til = p.c_plane == VN_PLANES_TILED;
+                    uint16_t* d = p.C16 + (til ? vn_tiled_off(row, ocol, p.ldc) : (size_t)row * p.ldc + ocol);
+                    const long cp = til ? 512 : p.c_plane;
+                    d[0] = t0; d[cp] = t1; d[2 * cp] = t2;
                 } else {
                     p.C[(size_t)row * p.ldc + ocol] = o;
                 }
@@ -229,8 +231,11 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
                 const int idx = tid + 512 * k;
                 const int q = idx / (RP * 8), R = (idx >> 3) % RP, c8 = (idx & 7) * 8;
                 const int row = m0 + (R >> 5) * 32 * RI + 32 * i + (R & 31), ocol = n0 / 2 + c8;
-                if (row < p.M && 2 * ocol < p.N)
-                    *(u32x4*)(p.C16 + (size_t)q * p.c_plane + (size_t)row * p.ldc + ocol) = *(const u32x4*)(L16 + q * (RP * 64) + R * 64 + c8);
+                if (row < p.M && 2 * ocol < p.N) {
+                    uint16_t* dst = p.c_plane == VN_PLANES_TILED ? p.C16 + vn_tiled_off(row, ocol, p.ldc) + 512 * q
+                                                                 : p.C16 + (size_t)q * p.c_plane + (size_t)row * p.ldc + ocol;
+                    *(u32x4*)dst = *(const u32x4*)(L16 + q * (RP * 64) + R * 64 + c8);
+                }
             }
         } else if constexpr (EPI == VN_EPI_QKV3) {
             const int D = p.H * VN_DHEAD;
@@ -327,7 +332,12 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                 const int pt = q / (G::BM / 16), row = (q % (G::BM / 16)) * 16 + drow;
                 int g = m0 + row;
                 g = g < p.M ? g : p.M - 1;
-                src[j] = A16 + (size_t)pt * p.a_plane + (size_t)g * p.K + dslot * 8 + kb * X3_KT;
+                if (p.a_plane == VN_PLANES_TILED && !(ABL & 4)) {
+                    src[j] = A16 + (((size_t)(g >> 4) * nk_all + kb) * 3 + pt) * 512 + (g & 15) * 32 + dslot * 8;
+                    kadv[j] = 3 * 512;
+                } else {
+                    src[j] = A16 + (size_t)pt * p.a_plane + (size_t)g * p.K + dslot * 8 + kb * X3_KT;
+                }
             } else {
                 const int qb = (q - 3 * (G::BM / 16)) % 24;             // (CFG 3, j = 7, waves 4-7: q >= NQ — never issued)
                 const int pt = qb >> 3, row = (qb & 7) * 16 + drow;
@@ -530,7 +540,8 @@ static int x3_staged_ok(const vn_gemm_args& a) {
     static const bool on = x3_env("VN_X3_STAGED", 1) != 0;
     if (!on) return 0;
     auto al = [](const void* p, uintptr_t m) { return ((uintptr_t)p & (m - 1)) == 0; };
-    if (EPI == VN_EPI_GEGLU) return a.C16 && al(a.C16, 16) && !(a.ldc & 7) && !(a.c_plane & 7) && !(a.N & 15);
+    if (EPI == VN_EPI_GEGLU)
+        return a.C16 && al(a.C16, 16) && !(a.N & 15) && (a.c_plane == VN_PLANES_TILED ? !(a.ldc & 31) : (!(a.ldc & 7) && !(a.c_plane & 7)));
     if (EPI == VN_EPI_QKV3)
         return al(a.C16, 16) && al(a.V16, 16) && !(a.c_plane & 7) && !(a.v_plane & 7) && !(a.qkv_plane & 7) && !((a.H * VN_DHEAD) & 127);
     if (!al(a.C, 16) || (a.N & 3)) return 0;
@@ -685,8 +696,8 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: empty problem%s", "");
     if (a.K % X3_KT) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: K=%s%ld must be a multiple of 32", "", a.K);
     if (a.N % 64) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: N=%s%ld must be a multiple of 64", "", a.N);
-    if (a.a_plane <= 0 || a.w_plane <= 0 || (a.a_plane & 7) || (a.w_plane & 7))
-        return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: plane strides must be positive multiples of 8 elements%s", "");
+    if ((a.a_plane != VN_PLANES_TILED && (a.a_plane <= 0 || (a.a_plane & 7))) || (!a.w_tiled && (a.w_plane <= 0 || (a.w_plane & 7))))
+        return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: plane strides must be positive multiples of 8 elements (or the tiled layout)%s", "");
     if (((uintptr_t)a.A | (uintptr_t)a.W) & 15) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: operands must be 16-byte aligned%s", "");
     if (!(ctx->attr_mask & VN_ATTR_GEMM_X3)) {
         int rc;
@@ -707,7 +718,8 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
             return x3_launch<VN_EPI_BIAS>(ctx, a, s);
         case VN_EPI_RESIDUAL: return x3_launch<VN_EPI_RESIDUAL>(ctx, a, s);
         case VN_EPI_GEGLU:
-            if (a.C16 && a.c_plane <= 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3/geglu: C16 needs c_plane%s", "");
+            if (a.C16 && a.c_plane <= 0 && a.c_plane != VN_PLANES_TILED) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3/geglu: C16 needs c_plane%s", "");
+            if (a.C16 && a.c_plane == VN_PLANES_TILED && (a.ldc & 31)) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3/geglu: tiled planes need ldc %% 32 == 0%s", "");
             return x3_launch<VN_EPI_GEGLU>(ctx, a, s);
         case VN_EPI_QKV: return x3_launch<VN_EPI_QKV>(ctx, a, s);
         case VN_EPI_QKV3:
@@ -767,5 +779,6 @@ extern "C" int vn_gemm_bf16x3(vn_ctx* ctx, const void* A3, int64_t a_plane, cons
     a.A = (const float*)A3; a.W = (const float*)W3; a.bias = bias; a.C = C; a.M = M; a.N = N; a.K = K;
     a.ldc = epilogue == VN_EPI_GEGLU ? N / 2 : N;
     a.bf16 = 2; a.a_plane = a_plane; a.w_plane = w_plane;
+    a.w_tiled = w_plane == VN_PLANES_TILED;               // -1 for either stride: that operand is given in the tiled layout
     return vn_launch_gemm_x3(ctx, a, epilogue, (hipStream_t)stream);
 }

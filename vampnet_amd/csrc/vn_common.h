@@ -56,6 +56,21 @@ __device__ __forceinline__ void vn_store_bf16x4(uint16_t* dst, long plane, const
     }
 }
 
+// Split planes of a [rows][K] GEMM operand come in two layouts: PLANAR, three [rows][K] images `plane` elements apart, and TILED
+// (plane stride VN_PLANES_TILED): [row / 16][k / 32][plane][row % 16][k % 32] — the 16-row x 32-k block of each plane is one
+// contiguous 1 KiB piece = exactly what one LDS-DMA instruction of gemm_x3.hip fetches (eight whole cache lines instead of sixteen
+// half lines from sixteen rows).  The model path uses TILED for weights and activations; PLANAR stays for the single-op test entries
+// and the training GEMMs' on-the-fly splits.
+#define VN_PLANES_TILED (-1L)
+__host__ __device__ __forceinline__ size_t vn_tiled_off(long row, int k, int K) {       // plane 0; plane q: + 512 q
+    return (((size_t)(row >> 4) * (K >> 5) + (k >> 5)) * 3) * 512 + (size_t)((row & 15) * 32 + (k & 31));
+}
+// four consecutive columns col .. col + 3 (col % 4 == 0) of row `row` of a [rows][ld] matrix -> its planes
+__device__ __forceinline__ void vn_store_planes4(uint16_t* base, long plane, long row, int col, int ld, const f32x4& o) {
+    if (plane == VN_PLANES_TILED) vn_store_bf16x4(base + vn_tiled_off(row, col, ld), 512, o);
+    else vn_store_bf16x4(base + (size_t)row * ld + col, plane, o);
+}
+
 #define VN_WAVE 64
 #define VN_DHEAD 64
 

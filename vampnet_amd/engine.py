@@ -123,8 +123,26 @@ class Engine:
         self.check(self.lib.vn_split3_f32(self.handle, x.data_ptr(), out.data_ptr(), n, n, self.stream()), "vn_split3_f32")
         return out
 
-    def gemm_bf16x3(self, a3, w3, bias=None, epilogue=_lib.EPI_STORE, out=None):
-        """fp32-grade GEMM on the bf16 matrix cores: a3 [3,M,K], w3 [3,N,K] split planes -> fp32 out (op)= a @ w.T"""
+    @staticmethod
+    def tile3(planes):
+        """[3, R, K] split planes -> the tiled layout [ceil(R/16), K/32, 3, 16, 32] of gemm_x3.hip (rows zero-padded to 16)."""
+        _, R, K = planes.shape
+        R16 = (R + 15) // 16 * 16
+        if R16 != R:
+            planes = torch.cat([planes, planes.new_zeros(3, R16 - R, K)], dim=1)
+        return planes.reshape(3, R16 // 16, 16, K // 32, 32).permute(1, 3, 0, 2, 4).contiguous()
+
+    def gemm_bf16x3(self, a3, w3, bias=None, epilogue=_lib.EPI_STORE, out=None, tiled_shape=None):
+        """fp32-grade GEMM on the bf16 matrix cores: a3 [3,M,K], w3 [3,N,K] split planes -> fp32 out (op)= a @ w.T.
+        tiled_shape=(M, N, K): a3 / w3 are tile3() images instead."""
+        if tiled_shape is not None:
+            M, N, K = tiled_shape
+            if out is None:
+                out = torch.empty(M, N // 2 if epilogue == _lib.EPI_GEGLU else N, device=a3.device, dtype=torch.float32)
+            self.check(self.lib.vn_gemm_bf16x3(self.handle, a3.data_ptr(), -1, w3.data_ptr(), -1,
+                                               bias.data_ptr() if bias is not None else None, out.data_ptr(), M, N, K, epilogue,
+                                               self.stream()), "vn_gemm_bf16x3")
+            return out
         _, M, K = a3.shape
         N = w3.shape[1]
         if out is None:
