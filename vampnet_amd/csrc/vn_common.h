@@ -66,9 +66,12 @@ __host__ __device__ __forceinline__ size_t vn_tiled_off(long row, int k, int K) 
     return (((size_t)(row >> 4) * (K >> 5) + (k >> 5)) * 3) * 512 + (size_t)((row & 15) * 32 + (k & 31));
 }
 // four consecutive columns col .. col + 3 (col % 4 == 0) of row `row` of a [rows][ld] matrix -> its planes
+// (one call of vn_store_bf16x4 with a selected address / stride: with a call per layout hipcc 7.2 tail-merged the three store
+// sequences of the D = 256 RMSNorm kernel and stored a stale register as the last dword of the planar form)
 __device__ __forceinline__ void vn_store_planes4(uint16_t* base, long plane, long row, int col, int ld, const f32x4& o) {
-    if (plane == VN_PLANES_TILED) vn_store_bf16x4(base + vn_tiled_off(row, col, ld), 512, o);
-    else vn_store_bf16x4(base + (size_t)row * ld + col, plane, o);
+    const bool tiled = plane == VN_PLANES_TILED;
+    const size_t off = tiled ? vn_tiled_off(row, col, ld) : (size_t)row * ld + col;
+    vn_store_bf16x4(base + off, tiled ? 512L : plane, o);
 }
 
 #define VN_WAVE 64
