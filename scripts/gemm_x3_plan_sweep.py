@@ -37,11 +37,11 @@ for _ in range(20):
     eng.gemm(w, w)
 for name, M, N, K, epi in SHAPES:
     g = torch.Generator(device="cuda").manual_seed(0)
-    a3 = eng.split3(torch.randn(M, K, device="cuda", generator=g))
-    w3 = eng.split3(torch.randn(N, K, device="cuda", generator=g) / K ** 0.5)
+    a3 = eng.tile3(eng.split3(torch.randn(M, K, device="cuda", generator=g)))          # the model path's tiled operand layout
+    w3 = eng.tile3(eng.split3(torch.randn(N, K, device="cuda", generator=g) / K ** 0.5))
     bias = torch.randn(N, device="cuda", generator=g)
     out = torch.zeros(M, N // 2 if epi == G else N, device="cuda")
-    fn = lambda: eng.gemm_bf16x3(a3, w3, bias=bias if epi == Bi else None, epilogue=epi, out=out)
+    fn = lambda: eng.gemm_bf16x3(a3, w3, bias=bias if epi == Bi else None, epilogue=epi, out=out, tiled_shape=(M, N, K))
     res = []
     for bm in (128, 192, 256):
         if epi == G and bm == 192:

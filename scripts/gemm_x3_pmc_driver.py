@@ -15,7 +15,7 @@ for (M, N, K, epi) in [(4096, 4096, 4096, _lib.EPI_STORE), (4600, 3840, 1280, _l
     a = torch.randn(M, K, device="cuda")
     w = torch.randn(N, K, device="cuda") / K ** 0.5
     out = torch.zeros(M, N // 2 if epi == _lib.EPI_GEGLU else N, device="cuda")
-    a3, w3 = eng.split3(a), eng.split3(w)
+    a3, w3 = eng.tile3(eng.split3(a)), eng.tile3(eng.split3(w))          # the model path's tiled operand layout
     for _ in range(3):
-        eng.gemm_bf16x3(a3, w3, epilogue=epi, out=out)
+        eng.gemm_bf16x3(a3, w3, epilogue=epi, out=out, tiled_shape=(M, N, K))
 torch.cuda.synchronize()
