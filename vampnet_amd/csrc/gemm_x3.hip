@@ -631,7 +631,8 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
     bool done = false;
     if constexpr (EPI == VN_EPI_STORE) {
         static const int abl_env = x3_env("VN_X3_ABL", 0) & 7;             // ablations (tuning only; results invalid)
-        const int abl = g_x3_abl >= 0 ? g_x3_abl : abl_env;
+        int abl = g_x3_abl >= 0 ? g_x3_abl : abl_env;
+        if (abl == 4 && (a.a_plane == VN_PLANES_TILED || a.w_tiled)) abl = 0;      // the full-line probe re-addresses PLANAR planes only
         if (abl) {
             const bool big = bm == 256;
             if (bm == 192) {
