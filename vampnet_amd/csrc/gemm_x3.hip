@@ -10,11 +10,16 @@
 // cores run bf16 at 16x the fp32-input MFMA rate (MI355X_MICROARCH.md: 2.5 PF vs 157 TF dense), so six passes cost
 // 6/16 of the exact-fp32 kernel's matrix time: the ceiling moves from 157 to ~417 fp32-equivalent TFLOP/s.
 //
-// Kernel: one 512-thread block (8 waves as 4 x 2) per output tile of 128 MI x 128 (MI = 1, 2; wave tile 32 MI x 64), one
-// block per CU, two waves per SIMD.
-//   * k-tile = 32 bf16 = 64 bytes per row.  A stage holds the six plane tiles (3 x 128 MI rows of A, 3 x 128 of W) = 48 / 72
-//     KiB, filled by LDS-DMA (global_load_lds_dwordx4: one wave instruction = 16 rows x 64 B); three (MI = 1) or two
-//     (MI = 2) stages are resident.
+// Kernel: one 512-thread block (8 waves) per output tile of BM x 128, one block per CU, two waves per SIMD; three tile
+// configurations (x3_geo below): 128 x 128 (waves 4 x 2, wave tile 32 x 64), 256 x 128 (4 x 2, 64 x 64) and 192 x 128 (2 x 4,
+// 96 x 32: the height that fills whole rounds of 256 CUs on the model's B = 8 shapes); x3_choose picks height and k-split per launch.
+//   * k-tile = 32 bf16 = 64 bytes per row.  A stage holds the six plane tiles (3 x BM rows of A, 3 x 128 of W) = 48 / 72 / 60
+//     KiB, filled by LDS-DMA (global_load_lds_dwordx4: one wave instruction = 16 rows x 64 B of one plane); three (128 rows) or
+//     two stages are resident.
+//   * Operand layouts in global memory: PLANAR (three [rows][K] images; single-op tests, training splits) or TILED
+//     ([row / 16][k / 32][plane][16][32]: the 16 rows x 64 B of an instruction are ONE contiguous 1 KiB piece, i.e. eight whole
+//     cache lines instead of sixteen half lines from sixteen rows — weights re-laid at load, activations written so by their
+//     producers; +2.6 % / +4.2 % end to end).  The LDS image and the swizzle below are the same for both.
 //   * Loading each plane tile ONCE and using it in two or three of the six products is what separates this kernel
 //     from running a K' = 6K bf16 GEMM over concatenated planes: 6 plane-tile loads per 6 MFMA groups instead of 12.
 //   * LDS image is lane-linear (DMA constraint), so the bank swizzle sits on the SOURCE address: 16-byte slot s of row r
@@ -25,7 +30,7 @@
 //   * Fragment of v_mfma_f32_32x32x16_bf16: lane l holds row l & 31, k = 8 (l >> 5) .. + 7 of the 16-wide step, i.e.
 //     slot 2 s + (l >> 5) of the row for sub-step s in {0, 1}.
 //   * "Ping-pong" schedule: the eight waves form two groups (waves 0-3 / 4-7: one wave of each group on every SIMD) that
-//     run the same step sequence ONE PHASE APART — while a group issues the 12 MI MFMAs of a k-step (s_setprio 1) the other
+//     run the same step sequence ONE PHASE APART — while a group issues the 12 / 24 / 18 MFMAs of a k-step (s_setprio 1) the other
 //     reads its next fragments and issues LDS-DMA; two raw s_barriers per k-step keep the alternation, counted vmcnt keeps
 //     the DMA in flight across them (guide section 5, 8-phase template).  Round-1's lock-step schedule ran 7-12 % slower
 //     (profiles/r02_gemm_x3_schedules.txt).
