@@ -143,9 +143,14 @@ def test_split_plane_attention_path_at_every_tile_height(eng, dims, B, T):
         for bm in (128, 192, 256):
             lib.vn_debug_x3_config(bm, -1, -1)
             outs[bm] = m.forward_codes(codes).clone()
-        lib.vn_debug_attention_x3_force(0)
+        lib.vn_debug_attention_x3_force(0)              # fp32-attention path: the QKV GEMM's fp32 head-major scatter epilogue
+        plains = {}
+        for bm in (128, 192, 256):
+            lib.vn_debug_x3_config(bm, -1, -1)
+            plains[bm] = m.forward_codes(codes).clone()
         lib.vn_debug_x3_config(0, -1, -1)
         plain = m.forward_codes(codes).clone()
+        assert torch.equal(plain, plains[128]) and torch.equal(plain, plains[192]) and torch.equal(plain, plains[256])
     finally:
         lib.vn_debug_attention_x3_force(-1)
         lib.vn_debug_x3_config(0, -1, -1)
