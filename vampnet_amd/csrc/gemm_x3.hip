@@ -77,8 +77,8 @@ __device__ __forceinline__ int x3_xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-__device__ __forceinline__ void x3_tile_coords(int t, int tiles_m, int tiles_n, int& tm, int& tn) {
-    constexpr int GROUP_M = 8;                    // 8 x 8 patches of tiles share A / W panels in one XCD's L2
+__device__ __forceinline__ void x3_tile_coords(int t, int tiles_m, int tiles_n, int& tm, int& tn, int GROUP_M) {
+    // GROUP_M (8): 8-row groups of tiles, so that the tiles an XCD runs together share A / W panels in its L2
     const int per_group = GROUP_M * tiles_n;
     const int grp = t / per_group;
     const int first_m = grp * GROUP_M;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         const int t = x3_xcd_remap(blockIdx.x, gridDim.x);
         const int kb = (int)((long)nk_all * blockIdx.y / gridDim.y), ke = (int)((long)nk_all * (blockIdx.y + 1) / gridDim.y);
         int tm, tn;
-        x3_tile_coords(t, tiles_m, tiles_n, tm, tn);
+        x3_tile_coords(t, tiles_m, tiles_n, tm, tn, p.group_m > 0 ? p.group_m : 8);
         const int m0 = tm * G::BM, n0 = tn * X3_BN;
 
         // per-lane DMA sources: instruction q fills 16 rows of one plane tile at LDS offset q KiB of the stage (A planes first: q <
@@ -559,6 +559,8 @@ template <int EPI, int CFG, int ABL = 0>
 static int x3_go(vn_ctx* ctx, const vn_gemm_args& a_in, int nsplit, hipStream_t s) {
     vn_gemm_args a = a_in;
     a.staged = x3_staged_ok<EPI>(a);
+    static const int group_m_env = x3_env("VN_X3_GROUPM", 0);          // tuning: rows of tiles per walk group (default 8)
+    a.group_m = group_m_env;
     const int tiles_m = vn_cdiv(a.M, x3_geo<CFG>::BM), tiles_n = vn_cdiv(a.N, X3_BN);
     hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, CFG, ABL>), dim3(tiles_m * tiles_n, nsplit), dim3(512), x3_lds_bytes<CFG>(), s, a, tiles_m, tiles_n);
     VN_LAUNCH_CHECK(ctx);

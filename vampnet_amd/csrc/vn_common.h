@@ -241,6 +241,7 @@ struct vn_gemm_args {
     // [row / 16][k / 32][plane][row % 16][k % 32] — an LDS-DMA instruction then fetches eight whole cache lines instead of sixteen
     // half lines (w_plane is ignored)
     int w_tiled;
+    int group_m;         // gemm_x3.hip tuning: rows of tiles per group of the XCD-aware tile walk (0 = 8)
     // RESIDUAL epilogue only, optional: the RMSNorm that follows this GEMM in the layer (y = RMSNorm(C) with weight norm_w).  A launch
     // that is split along K runs it inside its reduce pass (vn_splitk_reduce_rmsnorm_kernel) and sets *norm_done = 1; otherwise the
     // caller launches the norm itself.  norm_y16 / norm_plane as vn_launch_rmsnorm's y16 / plane16.
