@@ -621,3 +621,31 @@ def test_build_mask_device_word_ledger_and_kernel_arithmetic():
             assert np.array_equal(got, ref.numpy()), (ci, B, T)
             nxt = torch.empty(1).uniform_(0, 1).item()                 # the generator stands n_words further
             assert nxt == float(np.float32(int(raw[n_words]) & 0xFFFFFF) * np.float32(2.0 ** -24)), (ci, B, T)
+
+
+def test_tiled_plane_layout_formula():
+    """The tiled operand layout of gemm_x3.hip — vn_tiled_off in csrc/vn_common.h, written by vn_store_planes4 / vn_tile_planes_kernel,
+    read by the GEMM's LDS-DMA — against Engine.tile3 (the permutation the GPU tests build tiled operands with): element (row, k)
+    of plane q sits at (((row >> 4) (K >> 5) + (k >> 5)) 3 + q) 512 + (row & 15) 32 + (k & 31); a DMA piece (16 rows x 32 k of one
+    plane) is 512 consecutive elements = 1 KiB, and a k-tile step is +3 pieces."""
+    from vampnet_amd.engine import Engine
+
+    def tiled_off(row, k, K):
+        return (((row >> 4) * (K >> 5) + (k >> 5)) * 3) * 512 + (row & 15) * 32 + (k & 31)
+
+    for R, K in [(48, 64), (33, 96), (16, 32), (100, 256)]:
+        planes = torch.arange(3 * R * K, dtype=torch.int32).reshape(3, R, K)
+        flat = Engine.tile3(planes).reshape(-1)
+        R16 = (R + 15) // 16 * 16
+        assert flat.numel() == 3 * R16 * K
+        for q in range(3):
+            for row in (0, 1, 15, 16, R - 1):
+                for k in (0, 1, 31, 32, K - 1):
+                    assert int(flat[tiled_off(row, k, K) + 512 * q]) == int(planes[q, row, k]), (R, K, q, row, k)
+        # one piece = the 16 x 32 block of one plane, contiguous
+        piece = flat[tiled_off(16 if R > 16 else 0, 32 if K > 32 else 0, K) + 512:][:512].reshape(16, 32)
+        r0, k0 = (16 if R > 16 else 0), (32 if K > 32 else 0)
+        want = torch.zeros(16, 32, dtype=torch.int32)
+        rows = min(16, R - r0)
+        want[:rows] = planes[1, r0:r0 + rows, k0:k0 + 32]
+        assert torch.equal(piece, want)
