@@ -80,13 +80,14 @@ def cpu_baseline(threads=None, coarse_only=False):
     if threads:
         torch.set_num_threads(threads)
     else:
-        # torch's default (one thread per logical CPU) over-subscribes big hosts: probe a c2f step at a few counts
+        # torch's default (one thread per logical CPU) over-subscribes big hosts.  Probe ONE COARSE sampling step (T = 575: 86 % of
+        # the clip's FLOPs are coarse steps) at a few thread counts and keep the fastest; the c2f steps run at the same count
         best = (1e30, torch.get_num_threads())
         for n in sorted({min(os.cpu_count() or 8, c) for c in (16, 32, 64, 128)}):
             torch.set_num_threads(n)
-            O.generate(fsd, W.C2F_DIMS, cb, z[:, :, :173], m1, sampling_steps=1, seed=0)
+            O.generate(csd, W.COARSE_DIMS, cb, z[:, :4], mask[:, :4], sampling_steps=1, seed=0)
             t0 = time.perf_counter()
-            O.generate(fsd, W.C2F_DIMS, cb, z[:, :, :173], m1, sampling_steps=1, seed=0)
+            O.generate(csd, W.COARSE_DIMS, cb, z[:, :4], mask[:, :4], sampling_steps=1, seed=0)
             dt = time.perf_counter() - t0
             probe.append((n, round(dt, 3)))
             best = min(best, (dt, n))
@@ -110,7 +111,7 @@ def cpu_baseline(threads=None, coarse_only=False):
     what = "12 coarse steps (B=1, T=575)" if coarse_only else "12 coarse steps (T=575) + 4 chunks x 2 c2f steps (T=173), B=1"
     return {"value": tokens / clip_s, "unit": "codec-tokens/s", "cores": cores, "kind": kind,
             "sample": f"one whole clip, not extrapolated: {what} = {clip_s:.2f} s after a 1-step warm-up of each model; "
-                      f"torch {torch.__version__} CPU fp32, {cores} threads (c2f-step probe {probe})",
+                      f"torch {torch.__version__} CPU fp32, {cores} threads (coarse-step probe, s per step: {probe})",
             **_host_facts()}
 
 
@@ -228,6 +229,12 @@ def main():
                     help="vamp = the headline inference path (default); train = BASELINE configs[4] training step")
     ap.add_argument("--lora-only", action="store_true",
                     help="train workload: LoRA-only fine-tuning step (train.py:696) instead of full training")
+    ap.add_argument("--rng", choices=["device", "torch_device"], default="device",
+                    help="device (default) = in-kernel Philox noise; torch_device = seed-exact parity mode: torch's CPU mt19937 stream "
+                         "continued on the GPU (tokens identical to the reference's seeded run), timed at device speed")
+    ap.add_argument("--e2e", action="store_true",
+                    help="time the whole request encode -> build_mask -> vamp -> decode (DAC codec with seeded synthetic weights; "
+                         "codec parity is UNPINNED) instead of vamp() alone, with per-stage ms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--event-stride", type=int, default=8,
@@ -236,13 +243,29 @@ def main():
     if args.config == 1:
         args.coarse_only, args.batch_per_gpu = True, 1
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1) and hand
+        # the same arguments on; rank 0 of the children prints the JSON line
+        import socket
+        import subprocess
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus and os.environ.get("VN_BENCH_ONE_GPU") != "1":
+            raise SystemExit(f"--gpus {args.gpus}: only {ndev} device(s) visible (VN_BENCH_ONE_GPU=1 runs the {args.gpus} ranks on "
+                             "device 0 with a gloo exchange: exercises the sharded path, measures nothing about scaling)")
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-        args.gpus = world
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # debugging aid (single-GPU boxes): VN_BENCH_ONE_GPU=1 maps every rank to cuda:0 and uses gloo for the exchange
     one_gpu = os.environ.get("VN_BENCH_ONE_GPU") == "1"
     dev_index = 0 if one_gpu else local_rank
@@ -257,6 +280,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device(device))     # "nccl" is RCCL on ROCm
         pg = dist.group.WORLD
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
         # build the communicator (rings over xGMI) now, outside any timed region, whatever --warmup is
         _t = torch.ones(1, device=device) if not one_gpu else torch.ones(1)
         dist.all_reduce(_t)
@@ -280,14 +304,24 @@ def main():
     from vampnet_amd.synth import SynthCodec, model_kwargs
 
     cb = W.synth_codebooks()
-    itf = Interface.from_state_dicts(SynthCodec(cb), W.synth_state_dict(W.COARSE_DIMS, 0), model_kwargs(W.COARSE_DIMS),
+    if args.e2e:
+        if world > 1 or args.coarse_only:
+            raise SystemExit("--e2e times the whole single-GPU request (encode -> build_mask -> vamp -> decode)")
+        from vampnet_amd.codec import DacCodec
+        codec = DacCodec(W.synth_dac_state_dict(W.DAC_DEFAULT_CFG, 0), W.DAC_DEFAULT_CFG, device=device)
+    else:
+        codec = SynthCodec(cb)
+    itf = Interface.from_state_dicts(codec, W.synth_state_dict(W.COARSE_DIMS, 0), model_kwargs(W.COARSE_DIMS),
                                      W.synth_state_dict(W.C2F_DIMS, 1), model_kwargs(W.C2F_DIMS), device=device,
-                                     max_batch=args.batch_per_gpu, rng="device", process_group=pg, precision=args.dtype)
+                                     max_batch=args.batch_per_gpu, rng=args.rng, process_group=pg, precision=args.dtype)
     B = args.batch_per_gpu * world
     codes = W.synth_codes(B, 14, 575, seed=2).to(device)
     torch.manual_seed(0)
     mask = itf.build_mask(codes)                # periodic_prompt=7, upper_codebook_mask=3 (hello.py / BASELINE cfg)
     kw = dict(batch_size=B, _sampling_steps=args.coarse_steps, typical_filtering=True)
+    # noise: "device" = one Philox stream per call keyed by device_seed; "torch_device" = the reference's own seeding
+    # (seed= -> torch.manual_seed, transformer.py:718-719), the mt19937 stream continued on the GPU
+    seed_kw = (lambda sd: {"device_seed": sd}) if args.rng == "device" else (lambda sd: {"seed": sd})
 
     def barrier():
         torch.cuda.synchronize()
@@ -310,11 +344,36 @@ def main():
             return torch.cat(full)[:B_].to(z.device)
         itf._allgather_batch = _gather_via_host
 
-    if args.coarse_only:
+    stages = None
+    if args.e2e:
+        # the whole request of hello.py on resident inputs: 10 s of 44.1 kHz audio per item (already resampled / loudness-normalised:
+        # Interface._preprocess is host scipy code and stays outside) -> DAC encode + RVQ -> build_mask -> vamp -> DAC decode
+        audio = 0.1 * torch.randn(B, 1, 575 * codec.hop_length, device=device, generator=torch.Generator(device=device).manual_seed(7))
+
+        def run(seed, sync=None):
+            st = []
+
+            def stage(name, fn):
+                if sync is None:
+                    return fn()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                o = fn()
+                torch.cuda.synchronize()
+                st.append((name, round(1e3 * (time.perf_counter() - t), 3)))
+                return o
+            c = stage("encode", lambda: codec.encode(audio)["codes"])
+            m = stage("build_mask", lambda: itf.build_mask(c))
+            z = stage("vamp", lambda: itf.vamp(c, m, **seed_kw(seed), **kw))
+            stage("decode", lambda: itf.decode(z))
+            if sync is not None:
+                sync.extend(st)
+            return z
+    elif args.coarse_only:
         kw.pop("batch_size")
-        run = lambda seed: itf.coarse_vamp(codes, mask, device_seed=seed, **kw)
+        run = lambda seed: itf.coarse_vamp(codes, mask, **seed_kw(seed), **kw)
     else:
-        run = lambda seed: itf.vamp(codes, mask, device_seed=seed, **kw)
+        run = lambda seed: itf.vamp(codes, mask, **seed_kw(seed), **kw)
     for i in range(args.warmup):
         run(100 + i)
     barrier()
@@ -333,12 +392,18 @@ def main():
         elapsed = float(t.item())
     assert tuple(out.shape) == (B, 14, 575), out.shape   # coarse_vamp also returns all 14 codebooks
     itf.engine.health_check()
+    if args.e2e:                                          # one more, untimed pass with a device sync around every stage
+        stages = []
+        run(args.steps, sync=stages)
 
     if rank == 0:
         tokens = B * (4 * 575 if args.coarse_only else TOKENS_PER_CLIP) * args.steps
+        rng_txt = {"device": "device RNG (Philox)",
+                   "torch_device": "seed-exact parity mode: torch's mt19937 stream continued on the GPU (rng=torch_device)"}[args.rng]
         res = {
             "metric": "codec-tokens/s, coarse vamp (4 codebooks), 10 s clips" if args.coarse_only else
-                      "codec-tokens/s, coarse+c2f vamp(), 10 s clips", "value": tokens / elapsed,
+                      ("codec-tokens/s, whole request: DAC encode + build_mask + coarse+c2f vamp() + DAC decode, 10 s clips" if args.e2e
+                       else "codec-tokens/s, coarse+c2f vamp(), 10 s clips"), "value": tokens / elapsed,
             "unit": "codec-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (random-init weights of the real architecture, "
@@ -348,25 +413,40 @@ def main():
                                     if args.coarse_only else
                                     f"BASELINE configs[2]: Interface.vamp() coarse({args.coarse_steps} steps)+c2f(4x2 steps), "
                                     f"batch {args.batch_per_gpu}/GPU x 10 s @ 44.1 kHz (T=575, 14 codebooks), "
-                                    "typical_filtering=True, device RNG"),
-                       "codec": "outside the timed region (tokens in, tokens out); DAC encode/decode parity is UNPINNED "
+                                    "typical_filtering=True, " + rng_txt),
+                       "codec": ("INSIDE the timed region (--e2e): DAC encode + RVQ and DAC decode on seeded synthetic weights of the "
+                                 "published 44.1 kHz configuration; codec_parity = unpinned (lac sources and weights absent upstream, "
+                                 "HIP == oracle/dac_oracle.py only)") if args.e2e else
+                                "outside the timed region (tokens in, tokens out); DAC encode/decode parity is UNPINNED "
                                 "(lac sources and weights absent) and no codec figure is part of this line",
+                       **({"codec_parity": "unpinned", "stages_ms": dict(stages), "stages_note": "one extra pass with a device "
+                           "synchronise around every stage (the timed passes have none); Interface._preprocess (host resample / LUFS) "
+                           "is outside"} if args.e2e else {}),
+                       "rng": args.rng,
                        "global_batch": B, "coarse_steps": args.coarse_steps,
                        "parallelism": f"batch-shard x{world}" if world > 1 else "single GPU",
+                       **({"ranks": world, "devices": 1 if one_gpu else world,
+                           "exchange": "gloo all_gather staged through the host, every rank on device 0 (VN_BENCH_ONE_GPU=1: exercises "
+                                       "the sharded path on a one-GPU box, says nothing about scaling)" if one_gpu else
+                                       "RCCL all_gather_into_tensor of the (B,14,T) tokens, one rank per GPU"} if world > 1 else {}),
                        "s_per_clip": elapsed / args.steps / B * world,
                        "precision": {"f32": "fp32 operands on the fp32-input MFMA, fp32 accumulate",
                                      "bf16x3": "fp32-grade: each GEMM operand = 3 exact bf16 split planes (sum == fp32 value), 6 bf16-MFMA "
-                                               "products per k-step, fp32 accumulate; attention/norms/softmax/sampling fp32; "
+                                               "products per k-step, fp32 accumulate — the GEMMs (gemm_x3.hip) AND both attention products "
+                                               "(attention_x3.hip; P split in registers); norms / softmax / sampling fp32; "
                                                "same parity bars as f32 (tests/test_gpu_bf16x3.py)",
                                      "bf16": "bf16 GEMM/attention operands (fast mode, not bit-exact)"}[args.dtype]},
         }
         if prof is not None:
             n, ms, fl, gbytes = prof["gemm_bf16"] if args.dtype == "bf16" else prof["gemm"]
             an, ams, afl, _ = prof["attention"]
-            traffic = None      # fabric bytes per launch from the committed rocprofv3 --pmc passes of this same command
-            tpath = os.path.join(ROOT, "profiles", {"f32": "r01_traffic.json", "bf16x3": "r02_traffic_x3.json"}.get(args.dtype, "-"))
-            if os.path.exists(tpath) and world == 1 and args.batch_per_gpu == 8 and not args.coarse_only:
+            # fabric bytes per launch: NOT measured by this run — read from the committed rocprofv3 --pmc passes of this same command
+            traffic = traffic_source = None
+            tname = {"f32": "r01_traffic.json", "bf16x3": "r02_traffic_x3.json"}.get(args.dtype, "-")
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath) and world == 1 and args.batch_per_gpu == 8 and not args.coarse_only and not args.e2e:
                 traffic = json.load(open(tpath))["bytes_per_launch"]
+                traffic_source = f"profiles/{tname} (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command; a constant, not this run)"
             # bf16x3: `achieved` stays ALGORITHMIC (2MNK per GEMM, fp32-equivalent); every such flop costs six bf16-MFMA flops,
             # so the ceiling of this algorithm is the dense bf16 MFMA peak / 6 (the kernel executes 6 x achieved on the pipe)
             peak = {"f32": PEAK_F32_MFMA_TF, "bf16": PEAK_BF16_MFMA_TF, "bf16x3": PEAK_BF16_MFMA_TF / 6.0}[args.dtype]
@@ -375,7 +455,7 @@ def main():
             res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": fl / (ms * 1e-3) / 1e12 if ms else None,
                                "peak": peak, "unit": "TFLOP/s",
                                "frac": (fl / (ms * 1e-3) / 1e12) / peak if ms else None,
-                               "traffic": traffic, "algorithmic_bytes_per_launch": gbytes / n if n else None, "launches": int(n), "avg_launch_us": 1e3 * ms / n if n else None,
+                               "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": gbytes / n if n else None, "launches": int(n), "avg_launch_us": 1e3 * ms / n if n else None,
                                **({"peak_basis": "2500 TF dense bf16 MFMA / 6 plane products per fp32-grade product",
                                    "executed_mfma_tflops": 6.0 * fl / (ms * 1e-3) / 1e12 if ms else None,
                                    # context: the same algorithmic rate against the fp32-input MFMA peak (157.3 TF), the

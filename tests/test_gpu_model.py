@@ -31,8 +31,8 @@ def tiny(eng):
     from vampnet_amd.engine import VampNetModel
     cb = W.synth_codebooks()
     csd, fsd = W.synth_state_dict(W.TINY_COARSE_DIMS, 0), W.synth_state_dict(W.TINY_C2F_DIMS, 1)
-    coarse = VampNetModel(eng, csd, cb, max_batch=4, max_T=575, **model_kwargs(W.TINY_COARSE_DIMS))
-    c2f = VampNetModel(eng, fsd, cb, max_batch=4, max_T=173, **model_kwargs(W.TINY_C2F_DIMS))
+    coarse = VampNetModel(eng, csd, cb, max_batch=4, max_T=575, precision="f32", **model_kwargs(W.TINY_COARSE_DIMS))
+    c2f = VampNetModel(eng, fsd, cb, max_batch=4, max_T=173, precision="f32", **model_kwargs(W.TINY_C2F_DIMS))
     return dict(cb=cb, csd=csd, fsd=fsd, coarse=coarse, c2f=c2f,
                 models=O.OracleModels(csd, W.TINY_COARSE_DIMS, fsd, W.TINY_C2F_DIMS, cb))
 
@@ -70,7 +70,7 @@ def test_forward_full_size_vs_reference_probe(eng, name, dims, T, seed):
     from vampnet_amd.engine import VampNetModel
     g = np.load(os.path.join(G, "forward_full.npz"))
     cb = W.synth_codebooks()
-    model = VampNetModel(eng, W.synth_state_dict(dims, seed), cb, max_batch=1, max_T=T, **model_kwargs(dims))
+    model = VampNetModel(eng, W.synth_state_dict(dims, seed), cb, max_batch=1, max_T=T, precision="f32", **model_kwargs(dims))
     codes = W.synth_codes(1, dims["n_codebooks"], T, seed=11)
     codes[:, dims["n_cond"]:, 1::2] = 1024
     lg = model.forward_codes(codes, layout="native").cpu().reshape(-1, dims["vocab"])
@@ -215,7 +215,7 @@ def test_device_rng_mode_properties(tiny):
 def itf(tiny):
     from vampnet_amd.interface import Interface
     return Interface.from_state_dicts(SynthCodec(tiny["cb"]), tiny["csd"], model_kwargs(W.TINY_COARSE_DIMS),
-                                      tiny["fsd"], model_kwargs(W.TINY_C2F_DIMS), device="cuda:0", max_batch=4)
+                                      tiny["fsd"], model_kwargs(W.TINY_C2F_DIMS), device="cuda:0", max_batch=4, precision="f32")
 
 
 @pytest.mark.parametrize("B,kw", [(1, dict(seed=0, _sampling_steps=4)),
@@ -557,7 +557,7 @@ def test_abi_error_behaviour(eng):
     lib = eng.lib
     dims = W.TINY_COARSE_DIMS
     cb, sd = W.synth_codebooks(), W.synth_state_dict(dims, 0)
-    model = VampNetModel(eng, sd, cb, max_batch=2, max_T=40, **model_kwargs(dims))
+    model = VampNetModel(eng, sd, cb, max_batch=2, max_T=40, precision="f32", **model_kwargs(dims))
     h, st = model.handle, eng.stream()
     z = W.synth_codes(2, 4, 40, seed=1).cuda()
     logits = torch.empty(2, 40, 4, 1024, device="cuda")

@@ -272,7 +272,7 @@ def test_lora_finetune_step_vs_oracle(engine, which, B, T, p):
     # inference on the fine-tuned model == Interface-style load of base + lora.pth (merge at pack time)
     from vampnet_amd.engine import VampNetModel
     from vampnet_amd.synth import model_kwargs
-    ref_model = VampNetModel(engine, full, cb, **model_kwargs(dims), max_batch=B, max_T=T)
+    ref_model = VampNetModel(engine, full, cb, **model_kwargs(dims), max_batch=B, max_T=T, precision="f32")
     assert (ref_model.forward_codes(z_mask) - tr.model.forward_codes(z_mask)).abs().max().item() < 2e-5
     engine.health_check()
 
@@ -365,9 +365,44 @@ def test_checkpoint_resume_and_interface_load(engine, tmp_path, only_lora):
     from vampnet_amd.synth import model_kwargs
     tr3 = _trainer(engine, dims, sd, cb, **kw)
     tr3.load_checkpoint(folder)
-    inf = VampNetModel(engine, sd_ck, cb, **model_kwargs(dims), max_batch=2, max_T=32)
+    inf = VampNetModel(engine, sd_ck, cb, **model_kwargs(dims), max_batch=2, max_T=32, precision="f32")
     zm, _ = tr.make_batch(z, mask=mask)
     assert (inf.forward_codes(zm) - tr3.model.forward_codes(zm)).abs().max().item() < 2e-5
+
+
+def test_full_mode_resume_from_its_own_weights_file(engine, tmp_path):
+    """A full-mode Trainer built from an adapter-less state_dict saves a checkpoint; a FRESH Trainer built from that weights.pth
+    (not from the original state_dict) must load the optimizer file it was written with: the parameter list is the reference
+    model's (adapters included) in both."""
+    import os
+    from vampnet_amd.interface import _load_checkpoint
+    dims = W.TINY_COARSE_DIMS
+    sd, cb = W.synth_state_dict(dims, 0), W.synth_codebooks()
+    sd = {k: v for k, v in sd.items() if "lora_" not in k}
+    kw = dict(max_batch=2, max_T=32, dropout=0.0, seed=5)
+    tr = _trainer(engine, dims, sd, cb, **kw)
+    z = W.synth_codes(2, 4, 32, seed=3).cuda()
+    mask = torch.ones_like(z)
+    mask[:, :, ::3] = 0
+    for _ in range(2):
+        tr.step(z, mask=mask)
+    folder = tr.save_checkpoint(str(tmp_path / "run"), tag="latest")
+    tr.step(z, mask=mask)
+    n_lora = 2 * 5 * dims["n_layers"]
+    assert sum("lora_" in k for k in tr._all_param_names()) == n_lora
+    osd = torch.load(os.path.join(folder, "optimizer.pth"))
+    assert len(osd["param_groups"][0]["params"]) == len(tr._all_param_names())
+    sd_ck, _ = _load_checkpoint(os.path.join(folder, "vampnet", "weights.pth"))
+    assert sum("lora_" in k for k in sd_ck) == n_lora and all(float(v.abs().max()) == 0.0 for k, v in sd_ck.items() if "lora_" in k)
+    tr2 = _trainer(engine, dims, sd_ck, cb, **kw)            # template from the SAVED file
+    tr2.load_checkpoint(folder)
+    assert tr2.steps == 2
+    tr2.step(z, mask=mask)
+    assert torch.equal(tr2.loss, tr.loss)
+    a, b = tr.state_dict(), tr2.state_dict()
+    assert list(a) == list(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
 
 
 def test_zero1_shard_update_equals_full_update(engine):

@@ -649,3 +649,29 @@ def test_tiled_plane_layout_formula():
         rows = min(16, R - r0)
         want[:rows] = planes[1, r0:r0 + rows, k0:k0 + 32]
         assert torch.equal(piece, want)
+
+
+def test_mask_rng_self_check_formulas_hold_on_this_torch():
+    """The word arithmetic DeviceTorchRng.self_check("mask") compares against torch on the GPU box — bernoulli(p tensor) = 24 bits
+    of one word * 2^-24 < p, randint = one word % range, strictly sequential — holds for THIS torch build's CPU generator
+    (the stream here comes from numpy's MT19937 loaded with torch's state)."""
+    import numpy as np
+    from vampnet_amd.torch_rng import parse_torch_rng_state
+    torch.manual_seed(5)
+    torch.rand(100)
+    state, pos = parse_torch_rng_state(torch.get_rng_state())
+    bg = np.random.MT19937()
+    st = bg.state
+    st["state"]["key"] = state.astype(np.uint32)
+    st["state"]["pos"] = pos
+    bg.state = st
+    w = bg.random_raw(60).astype(np.uint32)
+    g = torch.Generator()
+    g.set_state(torch.get_rng_state())
+    p = torch.tensor([0.37, 0.5, 0.93, 1.0] * 12)
+    want_b = torch.bernoulli(p, generator=g)
+    ranges = (7, 575, 173, 13, 1000, 3) * 2
+    want_r = torch.cat([torch.randint(0, r, (1,), generator=g) for r in ranges])
+    u24 = (w[:48] & np.uint32(0xFFFFFF)).astype(np.float32) * np.float32(2.0 ** -24)
+    assert torch.equal(torch.from_numpy((u24 < p.numpy()).astype(np.float32)), want_b)
+    assert torch.equal(torch.from_numpy(w[48:].astype(np.int64) % np.array(ranges, dtype=np.int64)), want_r)

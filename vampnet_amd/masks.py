@@ -178,6 +178,9 @@ def mask_word_ledger(B: int, C: int, T: int, period: int, width: int, dropout: f
     return roll_word, drop_word, n_drop, drop_word + n_drop
 
 
+_warned_host_fallback = False
+
+
 def build_mask_device(engine, z: torch.Tensor, *, rand_mask_intensity=1.0, n_prefix=0, n_suffix=0, periodic_prompt=7,
                       periodic_prompt_width=1, onset_mask=None, dropout=0.0, upper_codebook_mask=3, ncc=0) -> torch.Tensor:
     """build_mask with every draw and the whole composition on the GPU (csrc/elementwise.hip: vn_build_mask_kernel): torch's CPU
@@ -197,7 +200,17 @@ def build_mask_device(engine, z: torch.Tensor, *, rand_mask_intensity=1.0, n_pre
     roll_word, drop_word, n_drop, n_words = mask_word_ledger(B, C, T, period, width, dropout)
     rng = engine.torch_rng()
     rng._producer = torch.cuda.current_stream(dev)
-    rng.load_from_torch()
+    try:
+        rng.load_from_torch("mask")       # checks (once) that this torch build draws bernoulli / randint the way the kernel does
+    except RuntimeError as e:
+        global _warned_host_fallback
+        if not _warned_host_fallback:
+            import warnings
+            warnings.warn(f"build_mask: {e}")
+            _warned_host_fallback = True
+        return build_mask(z, rand_mask_intensity=rand_mask_intensity, n_prefix=n_prefix, n_suffix=n_suffix,
+                          periodic_prompt=periodic_prompt, periodic_prompt_width=periodic_prompt_width, onset_mask=onset_mask,
+                          dropout=dropout, upper_codebook_mask=upper_codebook_mask, ncc=ncc)
     raw = torch.empty(n_words, dtype=torch.int32, device=dev)
     rng._gen(raw.data_ptr(), n_words)
     onset = None

@@ -59,40 +59,69 @@ class DeviceTorchRng:
             self._raw = torch.empty(n_words, dtype=torch.int32, device=self.engine.device)
         return self._raw
 
-    def self_check(self):
-        """Once per process: the device continuation rests on three facts about THIS torch build's CPU generator — exponential_
-        = float(-log1p(-u53)) of consecutive word pairs, uniform_ / bernoulli = the 24-bit formula of one word, randint = word %
-        range, all strictly sequential (tests/test_host_logic.py pins them where the CPU suite runs).  A build that vectorises
-        one of them differently (e.g. an MKL/VSL path) would silently part from the reference, so compare a few dozen device
-        samples with torch's own from a copy of the current generator and refuse to continue on a mismatch."""
-        if DeviceTorchRng._checked:
-            return
-        blob = torch.get_rng_state()
-        g = torch.Generator()
-        g.set_state(blob)
-        want_e = torch.empty(48).exponential_(1, generator=g)
-        want_u = torch.empty(48).uniform_(1e-20, 1.0, generator=g)
-        state, pos = parse_torch_rng_state(blob)
+    def _with_state_copy(self, fn):
+        """Run fn() on a copy of torch's CURRENT generator state loaded into the device stream, then restore the device state."""
+        state, pos = parse_torch_rng_state(torch.get_rng_state())
         keep_state, keep_pos = self.state.clone(), self.pos.clone()
         try:
             self.state.copy_(torch.from_numpy(state.view(np.int32)))
             self.pos.fill_(pos)
-            got_e = self.exponential_(torch.empty(48, device=self.engine.device)).cpu()
-            got_u = self.uniform_(torch.empty(48, device=self.engine.device), 1e-20, 1.0).cpu()
+            return fn()
         finally:
             self.state.copy_(keep_state)
             self.pos.copy_(keep_pos)
-        if not (torch.equal(got_e, want_e) and torch.equal(got_u, want_u)):
+
+    def self_check(self, kind: str = "noise"):
+        """Once per process and per kind: the device continuation rests on facts about THIS torch build's CPU generator —
+        kind "noise" (the sampling loop): exponential_ = float(-log1p(-u53)) of consecutive word pairs, uniform_ = the 24-bit
+        formula of one word; kind "mask" (build_mask): bernoulli(p tensor) = (24 bits of one word) * 2^-24 < p, randint = one
+        word % range — all strictly sequential (tests/test_host_logic.py pins them where the CPU suite runs).  A build that
+        vectorises one of them differently (e.g. an MKL/VSL path) would silently part from the reference, so compare a few dozen
+        device samples with torch's own from a copy of the current generator.  Raises RuntimeError on a mismatch (the caller
+        decides: the mask path falls back to the host twin, the noise path has rng='torch')."""
+        if kind in DeviceTorchRng._checked:
+            return
+        g = torch.Generator()
+        g.set_state(torch.get_rng_state())
+        dev = self.engine.device
+        if kind == "noise":
+            want_e = torch.empty(48).exponential_(1, generator=g)
+            want_u = torch.empty(48).uniform_(1e-20, 1.0, generator=g)
+            got_e, got_u = self._with_state_copy(lambda: (self.exponential_(torch.empty(48, device=dev)).cpu(),
+                                                          self.uniform_(torch.empty(48, device=dev), 1e-20, 1.0).cpu()))
+            ok = torch.equal(got_e, want_e) and torch.equal(got_u, want_u)
+            msg = ("exponential_ / uniform_ differ: use rng='torch' (host-drawn noise) instead of 'torch_device'")
+        elif kind == "mask":
+            # the draws of vampnet/mask.py: torch.bernoulli(p tensor) (linear_random, periodic_mask's coins), torch.randint (roll,
+            # dropout columns) — in the word arithmetic of vn_build_mask_kernel (csrc/elementwise.hip)
+            p = torch.tensor([0.37, 0.5, 0.93, 1.0] * 12)
+            want_b = torch.bernoulli(p, generator=g)
+            want_r = torch.cat([torch.randint(0, r, (1,), generator=g) for r in (7, 575, 173, 13, 1000, 3) * 2])
+
+            def words():
+                raw = torch.empty(48 + 12, dtype=torch.int32, device=dev)
+                self._gen(raw.data_ptr(), raw.numel())
+                return raw.cpu().numpy().view(np.uint32)
+            w = self._with_state_copy(words)
+            u24 = (w[:48] & np.uint32(0xFFFFFF)).astype(np.float32) * np.float32(2.0 ** -24)
+            got_b = torch.from_numpy((u24 < p.numpy()).astype(np.float32))
+            got_r = torch.from_numpy((w[48:].astype(np.int64) % np.array([7, 575, 173, 13, 1000, 3] * 2, dtype=np.int64)))
+            ok = torch.equal(got_b, want_b) and torch.equal(got_r, want_r)
+            msg = ("bernoulli(p tensor) / randint differ: build_mask runs on the host twin instead (VN_MASK_ON_DEVICE=0 selects "
+                   "it explicitly)")
+        else:
+            raise ValueError(kind)
+        if not ok:
             raise RuntimeError("this torch build's CPU generator does not follow the sequential mt19937 formulas the device RNG "
-                               "continues (exponential_ / uniform_ differ): use rng='torch' (host-drawn noise) instead of 'torch_device'")
-        DeviceTorchRng._checked = True
+                               "continues — " + msg)
+        DeviceTorchRng._checked.add(kind)
 
-    _checked = False
+    _checked = set()
 
-    def load_from_torch(self):
+    def load_from_torch(self, kind: str = "noise"):
         if getattr(self, "_producer", None) is None:
             self._producer = torch.cuda.current_stream(self.engine.device)
-        self.self_check()
+        self.self_check(kind)
         self._blob = torch.get_rng_state()
         state, pos = parse_torch_rng_state(self._blob)
         self.state.copy_(torch.from_numpy(state.view(np.int32)))

@@ -62,12 +62,14 @@ class Trainer:
         self.only_lora = only_lora
         # parameter order of the reference model (= model.parameters() = what its AdamW indexes): state_dict order, with the
         # loralib adapters right behind their Linear's weight (lora.Linear registers weight, lora_A, lora_B:
-        # transformer.py:67-68,109-114) — inserted here when the checkpoint does not hold them yet (LoRA mode only)
+        # transformer.py:67-68,109-114).  The reference model ALWAYS has them, so the slots are inserted whether or not this
+        # state_dict holds them and in both modes: optimizer.pth indices then line up with the reference's parameters() and a
+        # Trainer rebuilt from its own weights.pth (full mode writes zero adapters, see state_dict) sees the same list
         self._sd_template = {}
         lora_parents = {f"transformer.layers.{l}.{key}.weight" for l in range(n_layers) for key in LORA_KEYS}
         for k, t in sd.items():
             self._sd_template[k] = (tuple(t.shape), t.dtype)
-            if only_lora and k in lora_parents:
+            if k in lora_parents:
                 name = k[:-len(".weight")]
                 n_out, n_in = t.shape
                 if name + ".lora_A" not in sd:
@@ -117,7 +119,7 @@ class Trainer:
         self.model = VampNetModel(engine, sd, codebooks, n_heads=n_heads, n_layers=n_layers, n_codebooks=n_codebooks,
                                   n_conditioning_codebooks=n_conditioning_codebooks, latent_dim=latent_dim,
                                   embedding_dim=embedding_dim, vocab_size=vocab_size, max_batch=max_batch, max_T=max_T,
-                                  _blob=self.params)
+                                  precision="f32", _blob=self.params)      # f32: split planes of live parameters would go stale
         h = C.c_void_p()
         engine.check(self.lib.vn_train_create(self.model.handle, self.params.data_ptr(), C.byref(h)), "vn_train_create")
         self.handle = h
@@ -518,6 +520,9 @@ class Trainer:
             self._remerge()
         else:
             cb = self._tensor(self.params, _lib.W_EMB_TABLES).view(self.n_codebooks, self.vocab + 1, -1)[:, :self.vocab].cpu()
+            if any("lora_" in k for k in sd):              # adapters of a checkpoint are merged at load, as in the constructor
+                from .checkpoint import merge_lora_state_dict
+                sd = merge_lora_state_dict(sd)
             self.params.copy_(self.pack(sd, cb))
             self.engine.check(self.lib.vn_train_sync(self.handle, self.engine.stream()), "vn_train_sync")
 
@@ -583,7 +588,18 @@ class Trainer:
     def state_dict(self) -> dict:
         if self.only_lora:          # frozen base (as loaded) + the current adapters, like the reference model's state_dict()
             return {**self._base_sd, **self.lora_state_dict()}
-        return self.export(self.params)
+        # full mode: adapters a checkpoint held were merged into the weights at load, so the reference model that loads this
+        # file (it always owns lora_A / lora_B) gets the merged weights with ZERO adapters — the same function, the same
+        # parameter list as optimizer.pth indexes
+        out = self.export(self.params)
+        full = {}
+        for k, (shape, dtype) in getattr(self, "_sd_template", {}).items():
+            if k in out:
+                full[k] = out[k]
+            elif "lora_" in k:
+                full[k] = torch.zeros(shape, dtype=torch.float32)
+        full.update({k: v for k, v in out.items() if k not in full})
+        return full
 
     # ---- LoRA vector <-> loralib naming -------------------------------------------------------------
     def _lora_slot(self, layer, which, ab):
