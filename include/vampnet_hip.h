@@ -382,34 +382,8 @@ int vn_build_mask(vn_ctx* ctx, const uint32_t* raw, const int64_t* onset, int64_
                   int n_prefix, int n_suffix, int period, int width, int64_t roll_word, int64_t drop_word, int n_drop,
                   int ncc, int upper, void* stream);
 
-/* number of forward passes of this model that were served by replaying a captured hipGraph (tests)               */
-int vn_debug_graph_replays(const vn_model* model, int64_t* count);
-
-/* tuning hook (scripts/gemm_sweep.py): force the GEMM block tile (bm x bn in {128,64}^2; 0,0 = automatic) and the
- * tile walk order (0 column-major, 1 grouped 8-row patches, -1 keep).  Process-global; not for production use.   */
-int vn_debug_gemm_config(int bm, int bn, int order);
-/* same for the bf16x3 GEMM (gemm_x3.hip): bm = tile height 128 / 192 / 256 (0 = VN_X3_BM / by shape; the GEGLU epilogue has no 192-row form and takes 128 then); splitk 0/1 off, 2/4 forced,
- * -1 = cost model; abl = ablation bits (tuning; results invalid), -1 = none                                              */
-int vn_debug_x3_config(int bm, int splitk, int abl);
-/* bf16x3 models: 1 / 0 = always / never take the split-plane attention path (QKV GEMM with the plane epilogue + attention_x3.hip),
- * -1 = by occupancy (default; VN_ATTN_X3).  Process-global test hook.                                                      */
-int vn_debug_attention_x3_force(int on);
-/* a RESIDUAL bf16x3 GEMM that is split along K runs the RMSNorm that follows it in the layer inside its reduce pass
- * (vn_splitk_reduce_rmsnorm_kernel); 0 = keep the two kernels apart (A/B tests: both forms are bitwise equal), 1 = fuse,
- * -1 = VN_X3_FUSE_NORM / default (on).  Process-global.                                                             */
-int vn_debug_x3_fuse_norm(int on);
-/* the two forms as single ops (tests): x[rows][D] += sum of partial[s][rows][D], y16 = three split planes (plane16 elements
- * apart) of RMSNorm(x) with weight w; fused != 0 = one kernel, 0 = reduce kernel then norm kernel                      */
-int vn_debug_splitk_reduce_rmsnorm(vn_ctx* ctx, const float* partial, int nsplit, float* x, const float* w, void* y16,
-                                   int64_t plane16, int rows, int D, float eps, int fused, void* stream);
-/* average duration (us) of `iters` launches of the bf16x3 attention kernel alone (planes prepared outside the timed region) */
-int vn_debug_attention_x3_time(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias, float* out,
-                               int B, int H, int T, int iters, float* avg_us, void* stream);
-
-/* tuning hook of the bf16x3 attention kernel (scripts/attn_probe.py; process-global): abl = variant bits (-1 = VN_ATTN_X3_ABL),
- * lds_bytes = dynamic-LDS override (0 = natural; sets the blocks per CU), stagger = start delay per SIMD wave slot in units of 64
- * cycles (-1 = VN_ATTN_X3_STAGGER), trace_dev = uint32 [blocks / 16][8] phase-cycle sums for abl = 16 (NULL = none)            */
-int vn_debug_attention_x3_config(int abl, int lds_bytes, int stagger, void* trace_dev);
+/* Tuning / test hooks (vn_debug_*) are NOT part of this interface: include/vampnet_hip_debug.h.  They act on ONE vn_ctx; nothing in
+ * the library is process-global, so contexts are independent of each other (each must still be driven from one stream at a time). */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,48 @@
+/* vampnet_hip_debug.h — tuning and test hooks of libvampnet_hip.so.  NOT part of the drop-in boundary (include/vampnet_hip.h):
+ * nothing here is needed to run the path, and the ablation settings produce INVALID results by design.
+ *
+ * Every hook takes the vn_ctx it acts on and changes that context only (state: vn_ctx::tune in csrc/vn_common.h; defaults are
+ * read from the environment when the context is created).  A setter bumps the context's tuning epoch, so forward graphs that a
+ * model captured under the previous setting are captured again instead of replaying the old kernels.
+ */
+#ifndef VAMPNET_HIP_DEBUG_H
+#define VAMPNET_HIP_DEBUG_H
+#include "vampnet_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* number of forward passes of this model that were served by replaying a captured hipGraph (tests)               */
+int vn_debug_graph_replays(const vn_model* model, int64_t* count);
+
+/* fp32-input MFMA GEMM (gemm_f32.hip; scripts/gemm_sweep.py): force the block tile (bm x bn in {128,64}^2; 0,0 = automatic) and,
+ * with order >= 0, bits [0] tile walk (0 column-major, 1 grouped 8-row patches), [2:1] scheduler + 1 (0 auto, 1 data-parallel,
+ * 2 stream-K), [15:8] stream-K start stagger + 1; order = -1 keeps walk / scheduler                                  */
+int vn_debug_gemm_config(vn_ctx* ctx, int bm, int bn, int order);
+/* bf16x3 GEMM (gemm_x3.hip): bm = tile height 128 / 192 / 256 (0 = by shape; the GEGLU epilogue has no 192-row form and takes 128
+ * then); splitk 0 / 1 off, 2 / 4 forced, -1 = cost model; abl = ablation bits (tuning; results INVALID), <= 0 = none       */
+int vn_debug_x3_config(vn_ctx* ctx, int bm, int splitk, int abl);
+/* bf16x3 models of this context: 1 / 0 = always / never take the split-plane attention path (QKV GEMM with the plane epilogue +
+ * attention_x3.hip), -1 = whenever its LDS image fits (default; VN_ATTN_X3)                                               */
+int vn_debug_attention_x3_force(vn_ctx* ctx, int on);
+/* a RESIDUAL bf16x3 GEMM that is split along K runs the RMSNorm that follows it in the layer inside its reduce pass
+ * (vn_splitk_reduce_rmsnorm_kernel); 0 = keep the two kernels apart (A/B tests: both forms are bitwise equal), 1 = fuse,
+ * -1 = VN_X3_FUSE_NORM / default (on)                                                                               */
+int vn_debug_x3_fuse_norm(vn_ctx* ctx, int on);
+/* the two forms as single ops (tests): x[rows][D] += sum of partial[s][rows][D], y16 = three split planes (plane16 elements
+ * apart) of RMSNorm(x) with weight w; fused != 0 = one kernel, 0 = reduce kernel then norm kernel                      */
+int vn_debug_splitk_reduce_rmsnorm(vn_ctx* ctx, const float* partial, int nsplit, float* x, const float* w, void* y16,
+                                   int64_t plane16, int rows, int D, float eps, int fused, void* stream);
+/* average duration (us) of `iters` launches of the bf16x3 attention kernel alone (planes prepared outside the timed region) */
+int vn_debug_attention_x3_time(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias, float* out,
+                               int B, int H, int T, int iters, float* avg_us, void* stream);
+/* bf16x3 attention (attention_x3.hip; scripts/attn_probe.py): split = work decomposition (-1 by shape, 0 = 128-query blocks that
+ * share their K / V^T tiles, 1 / 2 / 4 = that many key-split waves per 32-query block); lds_bytes = dynamic-LDS override of the
+ * shared-tile kernel (0 = natural; sets the blocks per CU); stagger = start delay per SIMD wave slot in units of 64 cycles (< 0 = the
+ * context's default); trace_dev = uint32 [blocks / 16][8] phase-cycle sums of the shared-tile kernel (NULL = no trace)          */
+int vn_debug_attention_x3_config(vn_ctx* ctx, int split, int lds_bytes, int stagger, void* trace_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAMPNET_HIP_DEBUG_H */

@@ -19,9 +19,9 @@ for name, M, N, K in [("sq4096", 4096, 4096, 4096), ("sq8192", 8192, 8192, 8192)
     A32, W32 = A.float(), Wt.float()
     row = []
     for sched in (0, 1):
-        eng.lib.vn_debug_gemm_config(0, 0, 1 | ((sched + 1) << 1))
+        eng.lib.vn_debug_gemm_config(eng.handle, 0, 0, 1 | ((sched + 1) << 1))
         us = bench(lambda: eng.gemm_bf16(A, Wt))
         row.append(f"{'SK' if sched else 'DP'} {us:7.1f}us {2.0*M*N*K/us/1e6:7.1f}TF")
-    eng.lib.vn_debug_gemm_config(0, 0, 1)
+    eng.lib.vn_debug_gemm_config(eng.handle, 0, 0, 1)
     us32 = bench(lambda: eng.gemm(A32, W32), 10)
     print(f"{name:9s} bf16: " + " | ".join(row) + f" || f32 auto {us32:7.1f}us {2.0*M*N*K/us32/1e6:6.1f}TF", flush=True)

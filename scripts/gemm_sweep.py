@@ -42,7 +42,7 @@ def bench(fn, iters=20):
 
 
 def cfg(bm, bn, walk, sched):        # sched: -1 auto, 0 data-parallel, 1 stream-K
-    lib.vn_debug_gemm_config(bm, bn, walk | ((sched + 1) << 1))
+    lib.vn_debug_gemm_config(eng.handle, bm, bn, walk | ((sched + 1) << 1))
 
 
 # long warm-up so clocks settle before the first measurement

@@ -23,8 +23,8 @@ for name, M, N, K in [("qkv B8", 4600, 3840, 1280), ("wo B8", 4600, 1280, 1280),
     for bm in (128, 192, 256):
         row = []
         for abl in (0, 1, 2, 3, 4):
-            eng.lib.vn_debug_x3_config(bm, 1, abl if abl else -1)
+            eng.lib.vn_debug_x3_config(eng.handle, bm, 1, abl if abl else -1)
             row.append(timeit(lambda: eng.gemm_bf16x3(a3, w3, out=out)))
-        eng.lib.vn_debug_x3_config(0, -1, -1)
+        eng.lib.vn_debug_x3_config(eng.handle, 0, -1, -1)
         fl = 2.0 * M * N * K
         print(f"{name:14s} bm {bm}: " + "  ".join(f"abl{i} {us:6.1f} us ({fl / us / 1e6:5.1f} TF-eq)" for i, us in enumerate(row)) + f"   full-line gain {100 * (row[0] / row[4] - 1):+.1f} %", flush=True)

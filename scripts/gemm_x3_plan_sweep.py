@@ -49,9 +49,9 @@ for name, M, N, K, epi in SHAPES:
         for ns in ((1, 2, 4) if epi in (S, R) else (1,)):
             if ns > 1 and (K // 32) // ns < 8:
                 continue
-            eng.lib.vn_debug_x3_config(bm, ns, -1)
+            eng.lib.vn_debug_x3_config(eng.handle, bm, ns, -1)
             res.append((timeit(fn), bm, ns))
-    eng.lib.vn_debug_x3_config(0, -1, -1)
+    eng.lib.vn_debug_x3_config(eng.handle, 0, -1, -1)
     auto = timeit(fn)
     best = min(res)
     fl = 2.0 * M * N * K

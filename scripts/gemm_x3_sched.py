@@ -33,7 +33,7 @@ def timeit(fn, n=10):
 
 
 def cfg(p=0, split=-1, abl=-1):
-    eng.check(eng.lib.vn_debug_x3_config(p, split, abl), "vn_debug_x3_config")
+    eng.check(eng.lib.vn_debug_x3_config(eng.handle, p, split, abl), "vn_debug_x3_config")
 
 
 def name_of(p):

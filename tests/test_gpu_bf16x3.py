@@ -97,18 +97,18 @@ def test_fused_splitk_reduce_rmsnorm_is_bitwise_the_two_kernel_form(eng, dims, T
     codes[:, dims["n_cond"]:, ::3] = 1024
     lib = eng.lib
     try:
-        lib.vn_debug_x3_config(0, 2, -1)
-        lib.vn_debug_x3_fuse_norm(1)
+        lib.vn_debug_x3_config(eng.handle, 0, 2, -1)
+        lib.vn_debug_x3_fuse_norm(eng.handle, 1)
         a = m.forward_codes(codes, layout="native").clone()
         a2 = m.forward_codes(codes, layout="native").clone()
-        lib.vn_debug_x3_fuse_norm(0)
+        lib.vn_debug_x3_fuse_norm(eng.handle, 0)
         b = m.forward_codes(codes, layout="native").clone()
         b2 = m.forward_codes(codes, layout="native").clone()
-        lib.vn_debug_x3_config(0, 0, -1)            # no split at all: the residual epilogue + the stand-alone norm
+        lib.vn_debug_x3_config(eng.handle, 0, 0, -1)            # no split at all: the residual epilogue + the stand-alone norm
         c = m.forward_codes(codes, layout="native").clone()
     finally:
-        lib.vn_debug_x3_config(0, -1, -1)
-        lib.vn_debug_x3_fuse_norm(-1)
+        lib.vn_debug_x3_config(eng.handle, 0, -1, -1)
+        lib.vn_debug_x3_fuse_norm(eng.handle, -1)
     print(f"fused vs two-kernel logits: max |d| = {(a - b).abs().max().item():.3e}; run to run: fused {(a - a2).abs().max().item():.3e}, "
           f"two-kernel {(b - b2).abs().max().item():.3e}")
     assert torch.equal(a, a2) and torch.equal(b, b2)
@@ -116,11 +116,11 @@ def test_fused_splitk_reduce_rmsnorm_is_bitwise_the_two_kernel_form(eng, dims, T
     assert (a - c).abs().max().item() <= 2e-5       # split vs unsplit k-order: fp32 re-association only
     sd = W.synth_state_dict(dims, 3)
     ref = O.forward(sd, dims, O.from_codes(sd, cb, codes))
-    lib.vn_debug_x3_config(0, 2, -1)
+    lib.vn_debug_x3_config(eng.handle, 0, 2, -1)
     try:
         got = m.forward_codes(codes).cpu()          # reference layout, fused form
     finally:
-        lib.vn_debug_x3_config(0, -1, -1)
+        lib.vn_debug_x3_config(eng.handle, 0, -1, -1)
     assert (got - ref).abs().max().item() <= TM.LOGIT_ATOL_TINY
 
 
@@ -139,21 +139,21 @@ def test_split_plane_attention_path_at_every_tile_height(eng, dims, B, T):
     lib = eng.lib
     outs = {}
     try:
-        lib.vn_debug_attention_x3_force(1)
+        lib.vn_debug_attention_x3_force(eng.handle, 1)
         for bm in (128, 192, 256):
-            lib.vn_debug_x3_config(bm, -1, -1)
+            lib.vn_debug_x3_config(eng.handle, bm, -1, -1)
             outs[bm] = m.forward_codes(codes).clone()
-        lib.vn_debug_attention_x3_force(0)              # fp32-attention path: the QKV GEMM's fp32 head-major scatter epilogue
+        lib.vn_debug_attention_x3_force(eng.handle, 0)              # fp32-attention path: the QKV GEMM's fp32 head-major scatter epilogue
         plains = {}
         for bm in (128, 192, 256):
-            lib.vn_debug_x3_config(bm, -1, -1)
+            lib.vn_debug_x3_config(eng.handle, bm, -1, -1)
             plains[bm] = m.forward_codes(codes).clone()
-        lib.vn_debug_x3_config(0, -1, -1)
+        lib.vn_debug_x3_config(eng.handle, 0, -1, -1)
         plain = m.forward_codes(codes).clone()
         assert torch.equal(plain, plains[128]) and torch.equal(plain, plains[192]) and torch.equal(plain, plains[256])
     finally:
-        lib.vn_debug_attention_x3_force(-1)
-        lib.vn_debug_x3_config(0, -1, -1)
+        lib.vn_debug_attention_x3_force(eng.handle, -1)
+        lib.vn_debug_x3_config(eng.handle, 0, -1, -1)
     assert torch.equal(outs[128], outs[192]) and torch.equal(outs[128], outs[256])
     ref = O.forward(sd, dims, O.from_codes(sd, cb, codes))
     assert (outs[192].cpu() - ref).abs().max().item() <= TM.LOGIT_ATOL_TINY

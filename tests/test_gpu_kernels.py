@@ -122,17 +122,52 @@ def _attention_ref(q, k, v, table):
     return out.permute(1, 2, 0, 3).reshape(B, T, H * 64)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+# attention_x3.hip has two work decompositions: 128-query blocks that share their K / V^T tiles ("x3/shared") and 32-query blocks
+# whose KS waves walk disjoint key tiles and merge through LDS ("x3/ks1", "x3/ks2", "x3/ks4"); "bf16x3" = the launcher's own choice
+ATTN_FORMS = {"f32": ("f32", None), "bf16x3": ("bf16x3", -1), "x3/shared": ("bf16x3", 0), "x3/ks1": ("bf16x3", 1),
+              "x3/ks2": ("bf16x3", 2), "x3/ks4": ("bf16x3", 4)}
+
+
+def _attention(eng, form, q, k, v, table):
+    precision, split = ATTN_FORMS[form]
+    if split is None:
+        return eng.attention(q, k, v, table, precision=precision)
+    eng.check(eng.lib.vn_debug_attention_x3_config(eng.handle, split, 0, -1, None), "vn_debug_attention_x3_config")
+    try:
+        return eng.attention(q, k, v, table, precision=precision)
+    finally:
+        eng.check(eng.lib.vn_debug_attention_x3_config(eng.handle, -1, 0, -1, None), "vn_debug_attention_x3_config")
+
+
+@pytest.mark.parametrize("form", list(ATTN_FORMS))
 @pytest.mark.parametrize("B,H,T", [(1, 20, 575), (2, 20, 173), (3, 4, 64), (2, 2, 1), (1, 3, 65), (1, 2, 130), (2, 1, 600),
-                                   (1, 2, 32), (1, 1, 33), (2, 3, 128), (1, 2, 129), (1, 1, 97)])
-def test_attention(eng, B, H, T, precision):
-    """both attention kernels (fp32-input MFMA; bf16x3 = six bf16-MFMA products of exact splits) at the SAME tolerance; the T
-    values put the end of the sequence at every position of a 32-key tile and of a 64 / 128-query block"""
+                                   (1, 2, 32), (1, 1, 33), (2, 3, 128), (1, 2, 129), (1, 1, 97), (3, 2, 31)])
+def test_attention(eng, B, H, T, form):
+    """the fp32-input MFMA kernel and every decomposition of the bf16x3 kernel (six bf16-MFMA products of exact splits) at the
+    SAME tolerance; the T values put the end of the sequence at every position of a 32-key tile and of a 32 / 64 / 128-query
+    block, and T = 1 / 31 / 32 leave key-split waves without a tile (their empty partial result must merge as zero weight)"""
     q, k, v = _rand((B, H, T, 64), 10), _rand((B, H, T, 64), 11), _rand((B, H, T, 64), 12)
     table = _rand((32, H), 13)
     ref = _attention_ref(q, k, v, table)
-    got = eng.attention(q.cuda(), k.cuda(), v.cuda(), table.cuda(), precision=precision).cpu()
+    got = _attention(eng, form, q.cuda(), k.cuda(), v.cuda(), table.cuda()).cpu()
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-5, atol=3e-6)
+
+
+def test_attention_x3_decompositions_agree(eng):
+    """shared tiles vs key-split: the same products in a different summation order (per-wave partial sums merged at the end,
+    a per-wave softmax reference) -> equal to fp32 re-association noise, and each form is run-to-run bitwise reproducible
+    (the merge order is fixed)."""
+    B, H, T = 2, 20, 575
+    q, k, v = (_rand((B, H, T, 64), s).cuda() for s in (40, 41, 42))
+    table = _rand((32, H), 43).cuda()
+    outs = {}
+    for form in ("x3/shared", "x3/ks1", "x3/ks2", "x3/ks4"):
+        outs[form] = _attention(eng, form, q, k, v, table)
+        assert torch.equal(outs[form], _attention(eng, form, q, k, v, table)), form
+    for form in ("x3/ks1", "x3/ks2", "x3/ks4"):
+        d = (outs[form] - outs["x3/shared"]).abs().max().item()
+        print(f"{form} vs shared tiles: max |d| = {d:.3e}")
+        assert d < 2e-6
 
 
 def test_attention_bf16x3_forced_rescale_and_large_scores(eng):
@@ -145,18 +180,21 @@ def test_attention_bf16x3_forced_rescale_and_large_scores(eng):
     k[0, 0, 190] = q[0, 0, 7] * 5.0                       # q7 . k190 / 8 ~ 40 above everything else
     k[0, 1, 3] = q[0, 1, 150] * 4.0
     q[0, 1, 20] *= 6.0
+    # a score ramp for one query: +~2 per 32-key tile, ~12 over the sequence — every tile's growth stays under the deferred-max
+    # threshold of attention_x3.hip (P > 1 for a while), the accumulated growth does not (the reference must move eventually)
+    k[0, 0, :, :] += q[0, 0, 9][None, :] * (torch.arange(T, dtype=torch.float32) / T * 1.5)[:, None]
     table = torch.randn(32, H, generator=g)
     s = torch.einsum("bhld,bhtd->bhlt", q.double(), k.double()) / 8.0 + O.compute_bias(table, T).permute(1, 0, 2, 3).double()
     ref = torch.einsum("bhlt,bhtd->bhld", torch.softmax(s, -1), v.double()).permute(0, 2, 1, 3).reshape(B, T, H * 64)
-    for precision in ("f32", "bf16x3"):
-        got = eng.attention(q.cuda(), k.cuda(), v.cuda(), table.cuda(), precision=precision).cpu().double()
+    for form in ATTN_FORMS:
+        got = _attention(eng, form, q.cuda(), k.cuda(), v.cuda(), table.cuda()).cpu().double()
         err = (got - ref).abs().max().item()
-        print(f"{precision}: max |err| vs float64 = {err:.3e}")
+        print(f"{form}: max |err| vs float64 = {err:.3e}")
         assert err < 2e-5
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
-def test_attention_bias_buckets_exact(eng, precision):
+@pytest.mark.parametrize("form", ["f32", "x3/shared", "x3/ks2"])
+def test_attention_bias_buckets_exact(eng, form):
     """q = 0 -> scores are the bias alone; v = one-hot(position) -> output row = softmax(bias) itself,
     which pins every bucket boundary (rel = -574..574) against the oracle table."""
     T, H = 575, 2
@@ -168,7 +206,7 @@ def test_attention_bias_buckets_exact(eng, precision):
         v = torch.zeros(1, H, T, 64)
         n = min(64, T - blk)
         v[0, :, blk:blk + n, :n] = torch.eye(n)
-        got = eng.attention(q.cuda(), k.cuda(), v.cuda(), table.cuda(), precision=precision).cpu().reshape(T, H, 64)
+        got = _attention(eng, form, q.cuda(), k.cuda(), v.cuda(), table.cuda()).cpu().reshape(T, H, 64)
         want = ref_soft[:, :, blk:blk + n].permute(1, 0, 2)
         np.testing.assert_allclose(got[:, :, :n].numpy(), want.numpy(), rtol=1e-5, atol=1e-7)
 
@@ -382,12 +420,12 @@ X3_CONFIGS = [128, 192, 256, 0]
 
 
 def _x3_cfg(eng, bm=0, split=-1, abl=-1):
-    eng.check(eng.lib.vn_debug_x3_config(bm, split, abl), "vn_debug_x3_config")
+    eng.check(eng.lib.vn_debug_x3_config(eng.handle, bm, split, abl), "vn_debug_x3_config")
 
 
 @pytest.fixture(params=X3_CONFIGS, ids=["bm128", "bm192", "bm256", "auto"])
 def x3_pipe(eng, request):
-    """the three tile heights of gemm_x3.hip (and the by-shape default) through the same bodies (process-global tuning hook; reset afterwards)"""
+    """the three tile heights of gemm_x3.hip (and the by-shape default) through the same bodies (tuning hook of the test's context; reset afterwards)"""
     _x3_cfg(eng, request.param)
     yield request.param
     _x3_cfg(eng)
@@ -476,3 +514,39 @@ def test_gemm_bf16x3_identity_and_geglu(eng, x3_pipe):
     w1p = torch.stack([val, gate], dim=1).reshape(4 * D, D)
     got = eng.gemm_bf16x3(eng.split3(x.cuda()), eng.split3(w1p.cuda()), epilogue=_lib.EPI_GEGLU).cpu()
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_two_contexts_tune_independently(eng):
+    """Tuning state lives in vn_ctx (include/vampnet_hip_debug.h): two contexts in one process run DIFFERENT bf16x3 tile heights
+    concurrently on their own streams and give bitwise equal results (the heights add the same products in the same order), and a
+    setting made on one context does not leak into the other."""
+    from vampnet_amd.engine import Engine
+    eng2 = Engine("cuda:0")
+    M, N, K = 1150, 3840, 1280
+    a, w = _rand((M, K), 50).cuda(), (_rand((N, K), 51) / np.sqrt(K)).cuda()
+    a3, w3 = eng.split3(a), eng.split3(w)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    eng.check(eng.lib.vn_debug_x3_config(eng.handle, 128, -1, -1), "vn_debug_x3_config")
+    eng2.check(eng2.lib.vn_debug_x3_config(eng2.handle, 256, -1, -1), "vn_debug_x3_config")
+    try:
+        torch.cuda.synchronize()
+        outs1, outs2 = [], []
+        for _ in range(4):                           # interleaved launches: both contexts in flight at once
+            with torch.cuda.stream(s1):
+                outs1.append(eng.gemm_bf16x3(a3, w3))
+            with torch.cuda.stream(s2):
+                outs2.append(eng2.gemm_bf16x3(a3, w3))
+        torch.cuda.synchronize()
+        for o1, o2 in zip(outs1, outs2):
+            assert torch.equal(o1, outs1[0]) and torch.equal(o2, outs1[0])
+        # context 2 still runs 256-row tiles after context 1 is reset: its ablation-free result is unchanged, and a forced k-split
+        # on context 1 (different summation order) moves ONLY context 1's result
+        eng.check(eng.lib.vn_debug_x3_config(eng.handle, 128, 2, -1), "vn_debug_x3_config")
+        split1 = eng.gemm_bf16x3(a3, w3)
+        same2 = eng2.gemm_bf16x3(a3, w3)
+        torch.cuda.synchronize()
+        assert torch.equal(same2, outs1[0])
+        assert not torch.equal(split1, outs1[0]) and (split1 - outs1[0]).abs().max().item() < 1e-4
+    finally:
+        eng.check(eng.lib.vn_debug_x3_config(eng.handle, 0, -1, -1), "vn_debug_x3_config")
+        eng2.check(eng2.lib.vn_debug_x3_config(eng2.handle, 0, -1, -1), "vn_debug_x3_config")

@@ -99,13 +99,13 @@ SYMBOLS = {
     "vn_build_mask": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64,
                                C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
     "vn_debug_graph_replays": (C.c_int, [_P, C.POINTER(C.c_int64)]),
-    "vn_debug_gemm_config": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "vn_debug_gemm_config": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "vn_debug_attention_x3_time": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
-    "vn_debug_x3_config": (C.c_int, [C.c_int, C.c_int, C.c_int]),
-    "vn_debug_x3_fuse_norm": (C.c_int, [C.c_int]),
-    "vn_debug_attention_x3_force": (C.c_int, [C.c_int]),
+    "vn_debug_x3_config": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    "vn_debug_x3_fuse_norm": (C.c_int, [_P, C.c_int]),
+    "vn_debug_attention_x3_force": (C.c_int, [_P, C.c_int]),
     "vn_debug_splitk_reduce_rmsnorm": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int, _P]),
-    "vn_debug_attention_x3_config": (C.c_int, [C.c_int, C.c_int, C.c_int, _P]),
+    "vn_debug_attention_x3_config": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "vn_attention_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vn_attention_bf16x3": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vn_attention_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

@@ -20,7 +20,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     deps = [os.path.join(CSRC, h) for h in ("vn_common.h", "vn_model.h", "vn_train.h")] + [
-        os.path.join(HERE, "..", "include", "vampnet_hip.h")]
+        os.path.join(HERE, "..", "include", "vampnet_hip.h"), os.path.join(HERE, "..", "include", "vampnet_hip_debug.h")]
     objs, procs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

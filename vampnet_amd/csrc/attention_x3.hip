@@ -15,50 +15,247 @@
 //              aligned runs whatever T is.  Key tiles are therefore aligned to m, not to t: an item's first and last tile
 //              also hold the neighbouring items' tokens, which are masked (P = 0; the buffer is zero-filled once, so every
 //              masked value is finite).
-// Softmax probabilities are split into their three planes in registers (P in [0, 1]: exact).
+// Softmax probabilities are split into their three planes in registers (exact for any fp32 value).
 //
-// Work decomposition: one block per (b, h, q-block of 32 NW queries), XCD-aware 1-D walk; block = NW waves; wave w owns 32 query columns.
+// Per wave: 32 query columns.
 //   S^T[key][q] = K[key][:] . Q[q][:]      A = K tile rows (LDS), B = Q (registers, loaded once)
 //   O^T[d][q]   = V^T[d][key] . P^T[key][q]  A = V^T tile rows (LDS), B = P (the registers the softmax produced)
 // MFMA row rho of S^T is mapped to key swap_bits_2_3(rho) (the A operand simply reads that K row): a lane (query j = lane & 31,
 // half hh = lane >> 5) then holds keys 16 (r >> 3) + 8 hh + (r & 7), r = 0..15 — for each 16-key step of the second product
 // EIGHT CONSECUTIVE keys, i.e. exactly its k-slots of the B operand, and the V^T operand is one 16-byte LDS read.
-// K/V^T tiles (32 keys: 12 + 12 KiB for the three planes) are double-buffered by LDS-DMA (global_load_lds_dwordx4), one
-// barrier per tile.  LDS images are lane-linear, so the bank swizzles sit on the DMA source address:
+// K/V^T tiles (32 keys: 12 + 12 KiB for the three planes) come in by LDS-DMA (global_load_lds_dwordx4).  LDS images are
+// lane-linear, so the bank swizzles sit on the DMA source address:
 //   K rows are 128 B: slot s of row r lives at s ^ ((r >> 1) & 7);  V^T rows are 64 B: s ^ ((r >> 2) & 3)  (both give every
 //   16-lane ds_read_b128 group 16 distinct 16-byte slots of the 256-byte bank row).
+//
+// Two work decompositions (vn_launch_attention_x3 picks by how many blocks exist):
+//   * SHARED tiles (vn_attention_x3_kernel): block = 4 waves = 128 queries of one (b, h); the waves share every K / V^T tile
+//     (double-buffered, one barrier per tile), three blocks per CU.  The many-sequence shape (B >= 4 at T = 575).
+//   * KEY-SPLIT (vn_attention_x3_split_kernel<KS>): block = KS waves that all own the SAME 32 queries and walk DISJOINT key
+//     tiles (wave w: tiles w, w + KS, ...), each staging its own tiles into a wave-private LDS region — no barrier in the main
+//     loop — and the partial (m, l, O) triples are merged through LDS at the end in a fixed order (flash-decoding inside a
+//     block).  One or two sequences: 18 x 20 q-blocks x KS waves fill the chip where 5 x 20 blocks of 128 queries leave 60 % of
+//     the CUs idle, and a wave's serial chain is 19 / KS tiles long instead of 19 (round 2 fell back to the fp32-input MFMA
+//     kernel here: 39.6 us at B = 1).
+//
+// Softmax arithmetic (round 3; the PMC of round 2 showed 7.6 VALU instructions per MFMA against ~4 that ride along for free,
+// profiles/r02_final2_pmc_attention_x3.txt):
+//   * the S^T accumulator is INITIALISED with the bias row (the MFMAs add the products onto it) instead of adding it afterwards;
+//   * the running max is only raised when some score of the tile exceeds it by more than AX_THR (guide T13): P = exp(s - m_ref)
+//     may then be as large as e^AX_THR, which costs nothing here — P is split EXACTLY into three bf16 planes whatever its size
+//     and l / O accumulate in fp32 — and removes the 32 multiplies of O, the exp of the scale and their dependency from all
+//     but the first tiles; when the reference does move, O AND l are rescaled before any P of the tile is formed;
+//   * exp(t) = 2^hi * (1 + d), hi = fl(t log2 e), d = t - hi ln 2 by two fmas (Cody-Waite on the rounded product): the same
+//     fp32-grade accuracy as vn_exp_neg with one instruction less per score.
 // Algorithmic FLOPs: 4*T*T*64 per (b,h); executed on the bf16 pipe: 6x that.
+// History of measured-and-dropped variants (software-pipelined loop, start staggers, 96-query blocks, six-wave blocks, s_setprio):
+// DESIGN.md section 3 and profiles/r02_attention_x3_*.txt.
 #include <type_traits>
 #include "vn_common.h"
 
 #define AX_KT 32                          // keys per tile
 #define AX_PLANE_FLOATS 1024              // one plane tile of K (32 x 128 B) or V^T (64 x 64 B): 4 KiB
 #define AX_STAGE_FLOATS (6 * AX_PLANE_FLOATS)
+#define AX_THR 6.0f                       // the softmax reference max is raised when a tile's max exceeds it by more than this
 
 __device__ __forceinline__ int ax_swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
-// ABL (tuning only): bit 0 = no exp / split (P = bf16(S) in all planes), bit 1 = no S^T MFMAs, bit 2 = no O^T MFMAs (results invalid
-// with bits 0-2); bit 3 = s_setprio 1 around the MFMA phases (off by default: 110.7 vs 112.5 us at B = 8); bit 4 = phase trace: wave 0 of every 16th block accumulates
-// s_memtime deltas per phase over its tiles into trace[block / 16][8] = {wait, barrier, dma issue, qk, softmax, pv, total, hw_id}.
-// stagger (any variant): a block whose waves sit in SIMD wave slot w starts (w % 3) * stagger * 64 cycles late, so that the blocks
-// sharing a CU do not run the same phase at the same time.
-// (Tried and dropped, profiles/r02_attention_x3_phase_order_ab.txt: one VALU phase + one 48-MFMA phase per tile with K staged a
-// tile ahead of V^T — 125 vs 119 us; six- and two-wave blocks; see also r02_attention_x3_kernel_times.txt.
-// Round 2, second half (profiles/r02_attention_x3_probe_*.txt, r02_ubench_mfma_valu_coissue.txt): the phase trace shows a tile
-// costing one wave ~4500 cycles alone (MFMA 1536, ~280 VALU instructions ~1400, LDS / DMA / barrier waits the rest) and ~7400 with
-// three blocks per CU, i.e. the matrix pipe and the VALU are about equally loaded and overlap only partly — the micro-benchmark
-// puts the overlap the hardware gives at <= 4 plain VALU instructions per MFMA and wave for free, ~5 cycles each beyond that.
-// A software-pipelined main loop (S of the next tile and half of PV in the same basic block as the softmax, bitwise equal to
-// this loop, commit 491c2d5) ran 115.5 vs 112.5 us at two blocks per CU (256 VGPRs) and was removed; start staggers by SIMD wave
-// slot change nothing (117.8-118.9 vs 119.9 us); 2 blocks per CU 114.8, 1 block 145 us.  What did pay: DMA sources as a uniform tile
-// base + a fixed per-lane offset (-5 %), no s_setprio (-1.6 %).
-// The tail round (800 blocks of 128 queries on 768 slots: 110.7 us against 88.1 us for the 760 blocks of 19 heads,
-// profiles/r02_attention_x3_tail_round_probe.txt) was attacked with a 96-query block shape (three waves, V^T single-buffered + the
-// T+95-entry window of the bias table = 38.6 KiB, FOUR blocks per CU, 960 blocks = one round, no idle wave; bitwise equal to this
-// shape, commit "96-query block shape"): 104.7 vs 109.6 us kernel-only, but a tile costs a wave 8200 instead of 7200 cycles (second
-// barrier per tile, a third more K / V^T traffic per query) and inside the model it came out even to slower (271.0 vs 269.3 ms per
-// step, profiles/r02_attention_x3_probe_96_vs_128_query_blocks.txt) — removed.)
-template <int NW, int ABL = 0>
+// exp(t) at fp32 grade for t <= AX_THR:  hi = fl(t log2 e), e = 2^hi (v_exp_f32, 1 ulp), d = t - hi ln 2 exactly enough (two
+// fmas against ln 2 = LN2_HI + LN2_LO; |d| < 1e-5, so exp(d) = 1 + d to 1e-10).  !FINITE: t may be -inf (masked key): clamped
+// to -104, where 2^hi flushes to 0.
+template <bool FINITE>
+__device__ __forceinline__ float ax_exp(float t) {
+    if constexpr (!FINITE) t = fmaxf(t, -104.0f);
+    const float hi = t * 1.44269502162933349609375f;
+    const float e = __builtin_amdgcn_exp2f(hi);
+    float d = fmaf(hi, -0.693147182464599609375f, t);
+    d = fmaf(hi, 1.904654323148236e-09f, d);               // ln 2 = 0.69314718246... - 1.9047e-9
+    return fmaf(e, d, e);
+}
+
+// per-wave constants of the fragment reads
+struct ax_lane {
+    int l31, hh;
+    int kOff, kSw;          // K row feeding MFMA row l31 (floats) and its swizzle key; 128-byte rows
+    int vSw;                // rows d = 32 dt + l31: (d >> 2) & 3 == (l31 >> 2) & 3
+};
+__device__ __forceinline__ ax_lane ax_lane_init(int lane) {
+    ax_lane L;
+    L.l31 = lane & 31; L.hh = lane >> 5;
+    const int kr = ax_swap23(L.l31);
+    L.kOff = kr * 32; L.kSw = (kr >> 1) & 7;
+    L.vSw = (L.l31 >> 2) & 3;
+    return L;
+}
+
+// S^T accumulator start: the bias of (key, query) for this lane's 16 keys of the tile whose first key index is key0.
+// FULL: every key of the tile belongs to the item; else keys outside [0, T) read a clamped (finite) entry and are masked later.
+template <bool FULL>
+__device__ __forceinline__ void ax_bias_init(f32x16& sacc, const float* bt, int key0, int hh, int qrow_c, int T) {
+    if constexpr (FULL) {
+        const float* brow = bt + (key0 + 8 * hh - qrow_c + (T - 1));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = brow[16 * (r >> 3) + (r & 7)];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + 16 * (r >> 3) + 8 * hh + (r & 7);
+            const int key_c = key < 0 ? 0 : (key < T ? key : T - 1);
+            sacc[r] = bt[key_c - qrow_c + (T - 1)];
+        }
+    }
+}
+
+// S^T += K . Q^T for the K tile at Ks: four 16-wide d steps x six plane products (smallest terms first)
+__device__ __forceinline__ void ax_qk(f32x16& sacc, const float* Ks, const bf16x8 (&qf)[3][4], const ax_lane& L) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        bf16x8 kf[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            kf[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Ks + p * AX_PLANE_FLOATS + L.kOff + ((2 * s + L.hh) ^ L.kSw) * 4));
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[2][s], sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[0][s], sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[1][s], sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[1][s], sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[0][s], sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][s], sacc, 0, 0, 0);
+    }
+}
+
+// online softmax of one tile (scores incl. bias in sacc): P planes -> pf, reference max / sum, O rescaled when the reference moves.
+// `full` (uniform): every key of the tile belongs to the item.  Only the masking and the clamp inside exp differ between the two
+// cases; the rescale branch and the MFMA phases around this function exist ONCE (two whole copies of the tile code made the
+// register allocator keep two images of O: +32 VGPRs and 32 moves per tile).
+template <bool FULL>
+__device__ __forceinline__ float ax_probs(const f32x16& sacc, bf16x8 (&pf)[3][2], float m_run) {
+    float lsum = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        f32x8 pe;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            pe[e] = ax_exp<FULL>(sacc[8 * s + e] - m_run);
+            lsum += pe[e];
+        }
+        vn_split3_x8(pe, pf[0][s], pf[1][s], pf[2][s]);
+    }
+    return lsum;
+}
+__device__ __forceinline__ void ax_softmax(f32x16& sacc, bf16x8 (&pf)[3][2], float& m_run, float& l_run, f32x16 (&o)[2], int key0,
+                                           int hh, int T, bool full) {
+    if (!full) {                                            // first / last tile: the neighbours' tokens are masked out
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + 16 * (r >> 3) + 8 * hh + (r & 7);
+            sacc[r] = (key >= 0 && key < T) ? sacc[r] : -INFINITY;
+        }
+    }
+    float mx = sacc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));                     // finite: every tile has >= 1 valid key
+    if (!__all(mx - m_run <= AX_THR)) {                     // first tile: m_run = -inf -> taken (alpha = 0 on zeros)
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = vn_exp_neg(m_run - m_new);      // lanes whose reference stays: exp(0) = 1 exactly
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        l_run *= alpha;
+        m_run = m_new;
+    }
+    l_run += full ? ax_probs<true>(sacc, pf, m_run) : ax_probs<false>(sacc, pf, m_run);
+}
+
+// O^T += V^T . P^T for the V^T tile at Vs: two 32-row d tiles x two 16-key steps x six plane products
+__device__ __forceinline__ void ax_pv(f32x16 (&o)[2], const float* Vs, const bf16x8 (&pf)[3][2], const ax_lane& L) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            bf16x8 vf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                vf[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Vs + p * AX_PLANE_FLOATS + (32 * dt + L.l31) * 16 + ((2 * s + L.hh) ^ L.vSw) * 4));
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[2][s], o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], pf[0][s], o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf[1][s], o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[1][s], o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf[0][s], o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[0][s], o[dt], 0, 0, 0);
+        }
+}
+
+// one tile of the main loop from LDS images of K and V^T
+__device__ __forceinline__ void ax_tile(const float* Ks, const float* Vs, const float* bt, const bf16x8 (&qf)[3][4], const ax_lane& L,
+                                        float& m_run, float& l_run, f32x16 (&o)[2], int key0, int qrow_c, int T) {
+    const bool full = key0 >= 0 && key0 + AX_KT <= T;      // uniform
+    f32x16 sacc;
+    bf16x8 pf[3][2];
+    if (full) ax_bias_init<true>(sacc, bt, key0, L.hh, qrow_c, T);
+    else ax_bias_init<false>(sacc, bt, key0, L.hh, qrow_c, T);
+    ax_qk(sacc, Ks, qf, L);
+    ax_softmax(sacc, pf, m_run, l_run, o, key0, L.hh, T, full);
+    ax_pv(o, Vs, pf, L);
+}
+
+// LDS-DMA sources as buffer loads: descriptors over the k planes and the V^T planes, byte offsets of this block's tile 0 in plane 0
+// and the plane strides (all uniform -> SGPRs).  Tile 0 of an item starts at global token row 32 g_lo <= b T: for b > 0 that is
+// inside the previous item's rows of the same head-major image, never in front of the k planes (offset >= 0 for every b, h).
+struct ax_src {
+    __amdgpu_buffer_rsrc_t krs, vrs;
+    unsigned k0, v0, kplane, vplane;
+};
+__device__ __forceinline__ ax_src ax_src_init(const uint16_t* k16, const uint16_t* vt16, long plane_qk, long plane_vt, int b, int h, int H,
+                                              int T, int m_lo, int g_lo, int MT) {
+    ax_src s;
+    s.krs = __builtin_amdgcn_make_buffer_rsrc((void*)k16, 0, 0x7fffffff, 0x00020000);
+    s.vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vt16, 0, 0x7fffffff, 0x00020000);
+    s.k0 = (unsigned)((((long)b * H + h) * T + (g_lo * AX_KT - m_lo)) * (VN_DHEAD * 2));
+    s.v0 = (unsigned)(((long)h * MT + g_lo) * (VN_DHEAD * AX_KT * 2));
+    s.kplane = (unsigned)(plane_qk * 2);
+    s.vplane = (unsigned)(plane_vt * 2);
+    return s;
+}
+// one LDS-DMA wave-instruction: 64 lanes x 16 B from rsrc[voff (per lane) + soff (uniform) + imm] to lds .. + 1 KiB
+template <int IMM = 0>
+__device__ __forceinline__ void ax_dma(__amdgpu_buffer_rsrc_t rsrc, float* lds, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, IMM, 0);
+}
+
+// XCD-aware 1-D walk: blocks with blockIdx % 8 == x run on XCD x; every XCD gets a contiguous eighth of the (b, h, q-block) list,
+// so the q-blocks of a head run on ONE XCD and share its K / V^T tiles in that L2 (with the natural order a head's q-blocks went
+// round-robin over the XCDs and every one of them fetched the head's planes from the fabric: 235 MB per launch at B = 8)
+__device__ __forceinline__ int ax_walk(int bid, int nwg) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int qq = nwg >> 3, rr = nwg & 7;
+    return (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+}
+
+// Q fragments (B operand of S^T = K Q^T): lane (j, hh) holds Q[q_j][16 step + 8 hh .. + 7] of every plane
+__device__ __forceinline__ void ax_load_q(bf16x8 (&qf)[3][4], const uint16_t* Qp, long plane_qk, int qrow_c, int hh) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            qf[p][s] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Qp + (size_t)p * plane_qk + (size_t)qrow_c * VN_DHEAD + 16 * s + 8 * hh));
+}
+
+// normalise and store the 4-column group g of d tile dt of query row qrow:  o[dt][4 g ..] = O[q][32 dt + 8 g + 4 hh ..]
+// (C/D map of the 32x32 MFMA).  The reference divides (softmax), it does not multiply by a reciprocal: keep the division per element
+__device__ __forceinline__ void ax_store4(const f32x4& acc, float l_tot, float* out, uint16_t* out16, long plane16, long row, int h,
+                                          int H, int hh, int dt, int g) {
+    const f32x4 ov = {acc[0] / l_tot, acc[1] / l_tot, acc[2] / l_tot, acc[3] / l_tot};
+    const int col = h * VN_DHEAD + 4 * hh + 32 * dt + 8 * g;
+    if (out16) vn_store_planes4(out16, plane16, row, col, H * VN_DHEAD, ov);
+    else *(f32x4*)(out + (size_t)row * ((size_t)H * VN_DHEAD) + col) = ov;
+}
+
+// ---- shared-tile kernel: block = 4 waves x 32 queries of one (b, h), K / V^T tiles double-buffered for the whole block --------
+// TRACE (tuning): wave 0 of every 16th block accumulates s_memtime deltas per phase over its tiles into
+// trace[block / 16][8] = {wait, barrier, dma issue, tile math, -, -, total, hw_id}.
+template <int NW, bool TRACE = false>
 __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
                                                                     long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
                                                                     const float* __restrict__ bias_full, float* __restrict__ out,
@@ -68,17 +265,9 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
     float* bt = smem + 2 * AX_STAGE_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hh = lane >> 5;
-    // 1-D grid, XCD-aware: blocks with blockIdx % 8 == x run on XCD x; give every XCD a contiguous eighth of the (b, h, q-block)
-    // walk so that the q-blocks of a head run on ONE XCD and share its K / V^T tiles in that L2 (with the natural order a head's
-    // q-blocks went round-robin over the XCDs and every one of them fetched the head's planes from the fabric: 235 MB per launch)
+    const ax_lane L = ax_lane_init(lane);
     const int nqb = (T + NW * 32 - 1) / (NW * 32);
-    int lid;
-    {
-        const int nwg = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        const int qq = nwg >> 3, rr = nwg & 7;
-        lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
-    }
+    const int lid = ax_walk(blockIdx.x, gridDim.x);
     const int qb = lid % nqb, h = (lid / nqb) % H, b = lid / (nqb * H);
     // key tiles of this item in global token rows: tile g holds tokens 32 g .. 32 g + 31, key index t = m - b T
     const int m_lo = b * T;
@@ -86,52 +275,38 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
     const int MT = (B * T + AX_KT - 1) / AX_KT;
     const size_t head = (size_t)b * H + h;
     const uint16_t* Qp = q16 + head * (size_t)T * VN_DHEAD;
-    const uint16_t* Kp = k16 + head * (size_t)T * VN_DHEAD;
-    const uint16_t* Vp = vt16 + ((size_t)h * MT + g_lo) * (VN_DHEAD * AX_KT);
     const int q0 = qb * (NW * 32) + wave * 32;
     const bool active = q0 < T;                         // waves past the end only help with the DMA and the barriers
-    const int qrow = q0 + l31;
+    const int qrow = q0 + L.l31;
     const int qrow_c = qrow < T ? qrow : T - 1;
 
     const int nb = 2 * T - 1;
     for (int i = tid; i < nb; i += NW * 64) bt[i] = bias_full[(size_t)h * nb + i];
 
-    // Q fragments (B operand of S^T = K Q^T): lane (j, hh) holds Q[q_j][16 step + 8 hh .. + 7] of every plane
     bf16x8 qf[3][4];
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            qf[p][s] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Qp + (size_t)p * plane_qk + (size_t)qrow_c * VN_DHEAD + 16 * s + 8 * hh));
+    ax_load_q(qf, Qp, plane_qk, qrow_c, L.hh);
 
     // LDS-DMA: 24 wave-instructions of 1 KiB per stage (K: 3 planes x 4, each 8 rows x 128 B; V^T: 3 planes x 4, each 16 rows x 64 B);
-    // wave w issues piece w of every plane tile.  A piece's source is (uniform plane / tile base) + (a per-lane offset that is the
-    // same for every plane and tile), so a tile costs six scalar adds and no vector address arithmetic.  K rows are NOT clamped to
+    // wave w issues piece w of every plane tile, as buffer loads: descriptor (SGPRs) + ONE per-lane byte offset per operand that
+    // is the same for every plane and tile (VGPR) + a scalar offset for plane / tile — a tile costs six scalar adds, no vector
+    // address arithmetic and two address VGPRs in all (the flat-address form kept six 64-bit per-lane pointers live, which the
+    // register allocator spilled once the softmax changed shape).  K rows are NOT clamped to
     // the item: the rows of a first / last tile that belong to the neighbouring items (or to the q planes in front of / the
     // 32-row padding behind the k planes) are read as they are and masked to -inf before the softmax.
     static_assert(NW == 4, "one piece of every plane tile per wave");
     const int krow = 8 * wave + (lane >> 3), vrow = 16 * wave + (lane >> 2);
     const unsigned kvoff = (unsigned)(krow * VN_DHEAD + ((lane & 7) ^ ((krow >> 1) & 7)) * 8) * 2u;      // bytes inside a K tile
     const unsigned vvoff = (unsigned)(vrow * AX_KT + ((lane & 3) ^ ((vrow >> 2) & 3)) * 8) * 2u;         // bytes inside a V^T tile
-    const char* kbase = (const char*)(Kp + (long)(g_lo * AX_KT - m_lo) * VN_DHEAD);                       // tile 0, plane 0 (key0 <= 0)
-    const char* vbase = (const char*)Vp;
+    const ax_src src = ax_src_init(k16, vt16, plane_qk, plane_vt, b, h, H, T, m_lo, g_lo, MT);
     auto stage = [&](int buf, int kt) {                       // tile kt -> stage buf
         if (kt >= NT) return;
         float* base = smem + buf * AX_STAGE_FLOATS + wave * 256;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            const char* ks = kbase + ((size_t)p * plane_qk * 2 + (size_t)kt * (AX_KT * VN_DHEAD * 2));
-            const char* vs = vbase + ((size_t)p * plane_vt * 2 + (size_t)kt * (VN_DHEAD * AX_KT * 2));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ks + kvoff),
-                                             (__attribute__((address_space(3))) void*)(base + (4 * p) * 256), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vs + vvoff),
-                                             (__attribute__((address_space(3))) void*)(base + (12 + 4 * p) * 256), 16, 0, 0);
+            ax_dma(src.krs, base + (4 * p) * 256, kvoff, src.k0 + p * src.kplane + kt * (AX_KT * VN_DHEAD * 2));
+            ax_dma(src.vrs, base + (12 + 4 * p) * 256, vvoff, src.v0 + p * src.vplane + kt * (VN_DHEAD * AX_KT * 2));
         }
     };
-
-    const int kr = ax_swap23(l31);                      // K row feeding MFMA row l31
-    const int kOff = kr * 32, kSw = (kr >> 1) & 7;      // floats; 128-byte rows
-    const int vSw = (l31 >> 2) & 3;                     // rows d = 32 dt + l31: (d >> 2) & 3 == (l31 >> 2) & 3
 
     float m_run = -INFINITY, l_run = 0.f;
     f32x16 o[2];
@@ -140,121 +315,15 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
 
-    f32x16 sacc;
-    bf16x8 pf[3][2];
-    // ---- S^T = K . Q^T for the tile in stage `kb`: four 16-wide d steps x six plane products (smallest terms first)
-    auto qk_phase = [&](int kb) {
-        const float* Ks = smem + kb * AX_STAGE_FLOATS;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-        if constexpr (ABL & 8) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            bf16x8 kf[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                kf[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Ks + p * AX_PLANE_FLOATS + kOff + ((2 * s + hh) ^ kSw) * 4));
-            if constexpr (ABL & 2) {
-                sacc[s] += (float)kf[0][0] + (float)kf[1][1] + (float)kf[2][2];
-            } else {
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[2][s], sacc, 0, 0, 0);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[0][s], sacc, 0, 0, 0);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[1][s], sacc, 0, 0, 0);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[1][s], sacc, 0, 0, 0);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[0][s], sacc, 0, 0, 0);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][s], sacc, 0, 0, 0);
-            }
-        }
-        if constexpr (ABL & 8) __builtin_amdgcn_s_setprio(0);
-    };
-    // ---- online softmax of tile kt (scores in sacc): P planes -> pf, running max / sum, O rescaled
-    auto softmax_phase = [&](int kt) {
-        float mx = -INFINITY;
-        const int key0 = (g_lo + kt) * AX_KT - m_lo;                   // key index of the tile's first row
-        const float* brow = bt + (key0 + 8 * hh - qrow_c + (T - 1));   // bias of key key0 + 8 hh for this query
-        const bool full = key0 >= 0 && key0 + AX_KT <= T;              // every key of the tile belongs to this item (uniform)
-        if (full) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float x = sacc[r] + brow[16 * (r >> 3) + (r & 7)];   // q was pre-scaled by 1/sqrt(64); += bias
-                sacc[r] = x;
-                mx = fmaxf(mx, x);
-            }
-        } else {                                                       // first / last tile: the neighbours' tokens are masked out
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key0 + 16 * (r >> 3) + 8 * hh + (r & 7);
-                const int key_c = key < 0 ? 0 : (key < T ? key : T - 1);
-                float x = sacc[r] + bt[key_c - qrow_c + (T - 1)];
-                x = (key >= 0 && key < T) ? x : -INFINITY;
-                sacc[r] = x;
-                mx = fmaxf(mx, x);
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);                          // finite: every tile has >= 1 valid key
-        const float alpha = vn_exp_neg(m_run - m_new);                 // first tile: exp(-inf) = 0
-        float lsum = 0.f;
-        auto probs = [&](auto finite) {        // a full tile has no -inf score: exp without the clamp (same value for finite arguments)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                f32x8 pe;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    pe[e] = (ABL & 1) ? sacc[8 * s + e] - m_new : vn_exp_neg<decltype(finite)::value>(sacc[8 * s + e] - m_new);
-                    lsum += pe[e];
-                }
-                if constexpr (ABL & 1) pf[0][s] = pf[1][s] = pf[2][s] = __builtin_convertvector(pe, bf16x8);
-                else vn_split3_x8(pe, pf[0][s], pf[1][s], pf[2][s]);
-            }
-        };
-        if (full) probs(std::true_type{});
-        else probs(std::false_type{});
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
-        if (!__all(alpha == 1.0f)) {                                   // exp(0) = 1 exactly: skipping the multiply changes no bit
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-        }
-    };
-    // ---- O^T += V^T . P^T for the tile in stage `vb`: two 32-row d tiles x two 16-key steps x six plane products
-    auto pv_phase = [&](int vb) {
-        const float* Vs = smem + vb * AX_STAGE_FLOATS + 3 * AX_PLANE_FLOATS;
-        if constexpr (ABL & 8) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                bf16x8 vf[3];
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    vf[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Vs + p * AX_PLANE_FLOATS + (32 * dt + l31) * 16 + ((2 * s + hh) ^ vSw) * 4));
-                if constexpr (ABL & 4) {
-                    o[dt][s] += (float)vf[0][0] * (float)pf[0][s][0] + (float)vf[1][1] * (float)pf[1][s][1] + (float)vf[2][2] * (float)pf[2][s][2];
-                } else {
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[2][s], o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], pf[0][s], o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf[1][s], o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[1][s], o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf[0][s], o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[0][s], o[dt], 0, 0, 0);
-                }
-            }
-        if constexpr (ABL & 8) __builtin_amdgcn_s_setprio(0);
-    };
-
-    if (stagger > 0) {                                      // de-phase the blocks that share this CU
+    if (stagger > 0) {                                      // de-phase the blocks that share this CU (tuning)
         const int slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) % 3;         // HW_REG_HW_ID bits [3:0]: wave slot in the SIMD
         for (int i = 0; i < slot * stagger; ++i) __builtin_amdgcn_s_sleep(1);
     }
-    unsigned long long tr_t = 0;
-    unsigned tr_acc[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long tr_start = 0;
-    const bool tracing = (ABL & 16) && trace && wave == 0 && (lid & 15) == 0;
+    unsigned long long tr_t = 0, tr_start = 0;
+    unsigned tr_acc[4] = {0, 0, 0, 0};
+    const bool tracing = TRACE && trace && wave == 0 && (lid & 15) == 0;
     auto tick = [&](int slot) {
-        if constexpr (ABL & 16) {
+        if constexpr (TRACE) {
             if (tracing) {
                 const unsigned long long now = __builtin_readcyclecounter();
                 tr_acc[slot] += (unsigned)(now - tr_t);
@@ -262,7 +331,7 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
             }
         }
     };
-    if constexpr (ABL & 16) { tr_t = tr_start = __builtin_readcyclecounter(); }
+    if constexpr (TRACE) { tr_t = tr_start = __builtin_readcyclecounter(); }
     stage(0, 0);
     for (int kt = 0; kt < NT; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of tile kt have landed
@@ -272,87 +341,239 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
         stage((kt + 1) & 1, kt + 1);
         tick(2);
         if (!active) continue;
-        qk_phase(kt & 1);
+        const float* St = smem + (kt & 1) * AX_STAGE_FLOATS;
+        ax_tile(St, St + 3 * AX_PLANE_FLOATS, bt, qf, L, m_run, l_run, o, (g_lo + kt) * AX_KT - m_lo, qrow_c, T);
         tick(3);
-        softmax_phase(kt);
-        tick(4);
-        pv_phase(kt & 1);
-        tick(5);
     }
-    if constexpr (ABL & 16) {
+    if constexpr (TRACE) {
         if (tracing && lane == 0) {
             unsigned* t = trace + (lid >> 4) * 8;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) t[i] = tr_acc[i];
+            for (int i = 0; i < 4; ++i) t[i] = tr_acc[i];
+            t[4] = t[5] = 0;
             t[6] = (unsigned)(__builtin_readcyclecounter() - tr_start);
             t[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
         }
     }
 
-    // ---- finish: the two lanes of a query add their row sums; normalise; store.
-    // accumulator o[dt][r] = O[q_j][d = 32 dt + (r & 3) + 8 (r >> 2) + 4 hh]  (C/D map of the 32x32 MFMA)
-    float l_tot = l_run + __shfl_xor(l_run, 32);
+    // ---- finish: the two lanes of a query add their row sums; normalise; store
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
     if (active && qrow < T) {
-        const float inv = 1.0f / l_tot;
-        const size_t ooff = ((size_t)b * T + qrow) * ((size_t)H * VN_DHEAD) + h * VN_DHEAD + 4 * hh;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                // the reference divides (softmax), it does not multiply by a reciprocal: keep the division per element
-                const f32x4 ov = {o[dt][4 * g] / l_tot, o[dt][4 * g + 1] / l_tot, o[dt][4 * g + 2] / l_tot, o[dt][4 * g + 3] / l_tot};
-                (void)inv;
-                const size_t off = ooff + 32 * dt + 8 * g;
-                if (out16) vn_store_planes4(out16, plane16, (long)b * T + qrow, h * VN_DHEAD + 4 * hh + 32 * dt + 8 * g, H * VN_DHEAD, ov);
-                else *(f32x4*)(out + off) = ov;
+                const f32x4 a = {o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
+                ax_store4(a, l_tot, out, out16, plane16, (long)b * T + qrow, h, H, L.hh, dt, g);
             }
     }
 }
 
-// tuning hooks (process-global; scripts/attn_probe.py): ablation / variant bits, dynamic-LDS override (occupancy: > 80 KiB = one block
-// per CU, > 53.3 KiB = two), start stagger, phase-trace buffer
-static int g_ax_abl = -1, g_ax_lds = 0, g_ax_stagger = -1;
-static unsigned* g_ax_trace = nullptr;
-extern "C" int vn_debug_attention_x3_config(int abl, int lds_bytes, int stagger, void* trace_dev) {
-    g_ax_abl = abl; g_ax_lds = lds_bytes; g_ax_stagger = stagger; g_ax_trace = (unsigned*)trace_dev;
-    return VN_OK;
+// ---- key-split kernel: block = KS waves on the SAME 32 queries, wave w walks key tiles w, w + KS, ... ---------------------------
+// LDS: KS wave-private stages (K 12 KiB + V^T 12 KiB, single-buffered each: the K DMA of the wave's next tile is issued right after
+// the S^T products have read the current one and flies under softmax + PV, the V^T DMA after PV and flies under the next S^T +
+// softmax; vmcnt counts this wave's own pieces in issue order, so no barrier is needed), then the bias table.  After the loop every
+// wave leaves (m, l, O) in its stage, and after ONE barrier wave w merges 8 / KS of the eight 4-column groups in the fixed order
+// w' = 0 .. KS - 1 (deterministic), normalises and stores them.
+template <int KS>
+__global__ __launch_bounds__(KS * 64, 3) void vn_attention_x3_split_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
+                                                                          long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
+                                                                          const float* __restrict__ bias_full, float* __restrict__ out,
+                                                                          uint16_t* __restrict__ out16, long plane16, int B, int H, int T) {
+    static_assert(KS == 1 || KS == 2 || KS == 4, "the merge hands 8 / KS column groups to every wave");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* bt = smem + KS * AX_STAGE_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const ax_lane L = ax_lane_init(lane);
+    const int nqb = (T + 31) / 32;
+    const int lid = ax_walk(blockIdx.x, gridDim.x);
+    const int qb = lid % nqb, h = (lid / nqb) % H, b = lid / (nqb * H);
+    const int m_lo = b * T;
+    const int g_lo = m_lo / AX_KT, NT = (m_lo + T - 1) / AX_KT - g_lo + 1;
+    const int MT = (B * T + AX_KT - 1) / AX_KT;
+    const size_t head = (size_t)b * H + h;
+    const uint16_t* Qp = q16 + head * (size_t)T * VN_DHEAD;
+    const int qrow = qb * 32 + L.l31;
+    const int qrow_c = qrow < T ? qrow : T - 1;
+
+    const int nb = 2 * T - 1;
+    for (int i = tid; i < nb; i += KS * 64) bt[i] = bias_full[(size_t)h * nb + i];
+
+    bf16x8 qf[3][4];
+    ax_load_q(qf, Qp, plane_qk, qrow_c, L.hh);
+
+    // this wave stages whole tiles: pieces w' = 0..3 of every plane.  K piece w' = rows 8 w' .. + 7: the swizzle key ((row >> 1) & 7)
+    // = (4 w' + (lane >> 4)) & 7 differs between even and odd w', so two per-lane offsets; V^T piece w' = rows 16 w' .. + 15:
+    // ((row >> 2) & 3) = (lane >> 4) & 3 for every w', one offset.  Piece w' adds 1 KiB to both source and destination.
+    const int kr0 = lane >> 3, vr0 = lane >> 2;
+    const unsigned kvoff_e = (unsigned)(kr0 * VN_DHEAD + ((lane & 7) ^ ((kr0 >> 1) & 7)) * 8) * 2u;
+    const unsigned kvoff_o = (unsigned)(kr0 * VN_DHEAD + ((lane & 7) ^ (((kr0 >> 1) + 4) & 7)) * 8) * 2u;
+    const unsigned vvoff = (unsigned)(vr0 * AX_KT + ((lane & 3) ^ ((vr0 >> 2) & 3)) * 8) * 2u;
+    const ax_src src = ax_src_init(k16, vt16, plane_qk, plane_vt, b, h, H, T, m_lo, g_lo, MT);
+    float* mine = smem + wave * AX_STAGE_FLOATS;
+    auto stage_k = [&](int kt) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned so = src.k0 + p * src.kplane + kt * (AX_KT * VN_DHEAD * 2);
+            ax_dma<0>(src.krs, mine + (4 * p + 0) * 256, kvoff_e, so);
+            ax_dma<1024>(src.krs, mine + (4 * p + 1) * 256, kvoff_o, so);
+            ax_dma<2048>(src.krs, mine + (4 * p + 2) * 256, kvoff_e, so);
+            ax_dma<3072>(src.krs, mine + (4 * p + 3) * 256, kvoff_o, so);
+        }
+    };
+    auto stage_v = [&](int kt) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned so = src.v0 + p * src.vplane + kt * (VN_DHEAD * AX_KT * 2);
+            ax_dma<0>(src.vrs, mine + (12 + 4 * p + 0) * 256, vvoff, so);
+            ax_dma<1024>(src.vrs, mine + (12 + 4 * p + 1) * 256, vvoff, so);
+            ax_dma<2048>(src.vrs, mine + (12 + 4 * p + 2) * 256, vvoff, so);
+            ax_dma<3072>(src.vrs, mine + (12 + 4 * p + 3) * 256, vvoff, so);
+        }
+    };
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+
+    if (wave < NT) { stage_k(wave); stage_v(wave); }
+    __syncthreads();                                            // the bias table is complete
+    const float* Ks = mine;
+    const float* Vs = mine + 3 * AX_PLANE_FLOATS;
+    for (int kt = wave; kt < NT; kt += KS) {
+        const int key0 = (g_lo + kt) * AX_KT - m_lo;
+        const bool full = key0 >= 0 && key0 + AX_KT <= T;
+        const bool more = kt + KS < NT;
+        f32x16 sacc;
+        bf16x8 pf[3][2];
+        if (full) ax_bias_init<true>(sacc, bt, key0, L.hh, qrow_c, T);
+        else ax_bias_init<false>(sacc, bt, key0, L.hh, qrow_c, T);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // K of this tile landed (its V^T pieces may still fly)
+        ax_qk(sacc, Ks, qf, L);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every K fragment has been read: the K stage is free
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) stage_k(kt + KS);
+        ax_softmax(sacc, pf, m_run, l_run, o, key0, L.hh, T, full);
+        if (more) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // V^T of this tile landed (the next K flies)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ax_pv(o, Vs, pf, L);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) stage_v(kt + KS);
+    }
+
+    // ---- merge the KS partial results.  Image per wave (its own stage, free now): 8 groups of 64 lanes x 16 B, then m, l per lane
+    if constexpr (KS > 1) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(f32x4*)(mine + ((dt * 4 + g) * 64 + lane) * 4) = f32x4{o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
+        mine[2048 + lane] = m_run;
+        mine[2112 + lane] = l_run;
+        __syncthreads();
+        float m_all = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < KS; ++w) m_all = fmaxf(m_all, smem[w * AX_STAGE_FLOATS + 2048 + lane]);
+        float sc[KS], l_all = 0.f;
+#pragma unroll
+        for (int w = 0; w < KS; ++w) {                          // a wave without tiles holds m = -inf, l = 0: scale 0
+            sc[w] = vn_exp_neg(smem[w * AX_STAGE_FLOATS + 2048 + lane] - m_all);
+            l_all += smem[w * AX_STAGE_FLOATS + 2112 + lane] * sc[w];
+        }
+        const float l_tot = l_all + __shfl_xor(l_all, 32);
+        if (qrow < T) {
+#pragma unroll
+            for (int i = 0; i < 8 / KS; ++i) {
+                const int G = wave * (8 / KS) + i;              // uniform
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w = 0; w < KS; ++w) a += *(const f32x4*)(smem + w * AX_STAGE_FLOATS + (G * 64 + lane) * 4) * sc[w];
+                ax_store4(a, l_tot, out, out16, plane16, (long)b * T + qrow, h, H, L.hh, G >> 2, G & 3);
+            }
+        }
+    } else {
+        const float l_tot = l_run + __shfl_xor(l_run, 32);
+        if (qrow < T) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 a = {o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
+                    ax_store4(a, l_tot, out, out16, plane16, (long)b * T + qrow, h, H, L.hh, dt, g);
+                }
+        }
+    }
+}
+
+// LDS bytes of the two decompositions; the launcher (and the engine's choice of attention kernel) need them to fit the CU
+size_t vn_attention_x3_lds_bytes(int T, int key_split) {
+    const size_t stages = key_split > 0 ? (size_t)key_split : 2;
+    return (stages * AX_STAGE_FLOATS + 2 * (size_t)T - 1 + 3) * sizeof(float);
+}
+
+// which decomposition: 0 = shared tiles (128-query blocks), KS > 0 = key-split with KS waves per 32-query block
+int vn_attention_x3_plan(const vn_ctx* ctx, int B, int H, int T, int cus) {
+    if (ctx->tune.ax_split >= 0) return ctx->tune.ax_split;
+    // 128-query blocks fill the chip from ~1.5 blocks per CU on (three fit); below that a wave's serial chain of 19 tiles is what
+    // a launch costs and the key-split shape wins (two key halves per 32-query block: 52.6 KiB, three blocks per CU)
+    if (2L * B * H * ((T + 127) / 128) >= 3L * cus) return 0;
+    return 2;
 }
 
 int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16, long plane_qk, const uint16_t* vt16, long plane_vt,
-                           const float* relbias_full, float* out, uint16_t* out16, long plane16, int B, int H, int T, hipStream_t s) {
+                           const float* relbias_full, float* out, uint16_t* out16, long plane16, int B, int H, int T, int cus,
+                           hipStream_t s) {
     if (B <= 0 || T <= 0) return VN_OK;
-    size_t lds = (size_t)(2 * AX_STAGE_FLOATS + 2 * T - 1 + 3) * sizeof(float);
-    if (lds > 80 * 1024) return vn_fail(ctx, VN_ERR_INVALID, "attention_x3: T=%s%ld too long for two blocks per CU", "", T);
-    if (g_ax_lds > (int)lds && g_ax_lds <= 160 * 1024) lds = g_ax_lds;
+    const int ks = vn_attention_x3_plan(ctx, B, H, T, cus);
+    size_t lds = vn_attention_x3_lds_bytes(T, ks);
+    if (lds > 160 * 1024) return vn_fail(ctx, VN_ERR_INVALID, "attention_x3: T=%s%ld too long for the LDS bias table", "", T);
+    if (ks == 0 && ctx->tune.ax_lds > (int)lds && ctx->tune.ax_lds <= 160 * 1024) lds = ctx->tune.ax_lds;
     if (!(ctx->attr_mask & VN_ATTR_ATTN_X3)) {
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_split_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_split_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_split_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->attr_mask |= VN_ATTR_ATTN_X3;
     }
     const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
-    // four waves (128 queries) per block, three blocks per CU (LDS: 2 x 24 KiB stages + the bias table; 168 VGPRs).  Measured
-    // alternatives (profiles/r02_attention_x3_kernel_times.txt): six waves (one round of 480 blocks at B = 8) 119 vs 112 us,
-    // two waves no better at any batch size.
-    static const int abl_env = [] { const char* e = getenv("VN_ATTN_X3_ABL"); return e ? atoi(e) & 31 : 0; }();   // tuning only
-    static const int stagger_env = [] { const char* e = getenv("VN_ATTN_X3_STAGGER"); return e ? atoi(e) : 0; }();
-    const int abl = g_ax_abl >= 0 ? g_ax_abl : abl_env;
-    const int stagger = g_ax_stagger >= 0 ? g_ax_stagger : stagger_env;
-#define AX_GO(A) hipLaunchKernelGGL((vn_attention_x3_kernel<4, A>), dim3(vn_cdiv(T, 128) * H * B), dim3(256), lds, s, q16, k16, plane_qk, vt16, \
-                                    plane_vt, relbias_full, out, out16, plane16, B, H, T, stagger, g_ax_trace)
-    switch (abl) {
-        case 1: AX_GO(1); break;
-        case 6: AX_GO(6); break;
-        case 7: AX_GO(7); break;
-        case 8: AX_GO(8); break;
-        case 16: AX_GO(16); break;
-        default: AX_GO(0); break;
+    if (ks == 0) {
+        // four waves (128 queries) per block, three blocks per CU (LDS: 2 x 24 KiB stages + the bias table)
+        const dim3 grid(vn_cdiv(T, 128) * H * B);
+        if (ctx->tune.ax_trace)
+            hipLaunchKernelGGL((vn_attention_x3_kernel<4, true>), grid, dim3(256), lds, s, q16, k16, plane_qk, vt16, plane_vt, relbias_full, out,
+                               out16, plane16, B, H, T, ctx->tune.ax_stagger, ctx->tune.ax_trace);
+        else
+            hipLaunchKernelGGL((vn_attention_x3_kernel<4, false>), grid, dim3(256), lds, s, q16, k16, plane_qk, vt16, plane_vt, relbias_full, out,
+                               out16, plane16, B, H, T, ctx->tune.ax_stagger, (unsigned*)nullptr);
+    } else {
+        const dim3 grid(vn_cdiv(T, 32) * H * B);
+#define AX_SPLIT_GO(KS) hipLaunchKernelGGL((vn_attention_x3_split_kernel<KS>), grid, dim3(KS * 64), lds, s, q16, k16, plane_qk, vt16, plane_vt, \
+                                           relbias_full, out, out16, plane16, B, H, T)
+        if (ks == 1) AX_SPLIT_GO(1);
+        else if (ks == 2) AX_SPLIT_GO(2);
+        else AX_SPLIT_GO(4);
+#undef AX_SPLIT_GO
     }
-#undef AX_GO
     vn_prof_post(ctx, pi, s);
     VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// tuning hook of one context (scripts/attn_probe.py; include/vampnet_hip_debug.h)
+extern "C" int vn_debug_attention_x3_config(vn_ctx* ctx, int split, int lds_bytes, int stagger, void* trace_dev) {
+    if (!ctx) return VN_ERR_INVALID;
+    if (split != -1 && split != 0 && split != 1 && split != 2 && split != 4)
+        return vn_fail(ctx, VN_ERR_INVALID, "attention_x3: key split %s%ld is not -1 / 0 / 1 / 2 / 4", "", split);
+    ctx->tune.ax_split = split;
+    ctx->tune.ax_lds = lds_bytes;
+    if (stagger >= 0) ctx->tune.ax_stagger = stagger;
+    ctx->tune.ax_trace = (unsigned*)trace_dev;
+    ++ctx->tune.epoch;
     return VN_OK;
 }

@@ -84,6 +84,36 @@ static const float* W(const vn_model* m, int id, int layer = 0) { return m->blob
 // ---- context ---------------------------------------------------------------------------------
 extern "C" const char* vn_version(void) { return "vampnet_hip 0.1 gfx950 f32-mfma"; }
 
+// Defaults of the per-context tuning state from the environment (read when a context is created).  Every knob here selects
+// between forms that give VALID results (tile shapes, schedulers, layouts); the ablation variants whose results are invalid can
+// only be reached through vn_debug_x3_config on a context.
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+void vn_tune_init(vn_tune* t) {
+    memset(t, 0, sizeof(*t));
+    t->f32_order = env_int("VN_GEMM_ORDER", 1);
+    t->f32_stagger = 2;                       // stream-K: second-slot blocks start 2 x 1024 cycles late (measured +2..6 %)
+    if (const char* e = getenv("VN_GEMM_TILE")) sscanf(e, "%dx%d", &t->f32_bm, &t->f32_bn);
+    t->f32_sched = env_int("VN_GEMM_SCHED", -1);
+    t->f32_splitk = env_int("VN_GEMM_SPLITK", -1);
+    t->x3_bm = env_int("VN_X3_BM", 0);
+    { const int v = env_int("VN_X3_SPLITK", -1); t->x3_split = v < 0 ? -2 : v; }
+    t->x3_abl = 0;
+    t->x3_fuse_norm = env_int("VN_X3_FUSE_NORM", 1) != 0;
+    t->x3_staged = env_int("VN_X3_STAGED", 1) != 0;
+    t->x3_group_m = env_int("VN_X3_GROUPM", 0);
+    t->ax_split = env_int("VN_ATTN_X3_SPLIT", -1);
+    t->ax_lds = 0;
+    t->ax_stagger = env_int("VN_ATTN_X3_STAGGER", 0);
+    t->ax_trace = nullptr;
+    t->attn_x3 = env_int("VN_ATTN_X3", -1);
+    t->a_tiled = env_int("VN_X3_ATILED", 1) != 0;
+    t->w_tiled = env_int("VN_X3_WTILED", 1) != 0;
+    t->epoch = 0;
+}
+
 extern "C" int vn_ctx_create(int device, vn_ctx** out) {
     if (!out) return VN_ERR_INVALID;
     *out = nullptr;
@@ -95,6 +125,9 @@ extern "C" int vn_ctx_create(int device, vn_ctx** out) {
     c->err[0] = 0;
     c->prof = vn_prof();
     c->sk_slabs = nullptr; c->sk_flags = nullptr; c->zero_page = nullptr; c->x3_ws = nullptr; c->attr_mask = 0;
+    vn_tune_init(&c->tune);
+    c->cus = 0;
+    if (hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->cus <= 0) c->cus = 256;
     if (hipSetDevice(device) != hipSuccess) { delete c; return VN_ERR_HIP; }
     *out = c;
     return VN_OK;
@@ -236,10 +269,14 @@ int vn_model_ensure_bias(vn_model* m, int T, hipStream_t s) {
     return rc;
 }
 
-// test hook (process-global): 1 / 0 = bf16x3 models use / do not use the split-plane attention path (QKV3 epilogue + attention_x3.hip)
-// whatever the batch size, -1 = by occupancy (VN_ATTN_X3 / default)
-static int g_attn_x3_force = -1;
-extern "C" int vn_debug_attention_x3_force(int on) { g_attn_x3_force = on < 0 ? -1 : (on != 0); return VN_OK; }
+// test hook: 1 / 0 = bf16x3 models of this context use / do not use the split-plane attention path (QKV3 epilogue +
+// attention_x3.hip) whatever the shape, -1 = by shape (VN_ATTN_X3 / default)
+extern "C" int vn_debug_attention_x3_force(vn_ctx* ctx, int on) {
+    if (!ctx) return VN_ERR_INVALID;
+    ctx->tune.attn_x3 = on < 0 ? -1 : (on != 0);
+    ++ctx->tune.epoch;
+    return VN_OK;
+}
 
 // forward on the int32 token buffer m->z -> m->logits   (layers.py:134-163 + transformer.py:617-639)
 static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logits, hipStream_t s) {
@@ -258,7 +295,7 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
     // fp32-grade accuracy (gemm_x3.hip); everything else is the fp32 path.
     const int gm = bf ? (m->w_plane ? 2 : 1) : 0;                       // vn_gemm_args::bf16
     // plane strides of y16 / g16: bf16x3 = the tiled layout (whole-line LDS-DMA in gemm_x3.hip), fast mode = one plane
-    static const bool a_tiled_on = [] { const char* e = getenv("VN_X3_ATILED"); return !(e && e[0] == '0'); }();   // A/B runs
+    const bool a_tiled_on = ctx->tune.a_tiled != 0;
     const long yp = gm == 2 ? (a_tiled_on ? VN_PLANES_TILED : m->max_rows * (long)D) : 0;
     const long gp = gm == 2 ? (a_tiled_on ? VN_PLANES_TILED : 2 * m->max_rows * (long)D) : 0;
     auto W16 = [&](int id, int layer) { return (const float*)(m->blob16 + vn_tensor_offset(&m->d, id, layer)); };
@@ -266,21 +303,17 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
         a.A = bf ? (const float*)A16 : A32;
         a.W = bf ? W16(id, layer) : W(m, id, layer);
         a.bf16 = gm; a.a_plane = a_plane; a.w_plane = m->w_plane;
-        static const bool w_tiled_on = [] { const char* e = getenv("VN_X3_WTILED"); return !(e && e[0] == '0'); }();   // A/B runs
-        if (gm == 2 && m->w_tiled && w_tiled_on) {      // bf16x3: the tiled image of the same weight planes
+        if (gm == 2 && m->w_tiled && ctx->tune.w_tiled) {      // bf16x3: the tiled image of the same weight planes
             a.W = (const float*)(m->w_tiled + 3 * vn_tensor_offset(&m->d, id, layer));
             a.w_tiled = 1;
         }
     };
-    // bf16x3: attention on the bf16 matrix cores too (attention_x3.hip) once there are enough 128-query blocks to fill the chip
-    // (>= 1.5 per CU); below that (one or two sequences) the 64-query blocks of the fp32-input MFMA kernel fill it better
-    // (B = 1, coarse: 55.6 vs 57.8 ms per clip, profiles/r02_c10_3_cfg1_*.json).  VN_ATTN_X3 = 0 / 1 forces one of them (A/B runs).
-    static const int attn_x3_envv = [] { const char* e = getenv("VN_ATTN_X3"); return e ? atoi(e) : -1; }();
-    const int attn_x3_env = g_attn_x3_force >= 0 ? g_attn_x3_force : attn_x3_envv;
-    static int cus_of[64] = {0};                      // queried once per device, outside any stream capture (first forward is eager)
-    int& cus = cus_of[ctx->device & 63];
-    if (!cus && (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0)) cus = 256;
-    const bool attn_x3 = attn_x3_env >= 0 ? attn_x3_env != 0 : 2L * B * H * ((T + 127) / 128) >= 3L * cus;
+    // bf16x3: attention on the bf16 matrix cores too (attention_x3.hip: 128-query blocks sharing their tiles when those fill the
+    // chip, key-split 32-query blocks for one or two sequences) whenever its LDS image (stages + the 2T-1 bias table) fits the CU;
+    // the fp32-input MFMA kernel otherwise.  VN_ATTN_X3 = 0 / 1 or vn_debug_attention_x3_force override (A/B runs, tests).
+    const int cus = vn_num_cus(ctx);
+    const bool attn_x3_fits = vn_attention_x3_lds_bytes(T, vn_attention_x3_plan(ctx, B, H, T, cus)) <= 160 * 1024;
+    const bool attn_x3 = attn_x3_fits && (ctx->tune.attn_x3 >= 0 ? ctx->tune.attn_x3 != 0 : true);
     // a RESIDUAL GEMM that gets split along K runs the RMSNorm that follows it inside its reduce pass (gemm_x3.hip)
     int normed = 0;
     auto with_norm = [&](vn_gemm_args& a, const float* w) {
@@ -301,7 +334,7 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
             a.T = T; a.H = H; a.qkv_plane = plane;
             if ((rc = vn_launch_gemm_f32(ctx, a, VN_EPI_QKV3, s))) return rc;
             if ((rc = vn_launch_attention_x3(ctx, m->qk16, m->qk16 + plane, m->qk_plane, m->vt16, m->vt_plane, m->bias_full, nullptr,
-                                             m->y16, yp, B, H, T, s)))
+                                             m->y16, yp, B, H, T, cus, s)))
                 return rc;
         } else {
             vn_gemm_args a{};
@@ -348,6 +381,7 @@ struct vn_fwd_graph_entry {
     const void* blob16;
     long w_plane;
     int calls;
+    unsigned epoch;          // ctx->tune.epoch at capture: a vn_debug_* setter since then invalidates the entry
     bool failed;
     hipGraph_t graph;
     hipGraphExec_t exec;
@@ -381,9 +415,14 @@ static int forward_loop(vn_model* m, int B, int T, hipStream_t s) {
     vn_fwd_graph_entry* e = nullptr;
     for (auto& c : m->graphs->v)
         if (c.B == B && c.T == T && c.blob16 == (const void*)m->blob16 && c.w_plane == m->w_plane) { e = &c; break; }
+    if (e && e->epoch != ctx->tune.epoch) {      // a tuning hook changed which kernels a forward launches: capture again
+        if (e->exec) (void)hipGraphExecDestroy(e->exec);
+        if (e->graph) (void)hipGraphDestroy(e->graph);
+        *e = vn_fwd_graph_entry{B, T, (const void*)m->blob16, m->w_plane, 0, ctx->tune.epoch, false, nullptr, nullptr};
+    }
     if (!e) {
         if (m->graphs->v.size() >= 16) return forward_i32(m, m->z, B, T, m->logits, s);
-        m->graphs->v.push_back(vn_fwd_graph_entry{B, T, (const void*)m->blob16, m->w_plane, 0, false, nullptr, nullptr});
+        m->graphs->v.push_back(vn_fwd_graph_entry{B, T, (const void*)m->blob16, m->w_plane, 0, ctx->tune.epoch, false, nullptr, nullptr});
         e = &m->graphs->v.back();
     }
     int rc;
@@ -438,14 +477,19 @@ static int set_bf16_planes(vn_model* m, const void* blob16_dev, long w_plane) {
     const size_t rows16 = ((size_t)m->max_rows + 15) / 16 * 16;        // the tiled layout addresses rows in blocks of 16
     if (!m->y16 && (rc = dev_alloc(m->ctx, &m->y16, (size_t)3 * rows16 * m->D))) return rc;
     if (!m->g16 && (rc = dev_alloc(m->ctx, &m->g16, (size_t)3 * rows16 * 2 * m->D))) return rc;
-    if (w_plane > 0 && !m->qk16) {        // bf16x3: attention operands as planes (attention_x3.hip)
+    if (w_plane > 0 && (!m->qk16 || !m->vt16)) {        // bf16x3: attention operands as planes (attention_x3.hip)
         m->qk_plane = 2 * m->max_rows * (long)m->D;
         m->vt_plane = (long)m->H * ((m->max_rows + 31) / 32) * (VN_DHEAD * 32);
-        if ((rc = dev_alloc(m->ctx, &m->qk16, (size_t)3 * m->qk_plane + 32 * VN_DHEAD))) return rc;
-        if ((rc = dev_alloc(m->ctx, &m->vt16, (size_t)3 * m->vt_plane))) return rc;
-        // keys >= T of a head's last tile are multiplied by P = 0: they must be finite, so start from zeros
-        VN_HIP_CHECK(m->ctx, hipMemset(m->vt16, 0, (size_t)3 * m->vt_plane * sizeof(uint16_t)));
-        VN_HIP_CHECK(m->ctx, hipMemset(m->qk16, 0, ((size_t)3 * m->qk_plane + 32 * VN_DHEAD) * sizeof(uint16_t)));
+        // each buffer on its own null check: a failed second allocation must not leave a half-initialised pair behind
+        if (!m->qk16) {
+            if ((rc = dev_alloc(m->ctx, &m->qk16, (size_t)3 * m->qk_plane + 32 * VN_DHEAD))) return rc;
+            VN_HIP_CHECK(m->ctx, hipMemset(m->qk16, 0, ((size_t)3 * m->qk_plane + 32 * VN_DHEAD) * sizeof(uint16_t)));
+        }
+        if (!m->vt16) {
+            if ((rc = dev_alloc(m->ctx, &m->vt16, (size_t)3 * m->vt_plane))) return rc;
+            // keys >= T of a head's last tile are multiplied by P = 0: they must be finite, so start from zeros
+            VN_HIP_CHECK(m->ctx, hipMemset(m->vt16, 0, (size_t)3 * m->vt_plane * sizeof(uint16_t)));
+        }
     }
     if (w_plane > 0) {
         // the GEMM weight tensors once more as tiled planes (gemm_x3.hip's LDS-DMA then fetches whole cache lines): a setup call,
@@ -679,14 +723,14 @@ static int attention_x3_run(vn_ctx* ctx, const float* q, const float* k, const f
     if (rc == VN_OK) rc = vn_launch_bias_expand(ctx, rel_bias, lut_d, full, H, T, s);
     if (rc == VN_OK) {
         hipLaunchKernelGGL(vn_attn_x3_prep_kernel, dim3(1024), dim3(256), 0, s, q, k, v, qk16, plane_qk, vt16, plane_vt, heads, H, T);
-        rc = vn_launch_attention_x3(ctx, qk16, qk16 + n, plane_qk, vt16, plane_vt, full, out, nullptr, 0, B, H, T, s);
+        rc = vn_launch_attention_x3(ctx, qk16, qk16 + n, plane_qk, vt16, plane_vt, full, out, nullptr, 0, B, H, T, vn_num_cus(ctx), s);
     }
     if (rc == VN_OK && iters > 0 && avg_us) {
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipEventRecord(e0, s);
         for (int i = 0; i < iters && rc == VN_OK; ++i)
-            rc = vn_launch_attention_x3(ctx, qk16, qk16 + n, plane_qk, vt16, plane_vt, full, out, nullptr, 0, B, H, T, s);
+            rc = vn_launch_attention_x3(ctx, qk16, qk16 + n, plane_qk, vt16, plane_vt, full, out, nullptr, 0, B, H, T, vn_num_cus(ctx), s);
         (void)hipEventRecord(e1, s);
         (void)hipEventSynchronize(e1);
         float ms = 0.f;

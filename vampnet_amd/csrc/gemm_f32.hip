@@ -454,26 +454,16 @@ __global__ __launch_bounds__(256) void vn_splitk_reduce_kernel(const float* __re
 // host side
 // ---------------------------------------------------------------------------------------------
 // tuning hooks (scripts/gemm_sweep.py): force a tile / scheduler / tile order
-static int g_order = 1;
-static int g_stagger = 2;      // stream-K: second-slot blocks start 2 x 1024 cycles late (measured +2..6 %)
-static int g_force_bm = 0, g_force_bn = 0;
-static int g_sched = -1;          // -1 auto, 0 data-parallel, 1 stream-K
-static int g_splitk = -1;         // VN_GEMM_SPLITK: -1 auto, 0 off, >= 2 forced split count (small-M shapes only)
-static void read_env_once() {
-    static const bool done = [] {         // function-local static: initialised once, also under concurrent first calls
-        if (const char* e = getenv("VN_GEMM_ORDER")) g_order = atoi(e);
-        if (const char* e = getenv("VN_GEMM_TILE")) sscanf(e, "%dx%d", &g_force_bm, &g_force_bn);
-        if (const char* e = getenv("VN_GEMM_SCHED")) g_sched = atoi(e);
-        if (const char* e = getenv("VN_GEMM_SPLITK")) g_splitk = atoi(e);
-        return true;
-    }();
-    (void)done;
-}
-
-extern "C" int vn_debug_gemm_config(int bm, int bn, int order) {
-    read_env_once();
-    g_force_bm = bm; g_force_bn = bn;
-    if (order >= 0) { g_order = order & 1; g_sched = ((order >> 1) & 3) - 1; if (order >> 8) g_stagger = ((order >> 8) & 0xff) - 1; }   // bits: [0] walk, [2:1] sched+1, [15:8] stagger+1
+// (state in vn_ctx::tune: f32_order, f32_stagger, f32_bm / f32_bn, f32_sched -1 auto / 0 data-parallel / 1 stream-K, f32_splitk
+// -1 auto / 0 off / >= 2 forced split count for the small-M shapes; defaults from VN_GEMM_ORDER / _TILE / _SCHED / _SPLITK when the
+// context is created)
+extern "C" int vn_debug_gemm_config(vn_ctx* ctx, int bm, int bn, int order) {
+    if (!ctx) return VN_ERR_INVALID;
+    vn_tune& t = ctx->tune;
+    t.f32_bm = bm; t.f32_bn = bn;
+    // bits: [0] walk, [2:1] sched + 1, [15:8] stagger + 1
+    if (order >= 0) { t.f32_order = order & 1; t.f32_sched = ((order >> 1) & 3) - 1; if (order >> 8) t.f32_stagger = ((order >> 8) & 0xff) - 1; }
+    ++t.epoch;
     return VN_OK;
 }
 
@@ -516,10 +506,10 @@ static int launch_cfg(vn_ctx* ctx, const vn_gemm_args& a, bool streamk, hipStrea
         int G = SK_MAX_BLOCKS;
         if (total < G) G = (int)total;
         hipLaunchKernelGGL((vn_gemm_f32_sk_kernel<BM, BN, EPI, BF>), dim3(G), dim3(256), Cfg::LDS_BYTES, s, a, tiles_m,
-                           tiles_n, g_order | (g_stagger << 8), ctx->sk_slabs, ctx->sk_flags, ctx->sk_flags + SK_MAX_BLOCKS);
+                           tiles_n, ctx->tune.f32_order | (ctx->tune.f32_stagger << 8), ctx->sk_slabs, ctx->sk_flags, ctx->sk_flags + SK_MAX_BLOCKS);
     } else {
         hipLaunchKernelGGL((vn_gemm_f32_kernel<BM, BN, EPI, BF>), dim3(tiles_m * tiles_n), dim3(256), Cfg::LDS_BYTES, s, a,
-                           tiles_m, tiles_n, g_order);
+                           tiles_m, tiles_n, ctx->tune.f32_order);
     }
     vn_prof_post(ctx, pi, s);
     VN_LAUNCH_CHECK(ctx);
@@ -549,7 +539,7 @@ static int launch_splitk(vn_ctx* ctx, const vn_gemm_args& a, int nsplit, hipStre
     const double bytes = 4.0 * ((double)a.M * a.K + (double)a.N * a.K) + 4.0 * (double)a.M * a.N * (EPI == VN_EPI_RESIDUAL ? 2 : 1);
     const int pi = vn_prof_pre(ctx, 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);
     hipLaunchKernelGGL((vn_gemm_f32_splitk_kernel<64, 64>), dim3(tiles_m * tiles_n, nsplit), dim3(256), Cfg::LDS_BYTES, s, a, tiles_m,
-                       tiles_n, g_order, nsplit, ctx->sk_slabs);
+                       tiles_n, ctx->tune.f32_order, nsplit, ctx->sk_slabs);
     const long total4 = (long)a.M * (a.N / 4);
     const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
     hipLaunchKernelGGL((vn_splitk_reduce_kernel<EPI == VN_EPI_RESIDUAL>), dim3(blocks), dim3(256), 0, s, ctx->sk_slabs, nsplit, a.C,
@@ -572,30 +562,29 @@ int vn_launch_splitk_reduce(vn_ctx* ctx, const float* partial, int nsplit, float
 
 template <int EPI>
 static int launch_epi(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
-    read_env_once();
     if constexpr (EPI == VN_EPI_RESIDUAL || EPI == VN_EPI_STORE) {
         // one sequence (M <= 640): 64 x 64 tiles fill at most 70 % of the CUs at one wave per SIMD -> split K so that every CU
         // hosts two blocks; needs fp32 operands, a 4-aligned row stride and room in the 32 MiB slab workspace
-        if (!a.bf16 && !g_force_bm && g_sched != 1 && g_splitk != 0 && a.M <= 1280 && a.K >= 1024 && a.N % 4 == 0 && a.ldc % 4 == 0) {
+        if (!a.bf16 && !ctx->tune.f32_bm && ctx->tune.f32_sched != 1 && ctx->tune.f32_splitk != 0 && a.M <= 1280 && a.K >= 1024 && a.N % 4 == 0 && a.ldc % 4 == 0) {
             const int tiles = vn_cdiv(a.M, 64) * vn_cdiv(a.N, 64);
-            int ns = g_splitk >= 2 ? g_splitk : (tiles >= 512 ? 0 : (tiles >= 256 ? 2 : (tiles >= 128 ? 4 : 8)));
+            int ns = ctx->tune.f32_splitk >= 2 ? ctx->tune.f32_splitk : (tiles >= 512 ? 0 : (tiles >= 256 ? 2 : (tiles >= 128 ? 4 : 8)));
             while (ns > 1 && (a.K / BK) / ns < 4) ns >>= 1;
             if (ns >= 2 && (size_t)ns * a.M * a.N <= (size_t)SK_MAX_BLOCKS * 128 * 128) return launch_splitk<EPI>(ctx, a, ns, s);
         }
     }
-    int bm = g_force_bm, bn = g_force_bn;
-    bool sk = g_sched == 1;
+    int bm = ctx->tune.f32_bm, bn = ctx->tune.f32_bn;
+    bool sk = ctx->tune.f32_sched == 1;
     if (!bm) {
         const bool geglu = (EPI == VN_EPI_GEGLU);
         struct { int bm, bn; double eff; } cand[] = {{128, 128, 1.00}, {64, 128, 0.94}, {128, 64, 0.93}, {64, 64, 0.89}};
         double best = 1e300;
         for (auto& c : cand) {
             if (geglu && c.bn != 128) continue;
-            if (g_sched != 1) {
+            if (ctx->tune.f32_sched != 1) {
                 const double cost = dp_cost(a.M, a.N, a.K, c.bm, c.bn, c.eff);
                 if (cost < best) { best = cost; bm = c.bm; bn = c.bn; sk = false; }
             }
-            if (g_sched != 0) {
+            if (ctx->tune.f32_sched != 0) {
                 const double cost = sk_cost(a.M, a.N, a.K, c.bm, c.bn, c.eff);
                 if (cost < best) { best = cost; bm = c.bm; bn = c.bn; sk = true; }
             }
@@ -603,7 +592,7 @@ static int launch_epi(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
     }
     if (a.bf16) {      // fast mode: 128x128 data-parallel (kernels last 25-80 us: the ~20 us stream-K fix-up does not pay;
                        // measured DP 590-770 TF vs SK 400-670 TF on the model's shapes)
-        return launch_cfg<128, 128, EPI, true>(ctx, a, g_sched == 1, s);
+        return launch_cfg<128, 128, EPI, true>(ctx, a, ctx->tune.f32_sched == 1, s);
     }
     if (bm == 128 && bn == 128) return launch_cfg<128, 128, EPI>(ctx, a, sk, s);
     if (bm == 64 && bn == 128) return launch_cfg<64, 128, EPI>(ctx, a, sk, s);

@@ -511,39 +511,25 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
 
 #define X3_WS_FLOATS (32L << 20)          // 128 MiB of split-K partial images, allocated once (graph-safe: never re-allocated)
 
-static int x3_env(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
-// tuning / test hooks (process-global): tile height 128 / 192 / 256, forced split-K, ablation bits
-static int g_x3_bm = 0, g_x3_split = -2, g_x3_abl = -1;
-extern "C" int vn_debug_x3_config(int bm, int splitk, int abl) {
-    if (bm != 0 && bm != 128 && bm != 192 && bm != 256) return VN_ERR_INVALID;
-    g_x3_bm = bm; g_x3_split = splitk < 0 ? -2 : splitk;
-    g_x3_abl = abl < 0 ? -1 : (abl & 7);
+// tuning / test hook of ONE context: tile height 128 / 192 / 256 (0 = by shape), forced split-K (0 / 1 off, 2 / 4 forced, < 0 =
+// cost model), ablation bits (tuning only: results invalid; < 0 or 0 = none)
+extern "C" int vn_debug_x3_config(vn_ctx* ctx, int bm, int splitk, int abl) {
+    if (!ctx) return VN_ERR_INVALID;
+    if (bm != 0 && bm != 128 && bm != 192 && bm != 256) return vn_fail(ctx, VN_ERR_INVALID, "x3 tile height %s%ld is not 0 / 128 / 192 / 256", "", bm);
+    ctx->tune.x3_bm = bm;
+    ctx->tune.x3_split = splitk < 0 ? -2 : splitk;
+    ctx->tune.x3_abl = abl < 0 ? 0 : (abl & 7);
+    ++ctx->tune.epoch;
     return VN_OK;
 }
 
 template <int CFG>
 static constexpr size_t x3_lds_bytes() { return (size_t)x3_geo<CFG>::STAGE * 4 * x3_geo<CFG>::NBUF; }
 
-static int x3_num_cus(vn_ctx* ctx) {
-    static int cus[64] = {0};
-    const int d = ctx->device & 63;
-    if (!cus[d]) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || n <= 0) n = 256;
-        cus[d] = n;
-    }
-    return cus[d];
-}
-
 // may the epilogue go through LDS with 16-byte global accesses ?  (VN_X3_STAGED=0: never — A/B runs)
 template <int EPI>
-static int x3_staged_ok(const vn_gemm_args& a) {
-    static const bool on = x3_env("VN_X3_STAGED", 1) != 0;
-    if (!on) return 0;
+static int x3_staged_ok(const vn_ctx* ctx, const vn_gemm_args& a) {
+    if (!ctx->tune.x3_staged) return 0;
     auto al = [](const void* p, uintptr_t m) { return ((uintptr_t)p & (m - 1)) == 0; };
     if (EPI == VN_EPI_GEGLU)
         return a.C16 && al(a.C16, 16) && !(a.N & 15) && (a.c_plane == VN_PLANES_TILED ? !(a.ldc & 31) : (!(a.ldc & 7) && !(a.c_plane & 7)));
@@ -558,9 +544,8 @@ static int x3_staged_ok(const vn_gemm_args& a) {
 template <int EPI, int CFG, int ABL = 0>
 static int x3_go(vn_ctx* ctx, const vn_gemm_args& a_in, int nsplit, hipStream_t s) {
     vn_gemm_args a = a_in;
-    a.staged = x3_staged_ok<EPI>(a);
-    static const int group_m_env = x3_env("VN_X3_GROUPM", 0);          // tuning: rows of tiles per walk group (default 8)
-    a.group_m = group_m_env;
+    a.staged = x3_staged_ok<EPI>(ctx, a);
+    a.group_m = ctx->tune.x3_group_m;                                  // tuning: rows of tiles per walk group (0 = 8)
     const int tiles_m = vn_cdiv(a.M, x3_geo<CFG>::BM), tiles_n = vn_cdiv(a.N, X3_BN);
     hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, CFG, ABL>), dim3(tiles_m * tiles_n, nsplit), dim3(512), x3_lds_bytes<CFG>(), s, a, tiles_m, tiles_n);
     VN_LAUNCH_CHECK(ctx);
@@ -574,12 +559,17 @@ static int x3_go_bm(vn_ctx* ctx, const vn_gemm_args& a, int nsplit, int bm, hipS
     return bm == 256 ? x3_go<EPI, 2>(ctx, a, nsplit, s) : x3_go<EPI, 1>(ctx, a, nsplit, s);
 }
 
-static int g_x3_fuse_norm = -1;                  // test hook: -1 = VN_X3_FUSE_NORM (default on), 0 / 1 forced
-extern "C" int vn_debug_x3_fuse_norm(int on) { g_x3_fuse_norm = on < 0 ? -1 : (on != 0); return VN_OK; }
-static bool x3_norm_fusable(const vn_gemm_args& a) {
-    static const bool fuse_env = x3_env("VN_X3_FUSE_NORM", 1) != 0;
-    const bool fuse_norm = g_x3_fuse_norm >= 0 ? g_x3_fuse_norm != 0 : fuse_env;
-    return fuse_norm && a.norm_w && a.norm_done && a.ldc == a.N && (a.N == 1280 || a.N == 256);
+// test hook: 0 = keep the reduce pass of a split RESIDUAL GEMM and the RMSNorm that follows it as two kernels, 1 = fuse, -1 = the
+// context's default (VN_X3_FUSE_NORM, on)
+extern "C" int vn_debug_x3_fuse_norm(vn_ctx* ctx, int on) {
+    if (!ctx) return VN_ERR_INVALID;
+    if (on < 0) { vn_tune t; vn_tune_init(&t); ctx->tune.x3_fuse_norm = t.x3_fuse_norm; }
+    else ctx->tune.x3_fuse_norm = on != 0;
+    ++ctx->tune.epoch;
+    return VN_OK;
+}
+static bool x3_norm_fusable(const vn_ctx* ctx, const vn_gemm_args& a) {
+    return ctx->tune.x3_fuse_norm && a.norm_w && a.norm_done && a.ldc == a.N && (a.N == 1280 || a.N == 256);
 }
 
 // Tile height and k-split of a launch, by a cost model in microseconds calibrated on the model's shapes (scripts/gemm_x3_plan_sweep.py,
@@ -592,10 +582,9 @@ static bool x3_norm_fusable(const vn_gemm_args& a) {
 // wave tile); one or two sequences keep 128 rows (more tiles) and split the N = 1280 projections.
 struct x3_plan { int bm, ns; };
 template <int EPI>
-static x3_plan x3_choose(const vn_gemm_args& a, int cus) {
-    static const int bm_env = x3_env("VN_X3_BM", 0), split_env = x3_env("VN_X3_SPLITK", -1);      // split: 0 / 1 off, 2 / 4 forced
-    const int bm_forced = g_x3_bm ? g_x3_bm : bm_env;
-    const int split_forced = g_x3_split != -2 ? g_x3_split : split_env;
+static x3_plan x3_choose(const vn_ctx* ctx, const vn_gemm_args& a, int cus) {
+    const int bm_forced = ctx->tune.x3_bm;                   // 0 = by shape
+    const int split_forced = ctx->tune.x3_split == -2 ? -1 : ctx->tune.x3_split;      // 0 / 1 off, 2 / 4 forced, -1 cost model
     constexpr bool can_split = EPI == VN_EPI_STORE || EPI == VN_EPI_RESIDUAL;
     constexpr bool residual = EPI == VN_EPI_RESIDUAL;
     const int nk = a.K / X3_KT;
@@ -617,7 +606,7 @@ static x3_plan x3_choose(const vn_gemm_args& a, int cus) {
             double cost = (double)((tiles * ns + cus - 1) / cus) * (nk / (double)ns) * 1.45 * rel[hi];
             if (ns > 1) {
                 cost += (ns + (residual ? 2 : 1)) * 4.0 * a.M * (double)a.N / 3.5e6;
-                if (residual && x3_norm_fusable(a)) cost -= 4.0 * a.M * (double)a.N / 3.5e6 + 1.5;
+                if (residual && x3_norm_fusable(ctx, a)) cost -= 4.0 * a.M * (double)a.N / 3.5e6 + 1.5;
                 if (split_forced > 1 && ns == split_forced) cost = -1.0 + 1e-3 * hi;       // forced split: keep the height order
             }
             if (cost < best_cost) { best_cost = cost; best = x3_plan{bm, ns}; }
@@ -633,12 +622,11 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
                          ((EPI == VN_EPI_GEGLU && a.C16) ? 6.0 : 4.0) * (double)a.M * n_out * (EPI == VN_EPI_RESIDUAL ? 2 : 1);
     const int pi = vn_prof_pre(ctx, 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);       // algorithmic (fp32-equivalent) flops
     int rc = VN_OK;
-    const x3_plan plan = x3_choose<EPI>(a, x3_num_cus(ctx));
+    const x3_plan plan = x3_choose<EPI>(ctx, a, vn_num_cus(ctx));
     const int bm = plan.bm;
     bool done = false;
     if constexpr (EPI == VN_EPI_STORE) {
-        static const int abl_env = x3_env("VN_X3_ABL", 0) & 7;             // ablations (tuning only; results invalid)
-        int abl = g_x3_abl >= 0 ? g_x3_abl : abl_env;
+        int abl = ctx->tune.x3_abl;                                        // ablations (tuning only; results invalid): vn_debug_x3_config
         if (abl == 4 && (a.a_plane == VN_PLANES_TILED || a.w_tiled)) abl = 0;      // the full-line probe re-addresses PLANAR planes only
         if (abl) {
             const bool big = bm == 256;
@@ -665,7 +653,7 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
             rc = x3_go_bm<VN_EPI_STORE>(ctx, q, ns, bm, s);
             // while launches are being event-bracketed (pi >= 0) the two-kernel form runs, so that the GEMM's bracket holds the GEMM's
             // own work (split images + reduce) and nothing of the norm — the bitwise same result (tests/test_gpu_kernels.py)
-            if (EPI == VN_EPI_RESIDUAL && x3_norm_fusable(a) && pi < 0) {
+            if (EPI == VN_EPI_RESIDUAL && x3_norm_fusable(ctx, a) && pi < 0) {
                 if (rc == VN_OK)
                     rc = vn_launch_splitk_reduce_rmsnorm(ctx, ctx->x3_ws, ns, a.C, a.norm_w, a.norm_y, a.norm_y16, a.norm_plane, a.M, a.N,
                                                          a.norm_eps, s);

@@ -6,6 +6,7 @@
 #include <string.h>
 #include <math.h>
 #include "../../include/vampnet_hip.h"
+#include "../../include/vampnet_hip_debug.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -161,10 +162,32 @@ struct vn_prof {
     double* bytes = nullptr;       // algorithmic operand bytes of the launch
 };
 
+// Per-context tuning / test state.  Defaults come from the environment ONCE, when the context is created (vn_tune_init, engine.hip:
+// valid-result knobs only); the vn_debug_* entries of include/vampnet_hip_debug.h change them for ONE context and bump `epoch`, so
+// forward graphs captured under an older setting are re-captured.  Nothing here is process-global: two contexts may run different
+// settings concurrently on their own streams (tests/test_gpu_kernels.py::test_two_contexts_tune_independently).
+struct vn_tune {
+    // gemm_f32.hip: tile walk order, stream-K start stagger, forced tile, scheduler (-1 auto, 0 data-parallel, 1 stream-K), split-K
+    int f32_order, f32_stagger, f32_bm, f32_bn, f32_sched, f32_splitk;
+    // gemm_x3.hip: forced tile height (0 = by shape), forced k-split (-2 = cost model), ablation bits (0 = none; results INVALID,
+    // settable only through vn_debug_x3_config), fused reduce + norm, LDS-staged epilogues, tile-walk group height (0 = 8)
+    int x3_bm, x3_split, x3_abl, x3_fuse_norm, x3_staged, x3_group_m;
+    // attention_x3.hip: decomposition (-1 by shape, 0 shared tiles, 1 / 2 / 4 key-split waves), dynamic-LDS override of the shared
+    // kernel (occupancy probe), start stagger, phase-trace buffer (device)
+    int ax_split, ax_lds, ax_stagger;
+    unsigned* ax_trace;
+    // engine.hip: bf16x3 models take the split-plane attention path (-1 by shape / LDS fit, 0 never, 1 always); operand plane layouts
+    int attn_x3, a_tiled, w_tiled;
+    unsigned epoch;
+};
+void vn_tune_init(vn_tune* t);
+
 struct vn_ctx {
     int device;
     char err[512];
     vn_prof prof;
+    vn_tune tune;
+    int cus;                 // compute units of the device (vn_ctx_create)
     // lazily allocated per-context device scratch (freed by vn_ctx_destroy): stream-K partial-sum slabs + hand-off flags
     // (gemm_f32.hip; launches of one context must be stream-ordered with each other, see include/vampnet_hip.h) and the
     // zero page the conv kernel DMAs its padding from (conv1d_f32.hip)
@@ -274,7 +297,12 @@ int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float
 // bf16x3 attention (attention_x3.hip): q16 / k16 planes [3][B][H][T][64] (plane_qk elements apart, q pre-scaled by 1/8),
 // vt16 planes [3][H][ceil(B T / 32)][64][32] over global token rows (plane_vt apart); out fp32 [B][T][H*64] or out16 split planes (plane16 apart)
 int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16, long plane_qk, const uint16_t* vt16, long plane_vt,
-                           const float* relbias_full, float* out, uint16_t* out16, long plane16, int B, int H, int T, hipStream_t s);
+                           const float* relbias_full, float* out, uint16_t* out16, long plane16, int B, int H, int T, int cus,
+                           hipStream_t s);
+// decomposition it will use (0 = shared 128-query tiles, KS = key-split waves per 32-query block) and the dynamic LDS that needs
+int vn_attention_x3_plan(const vn_ctx* ctx, int B, int H, int T, int cus);
+size_t vn_attention_x3_lds_bytes(int T, int key_split);
+static inline int vn_num_cus(const vn_ctx* ctx) { return ctx->cus > 0 ? ctx->cus : 256; }
 // expands [num_buckets][H] into per-head tables over rel = key - query in [-(T-1), T-1]: out[h][rel + T - 1]
 void vn_bucket_lut_host(int T, int num_buckets, int max_distance, int32_t* lut /* [2T-1] */);
 int vn_launch_bias_expand(vn_ctx* ctx, const float* rel_bias, const int32_t* lut_dev, float* out, int H, int T,
