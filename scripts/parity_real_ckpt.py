@@ -38,16 +38,21 @@ def _dims(kw):
 
 
 def load_models(args):
-    from vampnet_amd.checkpoint import load_model_checkpoint, load_tensor_dict, merge_lora_state_dict
+    from vampnet_amd.checkpoint import (load_model_checkpoint, load_tensor_dict, lora_scaling, merge_lora_state_dict,
+                                        validate_vampnet_state_dict)
+    from vampnet_amd.codec import DEFAULT_CFG, normalize_codec_kwargs, validate_codec_state_dict
     out = {}
     for name, path, lora in (("coarse", args.coarse, args.coarse_lora), ("c2f", args.c2f, args.c2f_lora)):
         sd, kw = load_model_checkpoint(path, package_name="VampNet", kwarg_keys=_KEYS, trusted=args.trusted)
         if lora:
             sd = {**sd, **load_tensor_dict(lora, trusted=args.trusted)}
-        n_lora = sum(k.endswith(".lora_A") for k in sd)
+        rep = validate_vampnet_state_dict(sd, kw)         # keys / shapes / adapter pairs against metadata.kwargs, before any packing
         out[name] = (merge_lora_state_dict(sd), _dims(kw))
-        print(f"{name}: {path}: {len(sd)} tensors, {n_lora} LoRA pairs merged, dims {out[name][1]}")
-    csd, _ = load_model_checkpoint(args.codec, package_name="DAC", trusted=args.trusted)
+        print(f"{name}: {path}: {rep['n_tensors']} tensors OK against kwargs {rep['kwargs']}; {rep['n_lora_pairs']} LoRA pairs "
+              f"(rank {rep['lora_rank']}, scaling {lora_scaling(sd):g}) merged")
+    csd, ckw = load_model_checkpoint(args.codec, package_name="DAC", kwarg_keys=tuple(DEFAULT_CFG), trusted=args.trusted)
+    validate_codec_state_dict(csd, dict(DEFAULT_CFG, **normalize_codec_kwargs(ckw)))
+    print(f"codec: {args.codec}: {len(csd)} tensors OK against kwargs {normalize_codec_kwargs(ckw)}")
     n = 1 + max(int(k.split(".")[2]) for k in csd if k.startswith("quantizer.quantizers."))
     out["codebooks"] = torch.stack([csd[f"quantizer.quantizers.{i}.codebook.weight"].float() for i in range(n)])
     return out

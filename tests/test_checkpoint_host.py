@@ -148,3 +148,59 @@ def test_parity_script_on_synthetic_checkpoints(tmp_path):
     with pytest.raises(PermissionError):
         mod.main(argv)                                     # the torch.package checkpoint needs --trusted
     assert mod.main(argv + ["--trusted"]) == 0
+
+
+def test_lora_merge_is_loralibs_eval_formula():
+    """merge_lora_state_dict against the public loralib.Linear arithmetic (loralib/layers.py, fan_in_fan_out=False): in train mode
+    the layer computes  x W^T + (x A^T B^T) * (lora_alpha / r);  `train(False)` folds  W += (B @ A) * scaling  once.  The merged
+    weight must reproduce the train-mode output, with r read from the adapters (not a constant): ranks 8 (the reference's LORA_R)
+    and 4."""
+    from vampnet_amd.checkpoint import lora_scaling, merge_lora_state_dict
+    g = torch.Generator().manual_seed(0)
+    for r in (8, 4):
+        W = torch.randn(48, 32, generator=g)
+        A, B = torch.randn(r, 32, generator=g), torch.randn(48, r, generator=g)
+        sd = {"lin.weight": W, "lin.lora_A": A, "lin.lora_B": B, "other.weight": torch.randn(5, 5, generator=g)}
+        assert lora_scaling(sd) == 1.0 / r
+        merged = merge_lora_state_dict(sd)
+        assert set(merged) == {"lin.weight", "other.weight"} and torch.equal(merged["other.weight"], sd["other.weight"])
+        x = torch.randn(7, 32, generator=g)
+        train_mode = torch.nn.functional.linear(x, W) + (x @ A.t() @ B.t()) * (1.0 / r)        # loralib Linear.forward, not merged
+        assert torch.allclose(torch.nn.functional.linear(x, merged["lin.weight"]), train_mode, atol=1e-5, rtol=1e-5)
+        assert torch.equal(merged["lin.weight"], W + (B @ A) * (1.0 / r))                       # loralib Linear.train(False)
+    with pytest.raises(ValueError):
+        merge_lora_state_dict({"a.weight": torch.zeros(4, 4), "a.lora_A": torch.zeros(2, 4), "a.lora_B": torch.zeros(4, 2),
+                               "b.weight": torch.zeros(4, 4), "b.lora_A": torch.zeros(3, 4), "b.lora_B": torch.zeros(4, 3)})
+    with pytest.raises(ValueError):
+        merge_lora_state_dict({"a.weight": torch.zeros(4, 4), "a.lora_A": torch.zeros(2, 5), "a.lora_B": torch.zeros(4, 2)})
+
+
+def test_vampnet_state_dict_validation():
+    """validate_vampnet_state_dict: a synthetic state_dict of the real layout passes against its kwargs and fails with a message
+    naming the tensor when the kwargs belong to another architecture, a tensor is missing, or adapters are inconsistent."""
+    from vampnet_amd import synth as W
+    from vampnet_amd.checkpoint import validate_vampnet_state_dict
+    from vampnet_amd.synth import model_kwargs
+    dims = W.TINY_COARSE_DIMS
+    sd, kw = W.synth_state_dict(dims, 0), model_kwargs(dims)
+    rep = validate_vampnet_state_dict(sd, kw)
+    assert rep["n_lora_pairs"] == 0 and rep["lora_rank"] is None and rep["kwargs"]["n_layers"] == dims["n_layers"]
+    with pytest.raises(ValueError, match="n_layers|layers"):
+        validate_vampnet_state_dict(sd, dict(kw, n_layers=dims["n_layers"] - 1))
+    with pytest.raises(ValueError, match="embedding.special.MASK"):
+        validate_vampnet_state_dict(sd, dict(kw, n_codebooks=kw["n_codebooks"] + 1))
+    broken = dict(sd)
+    del broken["transformer.layers.0.feed_forward.w_2.weight"]
+    with pytest.raises(ValueError, match="w_2"):
+        validate_vampnet_state_dict(broken, kw)
+    D = dims["d_model"]
+    lora = dict(sd)
+    lora["transformer.layers.0.self_attn.w_qs.lora_A"] = torch.zeros(8, D)
+    with pytest.raises(ValueError, match="only one of"):
+        validate_vampnet_state_dict(lora, kw)
+    lora["transformer.layers.0.self_attn.w_qs.lora_B"] = torch.zeros(D, 8)
+    assert validate_vampnet_state_dict(lora, kw)["lora_rank"] == 8
+    lora["transformer.layers.0.self_attn.w_ks.lora_A"] = torch.zeros(8, D)
+    lora["transformer.layers.0.self_attn.w_ks.lora_B"] = torch.zeros(D, 8)
+    with pytest.raises(ValueError, match="only adapts"):
+        validate_vampnet_state_dict(lora, kw)

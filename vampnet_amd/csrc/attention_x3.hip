@@ -218,7 +218,9 @@ __device__ __forceinline__ ax_src ax_src_init(const uint16_t* k16, const uint16_
     s.vplane = (unsigned)(plane_vt * 2);
     return s;
 }
-// one LDS-DMA wave-instruction: 64 lanes x 16 B from rsrc[voff (per lane) + soff (uniform) + imm] to lds .. + 1 KiB
+// one LDS-DMA wave-instruction: 64 lanes x 16 B from rsrc[voff (per lane) + soff (uniform) + IMM] to lds + IMM .. + 1 KiB — the
+// instruction offset of a buffer load to LDS is added on BOTH sides (MUBUF: LDS_ADDR = M0 base + inst_offset + lane * 16), so the
+// four 1 KiB pieces of a plane tile are one M0 setting and IMM = 0 / 1024 / 2048 / 3072
 template <int IMM = 0>
 __device__ __forceinline__ void ax_dma(__amdgpu_buffer_rsrc_t rsrc, float* lds, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, IMM, 0);
@@ -416,20 +418,22 @@ __global__ __launch_bounds__(KS * 64, 3) void vn_attention_x3_split_kernel(const
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const unsigned so = src.k0 + p * src.kplane + kt * (AX_KT * VN_DHEAD * 2);
-            ax_dma<0>(src.krs, mine + (4 * p + 0) * 256, kvoff_e, so);
-            ax_dma<1024>(src.krs, mine + (4 * p + 1) * 256, kvoff_o, so);
-            ax_dma<2048>(src.krs, mine + (4 * p + 2) * 256, kvoff_e, so);
-            ax_dma<3072>(src.krs, mine + (4 * p + 3) * 256, kvoff_o, so);
+            float* dst = mine + (4 * p) * 256;               // the instruction offset moves BOTH the source and the LDS address
+            ax_dma<0>(src.krs, dst, kvoff_e, so);
+            ax_dma<1024>(src.krs, dst, kvoff_o, so);
+            ax_dma<2048>(src.krs, dst, kvoff_e, so);
+            ax_dma<3072>(src.krs, dst, kvoff_o, so);
         }
     };
     auto stage_v = [&](int kt) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const unsigned so = src.v0 + p * src.vplane + kt * (VN_DHEAD * AX_KT * 2);
-            ax_dma<0>(src.vrs, mine + (12 + 4 * p + 0) * 256, vvoff, so);
-            ax_dma<1024>(src.vrs, mine + (12 + 4 * p + 1) * 256, vvoff, so);
-            ax_dma<2048>(src.vrs, mine + (12 + 4 * p + 2) * 256, vvoff, so);
-            ax_dma<3072>(src.vrs, mine + (12 + 4 * p + 3) * 256, vvoff, so);
+            float* dst = mine + (12 + 4 * p) * 256;
+            ax_dma<0>(src.vrs, dst, vvoff, so);
+            ax_dma<1024>(src.vrs, dst, vvoff, so);
+            ax_dma<2048>(src.vrs, dst, vvoff, so);
+            ax_dma<3072>(src.vrs, dst, vvoff, so);
         }
     };
 

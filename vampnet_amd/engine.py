@@ -169,7 +169,7 @@ def _merge_lora(sd, key):
     w = sd[key + ".weight"].float()
     a, b = sd.get(key + ".lora_A"), sd.get(key + ".lora_B")
     if a is not None and b is not None:
-        w = w + (b.float() @ a.float()) * LORA_SCALING
+        w = w + (b.float() @ a.float()) * (1.0 / a.shape[0])     # loralib scaling = lora_alpha (1) / r, r = rows of lora_A
     return w
 
 

@@ -22,14 +22,16 @@ from pathlib import Path
 import torch
 
 from . import masks
-from .checkpoint import load_model_checkpoint, load_tensor_dict
+from .checkpoint import load_model_checkpoint, load_tensor_dict, validate_vampnet_state_dict
 from .engine import Engine, VampNetModel
 
 
 def _load_checkpoint(path):
     """`VampNet.load(location=Path(ckpt), map_location="cpu", strict=False)` (interface.py:34): audiotools dict checkpoint or
     torch.package archive -> (state_dict, constructor kwargs); formats and the trust rule in vampnet_amd/checkpoint.py."""
-    return load_model_checkpoint(path, package_name="VampNet", kwarg_keys=_MODEL_KEYS)
+    sd, kw = load_model_checkpoint(path, package_name="VampNet", kwarg_keys=_MODEL_KEYS)
+    validate_vampnet_state_dict(sd, kw)          # a clear error for a file of another architecture, before anything is packed
+    return sd, kw
 
 
 def _load_lora(sd, lora_ckpt):
