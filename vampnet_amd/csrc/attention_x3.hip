@@ -106,20 +106,55 @@ __device__ __forceinline__ void ax_bias_init(f32x16& sacc, const float* bt, int 
     }
 }
 
-// S^T += K . Q^T for the K tile at Ks: four 16-wide d steps x six plane products (smallest terms first)
+// S^T += K . Q^T for the K tile at Ks: four 16-wide d steps x six plane products (smallest terms first).
+// DUAL: the 24 MFMAs of a tile all accumulate into sacc — one dependent chain, each link waiting for the previous result.  With
+// three waves per SIMD (the shared-tile kernel) other waves fill those gaps; a key-split block runs one or two waves per SIMD, so it
+// accumulates odd d steps in a second accumulator (two interleaved chains) and adds the two once (16 VALU adds, +16 VGPRs).
+template <bool DUAL = false>
 __device__ __forceinline__ void ax_qk(f32x16& sacc, const float* Ks, const bf16x8 (&qf)[3][4], const ax_lane& L) {
+    f32x16 sacc2;
+    if constexpr (DUAL) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        bf16x8 kf[3];
+        for (int r = 0; r < 16; ++r) sacc2[r] = 0.f;
+    }
+    if constexpr (!DUAL) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-            kf[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Ks + p * AX_PLANE_FLOATS + L.kOff + ((2 * s + L.hh) ^ L.kSw) * 4));
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[2][s], sacc, 0, 0, 0);
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[0][s], sacc, 0, 0, 0);
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[1][s], sacc, 0, 0, 0);
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[1][s], sacc, 0, 0, 0);
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[0][s], sacc, 0, 0, 0);
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][s], sacc, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 kf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                kf[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Ks + p * AX_PLANE_FLOATS + L.kOff + ((2 * s + L.hh) ^ L.kSw) * 4));
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[2][s], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[0][s], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[1][s], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[1][s], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[0][s], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][s], sacc, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {                    // d steps 2 s2 (-> sacc) and 2 s2 + 1 (-> sacc2), MFMAs alternating
+            bf16x8 ka[3], kb[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                ka[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Ks + p * AX_PLANE_FLOATS + L.kOff + ((4 * s2 + L.hh) ^ L.kSw) * 4));
+                kb[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Ks + p * AX_PLANE_FLOATS + L.kOff + ((4 * s2 + 2 + L.hh) ^ L.kSw) * 4));
+            }
+            const int sa = 2 * s2, sb = 2 * s2 + 1;
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0], qf[2][sa], sacc, 0, 0, 0);
+            sacc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[0], qf[2][sb], sacc2, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[2], qf[0][sa], sacc, 0, 0, 0);
+            sacc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[2], qf[0][sb], sacc2, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[1], qf[1][sa], sacc, 0, 0, 0);
+            sacc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[1], qf[1][sb], sacc2, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0], qf[1][sa], sacc, 0, 0, 0);
+            sacc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[0], qf[1][sb], sacc2, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[1], qf[0][sa], sacc, 0, 0, 0);
+            sacc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[1], qf[0][sb], sacc2, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0], qf[0][sa], sacc, 0, 0, 0);
+            sacc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[0], qf[0][sb], sacc2, 0, 0, 0);
+        }
+        sacc += sacc2;
     }
 }
 
@@ -168,23 +203,48 @@ __device__ __forceinline__ void ax_softmax(f32x16& sacc, bf16x8 (&pf)[3][2], flo
     l_run += full ? ax_probs<true>(sacc, pf, m_run) : ax_probs<false>(sacc, pf, m_run);
 }
 
-// O^T += V^T . P^T for the V^T tile at Vs: two 32-row d tiles x two 16-key steps x six plane products
+// O^T += V^T . P^T for the V^T tile at Vs: two 32-row d tiles x two 16-key steps x six plane products.
+// ILV: the MFMAs of the two d tiles alternate (two independent chains in flight instead of six dependent MFMAs in a row) —
+// for the key-split blocks, as above; costs the second tile's V^T fragments live at the same time (+12 VGPRs).
+template <bool ILV = false>
 __device__ __forceinline__ void ax_pv(f32x16 (&o)[2], const float* Vs, const bf16x8 (&pf)[3][2], const ax_lane& L) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 2; ++s) {
+        if constexpr (!ILV) {
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            bf16x8 vf[3];
+            for (int dt = 0; dt < 2; ++dt) {
+                bf16x8 vf[3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                vf[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Vs + p * AX_PLANE_FLOATS + (32 * dt + L.l31) * 16 + ((2 * s + L.hh) ^ L.vSw) * 4));
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[2][s], o[dt], 0, 0, 0);
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], pf[0][s], o[dt], 0, 0, 0);
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf[1][s], o[dt], 0, 0, 0);
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[1][s], o[dt], 0, 0, 0);
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf[0][s], o[dt], 0, 0, 0);
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[0][s], o[dt], 0, 0, 0);
+                for (int p = 0; p < 3; ++p)
+                    vf[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Vs + p * AX_PLANE_FLOATS + (32 * dt + L.l31) * 16 + ((2 * s + L.hh) ^ L.vSw) * 4));
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[2][s], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], pf[0][s], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf[1][s], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[1][s], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf[0][s], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[0][s], o[dt], 0, 0, 0);
+            }
+        } else {
+            bf16x8 va[3], vb[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                va[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Vs + p * AX_PLANE_FLOATS + L.l31 * 16 + ((2 * s + L.hh) ^ L.vSw) * 4));
+                vb[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Vs + p * AX_PLANE_FLOATS + (32 + L.l31) * 16 + ((2 * s + L.hh) ^ L.vSw) * 4));
+            }
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0], pf[2][s], o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[0], pf[2][s], o[1], 0, 0, 0);
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2], pf[0][s], o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[2], pf[0][s], o[1], 0, 0, 0);
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1], pf[1][s], o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[1], pf[1][s], o[1], 0, 0, 0);
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0], pf[1][s], o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[0], pf[1][s], o[1], 0, 0, 0);
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1], pf[0][s], o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[1], pf[0][s], o[1], 0, 0, 0);
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0], pf[0][s], o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[0], pf[0][s], o[1], 0, 0, 0);
         }
+    }
 }
 
 // one tile of the main loop from LDS images of K and V^T
@@ -378,7 +438,7 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
 // wave leaves (m, l, O) in its stage, and after ONE barrier wave w merges 8 / KS of the eight 4-column groups in the fixed order
 // w' = 0 .. KS - 1 (deterministic), normalises and stores them.
 template <int KS>
-__global__ __launch_bounds__(KS * 64, 3) void vn_attention_x3_split_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
+__global__ __launch_bounds__(KS * 64, 2) void vn_attention_x3_split_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
                                                                           long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
                                                                           const float* __restrict__ bias_full, float* __restrict__ out,
                                                                           uint16_t* __restrict__ out16, long plane16, int B, int H, int T) {
@@ -457,14 +517,14 @@ __global__ __launch_bounds__(KS * 64, 3) void vn_attention_x3_split_kernel(const
         if (full) ax_bias_init<true>(sacc, bt, key0, L.hh, qrow_c, T);
         else ax_bias_init<false>(sacc, bt, key0, L.hh, qrow_c, T);
         asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // K of this tile landed (its V^T pieces may still fly)
-        ax_qk(sacc, Ks, qf, L);
+        ax_qk<true>(sacc, Ks, qf, L);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every K fragment has been read: the K stage is free
         __builtin_amdgcn_sched_barrier(0);
         if (more) stage_k(kt + KS);
         ax_softmax(sacc, pf, m_run, l_run, o, key0, L.hh, T, full);
         if (more) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // V^T of this tile landed (the next K flies)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ax_pv(o, Vs, pf, L);
+        ax_pv<true>(o, Vs, pf, L);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (more) stage_v(kt + KS);
