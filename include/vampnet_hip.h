@@ -234,12 +234,24 @@ int vn_attention_bf16(vn_ctx* ctx, const float* q, const float* k, const float* 
  *   for t' in [0, T_rows): t_in = t'*in_stride + j*dil - pad (zero outside [0, T_in)),
  *   t_out = t'*out_stride + out_off (rows outside [0, T_out) are dropped).
  *   w dev [C_out][taps][C_in] (C_in % 32 == 0); y raw result or NULL; y2 = snake(result, alpha) or NULL
- *   (Snake1d of the NEXT layer fused: vampnet/modules/layers.py:12-18); act 1 = tanh.
+ *   (Snake1d of the NEXT layer fused: vampnet/modules/layers.py:12-18); act 1 = tanh; y2_16 = the same snake output as three
+ *   exact split bf16 planes [3][B*T_out][C_out] (y2_plane elements apart) for a consumer on the bf16x3 pipe, or NULL.
  *   Covers WNConv1d (any k/dilation/stride) and, one call per phase, WNConvTranspose1d(k=2s, stride s).       */
 int vn_conv1d_f32(vn_ctx* ctx, const float* x, const float* w, const float* bias, const float* resid,
-                  const float* alpha, float* y, float* y2, int B, int T_in, int T_rows, int T_out, int C_in,
-                  int C_out, int taps, int in_stride, int dil, int pad, int out_stride, int out_off, int act,
+                  const float* alpha, float* y, float* y2, void* y2_16, int64_t y2_plane, int B, int T_in, int T_rows, int T_out,
+                  int C_in, int C_out, int taps, int in_stride, int dil, int pad, int out_stride, int out_off, int act,
                   void* stream);
+/* The same operator with the products on the bf16 matrix cores at fp32 grade (gemm_x3.hip's implicit-GEMM mode: six bf16-MFMA
+ * products of exact 3-way operand splits, fp32 accumulate): x16 = split planes of the input [3][B*T_in][C_in] (x_plane elements
+ * apart; C_in % 32 == 0), w_tiled = the TILED planes of w viewed as [C_out][taps*C_in] (vn_split3_f32, then vn_tile_planes_bf16x3;
+ * C_out % 16 == 0).  Outputs as vn_conv1d_f32 (at least one of y / y2 / y2_16).                                              */
+int vn_conv1d_bf16x3(vn_ctx* ctx, const void* x16, int64_t x_plane, const void* w_tiled, const float* bias, const float* resid,
+                     const float* alpha, float* y, float* y2, void* y2_16, int64_t y2_plane, int B, int T_in, int T_rows, int T_out,
+                     int C_in, int C_out, int taps, int in_stride, int dil, int pad, int out_stride, int out_off, int act,
+                     void* stream);
+/* planar split planes [3][rows][K] (plane_stride elements apart; rows % 16 == 0, K % 32 == 0) -> the tiled layout
+ * [rows/16][K/32][3][16][32] in which the bf16x3 GEMM / convolution read their weights (`tiled`: 3*rows*K bf16)              */
+int vn_tile_planes_bf16x3(vn_ctx* ctx, const void* planes, int64_t plane_stride, void* tiled, int64_t rows, int K, void* stream);
 /* encoder stem WNConv1d(1 -> C, k=7, pad 3): x dev [B][T], w dev [C][7]; y / y2 as above                      */
 int vn_dac_conv_in_f32(vn_ctx* ctx, const float* x, const float* w, const float* bias, const float* alpha,
                        float* y, float* y2, int B, int T, int C, void* stream);

@@ -8,8 +8,8 @@ from vampnet_amd.engine import Engine
 
 eng = Engine("cuda:0")
 cfg = D.DAC_DEFAULT_CFG
-codec = DacCodec(D.synth_dac_state_dict(cfg, 0), cfg, engine=eng)
-for B in (1, 8):
+for precision, B in (("bf16x3", 1), ("bf16x3", 8), ("f32", 8)):
+    codec = DacCodec(D.synth_dac_state_dict(cfg, 0), cfg, engine=eng, precision=precision)
     audio = 0.1 * torch.randn(B, 1, 575 * 768, device="cuda")
     for name, fn in (("encode", lambda: codec.encode(audio)["codes"]), ("decode", None)):
         if name == "decode":
@@ -24,6 +24,6 @@ for B in (1, 8):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         st = eng.profile_end()["conv1d"]
-        print(json.dumps({"op": name, "batch": B, "ms": round(dt * 1e3, 2), "clip_seconds_per_s": round(B * 10.0 / dt, 1),
+        print(json.dumps({"op": name, "pipe": precision, "batch": B, "ms": round(dt * 1e3, 2), "clip_seconds_per_s": round(B * 10.0 / dt, 1),
                           "conv_launches": int(st[0] / n), "conv_ms": round(st[1] / n, 2), "conv_TF": round(st[2] / st[1] / 1e9, 1),
                           "conv_GFLOP": round(st[2] / n / 1e9, 1), "conv_algorithmic_GB": round(st[3] / n / 1e9, 2)}), flush=True)

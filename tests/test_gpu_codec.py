@@ -24,11 +24,21 @@ def _audio(B, L, seed=0):
     return torch.from_numpy(x.astype(np.float32))
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
 @pytest.mark.parametrize("cfg,B,frames", [(D.DAC_TINY_CFG, 2, 50), (D.DAC_TINY_CFG, 1, 7), (D.DAC_DEFAULT_CFG, 2, 12)])
-def test_encode_decode_vs_oracle(eng, cfg, B, frames):
+def test_encode_decode_vs_oracle(eng, cfg, B, frames, precision):
+    """both codec pipes at the SAME bars: "f32" = every convolution on the fp32-input MFMA kernel; "bf16x3" (default) = the
+    MFMA-bound convolutions (>= 96 output channels, K >= 256) as six bf16-MFMA products of exact operand splits (gemm_x3.hip's
+    implicit-GEMM mode), the rest on the fp32 kernels, activations handed over as split planes / fp32 as each consumer reads them"""
     from vampnet_amd.codec import DacCodec
     sd = D.synth_dac_state_dict(cfg, 0)
-    codec = DacCodec(sd, cfg, engine=eng)
+    codec = DacCodec(sd, cfg, engine=eng, precision=precision)
+    n_x3 = sum(1 for blk in codec.enc["blocks"] for r in blk["res"] for c in (r["c7"], r["c1"]) if "w16" in c)
+    n_x3 += sum(1 for blk in codec.dec["blocks"] for r in blk["res"] for c in (r["c7"], r["c1"]) if "w16" in c)
+    if precision == "f32":
+        assert n_x3 == 0 and "w16" not in codec.dec["in"]
+    elif cfg is D.DAC_DEFAULT_CFG:
+        assert n_x3 > 0 and "w16" in codec.dec["in"]
     hop = D.hop_length(cfg)
     assert codec.hop_length == hop
     audio = _audio(B, hop * frames - 3)
@@ -133,3 +143,87 @@ def test_vamp_service_end_to_end(eng):
                  sample_cutoff=1.0)
     hand = itf.decode(z).normalize(torch.tensor([want, want]))
     assert torch.equal(torch.from_numpy(a0), hand.samples[0, 0].cpu()) and torch.equal(torch.from_numpy(a1), hand.samples[1, 0].cpu())
+
+
+CONV_CASES = [  # (B, T_in, C_in, C_out, taps, in_stride, dil, pad, note)
+    (2, 300, 128, 128, 7, 1, 1, 3, "k7"),
+    (2, 300, 128, 128, 7, 1, 9, 27, "k7 dilation 9: 27 zero rows either side"),
+    (1, 257, 256, 96, 7, 1, 3, 9, "96 output channels (a 128-wide tile with masked columns)"),
+    (2, 240, 128, 256, 8, 4, 1, 2, "strided down-sampling k = 2 s, s = 4"),
+    (3, 100, 512, 192, 1, 1, 1, 0, "k = 1 tail"),
+    (1, 33, 1024, 1024, 3, 1, 1, 1, "final encoder conv"),
+]
+
+
+@pytest.mark.parametrize("B,T,cin,cout,taps,stride,dil,pad,note", CONV_CASES)
+def test_conv1d_bf16x3_vs_torch_and_f32_kernel(eng, B, T, cin, cout, taps, stride, dil, pad, note):
+    """vn_conv1d_bf16x3 (implicit GEMM on the bf16 matrix cores, exact 3-way splits) against torch's conv1d in float64 and against
+    vn_conv1d_f32 on the same inputs: same fp32-grade tolerance; raw, snake-fp32 and snake-planes outputs, bias + residual."""
+    import ctypes as C
+    from vampnet_amd.codec import DacCodec
+    g = torch.Generator().manual_seed(hash((B, T, cin, cout, taps)) % 1000)
+    x = torch.randn(B, T, cin, generator=g)
+    w = torch.randn(cout, taps, cin, generator=g) / math.sqrt(taps * cin)
+    bias, alpha = torch.randn(cout, generator=g), torch.rand(cout, generator=g) + 0.5
+    T_out = (T + 2 * pad - dil * (taps - 1) - 1) // stride + 1
+    resid = torch.randn(B, T_out, cout, generator=g)
+    ref = torch.nn.functional.conv1d(x.double().permute(0, 2, 1), w.double().permute(0, 2, 1), bias.double(), stride=stride,
+                                     padding=pad, dilation=dil).permute(0, 2, 1) + resid.double()
+    ref_s = ref + torch.sin(alpha.double() * ref) ** 2 / (alpha.double() + 1e-9)
+    lib, dev = eng.lib, "cuda"
+    xd, wd, bd, ad, rd = (t.to(dev).contiguous() for t in (x, w, bias, alpha, resid))
+    x16 = eng.split3(xd.reshape(-1, cin))
+    codec = DacCodec.__new__(DacCodec)
+    codec.engine, codec.lib, codec.device = eng, lib, eng.device
+    w16 = codec._tile_planes(wd.reshape(cout, -1))
+    y, y2 = torch.empty(B, T_out, cout, device=dev), torch.empty(B, T_out, cout, device=dev)
+    y216 = torch.empty(3, B * T_out, cout, device=dev, dtype=torch.bfloat16)
+    eng.check(lib.vn_conv1d_bf16x3(eng.handle, x16.data_ptr(), B * T * cin, w16.data_ptr(), bd.data_ptr(), rd.data_ptr(), ad.data_ptr(),
+                                   y.data_ptr(), y2.data_ptr(), y216.data_ptr(), B * T_out * cout, B, T, T_out, T_out, cin, cout, taps,
+                                   stride, dil, pad, 1, 0, 0, eng.stream()), "vn_conv1d_bf16x3")
+    yf, y2f = torch.empty_like(y), torch.empty_like(y2)
+    y216f = torch.empty_like(y216)
+    eng.check(lib.vn_conv1d_f32(eng.handle, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr(), ad.data_ptr(), yf.data_ptr(),
+                                y2f.data_ptr(), y216f.data_ptr(), B * T_out * cout, B, T, T_out, T_out, cin, cout, taps, stride, dil, pad,
+                                1, 0, 0, eng.stream()), "vn_conv1d_f32")
+    torch.cuda.synchronize()
+    absdot = torch.nn.functional.conv1d(x.abs().double().permute(0, 2, 1), w.abs().double().permute(0, 2, 1), bias.abs().double(),
+                                        stride=stride, padding=pad, dilation=dil).permute(0, 2, 1) + resid.abs().double()
+    tol = (2e-6 * absdot + 1e-6)
+    for name, got in (("bf16x3", y), ("f32", yf)):
+        err = (got.cpu().double() - ref).abs()
+        print(f"{note}: {name} raw max err {err.max().item():.3e}")
+        assert bool((err <= tol).all()), name
+    for name, got in (("bf16x3", y2), ("f32", y2f)):
+        assert (got.cpu().double() - ref_s).abs().max().item() <= 2e-5, name
+    for name, planes, dense in (("bf16x3", y216, y2), ("f32", y216f, y2f)):
+        p = planes.float()
+        assert torch.equal((p[0] + p[1] + p[2]).reshape(B, T_out, cout), dense), name + ": the planes must sum to the fp32 snake output exactly"
+
+
+def test_conv_transpose_phases_on_bf16x3(eng):
+    """WNConvTranspose1d(k = 2 s, stride s) as s two-tap phase convolutions (dil = -1, out_stride = s) through the bf16x3 entry,
+    against torch's conv_transpose1d in float64."""
+    from vampnet_amd.codec import DacCodec
+    g = torch.Generator().manual_seed(3)
+    B, T, cin, cout, st = 2, 40, 256, 128, 4
+    x = torch.randn(B, T, cin, generator=g)
+    w = torch.randn(cin, cout, 2 * st, generator=g) / math.sqrt(2 * cin)          # ConvTranspose1d weight layout
+    bias = torch.randn(cout, generator=g)
+    pad = math.ceil(st / 2)
+    T_out = (T - 1) * st - 2 * pad + 2 * st
+    ref = torch.nn.functional.conv_transpose1d(x.double().permute(0, 2, 1), w.double(), bias.double(), stride=st, padding=pad).permute(0, 2, 1)
+    codec = DacCodec.__new__(DacCodec)
+    codec.engine, codec.lib, codec.device = eng, eng.lib, eng.device
+    x16 = eng.split3(x.cuda().reshape(-1, cin))
+    y = torch.zeros(B, T_out, cout, device="cuda")
+    bd = bias.cuda()
+    for r in range(st):
+        ph = torch.stack([w[:, :, r], w[:, :, r + st]], dim=0).permute(2, 0, 1).contiguous().cuda()      # [Cout][2][Cin]
+        w16 = codec._tile_planes(ph.reshape(cout, -1))
+        eng.check(eng.lib.vn_conv1d_bf16x3(eng.handle, x16.data_ptr(), B * T * cin, w16.data_ptr(), bd.data_ptr(), None, None,
+                                           y.data_ptr(), None, None, 0, B, T, T + 1, T_out, cin, cout, 2, 1, -1, 0, st, r - pad, 0,
+                                           eng.stream()), "vn_conv1d_bf16x3")
+    err = (y.cpu().double() - ref).abs().max().item()
+    print(f"transposed conv via {st} phases on the bf16x3 pipe: max err {err:.3e}")
+    assert err <= 2e-5

@@ -198,10 +198,28 @@ def _fold(sd, key):
     return sd[key + ".weight"].float()
 
 
+class _Act:
+    """A channels-last activation [B][T][C] in the format(s) its consumer reads: `f32` for the fp32-input MFMA convolution
+    (conv1d_f32.hip), `p16` = three exact split bf16 planes [3][B*T][C] for the bf16x3 pipe (gemm_x3.hip's implicit-GEMM mode)."""
+    __slots__ = ("f32", "p16")
+
+    def __init__(self, f32=None, p16=None):
+        self.f32, self.p16 = f32, p16
+
+
 class DacCodec:
-    def __init__(self, sd: dict, cfg: dict = None, device="cuda:0", engine: Engine = None):
+    # a convolution runs on the bf16x3 pipe (six bf16-MFMA products of exact operand splits: the transformer's GEMM kernel with the
+    # A rows gathered per tap) when it is MFMA-bound there: >= 96 output channels (the tile is 128 wide: 64 would waste half of it)
+    # and K = taps * C_in >= 256.  The 64-channel audio-rate block of the encoder, the k = 1 tails below 256 channels (HBM-bound:
+    # planes are 6 bytes per element against 4) and the 1-channel stem / head stay on the fp32 kernels.
+    X3_MIN_COUT, X3_MIN_K = 96, 256
+
+    def __init__(self, sd: dict, cfg: dict = None, device="cuda:0", engine: Engine = None, precision: str = "bf16x3"):
         cfg = dict(DEFAULT_CFG, **(cfg or {}))
         self.cfg = cfg
+        if precision not in ("bf16x3", "f32"):
+            raise ValueError("precision must be 'bf16x3' (fp32-grade products on the bf16 matrix cores) or 'f32'")
+        self.precision = precision
         self.engine = engine or Engine(device)
         self.lib = self.engine.lib
         self.device = self.engine.device
@@ -213,13 +231,19 @@ class DacCodec:
 
         def conv(key):          # Conv1d (Cout, Cin, k) -> [Cout][k][Cin]
             w = _fold(sd, key)
-            return dict(w=w.permute(0, 2, 1).contiguous().to(dev), b=sd[key + ".bias"].float().to(dev),
-                        cout=w.shape[0], cin=w.shape[1], k=w.shape[2])
+            c = dict(w=w.permute(0, 2, 1).contiguous().to(dev), b=sd[key + ".bias"].float().to(dev),
+                     cout=w.shape[0], cin=w.shape[1], k=w.shape[2])
+            if self._on_x3(c):
+                c["w16"] = self._tile_planes(c["w"].reshape(c["cout"], -1))
+            return c
 
         def convT(key, s):      # ConvTranspose1d (Cin, Cout, 2s) -> per phase r: [Cout][2][Cin] = w[ci][co][r + jj*s]
             w = _fold(sd, key)
             ph = torch.stack([torch.stack([w[:, :, r], w[:, :, r + s]], dim=0).permute(2, 0, 1) for r in range(s)])
-            return dict(w=ph.contiguous().to(dev), b=sd[key + ".bias"].float().to(dev), cout=w.shape[1], cin=w.shape[0], s=s)
+            c = dict(w=ph.contiguous().to(dev), b=sd[key + ".bias"].float().to(dev), cout=w.shape[1], cin=w.shape[0], s=s)
+            if self._on_x3(c, taps=2):
+                c["w16"] = [self._tile_planes(c["w"][r].reshape(c["cout"], -1)) for r in range(s)]
+            return c
 
         def alpha(key):
             return sd[key + ".alpha"].float().reshape(-1).contiguous().to(dev)
@@ -273,27 +297,70 @@ class DacCodec:
         return cls(sd, cfg, device=device, engine=engine)
 
     # ---- kernels ------------------------------------------------------------------------------
-    def _conv(self, x, c, *, T_in, T_rows, T_out, w=None, taps=None, in_stride=1, dil=1, pad=0, out_stride=1,
-              out_off=0, resid=None, alpha=None, want_raw=True, act=0, y=None, y2=None):
-        B = x.shape[0]
+    def _on_x3(self, c, taps=None):
+        taps = c.get("k", 2) if taps is None else taps
+        return (self.precision == "bf16x3" and c["cout"] >= self.X3_MIN_COUT and c["cout"] % 16 == 0 and c["cin"] % 32 == 0
+                and taps * c["cin"] >= self.X3_MIN_K)
+
+    def _fmt(self, c, taps=None):
+        """input format of convolution c: "x3" (split planes) or "f32" """
+        return "x3" if self._on_x3(c, taps) else "f32"
+
+    def _tile_planes(self, w2d):
+        """fp32 [rows][K] on the device -> the tiled split planes the bf16x3 kernel reads weights in (3 * rows * K bf16)"""
+        eng = self.engine
+        rows, K = w2d.shape
+        planes = eng.split3(w2d.contiguous())
+        tiled = torch.empty(3 * rows * K, dtype=torch.bfloat16, device=self.device)
+        eng.check(self.lib.vn_tile_planes_bf16x3(eng.handle, planes.data_ptr(), rows * K, tiled.data_ptr(), rows, K, eng.stream()),
+                  "vn_tile_planes_bf16x3")
+        return tiled
+
+    def _planes(self, x):
+        """fp32 [B][T][C] -> _Act with split planes (the few places where a producer outside the conv stack feeds the bf16x3 pipe)"""
+        return _Act(f32=x, p16=self.engine.split3(x.reshape(-1, x.shape[-1])))
+
+    def _conv(self, x, c, *, T_in, T_rows, T_out, phase=None, taps=None, in_stride=1, dil=1, pad=0, out_stride=1, out_off=0,
+              resid=None, alpha=None, want_raw=True, s_fmt=None, act=0, out=None):
+        """One convolution launch.  x: _Act holding the format this convolution reads.  Returns (raw fp32 result or None, _Act of
+        snake(result, alpha) in the format(s) `s_fmt` names: "f32", "x3", "both" or None).  `out` = (raw, _Act) buffers to write
+        into (the phases of a transposed convolution share theirs)."""
+        eng = self.engine
         cout, cin = c["cout"], c["cin"]
+        taps = c.get("k", 2) if taps is None else taps
+        x3 = self._on_x3(c, taps)
+        src = x.p16 if x3 else x.f32
+        assert src is not None, "producer / consumer format mismatch in the codec graph"
+        B = src.shape[0] if not x3 else src.shape[1] // T_in
+        y, sn = out if out is not None else (None, None)
         if want_raw and y is None:
             y = torch.empty(B, T_out, cout, device=self.device, dtype=torch.float32)
-        if alpha is not None and y2 is None:
-            y2 = torch.empty(B, T_out, cout, device=self.device, dtype=torch.float32)
-        w = c["w"] if w is None else w
-        taps = c.get("k", 2) if taps is None else taps
-        self.engine.check(self.lib.vn_conv1d_f32(
-            self.engine.handle, x.data_ptr(), w.data_ptr(), c["b"].data_ptr(),
-            resid.data_ptr() if resid is not None else None, alpha.data_ptr() if alpha is not None else None,
-            y.data_ptr() if y is not None else None, y2.data_ptr() if y2 is not None else None,
-            B, T_in, T_rows, T_out, cin, cout, taps, in_stride, dil, pad, out_stride, out_off, act,
-            self.engine.stream()), "vn_conv1d_f32")
-        return y, y2
+        if s_fmt is not None and sn is None:
+            assert alpha is not None
+            sn = _Act(torch.empty(B, T_out, cout, device=self.device, dtype=torch.float32) if s_fmt in ("f32", "both") else None,
+                      torch.empty(3, B * T_out, cout, device=self.device, dtype=torch.bfloat16) if s_fmt in ("x3", "both") else None)
+        p = lambda t: t.data_ptr() if t is not None else None
+        y2, y216 = (sn.f32, sn.p16) if sn is not None else (None, None)
+        plane = B * T_out * cout
+        if x3:
+            w16 = c["w16"] if phase is None else c["w16"][phase]
+            eng.check(self.lib.vn_conv1d_bf16x3(
+                eng.handle, src.data_ptr(), src.shape[1] * src.shape[2], w16.data_ptr(), c["b"].data_ptr(), p(resid), p(alpha),
+                p(y), p(y2), p(y216), plane, B, T_in, T_rows, T_out, cin, cout, taps, in_stride, dil, pad, out_stride, out_off, act,
+                eng.stream()), "vn_conv1d_bf16x3")
+        else:
+            w = c["w"] if phase is None else c["w"][phase]
+            eng.check(self.lib.vn_conv1d_f32(
+                eng.handle, src.data_ptr(), w.data_ptr(), c["b"].data_ptr(), p(resid), p(alpha), p(y), p(y2), p(y216), plane,
+                B, T_in, T_rows, T_out, cin, cout, taps, in_stride, dil, pad, out_stride, out_off, act, eng.stream()), "vn_conv1d_f32")
+        return y, sn
 
-    def _res_unit(self, x, s, r, dil, alpha_next, T):
-        _, hs = self._conv(s, r["c7"], T_in=T, T_rows=T, T_out=T, dil=dil, pad=3 * dil, alpha=r["a2"], want_raw=False)
-        return self._conv(hs, r["c1"], T_in=T, T_rows=T, T_out=T, resid=x, alpha=alpha_next)
+    def _res_unit(self, x, s, r, dil, alpha_next, T, next_fmt):
+        """ResidualUnit: x + conv1(snake(conv7(snake(x)))).  x = raw fp32 residual stream, s = snake(x) as the k = 7 convolution
+        reads it; returns (x', snake(x', alpha_next) in `next_fmt`)."""
+        _, hs = self._conv(s, r["c7"], T_in=T, T_rows=T, T_out=T, dil=dil, pad=3 * dil, alpha=r["a2"], want_raw=False,
+                           s_fmt=self._fmt(r["c1"]))
+        return self._conv(hs, r["c1"], T_in=T, T_rows=T, T_out=T, resid=x, alpha=alpha_next, s_fmt=next_fmt)
 
     # ---- reference API ------------------------------------------------------------------------
     def preprocess(self, audio_data, sample_rate=None):
@@ -314,22 +381,25 @@ class DacCodec:
         e, eng = self.enc, self.engine
         C0 = e["stem"]["c"]
         cur = torch.empty(B, L, C0, device=self.device)
-        s = torch.empty(B, L, C0, device=self.device)
+        s0 = torch.empty(B, L, C0, device=self.device)
         eng.check(self.lib.vn_dac_conv_in_f32(eng.handle, x.data_ptr(), e["stem"]["w"].data_ptr(), e["stem"]["b"].data_ptr(),
-                                              e["blocks"][0]["res"][0]["a1"].data_ptr(), cur.data_ptr(), s.data_ptr(), B, L, C0,
+                                              e["blocks"][0]["res"][0]["a1"].data_ptr(), cur.data_ptr(), s0.data_ptr(), B, L, C0,
                                               eng.stream()), "vn_dac_conv_in_f32")
+        s = _Act(f32=s0) if self._fmt(e["blocks"][0]["res"][0]["c7"]) == "f32" else self._planes(s0)
         T = L
         nb = len(e["blocks"])
         for bi, blk in enumerate(e["blocks"]):
             for j, dil in enumerate((1, 3, 9)):
                 a_next = blk["res"][j + 1]["a1"] if j < 2 else blk["a"]
-                cur, s = self._res_unit(cur, s, blk["res"][j], dil, a_next, T)
+                nxt = self._fmt(blk["res"][j + 1]["c7"]) if j < 2 else self._fmt(blk["down"])
+                cur, s = self._res_unit(cur, s, blk["res"][j], dil, a_next, T, nxt)
             st = blk["s"]
             pad = math.ceil(st / 2)
             T_out = (T + 2 * pad - 2 * st) // st + 1
             a_next = e["blocks"][bi + 1]["res"][0]["a1"] if bi + 1 < nb else e["a_out"]
+            nxt = self._fmt(e["blocks"][bi + 1]["res"][0]["c7"]) if bi + 1 < nb else self._fmt(e["out"])
             cur, s = self._conv(s, blk["down"], T_in=T, T_rows=T_out, T_out=T_out, in_stride=st, pad=pad, alpha=a_next,
-                                want_raw=bi + 1 < nb)
+                                want_raw=bi + 1 < nb, s_fmt=nxt)
             T = T_out
         z, _ = self._conv(s, e["out"], T_in=T, T_rows=T, T_out=T, pad=1)
         codes = torch.empty(B, self.n_codebooks, T, device=self.device, dtype=torch.int64)
@@ -351,22 +421,32 @@ class DacCodec:
         eng.check(self.lib.vn_rvq_decode_f32(eng.handle, codes.data_ptr(), r["cb"].data_ptr(), r["wout"].data_ptr(),
                                              r["bout"].data_ptr(), zq.data_ptr(), B, T, self.latent_dim, n,
                                              self.cfg["codebook_size"], eng.stream()), "vn_rvq_decode_f32")
-        _, s = self._conv(zq, d["in"], T_in=T, T_rows=T, T_out=T, pad=3, alpha=d["blocks"][0]["a"], want_raw=False)
+        zin = _Act(f32=zq) if self._fmt(d["in"]) == "f32" else self._planes(zq)
+        _, s = self._conv(zin, d["in"], T_in=T, T_rows=T, T_out=T, pad=3, alpha=d["blocks"][0]["a"], want_raw=False,
+                          s_fmt=self._fmt(d["blocks"][0]["up"], taps=2))
         nb = len(d["blocks"])
         cur = None
         for bi, blk in enumerate(d["blocks"]):
             st, up = blk["s"], blk["up"]
             pad = math.ceil(st / 2)
             T_out = (T - 1) * st - 2 * pad + 2 * st
+            f0 = self._fmt(blk["res"][0]["c7"])
             y = torch.empty(B, T_out, up["cout"], device=self.device)
-            y2 = torch.empty(B, T_out, up["cout"], device=self.device)
+            y2 = _Act(torch.empty(B, T_out, up["cout"], device=self.device) if f0 == "f32" else None,
+                      torch.empty(3, B * T_out, up["cout"], device=self.device, dtype=torch.bfloat16) if f0 == "x3" else None)
             for ph in range(st):        # polyphase: output rows t = t'*st + ph - pad read x[t'] and x[t'-1]
-                self._conv(s, up, w=up["w"][ph], taps=2, T_in=T, T_rows=T + 1, T_out=T_out, in_stride=1, dil=-1, pad=0,
-                           out_stride=st, out_off=ph - pad, alpha=blk["res"][0]["a1"], y=y, y2=y2)
+                self._conv(s, up, phase=ph, taps=2, T_in=T, T_rows=T + 1, T_out=T_out, in_stride=1, dil=-1, pad=0,
+                           out_stride=st, out_off=ph - pad, alpha=blk["res"][0]["a1"], s_fmt=f0, out=(y, y2))
             cur, s, T = y, y2, T_out
             for j, dil in enumerate((1, 3, 9)):
-                a_next = blk["res"][j + 1]["a1"] if j < 2 else (d["blocks"][bi + 1]["a"] if bi + 1 < nb else d["a_out"])
-                cur, s = self._res_unit(cur, s, blk["res"][j], dil, a_next, T)
+                if j < 2:
+                    a_next, nxt = blk["res"][j + 1]["a1"], self._fmt(blk["res"][j + 1]["c7"])
+                elif bi + 1 < nb:
+                    a_next, nxt = d["blocks"][bi + 1]["a"], self._fmt(d["blocks"][bi + 1]["up"], taps=2)
+                else:
+                    a_next, nxt = d["a_out"], "f32"                  # the 1-channel head reads fp32
+                cur, s = self._res_unit(cur, s, blk["res"][j], dil, a_next, T, nxt)
+        s = s.f32
         audio = torch.empty(B, T, device=self.device)
         eng.check(self.lib.vn_dac_conv_out_f32(eng.handle, s.data_ptr(), d["head_w"].data_ptr(), d["head_b"], audio.data_ptr(),
                                                B, T, s.shape[-1], eng.stream()), "vn_dac_conv_out_f32")

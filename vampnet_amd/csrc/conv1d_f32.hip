@@ -28,6 +28,8 @@ struct vn_conv_args {
     const float* alpha;   // [C_out] (needed iff y2)
     float* y;             // [B][T_out][C_out] raw result or null
     float* y2;            // snake(result) or null
+    uint16_t* y2_16;      // snake(result) as three split bf16 planes (y2_plane elements apart) for a consumer on the bf16x3 pipe, or null
+    long y2_plane;
     const float* zeros;   // >= 128 B of zeros
     int B, T_in, T_rows, T_out, C_in, C_out, taps;
     int in_stride, dil, pad;       // t_in  = t' * in_stride + j * dil - pad
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void vn_conv1d_f32_kernel(vn_conv_args p, i
     if (col < p.C_out && tid < CG * RPP) {                 // C_out % 4 == 0: a float4 is valid as a whole
         f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, al4 = {1.f, 1.f, 1.f, 1.f}, inv4 = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) bias4 = *(const f32x4*)(p.bias + col);
-        if (p.y2) {
+        if (p.y2 || p.y2_16) {
             al4 = *(const f32x4*)(p.alpha + col);
 #pragma unroll
             for (int e = 0; e < 4; ++e) inv4[e] = 1.0f / (al4[e] + 1e-9f);
@@ -182,14 +184,15 @@ __global__ __launch_bounds__(256, 2) void vn_conv1d_f32_kernel(vn_conv_args p, i
             }
             if (p.act == 1) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
             if (p.y) *(f32x4*)(p.y + o) = v;
-            if (p.y2) {
+            if (p.y2 || p.y2_16) {
                 f32x4 w4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float sn = sinf(al4[e] * v[e]);
                     w4[e] = v[e] + inv4[e] * (sn * sn);
                 }
-                *(f32x4*)(p.y2 + o) = w4;
+                if (p.y2) *(f32x4*)(p.y2 + o) = w4;
+                if (p.y2_16) vn_store_bf16x4(p.y2_16 + o, p.y2_plane, w4);
             }
         }
     }
@@ -201,7 +204,7 @@ static int launch_conv(vn_ctx* ctx, const vn_conv_args& a, hipStream_t s) {
     const int tiles_m = vn_cdiv(M, BM), tiles_n = vn_cdiv(a.C_out, BN);
     constexpr int LDS = 2 * (BM + BN) * BK * 4;
     const double bytes = 4.0 * ((double)a.B * a.T_in * a.C_in + (double)a.C_out * a.taps * a.C_in +
-                                (double)M * a.C_out * ((a.y ? 1 : 0) + (a.y2 ? 1 : 0) + (a.resid ? 1 : 0)));
+                                (double)M * a.C_out * ((a.y ? 1 : 0) + (a.y2 ? 1 : 0) + (a.y2_16 ? 1.5 : 0) + (a.resid ? 1 : 0)));
     const int pi = vn_prof_pre(ctx, 2, 2.0 * M * (double)a.C_out * a.taps * a.C_in, s, bytes);
     hipLaunchKernelGGL((vn_conv1d_f32_kernel<BM, BN, WM>), dim3(tiles_m * tiles_n), dim3(256), LDS, s, a, tiles_m, tiles_n);
     vn_prof_post(ctx, pi, s);
@@ -217,18 +220,20 @@ static int zero_page(vn_ctx* ctx) {
 }
 
 extern "C" int vn_conv1d_f32(vn_ctx* ctx, const float* x, const float* w, const float* bias, const float* resid,
-                             const float* alpha, float* y, float* y2, int B, int T_in, int T_rows, int T_out, int C_in,
-                             int C_out, int taps, int in_stride, int dil, int pad, int out_stride, int out_off, int act,
-                             void* stream) {
-    if (!ctx || !x || !w || (!y && !y2)) return VN_ERR_INVALID;
+                             const float* alpha, float* y, float* y2, void* y2_16, int64_t y2_plane, int B, int T_in, int T_rows,
+                             int T_out, int C_in, int C_out, int taps, int in_stride, int dil, int pad, int out_stride, int out_off,
+                             int act, void* stream) {
+    if (!ctx || !x || !w || (!y && !y2 && !y2_16)) return VN_ERR_INVALID;
+    if (y2_16 && (y2_plane <= 0 || (y2_plane & 3) || ((uintptr_t)y2_16 & 7)))
+        return vn_fail(ctx, VN_ERR_INVALID, "conv1d: the plane output needs an 8-byte aligned base and a plane stride %% 4 == 0%s", "");
     if (C_in % BK) return vn_fail(ctx, VN_ERR_INVALID, "conv1d: C_in=%s%ld must be a multiple of 32", "", C_in);
     if (C_out % 4) return vn_fail(ctx, VN_ERR_INVALID, "conv1d: C_out=%s%ld must be a multiple of 4", "", C_out);
-    if (y2 && !alpha) return vn_fail(ctx, VN_ERR_INVALID, "conv1d: snake output needs alpha%s", "");
+    if ((y2 || y2_16) && !alpha) return vn_fail(ctx, VN_ERR_INVALID, "conv1d: snake output needs alpha%s", "");
     if (B <= 0 || T_rows <= 0 || C_out <= 0 || taps <= 0) return vn_fail(ctx, VN_ERR_INVALID, "conv1d: empty problem%s", "");
     int rc = zero_page(ctx);
     if (rc) return rc;
-    vn_conv_args a{x, w, bias, resid, alpha, y, y2, ctx->zero_page, B, T_in, T_rows, T_out, C_in, C_out, taps,
-                   in_stride, dil, pad, out_stride, out_off, act};
+    vn_conv_args a{x, w, bias, resid, alpha, y, y2, (uint16_t*)y2_16, (long)y2_plane, ctx->zero_page, B, T_in, T_rows, T_out, C_in, C_out,
+                   taps, in_stride, dil, pad, out_stride, out_off, act};
     hipStream_t s = (hipStream_t)stream;
     const long M = (long)B * T_rows;
     // N tile: 128 wastes (128 - C_out % 128) columns of the last tile; 64 fits 64-multiples exactly (C_out = 192: 3 x 64

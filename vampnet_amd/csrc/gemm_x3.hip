@@ -267,6 +267,38 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
                         *(const u32x4*)(L16 + q * (128 * VP) + a * VP + b8);
                 }
             }
+        } else if constexpr (EPI == VN_EPI_CONV) {
+            // conv1d_f32.hip's epilogue: bias, residual, tanh, and the NEXT layer's Snake1d written beside the raw result.  Kept ROLLED:
+            // with the transcendental code unrolled into the pass loop hipcc gives up unrolling the loop over i, and the accumulators
+            // (indexed by i) go to scratch
+#pragma nounroll
+            for (int k = 0; k < RP * 32 / 512; ++k) {
+                const int idx = tid + 512 * k;
+                const int R = idx >> 5, c4 = (idx & 31) * 4;
+                const int row = m0 + (R >> 5) * 32 * RI + 32 * i + (R & 31), col = n0 + c4;
+                if (row >= p.M || col >= p.N) continue;
+                f32x4 v = *(const f32x4*)(lds + R * 128 + c4);
+                const int b = row / p.conv_trows, tq = row - b * p.conv_trows;
+                const int t_out = tq * p.conv_out_stride + p.conv_out_off;
+                if (t_out < 0 || t_out >= p.conv_tout) continue;
+                const long orow = (long)b * p.conv_tout + t_out;
+                const size_t o = (size_t)orow * p.N + col;
+                if (p.bias) v += *(const f32x4*)(p.bias + col);
+                if (p.resid) v += *(const f32x4*)(p.resid + o);
+                if (p.conv_act == 1) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
+                if (p.C) *(f32x4*)(p.C + o) = v;
+                if (p.Y2 || p.C16) {
+                    const f32x4 al = *(const f32x4*)(p.alpha + col);
+                    f32x4 w4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float sn = sinf(al[e] * v[e]);
+                        w4[e] = v[e] + (1.0f / (al[e] + 1e-9f)) * (sn * sn);
+                    }
+                    if (p.Y2) *(f32x4*)(p.Y2 + o) = w4;
+                    if (p.C16) vn_store_planes4(p.C16, p.c_plane, orow, col, p.N, w4);
+                }
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < RP * 32 / 512; ++k) {                               // RP rows x 32 pieces of 4 columns
@@ -327,8 +359,10 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         // 3 BM / 16, plane q / (BM / 16)).  CFG 1 / 2: a wave owns NPW consecutive instructions; CFG 3 (60 instructions): instruction
         // 8 j + wave, so waves 0-3 issue eight and waves 4-7 seven
         auto piece_q = [&](int j) { return CFG == 3 ? 8 * j + wave : wave * G::NPW + j; };
+        constexpr bool CONV = EPI == VN_EPI_CONV;
         const uint16_t* src[G::NPW];
         int kadv[G::NPW];                                   // elements per k-tile: 32 along a planar row, 3 x 512 between tiled pieces
+        int t0v[CONV ? G::NPW : 1];                         // CONV: input row of tap 0 for this lane's A row (may be < 0 / >= T_in)
 #pragma unroll
         for (int j = 0; j < G::NPW; ++j) {
             const int q = piece_q(j);
@@ -337,7 +371,13 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                 const int pt = q / (G::BM / 16), row = (q % (G::BM / 16)) * 16 + drow;
                 int g = m0 + row;
                 g = g < p.M ? g : p.M - 1;
-                if (p.a_plane == VN_PLANES_TILED && !(ABL & 4)) {
+                if constexpr (CONV) {
+                    // implicit GEMM: row g = (b, t') starts at input row t0 = t' in_stride - pad; tap j / channel block c0 of k-tile kt add
+                    // the UNIFORM offset (j dil C_in + c0) — only whether that row exists differs per lane (stage_piece)
+                    const int b = g / p.conv_trows, tq = g - b * p.conv_trows;
+                    t0v[j] = tq * p.conv_in_stride - p.conv_pad;
+                    src[j] = A16 + (size_t)pt * p.a_plane + ((long)b * p.conv_tin + t0v[j]) * (long)p.conv_cin + dslot * 8;
+                } else if (p.a_plane == VN_PLANES_TILED && !(ABL & 4)) {
                     src[j] = A16 + (((size_t)(g >> 4) * nk_all + kb) * 3 + pt) * 512 + (g & 15) * 32 + dslot * 8;
                     kadv[j] = 3 * 512;
                 } else {
@@ -356,14 +396,40 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                 }
             }
         }
+        // CONV: (tap, channel block) of the k-tile being staged, kept incrementally (k-tiles are staged in increasing order; a jump
+        // falls back to the division) — all uniform
+        int cv_kt = -1, cv_tap = 0, cv_c0 = 0, cv_dt = 0;
+        long cv_off = 0;
+        auto conv_tile = [&](int kt) {
+            if (kt == cv_kt) return;
+            if (kt == cv_kt + 1 && cv_kt >= 0) {
+                cv_c0 += X3_KT;
+                if (cv_c0 == p.conv_cin) { cv_c0 = 0; ++cv_tap; }
+            } else {
+                const int cpt = p.conv_cin / X3_KT;
+                cv_tap = kt / cpt;
+                cv_c0 = (kt - cv_tap * cpt) * X3_KT;
+            }
+            cv_kt = kt;
+            cv_dt = cv_tap * p.conv_dil;
+            cv_off = (long)cv_dt * p.conv_cin + cv_c0;
+        };
         auto stage_piece = [&](int buf, int k0, int j) {       // k0 = 32 x the k-tile index relative to kb
-            if constexpr (ABL & 4) k0 = (2 * k0) % p.K;     // a fresh 128-byte line per k-tile (probe: K % 64 == 0, data-parallel form)
-            else k0 = (k0 / X3_KT) * kadv[j];
             if constexpr (CFG == 3) {
                 if (j == G::NPW - 1 && wave >= 4) return;   // 60 = 4 x 8 + 4 x 7 instructions
             }
             float* base = lds + buf * G::STAGE + piece_q(j) * 256;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
+            const uint16_t* from;
+            if (CONV && piece_q(j) < 3 * (G::BM / 16)) {    // an A piece of the implicit GEMM: the tap's row, or zeros outside the signal
+                conv_tile(kb + k0 / X3_KT);
+                const bool ok = (unsigned)(t0v[CONV ? j : 0] + cv_dt) < (unsigned)p.conv_tin;
+                from = ok ? src[j] + cv_off : p.zeros16 + dslot * 8;
+            } else {
+                if constexpr (ABL & 4) k0 = (2 * k0) % p.K;     // a fresh 128-byte line per k-tile (probe: K % 64 == 0, data-parallel form)
+                else k0 = (k0 / X3_KT) * kadv[j];
+                from = src[j] + k0;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)from,
                                              (__attribute__((address_space(3))) void*)base, 16, 0, 0);
         };
         auto stage = [&](int buf, int k0) {
@@ -504,8 +570,12 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             }
         }
 
-        if (p.staged) x3_epilogue_staged<EPI, CFG>(p, acc, m0, n0, wave, lane, lds);
-        else x3_epilogue<EPI, CFG>(p, acc, m0, n0, wm, wn, lane);
+        if constexpr (EPI == VN_EPI_CONV) {
+            x3_epilogue_staged<EPI, CFG>(p, acc, m0, n0, wave, lane, lds);      // the launcher guarantees the alignment it needs
+        } else {
+            if (p.staged) x3_epilogue_staged<EPI, CFG>(p, acc, m0, n0, wave, lane, lds);
+            else x3_epilogue<EPI, CFG>(p, acc, m0, n0, wm, wn, lane);
+        }
     }
 }
 
@@ -620,7 +690,8 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
     const double n_out = (EPI == VN_EPI_GEGLU) ? a.N / 2 : a.N;
     const double bytes = 6.0 * ((double)a.M * a.K + (double)a.N * a.K) +
                          ((EPI == VN_EPI_GEGLU && a.C16) ? 6.0 : 4.0) * (double)a.M * n_out * (EPI == VN_EPI_RESIDUAL ? 2 : 1);
-    const int pi = vn_prof_pre(ctx, 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);       // algorithmic (fp32-equivalent) flops
+    // algorithmic (fp32-equivalent) flops; the codec's convolutions are booked under class 2 like conv1d_f32.hip's
+    const int pi = vn_prof_pre(ctx, EPI == VN_EPI_CONV ? 2 : 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);
     int rc = VN_OK;
     const x3_plan plan = x3_choose<EPI>(ctx, a, vn_num_cus(ctx));
     const int bm = plan.bm;
@@ -691,14 +762,16 @@ static int x3_attrs_abl(vn_ctx* ctx) {
 int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: empty problem%s", "");
     if (a.K % X3_KT) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: K=%s%ld must be a multiple of 32", "", a.K);
-    if (a.N % 64) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: N=%s%ld must be a multiple of 64", "", a.N);
+    if (epilogue == VN_EPI_CONV ? (a.N % 16) : (a.N % 64))
+        return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: N=%s%ld must be a multiple of 64 (16 for the convolution epilogue)", "", a.N);
     if ((a.a_plane != VN_PLANES_TILED && (a.a_plane <= 0 || (a.a_plane & 7))) || (!a.w_tiled && (a.w_plane <= 0 || (a.w_plane & 7))))
         return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: plane strides must be positive multiples of 8 elements (or the tiled layout)%s", "");
     if (((uintptr_t)a.A | (uintptr_t)a.W) & 15) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: operands must be 16-byte aligned%s", "");
     if (!(ctx->attr_mask & VN_ATTR_GEMM_X3)) {
         int rc;
         if ((rc = x3_attrs<VN_EPI_STORE>(ctx)) || (rc = x3_attrs<VN_EPI_BIAS>(ctx)) || (rc = x3_attrs<VN_EPI_RESIDUAL>(ctx)) ||
-            (rc = x3_attrs<VN_EPI_GEGLU>(ctx)) || (rc = x3_attrs<VN_EPI_QKV>(ctx)) || (rc = x3_attrs<VN_EPI_QKV3>(ctx)))
+            (rc = x3_attrs<VN_EPI_GEGLU>(ctx)) || (rc = x3_attrs<VN_EPI_QKV>(ctx)) || (rc = x3_attrs<VN_EPI_QKV3>(ctx)) ||
+            (rc = x3_attrs<VN_EPI_CONV>(ctx)))
             return rc;
         if ((rc = x3_attrs_abl<1, 1>(ctx)) || (rc = x3_attrs_abl<1, 2>(ctx)) || (rc = x3_attrs_abl<1, 3>(ctx)) ||
             (rc = x3_attrs_abl<2, 1>(ctx)) || (rc = x3_attrs_abl<2, 2>(ctx)) || (rc = x3_attrs_abl<2, 3>(ctx)) ||
@@ -722,6 +795,17 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
             if (!a.C16 || !a.V16 || a.c_plane <= 0 || a.v_plane <= 0 || a.T <= 0 || a.H <= 0 || a.N != 3 * a.H * VN_DHEAD)
                 return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: QKV plane epilogue needs C16 / V16 / plane strides / T / H and N = 3 H 64%s", "");
             return x3_launch<VN_EPI_QKV3>(ctx, a, s);
+        case VN_EPI_CONV:
+            if (a.conv_taps <= 0 || a.conv_cin <= 0 || (a.conv_cin % X3_KT) || a.K != a.conv_taps * a.conv_cin || a.conv_trows <= 0 ||
+                a.M % a.conv_trows || a.conv_tin <= 0 || a.conv_tout <= 0 || !a.zeros16)
+                return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3/conv: inconsistent geometry (taps=%s%ld, C_in=%ld)", "", a.conv_taps, a.conv_cin);
+            if (a.a_plane <= 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3/conv: the activation planes must be planar%s", "");
+            if ((!a.C && !a.Y2 && !a.C16) || ((a.Y2 || a.C16) && !a.alpha))
+                return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3/conv: needs an output, and alpha for the snake outputs%s", "");
+            if ((((uintptr_t)a.C | (uintptr_t)a.Y2 | (uintptr_t)a.resid | (uintptr_t)a.bias | (uintptr_t)a.alpha) & 15) || ((uintptr_t)a.C16 & 7) ||
+                (a.C16 && (a.c_plane <= 0 || (a.c_plane & 3))))
+                return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3/conv: outputs / bias / alpha must be 16-byte aligned%s", "");
+            return x3_launch<VN_EPI_CONV>(ctx, a, s);
     }
     return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: unknown epilogue %s%ld", "", epilogue);
 }
@@ -777,4 +861,37 @@ extern "C" int vn_gemm_bf16x3(vn_ctx* ctx, const void* A3, int64_t a_plane, cons
     a.bf16 = 2; a.a_plane = a_plane; a.w_plane = w_plane;
     a.w_tiled = w_plane == VN_PLANES_TILED;               // -1 for either stride: that operand is given in the tiled layout
     return vn_launch_gemm_x3(ctx, a, epilogue, (hipStream_t)stream);
+}
+
+// ---- the DAC convolutions on the bf16x3 pipe (codec rows a18 / a19; PARITY UNPINNED like conv1d_f32.hip) -------------------------
+// y[b][t_out][co] = act(bias[co] + sum_{j < taps} sum_ci w[co][j][ci] x[b][t' in_stride + j dil - pad][ci] (+ resid)), t_out = t'
+// out_stride + out_off — conv1d_f32.hip's operator with the products on the bf16 matrix cores at fp32 grade: x16 = three split planes
+// of the channels-last input [3][B T_in][C_in] (x_plane elements apart; written by the producing layer's epilogue), w_tiled = the
+// TILED planes of w [C_out][taps C_in] (vn_split3_f32 + vn_tile_planes_bf16x3 at load).  Outputs as in vn_conv1d_f32, plus
+// y2_16 = snake(y) as split planes (y2_plane apart) for a consumer on this pipe.
+extern "C" int vn_conv1d_bf16x3(vn_ctx* ctx, const void* x16, int64_t x_plane, const void* w_tiled, const float* bias, const float* resid,
+                                const float* alpha, float* y, float* y2, void* y2_16, int64_t y2_plane, int B, int T_in, int T_rows,
+                                int T_out, int C_in, int C_out, int taps, int in_stride, int dil, int pad, int out_stride, int out_off,
+                                int act, void* stream) {
+    if (!ctx || !x16 || !w_tiled || (!y && !y2 && !y2_16)) return VN_ERR_INVALID;
+    if (B <= 0 || T_rows <= 0 || C_out <= 0 || taps <= 0 || C_in <= 0) return vn_fail(ctx, VN_ERR_INVALID, "conv1d_bf16x3: empty problem%s", "");
+    if ((long)B * T_rows > 0x7fffffffL) return vn_fail(ctx, VN_ERR_INVALID, "conv1d_bf16x3: too many rows%s", "");
+    if (!ctx->zero_page) {
+        VN_HIP_CHECK(ctx, hipMalloc((void**)&ctx->zero_page, 1024));
+        VN_HIP_CHECK(ctx, hipMemset(ctx->zero_page, 0, 1024));
+    }
+    vn_gemm_args a{};
+    a.A = (const float*)x16; a.W = (const float*)w_tiled; a.bias = bias; a.C = y; a.C16 = (uint16_t*)y2_16; a.c_plane = y2_plane;
+    a.bf16 = 2; a.a_plane = x_plane; a.w_tiled = 1;
+    a.M = B * T_rows; a.N = C_out; a.K = taps * C_in; a.ldc = C_out;
+    a.conv_taps = taps; a.conv_cin = C_in; a.conv_tin = T_in; a.conv_trows = T_rows; a.conv_in_stride = in_stride; a.conv_dil = dil;
+    a.conv_pad = pad; a.conv_tout = T_out; a.conv_out_stride = out_stride; a.conv_out_off = out_off; a.conv_act = act;
+    a.zeros16 = (const uint16_t*)ctx->zero_page; a.resid = resid; a.alpha = alpha; a.Y2 = y2;
+    return vn_launch_gemm_x3(ctx, a, VN_EPI_CONV, (hipStream_t)stream);
+}
+
+// planar split planes [3][rows][K] (plane_stride elements apart) -> the tiled layout the bf16x3 GEMM / convolution read weights in
+extern "C" int vn_tile_planes_bf16x3(vn_ctx* ctx, const void* planes, int64_t plane_stride, void* tiled, int64_t rows, int K, void* stream) {
+    if (!ctx || !planes || !tiled) return VN_ERR_INVALID;
+    return vn_launch_tile_planes(ctx, (const uint16_t*)planes, (long)plane_stride, (uint16_t*)tiled, (long)rows, K, (hipStream_t)stream);
 }

@@ -242,7 +242,9 @@ static inline int vn_cdiv(int a, int b) { return (a + b - 1) / b; }
 // ---- launchers implemented in the .hip files ------------------------------------------------
 // QKV3 (gemm_x3.hip only): the operands of attention_x3.hip as split planes from ONE QKV GEMM — q (x 1/8) and k head-major,
 // V TRANSPOSED (through the epilogue's LDS image) and blocked by tiles of 32 global token rows
-enum { VN_EPI_STORE = 0, VN_EPI_BIAS = 1, VN_EPI_RESIDUAL = 2, VN_EPI_GEGLU = 3, VN_EPI_QKV = 4, VN_EPI_QKV3 = 5 };
+// CONV (gemm_x3.hip only): implicit-GEMM 1-D convolution of the DAC stacks — A rows gathered per tap, epilogue = bias (+ residual)
+// (+ tanh) -> y, snake(y) -> y2 as fp32 and / or split planes (conv1d_f32.hip's epilogue on the bf16x3 pipe)
+enum { VN_EPI_STORE = 0, VN_EPI_BIAS = 1, VN_EPI_RESIDUAL = 2, VN_EPI_GEGLU = 3, VN_EPI_QKV = 4, VN_EPI_QKV3 = 5, VN_EPI_CONV = 6 };
 
 struct vn_gemm_args {
     const float* A;      // [M][K] row-major, lda = K
@@ -274,6 +276,18 @@ struct vn_gemm_args {
     long norm_plane;
     float norm_eps;
     int* norm_done;
+    // CONV epilogue / operand (gemm_x3.hip): A = channels-last activation planes [3][B * T_in][C_in] (PLANAR, a_plane apart);
+    // GEMM row m = (b, t') of M = B * T_rows reads input row t' * in_stride + j * dil - pad for tap j (k = j * C_in + c; rows outside
+    // [0, T_in) come from the zero page); W = [C_out][taps * C_in] tiled planes; N = C_out, K = taps * C_in.
+    // Output row t_out = t' * out_stride + out_off (rows outside [0, T_out) are dropped: the phases of a transposed convolution);
+    // v = acc + bias (+ resid) (tanh if act) -> C (fp32, optional); snake(v, alpha) -> Y2 (fp32, optional) and / or C16 planes
+    // (planar, c_plane apart, optional).  All [B][T_out][C_out].
+    int conv_taps, conv_cin, conv_tin, conv_trows, conv_in_stride, conv_dil, conv_pad;
+    int conv_tout, conv_out_stride, conv_out_off, conv_act;
+    const uint16_t* zeros16;
+    const float* resid;
+    const float* alpha;
+    float* Y2;
 };
 int vn_launch_gemm_f32(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);
 int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);      // a.bf16 == 2
