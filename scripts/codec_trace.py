@@ -6,7 +6,7 @@ from vampnet_amd.codec import DacCodec
 from vampnet_amd.engine import Engine
 eng = Engine("cuda:0")
 cfg = D.DAC_DEFAULT_CFG
-codec = DacCodec(D.synth_dac_state_dict(cfg, 0), cfg, engine=eng)
+codec = DacCodec(D.synth_dac_state_dict(cfg, 0), cfg, engine=eng, precision=os.environ.get("VN_CODEC_PRECISION", "bf16x3"))
 audio = 0.1 * torch.randn(8, 1, 575 * 768, device="cuda")
 codes = codec.encode(audio)["codes"]
 codec.decode_codes(codes)

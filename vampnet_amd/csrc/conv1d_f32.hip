@@ -187,10 +187,7 @@ __global__ __launch_bounds__(256, 2) void vn_conv1d_f32_kernel(vn_conv_args p, i
             if (p.y2 || p.y2_16) {
                 f32x4 w4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float sn = sinf(al4[e] * v[e]);
-                    w4[e] = v[e] + inv4[e] * (sn * sn);
-                }
+                for (int e = 0; e < 4; ++e) w4[e] = vn_snake(v[e], al4[e], inv4[e]);
                 if (p.y2) *(f32x4*)(p.y2 + o) = w4;
                 if (p.y2_16) vn_store_bf16x4(p.y2_16 + o, p.y2_plane, w4);
             }
@@ -272,8 +269,8 @@ __global__ __launch_bounds__(256) void vn_dac_conv_in_kernel(const float* __rest
     }
     if (y) y[i] = v;
     if (y2) {
-        const float al = alpha[c], sn = sinf(al * v);
-        y2[i] = v + (1.0f / (al + 1e-9f)) * (sn * sn);
+        const float al = alpha[c];
+        y2[i] = vn_snake(v, al, 1.0f / (al + 1e-9f));
     }
 }
 

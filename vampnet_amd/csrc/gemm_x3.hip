@@ -268,35 +268,39 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
                 }
             }
         } else if constexpr (EPI == VN_EPI_CONV) {
-            // conv1d_f32.hip's epilogue: bias, residual, tanh, and the NEXT layer's Snake1d written beside the raw result.  Kept ROLLED:
-            // with the transcendental code unrolled into the pass loop hipcc gives up unrolling the loop over i, and the accumulators
-            // (indexed by i) go to scratch
-#pragma nounroll
-            for (int k = 0; k < RP * 32 / 512; ++k) {
-                const int idx = tid + 512 * k;
-                const int R = idx >> 5, c4 = (idx & 31) * 4;
-                const int row = m0 + (R >> 5) * 32 * RI + 32 * i + (R & 31), col = n0 + c4;
-                if (row >= p.M || col >= p.N) continue;
-                f32x4 v = *(const f32x4*)(lds + R * 128 + c4);
-                const int b = row / p.conv_trows, tq = row - b * p.conv_trows;
-                const int t_out = tq * p.conv_out_stride + p.conv_out_off;
-                if (t_out < 0 || t_out >= p.conv_tout) continue;
-                const long orow = (long)b * p.conv_tout + t_out;
-                const size_t o = (size_t)orow * p.N + col;
-                if (p.bias) v += *(const f32x4*)(p.bias + col);
-                if (p.resid) v += *(const f32x4*)(p.resid + o);
-                if (p.conv_act == 1) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
-                if (p.C) *(f32x4*)(p.C + o) = v;
+            // conv1d_f32.hip's epilogue: bias, residual, tanh, and the NEXT layer's Snake1d written beside the raw result.  A thread
+            // keeps ONE group of four output channels for the whole tile (idx & 31 does not depend on k or i): bias, alpha and
+            // 1 / (alpha + 1e-9) live in registers.  The loop is kept ROLLED: with the transcendental code unrolled into the pass loop
+            // hipcc gives up unrolling the loop over i, and the accumulators (indexed by i) go to scratch
+            const int c4 = (tid & 31) * 4, col = n0 + c4;
+            if (col < p.N) {
+                f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, al = {1.f, 1.f, 1.f, 1.f}, inv = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) bias4 = *(const f32x4*)(p.bias + col);
                 if (p.Y2 || p.C16) {
-                    const f32x4 al = *(const f32x4*)(p.alpha + col);
-                    f32x4 w4;
+                    al = *(const f32x4*)(p.alpha + col);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float sn = sinf(al[e] * v[e]);
-                        w4[e] = v[e] + (1.0f / (al[e] + 1e-9f)) * (sn * sn);
+                    for (int e = 0; e < 4; ++e) inv[e] = 1.0f / (al[e] + 1e-9f);
+                }
+#pragma nounroll
+                for (int k = 0; k < RP * 32 / 512; ++k) {
+                    const int R = (tid >> 5) + 16 * k;
+                    const int row = m0 + (R >> 5) * 32 * RI + 32 * i + (R & 31);
+                    if (row >= p.M) continue;
+                    f32x4 v = *(const f32x4*)(lds + R * 128 + c4) + bias4;
+                    const int b = row / p.conv_trows, tq = row - b * p.conv_trows;
+                    const int t_out = tq * p.conv_out_stride + p.conv_out_off;
+                    if (t_out < 0 || t_out >= p.conv_tout) continue;
+                    const long orow = (long)b * p.conv_tout + t_out;
+                    const size_t o = (size_t)orow * p.N + col;
+                    if (p.resid) v += *(const f32x4*)(p.resid + o);
+                    if (p.conv_act == 1) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
+                    if (p.C) *(f32x4*)(p.C + o) = v;
+                    if (p.Y2 || p.C16) {
+                        const f32x4 w4 = {vn_snake(v[0], al[0], inv[0]), vn_snake(v[1], al[1], inv[1]), vn_snake(v[2], al[2], inv[2]),
+                                          vn_snake(v[3], al[3], inv[3])};
+                        if (p.Y2) *(f32x4*)(p.Y2 + o) = w4;
+                        if (p.C16) vn_store_planes4(p.C16, p.c_plane, orow, col, p.N, w4);
                     }
-                    if (p.Y2) *(f32x4*)(p.Y2 + o) = w4;
-                    if (p.C16) vn_store_planes4(p.C16, p.c_plane, orow, col, p.N, w4);
                 }
             }
         } else {

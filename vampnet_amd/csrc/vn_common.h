@@ -101,6 +101,28 @@ __device__ __forceinline__ float vn_gelu_tanh(float x) {
 #endif
 
 #ifdef __HIPCC__
+// Snake1d of the DAC stacks (vampnet/modules/layers.py:12-18 via lac): v + sin(alpha v)^2 / (alpha + 1e-9), inv = 1 / (alpha + 1e-9).
+// sin^2 through an explicit reduction instead of ocml's sinf (half the instructions; the epilogues of the codec's convolutions are
+// VALU-bound on it): k = rint(x 2/pi), r = x - k pi/2 by a three-constant Cody-Waite reduction (exact products for |k| < 2^13),
+// s = sin(r) on [-pi/4, pi/4] by the degree-7 odd polynomial (2^-25 relative), sin^2(x) = s^2 for even k, 1 - s^2 (= cos^2 r) for odd k.
+// |x| > 8192 (never seen on this path) takes sinf.
+__device__ __forceinline__ float vn_sin_sq(float x) {
+    if (fabsf(x) > 8192.0f) { const float s = sinf(x); return s * s; }
+    const float kf = rintf(x * 0.636619772367581343f);
+    float r = fmaf(kf, -1.5703125f, x);
+    r = fmaf(kf, -4.837512969970703125e-4f, r);
+    r = fmaf(kf, -7.549789954891882e-8f, r);
+    const float r2 = r * r;
+    float pl = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    pl = fmaf(r2, pl, -1.6666654611e-1f);
+    const float sn = fmaf(r * r2, pl, r);
+    const float s2 = sn * sn;
+    return ((int)kf & 1) ? 1.0f - s2 : s2;
+}
+__device__ __forceinline__ float vn_snake(float v, float alpha, float inv) { return fmaf(inv, vn_sin_sq(alpha * v), v); }
+#endif
+
+#ifdef __HIPCC__
 // exp(x) for x <= 0 with fp32-level accuracy at a third of ocml expf's instruction count: x*log2(e) is split into a
 // rounded product and its exact fma remainder (plus the constant's low part), v_exp_f32 evaluates 2^hi (1 ulp) and the
 // remainder is applied to first order (|lo| < 2^-22, so the dropped term is < 2^-45 relative).
