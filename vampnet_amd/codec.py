@@ -208,11 +208,14 @@ class _Act:
 
 
 class DacCodec:
-    # a convolution runs on the bf16x3 pipe (six bf16-MFMA products of exact operand splits: the transformer's GEMM kernel with the
-    # A rows gathered per tap) when it is MFMA-bound there: >= 96 output channels (the tile is 128 wide: 64 would waste half of it)
-    # and K = taps * C_in >= 256.  The 64-channel audio-rate block of the encoder, the k = 1 tails below 256 channels (HBM-bound:
-    # planes are 6 bytes per element against 4) and the 1-channel stem / head stay on the fp32 kernels.
-    X3_MIN_COUT, X3_MIN_K = 96, 256
+    # A convolution runs on the bf16x3 pipe (six bf16-MFMA products of exact operand splits: the transformer's GEMM kernel with the
+    # A rows gathered per tap) where it is MFMA-bound there.  Measured per layer on the 44.1 kHz configuration at B = 8
+    # (profiles/r03_codec_kernel_trace_*.txt): k = 7 and strided / transposed convolutions with >= 128 output channels run 26-39 %
+    # faster than on the fp32-input MFMA kernel; the k = 1 tails below 512 channels are HBM-bound and LOSE (planes are 6 bytes per
+    # element against 4), and 96 / 192 output channels fill only 75 % of the 128-wide tile.  Rule: >= 128 output channels and
+    # K x (tile efficiency) >= 512, K = taps * C_in.  The 64- and 96-channel audio-rate blocks, the small k = 1 tails and the
+    # 1-channel stem / head stay on the fp32 kernels; every epilogue writes its Snake output in the format its consumer reads.
+    X3_MIN_COUT, X3_MIN_WORK = 128, 512
 
     def __init__(self, sd: dict, cfg: dict = None, device="cuda:0", engine: Engine = None, precision: str = "bf16x3"):
         cfg = dict(DEFAULT_CFG, **(cfg or {}))
@@ -299,8 +302,10 @@ class DacCodec:
     # ---- kernels ------------------------------------------------------------------------------
     def _on_x3(self, c, taps=None):
         taps = c.get("k", 2) if taps is None else taps
-        return (self.precision == "bf16x3" and c["cout"] >= self.X3_MIN_COUT and c["cout"] % 16 == 0 and c["cin"] % 32 == 0
-                and taps * c["cin"] >= self.X3_MIN_K)
+        cout = c["cout"]
+        eff = cout / (128.0 * math.ceil(cout / 128))                   # fraction of the 128-wide column tiles that is real output
+        return (self.precision == "bf16x3" and cout >= self.X3_MIN_COUT and cout % 16 == 0 and c["cin"] % 32 == 0
+                and taps * c["cin"] * eff >= self.X3_MIN_WORK)
 
     def _fmt(self, c, taps=None):
         """input format of convolution c: "x3" (split planes) or "f32" """
