@@ -442,7 +442,9 @@ def main():
             an, ams, afl, _ = prof["attention"]
             # fabric bytes per launch: NOT measured by this run — read from the committed rocprofv3 --pmc passes of this same command
             traffic = traffic_source = None
-            tname = {"f32": "r01_traffic.json", "bf16x3": "r02_traffic_x3.json"}.get(args.dtype, "-")
+            tname = {"f32": "r01_traffic.json", "bf16x3": "r03_traffic_x3.json"}.get(args.dtype, "-")
+            if not os.path.exists(os.path.join(ROOT, "profiles", tname)) and args.dtype == "bf16x3":
+                tname = "r02_traffic_x3.json"
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and world == 1 and args.batch_per_gpu == 8 and not args.coarse_only and not args.e2e:
                 traffic = json.load(open(tpath))["bytes_per_launch"]

@@ -2,7 +2,7 @@
 # rocprofv3 evidence for the headline command (python bench.py, BASELINE configs[2]): kernel trace + stats, then the
 # fabric-traffic counters FETCH_SIZE / WRITE_SIZE in separate --pmc passes (no trace domains in those).  $1 = output tag.
 T=${1:-x3}
-O=gpurun_out/prof_$T
+O=gpurun_out/$T
 mkdir -p $O
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
