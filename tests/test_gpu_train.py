@@ -470,6 +470,9 @@ def test_zero1_trainer_step_on_a_one_rank_rccl_group(engine):
             assert abs(o1["other/grad_norm"].item() - o2["other/grad_norm"].item()) <= 2e-6 * o2["other/grad_norm"].item()
         for k, v in ref.state_dict().items():
             assert (tr.state_dict()[k] - v).abs().max().item() < 1e-7, k
+        with pytest.raises(RuntimeError):
+            tr.optimizer_state_dict()                                        # ZeRO-1: needs consolidate() (a collective) first
+        tr.consolidate()
         a, b = tr.optimizer_state_dict(), ref.optimizer_state_dict()
         assert a["param_groups"] == b["param_groups"] and set(a["state"]) == set(b["state"])
         for i in b["state"]:

@@ -368,7 +368,14 @@ def _zero_worker(rank, world, port, q):
     for _ in range(2):
         out = tr.step(z, mask=mask)
         outs.append((float(out["loss"]), float(out["other/grad_norm"]), out["other/learning_rate"]))
-    osd = tr.optimizer_state_dict()                        # consolidates the sharded moments (collective)
+    try:
+        tr.optimizer_state_dict()                          # a lone caller must NOT walk into the all_gather
+        lone = False
+    except RuntimeError:
+        lone = True
+    assert lone, "optimizer_state_dict() without consolidate() has to refuse, not start a collective on one rank"
+    tr.consolidate()                                       # the collective, on every rank
+    osd = tr.optimizer_state_dict()                        # ... after which any rank may build the dict alone
     lo, hi = tr.shard_range()
     q.put((rank, outs, {k: v.numpy() for k, v in tr.state_dict().items()}, (lo, hi, tr.n_total, tr.shard_len),
            {i: e["exp_avg"].numpy() for i, e in osd["state"].items()}))

@@ -314,6 +314,13 @@ class Trainer:
             out.append(torch.cat(parts)[:self.n_total])
         return tuple(out)
 
+    def consolidate(self):
+        """ZeRO-1: gather the sharded Adam moments on every rank and keep them for the next optimizer_state_dict() / save_checkpoint()
+        of THIS step count.  A COLLECTIVE: every rank of the group calls it (the reference does the same before its rank-0 save,
+        train.py:376-378 `consolidate_state_dict`).  No-op without ZeRO-1."""
+        if getattr(self, "zero1", False):
+            self._consolidated = (self.steps, self.consolidate_state())
+
     def update(self):
         """(all-reduce) -> clip -> AdamW -> scheduler.step(); advances self.steps."""
         if getattr(self, "zero1", False):
@@ -408,8 +415,14 @@ class Trainer:
         reference has after mark_only_lora_as_trainable), full mode for every non-adapter parameter.  `lr` is what the
         reference's param group holds after N steps: NoamScheduler has already stepped to N + 1 (train.py:596)."""
         exp = self.export_lora if self.only_lora else self.export
-        if getattr(self, "zero1", False):                  # sharded moments: gather them first (every rank must call this)
-            m, v = (exp(t) for t in self.consolidate_state())
+        if getattr(self, "zero1", False):
+            # sharded moments: the gathered copy of consolidate() for this step count, so that a rank-0-only caller does not enter a
+            # collective alone (the usual `if rank == 0: save` pattern would hang in all_gather)
+            cons = getattr(self, "_consolidated", None)
+            if cons is None or cons[0] != self.steps:
+                raise RuntimeError("ZeRO-1: call Trainer.consolidate() on EVERY rank (a collective) before optimizer_state_dict() / "
+                                   "save_checkpoint() of this step; save_checkpoint(all_ranks=True) does it when every rank calls it")
+            m, v = (exp(t) for t in cons[1])
         else:
             m, v = exp(self.adam_m), exp(self.adam_v)
         index = {k: i for i, k in enumerate(self._all_param_names())}
@@ -476,13 +489,22 @@ class Trainer:
         return {"warmup": w, "factor": f, "d_model": self.D, "lr": noam_lr(nxt, self.D, f, w) if self.noam else None,
                 "steps": nxt}
 
-    def save_checkpoint(self, save_path: str, tag: str = "latest", fine_tune: bool = None, extra: dict = None) -> str:
+    def save_checkpoint(self, save_path: str, tag: str = "latest", fine_tune: bool = None, extra: dict = None,
+                        all_ranks: bool = False) -> str:
         """Writes what train.py:380-420 writes for one tag: <save_path>/<tag>/vampnet/weights.pth in the audiotools
         BaseModel layout ({"state_dict", "metadata": {"kwargs"}}), optimizer.pth, scheduler.pth and, when
-        fine-tuning, lora.pth (= loralib.lora_state_dict).  Readable by vampnet_amd.Interface(coarse_ckpt=..., coarse_lora_ckpt=...)."""
+        fine-tuning, lora.pth (= loralib.lora_state_dict).  Readable by vampnet_amd.Interface(coarse_ckpt=..., coarse_lora_ckpt=...).
+        Multi-rank jobs: either call consolidate() on every rank and then this on rank 0 (the reference's pattern), or call this with
+        all_ranks=True on EVERY rank — it consolidates (ZeRO-1) and only rank 0 writes."""
         import os
         fine_tune = self.only_lora if fine_tune is None else fine_tune
         folder = os.path.join(save_path, tag)
+        if all_ranks:
+            self.consolidate()
+            if self.pg is not None:
+                import torch.distributed as dist
+                if dist.get_rank(self.pg) != 0:
+                    return folder
         os.makedirs(os.path.join(folder, "vampnet"), exist_ok=True)
         d = self.dims
         kwargs = dict(n_heads=d.n_heads, n_layers=d.n_layers, n_codebooks=d.n_codebooks, n_conditioning_codebooks=d.n_cond,
