@@ -313,7 +313,7 @@ def test_conv1d_vs_torch(eng, B, T, cin, cout, k, dil):
     bd, ad = bias.cuda(), alpha.cuda()                                  # keep the device copies alive across the launch
     eng.check(eng.lib.vn_conv1d_f32(eng.handle, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(),
                                     rd.data_ptr() if rd is not None else None, ad.data_ptr(), y.data_ptr(),
-                                    y2.data_ptr(), B, T, T, T, cin, cout, k, 1, dil, pad, 1, 0, 0, eng.stream()),
+                                    y2.data_ptr(), None, 0, B, T, T, T, cin, cout, k, 1, dil, pad, 1, 0, 0, eng.stream()),
               "vn_conv1d_f32")
     scale = ref.abs().max().item()
     assert (y.cpu() - ref).abs().max().item() < 2e-5 * scale
