@@ -175,7 +175,7 @@ __device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 
 // of RP = 32 WR tile rows (the i-th 32-row block of every wave row), then all 512 threads read the image back in 16-byte pieces
 // and issue 16-byte global accesses.  The direct epilogue above issues one 2- or 4-byte store per accumulator register (32 per
 // MFMA tile, x3 for split planes), and the store tail of a tile is ISSUE-bound (guide T21): the in-model GEMMs with plane
-// epilogues ran 10-14 % below the fp32-store shapes (profiles/r02_c6_bench_kernel_stats_last_vamp.txt).  RI passes; every
+// epilogues ran 10-14 % below the fp32-store shapes (round-2 kernel stats).  RI passes; every
 // thread of the block must call it.
 //   fp32 kinds (store / bias / residual / QKV scatter): image [RP][128] fp32 (64 / 32 KiB)
 //   GEGLU planes: image [3][RP][64] bf16;  QKV3 planes: [3][RP][128] bf16 for the q / k tiles, TRANSPOSED [3][128 columns][RP + 8]
