@@ -105,7 +105,7 @@ template <int EPI, int CFG>
 __device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 (&acc)[x3_geo<CFG>::RI][x3_geo<CFG>::CJ], int m0, int n0,
                                             int wm, int wn, int lane) {
     using G = x3_geo<CFG>;
-    if constexpr (EPI == VN_EPI_GEGLU && G::CJ != 2) return;      // value / gate live in different waves: staged form only (x3_go_bm)
+    static_assert(EPI != VN_EPI_GEGLU || G::CJ == 2, "GEGLU pairs the wave's two column tiles (value, gate)");
     const int l31 = lane & 31, h = lane >> 5;
     const int colw = n0 + wn * 32 * G::CJ + l31;
 #pragma unroll
@@ -114,7 +114,7 @@ __device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wm * 32 * G::RI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (row >= p.M) continue;
-            if constexpr (EPI == VN_EPI_GEGLU && G::CJ == 2) {
+            if constexpr (EPI == VN_EPI_GEGLU) {
                 // wave tile = 64 packed columns = 32 value (j = 0) + 32 gate (j = 1), interleaved at pack time
                 const int ocol = (n0 + wn * 64) / 2 + l31;
                 if (2 * ocol >= p.N) continue;
@@ -185,10 +185,7 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
                                                    int wave, int lane, float* lds) {
     using G = x3_geo<CFG>;
     constexpr int RI = G::RI, CJ = G::CJ, RP = G::RP, VP = RP + 8;          // VP: pitch of the transposed v image
-    // GEGLU pairs 32 value with 32 gate columns of every 64 packed ones.  Wave tiles 64 wide (CJ = 2) hold both in one lane and
-    // stage the finished planes; the 192-row configuration (wave tile 96 x 32: value and gate sit in DIFFERENT waves) stages the raw
-    // fp32 image like the store kinds and forms value * gelu(gate) while reading it back (GEGLU_IMG)
-    constexpr bool GEGLU_IMG = EPI == VN_EPI_GEGLU && CJ != 2;
+    static_assert(EPI != VN_EPI_GEGLU || CJ == 2, "GEGLU pairs the wave's two column tiles (value, gate)");
     const int wm = wave / G::WC, wn = wave % G::WC, l31 = lane & 31, h = lane >> 5, tid = wave * 64 + lane;
     uint16_t* L16 = (uint16_t*)lds;
 #pragma unroll
@@ -197,7 +194,7 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int R = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;                 // image row; tile row = (R >> 5) * 32 RI + 32 i + (R & 31)
-            if constexpr (EPI == VN_EPI_GEGLU && !GEGLU_IMG) {
+            if constexpr (EPI == VN_EPI_GEGLU) {
                 const float o = acc[i][0][r] * vn_gelu_tanh(acc[i][CJ - 1][r]);
                 uint16_t t0, t1, t2;
                 vn_split3(o, t0, t1, t2);
@@ -233,41 +230,7 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
             }
         }
         __syncthreads();
-        if constexpr (GEGLU_IMG) {
-            // fp32 image [RP][128]: out columns 32 g + e of the tile come from value column 64 g + e and gate column 64 g + 32 + e;
-            // a thread forms eight outputs of one row and writes their three planes (RP x 8 pieces per pass)
-#pragma unroll
-            for (int k = 0; k < (RP * 8 + 511) / 512; ++k) {
-                const int idx = tid + 512 * k;
-                if (RP * 8 % 512 != 0 && idx >= RP * 8) break;
-                const int R = idx >> 3, c8 = (idx & 7) * 8;                           // c8: first of eight output columns (0 .. 56)
-                const int row = m0 + (R >> 5) * 32 * RI + 32 * i + (R & 31), ocol = n0 / 2 + c8;
-                if (row >= p.M || 2 * ocol >= p.N) continue;
-                const float* src = lds + R * 128 + 64 * (c8 >> 5) + (c8 & 31);
-                const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
-                const f32x4 g0 = *(const f32x4*)(src + 32), g1 = *(const f32x4*)(src + 36);
-                f32x8 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o[e] = v0[e] * vn_gelu_tanh(g0[e]);
-                    o[4 + e] = v1[e] * vn_gelu_tanh(g1[e]);
-                }
-                if (p.C16) {
-                    bf16x8 q0, q1, q2;
-                    vn_split3_x8(o, q0, q1, q2);
-                    const bool til = p.c_plane == VN_PLANES_TILED;
-                    uint16_t* dst = p.C16 + (til ? vn_tiled_off(row, ocol, p.ldc) : (size_t)row * p.ldc + ocol);
-                    const long cp = til ? 512 : p.c_plane;
-                    *(u32x4*)dst = __builtin_bit_cast(u32x4, q0);
-                    *(u32x4*)(dst + cp) = __builtin_bit_cast(u32x4, q1);
-                    *(u32x4*)(dst + 2 * cp) = __builtin_bit_cast(u32x4, q2);
-                } else {
-                    float* dst = p.C + (size_t)row * p.ldc + ocol;
-                    *(f32x4*)dst = f32x4{o[0], o[1], o[2], o[3]};
-                    *(f32x4*)(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
-                }
-            }
-        } else if constexpr (EPI == VN_EPI_GEGLU) {
+        if constexpr (EPI == VN_EPI_GEGLU) {
 #pragma unroll
             for (int k = 0; k < 3 * RP * 8 / 512; ++k) {                            // 3 planes x RP rows x 8 pieces of 8 columns
                 const int idx = tid + 512 * k;
@@ -664,8 +627,9 @@ static int x3_go(vn_ctx* ctx, const vn_gemm_args& a_in, int nsplit, hipStream_t 
 }
 template <int EPI>
 static int x3_go_bm(vn_ctx* ctx, const vn_gemm_args& a, int nsplit, int bm, hipStream_t s) {
-    // the 192-row GEGLU form exists only with the LDS-staged epilogue (x3_choose offers it only then)
-    if (bm == 192 && (EPI != VN_EPI_GEGLU || x3_staged_ok<EPI>(ctx, a))) return x3_go<EPI, 3>(ctx, a, nsplit, s);
+    if constexpr (EPI != VN_EPI_GEGLU) {
+        if (bm == 192) return x3_go<EPI, 3>(ctx, a, nsplit, s);
+    }
     return bm == 256 ? x3_go<EPI, 2>(ctx, a, nsplit, s) : x3_go<EPI, 1>(ctx, a, nsplit, s);
 }
 
@@ -704,9 +668,8 @@ static x3_plan x3_choose(const vn_ctx* ctx, const vn_gemm_args& a, int cus) {
     static const double rel[3] = {1.0, 1.5 * 0.97, 2.0 * 0.95};
     for (int hi = 0; hi < 3; ++hi) {
         const int bm = heights[hi];
-        const bool no192 = EPI == VN_EPI_GEGLU && !x3_staged_ok<EPI>(ctx, a);      // 192-row GEGLU: staged epilogue only
-        if (bm == 192 && no192) continue;
-        if (bm_forced && bm != bm_forced && !(bm_forced == 192 && no192 && bm == 128)) continue;
+        if (bm == 192 && EPI == VN_EPI_GEGLU) continue;
+        if (bm_forced && bm != bm_forced && !(bm_forced == 192 && EPI == VN_EPI_GEGLU && bm == 128)) continue;
         const long tiles = (long)vn_cdiv(a.M, bm) * vn_cdiv(a.N, X3_BN);
         for (int ns = 1; ns <= (can_split ? 4 : 1); ns *= 2) {
             if (ns > 1) {
@@ -790,7 +753,9 @@ template <int EPI>
 static int x3_attrs(vn_ctx* ctx) {
     int rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 1>, x3_lds_bytes<1>());
     if (!rc) rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 2>, x3_lds_bytes<2>());
-    if (!rc) rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 3>, x3_lds_bytes<3>());
+    if constexpr (EPI != VN_EPI_GEGLU) {
+        if (!rc) rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 3>, x3_lds_bytes<3>());
+    }
     return rc;
 }
 template <int MI, int ABL>
