@@ -683,3 +683,51 @@ def test_mask_rng_self_check_formulas_hold_on_this_torch():
     u24 = (w[:48] & np.uint32(0xFFFFFF)).astype(np.float32) * np.float32(2.0 ** -24)
     assert torch.equal(torch.from_numpy((u24 < p.numpy()).astype(np.float32)), want_b)
     assert torch.equal(torch.from_numpy(w[48:].astype(np.int64) % np.array(ranges, dtype=np.int64)), want_r)
+
+
+def test_attention_x3_key_split_dma_addressing():
+    """Model of the key-split kernel's LDS-DMA (attention_x3.hip: vn_attention_x3_split_kernel): ONE wave stages whole plane tiles
+    with four buffer loads per plane whose instruction offset 0 / 1024 / 2048 / 3072 is added on BOTH sides (MUBUF to LDS:
+    LDS address = M0 base + inst_offset + lane * 16; memory address = descriptor + per-lane offset + scalar offset + inst_offset) and
+    two per-lane K offsets (even / odd piece: the swizzle key (row >> 1) & 7 flips bit 2 with the piece).  The resulting LDS image
+    must be the one the shared-tile kernel builds with one piece per wave — the fragment reads are common to both kernels."""
+    # shared-tile kernel: wave w, lane -> (LDS byte, source byte inside the tile)
+    want_k, want_v = {}, {}
+    for w in range(4):
+        for lane in range(64):
+            krow = 8 * w + (lane >> 3)
+            want_k[w * 1024 + lane * 16] = krow * 128 + ((lane & 7) ^ ((krow >> 1) & 7)) * 16
+            vrow = 16 * w + (lane >> 2)
+            want_v[w * 1024 + lane * 16] = vrow * 64 + ((lane & 3) ^ ((vrow >> 2) & 3)) * 16
+    got_k, got_v = {}, {}
+    for lane in range(64):
+        kr0, vr0 = lane >> 3, lane >> 2
+        kvoff_e = (kr0 * 64 + ((lane & 7) ^ ((kr0 >> 1) & 7)) * 8) * 2
+        kvoff_o = (kr0 * 64 + ((lane & 7) ^ (((kr0 >> 1) + 4) & 7)) * 8) * 2
+        vvoff = (vr0 * 32 + ((lane & 3) ^ ((vr0 >> 2) & 3)) * 8) * 2
+        for w in range(4):
+            imm = 1024 * w
+            got_k[imm + lane * 16] = (kvoff_o if w & 1 else kvoff_e) + imm          # M0 = the plane tile's base for all four pieces
+            got_v[imm + lane * 16] = vvoff + imm
+    assert got_k == want_k and got_v == want_v
+    assert sorted(got_k.values()) == [16 * i for i in range(256)] and sorted(got_v.values()) == [16 * i for i in range(256)]
+
+
+def test_codec_routing_rule():
+    """DacCodec._on_x3: which convolutions of the published 44.1 kHz DAC configuration run on the bf16x3 pipe — the table behind
+    DESIGN.md section 3 (>= 128 output channels and K x tile efficiency >= 512), and nothing at all in the f32 pipe."""
+    from vampnet_amd.codec import DacCodec
+    c = DacCodec.__new__(DacCodec)
+    c.precision = "bf16x3"
+    conv = lambda cout, cin, k: dict(cout=cout, cin=cin, k=k)
+    table = {  # (C_out, C_in, taps): on the bf16x3 pipe ?
+        (64, 64, 7): False, (128, 64, 4): False, (128, 128, 7): True, (128, 128, 1): False, (256, 128, 8): True, (256, 256, 7): True,
+        (256, 256, 1): False, (512, 256, 16): True, (512, 512, 7): True, (512, 512, 1): True, (1024, 512, 24): True, (1024, 1024, 3): True,
+        (1536, 1024, 7): True, (768, 1536, 2): True, (768, 768, 7): True, (768, 768, 1): True, (384, 768, 2): True, (384, 384, 7): True,
+        (384, 384, 1): False, (192, 384, 2): True, (192, 192, 7): True, (192, 192, 1): False, (96, 192, 2): False, (96, 96, 7): False,
+        (96, 96, 1): False}
+    for (cout, cin, k), want in table.items():
+        assert c._on_x3(conv(cout, cin, k)) == want, (cout, cin, k)
+        assert c._fmt(conv(cout, cin, k)) == ("x3" if want else "f32")
+    c.precision = "f32"
+    assert not any(c._on_x3(conv(*key)) for key in table)
