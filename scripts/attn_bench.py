@@ -35,7 +35,7 @@ for (B, T) in [(1, 575), (2, 575), (3, 575), (4, 575), (8, 575), (4, 173), (8, 1
     table = torch.randn(32, H, device="cuda")
     out = torch.empty(B, T, H * 64, device="cuda")
     fl = 4.0 * T * T * 64 * H * B
-    res = {name: x3(q, k, v, table, out, split) for name, split in (("auto", -1), ("shared", 0), ("pair", 8), ("ks1", 1), ("ks2", 2), ("ks4", 4))}
+    res = {name: x3(q, k, v, table, out, split) for name, split in (("auto", -1), ("shared", 0), ("ks1", 1), ("ks2", 2), ("ks4", 4))}
     eng.attention(q, k, v, table)                  # fp32-input kernel through its single-op entry (allocates + frees per call)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

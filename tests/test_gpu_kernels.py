@@ -123,10 +123,9 @@ def _attention_ref(q, k, v, table):
 
 
 # attention_x3.hip has two work decompositions: 128-query blocks that share their K / V^T tiles ("x3/shared") and 32-query blocks
-# whose KS waves walk disjoint key tiles and merge through LDS ("x3/ks1", "x3/ks2", "x3/ks4"), and 64-query blocks of two waves on
-# single-buffered tiles ("x3/pair"); "bf16x3" = the launcher's own choice
+# whose KS waves walk disjoint key tiles and merge through LDS ("x3/ks1", "x3/ks2", "x3/ks4"); "bf16x3" = the launcher's own choice
 ATTN_FORMS = {"f32": ("f32", None), "bf16x3": ("bf16x3", -1), "x3/shared": ("bf16x3", 0), "x3/ks1": ("bf16x3", 1),
-              "x3/ks2": ("bf16x3", 2), "x3/ks4": ("bf16x3", 4), "x3/pair": ("bf16x3", 8)}
+              "x3/ks2": ("bf16x3", 2), "x3/ks4": ("bf16x3", 4)}
 
 
 def _attention(eng, form, q, k, v, table):
@@ -162,10 +161,9 @@ def test_attention_x3_decompositions_agree(eng):
     q, k, v = (_rand((B, H, T, 64), s).cuda() for s in (40, 41, 42))
     table = _rand((32, H), 43).cuda()
     outs = {}
-    for form in ("x3/shared", "x3/ks1", "x3/ks2", "x3/ks4", "x3/pair"):
+    for form in ("x3/shared", "x3/ks1", "x3/ks2", "x3/ks4"):
         outs[form] = _attention(eng, form, q, k, v, table)
         assert torch.equal(outs[form], _attention(eng, form, q, k, v, table)), form
-    assert torch.equal(outs["x3/pair"], outs["x3/shared"])         # the same per-wave arithmetic on the same tiles, another block shape
     for form in ("x3/ks1", "x3/ks2", "x3/ks4"):
         d = (outs[form] - outs["x3/shared"]).abs().max().item()
         print(f"{form} vs shared tiles: max |d| = {d:.3e}")

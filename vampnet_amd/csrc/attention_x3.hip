@@ -431,99 +431,6 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
     }
 }
 
-// ---- pair kernel: block = 2 waves x 32 queries sharing every tile, SINGLE-buffered, six blocks per CU -------------------------------
-// The shared-tile kernel pays for its 128-query blocks twice at B = 8: 800 blocks on 768 slots (a tail round worth ~20 % of the
-// launch) with two idle waves in every fifth block (575 = 4 x 128 + 63), and a barrier across four SIMDs per tile.  Here a block is
-// 64 queries (575 = 8.98 x 64: 1440 blocks, no idle wave), its stage is ONE tile (24 KiB) plus the window of the bias table its
-// queries can reach (T + 63 entries): 26.5 KiB, so SIX blocks fit a CU (12 waves = the same three per SIMD) and 1440 blocks run in
-// one round of 1536 slots.  Price: a tile is shared by two waves instead of four (twice the L2 -> LDS traffic), and with one buffer
-// the DMA of tile t + 1 is issued only after both waves have read tile t (second barrier), its latency covered by the other five
-// blocks of the CU.
-__global__ __launch_bounds__(128, 3) void vn_attention_x3_pair_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
-                                                                     long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
-                                                                     const float* __restrict__ bias_full, float* __restrict__ out,
-                                                                     uint16_t* __restrict__ out16, long plane16, int B, int H, int T) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* bw = smem + AX_STAGE_FLOATS;                   // bias window: entry i = bias[rel = i - (q0 + 63)], i in [0, T + 63)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const ax_lane L = ax_lane_init(lane);
-    const int nqb = (T + 63) / 64;
-    const int lid = ax_walk(blockIdx.x, gridDim.x);
-    const int qb = lid % nqb, h = (lid / nqb) % H, b = lid / (nqb * H);
-    const int m_lo = b * T;
-    const int g_lo = m_lo / AX_KT, NT = (m_lo + T - 1) / AX_KT - g_lo + 1;
-    const int MT = (B * T + AX_KT - 1) / AX_KT;
-    const size_t head = (size_t)b * H + h;
-    const uint16_t* Qp = q16 + head * (size_t)T * VN_DHEAD;
-    const int q0b = qb * 64, q0 = q0b + wave * 32;
-    const bool active = q0 < T;
-    const int qrow = q0 + L.l31;
-    const int qrow_c = qrow < T ? qrow : T - 1;
-
-    // window of the 2T-1 table: rel = key - query in [-(q0b + 63), T - 1 - q0b]; full-table index rel + T - 1 (clamped at its ends:
-    // rows past T are clamped queries and never stored)
-    const int nb = 2 * T - 1, nw = T + 63, shift = (T - 1) - (q0b + 63);
-    for (int i = tid; i < nw; i += 128) {
-        int f = i + shift;
-        f = f < 0 ? 0 : (f < nb ? f : nb - 1);
-        bw[i] = bias_full[(size_t)h * nb + f];
-    }
-    // ax_bias_init / the partial-tile path index a table `bt` with (key - q + T - 1): bt = bw - shift
-    const float* bt = bw - shift;
-
-    bf16x8 qf[3][4];
-    ax_load_q(qf, Qp, plane_qk, qrow_c, L.hh);
-
-    // this wave issues pieces `wave` and `wave + 2` of every plane tile: the same swizzle key for both (piece parity = wave), M0 and the
-    // source shifted by wave KiB, the instruction offset 2048 moves both sides to the second piece
-    const int kr0 = lane >> 3, vr0 = lane >> 2;
-    const unsigned kvoff = (unsigned)(kr0 * VN_DHEAD + ((lane & 7) ^ (((kr0 >> 1) + 4 * wave) & 7)) * 8) * 2u;
-    const unsigned vvoff = (unsigned)(vr0 * AX_KT + ((lane & 3) ^ ((vr0 >> 2) & 3)) * 8) * 2u;
-    const ax_src src = ax_src_init(k16, vt16, plane_qk, plane_vt, b, h, H, T, m_lo, g_lo, MT);
-    auto stage = [&](int kt) {
-        if (kt >= NT) return;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const unsigned ko = src.k0 + p * src.kplane + kt * (AX_KT * VN_DHEAD * 2) + wave * 1024;
-            const unsigned vo = src.v0 + p * src.vplane + kt * (VN_DHEAD * AX_KT * 2) + wave * 1024;
-            float* kd = smem + (4 * p + wave) * 256;
-            float* vd = smem + (12 + 4 * p + wave) * 256;
-            ax_dma<0>(src.krs, kd, kvoff, ko);
-            ax_dma<2048>(src.krs, kd, kvoff, ko);
-            ax_dma<0>(src.vrs, vd, vvoff, vo);
-            ax_dma<2048>(src.vrs, vd, vvoff, vo);
-        }
-    };
-
-    float m_run = -INFINITY, l_run = 0.f;
-    f32x16 o[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-
-    stage(0);
-    for (int kt = 0; kt < NT; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of tile kt have landed
-        __syncthreads();                                        // both waves' pieces landed (and, first time, the bias window)
-        if (active) ax_tile(smem, smem + 3 * AX_PLANE_FLOATS, bt, qf, L, m_run, l_run, o, (g_lo + kt) * AX_KT - m_lo, qrow_c, T);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();                                        // both waves are done with the tile: the stage is free
-        stage(kt + 1);
-    }
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    if (active && qrow < T) {
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 a = {o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
-                ax_store4(a, l_tot, out, out16, plane16, (long)b * T + qrow, h, H, L.hh, dt, g);
-            }
-    }
-}
-
 // ---- key-split kernel: block = KS waves on the SAME 32 queries, wave w walks key tiles w, w + KS, ... ---------------------------
 // LDS: KS wave-private stages (K 12 KiB + V^T 12 KiB, single-buffered each: the K DMA of the wave's next tile is issued right after
 // the S^T products have read the current one and flies under softmax + PV, the V^T DMA after PV and flies under the next S^T +
@@ -668,9 +575,7 @@ __global__ __launch_bounds__(KS * 64, 2) void vn_attention_x3_split_kernel(const
 }
 
 // LDS bytes of the two decompositions; the launcher (and the engine's choice of attention kernel) need them to fit the CU
-#define AX_PAIR 8            // plan code of the pair kernel (two waves share single-buffered tiles)
 size_t vn_attention_x3_lds_bytes(int T, int key_split) {
-    if (key_split == AX_PAIR) return ((size_t)AX_STAGE_FLOATS + T + 63 + 1) * sizeof(float);
     const size_t stages = key_split > 0 ? (size_t)key_split : 2;
     return (stages * AX_STAGE_FLOATS + 2 * (size_t)T - 1 + 3) * sizeof(float);
 }
@@ -698,7 +603,6 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_split_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_split_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_split_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_attention_x3_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->attr_mask |= VN_ATTR_ATTN_X3;
     }
     const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
@@ -711,9 +615,6 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
         else
             hipLaunchKernelGGL((vn_attention_x3_kernel<4, false>), grid, dim3(256), lds, s, q16, k16, plane_qk, vt16, plane_vt, relbias_full, out,
                                out16, plane16, B, H, T, ctx->tune.ax_stagger, (unsigned*)nullptr);
-    } else if (ks == AX_PAIR) {
-        hipLaunchKernelGGL(vn_attention_x3_pair_kernel, dim3(vn_cdiv(T, 64) * H * B), dim3(128), lds, s, q16, k16, plane_qk, vt16, plane_vt,
-                           relbias_full, out, out16, plane16, B, H, T);
     } else {
         const dim3 grid(vn_cdiv(T, 32) * H * B);
 #define AX_SPLIT_GO(KS) hipLaunchKernelGGL((vn_attention_x3_split_kernel<KS>), grid, dim3(KS * 64), lds, s, q16, k16, plane_qk, vt16, plane_vt, \
@@ -731,8 +632,8 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
 // tuning hook of one context (scripts/attn_probe.py; include/vampnet_hip_debug.h)
 extern "C" int vn_debug_attention_x3_config(vn_ctx* ctx, int split, int lds_bytes, int stagger, void* trace_dev) {
     if (!ctx) return VN_ERR_INVALID;
-    if (split != -1 && split != 0 && split != 1 && split != 2 && split != 4 && split != AX_PAIR)
-        return vn_fail(ctx, VN_ERR_INVALID, "attention_x3: decomposition %s%ld is not -1 / 0 / 1 / 2 / 4 / 8", "", split);
+    if (split != -1 && split != 0 && split != 1 && split != 2 && split != 4)
+        return vn_fail(ctx, VN_ERR_INVALID, "attention_x3: key split %s%ld is not -1 / 0 / 1 / 2 / 4", "", split);
     ctx->tune.ax_split = split;
     ctx->tune.ax_lds = lds_bytes;
     if (stagger >= 0) ctx->tune.ax_stagger = stagger;
