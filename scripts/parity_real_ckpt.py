@@ -111,7 +111,7 @@ def _run(args):
     elif args.wav:
         assert itf is not None, "--wav needs the HIP engine's codec (use --tokens for a dry run)"
         from vampnet_amd.codec import AudioSignal
-        z = itf.encode(AudioSignal.load(args.wav) if hasattr(AudioSignal, "load") else args.wav).cpu()
+        z = itf.encode(AudioSignal.from_wav(args.wav)).cpu()          # 16-bit PCM wav (assets/example.wav is one)
     else:
         raise SystemExit("give --tokens or --wav")
     assert z.ndim == 3 and z.shape[0] == 1, z.shape
