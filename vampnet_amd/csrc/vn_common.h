@@ -29,12 +29,25 @@ __device__ __forceinline__ void vn_split3(float x, uint16_t& p0, uint16_t& p1, u
     p1 = vn_f32_to_bf16(r1);
     p2 = vn_f32_to_bf16(r1 - vn_bf16_to_f32(p1));
 }
-// eight values at once (the B operand of one MFMA k-step): planes as packed bf16x8
+// eight values at once (the B operand of one MFMA k-step): planes as packed bf16x8.  The bf16 -> fp32 widening of a plane is
+// taken from the PACKED conversion result (low half << 16, high half & 0xffff0000: one integer op per value) — written as
+// __builtin_convertvector(p0, f32x8) hipcc re-converts every value on its own (a single-source v_cvt_pk_bf16_f32 + a shift per value
+// and level: +2 VALU per value; the softmax of attention_x3.hip is made of this).  Same planes bit for bit.
+__device__ __forceinline__ f32x8 vn_bf16x8_widen(const bf16x8& p) {
+    const u32x4 u = __builtin_bit_cast(u32x4, p);
+    f32x8 f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __builtin_bit_cast(float, u[i] << 16);
+        f[2 * i + 1] = __builtin_bit_cast(float, u[i] & 0xffff0000u);
+    }
+    return f;
+}
 __device__ __forceinline__ void vn_split3_x8(const f32x8& x, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
     p0 = __builtin_convertvector(x, bf16x8);
-    const f32x8 r1 = x - __builtin_convertvector(p0, f32x8);
+    const f32x8 r1 = x - vn_bf16x8_widen(p0);
     p1 = __builtin_convertvector(r1, bf16x8);
-    p2 = __builtin_convertvector(r1 - __builtin_convertvector(p1, f32x8), bf16x8);
+    p2 = __builtin_convertvector(r1 - vn_bf16x8_widen(p1), bf16x8);
 }
 // four consecutive values -> one 8-byte store per plane; plane == 0: single bf16 plane (fast mode)
 __device__ __forceinline__ void vn_store_bf16x4(uint16_t* dst, long plane, const f32x4& o) {
