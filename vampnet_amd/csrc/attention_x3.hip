@@ -56,6 +56,13 @@
 #define AX_KT 32                          // keys per tile
 #define AX_PLANE_FLOATS 1024              // one plane tile of K (32 x 128 B) or V^T (64 x 64 B): 4 KiB
 #define AX_STAGE_FLOATS (6 * AX_PLANE_FLOATS)
+// raw barrier (no implied vmcnt(0): LDS-DMA stays in flight across it); the asm fences keep hipcc from moving LDS accesses over it
+#define AX_RAW_BARRIER()                          \
+    do {                                          \
+        asm volatile("" ::: "memory");            \
+        __builtin_amdgcn_s_barrier();             \
+        asm volatile("" ::: "memory");            \
+    } while (0)
 #define AX_THR 6.0f                       // the softmax reference max is raised when a tile's max exceeds it by more than this
 
 __device__ __forceinline__ int ax_swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
@@ -328,16 +335,28 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const ax_lane L = ax_lane_init(lane);
-    const int nqb = (T + NW * 32 - 1) / (NW * 32);
-    const int lid = ax_walk(blockIdx.x, gridDim.x);
-    const int qb = lid % nqb, h = (lid / nqb) % H, b = lid / (nqb * H);
+    // Roles.  A head's queries are cut into 128-query blocks; a remainder of 1..64 queries (T = 575: 63) gets a TAIL block that
+    // uses its four waves as 2 query sub-blocks x 2 KEY HALVES (half the tiles per wave, partial results merged through LDS) and
+    // therefore lasts about half as long as a full block.  Tail blocks take the HIGHEST block indices, so they are dispatched
+    // last: at B = 8 the 800 blocks no longer need a second round of 19-tile blocks on the 768 slots (three per CU) — the 32 blocks
+    // that start late are short ones and end before the slowest full block does (round 2 / 3 probes: the tail round was ~30 % of
+    // the launch).  Both index ranges are walked XCD-aware so that a head's blocks share one L2.
+    const int nqbf = T / (NW * 32), rq = T - nqbf * (NW * 32);
+    const bool split_tail = rq > 0 && rq <= 64;
+    const int nqb = nqbf + ((rq > 0 && !split_tail) ? 1 : 0);           // full-role blocks per (b, h)
+    const int n_full = nqb * H * B;
+    const bool tail_role = (int)blockIdx.x >= n_full;
+    const int lid = tail_role ? ax_walk(blockIdx.x - n_full, gridDim.x - n_full) : ax_walk(blockIdx.x, n_full);
+    const int qb = tail_role ? nqbf : lid % nqb;
+    const int hbi = tail_role ? lid : lid / nqb;
+    const int h = hbi % H, b = hbi / H;
     // key tiles of this item in global token rows: tile g holds tokens 32 g .. 32 g + 31, key index t = m - b T
     const int m_lo = b * T;
     const int g_lo = m_lo / AX_KT, NT = (m_lo + T - 1) / AX_KT - g_lo + 1;
     const int MT = (B * T + AX_KT - 1) / AX_KT;
     const size_t head = (size_t)b * H + h;
     const uint16_t* Qp = q16 + head * (size_t)T * VN_DHEAD;
-    const int q0 = qb * (NW * 32) + wave * 32;
+    const int q0 = qb * (NW * 32) + (tail_role ? (wave & 1) : wave) * 32;
     const bool active = q0 < T;                         // waves past the end only help with the DMA and the barriers
     const int qrow = q0 + L.l31;
     const int qrow_c = qrow < T ? qrow : T - 1;
@@ -376,6 +395,91 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+
+    if (tail_role) {
+        // waves (qs, kh): query sub-block qs = wave & 1, key half kh = wave >> 1.  The two stages hold, SINGLE-buffered, the tile of
+        // key half 0 (tile i) and of key half 1 (tile NH + i) of the same iteration; all four waves stage both (piece `wave` of every
+        // plane tile, as in the full role).  Two barriers per iteration: tiles landed / tiles read.
+        // The DMA of the next iteration is issued as soon as BOTH waves of a key half have read the operand it overwrites (K after the
+        // S^T products, V^T after PV), so it flies under the softmax / the next S^T instead of being waited for (a first version
+        // issued it after the whole tile: the exposed L2 latency under load made a 10-tile tail block last as long as a 19-tile full
+        // block).  Every wave always issues 6 K and 6 V^T pieces per iteration (tiles past the end re-fetch the last tile), so the
+        // counted vmcnt below is exact.
+        const int kh = wave >> 1, NH = (NT + 1) >> 1;
+        auto stage_op = [&](int kt0, int kt1, bool v_op) {
+            kt0 = kt0 < NT ? kt0 : NT - 1;
+            kt1 = kt1 < NT ? kt1 : NT - 1;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                float* d0 = smem + wave * 256 + (v_op ? 12 + 4 * p : 4 * p) * 256;
+                if (v_op) {
+                    ax_dma(src.vrs, d0, vvoff, src.v0 + p * src.vplane + kt0 * (VN_DHEAD * AX_KT * 2));
+                    ax_dma(src.vrs, d0 + AX_STAGE_FLOATS, vvoff, src.v0 + p * src.vplane + kt1 * (VN_DHEAD * AX_KT * 2));
+                } else {
+                    ax_dma(src.krs, d0, kvoff, src.k0 + p * src.kplane + kt0 * (AX_KT * VN_DHEAD * 2));
+                    ax_dma(src.krs, d0 + AX_STAGE_FLOATS, kvoff, src.k0 + p * src.kplane + kt1 * (AX_KT * VN_DHEAD * 2));
+                }
+            }
+        };
+        stage_op(0, NH, false);
+        stage_op(0, NH, true);
+        const float* Ks = smem + kh * AX_STAGE_FLOATS;
+        const float* Vs = Ks + 3 * AX_PLANE_FLOATS;
+        for (int i = 0; i < NH; ++i) {
+            const int kt = kh ? NH + i : i;
+            const bool valid = active && kt < NT, more = i + 1 < NH;
+            const int key0 = (g_lo + kt) * AX_KT - m_lo;
+            const bool full = key0 >= 0 && key0 + AX_KT <= T;
+            f32x16 sacc;
+            bf16x8 pf[3][2];
+            // this wave's K pieces of the iteration landed (V^T may still fly); lgkmcnt: first time round, its part of the bias table
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            AX_RAW_BARRIER();
+            if (valid) {
+                if (full) ax_bias_init<true>(sacc, bt, key0, L.hh, qrow_c, T);
+                else ax_bias_init<false>(sacc, bt, key0, L.hh, qrow_c, T);
+                ax_qk(sacc, Ks, qf, L);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            AX_RAW_BARRIER();                                        // both K stages have been read by everybody
+            if (more) stage_op(i + 1, NH + i + 1, false);
+            if (valid) ax_softmax(sacc, pf, m_run, l_run, o, key0, L.hh, T, full);
+            if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // V^T of this iteration landed (the next K flies)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            AX_RAW_BARRIER();
+            if (valid) ax_pv(o, Vs, pf, L);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            AX_RAW_BARRIER();                                        // both V^T stages have been read
+            if (more) stage_op(i + 1, NH + i + 1, true);
+        }
+        // merge the two key halves of each query sub-block (fixed order: half 0, then half 1), as the key-split kernel does.  Image per
+        // wave in the (free) stages: 8 groups of 64 lanes x 16 B, then m, l per lane
+        float* mine = smem + wave * 2304;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(f32x4*)(mine + ((dt * 4 + g) * 64 + lane) * 4) = f32x4{o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
+        mine[2048 + lane] = m_run;
+        mine[2112 + lane] = l_run;
+        __syncthreads();
+        const float* im0 = smem + (wave & 1) * 2304;            // key half 0 of this query sub-block
+        const float* im1 = smem + ((wave & 1) + 2) * 2304;      // key half 1
+        const float m0 = im0[2048 + lane], m1 = im1[2048 + lane];
+        const float m_all = fmaxf(m0, m1);
+        const float s0 = vn_exp_neg(m0 - m_all), s1 = vn_exp_neg(m1 - m_all);      // a half without tiles holds m = -inf, l = 0
+        const float l_all = im0[2112 + lane] * s0 + im1[2112 + lane] * s1;
+        const float l_tot = l_all + __shfl_xor(l_all, 32);
+        if (active && qrow < T) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int G = kh * 4 + i;                       // this wave finishes four of the eight column groups
+                const f32x4 a = *(const f32x4*)(im0 + (G * 64 + lane) * 4) * s0 + *(const f32x4*)(im1 + (G * 64 + lane) * 4) * s1;
+                ax_store4(a, l_tot, out, out16, plane16, (long)b * T + qrow, h, H, L.hh, G >> 2, G & 3);
+            }
+        }
+        return;
+    }
 
     if (stagger > 0) {                                      // de-phase the blocks that share this CU (tuning)
         const int slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) % 3;         // HW_REG_HW_ID bits [3:0]: wave slot in the SIMD
@@ -608,7 +712,8 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
     const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
     if (ks == 0) {
         // four waves (128 queries) per block, three blocks per CU (LDS: 2 x 24 KiB stages + the bias table)
-        const dim3 grid(vn_cdiv(T, 128) * H * B);
+        const int nqbf = T / 128, rq = T - 128 * nqbf;              // full 128-query blocks (+ one for a remainder > 64) + key-split tail blocks
+        const dim3 grid((nqbf + (rq > 0 ? 1 : 0)) * H * B);
         if (ctx->tune.ax_trace)
             hipLaunchKernelGGL((vn_attention_x3_kernel<4, true>), grid, dim3(256), lds, s, q16, k16, plane_qk, vt16, plane_vt, relbias_full, out,
                                out16, plane16, B, H, T, ctx->tune.ax_stagger, ctx->tune.ax_trace);
