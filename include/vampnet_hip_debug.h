@@ -38,8 +38,8 @@ int vn_debug_attention_x3_time(vn_ctx* ctx, const float* q, const float* k, cons
                                int B, int H, int T, int iters, float* avg_us, void* stream);
 /* bf16x3 attention (attention_x3.hip; scripts/attn_probe.py): split = work decomposition (-1 by shape, 0 = 128-query blocks that
  * share their K / V^T tiles, 1 / 2 / 4 = that many key-split waves per 32-query block); lds_bytes = dynamic-LDS override of the
- * shared-tile kernel (0 = natural; sets the blocks per CU); stagger = start delay per SIMD wave slot in units of 64 cycles (< 0 = the
- * context's default); trace_dev = uint32 [blocks / 16][8] phase-cycle sums of the shared-tile kernel (NULL = no trace)          */
+ * shared-tile kernel (0 = natural; sets the blocks per CU); stagger = [15:0] start delay per SIMD wave slot in units of 64 cycles, bit 16 = tail blocks keep the default wave priority (< 0 = the
+ * context's default); trace_dev = uint32 [blocks][8] per-block phase-cycle sums + entry / exit time of the shared-tile kernel (NULL = none)          */
 int vn_debug_attention_x3_config(vn_ctx* ctx, int split, int lds_bytes, int stagger, void* trace_dev);
 
 #ifdef __cplusplus

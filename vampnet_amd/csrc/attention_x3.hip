@@ -322,8 +322,8 @@ __device__ __forceinline__ void ax_store4(const f32x4& acc, float l_tot, float* 
 }
 
 // ---- shared-tile kernel: block = 4 waves x 32 queries of one (b, h), K / V^T tiles double-buffered for the whole block --------
-// TRACE (tuning): wave 0 of every 16th block accumulates s_memtime deltas per phase over its tiles into
-// trace[block / 16][8] = {wait, barrier, dma issue, tile math, -, -, total, hw_id}.
+// TRACE (tuning): wave 0 of EVERY block writes trace[blockIdx][8] = {wait, barrier, dma issue, tile math (s_memtime deltas summed
+// over the tiles; full role only), entry time, exit time (low 32 bits of s_memtime), XCC id, HW_ID} — the launch's timeline.
 template <int NW, bool TRACE = false>
 __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
                                                                     long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
@@ -335,12 +335,15 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const ax_lane L = ax_lane_init(lane);
+    const bool tail_prio = (stagger >> 16) & 1;             // set by the launcher when the grid exceeds the resident slots
+    stagger &= 0xffff;
     // Roles.  A head's queries are cut into 128-query blocks; a remainder of 1..64 queries (T = 575: 63) gets a TAIL block that
     // uses its four waves as 2 query sub-blocks x 2 KEY HALVES (half the tiles per wave, partial results merged through LDS) and
     // therefore lasts about half as long as a full block.  Tail blocks take the HIGHEST block indices, so they are dispatched
     // last: at B = 8 the 800 blocks no longer need a second round of 19-tile blocks on the 768 slots (three per CU) — the 32 blocks
-    // that start late are short ones and end before the slowest full block does (round 2 / 3 probes: the tail round was ~30 % of
-    // the launch).  Both index ranges are walked XCD-aware so that a head's blocks share one L2.
+    // that start late are short ones and, at wave priority 3 (see the tail role), end before the CUs that hold three full blocks
+    // do (round 2 / 3 probes: the tail round was ~30 % of the launch).  Both index ranges are walked XCD-aware so that a head's
+    // blocks share one L2.
     const int nqbf = T / (NW * 32), rq = T - nqbf * (NW * 32);
     const bool split_tail = rq > 0 && rq <= 64;
     const int nqb = nqbf + ((rq > 0 && !split_tail) ? 1 : 0);           // full-role blocks per (b, h)
@@ -360,6 +363,23 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
     const bool active = q0 < T;                         // waves past the end only help with the DMA and the barriers
     const int qrow = q0 + L.l31;
     const int qrow_c = qrow < T ? qrow : T - 1;
+
+    unsigned long long tr_t = 0, tr_start = 0;
+    unsigned tr_acc[4] = {0, 0, 0, 0};
+    if constexpr (TRACE) { tr_t = tr_start = __builtin_readcyclecounter(); }
+    auto trace_out = [&]() {
+        if constexpr (TRACE) {
+            if (trace && wave == 0 && lane == 0) {
+                unsigned* t = trace + (size_t)blockIdx.x * 8;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = tr_acc[i];
+                t[4] = (unsigned)tr_start;
+                t[5] = (unsigned)__builtin_readcyclecounter();
+                t[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);           // HW_REG_XCC_ID
+                t[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);            // HW_REG_HW_ID
+            }
+        }
+    };
 
     const int nb = 2 * T - 1;
     for (int i = tid; i < nb; i += NW * 64) bt[i] = bias_full[(size_t)h * nb + i];
@@ -405,6 +425,13 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
         // issued it after the whole tile: the exposed L2 latency under load made a 10-tile tail block last as long as a 19-tile full
         // block).  Every wave always issues 6 K and 6 V^T pieces per iteration (tiles past the end re-fetch the last tile), so the
         // counted vmcnt below is exact.
+        // When some blocks have to wait for a slot, tail blocks run at wave priority 3.  The SQ issues oldest-first, so a tail block that starts late (the 32 of the 800 blocks
+        // at B = 8 that find no free slot) was starved by the two older full blocks of its CU: 88k cycles instead of the 52k it
+        // takes alone, ending 15-40k cycles after every other CU was idle.  With priority the tail blocks of the first wave end at
+        // ~75k, the late ones start at ~70k and end at ~130k — before the CUs that hold three full blocks (~160k) — and the launch
+        // is 7 % shorter (profiles/r03_attention_x3_timeline.txt).  When every block is resident from the start the priority only
+        // slows the full blocks that bound the launch (B = 3: 47.0 vs 41.9 us), hence the launcher's condition.
+        if (tail_prio) __builtin_amdgcn_s_setprio(3);
         const int kh = wave >> 1, NH = (NT + 1) >> 1;
         auto stage_op = [&](int kt0, int kt1, bool v_op) {
             kt0 = kt0 < NT ? kt0 : NT - 1;
@@ -478,6 +505,7 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
                 ax_store4(a, l_tot, out, out16, plane16, (long)b * T + qrow, h, H, L.hh, G >> 2, G & 3);
             }
         }
+        trace_out();
         return;
     }
 
@@ -485,9 +513,7 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
         const int slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) % 3;         // HW_REG_HW_ID bits [3:0]: wave slot in the SIMD
         for (int i = 0; i < slot * stagger; ++i) __builtin_amdgcn_s_sleep(1);
     }
-    unsigned long long tr_t = 0, tr_start = 0;
-    unsigned tr_acc[4] = {0, 0, 0, 0};
-    const bool tracing = TRACE && trace && wave == 0 && (lid & 15) == 0;
+    const bool tracing = TRACE && trace && wave == 0;
     auto tick = [&](int slot) {
         if constexpr (TRACE) {
             if (tracing) {
@@ -497,7 +523,7 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
             }
         }
     };
-    if constexpr (TRACE) { tr_t = tr_start = __builtin_readcyclecounter(); }
+    if constexpr (TRACE) { tr_t = __builtin_readcyclecounter(); }
     stage(0, 0);
     for (int kt = 0; kt < NT; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of tile kt have landed
@@ -511,17 +537,6 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
         ax_tile(St, St + 3 * AX_PLANE_FLOATS, bt, qf, L, m_run, l_run, o, (g_lo + kt) * AX_KT - m_lo, qrow_c, T);
         tick(3);
     }
-    if constexpr (TRACE) {
-        if (tracing && lane == 0) {
-            unsigned* t = trace + (lid >> 4) * 8;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) t[i] = tr_acc[i];
-            t[4] = t[5] = 0;
-            t[6] = (unsigned)(__builtin_readcyclecounter() - tr_start);
-            t[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-        }
-    }
-
     // ---- finish: the two lanes of a query add their row sums; normalise; store
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     if (active && qrow < T) {
@@ -533,6 +548,7 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
                 ax_store4(a, l_tot, out, out16, plane16, (long)b * T + qrow, h, H, L.hh, dt, g);
             }
     }
+    trace_out();
 }
 
 // ---- key-split kernel: block = KS waves on the SAME 32 queries, wave w walks key tiles w, w + KS, ... ---------------------------
@@ -684,13 +700,15 @@ size_t vn_attention_x3_lds_bytes(int T, int key_split) {
     return (stages * AX_STAGE_FLOATS + 2 * (size_t)T - 1 + 3) * sizeof(float);
 }
 
-// which decomposition: 0 = shared tiles (128-query blocks), KS > 0 = key-split with KS waves per 32-query block
+// which decomposition: 0 = shared tiles (128-query blocks + key-split tail blocks), KS > 0 = key-split with KS waves per 32-query block
 int vn_attention_x3_plan(const vn_ctx* ctx, int B, int H, int T, int cus) {
     if (ctx->tune.ax_split >= 0) return ctx->tune.ax_split;
-    // 128-query blocks fill the chip from ~1.5 blocks per CU on (three fit); below that a wave's serial chain of 19 tiles is what
-    // a launch costs and the key-split shape wins (two key halves per 32-query block: 52.6 KiB, three blocks per CU)
-    if (2L * B * H * ((T + 127) / 128) >= 3L * cus) return 0;
-    return 2;
+    // the key-split shape (two key halves per 32-query block: 52.6 KiB, three blocks per CU) halves the serial chain of tiles a
+    // wave walks and wins while ALL its blocks are resident at once; from its second round on the shared-tile kernel (a quarter of
+    // the blocks, K / V^T staged once per 128 queries, key-split tail blocks) is ahead (T = 575: B = 2 33.5 vs 35.4 us, B = 3
+    // 57.4 vs 40.9 us; T = 173: B = 4 15.2 vs 15.9, B = 8 25.5 vs 20.4 — profiles/r03_attention_x3_tail_role.txt)
+    if ((long)B * H * ((T + 31) / 32) <= 3L * cus) return 2;
+    return 0;
 }
 
 int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16, long plane_qk, const uint16_t* vt16, long plane_vt,
@@ -714,12 +732,14 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
         // four waves (128 queries) per block, three blocks per CU (LDS: 2 x 24 KiB stages + the bias table)
         const int nqbf = T / 128, rq = T - 128 * nqbf;              // full 128-query blocks (+ one for a remainder > 64) + key-split tail blocks
         const dim3 grid((nqbf + (rq > 0 ? 1 : 0)) * H * B);
+        const long slots = (long)(160 * 1024 / lds) * cus;
+        const int knobs = (ctx->tune.ax_stagger & 0xffff) | ((long)grid.x > slots && !(ctx->tune.ax_stagger >> 16) ? 0x10000 : 0);
         if (ctx->tune.ax_trace)
             hipLaunchKernelGGL((vn_attention_x3_kernel<4, true>), grid, dim3(256), lds, s, q16, k16, plane_qk, vt16, plane_vt, relbias_full, out,
-                               out16, plane16, B, H, T, ctx->tune.ax_stagger, ctx->tune.ax_trace);
+                               out16, plane16, B, H, T, knobs, ctx->tune.ax_trace);
         else
             hipLaunchKernelGGL((vn_attention_x3_kernel<4, false>), grid, dim3(256), lds, s, q16, k16, plane_qk, vt16, plane_vt, relbias_full, out,
-                               out16, plane16, B, H, T, ctx->tune.ax_stagger, (unsigned*)nullptr);
+                               out16, plane16, B, H, T, knobs, (unsigned*)nullptr);
     } else {
         const dim3 grid(vn_cdiv(T, 32) * H * B);
 #define AX_SPLIT_GO(KS) hipLaunchKernelGGL((vn_attention_x3_split_kernel<KS>), grid, dim3(KS * 64), lds, s, q16, k16, plane_qk, vt16, plane_vt, \
