@@ -213,6 +213,17 @@ int vn_gemm_bf16(vn_ctx* ctx, const void* A16, const void* W16, const float* bia
 int vn_gemm_bf16x3(vn_ctx* ctx, const void* A3, int64_t a_plane, const void* W3, int64_t w_plane, const float* bias,
                    float* C, int M, int N, int K, int epilogue, void* stream);
 
+/* "f16x2": the second fp32-grade operand format of the same kernel (gemm_x3.hip).  An operand is TWO fp16 planes, h0 = fp16(x)
+ * and h1 = fp16((x - h0) * 2^11): x = h0 + 2^-11 h1 to within 2^-22 |x| (four times fp32's own representation error, random in
+ * sign) over fp16's whole normal range, and A W^T takes THREE matrix-core products (a0 b0; a0 b1 + a1 b0 into a second accumulator
+ * that joins times 2^-11) instead of bf16x3's six — half the matrix time at an error that stays below the rounding noise of an
+ * fp32-accumulating fp32 GEMM (7e-8 vs 3.4e-7 rms on the model's shapes).  |x| > 65504 saturates.
+ * vn_split2_f16: fp32 [rows][K] -> planes; tiled != 0: [rows / 16][K / 32][2][16][32] (rows % 16 == 0, K % 32 == 0), else two
+ * planar planes plane_stride elements apart.  vn_gemm_f16x2: as vn_gemm_bf16x3 (plane stride -1 = that operand tiled).        */
+int vn_split2_f16(vn_ctx* ctx, const float* src, void* dst16, int64_t rows, int K, int64_t plane_stride, int tiled, void* stream);
+int vn_gemm_f16x2(vn_ctx* ctx, const void* A2, int64_t a_plane, const void* W2, int64_t w_plane, const float* bias,
+                  float* C, int M, int N, int K, int epilogue, void* stream);
+
 /* The same op in the bf16x3 precision (attention_x3.hip: both products as six bf16-MFMA products of exact three-way operand
  * splits, fp32 softmax): same arguments and output as vn_attention_f32.                                                  */
 int vn_attention_bf16x3(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,

@@ -56,6 +56,8 @@ SYMBOLS = {
     "vn_model_set_bf16x3": (C.c_int, [_P, _P, C.c_int64]),
     "vn_split3_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _P]),
     "vn_gemm_bf16x3": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "vn_split2_f16": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int64, C.c_int, _P]),
+    "vn_gemm_f16x2": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vn_gemm_bf16": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vn_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "vn_generate": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(vn_sample_params), C.POINTER(C.c_int64),

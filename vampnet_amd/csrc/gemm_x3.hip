@@ -58,17 +58,21 @@
 //          B = 8 (M = 4600 = 23.96 x 192: QKV 720 tiles = 2.8 rounds, Wo / W2 240 tiles = one round WITHOUT a k-split, classifier
 //          768 tiles = 3.0 rounds) where 128 rows leave the last of 5 / 2 rounds mostly empty and 256 rows quantise worse still.
 // A stage = three A plane tiles (BM rows x 64 B) then three W plane tiles (128 rows x 64 B).
-template <int CFG>
+// NP = planes per operand: 3 (bf16x3, six products per k-step) or 2 (f16x2, three products; vn_common.h vn_split2h).
+template <int CFG, int NP = 3>
 struct x3_geo {
     static constexpr int RI = CFG == 3 ? 3 : CFG, CJ = CFG == 3 ? 1 : 2, WR = CFG == 3 ? 2 : 4, WC = CFG == 3 ? 4 : 2;
     static constexpr int BM = 32 * RI * WR;
     static constexpr int APLANE = BM * 16;                          // floats
-    static constexpr int STAGE = 3 * (APLANE + X3_BPLANE);          // floats: 48 / 72 / 60 KiB
-    static constexpr int NQ = 3 * (BM + 128) / 16;                  // 1 KiB DMA wave-instructions per stage: 48 / 72 / 60
-    static constexpr int NPW = (NQ + 7) / 8;                        // per wave: 6 / 9 / 8 (CFG 3: the last one only in waves 0-3)
+    static constexpr int STAGE = NP * (APLANE + X3_BPLANE);         // floats: 48 / 72 / 60 KiB (NP = 2: 32 / 48 / 40)
+    static constexpr int NQ = NP * (BM + 128) / 16;                 // 1 KiB DMA wave-instructions per stage: 48 / 72 / 60 (32 / 48 / 40)
+    static constexpr int NPW = (NQ + 7) / 8;                        // per wave: 6 / 9 / 8 (CFG 3, NP 3: the last one only in waves 0-3); 4 / 6 / 5
     static constexpr int NBUF = CFG == 1 ? 3 : 2;                   // resident stages
     static constexpr int RP = 32 * WR;                              // rows of one pass of the staged epilogue's LDS image
+    static constexpr int NPROD = NP == 3 ? 6 : 3;                   // matrix-core products per 16-wide k-step
+    static constexpr int NI = NP == 3 ? 4 : 2;                      // two-buffer schedule: DMA pieces issued between the products of k-step 0
 };
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 static_assert(x3_geo<1>::BM == 128 && x3_geo<2>::BM == 256 && x3_geo<3>::BM == 192, "tile heights");
 
 __device__ __forceinline__ int x3_xcd_remap(int bid, int nwg) {
@@ -101,7 +105,7 @@ __device__ __forceinline__ void x3_tile_coords(int t, int tiles_m, int tiles_n, 
 
 // epilogue of one output tile from the accumulators in MFMA layout.
 // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-template <int EPI, int CFG>
+template <int EPI, int CFG, int FMT = 0>
 __device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 (&acc)[x3_geo<CFG>::RI][x3_geo<CFG>::CJ], int m0, int n0,
                                             int wm, int wn, int lane) {
     using G = x3_geo<CFG>;
@@ -120,12 +124,19 @@ __device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 
                 if (2 * ocol >= p.N) continue;
                 const float o = acc[i][0][r] * vn_gelu_tanh(acc[i][G::CJ - 1][r]);
                 if (p.C16) {
-                    uint16_t t0, t1, t2;
-                    vn_split3(o, t0, t1, t2);
-                    const bool til = p.c_plane == VN_PLANES_TILED;
-                    uint16_t* d = p.C16 + (til ? vn_tiled_off(row, ocol, p.ldc) : (size_t)row * p.ldc + ocol);
-                    const long cp = til ? 512 : p.c_plane;
-                    d[0] = t0; d[cp] = t1; d[2 * cp] = t2;
+                    const bool til = vn_planes_tiled(p.c_plane);
+                    const long cp = til ? 512 : (p.c_plane < 0 ? -p.c_plane : p.c_plane);
+                    if constexpr (FMT) {
+                        uint16_t t0, t1;
+                        vn_split2h(o, t0, t1);
+                        uint16_t* d = p.C16 + (til ? vn_tiled_off_np(row, ocol, p.ldc, 2) : (size_t)row * p.ldc + ocol);
+                        d[0] = t0; d[cp] = t1;
+                    } else {
+                        uint16_t t0, t1, t2;
+                        vn_split3(o, t0, t1, t2);
+                        uint16_t* d = p.C16 + (til ? vn_tiled_off(row, ocol, p.ldc) : (size_t)row * p.ldc + ocol);
+                        d[0] = t0; d[cp] = t1; d[2 * cp] = t2;
+                    }
                 } else {
                     p.C[(size_t)row * p.ldc + ocol] = o;
                 }
@@ -180,7 +191,7 @@ __device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 
 //   fp32 kinds (store / bias / residual / QKV scatter): image [RP][128] fp32 (64 / 32 KiB)
 //   GEGLU planes: image [3][RP][64] bf16;  QKV3 planes: [3][RP][128] bf16 for the q / k tiles, TRANSPOSED [3][128 columns][RP + 8]
 //   bf16 for the v tiles (a tile is all q, all k or all v: D % 128 == 0)
-template <int EPI, int CFG>
+template <int EPI, int CFG, int FMT = 0>
 __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const f32x16 (&acc)[x3_geo<CFG>::RI][x3_geo<CFG>::CJ], int m0, int n0,
                                                    int wave, int lane, float* lds) {
     using G = x3_geo<CFG>;
@@ -196,10 +207,16 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
             const int R = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;                 // image row; tile row = (R >> 5) * 32 RI + 32 i + (R & 31)
             if constexpr (EPI == VN_EPI_GEGLU) {
                 const float o = acc[i][0][r] * vn_gelu_tanh(acc[i][CJ - 1][r]);
-                uint16_t t0, t1, t2;
-                vn_split3(o, t0, t1, t2);
                 uint16_t* d = L16 + R * 64 + wn * 32 + l31;
-                d[0] = t0; d[RP * 64] = t1; d[2 * RP * 64] = t2;
+                if constexpr (FMT) {
+                    uint16_t t0, t1;
+                    vn_split2h(o, t0, t1);
+                    d[0] = t0; d[RP * 64] = t1;
+                } else {
+                    uint16_t t0, t1, t2;
+                    vn_split3(o, t0, t1, t2);
+                    d[0] = t0; d[RP * 64] = t1; d[2 * RP * 64] = t2;
+                }
             } else if constexpr (EPI == VN_EPI_QKV3) {
                 if (n0 < 2 * p.H * VN_DHEAD) {                                      // q / k tile: row-major image
 #pragma unroll
@@ -231,14 +248,15 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
         }
         __syncthreads();
         if constexpr (EPI == VN_EPI_GEGLU) {
+            constexpr int ONP = FMT ? 2 : 3;
 #pragma unroll
-            for (int k = 0; k < 3 * RP * 8 / 512; ++k) {                            // 3 planes x RP rows x 8 pieces of 8 columns
+            for (int k = 0; k < ONP * RP * 8 / 512; ++k) {                          // planes x RP rows x 8 pieces of 8 columns
                 const int idx = tid + 512 * k;
                 const int q = idx / (RP * 8), R = (idx >> 3) % RP, c8 = (idx & 7) * 8;
                 const int row = m0 + (R >> 5) * 32 * RI + 32 * i + (R & 31), ocol = n0 / 2 + c8;
                 if (row < p.M && 2 * ocol < p.N) {
-                    uint16_t* dst = p.c_plane == VN_PLANES_TILED ? p.C16 + vn_tiled_off(row, ocol, p.ldc) + 512 * q
-                                                                 : p.C16 + (size_t)q * p.c_plane + (size_t)row * p.ldc + ocol;
+                    uint16_t* dst = vn_planes_tiled(p.c_plane) ? p.C16 + vn_tiled_off_np(row, ocol, p.ldc, ONP) + 512 * q
+                                                               : p.C16 + (size_t)q * (p.c_plane < 0 ? -p.c_plane : p.c_plane) + (size_t)row * p.ldc + ocol;
                     *(u32x4*)dst = *(const u32x4*)(L16 + q * (RP * 64) + R * 64 + c8);
                 }
             }
@@ -330,10 +348,13 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
 // one block per output tile (gridDim.y > 1: split-K images, store epilogue only)
 // ABL (tuning only, results invalid): bit 0 = no DMA inside the k-loop, bit 1 = no fragment reads inside the k-loop, bit 2 =
 // every DMA instruction fetches 8 rows x 128 B (whole cache lines, same volume) instead of 16 rows x 64 B
-template <int EPI, int CFG, int ABL = 0>
+// FMT: 0 = bf16x3 operands (three planes, six products), 1 = f16x2 operands (two planes, three products, second accumulator)
+template <int EPI, int CFG, int ABL = 0, int FMT = 0>
 __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int tiles_m, int tiles_n) {
-    using G = x3_geo<CFG>;
+    constexpr int NP = FMT ? 2 : 3;
+    using G = x3_geo<CFG, NP>;
     constexpr int RI = G::RI, CJ = G::CJ;
+    static_assert(!FMT || (EPI != VN_EPI_CONV && ABL == 0), "the codec convolutions and the ablation probes stay on bf16x3");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -363,6 +384,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         // 3 BM / 16, plane q / (BM / 16)).  CFG 1 / 2: a wave owns NPW consecutive instructions; CFG 3 (60 instructions): instruction
         // 8 j + wave, so waves 0-3 issue eight and waves 4-7 seven
         auto piece_q = [&](int j) { return CFG == 3 ? 8 * j + wave : wave * G::NPW + j; };
+        constexpr int NA_PIECES = NP * (G::BM / 16);                // DMA instructions of a stage that fetch A
         constexpr bool CONV = EPI == VN_EPI_CONV;
         const uint16_t* src[G::NPW];
         int kadv[G::NPW];                                   // elements per k-tile: 32 along a planar row, 3 x 512 between tiled pieces
@@ -371,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         for (int j = 0; j < G::NPW; ++j) {
             const int q = piece_q(j);
             kadv[j] = X3_KT;
-            if (q < 3 * (G::BM / 16)) {
+            if (q < NA_PIECES) {
                 const int pt = q / (G::BM / 16), row = (q % (G::BM / 16)) * 16 + drow;
                 int g = m0 + row;
                 g = g < p.M ? g : p.M - 1;
@@ -381,20 +403,20 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                     const int b = g / p.conv_trows, tq = g - b * p.conv_trows;
                     t0v[j] = tq * p.conv_in_stride - p.conv_pad;
                     src[j] = A16 + (size_t)pt * p.a_plane + ((long)b * p.conv_tin + t0v[j]) * (long)p.conv_cin + dslot * 8;
-                } else if (p.a_plane == VN_PLANES_TILED && !(ABL & 4)) {
-                    src[j] = A16 + (((size_t)(g >> 4) * nk_all + kb) * 3 + pt) * 512 + (g & 15) * 32 + dslot * 8;
-                    kadv[j] = 3 * 512;
+                } else if (vn_planes_tiled(p.a_plane) && !(ABL & 4)) {
+                    src[j] = A16 + (((size_t)(g >> 4) * nk_all + kb) * NP + pt) * 512 + (g & 15) * 32 + dslot * 8;
+                    kadv[j] = NP * 512;
                 } else {
                     src[j] = A16 + (size_t)pt * p.a_plane + (size_t)g * p.K + dslot * 8 + kb * X3_KT;
                 }
             } else {
-                const int qb = (q - 3 * (G::BM / 16)) % 24;             // (CFG 3, j = 7, waves 4-7: q >= NQ — never issued)
+                const int qb = (q - NA_PIECES) % (8 * NP);              // (CFG 3, NP 3, j = 7, waves 4-7: q >= NQ — never issued)
                 const int pt = qb >> 3, row = (qb & 7) * 16 + drow;
                 int g = n0 + row;
                 g = g < p.N ? g : p.N - 1;
                 if (p.w_tiled && !(ABL & 4)) {          // piece = the contiguous 1 KiB of (row block g / 16, k-tile, plane pt)
-                    src[j] = W16 + (((size_t)(g >> 4) * nk_all + kb) * 3 + pt) * 512 + (g & 15) * 32 + dslot * 8;
-                    kadv[j] = 3 * 512;
+                    src[j] = W16 + (((size_t)(g >> 4) * nk_all + kb) * NP + pt) * 512 + (g & 15) * 32 + dslot * 8;
+                    kadv[j] = NP * 512;
                 } else {
                     src[j] = W16 + (size_t)pt * p.w_plane + (size_t)g * p.K + dslot * 8 + kb * X3_KT;
                 }
@@ -419,12 +441,12 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             cv_off = (long)cv_dt * p.conv_cin + cv_c0;
         };
         auto stage_piece = [&](int buf, int k0, int j) {       // k0 = 32 x the k-tile index relative to kb
-            if constexpr (CFG == 3) {
-                if (j == G::NPW - 1 && wave >= 4) return;   // 60 = 4 x 8 + 4 x 7 instructions
+            if constexpr (G::NQ % 8 != 0) {
+                if (j == G::NPW - 1 && wave >= G::NQ % 8) return;   // CFG 3, NP 3: 60 = 4 x 8 + 4 x 7 instructions
             }
             float* base = lds + buf * G::STAGE + piece_q(j) * 256;
             const uint16_t* from;
-            if (CONV && piece_q(j) < 3 * (G::BM / 16)) {    // an A piece of the implicit GEMM: the tap's row, or zeros outside the signal
+            if (CONV && piece_q(j) < NA_PIECES) {    // an A piece of the implicit GEMM: the tap's row, or zeros outside the signal
                 conv_tile(kb + k0 / X3_KT);
                 const bool ok = (unsigned)(t0v[CONV ? j : 0] + cv_dt) < (unsigned)p.conv_tin;
                 from = ok ? src[j] + cv_off : p.zeros16 + dslot * 8;
@@ -441,45 +463,61 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             for (int j = 0; j < G::NPW; ++j) stage_piece(buf, k0, j);
         };
 
-        f32x16 acc[RI][CJ];
+        // f16x2: acc takes a0 b0, acc_lo takes a0 b1 + a1 b0 (both second planes carry 2^11) and joins acc times 2^-11 at the end
+        f32x16 acc[RI][CJ], acc_lo[FMT ? RI : 1][FMT ? CJ : 1];
 #pragma unroll
         for (int i = 0; i < RI; ++i)
 #pragma unroll
             for (int j = 0; j < CJ; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) {
+                    acc[i][j][r] = 0.0f;
+                    if constexpr (FMT) acc_lo[i][j][r] = 0.0f;
+                }
 
-        struct Frags { bf16x8 a[3][RI], b[3][CJ]; };
+        struct Frags { f32x4 a[NP][RI], b[NP][CJ]; };
         auto load_frags = [&](Frags& f, int buf, int s) {
             const float* sA = lds + buf * G::STAGE;
-            const float* sB = sA + 3 * G::APLANE;
+            const float* sB = sA + NP * G::APLANE;
             const int off = ((2 * s + h) ^ sw) * 4;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NP; ++q) {
 #pragma unroll
-                for (int i = 0; i < RI; ++i)
-                    f.a[q][i] = __builtin_bit_cast(bf16x8, *(const f32x4*)(sA + q * G::APLANE + aRow + i * 32 * 16 + off));
+                for (int i = 0; i < RI; ++i) f.a[q][i] = *(const f32x4*)(sA + q * G::APLANE + aRow + i * 32 * 16 + off);
 #pragma unroll
-                for (int j = 0; j < CJ; ++j)
-                    f.b[q][j] = __builtin_bit_cast(bf16x8, *(const f32x4*)(sB + q * X3_BPLANE + bRow + j * 32 * 16 + off));
+                for (int j = 0; j < CJ; ++j) f.b[q][j] = *(const f32x4*)(sB + q * X3_BPLANE + bRow + j * 32 * 16 + off);
             }
         };
         // the six plane products of one 16-wide k-step, smallest terms first (t = 0: A0 W2, then A2 W0, A1 W1, A0 W1, A1 W0,
         // A0 W0); consecutive MFMAs go to different accumulators
+        // f16x2: t = 0: A1 W0, t = 1: A0 W1 (-> acc_lo), t = 2: A0 W0 (-> acc)
         auto mac_prod = [&](const Frags& f, int t) {
-            const int qa = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0, qb = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
+            if constexpr (FMT) {
+                const int qa = t == 0 ? 1 : 0, qb = t == 1 ? 1 : 0;
 #pragma unroll
-            for (int i = 0; i < RI; ++i)
+                for (int i = 0; i < RI; ++i)
 #pragma unroll
-                for (int j = 0; j < CJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[qa][i], f.b[qb][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < CJ; ++j) {
+                        const f16x8 av = __builtin_bit_cast(f16x8, f.a[qa][i]), bv = __builtin_bit_cast(f16x8, f.b[qb][j]);
+                        if (t == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[i][j], 0, 0, 0);
+                        else acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc_lo[i][j], 0, 0, 0);
+                    }
+            } else {
+                const int qa = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0, qb = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
+#pragma unroll
+                for (int i = 0; i < RI; ++i)
+#pragma unroll
+                    for (int j = 0; j < CJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[qa][i]), __builtin_bit_cast(bf16x8, f.b[qb][j]),
+                                                                            acc[i][j], 0, 0, 0);
+            }
         };
         Frags f;
         auto compute = [&]() {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int t = 0; t < 6; ++t) mac_prod(f, t);
+            for (int t = 0; t < G::NPROD; ++t) mac_prod(f, t);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -507,7 +545,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                 if constexpr (!(ABL & 2)) load_frags(f, b, 0);
                 if (more) {
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) stage_piece(b2, (kt + 2) * X3_KT, j);
+                    for (int j = 0; j < G::NPW / 2; ++j) stage_piece(b2, (kt + 2) * X3_KT, j);
                 }
                 X3_LGKM0();
                 X3_BARRIER();
@@ -517,7 +555,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                 if constexpr (!(ABL & 2)) load_frags(f, b, 1);
                 if (more) {
 #pragma unroll
-                    for (int j = 3; j < 6; ++j) stage_piece(b2, (kt + 2) * X3_KT, j);
+                    for (int j = G::NPW / 2; j < G::NPW; ++j) stage_piece(b2, (kt + 2) * X3_KT, j);
                     X3_VMCNT(G::NPW);                       // tile kt + 1 landed (this wave's pieces); tile kt + 2 in flight
                 } else {
                     X3_VMCNT(0);
@@ -535,7 +573,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             // (group 0: I_4kt, I_4kt+1; group 1: I_4kt+1, I_4kt+2) and waits for them at the last point that still has a
             // barrier between it and the first read: group 0 at the end of its second compute phase (I_4kt+3), group 1 at
             // the end of its second load phase (I_4kt+3).
-            constexpr int NA = G::NPW - 4;                  // 5 (CFG 2) / 4 (CFG 3)
+            constexpr int NA = G::NPW - G::NI;              // 5 (CFG 2) / 4 (CFG 3); f16x2: 4 / 3
             stage(0, 0);
             X3_VMCNT(0);
             X3_BARRIER();
@@ -556,9 +594,9 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                 X3_BARRIER();
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
+                for (int t = 0; t < G::NPROD; ++t) {
                     mac_prod(f, t);
-                    if (t < 4 && more) stage_piece(b ^ 1, k1, NA + t);
+                    if (t < G::NI && more) stage_piece(b ^ 1, k1, NA + t);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_s_setprio(0);
@@ -574,11 +612,17 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             }
         }
 
+        if constexpr (FMT) {
+#pragma unroll
+            for (int i = 0; i < RI; ++i)
+#pragma unroll
+                for (int j = 0; j < CJ; ++j) acc[i][j] += acc_lo[i][j] * VN_H2_INV_SCALE;
+        }
         if constexpr (EPI == VN_EPI_CONV) {
             x3_epilogue_staged<EPI, CFG>(p, acc, m0, n0, wave, lane, lds);      // the launcher guarantees the alignment it needs
         } else {
-            if (p.staged) x3_epilogue_staged<EPI, CFG>(p, acc, m0, n0, wave, lane, lds);
-            else x3_epilogue<EPI, CFG>(p, acc, m0, n0, wm, wn, lane);
+            if (p.staged) x3_epilogue_staged<EPI, CFG, FMT>(p, acc, m0, n0, wave, lane, lds);
+            else x3_epilogue<EPI, CFG, FMT>(p, acc, m0, n0, wm, wn, lane);
         }
     }
 }
@@ -597,8 +641,13 @@ extern "C" int vn_debug_x3_config(vn_ctx* ctx, int bm, int splitk, int abl) {
     return VN_OK;
 }
 
-template <int CFG>
-static constexpr size_t x3_lds_bytes() { return (size_t)x3_geo<CFG>::STAGE * 4 * x3_geo<CFG>::NBUF; }
+// the stages, or the largest image of a staged epilogue (the transposed V^T planes of QKV3: [3][128][RP + 8] bf16) if that is bigger
+template <int CFG, int NP = 3>
+static constexpr size_t x3_lds_bytes() {
+    constexpr size_t stages = (size_t)x3_geo<CFG, NP>::STAGE * 4 * x3_geo<CFG, NP>::NBUF;
+    constexpr size_t image = (size_t)3 * 128 * (x3_geo<CFG, NP>::RP + 8) * 2;
+    return stages > image ? stages : image;
+}
 
 // may the epilogue go through LDS with 16-byte global accesses ?  (VN_X3_STAGED=0: never — A/B runs)
 template <int EPI>
@@ -606,7 +655,7 @@ static int x3_staged_ok(const vn_ctx* ctx, const vn_gemm_args& a) {
     if (!ctx->tune.x3_staged) return 0;
     auto al = [](const void* p, uintptr_t m) { return ((uintptr_t)p & (m - 1)) == 0; };
     if (EPI == VN_EPI_GEGLU)
-        return a.C16 && al(a.C16, 16) && !(a.N & 15) && (a.c_plane == VN_PLANES_TILED ? !(a.ldc & 31) : (!(a.ldc & 7) && !(a.c_plane & 7)));
+        return a.C16 && al(a.C16, 16) && !(a.N & 15) && (vn_planes_tiled(a.c_plane) ? !(a.ldc & 31) : (!(a.ldc & 7) && !(a.c_plane & 7)));
     if (EPI == VN_EPI_QKV3)
         return al(a.C16, 16) && al(a.V16, 16) && !(a.c_plane & 7) && !(a.v_plane & 7) && !(a.qkv_plane & 7) && !((a.H * VN_DHEAD) & 127);
     if (!al(a.C, 16) || (a.N & 3)) return 0;
@@ -615,22 +664,24 @@ static int x3_staged_ok(const vn_ctx* ctx, const vn_gemm_args& a) {
     return !(a.ldc & 3);
 }
 
-template <int EPI, int CFG, int ABL = 0>
+template <int EPI, int CFG, int ABL = 0, int FMT = 0>
 static int x3_go(vn_ctx* ctx, const vn_gemm_args& a_in, int nsplit, hipStream_t s) {
     vn_gemm_args a = a_in;
     a.staged = x3_staged_ok<EPI>(ctx, a);
     a.group_m = ctx->tune.x3_group_m;                                  // tuning: rows of tiles per walk group (0 = 8)
     const int tiles_m = vn_cdiv(a.M, x3_geo<CFG>::BM), tiles_n = vn_cdiv(a.N, X3_BN);
-    hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, CFG, ABL>), dim3(tiles_m * tiles_n, nsplit), dim3(512), x3_lds_bytes<CFG>(), s, a, tiles_m, tiles_n);
+    constexpr int NP = FMT ? 2 : 3;
+    const size_t lds_bytes = x3_lds_bytes<CFG, NP>();
+    hipLaunchKernelGGL((vn_gemm_x3_kernel<EPI, CFG, ABL, FMT>), dim3(tiles_m * tiles_n, nsplit), dim3(512), lds_bytes, s, a, tiles_m, tiles_n);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
 }
-template <int EPI>
+template <int EPI, int FMT = 0>
 static int x3_go_bm(vn_ctx* ctx, const vn_gemm_args& a, int nsplit, int bm, hipStream_t s) {
     if constexpr (EPI != VN_EPI_GEGLU) {
-        if (bm == 192) return x3_go<EPI, 3>(ctx, a, nsplit, s);
+        if (bm == 192) return x3_go<EPI, 3, 0, FMT>(ctx, a, nsplit, s);
     }
-    return bm == 256 ? x3_go<EPI, 2>(ctx, a, nsplit, s) : x3_go<EPI, 1>(ctx, a, nsplit, s);
+    return bm == 256 ? x3_go<EPI, 2, 0, FMT>(ctx, a, nsplit, s) : x3_go<EPI, 1, 0, FMT>(ctx, a, nsplit, s);
 }
 
 // test hook: 0 = keep the reduce pass of a split RESIDUAL GEMM and the RMSNorm that follows it as two kernels, 1 = fuse, -1 = the
@@ -656,7 +707,7 @@ static bool x3_norm_fusable(const vn_ctx* ctx, const vn_gemm_args& a) {
 // wave tile); one or two sequences keep 128 rows (more tiles) and split the N = 1280 projections.
 struct x3_plan { int bm, ns; };
 template <int EPI>
-static x3_plan x3_choose(const vn_ctx* ctx, const vn_gemm_args& a, int cus) {
+static x3_plan x3_choose(const vn_ctx* ctx, const vn_gemm_args& a, int cus, double kt_us = 1.45) {
     const int bm_forced = ctx->tune.x3_bm;                   // 0 = by shape
     const int split_forced = ctx->tune.x3_split == -2 ? -1 : ctx->tune.x3_split;      // 0 / 1 off, 2 / 4 forced, -1 cost model
     constexpr bool can_split = EPI == VN_EPI_STORE || EPI == VN_EPI_RESIDUAL;
@@ -677,7 +728,7 @@ static x3_plan x3_choose(const vn_ctx* ctx, const vn_gemm_args& a, int cus) {
                 if (nk / ns < 8 || (double)ns * a.M * a.N > (double)X3_WS_FLOATS) continue;
             }
             if (split_forced > 1 && ns != split_forced && ns != 1) continue;
-            double cost = (double)((tiles * ns + cus - 1) / cus) * (nk / (double)ns) * 1.45 * rel[hi];
+            double cost = (double)((tiles * ns + cus - 1) / cus) * (nk / (double)ns) * kt_us * rel[hi];
             if (ns > 1) {
                 cost += (ns + (residual ? 2 : 1)) * 4.0 * a.M * (double)a.N / 3.5e6;
                 if (residual && x3_norm_fusable(ctx, a)) cost -= 4.0 * a.M * (double)a.N / 3.5e6 + 1.5;
@@ -689,18 +740,18 @@ static x3_plan x3_choose(const vn_ctx* ctx, const vn_gemm_args& a, int cus) {
     return best;
 }
 
-template <int EPI>
+template <int EPI, int FMT = 0>
 static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
     const double n_out = (EPI == VN_EPI_GEGLU) ? a.N / 2 : a.N;
-    const double bytes = 6.0 * ((double)a.M * a.K + (double)a.N * a.K) +
-                         ((EPI == VN_EPI_GEGLU && a.C16) ? 6.0 : 4.0) * (double)a.M * n_out * (EPI == VN_EPI_RESIDUAL ? 2 : 1);
+    const double bytes = (FMT ? 4.0 : 6.0) * ((double)a.M * a.K + (double)a.N * a.K) +
+                         ((EPI == VN_EPI_GEGLU && a.C16) ? (FMT ? 4.0 : 6.0) : 4.0) * (double)a.M * n_out * (EPI == VN_EPI_RESIDUAL ? 2 : 1);
     // algorithmic (fp32-equivalent) flops; the codec's convolutions are booked under class 2 like conv1d_f32.hip's
     const int pi = vn_prof_pre(ctx, EPI == VN_EPI_CONV ? 2 : 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);
     int rc = VN_OK;
-    const x3_plan plan = x3_choose<EPI>(ctx, a, vn_num_cus(ctx));
+    const x3_plan plan = x3_choose<EPI>(ctx, a, vn_num_cus(ctx), FMT ? 0.85 : 1.45);
     const int bm = plan.bm;
     bool done = false;
-    if constexpr (EPI == VN_EPI_STORE) {
+    if constexpr (EPI == VN_EPI_STORE && FMT == 0) {
         int abl = ctx->tune.x3_abl;                                        // ablations (tuning only; results invalid): vn_debug_x3_config
         if (abl == 4 && (a.a_plane == VN_PLANES_TILED || a.w_tiled)) abl = 0;      // the full-line probe re-addresses PLANAR planes only
         if (abl) {
@@ -725,7 +776,7 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
             vn_gemm_args q = a;                       // every split stores its raw image [M][N] into the workspace
             q.C = ctx->x3_ws;
             q.ldc = a.N;
-            rc = x3_go_bm<VN_EPI_STORE>(ctx, q, ns, bm, s);
+            rc = x3_go_bm<VN_EPI_STORE, FMT>(ctx, q, ns, bm, s);
             // while launches are being event-bracketed (pi >= 0) the two-kernel form runs, so that the GEMM's bracket holds the GEMM's
             // own work (split images + reduce) and nothing of the norm — the bitwise same result (tests/test_gpu_kernels.py)
             if (EPI == VN_EPI_RESIDUAL && x3_norm_fusable(ctx, a) && pi < 0) {
@@ -739,7 +790,7 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
             done = true;
         }
     }
-    if (!done) rc = x3_go_bm<EPI>(ctx, a, 1, bm, s);
+    if (!done) rc = x3_go_bm<EPI, FMT>(ctx, a, 1, bm, s);
     vn_prof_post(ctx, pi, s);
     return rc;
 }
@@ -749,12 +800,13 @@ static int x3_attr(vn_ctx* ctx, K kernel, size_t bytes) {
     VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return VN_OK;
 }
-template <int EPI>
+template <int EPI, int FMT = 0>
 static int x3_attrs(vn_ctx* ctx) {
-    int rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 1>, x3_lds_bytes<1>());
-    if (!rc) rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 2>, x3_lds_bytes<2>());
+    constexpr int NP = FMT ? 2 : 3;
+    int rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 1, 0, FMT>, x3_lds_bytes<1, NP>());
+    if (!rc) rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 2, 0, FMT>, x3_lds_bytes<2, NP>());
     if constexpr (EPI != VN_EPI_GEGLU) {
-        if (!rc) rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 3>, x3_lds_bytes<3>());
+        if (!rc) rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 3, 0, FMT>, x3_lds_bytes<3, NP>());
     }
     return rc;
 }
@@ -768,14 +820,20 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
     if (a.K % X3_KT) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: K=%s%ld must be a multiple of 32", "", a.K);
     if (epilogue == VN_EPI_CONV ? (a.N % 16) : (a.N % 64))
         return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: N=%s%ld must be a multiple of 64 (16 for the convolution epilogue)", "", a.N);
-    if ((a.a_plane != VN_PLANES_TILED && (a.a_plane <= 0 || (a.a_plane & 7))) || (!a.w_tiled && (a.w_plane <= 0 || (a.w_plane & 7))))
-        return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: plane strides must be positive multiples of 8 elements (or the tiled layout)%s", "");
+    const bool h2 = a.bf16 == 3;
+    if (h2 && epilogue == VN_EPI_CONV) return vn_fail(ctx, VN_ERR_UNSUPPORTED, "gemm_x3: the convolution mode takes bf16x3 planes%s", "");
+    if ((a.a_plane != (h2 ? VN_PLANES_TILED_H2 : VN_PLANES_TILED) && (a.a_plane <= 0 || (a.a_plane & 7))) ||
+        (!a.w_tiled && (a.w_plane <= 0 || (a.w_plane & 7))))
+        return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: plane strides must be positive multiples of 8 elements (or the tiled layout of the format)%s", "");
     if (((uintptr_t)a.A | (uintptr_t)a.W) & 15) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: operands must be 16-byte aligned%s", "");
     if (!(ctx->attr_mask & VN_ATTR_GEMM_X3)) {
         int rc;
         if ((rc = x3_attrs<VN_EPI_STORE>(ctx)) || (rc = x3_attrs<VN_EPI_BIAS>(ctx)) || (rc = x3_attrs<VN_EPI_RESIDUAL>(ctx)) ||
             (rc = x3_attrs<VN_EPI_GEGLU>(ctx)) || (rc = x3_attrs<VN_EPI_QKV>(ctx)) || (rc = x3_attrs<VN_EPI_QKV3>(ctx)) ||
             (rc = x3_attrs<VN_EPI_CONV>(ctx)))
+            return rc;
+        if ((rc = x3_attrs<VN_EPI_STORE, 1>(ctx)) || (rc = x3_attrs<VN_EPI_BIAS, 1>(ctx)) || (rc = x3_attrs<VN_EPI_RESIDUAL, 1>(ctx)) ||
+            (rc = x3_attrs<VN_EPI_GEGLU, 1>(ctx)) || (rc = x3_attrs<VN_EPI_QKV, 1>(ctx)) || (rc = x3_attrs<VN_EPI_QKV3, 1>(ctx)))
             return rc;
         if ((rc = x3_attrs_abl<1, 1>(ctx)) || (rc = x3_attrs_abl<1, 2>(ctx)) || (rc = x3_attrs_abl<1, 3>(ctx)) ||
             (rc = x3_attrs_abl<2, 1>(ctx)) || (rc = x3_attrs_abl<2, 2>(ctx)) || (rc = x3_attrs_abl<2, 3>(ctx)) ||
@@ -785,20 +843,22 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
         ctx->attr_mask |= VN_ATTR_GEMM_X3;
     }
     switch (epilogue) {
-        case VN_EPI_STORE: return x3_launch<VN_EPI_STORE>(ctx, a, s);
+        case VN_EPI_STORE: return h2 ? x3_launch<VN_EPI_STORE, 1>(ctx, a, s) : x3_launch<VN_EPI_STORE>(ctx, a, s);
         case VN_EPI_BIAS:
             if (!a.bias) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: bias epilogue needs bias%s", "");
-            return x3_launch<VN_EPI_BIAS>(ctx, a, s);
-        case VN_EPI_RESIDUAL: return x3_launch<VN_EPI_RESIDUAL>(ctx, a, s);
+            return h2 ? x3_launch<VN_EPI_BIAS, 1>(ctx, a, s) : x3_launch<VN_EPI_BIAS>(ctx, a, s);
+        case VN_EPI_RESIDUAL: return h2 ? x3_launch<VN_EPI_RESIDUAL, 1>(ctx, a, s) : x3_launch<VN_EPI_RESIDUAL>(ctx, a, s);
         case VN_EPI_GEGLU:
-            if (a.C16 && a.c_plane <= 0 && a.c_plane != VN_PLANES_TILED) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3/geglu: C16 needs c_plane%s", "");
-            if (a.C16 && a.c_plane == VN_PLANES_TILED && (a.ldc & 31)) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3/geglu: tiled planes need ldc %% 32 == 0%s", "");
-            return x3_launch<VN_EPI_GEGLU>(ctx, a, s);
-        case VN_EPI_QKV: return x3_launch<VN_EPI_QKV>(ctx, a, s);
+            // the planes of the result are written in the operands' format (they are the next GEMM's A operand)
+            if (a.C16 && (h2 ? (a.c_plane != VN_PLANES_TILED_H2 && a.c_plane <= 0) : (a.c_plane != VN_PLANES_TILED && a.c_plane <= 0)))
+                return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3/geglu: C16 needs c_plane (> 0 planar, or the tiled layout of the operands' format)%s", "");
+            if (a.C16 && vn_planes_tiled(a.c_plane) && (a.ldc & 31)) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3/geglu: tiled planes need ldc %% 32 == 0%s", "");
+            return h2 ? x3_launch<VN_EPI_GEGLU, 1>(ctx, a, s) : x3_launch<VN_EPI_GEGLU>(ctx, a, s);
+        case VN_EPI_QKV: return h2 ? x3_launch<VN_EPI_QKV, 1>(ctx, a, s) : x3_launch<VN_EPI_QKV>(ctx, a, s);
         case VN_EPI_QKV3:
             if (!a.C16 || !a.V16 || a.c_plane <= 0 || a.v_plane <= 0 || a.T <= 0 || a.H <= 0 || a.N != 3 * a.H * VN_DHEAD)
                 return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: QKV plane epilogue needs C16 / V16 / plane strides / T / H and N = 3 H 64%s", "");
-            return x3_launch<VN_EPI_QKV3>(ctx, a, s);
+            return h2 ? x3_launch<VN_EPI_QKV3, 1>(ctx, a, s) : x3_launch<VN_EPI_QKV3>(ctx, a, s);
         case VN_EPI_CONV:
             if (a.conv_taps <= 0 || a.conv_cin <= 0 || (a.conv_cin % X3_KT) || a.K != a.conv_taps * a.conv_cin || a.conv_trows <= 0 ||
                 a.M % a.conv_trows || a.conv_tin <= 0 || a.conv_tout <= 0 || !a.zeros16)
@@ -864,6 +924,46 @@ extern "C" int vn_gemm_bf16x3(vn_ctx* ctx, const void* A3, int64_t a_plane, cons
     a.ldc = epilogue == VN_EPI_GEGLU ? N / 2 : N;
     a.bf16 = 2; a.a_plane = a_plane; a.w_plane = w_plane;
     a.w_tiled = w_plane == VN_PLANES_TILED;               // -1 for either stride: that operand is given in the tiled layout
+    return vn_launch_gemm_x3(ctx, a, epilogue, (hipStream_t)stream);
+}
+
+// ---- f16x2 (vn_common.h vn_split2h): plane builders and the single-op entry -------------------------------------------------------
+// fp32 [rows][K] -> f16x2 planes, planar (dst[q][rows][K], `plane` elements apart) or tiled ([rows / 16][K / 32][2][16][32])
+__global__ __launch_bounds__(256) void vn_split2h_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long rows, int K,
+                                                         long plane) {
+    const long n4 = rows * (K >> 2);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
+        const long row = i / (K >> 2);
+        const int col = (int)(i - row * (K >> 2)) * 4;
+        vn_store_planes4(dst, plane, row, col, K, ((const f32x4*)src)[i]);
+    }
+}
+int vn_launch_split2h(vn_ctx* ctx, const float* src, uint16_t* dst, long rows, int K, long plane, hipStream_t s) {
+    if (rows <= 0 || K <= 0 || (K & 3) || !vn_planes_h2(plane) || (plane == VN_PLANES_TILED_H2 && ((rows & 15) || (K & 31))) ||
+        (plane != VN_PLANES_TILED_H2 && ((-plane) & 7)))
+        return vn_fail(ctx, VN_ERR_INVALID, "split2h: K %% 4 == 0 (tiled: rows %% 16, K %% 32; planar: stride %% 8) (rows=%s%ld, K=%ld)", "", rows, K);
+    const long n4 = rows * (K >> 2);
+    const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(vn_split2h_kernel, dim3(blocks), dim3(256), 0, s, src, dst, rows, K, plane);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+// C-ABI: tiled != 0 -> the tiled layout (rows % 16 == 0, K % 32 == 0), else two planar planes plane_stride elements apart
+extern "C" int vn_split2_f16(vn_ctx* ctx, const float* src, void* dst16, int64_t rows, int K, int64_t plane_stride, int tiled, void* stream) {
+    if (!ctx || !src || !dst16) return VN_ERR_INVALID;
+    if (!tiled && (plane_stride < rows * K || (plane_stride & 7))) return vn_fail(ctx, VN_ERR_INVALID, "split2_f16: plane stride %s%ld too small or not a multiple of 8", "", (long)plane_stride);
+    return vn_launch_split2h(ctx, src, (uint16_t*)dst16, (long)rows, K, tiled ? VN_PLANES_TILED_H2 : -(long)plane_stride, (hipStream_t)stream);
+}
+// single-op entry (tests / tuning): A2 [2][M][K] and W2 [2][N][K] fp16 planes (a stride of -1: that operand in the tiled layout) -> fp32 C
+extern "C" int vn_gemm_f16x2(vn_ctx* ctx, const void* A2, int64_t a_plane, const void* W2, int64_t w_plane, const float* bias,
+                             float* C, int M, int N, int K, int epilogue, void* stream) {
+    if (!ctx || !A2 || !W2 || !C) return VN_ERR_INVALID;
+    if (epilogue < VN_EPI_STORE || epilogue > VN_EPI_GEGLU) return vn_fail(ctx, VN_ERR_INVALID, "bad epilogue%s", "");
+    vn_gemm_args a{};
+    a.A = (const float*)A2; a.W = (const float*)W2; a.bias = bias; a.C = C; a.M = M; a.N = N; a.K = K;
+    a.ldc = epilogue == VN_EPI_GEGLU ? N / 2 : N;
+    a.bf16 = 3; a.a_plane = a_plane == -1 ? VN_PLANES_TILED_H2 : a_plane; a.w_plane = w_plane;
+    a.w_tiled = w_plane == -1;
     return vn_launch_gemm_x3(ctx, a, epilogue, (hipStream_t)stream);
 }
 

@@ -70,20 +70,70 @@ __device__ __forceinline__ void vn_store_bf16x4(uint16_t* dst, long plane, const
     }
 }
 
+// fp32 -> TWO fp16 terms ("f16x2", gemm_x3.hip's second operand format): h0 = fp16(x), h1 = fp16((x - h0) * 2^11).  fp16 carries 11
+// significand bits, the remainder of a round-to-nearest conversion is at most 2^-11 |x| and exact in fp32, and scaling it by 2^11
+// puts it in the SAME binade range as h0 — so x = h0 + 2^-11 h1 to within 2^-22 |x| for every |x| in fp16's normal range
+// (6.1e-5 .. 65504; below that the absolute error is 2^-25: fp16 subnormals are produced by v_cvt_f16_f32 and kept by the f16 MFMA
+// on gfx950 — scripts/ubench/f16_denorm_probe.hip).  A product of such pairs needs THREE matrix-core products instead of the six
+// of the bf16 triples: a0 b0 into one accumulator, a0 b1 + a1 b0 into a second one that enters the result times 2^-11 (a1 b1 is
+// 2^-22 of the leading term and dropped).  Operand error 2^-22 is four times the representation error of fp32 itself and random in
+// sign: on the model's shapes the result is 7e-8 rms from the float64 product, an fp32-accumulating GEMM of the unsplit operands
+// 3.4e-7 (tests/test_gpu_f16x2.py).  Values beyond +-65504 SATURATE (v_med3) instead of turning into inf.
+#define VN_H2_SCALE 2048.0f
+#define VN_H2_INV_SCALE (1.0f / 2048.0f)
+__device__ __forceinline__ void vn_split2h(float x, uint16_t& h0, uint16_t& h1) {
+    x = __builtin_fminf(__builtin_fmaxf(x, -65504.0f), 65504.0f);
+    const _Float16 a = (_Float16)x;
+    const _Float16 b = (_Float16)((x - (float)a) * VN_H2_SCALE);
+    h0 = __builtin_bit_cast(uint16_t, a);
+    h1 = __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float vn_h2_value(uint16_t h0, uint16_t h1) {
+    return (float)__builtin_bit_cast(_Float16, h0) + (float)__builtin_bit_cast(_Float16, h1) * VN_H2_INV_SCALE;
+}
+// four consecutive values -> one 8-byte store per f16x2 plane
+__device__ __forceinline__ void vn_store_h2x4(uint16_t* dst, long plane, const f32x4& o) {
+    uint16_t t[2][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vn_split2h(o[e], t[0][e], t[1][e]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        uint2 pk;
+        pk.x = t[q][0] | ((unsigned)t[q][1] << 16);
+        pk.y = t[q][2] | ((unsigned)t[q][3] << 16);
+        *(uint2*)(dst + q * plane) = pk;
+    }
+}
+
 // Split planes of a [rows][K] GEMM operand come in two layouts: PLANAR, three [rows][K] images `plane` elements apart, and TILED
 // (plane stride VN_PLANES_TILED): [row / 16][k / 32][plane][row % 16][k % 32] — the 16-row x 32-k block of each plane is one
 // contiguous 1 KiB piece = exactly what one LDS-DMA instruction of gemm_x3.hip fetches (eight whole cache lines instead of sixteen
 // half lines from sixteen rows).  The model path uses TILED for weights and activations; PLANAR stays for the single-op test entries
 // and the training GEMMs' on-the-fly splits.
+// The plane-stride argument of every producer (RMSNorm, attention output, GEGLU epilogue) also names the FORMAT, so that the
+// model path switches formats without a second argument anywhere:
+//   stride > 0                planar bf16x3, three planes `stride` elements apart
+//   VN_PLANES_TILED (-1)      tiled bf16x3
+//   VN_PLANES_TILED_H2 (-2)   tiled f16x2: [row / 16][k / 32][2 planes][16][32]
+//   stride < -2               planar f16x2, two planes -stride elements apart (single-op tests)
 #define VN_PLANES_TILED (-1L)
-__host__ __device__ __forceinline__ size_t vn_tiled_off(long row, int k, int K) {       // plane 0; plane q: + 512 q
-    return (((size_t)(row >> 4) * (K >> 5) + (k >> 5)) * 3) * 512 + (size_t)((row & 15) * 32 + (k & 31));
+#define VN_PLANES_TILED_H2 (-2L)
+__host__ __device__ __forceinline__ bool vn_planes_h2(long plane) { return plane <= VN_PLANES_TILED_H2; }
+__host__ __device__ __forceinline__ bool vn_planes_tiled(long plane) { return plane == VN_PLANES_TILED || plane == VN_PLANES_TILED_H2; }
+__host__ __device__ __forceinline__ size_t vn_tiled_off_np(long row, int k, int K, int NP) {       // plane 0; plane q: + 512 q
+    return (((size_t)(row >> 4) * (K >> 5) + (k >> 5)) * NP) * 512 + (size_t)((row & 15) * 32 + (k & 31));
 }
+__host__ __device__ __forceinline__ size_t vn_tiled_off(long row, int k, int K) { return vn_tiled_off_np(row, k, K, 3); }
 // four consecutive columns col .. col + 3 (col % 4 == 0) of row `row` of a [rows][ld] matrix -> its planes
 // (one call of vn_store_bf16x4 with a selected address / stride: with a call per layout hipcc 7.2 tail-merged the three store
 // sequences of the D = 256 RMSNorm kernel and stored a stale register as the last dword of the planar form)
 __device__ __forceinline__ void vn_store_planes4(uint16_t* base, long plane, long row, int col, int ld, const f32x4& o) {
-    const bool tiled = plane == VN_PLANES_TILED;
+    const bool tiled = vn_planes_tiled(plane);
+    if (vn_planes_h2(plane)) {
+        const size_t off = tiled ? vn_tiled_off_np(row, col, ld, 2) : (size_t)row * ld + col;
+        vn_store_h2x4(base + off, tiled ? 512L : -plane, o);
+        return;
+    }
     const size_t off = tiled ? vn_tiled_off(row, col, ld) : (size_t)row * ld + col;
     vn_store_bf16x4(base + off, tiled ? 512L : plane, o);
 }
@@ -287,8 +337,8 @@ struct vn_gemm_args {
     const float* bias;   // [N] or null
     float* C;            // epilogue dependent
     uint16_t* C16;       // GEGLU epilogue: write bf16 instead of C (fast mode / bf16x3 planes)
-    int bf16;            // 1: A and W hold bf16 (K counts elements), fp32 accumulate; 2: bf16x3 split planes (gemm_x3.hip)
-    long a_plane, w_plane, c_plane;   // bf16x3: elements between the three planes of A / W / C16
+    int bf16;            // 1: A and W hold bf16 (K counts elements), fp32 accumulate; 2: bf16x3 split planes, 3: f16x2 split planes (gemm_x3.hip)
+    long a_plane, w_plane, c_plane;   // bf16x3 / f16x2: elements between the planes of A / W / C16 (> 0 planar, VN_PLANES_TILED[_H2])
     int M, N, K;
     int ldc;             // row stride of C (floats)
     // QKV scatter: C = qkv base [3][B][H][T][64]; row m = b*T + t
@@ -328,6 +378,8 @@ int vn_launch_gemm_f32(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStre
 int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);      // a.bf16 == 2
 // planar split planes [3][rows][K] (plane elements apart) -> tiled planes [rows / 16][K / 32][3][16][32]; rows % 16 == 0, K % 32 == 0
 int vn_launch_tile_planes(vn_ctx* ctx, const uint16_t* planes, long plane, uint16_t* tiled, long rows, int K, hipStream_t s);
+// fp32 [rows][K] -> f16x2 planes: plane = VN_PLANES_TILED_H2 (rows % 16 == 0, K % 32 == 0) or -(planar stride)
+int vn_launch_split2h(vn_ctx* ctx, const float* src, uint16_t* dst, long rows, int K, long plane, hipStream_t s);
 // C[M][N] (row stride ldc) (+)= sum over the nsplit partial images partial[s][M][N], in fixed order (gemm_f32.hip)
 int vn_launch_splitk_reduce(vn_ctx* ctx, const float* partial, int nsplit, float* C, int M, int N, int ldc, bool residual,
                             hipStream_t s);

@@ -152,6 +152,39 @@ class Engine:
                                            self.stream()), "vn_gemm_bf16x3")
         return out
 
+    def split2h(self, x, tiled=False):
+        """fp32 [R, K] -> the f16x2 operand format of gemm_f16x2: float16 [2, R, K] (h0 = fp16(x), h1 = fp16((x - h0) * 2048)), or with
+        tiled=True the tiled image [ceil(R/16), K/32, 2, 16, 32] (rows zero-padded to 16)."""
+        x = x.contiguous()
+        R, K = x.shape
+        if tiled:
+            R16 = (R + 15) // 16 * 16
+            if R16 != R:
+                x = torch.cat([x, x.new_zeros(R16 - R, K)], dim=0)
+            out = torch.empty(R16 // 16, K // 32, 2, 16, 32, dtype=torch.float16, device=x.device)
+            self.check(self.lib.vn_split2_f16(self.handle, x.data_ptr(), out.data_ptr(), R16, K, 0, 1, self.stream()), "vn_split2_f16")
+            return out
+        out = torch.empty(2, R, K, dtype=torch.float16, device=x.device)
+        self.check(self.lib.vn_split2_f16(self.handle, x.data_ptr(), out.data_ptr(), R, K, R * K, 0, self.stream()), "vn_split2_f16")
+        return out
+
+    def gemm_f16x2(self, a2, w2, bias=None, epilogue=_lib.EPI_STORE, out=None, tiled_shape=None):
+        """fp32-grade GEMM as three fp16 matrix-core products: a2 [2,M,K], w2 [2,N,K] (split2h) -> fp32 out (op)= a @ w.T.
+        tiled_shape=(M, N, K): a2 / w2 are split2h(tiled=True) images instead."""
+        if tiled_shape is not None:
+            M, N, K = tiled_shape
+            ap = wp = -1
+        else:
+            _, M, K = a2.shape
+            N = w2.shape[1]
+            ap, wp = M * K, N * K
+        if out is None:
+            out = torch.empty(M, N // 2 if epilogue == _lib.EPI_GEGLU else N, device=a2.device, dtype=torch.float32)
+        self.check(self.lib.vn_gemm_f16x2(self.handle, a2.data_ptr(), ap, w2.data_ptr(), wp,
+                                          bias.data_ptr() if bias is not None else None, out.data_ptr(), M, N, K, epilogue,
+                                          self.stream()), "vn_gemm_f16x2")
+        return out
+
     def attention(self, q, k, v, rel_bias, num_buckets=32, max_distance=128, precision="f32"):
         """q,k,v [B,H,T,64]; rel_bias [num_buckets,H] -> [B,T,H*64].  precision "f32": fp32-input MFMA (attention_f32.hip);
         "bf16x3": six bf16-MFMA products of exact operand splits (attention_x3.hip), same error class."""
