@@ -221,8 +221,10 @@ def main():
     ap.add_argument("--config", type=int, choices=[1, 2], default=2,
                     help="BASELINE.json configs index: 1 = coarse model only, batch 1, 12 sampling steps (= --coarse-only "
                          "--batch-per-gpu 1); 2 (default) = coarse + c2f vamp(), batch 8")
-    ap.add_argument("--dtype", choices=["f32", "bf16x3", "bf16"], default="bf16x3",
-                    help="bf16x3 (default) = fp32-grade GEMMs as six bf16-MFMA products of exact 3-way operand splits, fp32 "
+    ap.add_argument("--dtype", choices=["f32", "bf16x3", "f16x2", "bf16"], default="bf16x3",
+                    help="f16x2 = fp32-grade GEMMs as three fp16-MFMA products of two-plane operand splits (second plane scaled by "
+                         "2^11, second accumulator), same parity bars; "
+                         "bf16x3 (default) = fp32-grade GEMMs as six bf16-MFMA products of exact 3-way operand splits, fp32 "
                          "accumulate: held to the same parity bars as f32 (tests/test_gpu_bf16x3.py: tokens bit-identical to the "
                          "oracle and the reference's golden tokens); f32 = exact-fp32 MFMA; bf16 = fast mode, not bit-exact")
     ap.add_argument("--workload", choices=["vamp", "train"], default="vamp",
@@ -435,6 +437,10 @@ def main():
                                                "products per k-step, fp32 accumulate — the GEMMs (gemm_x3.hip) AND both attention products "
                                                "(attention_x3.hip; P split in registers); norms / softmax / sampling fp32; "
                                                "same parity bars as f32 (tests/test_gpu_bf16x3.py)",
+                                     "f16x2": "fp32-grade: each GEMM operand = 2 fp16 planes (h0 = fp16(x), h1 = fp16((x - h0) 2^11): x to 2^-22), "
+                                              "3 fp16-MFMA products per k-step into two fp32 accumulators (gemm_x3.hip); attention on bf16x3 planes "
+                                              "(attention_x3.hip); norms / softmax / sampling fp32; same parity bars as f32 "
+                                              "(tests/test_gpu_bf16x3.py, tests/test_gpu_f16x2.py)",
                                      "bf16": "bf16 GEMM/attention operands (fast mode, not bit-exact)"}[args.dtype]},
         }
         if prof is not None:
@@ -451,19 +457,21 @@ def main():
                 traffic_source = f"profiles/{tname} (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command; a constant, not this run)"
             # bf16x3: `achieved` stays ALGORITHMIC (2MNK per GEMM, fp32-equivalent); every such flop costs six bf16-MFMA flops,
             # so the ceiling of this algorithm is the dense bf16 MFMA peak / 6 (the kernel executes 6 x achieved on the pipe)
-            peak = {"f32": PEAK_F32_MFMA_TF, "bf16": PEAK_BF16_MFMA_TF, "bf16x3": PEAK_BF16_MFMA_TF / 6.0}[args.dtype]
+            # f16x2: three fp16-MFMA flops per algorithmic flop: ceiling = dense fp16 MFMA peak (= the bf16 one) / 3
+            nprod = {"bf16x3": 6.0, "f16x2": 3.0}.get(args.dtype)
+            peak = {"f32": PEAK_F32_MFMA_TF, "bf16": PEAK_BF16_MFMA_TF, "bf16x3": PEAK_BF16_MFMA_TF / 6.0, "f16x2": PEAK_BF16_MFMA_TF / 3.0}[args.dtype]
             kname = {"f32": "vn_gemm_f32[_sk]_kernel", "bf16": "vn_gemm_f32_kernel<128,128,BF16>",
-                     "bf16x3": "vn_gemm_x3_kernel"}[args.dtype]
+                     "bf16x3": "vn_gemm_x3_kernel", "f16x2": "vn_gemm_x3_kernel<.., FMT = 1>"}[args.dtype]
             res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": fl / (ms * 1e-3) / 1e12 if ms else None,
                                "peak": peak, "unit": "TFLOP/s",
                                "frac": (fl / (ms * 1e-3) / 1e12) / peak if ms else None,
                                "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": gbytes / n if n else None, "launches": int(n), "avg_launch_us": 1e3 * ms / n if n else None,
-                               **({"peak_basis": "2500 TF dense bf16 MFMA / 6 plane products per fp32-grade product",
-                                   "executed_mfma_tflops": 6.0 * fl / (ms * 1e-3) / 1e12 if ms else None,
+                               **({"peak_basis": f"2500 TF dense bf16 / fp16 MFMA / {int(nprod)} plane products per fp32-grade product",
+                                   "executed_mfma_tflops": nprod * fl / (ms * 1e-3) / 1e12 if ms else None,
                                    # context: the same algorithmic rate against the fp32-input MFMA peak (157.3 TF), the
                                    # ceiling of the exact-fp32 kernel this precision replaces
                                    "achieved_over_f32_mfma_peak": fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF if ms else None}
-                                  if args.dtype == "bf16x3" else {}),
+                                  if nprod else {}),
                                "event_stride": args.event_stride,        # launches / times above: the bracketed sample
                                "gemm_time_frac": args.event_stride * ms / (1e3 * elapsed) if elapsed else None,
                                "attention": {"launches": int(an), "avg_launch_us": 1e3 * ams / an if an else None,

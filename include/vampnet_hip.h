@@ -155,6 +155,12 @@ int vn_model_set_bf16(vn_model* model, const void* blob_bf16_dev);
  * apart (>= vn_weights_size, multiple of 8), 16-byte aligned device memory that must outlive the model; NULL switches
  * back to exact fp32.  Attention, norms, residual stream, softmax and sampling are the fp32 path unchanged.            */
 int vn_model_set_bf16x3(vn_model* model, const void* blob_planes_dev, int64_t plane_stride);
+/* Optional "f16x2" mode: fp32-GRADE GEMMs as THREE fp16 matrix-core products.  Every GEMM operand is two fp16 planes, h0 = fp16(x)
+ * and h1 = fp16((x - h0) * 2^11) (vn_split2_f16 below): x = h0 + 2^-11 h1 to within 2^-22 |x| — four times fp32's own
+ * representation error and random in sign, so the product stays below the rounding noise of an fp32-accumulating fp32 GEMM
+ *  — at half of bf16x3's matrix time.  on != 0: the engine builds the weight planes from the fp32 blob it already
+ * holds; on == 0: back to exact fp32.  Values beyond +-65504 saturate.  Attention runs on bf16x3 planes as in the bf16x3 mode.   */
+int vn_model_set_f16x2(vn_model* model, int on);
 /* dst16[q * plane_stride + i] = q-th split term of src[i], q = 0..2 (n % 4 == 0, src 16-byte aligned) */
 int vn_split3_f32(vn_ctx* ctx, const float* src, void* dst16, int64_t n, int64_t plane_stride, void* stream);
 

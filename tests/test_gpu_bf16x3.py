@@ -1,7 +1,8 @@
-"""-m gpu: the "bf16x3" precision (fp32-grade GEMMs as six bf16-MFMA products of exact operand splits, gemm_x3.hip) is held
-to the SAME parity bars as the exact-fp32 MFMA path: the test bodies are the ones of tests/test_gpu_model.py, run on
-models switched to precision="bf16x3" — logits vs the CPU oracle and the reference's frozen probes at the fp32 tolerances,
-tokens bit-identical to the oracle and to the reference's golden tokens."""
+"""-m gpu: the split-plane precisions of gemm_x3.hip — "bf16x3" (fp32-grade GEMMs as six bf16-MFMA products of exact three-way
+operand splits) and "f16x2" (three fp16-MFMA products of two-plane splits, second accumulator) — are held to the SAME parity bars as
+the exact-fp32 MFMA path: the test bodies are the ones of tests/test_gpu_model.py, run on models switched to that precision —
+logits vs the CPU oracle and the reference's frozen probes at the fp32 tolerances, tokens bit-identical to the oracle and to the
+reference's golden tokens."""
 import pytest
 import torch
 
@@ -18,12 +19,20 @@ def eng():
     return Engine("cuda:0")
 
 
+SPLIT_PRECISIONS = ["bf16x3", "f16x2"]
+
+
+@pytest.fixture(scope="module", params=SPLIT_PRECISIONS)
+def prec(request):
+    return request.param
+
+
 @pytest.fixture(scope="module")
-def tiny3(eng):
+def tiny3(eng, prec):
     from vampnet_amd.engine import VampNetModel
     cb = W.synth_codebooks()
     csd, fsd = W.synth_state_dict(W.TINY_COARSE_DIMS, 0), W.synth_state_dict(W.TINY_C2F_DIMS, 1)
-    kw = dict(precision="bf16x3")
+    kw = dict(precision=prec)
     coarse = VampNetModel(eng, csd, cb, max_batch=4, max_T=575, **kw, **model_kwargs(W.TINY_COARSE_DIMS))
     c2f = VampNetModel(eng, fsd, cb, max_batch=4, max_T=173, **kw, **model_kwargs(W.TINY_C2F_DIMS))
     return dict(cb=cb, csd=csd, fsd=fsd, coarse=coarse, c2f=c2f,
@@ -31,11 +40,11 @@ def tiny3(eng):
 
 
 @pytest.fixture(scope="module")
-def itf3(tiny3):
+def itf3(tiny3, prec):
     from vampnet_amd.interface import Interface
     return Interface.from_state_dicts(SynthCodec(tiny3["cb"]), tiny3["csd"], model_kwargs(W.TINY_COARSE_DIMS),
                                       tiny3["fsd"], model_kwargs(W.TINY_C2F_DIMS), device="cuda:0", max_batch=4,
-                                      precision="bf16x3")
+                                      precision=prec)
 
 
 @pytest.mark.parametrize("which,B,T", [("coarse", 2, 50), ("coarse", 1, 575), ("c2f", 3, 37), ("c2f", 1, 173), ("coarse", 1, 1)])
@@ -59,7 +68,7 @@ def test_generate_and_vamp_vs_golden(tiny3, itf3):
 
 
 @pytest.mark.parametrize("name,dims,T,seed", [("coarse", W.COARSE_DIMS, 575, 0), ("c2f", W.C2F_DIMS, 173, 1)])
-def test_forward_full_size_vs_reference_probe(eng, name, dims, T, seed, monkeypatch):
+def test_forward_full_size_vs_reference_probe(eng, prec, name, dims, T, seed, monkeypatch):
     """Full-size models against the REFERENCE's frozen logits, same bars as the exact-fp32 path; then the two precisions
     against each other on the same weights."""
     from vampnet_amd import engine as E
@@ -68,7 +77,7 @@ def test_forward_full_size_vs_reference_probe(eng, name, dims, T, seed, monkeypa
 
     def make(*a, **k):
         m = orig(*a, **k)
-        m.set_precision("bf16x3")
+        m.set_precision(prec)
         made.append(m)
         return m
 
@@ -81,18 +90,18 @@ def test_forward_full_size_vs_reference_probe(eng, name, dims, T, seed, monkeypa
     model.set_precision("f32")
     b = model.forward_codes(codes, layout="native")
     d = (a - b).abs().max().item()
-    print(f"{name}: max |logit(bf16x3) - logit(f32 mfma)| = {d:.3e}")
+    print(f"{name}: max |logit({prec}) - logit(f32 mfma)| = {d:.3e}")
     assert d <= TM.LOGIT_ATOL_FULL
 
 
 @pytest.mark.parametrize("dims,T,B", [(W.TINY_COARSE_DIMS, 200, 3), (W.TINY_C2F_DIMS, 173, 2)])
-def test_fused_splitk_reduce_rmsnorm_is_bitwise_the_two_kernel_form(eng, dims, T, B):
+def test_fused_splitk_reduce_rmsnorm_is_bitwise_the_two_kernel_form(eng, prec, dims, T, B):
     """A RESIDUAL GEMM that is split along K runs the next RMSNorm inside its reduce pass (vn_splitk_reduce_rmsnorm_kernel): the
     logits must not move by a bit against the reduce kernel followed by the norm kernel (same summation order, same row math).
     Split-K forced to 2 so that the small shapes take the path the B = 8 model shapes take by the cost model."""
     from vampnet_amd.engine import VampNetModel
     cb = W.synth_codebooks()
-    m = VampNetModel(eng, W.synth_state_dict(dims, 3), cb, max_batch=4, max_T=256, precision="bf16x3", **model_kwargs(dims))
+    m = VampNetModel(eng, W.synth_state_dict(dims, 3), cb, max_batch=4, max_T=256, precision=prec, **model_kwargs(dims))
     codes = W.synth_codes(B, dims["n_codebooks"], T, seed=5)
     codes[:, dims["n_cond"]:, ::3] = 1024
     lib = eng.lib
@@ -125,7 +134,7 @@ def test_fused_splitk_reduce_rmsnorm_is_bitwise_the_two_kernel_form(eng, dims, T
 
 
 @pytest.mark.parametrize("dims,B,T", [(W.TINY_COARSE_DIMS, 3, 200), (W.TINY_C2F_DIMS, 2, 173), (W.TINY_COARSE_DIMS, 1, 33)])
-def test_split_plane_attention_path_at_every_tile_height(eng, dims, B, T):
+def test_split_plane_attention_path_at_every_tile_height(eng, prec, dims, B, T):
     """The QKV GEMM with the plane epilogue (q x 1/8 and k planes head-major, V^T transposed through the LDS image into the blocked
     layout) + attention_x3.hip, forced on for a small model, at the three tile heights of gemm_x3.hip (192 rows: 2 x 4 wave
     grid, 64-row epilogue images): logits bitwise equal across the heights, equal to the oracle at the tiny-model tolerance, and
@@ -133,7 +142,7 @@ def test_split_plane_attention_path_at_every_tile_height(eng, dims, B, T):
     from vampnet_amd.engine import VampNetModel
     cb = W.synth_codebooks()
     sd = W.synth_state_dict(dims, 4)
-    m = VampNetModel(eng, sd, cb, max_batch=4, max_T=256, precision="bf16x3", **model_kwargs(dims))
+    m = VampNetModel(eng, sd, cb, max_batch=4, max_T=256, precision=prec, **model_kwargs(dims))
     codes = W.synth_codes(B, dims["n_codebooks"], T, seed=6)
     codes[:, dims["n_cond"]:, ::2] = 1024
     lib = eng.lib

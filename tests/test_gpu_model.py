@@ -264,7 +264,7 @@ def test_interface_api_surface(itf):
 # ---------------------------------------------------------------------------------------- full size
 # Every full-size test runs in BOTH fp32-grade precisions: "f32" (fp32-input MFMA) and "bf16x3" (the precision bench.py
 # times).  The oracle side (CPU, seconds to a minute) is computed once per argument set and shared.
-PRECISIONS = ["f32", "bf16x3"]
+PRECISIONS = ["f32", "bf16x3", "f16x2"]
 _ORACLE_CACHE = {}
 
 

@@ -142,7 +142,7 @@ int vn_launch_splitk_reduce_rmsnorm(vn_ctx* ctx, const float* partial, int nspli
 // followed by the norm kernel — tests/test_gpu_kernels.py holds the two forms to bitwise equality
 extern "C" int vn_debug_splitk_reduce_rmsnorm(vn_ctx* ctx, const float* partial, int nsplit, float* x, const float* w, void* y16,
                                               int64_t plane16, int rows, int D, float eps, int fused, void* stream) {
-    if (!ctx || !partial || !x || !w || !y16 || nsplit < 1 || rows <= 0 || (plane16 != VN_PLANES_TILED && plane16 < (int64_t)rows * D)) return VN_ERR_INVALID;
+    if (!ctx || !partial || !x || !w || !y16 || nsplit < 1 || rows <= 0 || (!vn_planes_tiled(plane16) && plane16 < (int64_t)rows * D)) return VN_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     if (fused) return vn_launch_splitk_reduce_rmsnorm(ctx, partial, nsplit, x, w, nullptr, (uint16_t*)y16, plane16, rows, D, eps, s);
     const int rc = vn_launch_splitk_reduce(ctx, partial, nsplit, x, rows, D, D, true, s);

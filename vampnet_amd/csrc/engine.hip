@@ -219,6 +219,7 @@ extern "C" void vn_model_destroy(vn_model* m) {
     (void)hipFree(m->y16);
     (void)hipFree(m->g16);
     (void)hipFree(m->w_tiled);
+    (void)hipFree(m->w_h2);
     (void)hipFree(m->qk16);
     (void)hipFree(m->vt16);
     delete m;
@@ -293,11 +294,13 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
     // accumulation / residual stream / attention / norms / logits stay fp32.  NOT bit-exact.
     // bf16x3 mode: the same four operands as three exact split planes each, multiplied on the bf16 matrix cores with
     // fp32-grade accuracy (gemm_x3.hip); everything else is the fp32 path.
-    const int gm = bf ? (m->w_plane ? 2 : 1) : 0;                       // vn_gemm_args::bf16
-    // plane strides of y16 / g16: bf16x3 = the tiled layout (whole-line LDS-DMA in gemm_x3.hip), fast mode = one plane
+    // f16x2 mode: the same operands as TWO fp16 planes, three matrix-core products per k-step (vn_common.h vn_split2h): fp32-grade at
+    // half the matrix time of bf16x3.  The attention operands stay bf16x3 planes (QKV3 epilogue + attention_x3.hip).
+    const int gm = bf ? (m->w_plane == VN_PLANES_TILED_H2 ? 3 : m->w_plane ? 2 : 1) : 0;       // vn_gemm_args::bf16
+    // plane strides of y16 / g16: bf16x3 / f16x2 = the tiled layout (whole-line LDS-DMA in gemm_x3.hip), fast mode = one plane
     const bool a_tiled_on = ctx->tune.a_tiled != 0;
-    const long yp = gm == 2 ? (a_tiled_on ? VN_PLANES_TILED : m->max_rows * (long)D) : 0;
-    const long gp = gm == 2 ? (a_tiled_on ? VN_PLANES_TILED : 2 * m->max_rows * (long)D) : 0;
+    const long yp = gm == 3 ? VN_PLANES_TILED_H2 : gm == 2 ? (a_tiled_on ? VN_PLANES_TILED : m->max_rows * (long)D) : 0;
+    const long gp = gm == 3 ? VN_PLANES_TILED_H2 : gm == 2 ? (a_tiled_on ? VN_PLANES_TILED : 2 * m->max_rows * (long)D) : 0;
     auto W16 = [&](int id, int layer) { return (const float*)(m->blob16 + vn_tensor_offset(&m->d, id, layer)); };
     auto operands = [&](vn_gemm_args& a, const float* A32, const uint16_t* A16, long a_plane, int id, int layer) {
         a.A = bf ? (const float*)A16 : A32;
@@ -305,6 +308,10 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
         a.bf16 = gm; a.a_plane = a_plane; a.w_plane = m->w_plane;
         if (gm == 2 && m->w_tiled && ctx->tune.w_tiled) {      // bf16x3: the tiled image of the same weight planes
             a.W = (const float*)(m->w_tiled + 3 * vn_tensor_offset(&m->d, id, layer));
+            a.w_tiled = 1;
+        }
+        if (gm == 3) {
+            a.W = (const float*)(m->w_h2 + 2 * vn_tensor_offset(&m->d, id, layer));
             a.w_tiled = 1;
         }
     };
@@ -324,7 +331,7 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
     for (int l = 0; l < m->L; ++l) {
         // y = RMSNorm(x) ; FiLM = identity (d_cond = 0, transformer.py:554)
         if (!normed && (rc = vn_launch_rmsnorm(ctx, m->x, W(m, VN_W_NORM1, l), m->y, M, D, m->d.eps, s, bf ? m->y16 : nullptr, yp))) return rc;
-        if (gm == 2 && attn_x3) {
+        if (gm >= 2 && attn_x3) {
             // ONE QKV GEMM whose epilogue writes the attention operands as split planes: q (x 1/8) and k head-major, V^T blocked by
             // tiles of 32 token rows (transposed through the epilogue's LDS image)
             vn_gemm_args a{};
@@ -470,14 +477,14 @@ extern "C" int vn_debug_graph_replays(const vn_model* m, int64_t* count) {
     return VN_OK;
 }
 
-static int set_bf16_planes(vn_model* m, const void* blob16_dev, long w_plane) {
-    if (!blob16_dev) { m->blob16 = nullptr; m->w_plane = 0; return VN_OK; }          // back to exact fp32 MFMA
-    if (m->D % 64) return vn_fail(m->ctx, VN_ERR_UNSUPPORTED, "bf16 modes need d_model %% 64 == 0%s", "");
-    int rc;        // the bf16 A-operand images are sized for three planes in either mode (graphs keep pointing at them)
+// the 16-bit A-operand images (sized for three planes in every mode: graphs keep pointing at them) and, for the split-plane modes,
+// the attention operands
+static int plane_buffers(vn_model* m, bool attention_planes) {
+    int rc;
     const size_t rows16 = ((size_t)m->max_rows + 15) / 16 * 16;        // the tiled layout addresses rows in blocks of 16
     if (!m->y16 && (rc = dev_alloc(m->ctx, &m->y16, (size_t)3 * rows16 * m->D))) return rc;
     if (!m->g16 && (rc = dev_alloc(m->ctx, &m->g16, (size_t)3 * rows16 * 2 * m->D))) return rc;
-    if (w_plane > 0 && (!m->qk16 || !m->vt16)) {        // bf16x3: attention operands as planes (attention_x3.hip)
+    if (attention_planes && (!m->qk16 || !m->vt16)) {   // attention operands as bf16x3 planes (attention_x3.hip)
         m->qk_plane = 2 * m->max_rows * (long)m->D;
         m->vt_plane = (long)m->H * ((m->max_rows + 31) / 32) * (VN_DHEAD * 32);
         // each buffer on its own null check: a failed second allocation must not leave a half-initialised pair behind
@@ -491,6 +498,14 @@ static int set_bf16_planes(vn_model* m, const void* blob16_dev, long w_plane) {
             VN_HIP_CHECK(m->ctx, hipMemset(m->vt16, 0, (size_t)3 * m->vt_plane * sizeof(uint16_t)));
         }
     }
+    return VN_OK;
+}
+
+static int set_bf16_planes(vn_model* m, const void* blob16_dev, long w_plane) {
+    if (!blob16_dev) { m->blob16 = nullptr; m->w_plane = 0; return VN_OK; }          // back to exact fp32 MFMA
+    if (m->D % 64) return vn_fail(m->ctx, VN_ERR_UNSUPPORTED, "bf16 modes need d_model %% 64 == 0%s", "");
+    int rc;
+    if ((rc = plane_buffers(m, w_plane > 0))) return rc;
     if (w_plane > 0) {
         // the GEMM weight tensors once more as tiled planes (gemm_x3.hip's LDS-DMA then fetches whole cache lines): a setup call,
         // so simply fence it against whatever stream produced the caller's planes and whatever stream runs the model next
@@ -529,6 +544,35 @@ extern "C" int vn_model_set_bf16x3(vn_model* m, const void* blob_planes_dev, int
     if (plane_stride < n || (plane_stride & 7)) return vn_fail(m->ctx, VN_ERR_INVALID, "bf16x3: plane stride %s%ld too small or not a multiple of 8", "", (long)plane_stride);
     if (((uintptr_t)blob_planes_dev) & 15) return vn_fail(m->ctx, VN_ERR_INVALID, "bf16x3: planes must be 16-byte aligned%s", "");
     return set_bf16_planes(m, blob_planes_dev, (long)plane_stride);
+}
+
+// f16x2 mode: needs nothing from the caller — the tiled fp16 planes of the GEMM weight tensors are built from the fp32 blob
+extern "C" int vn_model_set_f16x2(vn_model* m, int on) {
+    if (!m) return VN_ERR_INVALID;
+    if (!on) return set_bf16_planes(m, nullptr, 0);
+    if (m->D % 64) return vn_fail(m->ctx, VN_ERR_UNSUPPORTED, "f16x2 needs d_model %% 64 == 0%s", "");
+    int rc;
+    if ((rc = plane_buffers(m, true))) return rc;
+    if (!m->w_h2) {
+        int64_t n = 0;
+        vn_weights_size(&m->d, &n);
+        if ((rc = dev_alloc(m->ctx, &m->w_h2, (size_t)2 * n))) return rc;
+        VN_HIP_CHECK(m->ctx, hipDeviceSynchronize());          // a setup call: fence it against whatever stream wrote the blob
+        const long D = m->D;
+        auto build = [&](int id, int layer, long rows, int K) {
+            const long off = vn_tensor_offset(&m->d, id, layer);
+            return vn_launch_split2h(m->ctx, m->blob + off, m->w_h2 + 2 * off, rows, K, VN_PLANES_TILED_H2, nullptr);
+        };
+        for (int l = 0; l < m->L && !rc; ++l)
+            (rc = build(VN_W_QKV, l, 3 * D, (int)D)) || (rc = build(VN_W_WO, l, D, (int)D)) || (rc = build(VN_W_W1, l, 4 * D, (int)D)) ||
+                (rc = build(VN_W_W2, l, D, (int)(2 * D)));
+        if (!rc) rc = build(VN_W_CLS_W, 0, (long)m->Cp * m->d.vocab, (int)D);
+        if (rc) { (void)hipFree(m->w_h2); m->w_h2 = nullptr; return rc; }
+        VN_HIP_CHECK(m->ctx, hipDeviceSynchronize());
+    }
+    m->blob16 = m->w_h2;
+    m->w_plane = VN_PLANES_TILED_H2;
+    return VN_OK;
 }
 
 static int shape_check(vn_model* m, int B, int T) {

@@ -604,7 +604,7 @@ static int launch_epi(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
 }
 
 int vn_launch_gemm_f32(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s) {
-    if (a.bf16 == 2) return vn_launch_gemm_x3(ctx, a, epilogue, s);
+    if (a.bf16 >= 2) return vn_launch_gemm_x3(ctx, a, epilogue, s);            // 2: bf16x3 planes, 3: f16x2 planes
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm: empty problem%s", "");
     if (a.K % (a.bf16 ? 2 * BK : BK) != 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm: K=%s%ld must be a multiple of 32 (64 for bf16)", "", a.K);
     if (a.N % 64 != 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm: N=%s%ld must be a multiple of 64", "", a.N);

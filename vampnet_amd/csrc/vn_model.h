@@ -19,6 +19,9 @@ struct vn_model {
     uint16_t *y16, *g16;     // sized for three planes
     // bf16x3: the GEMM weight tensors of blob16 once more as TILED planes (tensor at blob offset o -> 3 o; gemm_x3.hip reads these)
     uint16_t* w_tiled;
+    // f16x2 mode (vn_model_set_f16x2): the GEMM weight tensors as tiled f16x2 planes built from the fp32 blob (tensor at blob offset
+    // o -> 2 o); while the mode is on, blob16 == w_h2 and w_plane == VN_PLANES_TILED_H2
+    uint16_t* w_h2;
     // bf16x3 attention operands (attention_x3.hip), written by the QKV GEMM epilogues: qk16 = q then k planes
     // [3][2][max_rows * D]; vt16 = blocked V^T planes [3][H * ceil(max_rows / 32) * 64 * 32], zero-filled once
     uint16_t *qk16, *vt16;

@@ -310,8 +310,10 @@ class VampNetModel:
         self.set_precision(precision)
 
     def set_precision(self, precision: str):
-        """"f32": exact-fp32 MFMA (parity mode, default).  "bf16x3": fp32-grade GEMMs evaluated as six bf16 MFMA
-        products of exact three-way operand splits (same accuracy class as "f32", faster matrix pipe).  "bf16": fast mode —
+        """"f32": exact-fp32 MFMA.  "bf16x3": fp32-grade GEMMs evaluated as six bf16 MFMA products of exact three-way operand
+        splits (same accuracy class as "f32", faster matrix pipe).  "f16x2": fp32-grade GEMMs as three fp16 MFMA products of
+        two-plane splits (operand error 2^-22, below an fp32 GEMM's own rounding noise; half of bf16x3's matrix time; values beyond
+        +-65504 saturate).  "bf16": fast mode —
         GEMM operands in bf16 like the reference's own GPU path (torch.autocast(bf16), interface.py:364,428); NOT bit-exact."""
         if precision == "bf16":
             if self.blob16 is None:
@@ -325,10 +327,14 @@ class VampNetModel:
                 self.engine.check(self.lib.vn_split3_f32(self.engine.handle, self.blob.data_ptr(), self.blob3.data_ptr(), n, n,
                                                          self.engine.stream()), "vn_split3_f32")
             self.engine.check(self.lib.vn_model_set_bf16x3(self.handle, self.blob3.data_ptr(), n), "vn_model_set_bf16x3")
+        elif precision == "f16x2":
+            # fp32-grade GEMMs as three fp16 matrix-core products of two-plane operand splits (gemm_x3.hip); the engine builds the
+            # weight planes from the fp32 blob itself
+            self.engine.check(self.lib.vn_model_set_f16x2(self.handle, 1), "vn_model_set_f16x2")
         elif precision == "f32":
             self.engine.check(self.lib.vn_model_set_bf16(self.handle, None), "vn_model_set_bf16")
         else:
-            raise ValueError("precision must be 'f32', 'bf16x3' or 'bf16'")
+            raise ValueError("precision must be 'f32', 'f16x2', 'bf16x3' or 'bf16'")
         self.precision = precision
 
     @property
