@@ -67,7 +67,7 @@ struct x3_geo {
     static constexpr int STAGE = NP * (APLANE + X3_BPLANE);         // floats: 48 / 72 / 60 KiB (NP = 2: 32 / 48 / 40)
     static constexpr int NQ = NP * (BM + 128) / 16;                 // 1 KiB DMA wave-instructions per stage: 48 / 72 / 60 (32 / 48 / 40)
     static constexpr int NPW = (NQ + 7) / 8;                        // per wave: 6 / 9 / 8 (CFG 3, NP 3: the last one only in waves 0-3); 4 / 6 / 5
-    static constexpr int NBUF = CFG == 1 ? 3 : 2;                   // resident stages
+    static constexpr int NBUF = (CFG == 1 || NP == 2) ? 3 : 2;      // resident stages (f16x2: 96 / 144 / 120 KiB)
     static constexpr int RP = 32 * WR;                              // rows of one pass of the staged epilogue's LDS image
     static constexpr int NPROD = NP == 3 ? 6 : 3;                   // matrix-core products per 16-wide k-step
     static constexpr int NI = NP == 3 ? 4 : 2;                      // two-buffer schedule: DMA pieces issued between the products of k-step 0
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
     constexpr int NP = FMT ? 2 : 3;
     using G = x3_geo<CFG, NP>;
     constexpr int RI = G::RI, CJ = G::CJ;
-    static_assert(!FMT || (EPI != VN_EPI_CONV && ABL == 0), "the codec convolutions and the ablation probes stay on bf16x3");
+    static_assert(!FMT || EPI != VN_EPI_CONV, "the codec convolutions stay on bf16x3");        // FMT = 1: ABL bit 2 = DMA never waited for
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -364,8 +364,8 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
     const uint16_t* A16 = (const uint16_t*)p.A;
     const uint16_t* W16 = (const uint16_t*)p.W;
     const int nk_all = p.K / X3_KT;
-    const int drow = (ABL & 4) ? lane >> 3 : lane >> 2;
-    const int dslot = (ABL & 4) ? lane & 7 : (lane & 3) ^ ((lane >> 4) & 3);     // (row >> 2) & 3 == (lane >> 4) & 3
+    const int drow = (ABL & 4) && !FMT ? lane >> 3 : lane >> 2;
+    const int dslot = (ABL & 4) && !FMT ? lane & 7 : (lane & 3) ^ ((lane >> 4) & 3);     // (row >> 2) & 3 == (lane >> 4) & 3
     // fragment offsets (floats) inside a plane tile: row * 16 + ((2 s + h) ^ ((row >> 2) & 3)) * 4
     const int l31 = lane & 31, h = lane >> 5, sw = (lane >> 2) & 3;
     const int aRow = (wm * 32 * RI + l31) * 16;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                     const int b = g / p.conv_trows, tq = g - b * p.conv_trows;
                     t0v[j] = tq * p.conv_in_stride - p.conv_pad;
                     src[j] = A16 + (size_t)pt * p.a_plane + ((long)b * p.conv_tin + t0v[j]) * (long)p.conv_cin + dslot * 8;
-                } else if (vn_planes_tiled(p.a_plane) && !(ABL & 4)) {
+                } else if (vn_planes_tiled(p.a_plane) && !((ABL & 4) && !FMT)) {
                     src[j] = A16 + (((size_t)(g >> 4) * nk_all + kb) * NP + pt) * 512 + (g & 15) * 32 + dslot * 8;
                     kadv[j] = NP * 512;
                 } else {
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                 const int pt = qb >> 3, row = (qb & 7) * 16 + drow;
                 int g = n0 + row;
                 g = g < p.N ? g : p.N - 1;
-                if (p.w_tiled && !(ABL & 4)) {          // piece = the contiguous 1 KiB of (row block g / 16, k-tile, plane pt)
+                if (p.w_tiled && !((ABL & 4) && !FMT)) {          // piece = the contiguous 1 KiB of (row block g / 16, k-tile, plane pt)
                     src[j] = W16 + (((size_t)(g >> 4) * nk_all + kb) * NP + pt) * 512 + (g & 15) * 32 + dslot * 8;
                     kadv[j] = NP * 512;
                 } else {
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                 const bool ok = (unsigned)(t0v[CONV ? j : 0] + cv_dt) < (unsigned)p.conv_tin;
                 from = ok ? src[j] + cv_off : p.zeros16 + dslot * 8;
             } else {
-                if constexpr (ABL & 4) k0 = (2 * k0) % p.K;     // a fresh 128-byte line per k-tile (probe: K % 64 == 0, data-parallel form)
+                if constexpr ((ABL & 4) && !FMT) k0 = (2 * k0) % p.K;     // a fresh 128-byte line per k-tile (probe: K % 64 == 0, data-parallel form)
                 else k0 = (k0 / X3_KT) * kadv[j];
                 from = src[j] + k0;
             }
@@ -523,7 +523,60 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         };
 
         const int nk = ke - kb;
-        if constexpr (CFG == 1) {
+        if constexpr (FMT) {
+            // f16x2: ONE phase per k-tile and group.  A k-step has half the matrix work of bf16x3's (three products), so the bf16x3
+            // schedules' phases of one k-step (12 / 9 MFMAs) are too short against their barrier and LDS latency; here a load phase
+            // reads the fragments of BOTH k-steps of a tile (16 KiB per wave) and a compute phase issues both steps' products
+            // (2 x 3 x RI x CJ MFMAs): two barriers per k-tile instead of four.  Three buffers, tile kt in buffer kt % 3: phase
+            // 2 kt = group 0 loads tile kt, 2 kt + 1 = group 0 computes it while group 1 loads it, 2 kt + 2 = group 1 computes it.
+            // Tile kt + 2 goes into the buffer of tile kt - 1 (last read in phase 2 kt - 1) and is first read in phase 2 kt + 4:
+            // every wave issues its pieces in phase 2 kt + 1 (group 0 between the MFMAs of its compute phase, group 1 after the
+            // reads of its load phase) and waits for them at the end of phase 2 kt + 3 with the pieces of tile kt + 3 in flight
+            // (counted vmcnt) — two full phases between issue and wait.
+            Frags f1;
+            stage(0, 0);
+            if (nk > 1) stage(1, X3_KT);
+            if (nk > 1) X3_VMCNT(G::NPW); else X3_VMCNT(0);
+            X3_BARRIER();                                   // tile 0 complete
+            if (grp) X3_BARRIER();                          // group 1 runs one phase behind
+            if constexpr (ABL & 2) { load_frags(f, 0, 0); load_frags(f1, 0, 1); }
+            int b = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                const int b2 = b == 0 ? 2 : b - 1;          // buffer of tile kt + 2
+                const bool more = (kt + 2 < nk) && !(ABL & 1);
+                const bool last = kt + 1 == nk;
+                // ---- load phase
+                if constexpr (!(ABL & 2)) {
+                    load_frags(f, b, 0);
+                    load_frags(f1, b, 1);
+                }
+                if (grp || p.group_m >= 0) {
+                    if (more) {
+                        stage(b2, (kt + 2) * X3_KT);
+                        if constexpr (!(ABL & 4)) X3_VMCNT(G::NPW);     // tile kt + 1 landed (this wave's pieces); tile kt + 2 in flight
+                    } else {
+                        if constexpr (!(ABL & 4)) X3_VMCNT(0);
+                    }
+                }
+                X3_LGKM0();
+                X3_BARRIER();
+                // ---- compute phase
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    mac_prod(t < 3 ? f : f1, t < 3 ? t : t - 3);
+                    if (!grp && p.group_m < 0 && more && t < G::NPW) stage_piece(b2, (kt + 2) * X3_KT, t);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                if (!grp && p.group_m < 0) {
+                    if (more) X3_VMCNT(G::NPW); else X3_VMCNT(0);
+                }
+                if (!(last && grp)) X3_BARRIER();           // group 1's last compute phase has no partner phase
+                b = b == 2 ? 0 : b + 1;
+            }
+        } else if constexpr (CFG == 1) {
             // three buffers; tile kt lives in buffer kt % 3.  Phase intervals I_j between consecutive barriers: group 0 loads
             // step i in I_2i and computes it in I_2i+1, group 1 one interval later.  Tile kt is read in I_4kt .. I_4kt+3 (every
             // load phase ends with lgkmcnt(0) BEFORE its barrier, so those reads have retired when I_4kt+4 starts), tile
@@ -751,21 +804,21 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
     const x3_plan plan = x3_choose<EPI>(ctx, a, vn_num_cus(ctx), FMT ? 0.85 : 1.45);
     const int bm = plan.bm;
     bool done = false;
-    if constexpr (EPI == VN_EPI_STORE && FMT == 0) {
+    if constexpr (EPI == VN_EPI_STORE) {
         int abl = ctx->tune.x3_abl;                                        // ablations (tuning only; results invalid): vn_debug_x3_config
-        if (abl == 4 && (a.a_plane == VN_PLANES_TILED || a.w_tiled)) abl = 0;      // the full-line probe re-addresses PLANAR planes only
+        if (abl == 4 && !FMT && (a.a_plane == VN_PLANES_TILED || a.w_tiled)) abl = 0;     // the full-line probe re-addresses PLANAR bf16x3 planes only
         if (abl) {
             const bool big = bm == 256;
             if (bm == 192) {
-                if (abl == 1) rc = x3_go<VN_EPI_STORE, 3, 1>(ctx, a, 1, s);
-                else if (abl == 2) rc = x3_go<VN_EPI_STORE, 3, 2>(ctx, a, 1, s);
-                else if (abl == 3) rc = x3_go<VN_EPI_STORE, 3, 3>(ctx, a, 1, s);
-                else rc = x3_go<VN_EPI_STORE, 3, 4>(ctx, a, 1, s);
+                if (abl == 1) rc = x3_go<VN_EPI_STORE, 3, 1, FMT>(ctx, a, 1, s);
+                else if (abl == 2) rc = x3_go<VN_EPI_STORE, 3, 2, FMT>(ctx, a, 1, s);
+                else if (abl == 3) rc = x3_go<VN_EPI_STORE, 3, 3, FMT>(ctx, a, 1, s);
+                else rc = x3_go<VN_EPI_STORE, 3, 4, FMT>(ctx, a, 1, s);
             }
-            else if (abl == 1) rc = big ? x3_go<VN_EPI_STORE, 2, 1>(ctx, a, 1, s) : x3_go<VN_EPI_STORE, 1, 1>(ctx, a, 1, s);
-            else if (abl == 2) rc = big ? x3_go<VN_EPI_STORE, 2, 2>(ctx, a, 1, s) : x3_go<VN_EPI_STORE, 1, 2>(ctx, a, 1, s);
-            else if (abl == 3) rc = big ? x3_go<VN_EPI_STORE, 2, 3>(ctx, a, 1, s) : x3_go<VN_EPI_STORE, 1, 3>(ctx, a, 1, s);
-            else rc = big ? x3_go<VN_EPI_STORE, 2, 4>(ctx, a, 1, s) : x3_go<VN_EPI_STORE, 1, 4>(ctx, a, 1, s);
+            else if (abl == 1) rc = big ? x3_go<VN_EPI_STORE, 2, 1, FMT>(ctx, a, 1, s) : x3_go<VN_EPI_STORE, 1, 1, FMT>(ctx, a, 1, s);
+            else if (abl == 2) rc = big ? x3_go<VN_EPI_STORE, 2, 2, FMT>(ctx, a, 1, s) : x3_go<VN_EPI_STORE, 1, 2, FMT>(ctx, a, 1, s);
+            else if (abl == 3) rc = big ? x3_go<VN_EPI_STORE, 2, 3, FMT>(ctx, a, 1, s) : x3_go<VN_EPI_STORE, 1, 3, FMT>(ctx, a, 1, s);
+            else rc = big ? x3_go<VN_EPI_STORE, 2, 4, FMT>(ctx, a, 1, s) : x3_go<VN_EPI_STORE, 1, 4, FMT>(ctx, a, 1, s);
             done = true;
         }
     }
@@ -810,9 +863,9 @@ static int x3_attrs(vn_ctx* ctx) {
     }
     return rc;
 }
-template <int MI, int ABL>
+template <int MI, int ABL, int FMT = 0>
 static int x3_attrs_abl(vn_ctx* ctx) {
-    return x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_STORE, MI, ABL>, x3_lds_bytes<MI>());
+    return x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_STORE, MI, ABL, FMT>, x3_lds_bytes<MI, FMT ? 2 : 3>());
 }
 
 int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s) {
@@ -839,6 +892,11 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
             (rc = x3_attrs_abl<2, 1>(ctx)) || (rc = x3_attrs_abl<2, 2>(ctx)) || (rc = x3_attrs_abl<2, 3>(ctx)) ||
             (rc = x3_attrs_abl<1, 4>(ctx)) || (rc = x3_attrs_abl<2, 4>(ctx)) || (rc = x3_attrs_abl<3, 1>(ctx)) ||
             (rc = x3_attrs_abl<3, 2>(ctx)) || (rc = x3_attrs_abl<3, 3>(ctx)) || (rc = x3_attrs_abl<3, 4>(ctx)))
+            return rc;
+        if ((rc = x3_attrs_abl<1, 1, 1>(ctx)) || (rc = x3_attrs_abl<1, 2, 1>(ctx)) || (rc = x3_attrs_abl<1, 3, 1>(ctx)) ||
+            (rc = x3_attrs_abl<2, 1, 1>(ctx)) || (rc = x3_attrs_abl<2, 2, 1>(ctx)) || (rc = x3_attrs_abl<2, 3, 1>(ctx)) ||
+            (rc = x3_attrs_abl<3, 1, 1>(ctx)) || (rc = x3_attrs_abl<3, 2, 1>(ctx)) || (rc = x3_attrs_abl<3, 3, 1>(ctx)) ||
+            (rc = x3_attrs_abl<1, 4, 1>(ctx)) || (rc = x3_attrs_abl<2, 4, 1>(ctx)) || (rc = x3_attrs_abl<3, 4, 1>(ctx)))
             return rc;
         ctx->attr_mask |= VN_ATTR_GEMM_X3;
     }
