@@ -6,7 +6,8 @@ synthetic 10 s clips (T = 575 tokens, 14 codebooks) that is already resident in 
 configs[2] ("coarse + c2f full vamp(), batch=8, 10 s clips, typical_filtering=True, 1xMI355X"); with --gpus N each
 GPU keeps 8 clips (weak scaling; N = 8 is configs[3], batch 64 sharded 8-way with one all-gather of the tokens).
 Random-init weights of the real architecture (no checkpoints in this image), device Philox RNG; default precision
-"bf16x3" (fp32-grade GEMMs as six bf16-MFMA products of exact 3-way operand splits; --dtype f32 = fp32-input MFMA).
+"f16x2" (fp32-grade GEMMs as three fp16-MFMA products of two-plane operand splits; --dtype bf16x3 = six bf16-MFMA products of exact
+3-way splits, --dtype f32 = fp32-input MFMA).
 --config 1 = BASELINE configs[1] (coarse model only, batch 1, 12 steps); --config 2 (default) = configs[2].
 
 Prints ONE JSON line on rank 0.
@@ -221,10 +222,10 @@ def main():
     ap.add_argument("--config", type=int, choices=[1, 2], default=2,
                     help="BASELINE.json configs index: 1 = coarse model only, batch 1, 12 sampling steps (= --coarse-only "
                          "--batch-per-gpu 1); 2 (default) = coarse + c2f vamp(), batch 8")
-    ap.add_argument("--dtype", choices=["f32", "bf16x3", "f16x2", "bf16"], default="bf16x3",
-                    help="f16x2 = fp32-grade GEMMs as three fp16-MFMA products of two-plane operand splits (second plane scaled by "
-                         "2^11, second accumulator), same parity bars; "
-                         "bf16x3 (default) = fp32-grade GEMMs as six bf16-MFMA products of exact 3-way operand splits, fp32 "
+    ap.add_argument("--dtype", choices=["f32", "bf16x3", "f16x2", "bf16"], default="f16x2",
+                    help="f16x2 (default) = fp32-grade GEMMs as three fp16-MFMA products of two-plane operand splits (second plane scaled "
+                         "by 2^11, second accumulator), same parity bars as f32; "
+                         "bf16x3 = fp32-grade GEMMs as six bf16-MFMA products of exact 3-way operand splits, fp32 "
                          "accumulate: held to the same parity bars as f32 (tests/test_gpu_bf16x3.py: tokens bit-identical to the "
                          "oracle and the reference's golden tokens); f32 = exact-fp32 MFMA; bf16 = fast mode, not bit-exact")
     ap.add_argument("--workload", choices=["vamp", "train"], default="vamp",
@@ -448,7 +449,7 @@ def main():
             an, ams, afl, _ = prof["attention"]
             # fabric bytes per launch: NOT measured by this run — read from the committed rocprofv3 --pmc passes of this same command
             traffic = traffic_source = None
-            tname = {"f32": "r01_traffic.json", "bf16x3": "r03_traffic_x3.json"}.get(args.dtype, "-")
+            tname = {"f32": "r01_traffic.json", "bf16x3": "r03_traffic_x3.json", "f16x2": "r03_traffic_h2.json"}.get(args.dtype, "-")
             if not os.path.exists(os.path.join(ROOT, "profiles", tname)) and args.dtype == "bf16x3":
                 tname = "r02_traffic_x3.json"
             tpath = os.path.join(ROOT, "profiles", tname)

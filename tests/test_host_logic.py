@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 
+import math
 import numpy as np
 import pytest
 import torch
@@ -340,6 +341,49 @@ def test_bf16x3_split_numerics_on_the_host():
     assert three > 4 * six                                          # the 2^-16 terms matter: ~2e-5
 
 
+def test_f16x2_split_numerics_on_the_host():
+    """The numerics claim behind precision="f16x2" (DESIGN.md §3/§4), checked with torch on the CPU: (1) h0 = fp16(x),
+    h1 = fp16((x - h0) 2^11) reproduce x to 2^-22 |x| over fp16's normal range (round-to-nearest at both levels) and to 2^-25 in
+    absolute terms below it; (2) the three kept products — a0 b0 into one fp32 accumulator, a0 b1 + a1 b0 into a second one that
+    joins times 2^-11 — are as close to the float64 product as an fp32-accumulating fp32 GEMM of the unsplit operands, at every
+    operand magnitude fp16 can hold (no per-tensor scaling); (3) WITHOUT the 2^11 on the second plane small operands lose it to
+    fp16's subnormal range; (4) two products are not enough."""
+    g = torch.Generator().manual_seed(0)
+
+    def split2h(x, scale=2048.0):
+        x = x.clamp(-65504.0, 65504.0)
+        h0 = x.to(torch.float16).to(torch.float32)
+        h1 = ((x - h0) * scale).to(torch.float16).to(torch.float32)
+        return h0, h1
+
+    mag = torch.exp(torch.empty(1 << 14).uniform_(math.log(1e-9), math.log(6e4), generator=g))
+    x = mag * torch.where(torch.rand(1 << 14, generator=g) < 0.5, -1.0, 1.0)
+    h0, h1 = split2h(x)
+    err = (h0.double() + h1.double() / 2048.0 - x.double()).abs()
+    assert torch.all(err <= torch.maximum(x.double().abs() * 2.0 ** -22, torch.tensor(2.0 ** -24, dtype=torch.float64)))
+    assert split2h(torch.tensor([1e6, -3e38]))[0].tolist() == [65504.0, -65504.0]            # saturation, not inf
+    M, N, K = 257, 384, 1280
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+
+    def rms_rel(c, ref):
+        return ((c.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+
+    for a_scale, w_scale in [(1.0, 1.0), (0.02, 1.0), (300.0, 1.0), (1.0, 0.05)]:
+        A = torch.randn(M, K, generator=g) * a_scale
+        Wm = W * w_scale
+        ref = A.double() @ Wm.double().t()
+        e_f32 = rms_rel(A @ Wm.t(), ref)
+        (a0, a1), (w0, w1) = split2h(A), split2h(Wm)
+        three = rms_rel(a0 @ w0.t() + (a0 @ w1.t() + a1 @ w0.t()) * (1.0 / 2048.0), ref)
+        two = rms_rel(a0 @ w0.t() + (a0 @ w1.t()) * (1.0 / 2048.0), ref)
+        assert three <= 1.25 * e_f32 + 2e-8, (a_scale, w_scale, three, e_f32)       # measured: 2.4e-7 vs 2.5e-7 (the fp32 accumulation itself)
+        assert two > 100 * three
+    (a0, a1), (w0, w1) = split2h(torch.randn(M, K, generator=g), 1.0), split2h(W * 0.05, 1.0)       # second plane NOT scaled
+    A = a0 + 0.0
+    plain = rms_rel(a0 @ w0.t() + a0 @ w1.t() + a1 @ w0.t(), (a0 + a1).double() @ (W * 0.05).double().t())
+    assert plain > 2e-6                                             # weights ~ 1e-3: their remainders fall into fp16 subnormals
+
+
 def _click_track(sr, seconds, times, seed=0):
     rng = np.random.default_rng(seed)
     y = 1e-4 * rng.standard_normal(int(sr * seconds)).astype(np.float32)
@@ -657,6 +701,21 @@ def test_tiled_plane_layout_formula():
         rows = min(16, R - r0)
         want[:rows] = planes[1, r0:r0 + rows, k0:k0 + 32]
         assert torch.equal(piece, want)
+
+
+def test_tiled_plane_layout_formula_f16x2():
+    """the same layout with TWO planes per piece group (vn_tiled_off_np(.., 2): f16x2 operands), against the permutation the GPU
+    tests compare Engine.split2h(tiled=True) with"""
+    def tiled_off(row, k, K):
+        return (((row >> 4) * (K >> 5) + (k >> 5)) * 2) * 512 + (row & 15) * 32 + (k & 31)
+
+    for R, K in [(48, 64), (16, 32), (96, 256)]:
+        planes = torch.arange(2 * R * K, dtype=torch.int32).reshape(2, R, K)
+        flat = planes.reshape(2, R // 16, 16, K // 32, 32).permute(1, 3, 0, 2, 4).contiguous().reshape(-1)
+        for q in range(2):
+            for row in sorted({0, 1, 15, min(16, R - 1), R - 1}):
+                for k in sorted({0, 1, 31, min(32, K - 1), K - 1}):
+                    assert int(flat[tiled_off(row, k, K) + 512 * q]) == int(planes[q, row, k]), (R, K, q, row, k)
 
 
 def test_mask_rng_self_check_formulas_hold_on_this_torch():

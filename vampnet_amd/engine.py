@@ -284,7 +284,7 @@ class VampNetModel:
 
     def __init__(self, engine: Engine, sd: dict, codebooks: torch.Tensor, *, n_heads, n_layers, n_codebooks,
                  n_conditioning_codebooks=0, latent_dim=8, embedding_dim=1280, vocab_size=1024,
-                 max_batch=8, max_T=575, chunk_size_s=10, precision="bf16x3", _blob=None, **_ignored):
+                 max_batch=8, max_T=575, chunk_size_s=10, precision="f16x2", _blob=None, **_ignored):
         self.engine = engine
         self.lib = engine.lib
         self.n_heads, self.n_layers = n_heads, n_layers

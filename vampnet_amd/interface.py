@@ -96,7 +96,7 @@ class Interface:
                  coarse2fine_lora_ckpt: str = None, codec_ckpt: str = None,
                  wavebeat_ckpt: str = None, device: str = "cuda:0", coarse_chunk_size_s: int = 10,
                  coarse2fine_chunk_size_s: int = 3, compile=True, *, codec=None, max_batch: int = 8,
-                 rng: str = "torch", process_group=None, precision: str = "bf16x3"):
+                 rng: str = "torch", process_group=None, precision: str = "f16x2"):
         assert codec_ckpt is not None or codec is not None, "must provide a codec checkpoint"
         assert coarse_ckpt is not None, "must provide a coarse checkpoint"
         if codec is None:
@@ -119,7 +119,7 @@ class Interface:
     @classmethod
     def from_state_dicts(cls, codec, coarse_sd, coarse_kwargs, c2f_sd=None, c2f_kwargs=None, device="cuda:0",
                          coarse_chunk_size_s=10, coarse2fine_chunk_size_s=3, max_batch=8, rng="torch",
-                         process_group=None, precision="bf16x3"):
+                         process_group=None, precision="f16x2"):
         """Build from in-memory reference-format state_dicts (what the checkpoints hold)."""
         self = object.__new__(cls)
         self._init(codec, coarse_sd, coarse_kwargs, c2f_sd, c2f_kwargs, device, coarse_chunk_size_s,
@@ -128,7 +128,7 @@ class Interface:
         return self
 
     def _init(self, codec, csd, ckw, fsd, fkw, device, coarse_chunk_s, c2f_chunk_s, max_batch, rng, process_group,
-              precision="bf16x3"):
+              precision="f16x2"):
         self.precision = precision
         self.codec = codec
         self.device = torch.device(device)
