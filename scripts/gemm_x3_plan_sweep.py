@@ -1,5 +1,5 @@
-"""bf16x3 GEMM: every (tile height, k-split) option on the model's shapes, against the by-shape choice of gemm_x3.hip's cost model
-(x3_choose).  Output -> profiles/r02_gemm_x3_plan_sweep.txt."""
+"""gemm_x3.hip, bf16x3 (default) or f16x2 operands (argv[1] = "f16x2"): every (tile height, k-split) option on the model's shapes,
+against the by-shape choice of the kernel's cost model (x3_choose).  Output -> profiles/r0N_gemm_x3_plan_sweep*.txt."""
 import sys
 
 import torch
@@ -9,6 +9,7 @@ from vampnet_amd import _lib
 from vampnet_amd.engine import Engine
 
 eng = Engine("cuda:0")
+H2 = len(sys.argv) > 1 and sys.argv[1] == "f16x2"
 S, R, G, Bi = _lib.EPI_STORE, _lib.EPI_RESIDUAL, _lib.EPI_GEGLU, _lib.EPI_BIAS
 SHAPES = [("qkv  B8 (store proxy)", 4600, 3840, 1280, S), ("wo   B8", 4600, 1280, 1280, R), ("w1g  B8", 4600, 5120, 1280, G),
           ("w2   B8", 4600, 1280, 2560, R), ("cls  B8", 4600, 4096, 1280, Bi),
@@ -37,11 +38,14 @@ for _ in range(20):
     eng.gemm(w, w)
 for name, M, N, K, epi in SHAPES:
     g = torch.Generator(device="cuda").manual_seed(0)
-    a3 = eng.tile3(eng.split3(torch.randn(M, K, device="cuda", generator=g)))          # the model path's tiled operand layout
-    w3 = eng.tile3(eng.split3(torch.randn(N, K, device="cuda", generator=g) / K ** 0.5))
+    a32, w32 = torch.randn(M, K, device="cuda", generator=g), torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    if H2:
+        a3, w3 = eng.split2h(a32, tiled=True), eng.split2h(w32, tiled=True)
+    else:
+        a3, w3 = eng.tile3(eng.split3(a32)), eng.tile3(eng.split3(w32))          # the model path's tiled operand layout
     bias = torch.randn(N, device="cuda", generator=g)
     out = torch.zeros(M, N // 2 if epi == G else N, device="cuda")
-    fn = lambda: eng.gemm_bf16x3(a3, w3, bias=bias if epi == Bi else None, epilogue=epi, out=out, tiled_shape=(M, N, K))
+    fn = lambda: (eng.gemm_f16x2 if H2 else eng.gemm_bf16x3)(a3, w3, bias=bias if epi == Bi else None, epilogue=epi, out=out, tiled_shape=(M, N, K))
     res = []
     for bm in (128, 192, 256):
         if epi == G and bm == 192:

@@ -760,7 +760,7 @@ static bool x3_norm_fusable(const vn_ctx* ctx, const vn_gemm_args& a) {
 // wave tile); one or two sequences keep 128 rows (more tiles) and split the N = 1280 projections.
 struct x3_plan { int bm, ns; };
 template <int EPI>
-static x3_plan x3_choose(const vn_ctx* ctx, const vn_gemm_args& a, int cus, double kt_us = 1.45) {
+static x3_plan x3_choose(const vn_ctx* ctx, const vn_gemm_args& a, int cus, double kt_us = 1.45, double partial = 1.0) {
     const int bm_forced = ctx->tune.x3_bm;                   // 0 = by shape
     const int split_forced = ctx->tune.x3_split == -2 ? -1 : ctx->tune.x3_split;      // 0 / 1 off, 2 / 4 forced, -1 cost model
     constexpr bool can_split = EPI == VN_EPI_STORE || EPI == VN_EPI_RESIDUAL;
@@ -782,6 +782,7 @@ static x3_plan x3_choose(const vn_ctx* ctx, const vn_gemm_args& a, int cus, doub
             }
             if (split_forced > 1 && ns != split_forced && ns != 1) continue;
             double cost = (double)((tiles * ns + cus - 1) / cus) * (nk / (double)ns) * kt_us * rel[hi];
+            if (tiles * ns < cus) cost *= partial;           // a launch that leaves CUs idle runs at a higher clock (f16x2 sweep: x 0.8)
             if (ns > 1) {
                 cost += (ns + (residual ? 2 : 1)) * 4.0 * a.M * (double)a.N / 3.5e6;
                 if (residual && x3_norm_fusable(ctx, a)) cost -= 4.0 * a.M * (double)a.N / 3.5e6 + 1.5;
@@ -801,7 +802,8 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
     // algorithmic (fp32-equivalent) flops; the codec's convolutions are booked under class 2 like conv1d_f32.hip's
     const int pi = vn_prof_pre(ctx, EPI == VN_EPI_CONV ? 2 : 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);
     int rc = VN_OK;
-    const x3_plan plan = x3_choose<EPI>(ctx, a, vn_num_cus(ctx), FMT ? 0.85 : 1.45);
+    // f16x2: half the matrix work per k-tile (profiles/r03_gemm_f16x2_plan_sweep.txt)
+    const x3_plan plan = FMT ? x3_choose<EPI>(ctx, a, vn_num_cus(ctx), 0.85, 0.8) : x3_choose<EPI>(ctx, a, vn_num_cus(ctx));
     const int bm = plan.bm;
     bool done = false;
     if constexpr (EPI == VN_EPI_STORE) {
