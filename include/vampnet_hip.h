@@ -234,6 +234,10 @@ int vn_gemm_f16x2(vn_ctx* ctx, const void* A2, int64_t a_plane, const void* W2, 
  * splits, fp32 softmax): same arguments and output as vn_attention_f32.                                                  */
 int vn_attention_bf16x3(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
                         float* out, int B, int H, int T, int num_buckets, int max_distance, void* stream);
+/* ... and in the f16x2 precision: q / 8, k and 16 v as fp16 two-plane splits (h0 = fp16(x), h1 = fp16(x - h0)), the softmax weights
+ * (times 16) split the same way in registers, THREE fp16-MFMA products per step into the one accumulator (attention_x3.hip, NP = 2). */
+int vn_attention_f16x2(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                       float* out, int B, int H, int T, int num_buckets, int max_distance, void* stream);
 
 /* Self-attention core (transformer.py:229-254): q,k,v dev f32 [B][H][T][64];
  * rel_bias dev f32 [num_buckets][H]; out dev f32 [B][T][H*64].                                */

@@ -33,7 +33,8 @@ int vn_debug_x3_fuse_norm(vn_ctx* ctx, int on);
  * apart) of RMSNorm(x) with weight w; fused != 0 = one kernel, 0 = reduce kernel then norm kernel                      */
 int vn_debug_splitk_reduce_rmsnorm(vn_ctx* ctx, const float* partial, int nsplit, float* x, const float* w, void* y16,
                                    int64_t plane16, int rows, int D, float eps, int fused, void* stream);
-/* average duration (us) of `iters` launches of the bf16x3 attention kernel alone (planes prepared outside the timed region) */
+/* average duration (us) of `iters` launches of the bf16x3 attention kernel alone (planes prepared outside the timed region);
+ * iters < 0: -iters launches on the f16x2 precision's fp16 two-plane operands                                                  */
 int vn_debug_attention_x3_time(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias, float* out,
                                int B, int H, int T, int iters, float* avg_us, void* stream);
 /* bf16x3 attention (attention_x3.hip; scripts/attn_probe.py): split = work decomposition (-1 by shape, 0 = 128-query blocks that

@@ -125,7 +125,8 @@ def _attention_ref(q, k, v, table):
 # attention_x3.hip has two work decompositions: 128-query blocks that share their K / V^T tiles ("x3/shared") and 32-query blocks
 # whose KS waves walk disjoint key tiles and merge through LDS ("x3/ks1", "x3/ks2", "x3/ks4"); "bf16x3" = the launcher's own choice
 ATTN_FORMS = {"f32": ("f32", None), "bf16x3": ("bf16x3", -1), "x3/shared": ("bf16x3", 0), "x3/ks1": ("bf16x3", 1),
-              "x3/ks2": ("bf16x3", 2), "x3/ks4": ("bf16x3", 4)}
+              "x3/ks2": ("bf16x3", 2), "x3/ks4": ("bf16x3", 4),
+              "f16x2": ("f16x2", -1), "h2/shared": ("f16x2", 0), "h2/ks1": ("f16x2", 1), "h2/ks2": ("f16x2", 2), "h2/ks4": ("f16x2", 4)}
 
 
 def _attention(eng, form, q, k, v, table):
@@ -161,13 +162,17 @@ def test_attention_x3_decompositions_agree(eng):
     q, k, v = (_rand((B, H, T, 64), s).cuda() for s in (40, 41, 42))
     table = _rand((32, H), 43).cuda()
     outs = {}
-    for form in ("x3/shared", "x3/ks1", "x3/ks2", "x3/ks4"):
-        outs[form] = _attention(eng, form, q, k, v, table)
-        assert torch.equal(outs[form], _attention(eng, form, q, k, v, table)), form
-    for form in ("x3/ks1", "x3/ks2", "x3/ks4"):
-        d = (outs[form] - outs["x3/shared"]).abs().max().item()
-        print(f"{form} vs shared tiles: max |d| = {d:.3e}")
-        assert d < 2e-6
+    for fam in ("x3", "h2"):
+        for form in (f"{fam}/shared", f"{fam}/ks1", f"{fam}/ks2", f"{fam}/ks4"):
+            outs[form] = _attention(eng, form, q, k, v, table)
+            assert torch.equal(outs[form], _attention(eng, form, q, k, v, table)), form
+        for form in (f"{fam}/ks1", f"{fam}/ks2", f"{fam}/ks4"):
+            d = (outs[form] - outs[f"{fam}/shared"]).abs().max().item()
+            print(f"{form} vs shared tiles: max |d| = {d:.3e}")
+            assert d < 2e-6
+    d = (outs["h2/shared"] - outs["x3/shared"]).abs().max().item()
+    print(f"f16x2 vs bf16x3 operands, shared tiles: max |d| = {d:.3e}")
+    assert d < 4e-6
 
 
 def test_attention_bf16x3_forced_rescale_and_large_scores(eng):
@@ -193,7 +198,7 @@ def test_attention_bf16x3_forced_rescale_and_large_scores(eng):
         assert err < 2e-5
 
 
-@pytest.mark.parametrize("form", ["f32", "x3/shared", "x3/ks2"])
+@pytest.mark.parametrize("form", ["f32", "x3/shared", "x3/ks2", "h2/shared", "h2/ks2"])
 def test_attention_bias_buckets_exact(eng, form):
     """q = 0 -> scores are the bias alone; v = one-hot(position) -> output row = softmax(bias) itself,
     which pins every bucket boundary (rel = -574..574) against the oracle table."""

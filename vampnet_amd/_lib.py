@@ -113,6 +113,7 @@ SYMBOLS = {
     "vn_debug_attention_x3_config": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "vn_attention_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vn_attention_bf16x3": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "vn_attention_f16x2": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vn_attention_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
 }
 

@@ -55,7 +55,19 @@
 
 #define AX_KT 32                          // keys per tile
 #define AX_PLANE_FLOATS 1024              // one plane tile of K (32 x 128 B) or V^T (64 x 64 B): 4 KiB
-#define AX_STAGE_FLOATS (6 * AX_PLANE_FLOATS)
+// NP = planes per operand: 3 = bf16x3 (exact three-way bf16 split, six products), 2 = the f16x2 precision's attention format (two fp16
+// planes, second one unscaled, three products into the same accumulator; P and V carry a factor 16 each — vn_common.h vn_split2u).
+// A stage = NP K plane tiles then NP V^T plane tiles.
+#define AX_STAGE_FLOATS_NP(NP) (2 * (NP) * AX_PLANE_FLOATS)
+template <int NP>
+__device__ __forceinline__ f32x16 ax_mfma(const f32x4& a, const f32x4& b, const f32x16& c) {
+    if constexpr (NP == 3) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// the kept plane products (A-operand plane, B-operand plane), smallest terms first
+template <int NP> __device__ __forceinline__ constexpr int ax_nprod() { return NP == 3 ? 6 : 3; }
+template <int NP> __device__ __forceinline__ constexpr int ax_pa(int t) { return NP == 3 ? (t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0) : (t == 1 ? 1 : 0); }
+template <int NP> __device__ __forceinline__ constexpr int ax_pb(int t) { return NP == 3 ? (t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0) : (t == 0 ? 1 : 0); }
 // raw barrier (no implied vmcnt(0): LDS-DMA stays in flight across it); the asm fences keep hipcc from moving LDS accesses over it
 #define AX_RAW_BARRIER()                          \
     do {                                          \
@@ -117,8 +129,8 @@ __device__ __forceinline__ void ax_bias_init(f32x16& sacc, const float* bt, int 
 // DUAL: the 24 MFMAs of a tile all accumulate into sacc — one dependent chain, each link waiting for the previous result.  With
 // three waves per SIMD (the shared-tile kernel) other waves fill those gaps; a key-split block runs one or two waves per SIMD, so it
 // accumulates odd d steps in a second accumulator (two interleaved chains) and adds the two once (16 VALU adds, +16 VGPRs).
-template <bool DUAL = false>
-__device__ __forceinline__ void ax_qk(f32x16& sacc, const float* Ks, const bf16x8 (&qf)[3][4], const ax_lane& L) {
+template <int NP, bool DUAL = false>
+__device__ __forceinline__ void ax_qk(f32x16& sacc, const float* Ks, const f32x4 (&qf)[NP][4], const ax_lane& L) {
     f32x16 sacc2;
     if constexpr (DUAL) {
 #pragma unroll
@@ -127,39 +139,27 @@ __device__ __forceinline__ void ax_qk(f32x16& sacc, const float* Ks, const bf16x
     if constexpr (!DUAL) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            bf16x8 kf[3];
+            f32x4 kf[NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                kf[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Ks + p * AX_PLANE_FLOATS + L.kOff + ((2 * s + L.hh) ^ L.kSw) * 4));
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[2][s], sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[0][s], sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[1][s], sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[1][s], sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[0][s], sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][s], sacc, 0, 0, 0);
+            for (int p = 0; p < NP; ++p) kf[p] = *(const f32x4*)(Ks + p * AX_PLANE_FLOATS + L.kOff + ((2 * s + L.hh) ^ L.kSw) * 4);
+#pragma unroll
+            for (int t = 0; t < ax_nprod<NP>(); ++t) sacc = ax_mfma<NP>(kf[ax_pa<NP>(t)], qf[ax_pb<NP>(t)][s], sacc);
         }
     } else {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {                    // d steps 2 s2 (-> sacc) and 2 s2 + 1 (-> sacc2), MFMAs alternating
-            bf16x8 ka[3], kb[3];
+            f32x4 ka[NP], kb[NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                ka[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Ks + p * AX_PLANE_FLOATS + L.kOff + ((4 * s2 + L.hh) ^ L.kSw) * 4));
-                kb[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Ks + p * AX_PLANE_FLOATS + L.kOff + ((4 * s2 + 2 + L.hh) ^ L.kSw) * 4));
+            for (int p = 0; p < NP; ++p) {
+                ka[p] = *(const f32x4*)(Ks + p * AX_PLANE_FLOATS + L.kOff + ((4 * s2 + L.hh) ^ L.kSw) * 4);
+                kb[p] = *(const f32x4*)(Ks + p * AX_PLANE_FLOATS + L.kOff + ((4 * s2 + 2 + L.hh) ^ L.kSw) * 4);
             }
             const int sa = 2 * s2, sb = 2 * s2 + 1;
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0], qf[2][sa], sacc, 0, 0, 0);
-            sacc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[0], qf[2][sb], sacc2, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[2], qf[0][sa], sacc, 0, 0, 0);
-            sacc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[2], qf[0][sb], sacc2, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[1], qf[1][sa], sacc, 0, 0, 0);
-            sacc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[1], qf[1][sb], sacc2, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0], qf[1][sa], sacc, 0, 0, 0);
-            sacc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[0], qf[1][sb], sacc2, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[1], qf[0][sa], sacc, 0, 0, 0);
-            sacc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[1], qf[0][sb], sacc2, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0], qf[0][sa], sacc, 0, 0, 0);
-            sacc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[0], qf[0][sb], sacc2, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < ax_nprod<NP>(); ++t) {
+                sacc = ax_mfma<NP>(ka[ax_pa<NP>(t)], qf[ax_pb<NP>(t)][sa], sacc);
+                sacc2 = ax_mfma<NP>(kb[ax_pa<NP>(t)], qf[ax_pb<NP>(t)][sb], sacc2);
+            }
         }
         sacc += sacc2;
     }
@@ -169,8 +169,8 @@ __device__ __forceinline__ void ax_qk(f32x16& sacc, const float* Ks, const bf16x
 // `full` (uniform): every key of the tile belongs to the item.  Only the masking and the clamp inside exp differ between the two
 // cases; the rescale branch and the MFMA phases around this function exist ONCE (two whole copies of the tile code made the
 // register allocator keep two images of O: +32 VGPRs and 32 moves per tile).
-template <bool FULL>
-__device__ __forceinline__ float ax_probs(const f32x16& sacc, bf16x8 (&pf)[3][2], float m_run) {
+template <int NP, bool FULL>
+__device__ __forceinline__ float ax_probs(const f32x16& sacc, f32x4 (&pf)[NP][2], float m_run) {
     float lsum = 0.f;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -180,11 +180,20 @@ __device__ __forceinline__ float ax_probs(const f32x16& sacc, bf16x8 (&pf)[3][2]
             pe[e] = ax_exp<FULL>(sacc[8 * s + e] - m_run);
             lsum += pe[e];
         }
-        vn_split3_x8(pe, pf[0][s], pf[1][s], pf[2][s]);
+        if constexpr (NP == 3) {
+            bf16x8 p0, p1, p2;
+            vn_split3_x8(pe, p0, p1, p2);
+            pf[0][s] = __builtin_bit_cast(f32x4, p0); pf[1][s] = __builtin_bit_cast(f32x4, p1); pf[2][s] = __builtin_bit_cast(f32x4, p2);
+        } else {
+            f16x8 p0, p1;
+            vn_split2u_x8(pe * 16.0f, p0, p1);              // <= 16 e^AX_THR < 6.5e3
+            pf[0][s] = __builtin_bit_cast(f32x4, p0); pf[1][s] = __builtin_bit_cast(f32x4, p1);
+        }
     }
     return lsum;
 }
-__device__ __forceinline__ void ax_softmax(f32x16& sacc, bf16x8 (&pf)[3][2], float& m_run, float& l_run, f32x16 (&o)[2], int key0,
+template <int NP>
+__device__ __forceinline__ void ax_softmax(f32x16& sacc, f32x4 (&pf)[NP][2], float& m_run, float& l_run, f32x16 (&o)[2], int key0,
                                            int hh, int T, bool full) {
     if (!full) {                                            // first / last tile: the neighbours' tokens are masked out
 #pragma unroll
@@ -207,64 +216,53 @@ __device__ __forceinline__ void ax_softmax(f32x16& sacc, bf16x8 (&pf)[3][2], flo
         l_run *= alpha;
         m_run = m_new;
     }
-    l_run += full ? ax_probs<true>(sacc, pf, m_run) : ax_probs<false>(sacc, pf, m_run);
+    l_run += full ? ax_probs<NP, true>(sacc, pf, m_run) : ax_probs<NP, false>(sacc, pf, m_run);
 }
 
 // O^T += V^T . P^T for the V^T tile at Vs: two 32-row d tiles x two 16-key steps x six plane products.
 // ILV: the MFMAs of the two d tiles alternate (two independent chains in flight instead of six dependent MFMAs in a row) —
 // for the key-split blocks, as above; costs the second tile's V^T fragments live at the same time (+12 VGPRs).
-template <bool ILV = false>
-__device__ __forceinline__ void ax_pv(f32x16 (&o)[2], const float* Vs, const bf16x8 (&pf)[3][2], const ax_lane& L) {
+template <int NP, bool ILV = false>
+__device__ __forceinline__ void ax_pv(f32x16 (&o)[2], const float* Vs, const f32x4 (&pf)[NP][2], const ax_lane& L) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         if constexpr (!ILV) {
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                bf16x8 vf[3];
+                f32x4 vf[NP];
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    vf[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Vs + p * AX_PLANE_FLOATS + (32 * dt + L.l31) * 16 + ((2 * s + L.hh) ^ L.vSw) * 4));
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[2][s], o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], pf[0][s], o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf[1][s], o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[1][s], o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf[0][s], o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[0][s], o[dt], 0, 0, 0);
+                for (int p = 0; p < NP; ++p) vf[p] = *(const f32x4*)(Vs + p * AX_PLANE_FLOATS + (32 * dt + L.l31) * 16 + ((2 * s + L.hh) ^ L.vSw) * 4);
+#pragma unroll
+                for (int t = 0; t < ax_nprod<NP>(); ++t) o[dt] = ax_mfma<NP>(vf[ax_pa<NP>(t)], pf[ax_pb<NP>(t)][s], o[dt]);
             }
         } else {
-            bf16x8 va[3], vb[3];
+            f32x4 va[NP], vb[NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                va[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Vs + p * AX_PLANE_FLOATS + L.l31 * 16 + ((2 * s + L.hh) ^ L.vSw) * 4));
-                vb[p] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Vs + p * AX_PLANE_FLOATS + (32 + L.l31) * 16 + ((2 * s + L.hh) ^ L.vSw) * 4));
+            for (int p = 0; p < NP; ++p) {
+                va[p] = *(const f32x4*)(Vs + p * AX_PLANE_FLOATS + L.l31 * 16 + ((2 * s + L.hh) ^ L.vSw) * 4);
+                vb[p] = *(const f32x4*)(Vs + p * AX_PLANE_FLOATS + (32 + L.l31) * 16 + ((2 * s + L.hh) ^ L.vSw) * 4);
             }
-            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0], pf[2][s], o[0], 0, 0, 0);
-            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[0], pf[2][s], o[1], 0, 0, 0);
-            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2], pf[0][s], o[0], 0, 0, 0);
-            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[2], pf[0][s], o[1], 0, 0, 0);
-            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1], pf[1][s], o[0], 0, 0, 0);
-            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[1], pf[1][s], o[1], 0, 0, 0);
-            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0], pf[1][s], o[0], 0, 0, 0);
-            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[0], pf[1][s], o[1], 0, 0, 0);
-            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1], pf[0][s], o[0], 0, 0, 0);
-            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[1], pf[0][s], o[1], 0, 0, 0);
-            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0], pf[0][s], o[0], 0, 0, 0);
-            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[0], pf[0][s], o[1], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < ax_nprod<NP>(); ++t) {
+                o[0] = ax_mfma<NP>(va[ax_pa<NP>(t)], pf[ax_pb<NP>(t)][s], o[0]);
+                o[1] = ax_mfma<NP>(vb[ax_pa<NP>(t)], pf[ax_pb<NP>(t)][s], o[1]);
+            }
         }
     }
 }
 
 // one tile of the main loop from LDS images of K and V^T
-__device__ __forceinline__ void ax_tile(const float* Ks, const float* Vs, const float* bt, const bf16x8 (&qf)[3][4], const ax_lane& L,
+template <int NP>
+__device__ __forceinline__ void ax_tile(const float* Ks, const float* Vs, const float* bt, const f32x4 (&qf)[NP][4], const ax_lane& L,
                                         float& m_run, float& l_run, f32x16 (&o)[2], int key0, int qrow_c, int T) {
     const bool full = key0 >= 0 && key0 + AX_KT <= T;      // uniform
     f32x16 sacc;
-    bf16x8 pf[3][2];
+    f32x4 pf[NP][2];
     if (full) ax_bias_init<true>(sacc, bt, key0, L.hh, qrow_c, T);
     else ax_bias_init<false>(sacc, bt, key0, L.hh, qrow_c, T);
-    ax_qk(sacc, Ks, qf, L);
-    ax_softmax(sacc, pf, m_run, l_run, o, key0, L.hh, T, full);
-    ax_pv(o, Vs, pf, L);
+    ax_qk<NP>(sacc, Ks, qf, L);
+    ax_softmax<NP>(sacc, pf, m_run, l_run, o, key0, L.hh, T, full);
+    ax_pv<NP>(o, Vs, pf, L);
 }
 
 // LDS-DMA sources as buffer loads: descriptors over the k planes and the V^T planes, byte offsets of this block's tile 0 in plane 0
@@ -303,12 +301,12 @@ __device__ __forceinline__ int ax_walk(int bid, int nwg) {
 }
 
 // Q fragments (B operand of S^T = K Q^T): lane (j, hh) holds Q[q_j][16 step + 8 hh .. + 7] of every plane
-__device__ __forceinline__ void ax_load_q(bf16x8 (&qf)[3][4], const uint16_t* Qp, long plane_qk, int qrow_c, int hh) {
+template <int NP>
+__device__ __forceinline__ void ax_load_q(f32x4 (&qf)[NP][4], const uint16_t* Qp, long plane_qk, int qrow_c, int hh) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            qf[p][s] = __builtin_bit_cast(bf16x8, *(const f32x4*)(Qp + (size_t)p * plane_qk + (size_t)qrow_c * VN_DHEAD + 16 * s + 8 * hh));
+        for (int s = 0; s < 4; ++s) qf[p][s] = *(const f32x4*)(Qp + (size_t)p * plane_qk + (size_t)qrow_c * VN_DHEAD + 16 * s + 8 * hh);
 }
 
 // normalise and store the 4-column group g of d tile dt of query row qrow:  o[dt][4 g ..] = O[q][32 dt + 8 g + 4 hh ..]
@@ -324,14 +322,15 @@ __device__ __forceinline__ void ax_store4(const f32x4& acc, float l_tot, float* 
 // ---- shared-tile kernel: block = 4 waves x 32 queries of one (b, h), K / V^T tiles double-buffered for the whole block --------
 // TRACE (tuning): wave 0 of EVERY block writes trace[blockIdx][8] = {wait, barrier, dma issue, tile math (s_memtime deltas summed
 // over the tiles; full role only), entry time, exit time (low 32 bits of s_memtime), XCC id, HW_ID} — the launch's timeline.
-template <int NW, bool TRACE = false>
+template <int NW, bool TRACE = false, int NP = 3>
 __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
                                                                     long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
                                                                     const float* __restrict__ bias_full, float* __restrict__ out,
                                                                     uint16_t* __restrict__ out16, long plane16, int B, int H, int T,
                                                                     int stagger, unsigned* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* bt = smem + 2 * AX_STAGE_FLOATS;
+    constexpr int AXS = AX_STAGE_FLOATS_NP(NP);          // floats of one stage: NP K plane tiles, then NP V^T plane tiles
+    float* bt = smem + 2 * AXS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const ax_lane L = ax_lane_init(lane);
@@ -384,8 +383,8 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
     const int nb = 2 * T - 1;
     for (int i = tid; i < nb; i += NW * 64) bt[i] = bias_full[(size_t)h * nb + i];
 
-    bf16x8 qf[3][4];
-    ax_load_q(qf, Qp, plane_qk, qrow_c, L.hh);
+    f32x4 qf[NP][4];
+    ax_load_q<NP>(qf, Qp, plane_qk, qrow_c, L.hh);
 
     // LDS-DMA: 24 wave-instructions of 1 KiB per stage (K: 3 planes x 4, each 8 rows x 128 B; V^T: 3 planes x 4, each 16 rows x 64 B);
     // wave w issues piece w of every plane tile, as buffer loads: descriptor (SGPRs) + ONE per-lane byte offset per operand that
@@ -401,11 +400,11 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
     const ax_src src = ax_src_init(k16, vt16, plane_qk, plane_vt, b, h, H, T, m_lo, g_lo, MT);
     auto stage = [&](int buf, int kt) {                       // tile kt -> stage buf
         if (kt >= NT) return;
-        float* base = smem + buf * AX_STAGE_FLOATS + wave * 256;
+        float* base = smem + buf * AXS + wave * 256;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
             ax_dma(src.krs, base + (4 * p) * 256, kvoff, src.k0 + p * src.kplane + kt * (AX_KT * VN_DHEAD * 2));
-            ax_dma(src.vrs, base + (12 + 4 * p) * 256, vvoff, src.v0 + p * src.vplane + kt * (VN_DHEAD * AX_KT * 2));
+            ax_dma(src.vrs, base + (4 * NP + 4 * p) * 256, vvoff, src.v0 + p * src.vplane + kt * (VN_DHEAD * AX_KT * 2));
         }
     };
 
@@ -437,44 +436,50 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
             kt0 = kt0 < NT ? kt0 : NT - 1;
             kt1 = kt1 < NT ? kt1 : NT - 1;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                float* d0 = smem + wave * 256 + (v_op ? 12 + 4 * p : 4 * p) * 256;
+            for (int p = 0; p < NP; ++p) {
+                float* d0 = smem + wave * 256 + (v_op ? 4 * NP + 4 * p : 4 * p) * 256;
                 if (v_op) {
                     ax_dma(src.vrs, d0, vvoff, src.v0 + p * src.vplane + kt0 * (VN_DHEAD * AX_KT * 2));
-                    ax_dma(src.vrs, d0 + AX_STAGE_FLOATS, vvoff, src.v0 + p * src.vplane + kt1 * (VN_DHEAD * AX_KT * 2));
+                    ax_dma(src.vrs, d0 + AXS, vvoff, src.v0 + p * src.vplane + kt1 * (VN_DHEAD * AX_KT * 2));
                 } else {
                     ax_dma(src.krs, d0, kvoff, src.k0 + p * src.kplane + kt0 * (AX_KT * VN_DHEAD * 2));
-                    ax_dma(src.krs, d0 + AX_STAGE_FLOATS, kvoff, src.k0 + p * src.kplane + kt1 * (AX_KT * VN_DHEAD * 2));
+                    ax_dma(src.krs, d0 + AXS, kvoff, src.k0 + p * src.kplane + kt1 * (AX_KT * VN_DHEAD * 2));
                 }
             }
         };
         stage_op(0, NH, false);
         stage_op(0, NH, true);
-        const float* Ks = smem + kh * AX_STAGE_FLOATS;
-        const float* Vs = Ks + 3 * AX_PLANE_FLOATS;
+        const float* Ks = smem + kh * AXS;
+        const float* Vs = Ks + NP * AX_PLANE_FLOATS;
         for (int i = 0; i < NH; ++i) {
             const int kt = kh ? NH + i : i;
             const bool valid = active && kt < NT, more = i + 1 < NH;
             const int key0 = (g_lo + kt) * AX_KT - m_lo;
             const bool full = key0 >= 0 && key0 + AX_KT <= T;
             f32x16 sacc;
-            bf16x8 pf[3][2];
-            // this wave's K pieces of the iteration landed (V^T may still fly); lgkmcnt: first time round, its part of the bias table
-            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            f32x4 pf[NP][2];
+            // this wave's K pieces of the iteration landed (V^T may still fly: 2 NP pieces); lgkmcnt: first time round, its part of the
+            // bias table
+            if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             AX_RAW_BARRIER();
             if (valid) {
                 if (full) ax_bias_init<true>(sacc, bt, key0, L.hh, qrow_c, T);
                 else ax_bias_init<false>(sacc, bt, key0, L.hh, qrow_c, T);
-                ax_qk(sacc, Ks, qf, L);
+                ax_qk<NP>(sacc, Ks, qf, L);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             AX_RAW_BARRIER();                                        // both K stages have been read by everybody
             if (more) stage_op(i + 1, NH + i + 1, false);
-            if (valid) ax_softmax(sacc, pf, m_run, l_run, o, key0, L.hh, T, full);
-            if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // V^T of this iteration landed (the next K flies)
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (valid) ax_softmax<NP>(sacc, pf, m_run, l_run, o, key0, L.hh, T, full);
+            if (more) {                                                      // V^T of this iteration landed (the next K flies)
+                if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             AX_RAW_BARRIER();
-            if (valid) ax_pv(o, Vs, pf, L);
+            if (valid) ax_pv<NP>(o, Vs, pf, L);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             AX_RAW_BARRIER();                                        // both V^T stages have been read
             if (more) stage_op(i + 1, NH + i + 1, true);
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
         const float m_all = fmaxf(m0, m1);
         const float s0 = vn_exp_neg(m0 - m_all), s1 = vn_exp_neg(m1 - m_all);      // a half without tiles holds m = -inf, l = 0
         const float l_all = im0[2112 + lane] * s0 + im1[2112 + lane] * s1;
-        const float l_tot = l_all + __shfl_xor(l_all, 32);
+        const float l_tot = (l_all + __shfl_xor(l_all, 32)) * (NP == 2 ? 256.0f : 1.0f);       // f16: P and V carry 16 each
         if (active && qrow < T) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -533,12 +538,12 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
         stage((kt + 1) & 1, kt + 1);
         tick(2);
         if (!active) continue;
-        const float* St = smem + (kt & 1) * AX_STAGE_FLOATS;
-        ax_tile(St, St + 3 * AX_PLANE_FLOATS, bt, qf, L, m_run, l_run, o, (g_lo + kt) * AX_KT - m_lo, qrow_c, T);
+        const float* St = smem + (kt & 1) * AXS;
+        ax_tile<NP>(St, St + NP * AX_PLANE_FLOATS, bt, qf, L, m_run, l_run, o, (g_lo + kt) * AX_KT - m_lo, qrow_c, T);
         tick(3);
     }
     // ---- finish: the two lanes of a query add their row sums; normalise; store
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_tot = (l_run + __shfl_xor(l_run, 32)) * (NP == 2 ? 256.0f : 1.0f);
     if (active && qrow < T) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -557,14 +562,15 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
 // softmax; vmcnt counts this wave's own pieces in issue order, so no barrier is needed), then the bias table.  After the loop every
 // wave leaves (m, l, O) in its stage, and after ONE barrier wave w merges 8 / KS of the eight 4-column groups in the fixed order
 // w' = 0 .. KS - 1 (deterministic), normalises and stores them.
-template <int KS>
+template <int KS, int NP = 3>
 __global__ __launch_bounds__(KS * 64, 2) void vn_attention_x3_split_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
                                                                           long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
                                                                           const float* __restrict__ bias_full, float* __restrict__ out,
                                                                           uint16_t* __restrict__ out16, long plane16, int B, int H, int T) {
     static_assert(KS == 1 || KS == 2 || KS == 4, "the merge hands 8 / KS column groups to every wave");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* bt = smem + KS * AX_STAGE_FLOATS;
+    constexpr int AXS = AX_STAGE_FLOATS_NP(NP);
+    float* bt = smem + KS * AXS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const ax_lane L = ax_lane_init(lane);
@@ -582,8 +588,8 @@ __global__ __launch_bounds__(KS * 64, 2) void vn_attention_x3_split_kernel(const
     const int nb = 2 * T - 1;
     for (int i = tid; i < nb; i += KS * 64) bt[i] = bias_full[(size_t)h * nb + i];
 
-    bf16x8 qf[3][4];
-    ax_load_q(qf, Qp, plane_qk, qrow_c, L.hh);
+    f32x4 qf[NP][4];
+    ax_load_q<NP>(qf, Qp, plane_qk, qrow_c, L.hh);
 
     // this wave stages whole tiles: pieces w' = 0..3 of every plane.  K piece w' = rows 8 w' .. + 7: the swizzle key ((row >> 1) & 7)
     // = (4 w' + (lane >> 4)) & 7 differs between even and odd w', so two per-lane offsets; V^T piece w' = rows 16 w' .. + 15:
@@ -593,10 +599,10 @@ __global__ __launch_bounds__(KS * 64, 2) void vn_attention_x3_split_kernel(const
     const unsigned kvoff_o = (unsigned)(kr0 * VN_DHEAD + ((lane & 7) ^ (((kr0 >> 1) + 4) & 7)) * 8) * 2u;
     const unsigned vvoff = (unsigned)(vr0 * AX_KT + ((lane & 3) ^ ((vr0 >> 2) & 3)) * 8) * 2u;
     const ax_src src = ax_src_init(k16, vt16, plane_qk, plane_vt, b, h, H, T, m_lo, g_lo, MT);
-    float* mine = smem + wave * AX_STAGE_FLOATS;
+    float* mine = smem + wave * AXS;
     auto stage_k = [&](int kt) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const unsigned so = src.k0 + p * src.kplane + kt * (AX_KT * VN_DHEAD * 2);
             float* dst = mine + (4 * p) * 256;               // the instruction offset moves BOTH the source and the LDS address
             ax_dma<0>(src.krs, dst, kvoff_e, so);
@@ -607,9 +613,9 @@ __global__ __launch_bounds__(KS * 64, 2) void vn_attention_x3_split_kernel(const
     };
     auto stage_v = [&](int kt) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const unsigned so = src.v0 + p * src.vplane + kt * (VN_DHEAD * AX_KT * 2);
-            float* dst = mine + (12 + 4 * p) * 256;
+            float* dst = mine + (4 * NP + 4 * p) * 256;
             ax_dma<0>(src.vrs, dst, vvoff, so);
             ax_dma<1024>(src.vrs, dst, vvoff, so);
             ax_dma<2048>(src.vrs, dst, vvoff, so);
@@ -627,24 +633,30 @@ __global__ __launch_bounds__(KS * 64, 2) void vn_attention_x3_split_kernel(const
     if (wave < NT) { stage_k(wave); stage_v(wave); }
     __syncthreads();                                            // the bias table is complete
     const float* Ks = mine;
-    const float* Vs = mine + 3 * AX_PLANE_FLOATS;
+    const float* Vs = mine + NP * AX_PLANE_FLOATS;
     for (int kt = wave; kt < NT; kt += KS) {
         const int key0 = (g_lo + kt) * AX_KT - m_lo;
         const bool full = key0 >= 0 && key0 + AX_KT <= T;
         const bool more = kt + KS < NT;
         f32x16 sacc;
-        bf16x8 pf[3][2];
+        f32x4 pf[NP][2];
         if (full) ax_bias_init<true>(sacc, bt, key0, L.hh, qrow_c, T);
         else ax_bias_init<false>(sacc, bt, key0, L.hh, qrow_c, T);
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // K of this tile landed (its V^T pieces may still fly)
-        ax_qk<true>(sacc, Ks, qf, L);
+        // K of this tile landed (its 4 NP V^T pieces may still fly)
+        if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        ax_qk<NP, true>(sacc, Ks, qf, L);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every K fragment has been read: the K stage is free
         __builtin_amdgcn_sched_barrier(0);
         if (more) stage_k(kt + KS);
-        ax_softmax(sacc, pf, m_run, l_run, o, key0, L.hh, T, full);
-        if (more) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // V^T of this tile landed (the next K flies)
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ax_pv<true>(o, Vs, pf, L);
+        ax_softmax<NP>(sacc, pf, m_run, l_run, o, key0, L.hh, T, full);
+        if (more) {                                             // V^T of this tile landed (the next K flies)
+            if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        ax_pv<NP, true>(o, Vs, pf, L);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (more) stage_v(kt + KS);
@@ -662,26 +674,26 @@ __global__ __launch_bounds__(KS * 64, 2) void vn_attention_x3_split_kernel(const
         __syncthreads();
         float m_all = -INFINITY;
 #pragma unroll
-        for (int w = 0; w < KS; ++w) m_all = fmaxf(m_all, smem[w * AX_STAGE_FLOATS + 2048 + lane]);
+        for (int w = 0; w < KS; ++w) m_all = fmaxf(m_all, smem[w * AXS + 2048 + lane]);
         float sc[KS], l_all = 0.f;
 #pragma unroll
         for (int w = 0; w < KS; ++w) {                          // a wave without tiles holds m = -inf, l = 0: scale 0
-            sc[w] = vn_exp_neg(smem[w * AX_STAGE_FLOATS + 2048 + lane] - m_all);
-            l_all += smem[w * AX_STAGE_FLOATS + 2112 + lane] * sc[w];
+            sc[w] = vn_exp_neg(smem[w * AXS + 2048 + lane] - m_all);
+            l_all += smem[w * AXS + 2112 + lane] * sc[w];
         }
-        const float l_tot = l_all + __shfl_xor(l_all, 32);
+        const float l_tot = (l_all + __shfl_xor(l_all, 32)) * (NP == 2 ? 256.0f : 1.0f);       // f16: P and V carry 16 each
         if (qrow < T) {
 #pragma unroll
             for (int i = 0; i < 8 / KS; ++i) {
                 const int G = wave * (8 / KS) + i;              // uniform
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int w = 0; w < KS; ++w) a += *(const f32x4*)(smem + w * AX_STAGE_FLOATS + (G * 64 + lane) * 4) * sc[w];
+                for (int w = 0; w < KS; ++w) a += *(const f32x4*)(smem + w * AXS + (G * 64 + lane) * 4) * sc[w];
                 ax_store4(a, l_tot, out, out16, plane16, (long)b * T + qrow, h, H, L.hh, G >> 2, G & 3);
             }
         }
     } else {
-        const float l_tot = l_run + __shfl_xor(l_run, 32);
+        const float l_tot = (l_run + __shfl_xor(l_run, 32)) * (NP == 2 ? 256.0f : 1.0f);
         if (qrow < T) {
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -695,9 +707,13 @@ __global__ __launch_bounds__(KS * 64, 2) void vn_attention_x3_split_kernel(const
 }
 
 // LDS bytes of the two decompositions; the launcher (and the engine's choice of attention kernel) need them to fit the CU
-size_t vn_attention_x3_lds_bytes(int T, int key_split) {
+size_t vn_attention_x3_lds_bytes(int T, int key_split, int np) {
     const size_t stages = key_split > 0 ? (size_t)key_split : 2;
-    return (stages * AX_STAGE_FLOATS + 2 * (size_t)T - 1 + 3) * sizeof(float);
+    const size_t bytes = (stages * AX_STAGE_FLOATS_NP(np) + 2 * (size_t)T - 1 + 3) * sizeof(float);
+    // shared tiles: the tail blocks merge their key halves through four 9 KiB images laid over the stages (and, for two-plane
+    // stages and a short bias table, past them)
+    const size_t merge = key_split > 0 ? 0 : 4 * 2304 * sizeof(float);
+    return bytes > merge ? bytes : merge;
 }
 
 // which decomposition: 0 = shared tiles (128-query blocks + key-split tail blocks), KS > 0 = key-split with KS waves per 32-query block
@@ -711,12 +727,15 @@ int vn_attention_x3_plan(const vn_ctx* ctx, int B, int H, int T, int cus) {
     return 0;
 }
 
+// np = 3: q16 / k16 / vt16 are bf16x3 planes; np = 2: fp16 two-plane operands (second plane unscaled, V^T times 16), the attention
+// format of the f16x2 precision
 int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16, long plane_qk, const uint16_t* vt16, long plane_vt,
-                           const float* relbias_full, float* out, uint16_t* out16, long plane16, int B, int H, int T, int cus,
+                           const float* relbias_full, float* out, uint16_t* out16, long plane16, int B, int H, int T, int cus, int np,
                            hipStream_t s) {
     if (B <= 0 || T <= 0) return VN_OK;
+    if (np != 2 && np != 3) return vn_fail(ctx, VN_ERR_INVALID, "attention_x3: %s%ld planes per operand (2 or 3)", "", np);
     const int ks = vn_attention_x3_plan(ctx, B, H, T, cus);
-    size_t lds = vn_attention_x3_lds_bytes(T, ks);
+    size_t lds = vn_attention_x3_lds_bytes(T, ks, np);
     if (lds > 160 * 1024) return vn_fail(ctx, VN_ERR_INVALID, "attention_x3: T=%s%ld too long for the LDS bias table", "", T);
     if (ks == 0 && ctx->tune.ax_lds > (int)lds && ctx->tune.ax_lds <= 160 * 1024) lds = ctx->tune.ax_lds;
     if (!(ctx->attr_mask & VN_ATTR_ATTN_X3)) {
@@ -725,6 +744,11 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_split_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_split_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_split_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_split_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_split_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_split_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->attr_mask |= VN_ATTR_ATTN_X3;
     }
     const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
@@ -732,21 +756,27 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
         // four waves (128 queries) per block, three blocks per CU (LDS: 2 x 24 KiB stages + the bias table)
         const int nqbf = T / 128, rq = T - 128 * nqbf;              // full 128-query blocks (+ one for a remainder > 64) + key-split tail blocks
         const dim3 grid((nqbf + (rq > 0 ? 1 : 0)) * H * B);
-        const long slots = (long)(160 * 1024 / lds) * cus;
+        const long per_cu = (long)(160 * 1024 / lds) < 3 ? (long)(160 * 1024 / lds) : 3;      // registers allow three waves per SIMD
+        const long slots = per_cu * cus;
         const int knobs = (ctx->tune.ax_stagger & 0xffff) | ((long)grid.x > slots && !(ctx->tune.ax_stagger >> 16) ? 0x10000 : 0);
-        if (ctx->tune.ax_trace)
-            hipLaunchKernelGGL((vn_attention_x3_kernel<4, true>), grid, dim3(256), lds, s, q16, k16, plane_qk, vt16, plane_vt, relbias_full, out,
-                               out16, plane16, B, H, T, knobs, ctx->tune.ax_trace);
-        else
-            hipLaunchKernelGGL((vn_attention_x3_kernel<4, false>), grid, dim3(256), lds, s, q16, k16, plane_qk, vt16, plane_vt, relbias_full, out,
-                               out16, plane16, B, H, T, knobs, (unsigned*)nullptr);
+#define AX_SHARED_GO(TR, NP) hipLaunchKernelGGL((vn_attention_x3_kernel<4, TR, NP>), grid, dim3(256), lds, s, q16, k16, plane_qk, vt16, plane_vt, \
+                                                relbias_full, out, out16, plane16, B, H, T, knobs, TR ? ctx->tune.ax_trace : (unsigned*)nullptr)
+        if (ctx->tune.ax_trace) { if (np == 3) AX_SHARED_GO(true, 3); else AX_SHARED_GO(true, 2); }
+        else { if (np == 3) AX_SHARED_GO(false, 3); else AX_SHARED_GO(false, 2); }
+#undef AX_SHARED_GO
     } else {
         const dim3 grid(vn_cdiv(T, 32) * H * B);
-#define AX_SPLIT_GO(KS) hipLaunchKernelGGL((vn_attention_x3_split_kernel<KS>), grid, dim3(KS * 64), lds, s, q16, k16, plane_qk, vt16, plane_vt, \
-                                           relbias_full, out, out16, plane16, B, H, T)
-        if (ks == 1) AX_SPLIT_GO(1);
-        else if (ks == 2) AX_SPLIT_GO(2);
-        else AX_SPLIT_GO(4);
+#define AX_SPLIT_GO(KS, NP) hipLaunchKernelGGL((vn_attention_x3_split_kernel<KS, NP>), grid, dim3(KS * 64), lds, s, q16, k16, plane_qk, vt16, \
+                                               plane_vt, relbias_full, out, out16, plane16, B, H, T)
+        if (np == 3) {
+            if (ks == 1) AX_SPLIT_GO(1, 3);
+            else if (ks == 2) AX_SPLIT_GO(2, 3);
+            else AX_SPLIT_GO(4, 3);
+        } else {
+            if (ks == 1) AX_SPLIT_GO(1, 2);
+            else if (ks == 2) AX_SPLIT_GO(2, 2);
+            else AX_SPLIT_GO(4, 2);
+        }
 #undef AX_SPLIT_GO
     }
     vn_prof_post(ctx, pi, s);

@@ -319,7 +319,8 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
     // chip, key-split 32-query blocks for one or two sequences) whenever its LDS image (stages + the 2T-1 bias table) fits the CU;
     // the fp32-input MFMA kernel otherwise.  VN_ATTN_X3 = 0 / 1 or vn_debug_attention_x3_force override (A/B runs, tests).
     const int cus = vn_num_cus(ctx);
-    const bool attn_x3_fits = vn_attention_x3_lds_bytes(T, vn_attention_x3_plan(ctx, B, H, T, cus)) <= 160 * 1024;
+    const int attn_np = gm == 3 ? 2 : 3;                 // f16x2: fp16 two-plane attention operands, else bf16x3 planes
+    const bool attn_x3_fits = vn_attention_x3_lds_bytes(T, vn_attention_x3_plan(ctx, B, H, T, cus), attn_np) <= 160 * 1024;
     const bool attn_x3 = attn_x3_fits && (ctx->tune.attn_x3 >= 0 ? ctx->tune.attn_x3 != 0 : true);
     // a RESIDUAL GEMM that gets split along K runs the RMSNorm that follows it inside its reduce pass (gemm_x3.hip)
     int normed = 0;
@@ -341,7 +342,7 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
             a.T = T; a.H = H; a.qkv_plane = plane;
             if ((rc = vn_launch_gemm_f32(ctx, a, VN_EPI_QKV3, s))) return rc;
             if ((rc = vn_launch_attention_x3(ctx, m->qk16, m->qk16 + plane, m->qk_plane, m->vt16, m->vt_plane, m->bias_full, nullptr,
-                                             m->y16, yp, B, H, T, cus, s)))
+                                             m->y16, yp, B, H, T, cus, attn_np, s)))
                 return rc;
         } else {
             vn_gemm_args a{};
@@ -723,9 +724,10 @@ extern "C" int vn_attention_bf16(vn_ctx* ctx, const float* q, const float* k, co
 
 // bf16x3 attention as a single op (tests): fp32 q, k, v [B][H][T][64] are split / transposed here exactly as the QKV GEMM
 // epilogues do (q x 1/8; V^T blocked by 32-key tile), then attention_x3.hip runs; out fp32 [B][T][H*64]
+// np = 2: the f16x2 precision's attention operands (fp16 two-plane, second plane unscaled, V^T times 16)
 __global__ void vn_attn_x3_prep_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                        uint16_t* __restrict__ qk16, long plane_qk, uint16_t* __restrict__ vt16, long plane_vt,
-                                       long heads, int H, int T) {
+                                       long heads, int H, int T, int np) {
     const long n = heads * T * VN_DHEAD;
     const long mt = ((heads / H) * T + 31) >> 5;          // tiles of 32 global token rows m = b T + t
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
@@ -735,19 +737,28 @@ __global__ void vn_attn_x3_prep_kernel(const float* __restrict__ q, const float*
         const int t = (int)(ht - hd * T);
         const long mrow = (hd / H) * T + t;
         uint16_t a, b, c;
+        const long o = (((hd % H) * mt + (mrow >> 5)) * VN_DHEAD + d) * 32 + (mrow & 31);
+        if (np == 2) {
+            vn_split2u(q[i] * 0.125f, a, b);
+            qk16[i] = a; qk16[i + plane_qk] = b;
+            vn_split2u(k[i], a, b);
+            qk16[n + i] = a; qk16[n + i + plane_qk] = b;
+            vn_split2u(v[i] * 16.0f, a, b);
+            vt16[o] = a; vt16[o + plane_vt] = b;
+            continue;
+        }
         vn_split3(q[i] * 0.125f, a, b, c);
         qk16[i] = a; qk16[i + plane_qk] = b; qk16[i + 2 * plane_qk] = c;
         vn_split3(k[i], a, b, c);
         qk16[n + i] = a; qk16[n + i + plane_qk] = b; qk16[n + i + 2 * plane_qk] = c;
         vn_split3(v[i], a, b, c);
-        const long o = (((hd % H) * mt + (mrow >> 5)) * VN_DHEAD + d) * 32 + (mrow & 31);
         vt16[o] = a; vt16[o + plane_vt] = b; vt16[o + 2 * plane_vt] = c;
     }
 }
 
 // shared by the single-op entry and the timing hook: scratch, bias table, plane images; *launches of the kernel only
 static int attention_x3_run(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias, float* out, int B,
-                            int H, int T, int num_buckets, int max_distance, int iters, float* avg_us, hipStream_t s) {
+                            int H, int T, int num_buckets, int max_distance, int iters, float* avg_us, int np, hipStream_t s) {
     const long heads = (long)B * H, n = heads * T * VN_DHEAD;
     const long plane_qk = 2 * n, plane_vt = (long)H * (((long)B * T + 31) / 32) * (VN_DHEAD * 32);
     float* full = nullptr;
@@ -766,15 +777,15 @@ static int attention_x3_run(vn_ctx* ctx, const float* q, const float* k, const f
         rc = VN_ERR_HIP;
     if (rc == VN_OK) rc = vn_launch_bias_expand(ctx, rel_bias, lut_d, full, H, T, s);
     if (rc == VN_OK) {
-        hipLaunchKernelGGL(vn_attn_x3_prep_kernel, dim3(1024), dim3(256), 0, s, q, k, v, qk16, plane_qk, vt16, plane_vt, heads, H, T);
-        rc = vn_launch_attention_x3(ctx, qk16, qk16 + n, plane_qk, vt16, plane_vt, full, out, nullptr, 0, B, H, T, vn_num_cus(ctx), s);
+        hipLaunchKernelGGL(vn_attn_x3_prep_kernel, dim3(1024), dim3(256), 0, s, q, k, v, qk16, plane_qk, vt16, plane_vt, heads, H, T, np);
+        rc = vn_launch_attention_x3(ctx, qk16, qk16 + n, plane_qk, vt16, plane_vt, full, out, nullptr, 0, B, H, T, vn_num_cus(ctx), np, s);
     }
     if (rc == VN_OK && iters > 0 && avg_us) {
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipEventRecord(e0, s);
         for (int i = 0; i < iters && rc == VN_OK; ++i)
-            rc = vn_launch_attention_x3(ctx, qk16, qk16 + n, plane_qk, vt16, plane_vt, full, out, nullptr, 0, B, H, T, vn_num_cus(ctx), s);
+            rc = vn_launch_attention_x3(ctx, qk16, qk16 + n, plane_qk, vt16, plane_vt, full, out, nullptr, 0, B, H, T, vn_num_cus(ctx), np, s);
         (void)hipEventRecord(e1, s);
         (void)hipEventSynchronize(e1);
         float ms = 0.f;
@@ -790,15 +801,22 @@ static int attention_x3_run(vn_ctx* ctx, const float* q, const float* k, const f
 extern "C" int vn_attention_bf16x3(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
                                    float* out, int B, int H, int T, int num_buckets, int max_distance, void* stream) {
     if (!ctx || !q || !k || !v || !rel_bias || !out || T <= 0 || H <= 0 || B <= 0) return VN_ERR_INVALID;
-    return attention_x3_run(ctx, q, k, v, rel_bias, out, B, H, T, num_buckets, max_distance, 0, nullptr, (hipStream_t)stream);
+    return attention_x3_run(ctx, q, k, v, rel_bias, out, B, H, T, num_buckets, max_distance, 0, nullptr, 3, (hipStream_t)stream);
+}
+// the same op on the f16x2 precision's attention operands (fp16 two-plane splits, three products per MFMA step)
+extern "C" int vn_attention_f16x2(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                                  float* out, int B, int H, int T, int num_buckets, int max_distance, void* stream) {
+    if (!ctx || !q || !k || !v || !rel_bias || !out || T <= 0 || H <= 0 || B <= 0) return VN_ERR_INVALID;
+    return attention_x3_run(ctx, q, k, v, rel_bias, out, B, H, T, num_buckets, max_distance, 0, nullptr, 2, (hipStream_t)stream);
 }
 
 // tuning hook (scripts/attn_bench.py): average duration of `iters` back-to-back launches of the bf16x3 attention KERNEL
 // (operand planes prepared once, outside the timed region)
 extern "C" int vn_debug_attention_x3_time(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
                                           float* out, int B, int H, int T, int iters, float* avg_us, void* stream) {
-    if (!ctx || !q || !k || !v || !rel_bias || !out || !avg_us || T <= 0 || H <= 0 || B <= 0 || iters <= 0) return VN_ERR_INVALID;
-    return attention_x3_run(ctx, q, k, v, rel_bias, out, B, H, T, 32, 128, iters, avg_us, (hipStream_t)stream);
+    if (!ctx || !q || !k || !v || !rel_bias || !out || !avg_us || T <= 0 || H <= 0 || B <= 0 || iters == 0) return VN_ERR_INVALID;
+    // iters < 0: -iters launches on the f16x2 precision's two-plane operands
+    return attention_x3_run(ctx, q, k, v, rel_bias, out, B, H, T, 32, 128, iters < 0 ? -iters : iters, avg_us, iters < 0 ? 2 : 3, (hipStream_t)stream);
 }
 
 extern "C" int vn_rmsnorm_f32(vn_ctx* ctx, const float* x, const float* w, float* y, int rows, int D, float eps,

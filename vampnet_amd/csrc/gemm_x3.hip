@@ -72,7 +72,6 @@ struct x3_geo {
     static constexpr int NPROD = NP == 3 ? 6 : 3;                   // matrix-core products per 16-wide k-step
     static constexpr int NI = NP == 3 ? 4 : 2;                      // two-buffer schedule: DMA pieces issued between the products of k-step 0
 };
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 static_assert(x3_geo<1>::BM == 128 && x3_geo<2>::BM == 256 && x3_geo<3>::BM == 192, "tile heights");
 
 __device__ __forceinline__ int x3_xcd_remap(int bid, int nwg) {
@@ -165,15 +164,19 @@ __device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 
                         const int D = p.H * VN_DHEAD;
                         const int which = col / D, rem = col - which * D;
                         const int hd = rem >> 6, d = rem & 63;
-                        uint16_t t0, t1, t2;
-                        vn_split3(which ? v : v * 0.125f, t0, t1, t2);
+                        uint16_t t0, t1, t2 = 0;
+                        // FMT 1: the attention operands of the f16x2 precision — fp16 two-plane, second plane unscaled, V times 16
+                        if constexpr (FMT) vn_split2u(which == 0 ? v * 0.125f : which == 1 ? v : v * 16.0f, t0, t1);
+                        else vn_split3(which ? v : v * 0.125f, t0, t1, t2);
                         if (which < 2) {
                             const int b = row / p.T, t = row - b * p.T;
                             uint16_t* dst = p.C16 + which * p.qkv_plane + (((size_t)b * p.H + hd) * p.T + t) * VN_DHEAD + d;
-                            dst[0] = t0; dst[p.c_plane] = t1; dst[2 * p.c_plane] = t2;
+                            dst[0] = t0; dst[p.c_plane] = t1;
+                            if constexpr (!FMT) dst[2 * p.c_plane] = t2;
                         } else {
                             uint16_t* dst = p.V16 + (((size_t)hd * ((p.M + 31) >> 5) + (row >> 5)) * VN_DHEAD + d) * 32 + (row & 31);
-                            dst[0] = t0; dst[p.v_plane] = t1; dst[2 * p.v_plane] = t2;
+                            dst[0] = t0; dst[p.v_plane] = t1;
+                            if constexpr (!FMT) dst[2 * p.v_plane] = t2;
                         }
                     }
                 }
@@ -222,10 +225,13 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
 #pragma unroll
                     for (int j = 0; j < CJ; ++j) {
                         const int c = wn * 32 * CJ + j * 32 + l31;
-                        uint16_t t0, t1, t2;
-                        vn_split3(n0 < p.H * VN_DHEAD ? acc[i][j][r] * 0.125f : acc[i][j][r], t0, t1, t2);      // q: x 1/sqrt(64)
+                        uint16_t t0, t1, t2 = 0;
+                        const float qv = n0 < p.H * VN_DHEAD ? acc[i][j][r] * 0.125f : acc[i][j][r];              // q: x 1/sqrt(64)
+                        if constexpr (FMT) vn_split2u(qv, t0, t1);
+                        else vn_split3(qv, t0, t1, t2);
                         uint16_t* d = L16 + R * 128 + c;
-                        d[0] = t0; d[RP * 128] = t1; d[2 * RP * 128] = t2;
+                        d[0] = t0; d[RP * 128] = t1;
+                        if constexpr (!FMT) d[2 * RP * 128] = t2;
                     }
                 } else if ((r & 3) == 0) {                                          // v tile: transposed image [column][row], pitch VP
 #pragma unroll
@@ -233,9 +239,12 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
                         const int c = wn * 32 * CJ + j * 32 + l31;
                         uint16_t t[3][4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) vn_split3(acc[i][j][r + e], t[0][e], t[1][e], t[2][e]);
+                        for (int e = 0; e < 4; ++e) {
+                            if constexpr (FMT) vn_split2u(acc[i][j][r + e] * 16.0f, t[0][e], t[1][e]);
+                            else vn_split3(acc[i][j][r + e], t[0][e], t[1][e], t[2][e]);
+                        }
 #pragma unroll
-                        for (int q = 0; q < 3; ++q) {
+                        for (int q = 0; q < (FMT ? 2 : 3); ++q) {
                             uint2 pk = {t[q][0] | ((unsigned)t[q][1] << 16), t[q][2] | ((unsigned)t[q][3] << 16)};
                             *(uint2*)(L16 + q * (128 * VP) + c * VP + R) = pk;      // rows R .. R + 3 (r & 3 = 0 .. 3)
                         }
@@ -264,7 +273,7 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
             const int D = p.H * VN_DHEAD;
             if (n0 < 2 * D) {
 #pragma unroll
-                for (int k = 0; k < 3 * RP * 16 / 512; ++k) {                       // 3 planes x RP rows x 16 pieces of 8 columns
+                for (int k = 0; k < (FMT ? 2 : 3) * RP * 16 / 512; ++k) {           // planes x RP rows x 16 pieces of 8 columns
                     const int idx = tid + 512 * k;
                     const int q = idx / (RP * 16), a = (idx >> 4) % RP, b8 = (idx & 15) * 8;
                     const int row = m0 + (a >> 5) * 32 * RI + 32 * i + (a & 31), col = n0 + b8;
@@ -276,7 +285,7 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < 3 * 128 * (RP / 8) / 512; ++k) {                // 3 planes x 128 columns x RP / 8 pieces of 8 rows
+                for (int k = 0; k < (FMT ? 2 : 3) * 128 * (RP / 8) / 512; ++k) {    // planes x 128 columns x RP / 8 pieces of 8 rows
                     const int idx = tid + 512 * k;
                     const int q = idx / (128 * (RP / 8)), a = (idx / (RP / 8)) & 127, b8 = (idx % (RP / 8)) * 8;     // a = column (feature)
                     const int row = m0 + (b8 >> 5) * 32 * RI + 32 * i + (b8 & 31), f = n0 + a - 2 * D;

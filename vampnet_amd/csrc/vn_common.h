@@ -91,6 +91,23 @@ __device__ __forceinline__ void vn_split2h(float x, uint16_t& h0, uint16_t& h1) 
 __device__ __forceinline__ float vn_h2_value(uint16_t h0, uint16_t h1) {
     return (float)__builtin_bit_cast(_Float16, h0) + (float)__builtin_bit_cast(_Float16, h1) * VN_H2_INV_SCALE;
 }
+// The attention operands of the f16x2 precision (attention_x3.hip; written by the QKV3 epilogue of gemm_x3.hip) are two fp16 planes
+// WITHOUT the 2^11 on the second one, h1 = fp16(x - h0): all three kept products then go into ONE accumulator (a second S / O
+// accumulator would cost the kernel its third wave per SIMD).  The remainder of a value below 0.125 falls into fp16's subnormal
+// range, i.e. the split is exact to 2^-25 absolute instead of 2^-22 relative — harmless for q / 8 and k (a score moves by < 3e-7)
+// and for softmax weights and values once those carry a factor 16 (P <= e^6: 16 P < 6.5e3; the factors leave with the final division).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void vn_split2u(float x, uint16_t& h0, uint16_t& h1) {
+    x = __builtin_fminf(__builtin_fmaxf(x, -65504.0f), 65504.0f);
+    const _Float16 a = (_Float16)x;
+    const _Float16 b = (_Float16)(x - (float)a);
+    h0 = __builtin_bit_cast(uint16_t, a);
+    h1 = __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ void vn_split2u_x8(const f32x8& x, f16x8& h0, f16x8& h1) {        // |x| < 65504 (softmax weights)
+    h0 = __builtin_convertvector(x, f16x8);
+    h1 = __builtin_convertvector(x - __builtin_convertvector(h0, f32x8), f16x8);
+}
 // four consecutive values -> one 8-byte store per f16x2 plane
 __device__ __forceinline__ void vn_store_h2x4(uint16_t* dst, long plane, const f32x4& o) {
     uint16_t t[2][4];
@@ -399,10 +416,10 @@ int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float
 // vt16 planes [3][H][ceil(B T / 32)][64][32] over global token rows (plane_vt apart); out fp32 [B][T][H*64] or out16 split planes (plane16 apart)
 int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16, long plane_qk, const uint16_t* vt16, long plane_vt,
                            const float* relbias_full, float* out, uint16_t* out16, long plane16, int B, int H, int T, int cus,
-                           hipStream_t s);
+                           int np, hipStream_t s);       // np = 3: bf16x3 planes; 2: fp16 two-plane operands (f16x2 precision)
 // decomposition it will use (0 = shared 128-query tiles, KS = key-split waves per 32-query block) and the dynamic LDS that needs
 int vn_attention_x3_plan(const vn_ctx* ctx, int B, int H, int T, int cus);
-size_t vn_attention_x3_lds_bytes(int T, int key_split);
+size_t vn_attention_x3_lds_bytes(int T, int key_split, int np);
 static inline int vn_num_cus(const vn_ctx* ctx) { return ctx->cus > 0 ? ctx->cus : 256; }
 // expands [num_buckets][H] into per-head tables over rel = key - query in [-(T-1), T-1]: out[h][rel + T - 1]
 void vn_bucket_lut_host(int T, int num_buckets, int max_distance, int32_t* lut /* [2T-1] */);

@@ -187,10 +187,11 @@ class Engine:
 
     def attention(self, q, k, v, rel_bias, num_buckets=32, max_distance=128, precision="f32"):
         """q,k,v [B,H,T,64]; rel_bias [num_buckets,H] -> [B,T,H*64].  precision "f32": fp32-input MFMA (attention_f32.hip);
-        "bf16x3": six bf16-MFMA products of exact operand splits (attention_x3.hip), same error class."""
+        "bf16x3": six bf16-MFMA products of exact operand splits (attention_x3.hip), same error class; "f16x2": three fp16-MFMA
+        products of two-plane splits (the attention format of the f16x2 precision), same error class."""
         B, H, T, dh = q.shape
         out = torch.empty(B, T, H * dh, device=q.device, dtype=torch.float32)
-        fn = {"f32": self.lib.vn_attention_f32, "bf16x3": self.lib.vn_attention_bf16x3}[precision]
+        fn = {"f32": self.lib.vn_attention_f32, "bf16x3": self.lib.vn_attention_bf16x3, "f16x2": self.lib.vn_attention_f16x2}[precision]
         self.check(fn(self.handle, q.contiguous().data_ptr(), k.contiguous().data_ptr(), v.contiguous().data_ptr(),
                       rel_bias.data_ptr(), out.data_ptr(), B, H, T, num_buckets, max_distance, self.stream()),
                    "vn_attention_" + precision)
