@@ -270,6 +270,13 @@ int vn_conv1d_bf16x3(vn_ctx* ctx, const void* x16, int64_t x_plane, const void* 
                      const float* alpha, float* y, float* y2, void* y2_16, int64_t y2_plane, int B, int T_in, int T_rows, int T_out,
                      int C_in, int C_out, int taps, int in_stride, int dil, int pad, int out_stride, int out_off, int act,
                      void* stream);
+/* ... and on f16x2 operands (three fp16-MFMA products, vn_gemm_f16x2's format): x16 = TWO planar fp16 planes [2][B*T_in][C_in]
+ * (vn_split2_f16, tiled = 0), w_tiled = vn_split2_f16(w as [C_out][taps*C_in], tiled = 1); y2_16 = snake(y) as two planar fp16 planes
+ * y2_plane apart.  (vn_conv1d_f32 writes that format when its y2_plane is NEGATIVE: two planes -y2_plane apart.)                  */
+int vn_conv1d_f16x2(vn_ctx* ctx, const void* x16, int64_t x_plane, const void* w_tiled, const float* bias, const float* resid,
+                    const float* alpha, float* y, float* y2, void* y2_16, int64_t y2_plane, int B, int T_in, int T_rows, int T_out,
+                    int C_in, int C_out, int taps, int in_stride, int dil, int pad, int out_stride, int out_off, int act,
+                    void* stream);
 /* planar split planes [3][rows][K] (plane_stride elements apart; rows % 16 == 0, K % 32 == 0) -> the tiled layout
  * [rows/16][K/32][3][16][32] in which the bf16x3 GEMM / convolution read their weights (`tiled`: 3*rows*K bf16)              */
 int vn_tile_planes_bf16x3(vn_ctx* ctx, const void* planes, int64_t plane_stride, void* tiled, int64_t rows, int K, void* stream);

@@ -8,7 +8,7 @@ from vampnet_amd.engine import Engine
 
 eng = Engine("cuda:0")
 cfg = D.DAC_DEFAULT_CFG
-for precision, B in (("bf16x3", 1), ("bf16x3", 8), ("f32", 8)):
+for precision, B in (("f16x2", 1), ("f16x2", 8), ("bf16x3", 8), ("f32", 8)):
     codec = DacCodec(D.synth_dac_state_dict(cfg, 0), cfg, engine=eng, precision=precision)
     audio = 0.1 * torch.randn(B, 1, 575 * 768, device="cuda")
     for name, fn in (("encode", lambda: codec.encode(audio)["codes"]), ("decode", None)):

@@ -24,12 +24,13 @@ def _audio(B, L, seed=0):
     return torch.from_numpy(x.astype(np.float32))
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
+@pytest.mark.parametrize("precision", ["f16x2", "bf16x3", "f32"])
 @pytest.mark.parametrize("cfg,B,frames", [(D.DAC_TINY_CFG, 2, 50), (D.DAC_TINY_CFG, 1, 7), (D.DAC_DEFAULT_CFG, 2, 12)])
 def test_encode_decode_vs_oracle(eng, cfg, B, frames, precision):
-    """both codec pipes at the SAME bars: "f32" = every convolution on the fp32-input MFMA kernel; "bf16x3" (default) = the
-    MFMA-bound convolutions (>= 96 output channels, K >= 256) as six bf16-MFMA products of exact operand splits (gemm_x3.hip's
-    implicit-GEMM mode), the rest on the fp32 kernels, activations handed over as split planes / fp32 as each consumer reads them"""
+    """all codec pipes at the SAME bars: "f32" = every convolution on the fp32-input MFMA kernel; "bf16x3" = the MFMA-bound
+    convolutions (>= 96 output channels, K >= 256) as six bf16-MFMA products of exact operand splits (gemm_x3.hip's implicit-GEMM
+    mode), "f16x2" (default) = the same convolutions as three fp16-MFMA products of two-plane splits; the rest on the fp32
+    kernels, activations handed over as split planes / fp32 as each consumer reads them"""
     from vampnet_amd.codec import DacCodec
     sd = D.synth_dac_state_dict(cfg, 0)
     codec = DacCodec(sd, cfg, engine=eng, precision=precision)
@@ -174,7 +175,7 @@ def test_conv1d_bf16x3_vs_torch_and_f32_kernel(eng, B, T, cin, cout, taps, strid
     xd, wd, bd, ad, rd = (t.to(dev).contiguous() for t in (x, w, bias, alpha, resid))
     x16 = eng.split3(xd.reshape(-1, cin))
     codec = DacCodec.__new__(DacCodec)
-    codec.engine, codec.lib, codec.device = eng, lib, eng.device
+    codec.engine, codec.lib, codec.device, codec.precision = eng, lib, eng.device, "bf16x3"
     w16 = codec._tile_planes(wd.reshape(cout, -1))
     y, y2 = torch.empty(B, T_out, cout, device=dev), torch.empty(B, T_out, cout, device=dev)
     y216 = torch.empty(3, B * T_out, cout, device=dev, dtype=torch.bfloat16)
@@ -199,6 +200,27 @@ def test_conv1d_bf16x3_vs_torch_and_f32_kernel(eng, B, T, cin, cout, taps, strid
     for name, planes, dense in (("bf16x3", y216, y2), ("f32", y216f, y2f)):
         p = planes.float()
         assert torch.equal((p[0] + p[1] + p[2]).reshape(B, T_out, cout), dense), name + ": the planes must sum to the fp32 snake output exactly"
+    # ---- the same convolution on f16x2 operands (three fp16-MFMA products): same tolerance; its planes, and the fp16 planes the fp32
+    # kernel writes for a consumer on that pipe (negative plane stride), reproduce the dense snake output to 2^-22
+    x2, w2 = eng.split2h(xd.reshape(-1, cin)), eng.split2h(wd.reshape(cout, -1).contiguous(), tiled=True)
+    yh, y2h = torch.empty_like(y), torch.empty_like(y2)
+    y2h16 = torch.empty(2, B * T_out, cout, device=dev, dtype=torch.float16)
+    eng.check(lib.vn_conv1d_f16x2(eng.handle, x2.data_ptr(), B * T * cin, w2.data_ptr(), bd.data_ptr(), rd.data_ptr(), ad.data_ptr(),
+                                  yh.data_ptr(), y2h.data_ptr(), y2h16.data_ptr(), B * T_out * cout, B, T, T_out, T_out, cin, cout, taps,
+                                  stride, dil, pad, 1, 0, 0, eng.stream()), "vn_conv1d_f16x2")
+    y2f16h = torch.empty_like(y2h16)
+    eng.check(lib.vn_conv1d_f32(eng.handle, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr(), ad.data_ptr(), None, y2f.data_ptr(),
+                                y2f16h.data_ptr(), -(B * T_out * cout), B, T, T_out, T_out, cin, cout, taps, stride, dil, pad, 1, 0, 0,
+                                eng.stream()), "vn_conv1d_f32")
+    torch.cuda.synchronize()
+    err = (yh.cpu().double() - ref).abs()
+    print(f"{note}: f16x2 raw max err {err.max().item():.3e}")
+    assert bool((err <= tol).all())
+    assert (y2h.cpu().double() - ref_s).abs().max().item() <= 2e-5
+    for name, planes, dense in (("f16x2", y2h16, y2h), ("f32 -> fp16 planes", y2f16h, y2f)):
+        back = planes[0].double() + planes[1].double() / 2048.0
+        d = (back.reshape(B, T_out, cout) - dense.double()).abs()
+        assert bool((d <= dense.double().abs() * 2.0 ** -22 + 2.0 ** -24).all()), name
 
 
 def test_conv_transpose_phases_on_bf16x3(eng):
@@ -214,7 +236,7 @@ def test_conv_transpose_phases_on_bf16x3(eng):
     T_out = (T - 1) * st - 2 * pad + 2 * st
     ref = torch.nn.functional.conv_transpose1d(x.double().permute(0, 2, 1), w.double(), bias.double(), stride=st, padding=pad).permute(0, 2, 1)
     codec = DacCodec.__new__(DacCodec)
-    codec.engine, codec.lib, codec.device = eng, eng.lib, eng.device
+    codec.engine, codec.lib, codec.device, codec.precision = eng, eng.lib, eng.device, "bf16x3"
     x16 = eng.split3(x.cuda().reshape(-1, cin))
     y = torch.zeros(B, T_out, cout, device="cuda")
     bd = bias.cuda()

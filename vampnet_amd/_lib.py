@@ -69,6 +69,7 @@ SYMBOLS = {
     "vn_gemm_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vn_conv1d_f32": (C.c_int, [_P] * 9 + [C.c_int64] + [C.c_int] * 13 + [_P]),
     "vn_conv1d_bf16x3": (C.c_int, [_P, _P, C.c_int64] + [_P] * 7 + [C.c_int64] + [C.c_int] * 13 + [_P]),
+    "vn_conv1d_f16x2": (C.c_int, [_P, _P, C.c_int64] + [_P] * 7 + [C.c_int64] + [C.c_int] * 13 + [_P]),
     "vn_tile_planes_bf16x3": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int, _P]),
     "vn_dac_conv_in_f32": (C.c_int, [_P] * 7 + [C.c_int] * 3 + [_P]),
     "vn_dac_conv_out_f32": (C.c_int, [_P, _P, _P, C.c_float, _P, C.c_int, C.c_int, C.c_int, _P]),

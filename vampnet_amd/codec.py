@@ -217,11 +217,11 @@ class DacCodec:
     # 1-channel stem / head stay on the fp32 kernels; every epilogue writes its Snake output in the format its consumer reads.
     X3_MIN_COUT, X3_MIN_WORK = 128, 512
 
-    def __init__(self, sd: dict, cfg: dict = None, device="cuda:0", engine: Engine = None, precision: str = "bf16x3"):
+    def __init__(self, sd: dict, cfg: dict = None, device="cuda:0", engine: Engine = None, precision: str = "f16x2"):
         cfg = dict(DEFAULT_CFG, **(cfg or {}))
         self.cfg = cfg
-        if precision not in ("bf16x3", "f32"):
-            raise ValueError("precision must be 'bf16x3' (fp32-grade products on the bf16 matrix cores) or 'f32'")
+        if precision not in ("f16x2", "bf16x3", "f32"):
+            raise ValueError("precision must be 'f16x2' / 'bf16x3' (fp32-grade products on the fp16 / bf16 matrix cores) or 'f32'")
         self.precision = precision
         self.engine = engine or Engine(device)
         self.lib = self.engine.lib
@@ -304,7 +304,7 @@ class DacCodec:
         taps = c.get("k", 2) if taps is None else taps
         cout = c["cout"]
         eff = cout / (128.0 * math.ceil(cout / 128))                   # fraction of the 128-wide column tiles that is real output
-        return (self.precision == "bf16x3" and cout >= self.X3_MIN_COUT and cout % 16 == 0 and c["cin"] % 32 == 0
+        return (self.precision in ("bf16x3", "f16x2") and cout >= self.X3_MIN_COUT and cout % 16 == 0 and c["cin"] % 32 == 0
                 and taps * c["cin"] * eff >= self.X3_MIN_WORK)
 
     def _fmt(self, c, taps=None):
@@ -315,15 +315,24 @@ class DacCodec:
         """fp32 [rows][K] on the device -> the tiled split planes the bf16x3 kernel reads weights in (3 * rows * K bf16)"""
         eng = self.engine
         rows, K = w2d.shape
+        if self.precision == "f16x2":
+            return eng.split2h(w2d.contiguous(), tiled=True).reshape(-1)       # [rows / 16][K / 32][2][16][32] fp16
         planes = eng.split3(w2d.contiguous())
         tiled = torch.empty(3 * rows * K, dtype=torch.bfloat16, device=self.device)
         eng.check(self.lib.vn_tile_planes_bf16x3(eng.handle, planes.data_ptr(), rows * K, tiled.data_ptr(), rows, K, eng.stream()),
                   "vn_tile_planes_bf16x3")
         return tiled
 
+    def _empty_planes(self, rows, cols):
+        """planar split planes of a [rows][cols] activation in this codec's format: three bf16 or two fp16 planes"""
+        if self.precision == "f16x2":
+            return torch.empty(2, rows, cols, device=self.device, dtype=torch.float16)
+        return torch.empty(3, rows, cols, device=self.device, dtype=torch.bfloat16)
+
     def _planes(self, x):
         """fp32 [B][T][C] -> _Act with split planes (the few places where a producer outside the conv stack feeds the bf16x3 pipe)"""
-        return _Act(f32=x, p16=self.engine.split3(x.reshape(-1, x.shape[-1])))
+        x2d = x.reshape(-1, x.shape[-1])
+        return _Act(f32=x, p16=self.engine.split2h(x2d) if self.precision == "f16x2" else self.engine.split3(x2d))
 
     def _conv(self, x, c, *, T_in, T_rows, T_out, phase=None, taps=None, in_stride=1, dil=1, pad=0, out_stride=1, out_off=0,
               resid=None, alpha=None, want_raw=True, s_fmt=None, act=0, out=None):
@@ -343,20 +352,22 @@ class DacCodec:
         if s_fmt is not None and sn is None:
             assert alpha is not None
             sn = _Act(torch.empty(B, T_out, cout, device=self.device, dtype=torch.float32) if s_fmt in ("f32", "both") else None,
-                      torch.empty(3, B * T_out, cout, device=self.device, dtype=torch.bfloat16) if s_fmt in ("x3", "both") else None)
+                      self._empty_planes(B * T_out, cout) if s_fmt in ("x3", "both") else None)
         p = lambda t: t.data_ptr() if t is not None else None
         y2, y216 = (sn.f32, sn.p16) if sn is not None else (None, None)
         plane = B * T_out * cout
+        h2 = self.precision == "f16x2"
         if x3:
             w16 = c["w16"] if phase is None else c["w16"][phase]
-            eng.check(self.lib.vn_conv1d_bf16x3(
+            eng.check((self.lib.vn_conv1d_f16x2 if h2 else self.lib.vn_conv1d_bf16x3)(
                 eng.handle, src.data_ptr(), src.shape[1] * src.shape[2], w16.data_ptr(), c["b"].data_ptr(), p(resid), p(alpha),
                 p(y), p(y2), p(y216), plane, B, T_in, T_rows, T_out, cin, cout, taps, in_stride, dil, pad, out_stride, out_off, act,
-                eng.stream()), "vn_conv1d_bf16x3")
+                eng.stream()), "vn_conv1d_f16x2" if h2 else "vn_conv1d_bf16x3")
         else:
             w = c["w"] if phase is None else c["w"][phase]
             eng.check(self.lib.vn_conv1d_f32(
-                eng.handle, src.data_ptr(), w.data_ptr(), c["b"].data_ptr(), p(resid), p(alpha), p(y), p(y2), p(y216), plane,
+                eng.handle, src.data_ptr(), w.data_ptr(), c["b"].data_ptr(), p(resid), p(alpha), p(y), p(y2), p(y216),
+                -plane if h2 else plane,        # the fp32 kernel writes two fp16 planes when the stride is negative
                 B, T_in, T_rows, T_out, cin, cout, taps, in_stride, dil, pad, out_stride, out_off, act, eng.stream()), "vn_conv1d_f32")
         return y, sn
 
@@ -438,7 +449,7 @@ class DacCodec:
             f0 = self._fmt(blk["res"][0]["c7"])
             y = torch.empty(B, T_out, up["cout"], device=self.device)
             y2 = _Act(torch.empty(B, T_out, up["cout"], device=self.device) if f0 == "f32" else None,
-                      torch.empty(3, B * T_out, up["cout"], device=self.device, dtype=torch.bfloat16) if f0 == "x3" else None)
+                      self._empty_planes(B * T_out, up["cout"]) if f0 == "x3" else None)
             for ph in range(st):        # polyphase: output rows t = t'*st + ph - pad read x[t'] and x[t'-1]
                 self._conv(s, up, phase=ph, taps=2, T_in=T, T_rows=T + 1, T_out=T_out, in_stride=1, dil=-1, pad=0,
                            out_stride=st, out_off=ph - pad, alpha=blk["res"][0]["a1"], s_fmt=f0, out=(y, y2))

@@ -189,7 +189,10 @@ __global__ __launch_bounds__(256, 2) void vn_conv1d_f32_kernel(vn_conv_args p, i
 #pragma unroll
                 for (int e = 0; e < 4; ++e) w4[e] = vn_snake(v[e], al4[e], inv4[e]);
                 if (p.y2) *(f32x4*)(p.y2 + o) = w4;
-                if (p.y2_16) vn_store_bf16x4(p.y2_16 + o, p.y2_plane, w4);
+                if (p.y2_16) {                                  // y2_plane < 0: two fp16 planes (f16x2), -y2_plane apart
+                    if (p.y2_plane < 0) vn_store_h2x4(p.y2_16 + o, -p.y2_plane, w4);
+                    else vn_store_bf16x4(p.y2_16 + o, p.y2_plane, w4);
+                }
             }
         }
     }
@@ -221,7 +224,7 @@ extern "C" int vn_conv1d_f32(vn_ctx* ctx, const float* x, const float* w, const 
                              int T_out, int C_in, int C_out, int taps, int in_stride, int dil, int pad, int out_stride, int out_off,
                              int act, void* stream) {
     if (!ctx || !x || !w || (!y && !y2 && !y2_16)) return VN_ERR_INVALID;
-    if (y2_16 && (y2_plane <= 0 || (y2_plane & 3) || ((uintptr_t)y2_16 & 7)))
+    if (y2_16 && (y2_plane == 0 || ((y2_plane < 0 ? -y2_plane : y2_plane) & 3) || ((uintptr_t)y2_16 & 7)))
         return vn_fail(ctx, VN_ERR_INVALID, "conv1d: the plane output needs an 8-byte aligned base and a plane stride %% 4 == 0%s", "");
     if (C_in % BK) return vn_fail(ctx, VN_ERR_INVALID, "conv1d: C_in=%s%ld must be a multiple of 32", "", C_in);
     if (C_out % 4) return vn_fail(ctx, VN_ERR_INVALID, "conv1d: C_out=%s%ld must be a multiple of 4", "", C_out);

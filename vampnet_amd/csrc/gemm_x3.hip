@@ -363,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
     constexpr int NP = FMT ? 2 : 3;
     using G = x3_geo<CFG, NP>;
     constexpr int RI = G::RI, CJ = G::CJ;
-    static_assert(!FMT || EPI != VN_EPI_CONV, "the codec convolutions stay on bf16x3");        // FMT = 1: ABL bit 2 = DMA never waited for
+    // FMT = 1: ABL bit 2 = DMA never waited for
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                 for (int j = 0; j < CJ; ++j) acc[i][j] += acc_lo[i][j] * VN_H2_INV_SCALE;
         }
         if constexpr (EPI == VN_EPI_CONV) {
-            x3_epilogue_staged<EPI, CFG>(p, acc, m0, n0, wave, lane, lds);      // the launcher guarantees the alignment it needs
+            x3_epilogue_staged<EPI, CFG, FMT>(p, acc, m0, n0, wave, lane, lds);      // the launcher guarantees the alignment it needs
         } else {
             if (p.staged) x3_epilogue_staged<EPI, CFG, FMT>(p, acc, m0, n0, wave, lane, lds);
             else x3_epilogue<EPI, CFG, FMT>(p, acc, m0, n0, wm, wn, lane);
@@ -885,7 +885,6 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
     if (epilogue == VN_EPI_CONV ? (a.N % 16) : (a.N % 64))
         return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: N=%s%ld must be a multiple of 64 (16 for the convolution epilogue)", "", a.N);
     const bool h2 = a.bf16 == 3;
-    if (h2 && epilogue == VN_EPI_CONV) return vn_fail(ctx, VN_ERR_UNSUPPORTED, "gemm_x3: the convolution mode takes bf16x3 planes%s", "");
     if ((a.a_plane != (h2 ? VN_PLANES_TILED_H2 : VN_PLANES_TILED) && (a.a_plane <= 0 || (a.a_plane & 7))) ||
         (!a.w_tiled && (a.w_plane <= 0 || (a.w_plane & 7))))
         return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: plane strides must be positive multiples of 8 elements (or the tiled layout of the format)%s", "");
@@ -897,7 +896,8 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
             (rc = x3_attrs<VN_EPI_CONV>(ctx)))
             return rc;
         if ((rc = x3_attrs<VN_EPI_STORE, 1>(ctx)) || (rc = x3_attrs<VN_EPI_BIAS, 1>(ctx)) || (rc = x3_attrs<VN_EPI_RESIDUAL, 1>(ctx)) ||
-            (rc = x3_attrs<VN_EPI_GEGLU, 1>(ctx)) || (rc = x3_attrs<VN_EPI_QKV, 1>(ctx)) || (rc = x3_attrs<VN_EPI_QKV3, 1>(ctx)))
+            (rc = x3_attrs<VN_EPI_GEGLU, 1>(ctx)) || (rc = x3_attrs<VN_EPI_QKV, 1>(ctx)) || (rc = x3_attrs<VN_EPI_QKV3, 1>(ctx)) ||
+            (rc = x3_attrs<VN_EPI_CONV, 1>(ctx)))
             return rc;
         if ((rc = x3_attrs_abl<1, 1>(ctx)) || (rc = x3_attrs_abl<1, 2>(ctx)) || (rc = x3_attrs_abl<1, 3>(ctx)) ||
             (rc = x3_attrs_abl<2, 1>(ctx)) || (rc = x3_attrs_abl<2, 2>(ctx)) || (rc = x3_attrs_abl<2, 3>(ctx)) ||
@@ -935,10 +935,11 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
             if (a.a_plane <= 0) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3/conv: the activation planes must be planar%s", "");
             if ((!a.C && !a.Y2 && !a.C16) || ((a.Y2 || a.C16) && !a.alpha))
                 return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3/conv: needs an output, and alpha for the snake outputs%s", "");
+            // C16 planes: planar, in the operands' format (c_plane > 0 for bf16x3, < -2 for f16x2: the producers' stride convention)
             if ((((uintptr_t)a.C | (uintptr_t)a.Y2 | (uintptr_t)a.resid | (uintptr_t)a.bias | (uintptr_t)a.alpha) & 15) || ((uintptr_t)a.C16 & 7) ||
-                (a.C16 && (a.c_plane <= 0 || (a.c_plane & 3))))
+                (a.C16 && (h2 ? (a.c_plane >= VN_PLANES_TILED_H2 || ((-a.c_plane) & 3)) : (a.c_plane <= 0 || (a.c_plane & 3)))))
                 return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3/conv: outputs / bias / alpha must be 16-byte aligned%s", "");
-            return x3_launch<VN_EPI_CONV>(ctx, a, s);
+            return h2 ? x3_launch<VN_EPI_CONV, 1>(ctx, a, s) : x3_launch<VN_EPI_CONV>(ctx, a, s);
     }
     return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: unknown epilogue %s%ld", "", epilogue);
 }
@@ -1042,10 +1043,10 @@ extern "C" int vn_gemm_f16x2(vn_ctx* ctx, const void* A2, int64_t a_plane, const
 // of the channels-last input [3][B T_in][C_in] (x_plane elements apart; written by the producing layer's epilogue), w_tiled = the
 // TILED planes of w [C_out][taps C_in] (vn_split3_f32 + vn_tile_planes_bf16x3 at load).  Outputs as in vn_conv1d_f32, plus
 // y2_16 = snake(y) as split planes (y2_plane apart) for a consumer on this pipe.
-extern "C" int vn_conv1d_bf16x3(vn_ctx* ctx, const void* x16, int64_t x_plane, const void* w_tiled, const float* bias, const float* resid,
-                                const float* alpha, float* y, float* y2, void* y2_16, int64_t y2_plane, int B, int T_in, int T_rows,
-                                int T_out, int C_in, int C_out, int taps, int in_stride, int dil, int pad, int out_stride, int out_off,
-                                int act, void* stream) {
+static int conv1d_planes(vn_ctx* ctx, int h2, const void* x16, int64_t x_plane, const void* w_tiled, const float* bias, const float* resid,
+                         const float* alpha, float* y, float* y2, void* y2_16, int64_t y2_plane, int B, int T_in, int T_rows,
+                         int T_out, int C_in, int C_out, int taps, int in_stride, int dil, int pad, int out_stride, int out_off,
+                         int act, void* stream) {
     if (!ctx || !x16 || !w_tiled || (!y && !y2 && !y2_16)) return VN_ERR_INVALID;
     if (B <= 0 || T_rows <= 0 || C_out <= 0 || taps <= 0 || C_in <= 0) return vn_fail(ctx, VN_ERR_INVALID, "conv1d_bf16x3: empty problem%s", "");
     if ((long)B * T_rows > 0x7fffffffL) return vn_fail(ctx, VN_ERR_INVALID, "conv1d_bf16x3: too many rows%s", "");
@@ -1054,13 +1055,30 @@ extern "C" int vn_conv1d_bf16x3(vn_ctx* ctx, const void* x16, int64_t x_plane, c
         VN_HIP_CHECK(ctx, hipMemset(ctx->zero_page, 0, 1024));
     }
     vn_gemm_args a{};
-    a.A = (const float*)x16; a.W = (const float*)w_tiled; a.bias = bias; a.C = y; a.C16 = (uint16_t*)y2_16; a.c_plane = y2_plane;
-    a.bf16 = 2; a.a_plane = x_plane; a.w_tiled = 1;
+    a.A = (const float*)x16; a.W = (const float*)w_tiled; a.bias = bias; a.C = y; a.C16 = (uint16_t*)y2_16;
+    a.c_plane = h2 ? -y2_plane : y2_plane;               // planar planes; a negative stride names the f16x2 format (vn_common.h)
+    a.bf16 = h2 ? 3 : 2; a.a_plane = x_plane; a.w_tiled = 1;
     a.M = B * T_rows; a.N = C_out; a.K = taps * C_in; a.ldc = C_out;
     a.conv_taps = taps; a.conv_cin = C_in; a.conv_tin = T_in; a.conv_trows = T_rows; a.conv_in_stride = in_stride; a.conv_dil = dil;
     a.conv_pad = pad; a.conv_tout = T_out; a.conv_out_stride = out_stride; a.conv_out_off = out_off; a.conv_act = act;
     a.zeros16 = (const uint16_t*)ctx->zero_page; a.resid = resid; a.alpha = alpha; a.Y2 = y2;
     return vn_launch_gemm_x3(ctx, a, VN_EPI_CONV, (hipStream_t)stream);
+}
+extern "C" int vn_conv1d_bf16x3(vn_ctx* ctx, const void* x16, int64_t x_plane, const void* w_tiled, const float* bias, const float* resid,
+                                const float* alpha, float* y, float* y2, void* y2_16, int64_t y2_plane, int B, int T_in, int T_rows,
+                                int T_out, int C_in, int C_out, int taps, int in_stride, int dil, int pad, int out_stride, int out_off,
+                                int act, void* stream) {
+    return conv1d_planes(ctx, 0, x16, x_plane, w_tiled, bias, resid, alpha, y, y2, y2_16, y2_plane, B, T_in, T_rows, T_out, C_in, C_out, taps,
+                         in_stride, dil, pad, out_stride, out_off, act, stream);
+}
+// the same operator on f16x2 operands: x16 = TWO planar fp16 planes [2][B T_in][C_in] (vn_split2_f16), w_tiled = the tiled f16x2 planes of
+// w (vn_split2_f16 with tiled = 1), y2_16 = snake(y) as two planar fp16 planes
+extern "C" int vn_conv1d_f16x2(vn_ctx* ctx, const void* x16, int64_t x_plane, const void* w_tiled, const float* bias, const float* resid,
+                               const float* alpha, float* y, float* y2, void* y2_16, int64_t y2_plane, int B, int T_in, int T_rows,
+                               int T_out, int C_in, int C_out, int taps, int in_stride, int dil, int pad, int out_stride, int out_off,
+                               int act, void* stream) {
+    return conv1d_planes(ctx, 1, x16, x_plane, w_tiled, bias, resid, alpha, y, y2, y2_16, y2_plane, B, T_in, T_rows, T_out, C_in, C_out, taps,
+                         in_stride, dil, pad, out_stride, out_off, act, stream);
 }
 
 // planar split planes [3][rows][K] (plane_stride elements apart) -> the tiled layout the bf16x3 GEMM / convolution read weights in
