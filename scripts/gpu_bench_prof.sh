@@ -16,4 +16,5 @@ timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o write -
 cd $R
 python scripts/pmc_summary.py /tmp/pf FETCH_SIZE > $O/pmc_fetch_size.txt 2>&1
 python scripts/pmc_summary.py /tmp/pw WRITE_SIZE > $O/pmc_write_size.txt 2>&1
+python scripts/traffic_from_pmc.py $O/pmc_fetch_size.txt $O/pmc_write_size.txt vn_gemm_x3 $O/traffic_gemm_x3.json > /dev/null 2>&1
 head -12 $O/last_vamp_kernel_stats.txt; head -6 $O/pmc_fetch_size.txt; head -6 $O/pmc_write_size.txt
