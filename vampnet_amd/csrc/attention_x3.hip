@@ -17,6 +17,14 @@
 //              masked value is finite).
 // Softmax probabilities are split into their three planes in registers (exact for any fp32 value).
 //
+// f16x2 precision (round 3; NP = 2 in the templates below): the same kernels on fp16 TWO-plane operands, h0 = fp16(x), h1 = fp16(x - h0)
+// WITHOUT the 2^11 of the GEMM format, so that the three kept products (a0 b1, a1 b0, a0 b0) go into the ONE accumulator the six
+// bf16 products use (a second S / O accumulator would cost the third wave per SIMD): half the MFMAs, 2/3 of the tile bytes, 28 fewer
+// VGPRs.  An unscaled remainder falls into fp16's subnormal range for |x| < 0.125 — exact to 2^-25 absolute there instead of 2^-22
+// relative — which moves a score by < 3e-7; the softmax weights (<= e^6) and V carry a factor 16 each (16 P < 6.5e3), divided out
+// with l at the end.  Measured against float64 (tests/test_gpu_kernels.py): 1.2e-6 max, the bf16x3 operands 1.1e-6, the fp32-input
+// kernel 2.6e-6.  B = 8: 58.8 us vs 86.5 us (profiles/r03_attention_f16x2_vs_bf16x3.txt).
+//
 // Per wave: 32 query columns.
 //   S^T[key][q] = K[key][:] . Q[q][:]      A = K tile rows (LDS), B = Q (registers, loaded once)
 //   O^T[d][q]   = V^T[d][key] . P^T[key][q]  A = V^T tile rows (LDS), B = P (the registers the softmax produced)

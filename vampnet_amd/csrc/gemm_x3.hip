@@ -10,6 +10,30 @@
 // cores run bf16 at 16x the fp32-input MFMA rate (MI355X_MICROARCH.md: 2.5 PF vs 157 TF dense), so six passes cost
 // 6/16 of the exact-fp32 kernel's matrix time: the ceiling moves from 157 to ~417 fp32-equivalent TFLOP/s.
 //
+// SECOND OPERAND FORMAT, "f16x2" (round 3; FMT = 1 below, the model's default precision): TWO fp16 planes per operand,
+//     h0 = fp16(x),  h1 = fp16((x - h0) * 2^11)          (vn_common.h vn_split2h)
+// fp16 carries 11 significand bits, the remainder of the round-to-nearest conversion is <= 2^-11 |x| and exact in fp32, and the
+// 2^11 puts it into the same binades as h0, so x = h0 + 2^-11 h1 to within 2^-22 |x| over fp16's whole normal range (6.1e-5 ..
+// 65504, below it to 2^-25 absolute: gfx950 produces and multiplies fp16 subnormals, scripts/ubench/f16_denorm_probe.hip; beyond
+// it the split saturates).  The product keeps THREE terms,
+//     A W^T  ~=  A0 W0 + 2^-11 (A0 W1 + A1 W0),
+// as three v_mfma_f32_32x32x16_f16 per k-step into TWO fp32 accumulators (the second one joins times 2^-11 before the epilogue);
+// the dropped A1 W1 is 2^-22 of the leading term.  Operand error 2^-22 is four times the representation error of fp32 itself and
+// random in sign: on the model's shapes the result is 2.4e-7 rms from the float64 product — what an fp32-accumulating GEMM of the
+// UNSPLIT operands gives (2.5e-7), because the fp32 accumulation is the larger error in both (tests/test_gpu_f16x2.py,
+// tests/test_host_logic.py::test_f16x2_split_numerics_on_the_host) — at HALF the matrix work and 2/3 of the operand bytes of bf16x3:
+// the ceiling moves from 417 to 833 fp32-equivalent TFLOP/s, measured 1.5-1.7x on the model's shapes
+// (profiles/r03_gemm_f16x2_vs_bf16x3.txt).  No per-tensor scaling is needed (both planes keep 11 bits wherever the value sits in
+// fp16's range); what fp16 cannot hold is |x| > 65504 — no activation or weight of this model family comes near it (the reference
+// itself runs bf16 autocast on a GPU), and the split clamps instead of producing inf.  The backward GEMMs of training stay on
+// fp32 / bf16x3: gradients live far below fp16's range.
+// Geometry: a stage holds 2 x (BM + 128) rows = 32 / 48 / 40 KiB, THREE stages are resident for every tile height; schedule: one
+// phase per k-tile and wave group (fragments of both k-steps, 2 x 3 products; two barriers per k-tile) — see the k-loop.
+// Ablations (scripts/gemm_h2_ablation.py, profiles/r03_gemm_f16x2_ablation.txt): without the DMA -15 %, without the fragment reads
+// -2.5 %, MFMAs + barriers alone 428 TF-eq = 1283 TF executed on the QKV shape — the same executed rate the bf16x3 kernel stops at;
+// moving the DMA issue between the phases or never waiting for it changes nothing: this format too runs at the chip's power limit,
+// and what is left to gain is bytes moved per flop, not schedule.
+//
 // Kernel: one 512-thread block (8 waves) per output tile of BM x 128, one block per CU, two waves per SIMD; three tile
 // configurations (x3_geo below): 128 x 128 (waves 4 x 2, wave tile 32 x 64), 256 x 128 (4 x 2, 64 x 64) and 192 x 128 (2 x 4,
 // 96 x 32: the height that fills whole rounds of 256 CUs on the model's B = 8 shapes); x3_choose picks height and k-split per launch.
