@@ -167,3 +167,17 @@ def test_split_plane_attention_path_at_every_tile_height(eng, prec, dims, B, T):
     ref = O.forward(sd, dims, O.from_codes(sd, cb, codes))
     assert (outs[192].cpu() - ref).abs().max().item() <= TM.LOGIT_ATOL_TINY
     assert (outs[192] - plain).abs().max().item() <= TM.LOGIT_ATOL_TINY
+
+
+def test_f16x2_refuses_weights_beyond_fp16_range(eng):
+    """fp16 planes saturate beyond +-65504: a model with such a weight is refused in f16x2 (and named), bf16x3 takes it"""
+    from vampnet_amd.engine import VampNetModel
+    cb = W.synth_codebooks()
+    sd = {k: v.clone() for k, v in W.synth_state_dict(W.TINY_COARSE_DIMS, 0).items()}
+    key = next(k for k, v in sd.items() if k.endswith("w_1.weight"))
+    sd[key][0, 0] = 1.0e5
+    with pytest.raises(ValueError, match="f16x2"):
+        VampNetModel(eng, sd, cb, max_batch=1, max_T=64, precision="f16x2", **model_kwargs(W.TINY_COARSE_DIMS))
+    m = VampNetModel(eng, sd, cb, max_batch=1, max_T=64, precision="bf16x3", **model_kwargs(W.TINY_COARSE_DIMS))
+    codes = W.synth_codes(1, W.TINY_COARSE_DIMS["n_codebooks"], 40, seed=2)
+    assert torch.isfinite(m.forward_codes(codes)).all()
