@@ -68,17 +68,42 @@ __global__ __launch_bounds__(256) void vn_splitk_reduce_rmsnorm_kernel(const flo
     const f32x4* pr = (const f32x4*)partial + (size_t)row * (D >> 2);
     f32x4* xr = (f32x4*)(x + (size_t)row * D);
     f32x4 v[VEC];
+    if (nsplit <= 4) {
+        // every load of the row is issued before the first add (the launch is a few hundred waves of ~25 KB each at one sequence:
+        // with the loads inside the split loop it ran at the latency of 5 x nsplit dependent round trips, 10.7 us where the bytes
+        // need 4); the adds keep the order split 0, 1, .., residual — bitwise the loop below and the two-kernel form
+        f32x4 part[4][VEC], res[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        f32x4 a = pr[lane + 64 * i];
-        for (int sp = 1; sp < nsplit; ++sp) {
-            const f32x4 b = pr[lane + 64 * i + sp * plane4];
-            a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+        for (int sp = 0; sp < 4; ++sp)
+            if (sp < nsplit) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) part[sp][i] = pr[lane + 64 * i + sp * plane4];
+            }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) res[i] = xr[lane + 64 * i];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            f32x4 a = part[0][i];
+#pragma unroll
+            for (int sp = 1; sp < 4; ++sp)
+                if (sp < nsplit) { a[0] += part[sp][i][0]; a[1] += part[sp][i][1]; a[2] += part[sp][i][2]; a[3] += part[sp][i][3]; }
+            a[0] += res[i][0]; a[1] += res[i][1]; a[2] += res[i][2]; a[3] += res[i][3];
+            xr[lane + 64 * i] = a;
+            v[i] = a;
         }
-        const f32x4 r = xr[lane + 64 * i];
-        a[0] += r[0]; a[1] += r[1]; a[2] += r[2]; a[3] += r[3];
-        xr[lane + 64 * i] = a;
-        v[i] = a;
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            f32x4 a = pr[lane + 64 * i];
+            for (int sp = 1; sp < nsplit; ++sp) {
+                const f32x4 b = pr[lane + 64 * i + sp * plane4];
+                a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+            }
+            const f32x4 r = xr[lane + 64 * i];
+            a[0] += r[0]; a[1] += r[1]; a[2] += r[2]; a[3] += r[3];
+            xr[lane + 64 * i] = a;
+            v[i] = a;
+        }
     }
     vn_rmsnorm_row<VEC>(v, w, y, y16, plane16, row, D, eps, lane);
 }
