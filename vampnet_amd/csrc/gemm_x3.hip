@@ -563,9 +563,9 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             // (2 x 3 x RI x CJ MFMAs): two barriers per k-tile instead of four.  Three buffers, tile kt in buffer kt % 3: phase
             // 2 kt = group 0 loads tile kt, 2 kt + 1 = group 0 computes it while group 1 loads it, 2 kt + 2 = group 1 computes it.
             // Tile kt + 2 goes into the buffer of tile kt - 1 (last read in phase 2 kt - 1) and is first read in phase 2 kt + 4:
-            // every wave issues its pieces in phase 2 kt + 1 (group 0 between the MFMAs of its compute phase, group 1 after the
-            // reads of its load phase) and waits for them at the end of phase 2 kt + 3 with the pieces of tile kt + 3 in flight
-            // (counted vmcnt) — two full phases between issue and wait.
+            // every wave issues its pieces after the fragment reads of its own load phase and waits for them at the end of its NEXT
+            // load phase with the pieces of tile kt + 3 in flight (counted vmcnt) — two full phases between issue and wait.  (Issuing
+            // group 0's pieces between the MFMAs of its compute phase instead measured the same: profiles/r03_gemm_f16x2_ablation.txt.)
             Frags f1;
             stage(0, 0);
             if (nk > 1) stage(1, X3_KT);
@@ -583,13 +583,11 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                     load_frags(f, b, 0);
                     load_frags(f1, b, 1);
                 }
-                if (grp || p.group_m >= 0) {
-                    if (more) {
-                        stage(b2, (kt + 2) * X3_KT);
-                        if constexpr (!(ABL & 4)) X3_VMCNT(G::NPW);     // tile kt + 1 landed (this wave's pieces); tile kt + 2 in flight
-                    } else {
-                        if constexpr (!(ABL & 4)) X3_VMCNT(0);
-                    }
+                if (more) {
+                    stage(b2, (kt + 2) * X3_KT);
+                    if constexpr (!(ABL & 4)) X3_VMCNT(G::NPW);         // tile kt + 1 landed (this wave's pieces); tile kt + 2 in flight
+                } else {
+                    if constexpr (!(ABL & 4)) X3_VMCNT(0);
                 }
                 X3_LGKM0();
                 X3_BARRIER();
@@ -599,13 +597,9 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
 #pragma unroll
                 for (int t = 0; t < 6; ++t) {
                     mac_prod(t < 3 ? f : f1, t < 3 ? t : t - 3);
-                    if (!grp && p.group_m < 0 && more && t < G::NPW) stage_piece(b2, (kt + 2) * X3_KT, t);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_s_setprio(0);
-                if (!grp && p.group_m < 0) {
-                    if (more) X3_VMCNT(G::NPW); else X3_VMCNT(0);
-                }
                 if (!(last && grp)) X3_BARRIER();           // group 1's last compute phase has no partner phase
                 b = b == 2 ? 0 : b + 1;
             }
