@@ -554,10 +554,10 @@ extern "C" int vn_model_set_f16x2(vn_model* m, int on) {
     if (m->D % 64) return vn_fail(m->ctx, VN_ERR_UNSUPPORTED, "f16x2 needs d_model %% 64 == 0%s", "");
     int rc;
     if ((rc = plane_buffers(m, true))) return rc;
-    if (!m->w_h2) {
+    {   // (re)built on every call: the buffer keeps its address (captured graphs stay valid), a blob updated in place is picked up
         int64_t n = 0;
         vn_weights_size(&m->d, &n);
-        if ((rc = dev_alloc(m->ctx, &m->w_h2, (size_t)2 * n))) return rc;
+        if (!m->w_h2 && (rc = dev_alloc(m->ctx, &m->w_h2, (size_t)2 * n))) return rc;
         VN_HIP_CHECK(m->ctx, hipDeviceSynchronize());          // a setup call: fence it against whatever stream wrote the blob
         const long D = m->D;
         auto build = [&](int id, int layer, long rows, int K) {
@@ -568,7 +568,7 @@ extern "C" int vn_model_set_f16x2(vn_model* m, int on) {
             (rc = build(VN_W_QKV, l, 3 * D, (int)D)) || (rc = build(VN_W_WO, l, D, (int)D)) || (rc = build(VN_W_W1, l, 4 * D, (int)D)) ||
                 (rc = build(VN_W_W2, l, D, (int)(2 * D)));
         if (!rc) rc = build(VN_W_CLS_W, 0, (long)m->Cp * m->d.vocab, (int)D);
-        if (rc) { (void)hipFree(m->w_h2); m->w_h2 = nullptr; return rc; }
+        if (rc) return rc;
         VN_HIP_CHECK(m->ctx, hipDeviceSynchronize());
     }
     m->blob16 = m->w_h2;

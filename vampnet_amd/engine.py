@@ -331,7 +331,8 @@ class VampNetModel:
         elif precision == "f16x2":
             # fp32-grade GEMMs as three fp16 matrix-core products of two-plane operand splits (gemm_x3.hip); the engine builds the
             # weight planes from the fp32 blob itself
-            wmax = float(self.blob.abs().max())
+            lo, hi = torch.aminmax(self.blob)               # (no |blob| temporary: the blob is 1.3 GB)
+            wmax = max(abs(float(lo)), abs(float(hi)))
             if not wmax < 65504.0:          # also catches NaN; fp16 planes saturate beyond that: refuse instead
                 raise ValueError(f"precision='f16x2' cannot hold these weights (max |w| = {wmax:g} >= 65504): use precision='bf16x3'")
             self.engine.check(self.lib.vn_model_set_f16x2(self.handle, 1), "vn_model_set_f16x2")
