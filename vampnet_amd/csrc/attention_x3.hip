@@ -180,25 +180,43 @@ __device__ __forceinline__ void ax_qk(f32x16& sacc, const float* Ks, const f32x4
 template <int NP, bool FULL>
 __device__ __forceinline__ float ax_probs(const f32x16& sacc, f32x4 (&pf)[NP][2], float m_run) {
     float lsum = 0.f;
+    if constexpr (NP == 2) {
+        // fp16 planes: the weights carry a factor 16 (vn_common.h vn_split2u), which costs nothing when it rides in the exponent:
+        // P' = 16 exp(s - m) = 2^(s log2 e + c), c = 4 - m log2 e once per tile — ONE fma and one v_exp_f32 per score instead of the
+        // six instructions of ax_exp (PMC: this kernel issues 9.9 VALU per MFMA, profiles/r03_h2_pmc_attention.txt).  The two
+        // roundings (c and the fma) move the exponent by <= ulp(|m log2 e|) / 2 + ulp(|s log2 e + c|) / 2, i.e. a weight by a few
+        // 1e-7 relative at |scores| ~ 10 — the size of the rounding the scores themselves carry out of their fp32 accumulation; c is
+        // common to every weight formed under the same reference max, so it cancels between O and l.  A masked score (-inf) gives
+        // 2^-inf = 0 without a clamp.  l is summed in the same scaled units (the kernels divide by 16 l' at the end).
+        const float c = fmaf(m_run, -1.44269502162933349609375f, 4.0f);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        f32x8 pe;
+        for (int s = 0; s < 2; ++s) {
+            f32x8 pe;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            pe[e] = ax_exp<FULL>(sacc[8 * s + e] - m_run);
-            lsum += pe[e];
+            for (int e = 0; e < 8; ++e) {
+                pe[e] = __builtin_amdgcn_exp2f(fmaf(sacc[8 * s + e], 1.44269502162933349609375f, c));
+                lsum += pe[e];
+            }
+            f16x8 p0, p1;
+            vn_split2u_x8(pe, p0, p1);                      // <= 16 e^AX_THR < 6.5e3
+            pf[0][s] = __builtin_bit_cast(f32x4, p0); pf[1][s] = __builtin_bit_cast(f32x4, p1);
         }
-        if constexpr (NP == 3) {
+        return lsum;
+    } else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x8 pe;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pe[e] = ax_exp<FULL>(sacc[8 * s + e] - m_run);
+                lsum += pe[e];
+            }
             bf16x8 p0, p1, p2;
             vn_split3_x8(pe, p0, p1, p2);
             pf[0][s] = __builtin_bit_cast(f32x4, p0); pf[1][s] = __builtin_bit_cast(f32x4, p1); pf[2][s] = __builtin_bit_cast(f32x4, p2);
-        } else {
-            f16x8 p0, p1;
-            vn_split2u_x8(pe * 16.0f, p0, p1);              // <= 16 e^AX_THR < 6.5e3
-            pf[0][s] = __builtin_bit_cast(f32x4, p0); pf[1][s] = __builtin_bit_cast(f32x4, p1);
         }
+        return lsum;
     }
-    return lsum;
 }
 template <int NP>
 __device__ __forceinline__ void ax_softmax(f32x16& sacc, f32x4 (&pf)[NP][2], float& m_run, float& l_run, f32x16 (&o)[2], int key0,
@@ -509,7 +527,7 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
         const float m_all = fmaxf(m0, m1);
         const float s0 = vn_exp_neg(m0 - m_all), s1 = vn_exp_neg(m1 - m_all);      // a half without tiles holds m = -inf, l = 0
         const float l_all = im0[2112 + lane] * s0 + im1[2112 + lane] * s1;
-        const float l_tot = (l_all + __shfl_xor(l_all, 32)) * (NP == 2 ? 256.0f : 1.0f);       // f16: P and V carry 16 each
+        const float l_tot = (l_all + __shfl_xor(l_all, 32)) * (NP == 2 ? 16.0f : 1.0f);       // f16: l' = 16 l, O' = 256 O
         if (active && qrow < T) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -551,7 +569,7 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
         tick(3);
     }
     // ---- finish: the two lanes of a query add their row sums; normalise; store
-    const float l_tot = (l_run + __shfl_xor(l_run, 32)) * (NP == 2 ? 256.0f : 1.0f);
+    const float l_tot = (l_run + __shfl_xor(l_run, 32)) * (NP == 2 ? 16.0f : 1.0f);
     if (active && qrow < T) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -689,7 +707,7 @@ __global__ __launch_bounds__(KS * 64, 2) void vn_attention_x3_split_kernel(const
             sc[w] = vn_exp_neg(smem[w * AXS + 2048 + lane] - m_all);
             l_all += smem[w * AXS + 2112 + lane] * sc[w];
         }
-        const float l_tot = (l_all + __shfl_xor(l_all, 32)) * (NP == 2 ? 256.0f : 1.0f);       // f16: P and V carry 16 each
+        const float l_tot = (l_all + __shfl_xor(l_all, 32)) * (NP == 2 ? 16.0f : 1.0f);       // f16: l' = 16 l, O' = 256 O
         if (qrow < T) {
 #pragma unroll
             for (int i = 0; i < 8 / KS; ++i) {
@@ -701,7 +719,7 @@ __global__ __launch_bounds__(KS * 64, 2) void vn_attention_x3_split_kernel(const
             }
         }
     } else {
-        const float l_tot = (l_run + __shfl_xor(l_run, 32)) * (NP == 2 ? 256.0f : 1.0f);
+        const float l_tot = (l_run + __shfl_xor(l_run, 32)) * (NP == 2 ? 16.0f : 1.0f);
         if (qrow < T) {
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
