@@ -96,7 +96,9 @@ def main(argv=None):
     ap.add_argument("--seeds", type=int, nargs="+", default=[0])
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--engine", choices=["hip", "oracle"], default="hip")
-    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="bf16x3")
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x2"], default="f16x2",
+                    help="f16x2 = the engine's default; real checkpoints are also the first chance to see activation ranges of a TRAINED "
+                         "model: if the tokens part from the oracle here but not with --precision bf16x3, suspect fp16 saturation (|x| > 65504)")
     ap.add_argument("--trusted", action="store_true", help="allow torch.package archives / full unpickling (they execute code)")
     args = ap.parse_args(argv)
     with torch.no_grad():
