@@ -181,3 +181,22 @@ def test_f16x2_refuses_weights_beyond_fp16_range(eng):
     m = VampNetModel(eng, sd, cb, max_batch=1, max_T=64, precision="bf16x3", **model_kwargs(W.TINY_COARSE_DIMS))
     codes = W.synth_codes(1, W.TINY_COARSE_DIMS["n_codebooks"], 40, seed=2)
     assert torch.isfinite(m.forward_codes(codes)).all()
+
+
+def test_f16x2_probe_refuses_activations_beyond_fp16_range(eng):
+    """weights inside fp16's range whose ACTIVATIONS leave it (a feed-forward scaled by 3e3: GEGLU outputs ~ 1e7): the probe forward
+    at precision selection notices (saturated planes -> logits far from the fp32 path) and refuses the model; bf16x3 runs it"""
+    from vampnet_amd.engine import VampNetModel
+    cb = W.synth_codebooks()
+    sd = {k: v.clone() for k, v in W.synth_state_dict(W.TINY_COARSE_DIMS, 0).items()}
+    for k in sd:
+        if k.endswith("w_1.weight"):
+            sd[k] *= 3.0e3
+    assert max(float(v.abs().max()) for v in sd.values()) < 6.0e4
+    with pytest.raises(ValueError, match="probe forward"):
+        VampNetModel(eng, sd, cb, max_batch=1, max_T=64, precision="f16x2", **model_kwargs(W.TINY_COARSE_DIMS))
+    m = VampNetModel(eng, sd, cb, max_batch=1, max_T=64, precision="bf16x3", **model_kwargs(W.TINY_COARSE_DIMS))
+    codes = W.synth_codes(1, W.TINY_COARSE_DIMS["n_codebooks"], 40, seed=2)
+    ref = O.forward(sd, W.TINY_COARSE_DIMS, O.from_codes(sd, cb, codes))
+    got = m.forward_codes(codes).cpu()
+    assert torch.isfinite(got).all() and (got - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())

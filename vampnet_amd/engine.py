@@ -336,11 +336,35 @@ class VampNetModel:
             if not wmax < 65504.0:          # also catches NaN; fp16 planes saturate beyond that: refuse instead
                 raise ValueError(f"precision='f16x2' cannot hold these weights (max |w| = {wmax:g} >= 65504): use precision='bf16x3'")
             self.engine.check(self.lib.vn_model_set_f16x2(self.handle, 1), "vn_model_set_f16x2")
+            self._probe_f16x2()
         elif precision == "f32":
             self.engine.check(self.lib.vn_model_set_bf16(self.handle, None), "vn_model_set_bf16")
         else:
             raise ValueError("precision must be 'f32', 'f16x2', 'bf16x3' or 'bf16'")
         self.precision = precision
+
+    def _probe_f16x2(self):
+        """fp16 planes saturate beyond +-65504.  The weights were checked above; activations depend on the weights
+        AND the input, so this is a probe, not a proof: one short forward in f16x2 against the same forward on the exact-fp32 path.
+        A model whose activations leave fp16's range parts from it by orders of magnitude more than the 1e-5 the two precisions
+        differ by — refuse it (loudly) instead of returning saturated logits.  VN_F16X2_PROBE=0 skips the probe."""
+        import os
+        if os.environ.get("VN_F16X2_PROBE", "1") == "0":
+            return
+        T = max(1, min(int(self.dims.max_T), 96))
+        g = torch.Generator().manual_seed(0)
+        codes = torch.randint(0, self.vocab_size, (1, self.n_codebooks, T), generator=g)
+        codes[:, self.n_conditioning_codebooks:, ::2] = self.vocab_size                 # MASK tokens, as inside generate()
+        a = self.forward_codes(codes, layout="native").clone()
+        self.engine.check(self.lib.vn_model_set_bf16(self.handle, None), "vn_model_set_bf16")
+        b = self.forward_codes(codes, layout="native")
+        self.engine.check(self.lib.vn_model_set_f16x2(self.handle, 1), "vn_model_set_f16x2")
+        scale = max(1.0, float(b.abs().max()))
+        d = float((a - b).abs().max())
+        if not d <= 1e-3 * scale:        # NaN fails too; the precisions agree to ~1e-5 * scale when nothing saturates
+            self.engine.check(self.lib.vn_model_set_bf16(self.handle, None), "vn_model_set_bf16")
+            raise ValueError(f"precision='f16x2': a probe forward differs from the fp32 path by {d:g} (logit scale {scale:g}) — "
+                             "activations or weights of this model leave fp16's range; use precision='bf16x3'")
 
     @property
     def device(self):
