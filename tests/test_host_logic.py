@@ -384,6 +384,41 @@ def test_f16x2_split_numerics_on_the_host():
     assert plain > 2e-6                                             # weights ~ 1e-3: their remainders fall into fp16 subnormals
 
 
+def test_f16x2_attention_numerics_on_the_host():
+    """The numerics claim behind the attention of precision="f16x2" (attention_x3.hip, NP = 2), emulated with torch on the CPU: q / 8, k
+    and 16 v as fp16 two-plane splits WITHOUT the 2^11 on the second plane (one accumulator), softmax weights formed as
+    2^(s log2 e + c) with c = 4 - m log2 e (their factor 16 in the exponent), split the same way; three products per matrix product.
+    Against float64 the output error stays in the class of plain fp32 arithmetic — for random scores, for near-uniform attention
+    (small outputs), for peaky attention and with the reference max deferred by up to 6."""
+    g = torch.Generator().manual_seed(0)
+    LOG2E = 1.44269502162933349609375
+
+    def split2u(x):
+        x = x.clamp(-65504.0, 65504.0)
+        h0 = x.to(torch.float16).to(torch.float32)
+        return h0.double(), (x - h0).to(torch.float16).to(torch.float64)
+
+    T = 575
+    bias = 0.5 * torch.randn(T, T, generator=g)
+    cases = {"random": (1.0, 1.0, bias), "near-uniform": (0.05, 0.05, bias * 0), "peaky": (3.0, 3.0, bias)}
+    for name, (sq, sk, b) in cases.items():
+        q, k, v = sq * torch.randn(T, 64, generator=g), sk * torch.randn(T, 64, generator=g), torch.randn(T, 64, generator=g)
+        ref = torch.softmax(q.double() @ k.double().t() / 8 + b.double(), -1) @ v.double()
+        f32 = (torch.softmax(q @ k.t() / 8 + b, -1) @ v).double()
+        (q0, q1), (k0, k1), (v0, v1) = split2u(q * 0.125), split2u(k), split2u(v * 16.0)
+        S = (q0 @ k0.t() + q0 @ k1.t() + q1 @ k0.t() + b.double()).float()
+        for defer in (0.0, 6.0):                                   # reference max up to 6 below the row max: weights up to e^6
+            m = S.max(-1, keepdim=True).values - defer
+            c = torch.addcmul(torch.tensor(4.0), m, torch.tensor(-LOG2E))          # one fp32 fma per row (emulated: mul + add in fp32)
+            P = torch.exp2(torch.addcmul(c, S, torch.tensor(LOG2E)))               # 16 exp(s - m), fp32
+            assert float(P.max()) < 6.5e3
+            p0, p1 = split2u(P)
+            O = p0 @ v0 + p0 @ v1 + p1 @ v0
+            out = O / (P.double().sum(-1, keepdim=True) * 16.0)
+            err, err32 = (out - ref).abs().max().item(), (f32 - ref).abs().max().item()
+            assert err <= 2.0 * err32 + 3e-7 * ref.abs().max().item(), (name, defer, err, err32)
+
+
 def _click_track(sr, seconds, times, seed=0):
     rng = np.random.default_rng(seed)
     y = 1e-4 * rng.standard_normal(int(sr * seconds)).astype(np.float32)
