@@ -155,12 +155,23 @@ int vn_model_set_bf16(vn_model* model, const void* blob_bf16_dev);
  * apart (>= vn_weights_size, multiple of 8), 16-byte aligned device memory that must outlive the model; NULL switches
  * back to exact fp32.  Attention, norms, residual stream, softmax and sampling are the fp32 path unchanged.            */
 int vn_model_set_bf16x3(vn_model* model, const void* blob_planes_dev, int64_t plane_stride);
-/* Optional "f16x2" mode: fp32-GRADE GEMMs as THREE fp16 matrix-core products.  Every GEMM operand is two fp16 planes, h0 = fp16(x)
- * and h1 = fp16((x - h0) * 2^11) (vn_split2_f16 below): x = h0 + 2^-11 h1 to within 2^-22 |x| — four times fp32's own
- * representation error and random in sign, so the product stays below the rounding noise of an fp32-accumulating fp32 GEMM
- *  — at half of bf16x3's matrix time.  on != 0: the engine builds the weight planes from the fp32 blob it already
- * holds; on == 0: back to exact fp32.  Values beyond +-65504 saturate.  Attention runs on bf16x3 planes as in the bf16x3 mode.   */
+/* Optional, OPT-IN "f16x2" mode (NOT the default: its operands are NARROWER than fp32 — 22 significand bits, fp16's exponent range —
+ * so it is a fast mode with measured fp32-level results on well-scaled models, not an fp32-equivalent): GEMMs as THREE fp16
+ * matrix-core products.  Every GEMM operand is two fp16 planes, h0 = fp16(x) and h1 = fp16((x - h0) * 2^11) (vn_split2_f16 below):
+ * x = h0 + 2^-11 h1 to within 2^-22 |x| (four times fp32's own representation error) — at half of bf16x3's matrix time.
+ * on != 0: the engine builds the weight planes from the fp32 blob it already holds; on == 0: back to exact fp32.
+ * Attention runs on fp16 TWO-PLANE operands too (attention_x3.hip, NP = 2): q / 8 and k as h0 = fp16(x), h1 = fp16(x - h0) (second
+ * plane unscaled: values below 0.125 keep 2^-25 absolute instead of 2^-22 relative), V^T times 16 in the same form.
+ * RANGE: a GEMM operand with |x| >= 65504, or an attention value with |v| >= 4094 (16 v >= 65504), is CLAMPED — and recorded on the
+ * context's saturation ledger (vn_saturation_flags below); a caller must read the ledger after the work and repeat it in another
+ * precision if a word is set (vampnet_amd/engine.py does: the call is re-run on bf16x3).                                          */
 int vn_model_set_f16x2(vn_model* model, int on);
+/* The saturation ledger of the fp16 plane writers (f16x2 mode, vn_split2_f16, vn_conv1d_f16x2, vn_attention_f16x2): sticky device
+ * words, set when a value that was turned into fp16 planes did not fit (|x| >= 65504 or NaN) and was clamped.
+ * flags4[0] GEMM-operand planes (normalised rows, attention output, GEGLU output, codec activations), flags4[1] attention operands
+ * (q / 8, k, 16 v), flags4[2] weight planes, flags4[3] reserved.  Synchronises `stream`; clear != 0 resets the words.  A context that
+ * never runs an fp16-plane kernel always reads zeros.                                                                             */
+int vn_saturation_flags(vn_ctx* ctx, uint32_t* flags4, int clear, void* stream);
 /* dst16[q * plane_stride + i] = q-th split term of src[i], q = 0..2 (n % 4 == 0, src 16-byte aligned) */
 int vn_split3_f32(vn_ctx* ctx, const float* src, void* dst16, int64_t n, int64_t plane_stride, void* stream);
 

@@ -96,9 +96,11 @@ def main(argv=None):
     ap.add_argument("--seeds", type=int, nargs="+", default=[0])
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--engine", choices=["hip", "oracle"], default="hip")
-    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x2"], default="f16x2",
-                    help="f16x2 = the engine's default; real checkpoints are also the first chance to see activation ranges of a TRAINED "
-                         "model: if the tokens part from the oracle here but not with --precision bf16x3, suspect fp16 saturation (|x| > 65504)")
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x2"], default="bf16x3",
+                    help="bf16x3 = the engine's default (exact three-way bf16 splits: not narrower than fp32).  f16x2 is the opt-in fast "
+                         "mode: real checkpoints are the first chance to see activation ranges of a TRAINED model in it — a value beyond "
+                         "fp16's range puts the model back on bf16x3 with a PrecisionFallbackWarning (the saturation ledger), it never "
+                         "changes tokens silently")
     ap.add_argument("--trusted", action="store_true", help="allow torch.package archives / full unpickling (they execute code)")
     args = ap.parse_args(argv)
     with torch.no_grad():

@@ -16,7 +16,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from .engine import Engine
+from .engine import DEFAULT_PRECISION, Engine
 
 DEFAULT_CFG = dict(encoder_dim=64, encoder_rates=[2, 4, 8, 12], latent_dim=None, decoder_dim=1536,
                    decoder_rates=[12, 8, 4, 2], n_codebooks=14, codebook_size=1024, codebook_dim=8, sample_rate=44100)
@@ -217,12 +217,12 @@ class DacCodec:
     # 1-channel stem / head stay on the fp32 kernels; every epilogue writes its Snake output in the format its consumer reads.
     X3_MIN_COUT, X3_MIN_WORK = 128, 512
 
-    def __init__(self, sd: dict, cfg: dict = None, device="cuda:0", engine: Engine = None, precision: str = "f16x2"):
+    def __init__(self, sd: dict, cfg: dict = None, device="cuda:0", engine: Engine = None, precision: str = DEFAULT_PRECISION):
         cfg = dict(DEFAULT_CFG, **(cfg or {}))
         self.cfg = cfg
         if precision not in ("f16x2", "bf16x3", "f32"):
-            raise ValueError("precision must be 'f16x2' / 'bf16x3' (fp32-grade products on the fp16 / bf16 matrix cores) or 'f32'")
-        self.precision = precision
+            raise ValueError("precision must be 'bf16x3' (default: exact three-way bf16 splits on the matrix cores), 'f16x2' (opt-in fast "
+                             "mode, fp16's range) or 'f32'")
         self.engine = engine or Engine(device)
         self.lib = self.engine.lib
         self.device = self.engine.device
@@ -230,6 +230,37 @@ class DacCodec:
         self.hop_length = int(np.prod(cfg["encoder_rates"]))
         self.latent_dim = cfg["latent_dim"] or cfg["encoder_dim"] * 2 ** len(cfg["encoder_rates"])
         self.n_codebooks = cfg["n_codebooks"]
+        self._sd = sd                              # kept (host tensors): a precision fallback re-lays the weights
+        if precision == "f16x2":
+            self.engine.saturation(clear=True)
+        self._build(precision)
+        if precision == "f16x2":
+            sat = self.engine.saturation(clear=True)
+            if any(sat):                           # a weight that was clamped while its fp16 planes were built
+                self._fall_back(f"a codec weight does not fit fp16 (saturation ledger {sat})")
+
+    def _fall_back(self, why: str):
+        """precision "f16x2" met a value outside fp16's range: say so and re-lay the codec on "bf16x3" for good."""
+        import warnings
+        from .engine import PrecisionFallbackWarning
+        warnings.warn(f"DacCodec precision='f16x2': {why}; the codec runs on 'bf16x3' from here on", PrecisionFallbackWarning, stacklevel=3)
+        self._build("bf16x3")
+
+    def _guarded(self, fn, what):
+        """run fn(); in precision "f16x2" read the saturation ledger afterwards and, if an activation was clamped, repeat on bf16x3"""
+        if self.precision != "f16x2":
+            return fn()
+        out = fn()
+        sat = self.engine.saturation(clear=True)
+        if any(sat):
+            self._fall_back(f"{what} left fp16's range (saturation ledger: operands {sat[0]})")
+            out = fn()
+        return out
+
+    def _build(self, precision):
+        """(re)lay the weights for `precision` (device fp32 tensors + the split-plane images of the layers that run on the matrix-core pipe)"""
+        sd, cfg = self._sd, self.cfg
+        self.precision = precision
         dev = self.device
 
         def conv(key):          # Conv1d (Cout, Cin, k) -> [Cout][k][Cin]
@@ -390,6 +421,9 @@ class DacCodec:
     @torch.inference_mode()
     def encode(self, audio_data, sample_rate=None):
         """codec.encode(samples, sr) (interface.py:223): audio (B,1,L), L % hop == 0 -> {"codes": (B,n,T) int64, "z": ...}"""
+        return self._guarded(lambda: self._encode(audio_data), "encode()")
+
+    def _encode(self, audio_data):
         x = audio_data.to(self.device, torch.float32)
         B, ch, L = x.shape
         assert ch == 1 and L % self.hop_length == 0, "mono audio padded by preprocess() expected"
@@ -430,6 +464,9 @@ class DacCodec:
     def decode_codes(self, codes):
         """codes (B,n,T) -> audio (B,1,T*hop): codec.decode(codec.quantizer.from_latents(from_codes(z))[0])["audio"]
         (transformer.py:669-675)."""
+        return self._guarded(lambda: self._decode_codes(codes), "decode()")
+
+    def _decode_codes(self, codes):
         codes = codes.to(self.device, torch.int64).contiguous()
         B, n, T = codes.shape
         eng, d, r = self.engine, self.dec, self.rvq

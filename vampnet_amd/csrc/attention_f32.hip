@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void vn_attention_kernel(const float* __restri
                                                            const float* __restrict__ v,
                                                            const float* __restrict__ bias_full,  // [H][2T-1]
                                                            float* __restrict__ out, uint16_t* __restrict__ out16, long plane16,
-                                                           int B, int H, int T) {
+                                                           int B, int H, int T, unsigned* sat) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;
     float* Vs = Ks + ATT_KT * ATT_LD;
@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256) void vn_attention_kernel(const float* __restri
     l_tot += __shfl_xor(l_tot, 32);
     if (qrow < T) {
         const size_t ooff = ((size_t)b * T + qrow) * ((size_t)H * VN_DHEAD) + h * VN_DHEAD + 16 * g;
+        bool bad = false;                      // fp16 planes: saturation ledger (vn_common.h)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             f32x4 ov;
@@ -193,11 +194,12 @@ __global__ __launch_bounds__(256) void vn_attention_kernel(const float* __restri
             ov[2] = o[2][r] / l_tot;
             ov[3] = o[3][r] / l_tot;
             if (out16) {   // bf16 / bf16x3 modes: the attention output is only the A operand of the fc GEMM
-                vn_store_planes4(out16, plane16, (long)b * T + qrow, h * VN_DHEAD + 16 * g + 4 * r, H * VN_DHEAD, ov);
+                vn_store_planes4(out16, plane16, (long)b * T + qrow, h * VN_DHEAD + 16 * g + 4 * r, H * VN_DHEAD, ov, bad);
             } else {
                 *(f32x4*)(out + ooff + 4 * r) = ov;
             }
         }
+        vn_sat_report(sat, VN_SAT_OPERAND, bad);
     }
 }
 
@@ -405,8 +407,8 @@ int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float
         VN_LAUNCH_CHECK(ctx);
         return VN_OK;
     }
-    if (variant == 0) hipLaunchKernelGGL(vn_attention_kernel<0>, grid, dim3(256), lds, s, q, k, v, relbias_full, out, out16, plane16, B, H, T);
-    else hipLaunchKernelGGL(vn_attention_kernel<1>, grid, dim3(256), lds, s, q, k, v, relbias_full, out, out16, plane16, B, H, T);
+    if (variant == 0) hipLaunchKernelGGL(vn_attention_kernel<0>, grid, dim3(256), lds, s, q, k, v, relbias_full, out, out16, plane16, B, H, T, ctx->sat);
+    else hipLaunchKernelGGL(vn_attention_kernel<1>, grid, dim3(256), lds, s, q, k, v, relbias_full, out, out16, plane16, B, H, T, ctx->sat);
     vn_prof_post(ctx, pi, s);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;

@@ -341,7 +341,10 @@ __device__ __forceinline__ void ax_store4(const f32x4& acc, float l_tot, float* 
                                           int H, int hh, int dt, int g) {
     const f32x4 ov = {acc[0] / l_tot, acc[1] / l_tot, acc[2] / l_tot, acc[3] / l_tot};
     const int col = h * VN_DHEAD + 4 * hh + 32 * dt + 8 * g;
-    if (out16) vn_store_planes4(out16, plane16, row, col, H * VN_DHEAD, ov);
+    // fp16 planes: O is a convex combination of the values, and a value beyond 4094 (16 v >= 65504) is already on the saturation
+    // ledger from the QKV epilogue that wrote V^T — nothing new can saturate here, so the flag is not reported
+    bool bad = false;
+    if (out16) vn_store_planes4(out16, plane16, row, col, H * VN_DHEAD, ov, bad);
     else *(f32x4*)(out + (size_t)row * ((size_t)H * VN_DHEAD) + col) = ov;
 }
 

@@ -35,6 +35,7 @@ struct vn_conv_args {
     int in_stride, dil, pad;       // t_in  = t' * in_stride + j * dil - pad
     int out_stride, out_off;       // t_out = t' * out_stride + out_off
     int act;                       // 1: tanh on the result
+    unsigned* sat;                 // the context's saturation words (fp16 planes only; set by the launcher)
 };
 
 // WM = waves along M (4 waves per block, WN = 4 / WM along N): 2 x 2 wave grid for the 128/64-wide tiles, 4 x 1 for the
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(256, 2) void vn_conv1d_f32_kernel(vn_conv_args p, i
         int rl = tid / CG;
         int m = m0 + rl;
         int b = m / p.T_rows, tq = m - b * p.T_rows;
+        bool bad = false;                                  // fp16 planes: saturation ledger (vn_common.h)
         for (; rl < BM && m < M; rl += RPP, m += RPP, tq += RPP) {
             while (tq >= p.T_rows) { tq -= p.T_rows; ++b; }
             const int t_out = tq * p.out_stride + p.out_off;
@@ -190,16 +192,19 @@ __global__ __launch_bounds__(256, 2) void vn_conv1d_f32_kernel(vn_conv_args p, i
                 for (int e = 0; e < 4; ++e) w4[e] = vn_snake(v[e], al4[e], inv4[e]);
                 if (p.y2) *(f32x4*)(p.y2 + o) = w4;
                 if (p.y2_16) {                                  // y2_plane < 0: two fp16 planes (f16x2), -y2_plane apart
-                    if (p.y2_plane < 0) vn_store_h2x4(p.y2_16 + o, -p.y2_plane, w4);
+                    if (p.y2_plane < 0) vn_store_h2x4(p.y2_16 + o, -p.y2_plane, w4, bad);
                     else vn_store_bf16x4(p.y2_16 + o, p.y2_plane, w4);
                 }
             }
         }
+        vn_sat_report(p.sat, VN_SAT_OPERAND, bad);
     }
 }
 
 template <int BM, int BN, int WM = 2>
-static int launch_conv(vn_ctx* ctx, const vn_conv_args& a, hipStream_t s) {
+static int launch_conv(vn_ctx* ctx, const vn_conv_args& a_in, hipStream_t s) {
+    vn_conv_args a = a_in;
+    a.sat = ctx->sat;
     const int M = a.B * a.T_rows;
     const int tiles_m = vn_cdiv(M, BM), tiles_n = vn_cdiv(a.C_out, BN);
     constexpr int LDS = 2 * (BM + BN) * BK * 4;

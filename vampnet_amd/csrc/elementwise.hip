@@ -10,7 +10,9 @@
 // other contractible expression: the two paths are bitwise equal, tests/test_gpu_kernels.py): v = the lane's VEC float4 of row `row` (element 4 (lane + 64 i) + e)
 template <int VEC>
 __device__ __forceinline__ void vn_rmsnorm_row(const f32x4 (&v)[VEC], const float* __restrict__ w, float* __restrict__ y,
-                                               uint16_t* __restrict__ y16, long plane16, int row, int D, float eps, int lane) {
+                                               uint16_t* __restrict__ y16, long plane16, int row, int D, float eps, int lane,
+                                               unsigned* sat) {
+    bool bad = false;         // fp16 planes: saturation ledger (vn_common.h)
     float ss = 0.f;           // explicit fma chain: nothing is left to the compiler's contraction choices, which differ between kernels
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -33,17 +35,18 @@ __device__ __forceinline__ void vn_rmsnorm_row(const f32x4 (&v)[VEC], const floa
         o[2] = ww[2] * (v[i][2] * rstd);
         o[3] = ww[3] * (v[i][3] * rstd);
         if (y16) {     // bf16 / bf16x3 modes: the normalised row is only ever a GEMM A operand
-            vn_store_planes4(y16, plane16, row, 4 * (lane + 64 * i), D, o);
+            vn_store_planes4(y16, plane16, row, 4 * (lane + 64 * i), D, o, bad);
         } else {
             yr[lane + 64 * i] = o;
         }
     }
+    vn_sat_report(sat, VN_SAT_OPERAND, bad);
 }
 
 template <int VEC>   // VEC = float4 per lane = D / 256
 __global__ __launch_bounds__(256) void vn_rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          float* __restrict__ y, uint16_t* __restrict__ y16, long plane16,
-                                                         int rows, int D, float eps) {
+                                                         int rows, int D, float eps, unsigned* sat) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void vn_rmsnorm_kernel(const float* __restrict
     f32x4 v[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) v[i] = xr[lane + 64 * i];
-    vn_rmsnorm_row<VEC>(v, w, y, y16, plane16, row, D, eps, lane);
+    vn_rmsnorm_row<VEC>(v, w, y, y16, plane16, row, D, eps, lane, sat);
 }
 
 // Split-K reduce of a RESIDUAL GEMM fused with the RMSNorm that follows it in the layer (x += sum of the split images, in the
@@ -60,7 +63,8 @@ __global__ __launch_bounds__(256) void vn_rmsnorm_kernel(const float* __restrict
 template <int VEC>
 __global__ __launch_bounds__(256) void vn_splitk_reduce_rmsnorm_kernel(const float* __restrict__ partial, int nsplit, float* __restrict__ x,
                                                                        const float* __restrict__ w, float* __restrict__ y,
-                                                                       uint16_t* __restrict__ y16, long plane16, int rows, int D, float eps) {
+                                                                       uint16_t* __restrict__ y16, long plane16, int rows, int D, float eps,
+                                                                       unsigned* sat) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256) void vn_splitk_reduce_rmsnorm_kernel(const flo
             v[i] = a;
         }
     }
-    vn_rmsnorm_row<VEC>(v, w, y, y16, plane16, row, D, eps, lane);
+    vn_rmsnorm_row<VEC>(v, w, y, y16, plane16, row, D, eps, lane, sat);
 }
 
 // generic fallback (any D multiple of 4): strided loop, two passes over the row (second from L1/L2)
@@ -143,8 +147,8 @@ int vn_launch_rmsnorm(vn_ctx* ctx, const float* x, const float* w, float* y, int
     if (rows <= 0) return VN_OK;
     if (D % 4) return vn_fail(ctx, VN_ERR_INVALID, "rmsnorm: D=%s%ld must be a multiple of 4", "", D);
     const dim3 grid(vn_cdiv(rows, 4)), block(256);
-    if (D == 1280) hipLaunchKernelGGL(vn_rmsnorm_kernel<5>, grid, block, 0, s, x, w, y, y16, plane16, rows, D, eps);
-    else if (D == 256) hipLaunchKernelGGL(vn_rmsnorm_kernel<1>, grid, block, 0, s, x, w, y, y16, plane16, rows, D, eps);
+    if (D == 1280) hipLaunchKernelGGL(vn_rmsnorm_kernel<5>, grid, block, 0, s, x, w, y, y16, plane16, rows, D, eps, ctx->sat);
+    else if (D == 256) hipLaunchKernelGGL(vn_rmsnorm_kernel<1>, grid, block, 0, s, x, w, y, y16, plane16, rows, D, eps, ctx->sat);
     else if (y16) return vn_fail(ctx, VN_ERR_UNSUPPORTED, "rmsnorm: bf16 output needs D in {256, 1280}%s", "");
     else hipLaunchKernelGGL(vn_rmsnorm_generic_kernel, grid, block, 0, s, x, w, y, rows, D, eps);
     VN_LAUNCH_CHECK(ctx);
@@ -156,8 +160,8 @@ int vn_launch_splitk_reduce_rmsnorm(vn_ctx* ctx, const float* partial, int nspli
                                     long plane16, int rows, int D, float eps, hipStream_t s) {
     if (rows <= 0) return VN_OK;
     const dim3 grid(vn_cdiv(rows, 4)), block(256);
-    if (D == 1280) hipLaunchKernelGGL(vn_splitk_reduce_rmsnorm_kernel<5>, grid, block, 0, s, partial, nsplit, x, w, y, y16, plane16, rows, D, eps);
-    else if (D == 256) hipLaunchKernelGGL(vn_splitk_reduce_rmsnorm_kernel<1>, grid, block, 0, s, partial, nsplit, x, w, y, y16, plane16, rows, D, eps);
+    if (D == 1280) hipLaunchKernelGGL(vn_splitk_reduce_rmsnorm_kernel<5>, grid, block, 0, s, partial, nsplit, x, w, y, y16, plane16, rows, D, eps, ctx->sat);
+    else if (D == 256) hipLaunchKernelGGL(vn_splitk_reduce_rmsnorm_kernel<1>, grid, block, 0, s, partial, nsplit, x, w, y, y16, plane16, rows, D, eps, ctx->sat);
     else return vn_fail(ctx, VN_ERR_UNSUPPORTED, "splitk_reduce_rmsnorm: D=%s%ld must be 256 or 1280", "", D);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;

@@ -124,12 +124,30 @@ extern "C" int vn_ctx_create(int device, vn_ctx** out) {
     c->device = device;
     c->err[0] = 0;
     c->prof = vn_prof();
-    c->sk_slabs = nullptr; c->sk_flags = nullptr; c->zero_page = nullptr; c->x3_ws = nullptr; c->attr_mask = 0;
+    c->sk_slabs = nullptr; c->sk_flags = nullptr; c->zero_page = nullptr; c->x3_ws = nullptr; c->sat = nullptr; c->attr_mask = 0;
     vn_tune_init(&c->tune);
     c->cus = 0;
     if (hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->cus <= 0) c->cus = 256;
     if (hipSetDevice(device) != hipSuccess) { delete c; return VN_ERR_HIP; }
+    // the saturation ledger of the fp16 plane writers (vn_common.h): sticky words, read + cleared by vn_saturation_flags
+    if (hipMalloc((void**)&c->sat, VN_SAT_WORDS * sizeof(unsigned)) != hipSuccess ||
+        hipMemset(c->sat, 0, VN_SAT_WORDS * sizeof(unsigned)) != hipSuccess) {
+        (void)hipFree(c->sat);
+        delete c;
+        return VN_ERR_OOM;
+    }
     *out = c;
+    return VN_OK;
+}
+
+// Reads (and with clear != 0 resets) the saturation ledger: flags[0] GEMM-operand planes, [1] attention operands, [2] weight planes,
+// [3] unused.  Synchronises `stream` (the words are only meaningful once the work that may set them has run).
+extern "C" int vn_saturation_flags(vn_ctx* ctx, uint32_t* flags4, int clear, void* stream) {
+    if (!ctx || !flags4) return VN_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    VN_HIP_CHECK(ctx, hipMemcpyAsync(flags4, ctx->sat, VN_SAT_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    if (clear) VN_HIP_CHECK(ctx, hipMemsetAsync(ctx->sat, 0, VN_SAT_WORDS * sizeof(unsigned), s));
+    VN_HIP_CHECK(ctx, hipStreamSynchronize(s));
     return VN_OK;
 }
 static void prof_free(vn_ctx* ctx) {
@@ -147,6 +165,7 @@ extern "C" void vn_ctx_destroy(vn_ctx* ctx) {
     (void)hipFree(ctx->sk_flags);
     (void)hipFree(ctx->zero_page);
     (void)hipFree(ctx->x3_ws);
+    (void)hipFree(ctx->sat);
     delete ctx;
 }
 
@@ -295,7 +314,9 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
     // bf16x3 mode: the same four operands as three exact split planes each, multiplied on the bf16 matrix cores with
     // fp32-grade accuracy (gemm_x3.hip); everything else is the fp32 path.
     // f16x2 mode: the same operands as TWO fp16 planes, three matrix-core products per k-step (vn_common.h vn_split2h): fp32-grade at
-    // half the matrix time of bf16x3.  The attention operands stay bf16x3 planes (QKV3 epilogue + attention_x3.hip).
+    // half the matrix time of bf16x3.  The attention operands are fp16 two-plane splits as well (QKV3 epilogue with FMT = 1: q / 8, k,
+    // 16 v with an UNSCALED second plane; attention_x3.hip NP = 2); values the fp16 planes cannot hold are clamped and recorded on the
+    // context's saturation ledger (vn_saturation_flags).
     const int gm = bf ? (m->w_plane == VN_PLANES_TILED_H2 ? 3 : m->w_plane ? 2 : 1) : 0;       // vn_gemm_args::bf16
     // plane strides of y16 / g16: bf16x3 / f16x2 = the tiled layout (whole-line LDS-DMA in gemm_x3.hip), fast mode = one plane
     const bool a_tiled_on = ctx->tune.a_tiled != 0;
@@ -485,7 +506,7 @@ static int plane_buffers(vn_model* m, bool attention_planes) {
     const size_t rows16 = ((size_t)m->max_rows + 15) / 16 * 16;        // the tiled layout addresses rows in blocks of 16
     if (!m->y16 && (rc = dev_alloc(m->ctx, &m->y16, (size_t)3 * rows16 * m->D))) return rc;
     if (!m->g16 && (rc = dev_alloc(m->ctx, &m->g16, (size_t)3 * rows16 * 2 * m->D))) return rc;
-    if (attention_planes && (!m->qk16 || !m->vt16)) {   // attention operands as bf16x3 planes (attention_x3.hip)
+    if (attention_planes && (!m->qk16 || !m->vt16)) {   // attention operands as split planes (bf16x3: three, f16x2: two; sized for three)
         m->qk_plane = 2 * m->max_rows * (long)m->D;
         m->vt_plane = (long)m->H * ((m->max_rows + 31) / 32) * (VN_DHEAD * 32);
         // each buffer on its own null check: a failed second allocation must not leave a half-initialised pair behind
@@ -727,7 +748,8 @@ extern "C" int vn_attention_bf16(vn_ctx* ctx, const float* q, const float* k, co
 // np = 2: the f16x2 precision's attention operands (fp16 two-plane, second plane unscaled, V^T times 16)
 __global__ void vn_attn_x3_prep_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                        uint16_t* __restrict__ qk16, long plane_qk, uint16_t* __restrict__ vt16, long plane_vt,
-                                       long heads, int H, int T, int np) {
+                                       long heads, int H, int T, int np, unsigned* sat) {
+    bool bad = false;                                     // fp16 planes: saturation ledger (vn_common.h)
     const long n = heads * T * VN_DHEAD;
     const long mt = ((heads / H) * T + 31) >> 5;          // tiles of 32 global token rows m = b T + t
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
@@ -739,11 +761,11 @@ __global__ void vn_attn_x3_prep_kernel(const float* __restrict__ q, const float*
         uint16_t a, b, c;
         const long o = (((hd % H) * mt + (mrow >> 5)) * VN_DHEAD + d) * 32 + (mrow & 31);
         if (np == 2) {
-            vn_split2u(q[i] * 0.125f, a, b);
+            vn_split2u(q[i] * 0.125f, a, b, bad);
             qk16[i] = a; qk16[i + plane_qk] = b;
-            vn_split2u(k[i], a, b);
+            vn_split2u(k[i], a, b, bad);
             qk16[n + i] = a; qk16[n + i + plane_qk] = b;
-            vn_split2u(v[i] * 16.0f, a, b);
+            vn_split2u(v[i] * 16.0f, a, b, bad);
             vt16[o] = a; vt16[o + plane_vt] = b;
             continue;
         }
@@ -754,6 +776,7 @@ __global__ void vn_attn_x3_prep_kernel(const float* __restrict__ q, const float*
         vn_split3(v[i], a, b, c);
         vt16[o] = a; vt16[o + plane_vt] = b; vt16[o + 2 * plane_vt] = c;
     }
+    vn_sat_report(sat, VN_SAT_ATTN, bad);
 }
 
 // shared by the single-op entry and the timing hook: scratch, bias table, plane images; *launches of the kernel only
@@ -777,7 +800,7 @@ static int attention_x3_run(vn_ctx* ctx, const float* q, const float* k, const f
         rc = VN_ERR_HIP;
     if (rc == VN_OK) rc = vn_launch_bias_expand(ctx, rel_bias, lut_d, full, H, T, s);
     if (rc == VN_OK) {
-        hipLaunchKernelGGL(vn_attn_x3_prep_kernel, dim3(1024), dim3(256), 0, s, q, k, v, qk16, plane_qk, vt16, plane_vt, heads, H, T, np);
+        hipLaunchKernelGGL(vn_attn_x3_prep_kernel, dim3(1024), dim3(256), 0, s, q, k, v, qk16, plane_qk, vt16, plane_vt, heads, H, T, np, ctx->sat);
         rc = vn_launch_attention_x3(ctx, qk16, qk16 + n, plane_qk, vt16, plane_vt, full, out, nullptr, 0, B, H, T, vn_num_cus(ctx), np, s);
     }
     if (rc == VN_OK && iters > 0 && avg_us) {

@@ -135,6 +135,7 @@ __device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 
     static_assert(EPI != VN_EPI_GEGLU || G::CJ == 2, "GEGLU pairs the wave's two column tiles (value, gate)");
     const int l31 = lane & 31, h = lane >> 5;
     const int colw = n0 + wn * 32 * G::CJ + l31;
+    bool bad = false;                     // f16x2 plane epilogues: a value that did not fit fp16 (vn_common.h, saturation ledger)
 #pragma unroll
     for (int i = 0; i < G::RI; ++i) {
 #pragma unroll
@@ -151,7 +152,7 @@ __device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 
                     const long cp = til ? 512 : (p.c_plane < 0 ? -p.c_plane : p.c_plane);
                     if constexpr (FMT) {
                         uint16_t t0, t1;
-                        vn_split2h(o, t0, t1);
+                        vn_split2h(o, t0, t1, bad);
                         uint16_t* d = p.C16 + (til ? vn_tiled_off_np(row, ocol, p.ldc, 2) : (size_t)row * p.ldc + ocol);
                         d[0] = t0; d[cp] = t1;
                     } else {
@@ -190,7 +191,7 @@ __device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 
                         const int hd = rem >> 6, d = rem & 63;
                         uint16_t t0, t1, t2 = 0;
                         // FMT 1: the attention operands of the f16x2 precision — fp16 two-plane, second plane unscaled, V times 16
-                        if constexpr (FMT) vn_split2u(which == 0 ? v * 0.125f : which == 1 ? v : v * 16.0f, t0, t1);
+                        if constexpr (FMT) vn_split2u(which == 0 ? v * 0.125f : which == 1 ? v : v * 16.0f, t0, t1, bad);
                         else vn_split3(which ? v : v * 0.125f, t0, t1, t2);
                         if (which < 2) {
                             const int b = row / p.T, t = row - b * p.T;
@@ -207,6 +208,7 @@ __device__ __forceinline__ void x3_epilogue(const vn_gemm_args& p, const f32x16 
             }
         }
     }
+    if constexpr (FMT && (EPI == VN_EPI_GEGLU || EPI == VN_EPI_QKV3)) vn_sat_report(p.sat, EPI == VN_EPI_QKV3 ? VN_SAT_ATTN : VN_SAT_OPERAND, bad);
 }
 
 // The same epilogues staged through LDS (free after the k-loop): every wave drops its accumulators into a row-major image
@@ -226,6 +228,7 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
     static_assert(EPI != VN_EPI_GEGLU || CJ == 2, "GEGLU pairs the wave's two column tiles (value, gate)");
     const int wm = wave / G::WC, wn = wave % G::WC, l31 = lane & 31, h = lane >> 5, tid = wave * 64 + lane;
     uint16_t* L16 = (uint16_t*)lds;
+    bool bad = false;                     // saturation ledger (vn_common.h)
 #pragma unroll
     for (int i = 0; i < RI; ++i) {
         __syncthreads();                  // k-loop reads / the previous pass's read-out are done in every wave
@@ -237,7 +240,7 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
                 uint16_t* d = L16 + R * 64 + wn * 32 + l31;
                 if constexpr (FMT) {
                     uint16_t t0, t1;
-                    vn_split2h(o, t0, t1);
+                    vn_split2h(o, t0, t1, bad);
                     d[0] = t0; d[RP * 64] = t1;
                 } else {
                     uint16_t t0, t1, t2;
@@ -251,7 +254,7 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
                         const int c = wn * 32 * CJ + j * 32 + l31;
                         uint16_t t0, t1, t2 = 0;
                         const float qv = n0 < p.H * VN_DHEAD ? acc[i][j][r] * 0.125f : acc[i][j][r];              // q: x 1/sqrt(64)
-                        if constexpr (FMT) vn_split2u(qv, t0, t1);
+                        if constexpr (FMT) vn_split2u(qv, t0, t1, bad);
                         else vn_split3(qv, t0, t1, t2);
                         uint16_t* d = L16 + R * 128 + c;
                         d[0] = t0; d[RP * 128] = t1;
@@ -264,7 +267,7 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
                         uint16_t t[3][4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            if constexpr (FMT) vn_split2u(acc[i][j][r + e] * 16.0f, t[0][e], t[1][e]);
+                            if constexpr (FMT) vn_split2u(acc[i][j][r + e] * 16.0f, t[0][e], t[1][e], bad);
                             else vn_split3(acc[i][j][r + e], t[0][e], t[1][e], t[2][e]);
                         }
 #pragma unroll
@@ -350,7 +353,7 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
                         const f32x4 w4 = {vn_snake(v[0], al[0], inv[0]), vn_snake(v[1], al[1], inv[1]), vn_snake(v[2], al[2], inv[2]),
                                           vn_snake(v[3], al[3], inv[3])};
                         if (p.Y2) *(f32x4*)(p.Y2 + o) = w4;
-                        if (p.C16) vn_store_planes4(p.C16, p.c_plane, orow, col, p.N, w4);
+                        if (p.C16) vn_store_planes4(p.C16, p.c_plane, orow, col, p.N, w4, bad);
                     }
                 }
             }
@@ -376,6 +379,8 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
             }
         }
     }
+    if constexpr (FMT && (EPI == VN_EPI_GEGLU || EPI == VN_EPI_QKV3 || EPI == VN_EPI_CONV))
+        vn_sat_report(p.sat, EPI == VN_EPI_QKV3 ? VN_SAT_ATTN : VN_SAT_OPERAND, bad);
 }
 
 // one block per output tile (gridDim.y > 1: split-K images, store epilogue only)
@@ -748,6 +753,7 @@ template <int EPI, int CFG, int ABL = 0, int FMT = 0>
 static int x3_go(vn_ctx* ctx, const vn_gemm_args& a_in, int nsplit, hipStream_t s) {
     vn_gemm_args a = a_in;
     a.staged = x3_staged_ok<EPI>(ctx, a);
+    a.sat = ctx->sat;
     a.group_m = ctx->tune.x3_group_m;                                  // tuning: rows of tiles per walk group (0 = 8)
     const int tiles_m = vn_cdiv(a.M, x3_geo<CFG>::BM), tiles_n = vn_cdiv(a.N, X3_BN);
     constexpr int NP = FMT ? 2 : 3;
@@ -1018,13 +1024,15 @@ extern "C" int vn_gemm_bf16x3(vn_ctx* ctx, const void* A3, int64_t a_plane, cons
 // ---- f16x2 (vn_common.h vn_split2h): plane builders and the single-op entry -------------------------------------------------------
 // fp32 [rows][K] -> f16x2 planes, planar (dst[q][rows][K], `plane` elements apart) or tiled ([rows / 16][K / 32][2][16][32])
 __global__ __launch_bounds__(256) void vn_split2h_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long rows, int K,
-                                                         long plane) {
+                                                         long plane, unsigned* sat) {
     const long n4 = rows * (K >> 2);
+    bool bad = false;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
         const long row = i / (K >> 2);
         const int col = (int)(i - row * (K >> 2)) * 4;
-        vn_store_planes4(dst, plane, row, col, K, ((const f32x4*)src)[i]);
+        vn_store_planes4(dst, plane, row, col, K, ((const f32x4*)src)[i], bad);
     }
+    vn_sat_report(sat, VN_SAT_WEIGHT, bad);
 }
 int vn_launch_split2h(vn_ctx* ctx, const float* src, uint16_t* dst, long rows, int K, long plane, hipStream_t s) {
     if (rows <= 0 || K <= 0 || (K & 3) || !vn_planes_h2(plane) || (plane == VN_PLANES_TILED_H2 && ((rows & 15) || (K & 31))) ||
@@ -1032,7 +1040,7 @@ int vn_launch_split2h(vn_ctx* ctx, const float* src, uint16_t* dst, long rows, i
         return vn_fail(ctx, VN_ERR_INVALID, "split2h: K %% 4 == 0 (tiled: rows %% 16, K %% 32; planar: stride %% 8) (rows=%s%ld, K=%ld)", "", rows, K);
     const long n4 = rows * (K >> 2);
     const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
-    hipLaunchKernelGGL(vn_split2h_kernel, dim3(blocks), dim3(256), 0, s, src, dst, rows, K, plane);
+    hipLaunchKernelGGL(vn_split2h_kernel, dim3(blocks), dim3(256), 0, s, src, dst, rows, K, plane, ctx->sat);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
 }

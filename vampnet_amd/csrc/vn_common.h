@@ -81,7 +81,21 @@ __device__ __forceinline__ void vn_store_bf16x4(uint16_t* dst, long plane, const
 // 3.4e-7 (tests/test_gpu_f16x2.py).  Values beyond +-65504 SATURATE (v_med3) instead of turning into inf.
 #define VN_H2_SCALE 2048.0f
 #define VN_H2_INV_SCALE (1.0f / 2048.0f)
-__device__ __forceinline__ void vn_split2h(float x, uint16_t& h0, uint16_t& h1) {
+// SATURATION LEDGER of the fp16 plane writers.  Every value that is turned into fp16 planes passes vn_split2h / vn_split2u, which clamp;
+// each of them also ORs "this value did not fit (|x| >= 65504, or NaN)" into a per-thread flag, and the kernel reports the flag once per
+// thread into the context's sticky device words (vn_ctx::sat; read and cleared by vn_saturation_flags, include/vampnet_hip.h):
+//   word 0  GEMM-operand planes (normalised rows, attention output, GEGLU output, codec activations)
+//   word 1  attention operands (q / 8, k, 16 v — so |v| >= 4094 is reported)
+//   word 2  weight planes (vn_split2_f16 / vn_model_set_f16x2)
+// The host side (vampnet_amd/engine.py) reads the words after every generate() in the f16x2 precision and re-runs a call that
+// saturated on bf16x3, so a clamped value never reaches a caller silently.  Cost: one v_cmp + s_or per value.
+enum { VN_SAT_OPERAND = 0, VN_SAT_ATTN = 1, VN_SAT_WEIGHT = 2, VN_SAT_WORDS = 4 };
+__device__ __forceinline__ void vn_sat_note(bool& bad, float x) { bad |= !(__builtin_fabsf(x) < 65504.0f); }
+__device__ __forceinline__ void vn_sat_report(unsigned* sat, int word, bool bad) {
+    if (bad && sat) sat[word] = 1u;          // every writer stores the same value: no atomic needed
+}
+__device__ __forceinline__ void vn_split2h(float x, uint16_t& h0, uint16_t& h1, bool& bad) {
+    vn_sat_note(bad, x);
     x = __builtin_fminf(__builtin_fmaxf(x, -65504.0f), 65504.0f);
     const _Float16 a = (_Float16)x;
     const _Float16 b = (_Float16)((x - (float)a) * VN_H2_SCALE);
@@ -97,7 +111,8 @@ __device__ __forceinline__ float vn_h2_value(uint16_t h0, uint16_t h1) {
 // range, i.e. the split is exact to 2^-25 absolute instead of 2^-22 relative — harmless for q / 8 and k (a score moves by < 3e-7)
 // and for softmax weights and values once those carry a factor 16 (P <= e^6: 16 P < 6.5e3; the factors leave with the final division).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void vn_split2u(float x, uint16_t& h0, uint16_t& h1) {
+__device__ __forceinline__ void vn_split2u(float x, uint16_t& h0, uint16_t& h1, bool& bad) {
+    vn_sat_note(bad, x);
     x = __builtin_fminf(__builtin_fmaxf(x, -65504.0f), 65504.0f);
     const _Float16 a = (_Float16)x;
     const _Float16 b = (_Float16)(x - (float)a);
@@ -109,10 +124,10 @@ __device__ __forceinline__ void vn_split2u_x8(const f32x8& x, f16x8& h0, f16x8& 
     h1 = __builtin_convertvector(x - __builtin_convertvector(h0, f32x8), f16x8);
 }
 // four consecutive values -> one 8-byte store per f16x2 plane
-__device__ __forceinline__ void vn_store_h2x4(uint16_t* dst, long plane, const f32x4& o) {
+__device__ __forceinline__ void vn_store_h2x4(uint16_t* dst, long plane, const f32x4& o, bool& bad) {
     uint16_t t[2][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) vn_split2h(o[e], t[0][e], t[1][e]);
+    for (int e = 0; e < 4; ++e) vn_split2h(o[e], t[0][e], t[1][e], bad);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         uint2 pk;
@@ -144,11 +159,12 @@ __host__ __device__ __forceinline__ size_t vn_tiled_off(long row, int k, int K) 
 // four consecutive columns col .. col + 3 (col % 4 == 0) of row `row` of a [rows][ld] matrix -> its planes
 // (one call of vn_store_bf16x4 with a selected address / stride: with a call per layout hipcc 7.2 tail-merged the three store
 // sequences of the D = 256 RMSNorm kernel and stored a stale register as the last dword of the planar form)
-__device__ __forceinline__ void vn_store_planes4(uint16_t* base, long plane, long row, int col, int ld, const f32x4& o) {
+// `bad`: the caller's saturation flag (touched by the f16x2 formats only; see the saturation ledger above)
+__device__ __forceinline__ void vn_store_planes4(uint16_t* base, long plane, long row, int col, int ld, const f32x4& o, bool& bad) {
     const bool tiled = vn_planes_tiled(plane);
     if (vn_planes_h2(plane)) {
         const size_t off = tiled ? vn_tiled_off_np(row, col, ld, 2) : (size_t)row * ld + col;
-        vn_store_h2x4(base + off, tiled ? 512L : -plane, o);
+        vn_store_h2x4(base + off, tiled ? 512L : -plane, o, bad);
         return;
     }
     const size_t off = tiled ? vn_tiled_off(row, col, ld) : (size_t)row * ld + col;
@@ -297,6 +313,7 @@ struct vn_ctx {
     unsigned* sk_flags;
     float* zero_page;
     float* x3_ws;            // split-K partial tiles of the bf16x3 GEMM (gemm_x3.hip), fixed size, allocated on first use
+    unsigned* sat;           // VN_SAT_WORDS sticky saturation words of the fp16 plane writers (allocated with the context)
     // kernels whose dynamic-LDS limit was raised on THIS context's device (hipFuncSetAttribute is per device, and one
     // process may hold contexts on several)
     unsigned attr_mask;
@@ -363,6 +380,7 @@ struct vn_gemm_args {
     long qkv_plane;      // B*H*T*64
     uint16_t* V16;       // QKV3 epilogue: V^T planes [3][H][ceil(M / 32)][64][32], v_plane elements apart (C16 = q then k planes)
     long v_plane;
+    unsigned* sat;       // gemm_x3.hip: the context's saturation words (set by the launcher; f16x2 plane epilogues report into them)
     int staged;          // gemm_x3.hip: epilogue through LDS with 16-byte global accesses (set by the launcher when alignment allows)
     // gemm_x3.hip: W given as TILED planes (vn_launch_tile_planes): the 16-row x 32-k block of each plane is one contiguous 1 KiB piece,
     // [row / 16][k / 32][plane][row % 16][k % 32] — an LDS-DMA instruction then fetches eight whole cache lines instead of sixteen

@@ -22,8 +22,9 @@ struct vn_model {
     // f16x2 mode (vn_model_set_f16x2): the GEMM weight tensors as tiled f16x2 planes built from the fp32 blob (tensor at blob offset
     // o -> 2 o); while the mode is on, blob16 == w_h2 and w_plane == VN_PLANES_TILED_H2
     uint16_t* w_h2;
-    // bf16x3 attention operands (attention_x3.hip), written by the QKV GEMM epilogues: qk16 = q then k planes
-    // [3][2][max_rows * D]; vt16 = blocked V^T planes [3][H * ceil(max_rows / 32) * 64 * 32], zero-filled once
+    // attention operands as split planes (attention_x3.hip), written by the QKV GEMM epilogues: qk16 = q then k planes
+    // [3][2][max_rows * D]; vt16 = blocked V^T planes [3][H * ceil(max_rows / 32) * 64 * 32], zero-filled once.  bf16x3: three exact
+    // bf16 planes; f16x2: the first two planes hold the fp16 two-plane split (q / 8, k, 16 v; second plane unscaled: |v| < 4094)
     uint16_t *qk16, *vt16;
     long qk_plane, vt_plane;
     int bias_T;              // T the expanded bias table is currently built for (-1 = none)

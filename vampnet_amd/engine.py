@@ -9,6 +9,7 @@ torch only owns device memory and the stream.  Nothing here imports `oracle/`.
 import ctypes as C
 import math
 import random
+import warnings
 
 import numpy as np
 import torch
@@ -17,6 +18,16 @@ from . import _lib
 from ._lib import VnError, vn_dims, vn_sample_params
 
 LORA_SCALING = 1.0 / 8.0      # loralib: lora_alpha / r = 1 / 8 (transformer.py:22 LORA_R)
+
+# The engine's default precision: "bf16x3" — every GEMM / attention operand as three bf16 planes whose sum IS the fp32 value (8 + 8 + 8
+# significand bits, fp32's exponent range), six matrix-core products, fp32 accumulation: arithmetic that is not narrower than the
+# reference's fp32.  "f16x2" (two fp16 planes: 22 significand bits, fp16's exponent range) is an OPT-IN fast
+# mode guarded by the saturation ledger below.
+DEFAULT_PRECISION = "bf16x3"
+
+
+class PrecisionFallbackWarning(UserWarning):
+    """precision='f16x2' could not hold a weight / an activation in fp16's range; the work was (re)done on 'bf16x3'."""
 
 
 def seed_all(seed: int):
@@ -59,6 +70,13 @@ class Engine:
             from .torch_rng import DeviceTorchRng
             self._torch_rng = DeviceTorchRng(self)
         return self._torch_rng
+
+    def saturation(self, clear=True):
+        """The context's saturation ledger (include/vampnet_hip.h vn_saturation_flags): (GEMM-operand planes, attention operands,
+        weight planes, reserved) — non-zero where an fp16 plane writer had to clamp a value since the last clear.  Synchronises."""
+        fl = (C.c_uint32 * 4)()
+        self.check(self.lib.vn_saturation_flags(self.handle, fl, 1 if clear else 0, self.stream()), "vn_saturation_flags")
+        return tuple(int(v) for v in fl)
 
     def health_check(self):
         """Synchronise and raise if a stream-K GEMM ever gave up waiting for a partial tile (never expected)."""
@@ -285,7 +303,7 @@ class VampNetModel:
 
     def __init__(self, engine: Engine, sd: dict, codebooks: torch.Tensor, *, n_heads, n_layers, n_codebooks,
                  n_conditioning_codebooks=0, latent_dim=8, embedding_dim=1280, vocab_size=1024,
-                 max_batch=8, max_T=575, chunk_size_s=10, precision="f16x2", _blob=None, **_ignored):
+                 max_batch=8, max_T=575, chunk_size_s=10, precision=DEFAULT_PRECISION, _blob=None, **_ignored):
         self.engine = engine
         self.lib = engine.lib
         self.n_heads, self.n_layers = n_heads, n_layers
@@ -311,11 +329,13 @@ class VampNetModel:
         self.set_precision(precision)
 
     def set_precision(self, precision: str):
-        """"f32": exact-fp32 MFMA.  "bf16x3": fp32-grade GEMMs evaluated as six bf16 MFMA products of exact three-way operand
-        splits (same accuracy class as "f32", faster matrix pipe).  "f16x2": fp32-grade GEMMs as three fp16 MFMA products of
-        two-plane splits (operand error 2^-22, below an fp32 GEMM's own rounding noise; half of bf16x3's matrix time; values beyond
-        +-65504 saturate).  "bf16": fast mode —
-        GEMM operands in bf16 like the reference's own GPU path (torch.autocast(bf16), interface.py:364,428); NOT bit-exact."""
+        """"f32": exact-fp32 MFMA.  "bf16x3" (default): fp32-grade GEMMs evaluated as six bf16 MFMA products of exact three-way
+        operand splits (same accuracy class as "f32", faster matrix pipe).  "f16x2" (opt-in fast mode, operands NARROWER than fp32):
+        GEMMs as three fp16 MFMA products of two-plane splits (operand error 2^-22; half of bf16x3's matrix time; fp16's range).  A
+        model whose weights do not fit fp16, or whose probe forward puts a value on the saturation ledger, is NOT run in it: the
+        model falls back to "bf16x3" with a PrecisionFallbackWarning; every later generate() re-checks the ledger (see generate).
+        "bf16": fast mode — GEMM operands in bf16 like the reference's own GPU path (torch.autocast(bf16), interface.py:364,428);
+        NOT bit-exact."""
         if precision == "bf16":
             if self.blob16 is None:
                 self.blob16 = self.blob.to(torch.bfloat16)          # same element offsets, RNE like torch autocast
@@ -331,40 +351,44 @@ class VampNetModel:
         elif precision == "f16x2":
             # fp32-grade GEMMs as three fp16 matrix-core products of two-plane operand splits (gemm_x3.hip); the engine builds the
             # weight planes from the fp32 blob itself
-            lo, hi = torch.aminmax(self.blob)               # (no |blob| temporary: the blob is 1.3 GB)
-            wmax = max(abs(float(lo)), abs(float(hi)))
-            if not wmax < 65504.0:          # also catches NaN; fp16 planes saturate beyond that: refuse instead
-                raise ValueError(f"precision='f16x2' cannot hold these weights (max |w| = {wmax:g} >= 65504): use precision='bf16x3'")
+            self.engine.saturation(clear=True)              # start from a clean ledger (synchronises: a setup call)
             self.engine.check(self.lib.vn_model_set_f16x2(self.handle, 1), "vn_model_set_f16x2")
-            self._probe_f16x2()
+            sat = self.engine.saturation(clear=True)        # word 2: a weight that was clamped while the planes were built
+            why = f"a weight does not fit fp16 (saturation ledger {sat})" if any(sat) else self._probe_f16x2()
+            if why:
+                self._fall_back(why)
+                return
         elif precision == "f32":
             self.engine.check(self.lib.vn_model_set_bf16(self.handle, None), "vn_model_set_bf16")
         else:
             raise ValueError("precision must be 'f32', 'f16x2', 'bf16x3' or 'bf16'")
         self.precision = precision
 
+    def _fall_back(self, why: str):
+        """precision "f16x2" cannot be trusted for this model / call: say so and move the model to "bf16x3" for good."""
+        warnings.warn(f"precision='f16x2': {why}; this model runs on 'bf16x3' from here on", PrecisionFallbackWarning, stacklevel=3)
+        self.set_precision("bf16x3")
+
     def _probe_f16x2(self):
-        """fp16 planes saturate beyond +-65504.  The weights were checked above; activations depend on the weights
-        AND the input, so this is a probe, not a proof: one short forward in f16x2 against the same forward on the exact-fp32 path.
-        A model whose activations leave fp16's range parts from it by orders of magnitude more than the 1e-5 the two precisions
-        differ by — refuse it (loudly) instead of returning saturated logits.  VN_F16X2_PROBE=0 skips the probe."""
+        """An early warning at precision selection: one short forward on random codes, then the saturation ledger.  Activations depend
+        on the input as well, so passing the probe proves nothing about later calls — those are covered by the ledger check after
+        every generate() / forward_codes() in this precision.  Returns a reason string when the probe saturated, else None.
+        VN_F16X2_PROBE=0 skips the probe."""
         import os
         if os.environ.get("VN_F16X2_PROBE", "1") == "0":
-            return
+            return None
         T = max(1, min(int(self.dims.max_T), 96))
         g = torch.Generator().manual_seed(0)
         codes = torch.randint(0, self.vocab_size, (1, self.n_codebooks, T), generator=g)
         codes[:, self.n_conditioning_codebooks:, ::2] = self.vocab_size                 # MASK tokens, as inside generate()
-        a = self.forward_codes(codes, layout="native").clone()
-        self.engine.check(self.lib.vn_model_set_bf16(self.handle, None), "vn_model_set_bf16")
-        b = self.forward_codes(codes, layout="native")
-        self.engine.check(self.lib.vn_model_set_f16x2(self.handle, 1), "vn_model_set_f16x2")
-        scale = max(1.0, float(b.abs().max()))
-        d = float((a - b).abs().max())
-        if not d <= 1e-3 * scale:        # NaN fails too; the precisions agree to ~1e-5 * scale when nothing saturates
-            self.engine.check(self.lib.vn_model_set_bf16(self.handle, None), "vn_model_set_bf16")
-            raise ValueError(f"precision='f16x2': a probe forward differs from the fp32 path by {d:g} (logit scale {scale:g}) — "
-                             "activations or weights of this model leave fp16's range; use precision='bf16x3'")
+        self.precision = "f32"                                                          # (no ledger handling inside the probe itself)
+        logits = self.forward_codes(codes, layout="native")
+        sat = self.engine.saturation(clear=True)
+        if any(sat):
+            return f"a probe forward left fp16's range (saturation ledger: operands {sat[0]}, attention {sat[1]})"
+        if not bool(torch.isfinite(logits).all()):
+            return "a probe forward produced non-finite logits"
+        return None
 
     @property
     def device(self):
@@ -388,6 +412,12 @@ class VampNetModel:
         logits = torch.empty(B, T, self.n_predict_codebooks, self.vocab_size, device=self.device, dtype=torch.float32)
         self.engine.check(self.lib.vn_forward(self.handle, codes.data_ptr(), B, T, logits.data_ptr(),
                                               self.engine.stream()), "vn_forward")
+        if self.precision == "f16x2":
+            sat = self.engine.saturation(clear=True)
+            if any(sat):                    # a clamped value never reaches the caller: repeat the forward on bf16x3
+                self._fall_back(f"a forward left fp16's range (saturation ledger: operands {sat[0]}, attention {sat[1]})")
+                self.engine.check(self.lib.vn_forward(self.handle, codes.data_ptr(), B, T, logits.data_ptr(),
+                                                      self.engine.stream()), "vn_forward")
         if layout == "native":
             return logits
         return logits.reshape(B, T * self.n_predict_codebooks, self.vocab_size).permute(0, 2, 1)
@@ -435,7 +465,32 @@ class VampNetModel:
                  cfg_scale: float = 3.0, cfg_guidance: float = None, cond=None,
                  rng: str = "torch", n0_override: int = None, device_seed: int = None,
                  global_batch: int = None, batch_offset: int = 0, noise=None, call_batch: int = None):
-        """Drop-in for VampNet.generate (transformer.py:686-946).  Extra keywords (not in the reference):
+        """Drop-in for VampNet.generate (transformer.py:686-946): see _generate for the keywords.  In precision "f16x2" the call is
+        followed by a read of the context's saturation ledger (one stream synchronisation); if any fp16 plane writer had to clamp a
+        value during the call, its tokens are DISCARDED, the model moves to "bf16x3" (PrecisionFallbackWarning) and the call is
+        repeated from the same generator state — a saturated result never reaches the caller."""
+        kw = dict(locals())
+        kw.pop("self")
+        if self.precision != "f16x2":
+            return self._generate(**kw)
+        snap = torch.get_rng_state()                       # what a seed-less call draws its noise / device seed from
+        out = self._generate(**kw)
+        sat = self.engine.saturation(clear=True)
+        if any(sat):
+            self._fall_back(f"generate() left fp16's range (saturation ledger: operands {sat[0]}, attention {sat[1]}, weights {sat[2]})")
+            torch.set_rng_state(snap)
+            out = self._generate(**kw)
+        return out
+
+    @torch.inference_mode()
+    def _generate(self, codec=None, time_steps: int = 300, _sampling_steps: int = 12, start_tokens=None,
+                  temperature: float = 1.0, mask=None, mask_temperature: float = 10.5, ctrls=None, ctrl_masks=None,
+                  typical_filtering=True, typical_mass=0.15, typical_min_tokens=64, top_p=None, seed: int = None,
+                  sample_cutoff: float = 1.0, return_signal=True, debug=False, causal_weight: float = 0.0,
+                  cfg_scale: float = 3.0, cfg_guidance: float = None, cond=None,
+                  rng: str = "torch", n0_override: int = None, device_seed: int = None,
+                  global_batch: int = None, batch_offset: int = 0, noise=None, call_batch: int = None):
+        """VampNet.generate (transformer.py:686-946).  Extra keywords (not in the reference):
           rng="torch"  : parity mode — noise is drawn from torch's CPU generator in the reference's order;
           rng="torch_device" : the same stream, continued on the GPU (mt19937 + the two distribution transforms run in
                          HIP; torch's generator is advanced as if the host had drawn): seed-exact at device speed;

@@ -23,7 +23,7 @@ import torch
 
 from . import masks
 from .checkpoint import load_model_checkpoint, load_tensor_dict, validate_vampnet_state_dict
-from .engine import Engine, VampNetModel
+from .engine import DEFAULT_PRECISION, Engine, VampNetModel
 
 
 def _load_checkpoint(path):
@@ -96,7 +96,7 @@ class Interface:
                  coarse2fine_lora_ckpt: str = None, codec_ckpt: str = None,
                  wavebeat_ckpt: str = None, device: str = "cuda:0", coarse_chunk_size_s: int = 10,
                  coarse2fine_chunk_size_s: int = 3, compile=True, *, codec=None, max_batch: int = 8,
-                 rng: str = "torch", process_group=None, precision: str = "f16x2"):
+                 rng: str = "torch", process_group=None, precision: str = DEFAULT_PRECISION):
         assert codec_ckpt is not None or codec is not None, "must provide a codec checkpoint"
         assert coarse_ckpt is not None, "must provide a coarse checkpoint"
         if codec is None:
@@ -119,7 +119,7 @@ class Interface:
     @classmethod
     def from_state_dicts(cls, codec, coarse_sd, coarse_kwargs, c2f_sd=None, c2f_kwargs=None, device="cuda:0",
                          coarse_chunk_size_s=10, coarse2fine_chunk_size_s=3, max_batch=8, rng="torch",
-                         process_group=None, precision="f16x2"):
+                         process_group=None, precision=DEFAULT_PRECISION):
         """Build from in-memory reference-format state_dicts (what the checkpoints hold)."""
         self = object.__new__(cls)
         self._init(codec, coarse_sd, coarse_kwargs, c2f_sd, c2f_kwargs, device, coarse_chunk_size_s,
@@ -128,7 +128,7 @@ class Interface:
         return self
 
     def _init(self, codec, csd, ckw, fsd, fkw, device, coarse_chunk_s, c2f_chunk_s, max_batch, rng, process_group,
-              precision="f16x2"):
+              precision=DEFAULT_PRECISION):
         self.precision = precision
         self.codec = codec
         self.device = torch.device(device)
@@ -143,6 +143,7 @@ class Interface:
         self.rng = rng
         self.max_batch = max_batch
         self.pg = process_group
+        self.exchange_log = None          # set to a list to have _allgather_batch record (start, end) events
         self._call_idx = 0
         if process_group is not None:
             import torch.distributed as dist
@@ -153,6 +154,12 @@ class Interface:
         self.coarse = self._make_model(csd, ckw, coarse_chunk_s)
         # the coarse-to-fine chunks of one coarse chunk are batched into one launch: size its workspace for them
         self.c2f = self._make_model(fsd, fkw, c2f_chunk_s, self._c2f_max_batch(coarse_chunk_s, c2f_chunk_s)) if fsd is not None else None
+
+    @property
+    def effective_precision(self):
+        """the precision each model ACTUALLY runs in: an opt-in "f16x2" model that met a value outside fp16's range has moved itself
+        to "bf16x3" (engine.PrecisionFallbackWarning)"""
+        return {"coarse": self.coarse.precision, "c2f": self.c2f.precision if self.c2f is not None else None}
 
     def _c2f_max_batch(self, coarse_chunk_s, c2f_chunk_s):
         """workspace rows of the c2f model: every coarse-to-fine chunk of one coarse chunk, for every item, in one launch"""
@@ -388,18 +395,29 @@ class Interface:
         return outs
 
     def _allgather_batch(self, z):
-        """The single exchange step: every rank contributes its block of batch items (RCCL all-gather over xGMI)."""
-        if self.world == 1:
+        """The single exchange step: every rank contributes its block of batch items (RCCL all-gather over xGMI).  Runs whenever a
+        process group was given — also a one-rank group, so that the device collective (padding to `per * world` rows included) is the
+        same code on one GPU as on eight.  `exchange_log` (a list, or None): (start, end) torch.cuda.Event pairs of every exchange,
+        for bench.py's `exchange_ms`."""
+        if self.pg is None:
             return z
         import torch.distributed as dist
         B = z.shape[0]
         per = math.ceil(B / self.world)
         b0, b1 = self._shard(B)
+        log = getattr(self, "exchange_log", None)
+        if log is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         local = torch.zeros((per,) + tuple(z.shape[1:]), dtype=z.dtype, device=z.device)
         local[:b1 - b0] = z[b0:b1]
         full = torch.empty((per * self.world,) + tuple(z.shape[1:]), dtype=z.dtype, device=z.device)
         dist.all_gather_into_tensor(full, local, group=self.pg)
-        return full[:B].contiguous()
+        out = full[:B].contiguous()
+        if log is not None:
+            ev1.record()
+            log.append((ev0, ev1))
+        return out
 
     # ---- the hot path --------------------------------------------------------------------------
     @torch.inference_mode()

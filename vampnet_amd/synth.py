@@ -44,7 +44,72 @@ def _normal(rng, shape, std=1.0):
     return torch.from_numpy((rng.standard_normal(size=shape) * std).astype(np.float32))
 
 
-def synth_state_dict(dims: dict, seed: int = 0) -> dict:
+def synth_state_dict(dims: dict, seed: int = 0, heavy_tail=None) -> dict:
+    """heavy_tail: None = PyTorch-default-like scales (activations O(1)); "in_range" / "saturating" = the same model re-shaped into
+    what TRAINED T5-style stacks look like (see _heavy_tail): outlier residual channels, large norm gains, log-normal row scales —
+    with every value still inside fp16's range ("in_range") or with a GEGLU unit beyond 65504 and attention values beyond 4094
+    ("saturating": what precision "f16x2" must detect and hand to "bf16x3")."""
+    sd = _synth_state_dict(dims, seed)
+    if heavy_tail:
+        _heavy_tail(sd, dims, seed, heavy_tail)
+    return sd
+
+
+# outlier residual channels of the heavy-tailed variants (indices < 256 so that the tiny test dims work too)
+HEAVY_CHANNELS = (5, 77, 200)
+
+
+def _heavy_tail(sd, dims, seed, kind):
+    """Re-shape a default-init state_dict into a "trained-like" one, in place (numpy PCG64 stream of its own):
+      * log-normal scales on the rows of every attention / FFN matrix (sigma 0.4);
+      * three OUTLIER residual channels: the embedding bias puts +-A there for every token (A = 1e3 "in_range", 1e4 "saturating"),
+        i.e. after RMSNorm those channels sit at ~ +-20 and everything else at ~ 1 / (A sqrt(3 / D));
+      * norm gains up to 30 (all norms: a random 2 % of the channels between 5 and 30; the outlier channels get gain 30 in layer 0
+        -> normalised outliers of ~ 600);
+      * layer 0: one GEGLU unit whose value and gate both read outlier channel 0 with weight w_g -> |p1 gelu(p2)| ~ (600 w_g)^2, and one
+        attention value channel reading it with weight w_v -> |v| ~ 600 w_v.  "in_range": ~3e4 and ~3e3 (inside fp16 / inside the
+        x16 attention operand); "saturating": ~3.6e5 and ~6e3 (beyond both).  The consumers of those two units (a W2 column, an fc
+        column) are scaled down so the rest of the model keeps seeing O(1) updates: the point is the operand range, not chaos."""
+    assert kind in ("in_range", "saturating"), kind
+    rng = np.random.default_rng(1000003 * (seed + 1) + (1 if kind == "saturating" else 0))
+    D, L = dims["d_model"], dims["n_layers"]
+    A = 1e4 if kind == "saturating" else 1e3
+    y_out = 30.0 * math.sqrt(D / 3.0)                      # normalised outlier magnitude at gain 30 (620 at D = 1280)
+    w_g = math.sqrt(3.6e5 if kind == "saturating" else 3.0e4) / y_out        # |p1 gelu(p2)| = (y_out w_g)^2
+    w_v = (6.0e3 if kind == "saturating" else 3.0e3) / y_out                 # |v| = y_out w_v
+    c0 = HEAVY_CHANNELS[0]
+    for i in range(L):
+        p = f"transformer.layers.{i}."
+        for name in ("self_attn.w_qs", "self_attn.w_ks", "self_attn.w_vs", "self_attn.fc", "feed_forward.w_1", "feed_forward.w_2"):
+            w = sd[p + name + ".weight"]
+            w *= torch.from_numpy(np.exp(0.4 * rng.standard_normal(w.shape[0])).astype(np.float32))[:, None]
+        for nm in ("norm_1", "norm_3"):
+            g = sd[p + nm + ".weight"]
+            pick = rng.random(D) < 0.02
+            g[torch.from_numpy(pick)] = torch.from_numpy(rng.uniform(5.0, 30.0, int(pick.sum())).astype(np.float32))
+    g = sd["transformer.norm.weight"]
+    pick = rng.random(D) < 0.02
+    g[torch.from_numpy(pick)] = torch.from_numpy(rng.uniform(5.0, 30.0, int(pick.sum())).astype(np.float32))
+    bias = sd["embedding.out_proj.bias"]
+    for k, c in enumerate(HEAVY_CHANNELS):
+        bias[c] = A * (1.0 if k % 2 == 0 else -1.0)
+    p = "transformer.layers.0."
+    for nm in ("norm_1", "norm_3"):
+        for c in HEAVY_CHANNELS:
+            sd[p + nm + ".weight"][c] = 30.0
+    # the GEGLU unit: value row j and gate row 2D + j of w_1 read outlier channel c0 (positive gate: gelu ~ identity)
+    j = 11
+    w1 = sd[p + "feed_forward.w_1.weight"]
+    w1[j].zero_(); w1[2 * D + j].zero_()
+    w1[j, c0] = w_g; w1[2 * D + j, c0] = w_g
+    sd[p + "feed_forward.w_2.weight"][:, j] *= 1e-5
+    # the attention value channel (head 0, d = 3)
+    wv = sd[p + "self_attn.w_vs.weight"]
+    wv[3].zero_(); wv[3, c0] = w_v
+    sd[p + "self_attn.fc.weight"][:, 3] *= 1e-3
+
+
+def _synth_state_dict(dims: dict, seed: int = 0) -> dict:
     rng = np.random.default_rng(seed)
     D, H, L = dims["d_model"], dims["n_heads"], dims["n_layers"]
     C, nc, ld, V = dims["n_codebooks"], dims["n_cond"], dims["latent_dim"], dims["vocab"]
