@@ -80,6 +80,9 @@ GEN_CASES = [
     dict(B=2, T=33, kw=dict(_sampling_steps=4, seed=3, top_p=0.9)),
     dict(B=1, T=50, kw=dict(_sampling_steps=4, seed=4, temperature=1e-8)),
     dict(B=2, T=29, kw=dict(_sampling_steps=3, seed=5, temperature=0.0, sample_cutoff=0.5)),
+    # cfg_guidance: the reference doubles the batch with an all-MASK copy and then discards the guided logits (transformer.py:845-847)
+    dict(B=2, T=31, kw=dict(_sampling_steps=4, seed=6, cfg_guidance=3.0)),
+    dict(B=1, T=40, kw=dict(_sampling_steps=3, seed=7, cfg_guidance=0.5, temperature=0.9, top_p=0.95)),
 ]
 
 

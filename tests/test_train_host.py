@@ -305,6 +305,54 @@ def test_optimizer_indices_follow_the_reference_parameter_order_with_adapters():
         tr.load_optimizer_state_dict({"state": ref_state, "param_groups": [{"params": list(range(len(base)))}]})
 
 
+def test_full_mode_save_writes_trainable_adapters():
+    """A full-mode state_dict() feeds a later LoRA fine-tune (pretrain -> `fine_tune`, train.py:696): its adapters must be loralib's
+    FRESH ones — lora_B = 0 (the function is the saved weights') and lora_A kaiming-uniform(a = sqrt 5), not zeros: with A = 0 and
+    B = 0 both adapter gradients (dL/dA ~ B^T .., dL/dB ~ .. A^T) vanish and the fine-tune never moves.  Checked on the gradient."""
+    import math
+    from vampnet_amd.train import LORA_KEYS, LORA_R
+    dims = W.TINY_COARSE_DIMS
+    base, cb = W.synth_state_dict(dims, 0), W.synth_codebooks()
+    tr = OracleBackedTrainer(base, dims, cb)
+    tmpl = {}
+    for k, v in base.items():                             # the template Trainer.__init__ builds: adapters behind their Linear
+        tmpl[k] = (tuple(v.shape), v.dtype)
+        stem = k[:-len(".weight")]
+        if k.endswith(".weight") and any(stem.endswith(key) for key in LORA_KEYS):
+            tmpl[stem + ".lora_A"] = ((LORA_R, v.shape[1]), torch.float32)
+            tmpl[stem + ".lora_B"] = ((v.shape[0], LORA_R), torch.float32)
+    tr._sd_template = tmpl
+    full = tr.state_dict()
+    again = tr.state_dict()
+    n_ad = 0
+    for k, v in full.items():
+        if k.endswith(".lora_B"):
+            assert not bool(v.any()), k
+        elif k.endswith(".lora_A"):
+            n_ad += 1
+            bound = 1.0 / math.sqrt(v.shape[1])           # kaiming_uniform_(a = sqrt 5) on (r, fan_in): U(+-1 / sqrt(fan_in))
+            assert float(v.abs().max()) <= bound and float(v.abs().max()) > 0.5 * bound and float(v.std()) > 0.4 * bound, k
+            assert torch.equal(v, again[k]), "repeated saves must write the same adapters"
+        else:
+            assert torch.equal(v.reshape(base[k].shape), base[k]), k
+    assert n_ad == len(LORA_KEYS) * dims["n_layers"]
+    # the function is unchanged (B = 0) and dL/dB is NOT zero for y = x W^T + s (x A^T) B^T: dL/dB = s g^T (x A^T)
+    k0 = "transformer.layers.0.self_attn.w_qs"
+    x = torch.randn(5, full[k0 + ".weight"].shape[1])
+    A, B = full[k0 + ".lora_A"], full[k0 + ".lora_B"].clone().requires_grad_(True)
+    y = x @ full[k0 + ".weight"].t() + 0.125 * (x @ A.t()) @ B.t()
+    assert torch.equal(y.detach(), x @ base[k0 + ".weight"].t())
+    y.square().sum().backward()
+    assert float(B.grad.abs().max()) > 0.0
+    # files of the old form (A = 0 and B = 0) are treated as "no adapters" by the LoRA packer: A is drawn fresh
+    tr.only_lora = True
+    old = {**full, **{k: torch.zeros_like(v) for k, v in full.items() if "lora_" in k}}
+    vec = tr.pack_lora(old)
+    assert float(vec.abs().max()) > 0.0
+    got = tr.export_lora(vec)
+    assert bool(got[k0 + ".lora_A"].any()) and not bool(got[k0 + ".lora_B"].any())
+
+
 # ---------------------------------------------------------------------------------------- ZeRO-1 (train.py:588-590)
 class OracleBackedZeroTrainer(OracleBackedTrainer):
     """ZeRO-1 protocol of the product Trainer (reduce-scatter, norm from the slices' sums of squares, slice update, all-gather,

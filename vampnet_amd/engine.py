@@ -501,9 +501,14 @@ class VampNetModel:
           n0_override may be a per-item list and `noise` a pre-drawn (exp, unif) ledger when the caller batches
                          items of several reference generate() calls (Interface.coarse_to_fine's chunks).
         `typical_filtering/typical_mass/typical_min_tokens` are accepted and have no effect, exactly like the
-        reference (transformer.py:989-993 discards the filter's result)."""
-        if ctrls is not None or cfg_guidance is not None:
-            raise NotImplementedError("ctrls / cfg_guidance are never used by Interface (SURVEY.md App. A.3)")
+        reference (transformer.py:989-993 discards the filter's result).
+        `cfg_guidance` (transformer.py:771-783, :845-847, :940): like the reference, the batch is doubled with an all-MASK copy
+        (every codebook; mask all ones) after N0 was counted on the caller's items, all 2B items are sampled — consuming 2B items'
+        worth of noise per step — and the first B are returned.  The reference computes the guided logits into a local it never
+        uses (:845-847), so the logits that are sampled are the plain ones; the VALUE of cfg_guidance has no effect there or here
+        (pinned against the reference: tests/test_oracle_vs_reference.py).  Needs max_batch >= 2B; not offered for sharded calls."""
+        if ctrls is not None:
+            raise NotImplementedError("ctrls are never used by Interface and the shipped models have no control inputs (SURVEY.md App. A.3)")
         if return_signal and not hasattr(codec, "decode_signal"):
             raise ValueError("return_signal=True (the reference's default, transformer.py:704) decodes the sampled tokens through "
                              "`codec` (transformer.py:943-944): pass a codec that can decode, or return_signal=False for tokens")
@@ -522,6 +527,18 @@ class VampNetModel:
             mask = mask[:, None, :].repeat(1, Cn, 1)
         mask = (mask != 0).to(torch.int64).contiguous()
         steps = int(_sampling_steps)
+        nb_ret = B
+        if cfg_guidance is not None:
+            if n0_override is not None or noise is not None or call_batch or (global_batch or B) != B or batch_offset:
+                raise NotImplementedError("cfg_guidance on a sharded / batched-call generate(): the reference's doubled batch puts the "
+                                          "all-MASK copies of ALL items behind the last real item, which a shard cannot see")
+            if 2 * B > self.dims.max_batch:
+                raise ValueError(f"cfg_guidance doubles the batch (transformer.py:771-783): {2 * B} items exceed this model's "
+                                 f"workspace (max_batch = {self.dims.max_batch})")
+            n0_override = int(((mask != 0) | (z == self.mask_token)).sum().item())      # :766 counted BEFORE the doubling
+            z = torch.cat([z, torch.full_like(z, self.mask_token)], dim=0).contiguous()
+            mask = torch.cat([mask, torch.ones_like(mask)], dim=0).contiguous()
+            B = 2 * B
         if n0_override is None:
             n0 = int(((mask != 0) | (z == self.mask_token)).sum().item())   # transformer.py:762-766, batch-wide
             n0_items = [n0] * B
@@ -570,6 +587,8 @@ class VampNetModel:
             self.engine.torch_rng().store_to_torch()        # waits for the side stream only; the model keeps running
         if exp is not None:      # keep the noise alive until the enqueued work has consumed it
             torch.cuda.current_stream(self.device).synchronize()
+        if cfg_guidance is not None:
+            out = out[:nb_ret].contiguous()                                   # transformer.py:940-941
         return self.decode(out, codec) if return_signal else out
 
     @torch.inference_mode()

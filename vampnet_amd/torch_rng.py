@@ -81,6 +81,8 @@ class DeviceTorchRng:
         decides: the mask path falls back to the host twin, the noise path has rng='torch')."""
         if kind in DeviceTorchRng._checked:
             return
+        if kind in DeviceTorchRng._failed:                 # a failed check is remembered too: every later call falls back at once
+            raise RuntimeError(DeviceTorchRng._failed[kind])
         g = torch.Generator()
         g.set_state(torch.get_rng_state())
         dev = self.engine.device
@@ -112,11 +114,13 @@ class DeviceTorchRng:
         else:
             raise ValueError(kind)
         if not ok:
-            raise RuntimeError("this torch build's CPU generator does not follow the sequential mt19937 formulas the device RNG "
-                               "continues — " + msg)
+            DeviceTorchRng._failed[kind] = ("this torch build's CPU generator does not follow the sequential mt19937 formulas the "
+                                            "device RNG continues — " + msg)
+            raise RuntimeError(DeviceTorchRng._failed[kind])
         DeviceTorchRng._checked.add(kind)
 
     _checked = set()
+    _failed = {}
 
     def load_from_torch(self, kind: str = "noise"):
         if getattr(self, "_producer", None) is None:

@@ -319,7 +319,9 @@ class Trainer:
         of THIS step count.  A COLLECTIVE: every rank of the group calls it (the reference does the same before its rank-0 save,
         train.py:376-378 `consolidate_state_dict`).  No-op without ZeRO-1."""
         if getattr(self, "zero1", False):
-            self._consolidated = (self.steps, self.consolidate_state())
+            # kept on the HOST (2 x n_total fp32 = 2.7 GB for the coarse model would otherwise sit on every rank's GPU and undo the
+            # ZeRO-1 saving) and dropped again by the optimizer_state_dict() that consumes it
+            self._consolidated = (self.steps, tuple(t.cpu() for t in self.consolidate_state()))
 
     def update(self):
         """(all-reduce) -> clip -> AdamW -> scheduler.step(); advances self.steps."""
@@ -423,6 +425,7 @@ class Trainer:
                 raise RuntimeError("ZeRO-1: call Trainer.consolidate() on EVERY rank (a collective) before optimizer_state_dict() / "
                                    "save_checkpoint() of this step; save_checkpoint(all_ranks=True) does it when every rank calls it")
             m, v = (exp(t) for t in cons[1])
+            self._consolidated = None            # consumed: the next save of another step needs a fresh consolidate()
         else:
             m, v = exp(self.adam_m), exp(self.adam_v)
         index = {k: i for i, k in enumerate(self._all_param_names())}
@@ -611,13 +614,21 @@ class Trainer:
         if self.only_lora:          # frozen base (as loaded) + the current adapters, like the reference model's state_dict()
             return {**self._base_sd, **self.lora_state_dict()}
         # full mode: adapters a checkpoint held were merged into the weights at load, so the reference model that loads this
-        # file (it always owns lora_A / lora_B) gets the merged weights with ZERO adapters — the same function, the same
-        # parameter list as optimizer.pth indexes
+        # file (it always owns lora_A / lora_B) gets the merged weights with FRESH adapters — lora_B = 0 (the function is the merged
+        # weights'), lora_A as loralib.Linear.reset_parameters leaves it (kaiming-uniform, a = sqrt 5).  Not zeros for A: with A = 0
+        # AND B = 0 both adapter gradients vanish (dL/dA ~ B^T, dL/dB ~ A^T) and a LoRA fine-tune started from this file — here or
+        # in the reference — would never move.  The draw is seeded by the parameter name, so repeated saves write the same file.
         out = self.export(self.params)
         full = {}
         for k, (shape, dtype) in getattr(self, "_sd_template", {}).items():
             if k in out:
                 full[k] = out[k]
+            elif k.endswith(".lora_A"):
+                import zlib
+                a = torch.empty(shape, dtype=torch.float32)
+                g = torch.Generator().manual_seed(zlib.crc32(k.encode()))
+                bound = math.sqrt(6.0 / ((1.0 + 5.0) * shape[1]))                 # kaiming_uniform_(a = sqrt 5): gain^2 = 2 / (1 + a^2)
+                full[k] = a.uniform_(-bound, bound, generator=g)
             elif "lora_" in k:
                 full[k] = torch.zeros(shape, dtype=torch.float32)
         full.update({k: v for k, v in out.items() if k not in full})
@@ -648,6 +659,8 @@ class Trainer:
                 n_out, n_in = self._sd_template[name + ".weight"][0]
                 a = sd.get(name + ".lora_A")
                 b = sd.get(name + ".lora_B")
+                if a is not None and b is not None and init_missing and not bool(a.any()) and not bool(b.any()):
+                    a = None                  # an all-zero pair (files of an older full-mode save) can never train: treat as missing
                 if a is None:
                     a = torch.zeros(LORA_R, n_in)
                     if init_missing:
