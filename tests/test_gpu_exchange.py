@@ -39,13 +39,13 @@ def _worker(port, q):
         torch.manual_seed(3)
         mask = itf.build_mask(z)
         got = itf.vamp(z, mask, batch_size=3, seed=11, _sampling_steps=3).cpu()
-        torch.cuda.synchronize()
-        ms = [a.elapsed_time(b) for a, b in itf.exchange_log]
         ref = O.vamp(O.OracleModels(csd, W.TINY_COARSE_DIMS, fsd, W.TINY_C2F_DIMS, cb), z, mask, batch_size=3, seed=11, _sampling_steps=3)
         # the raw collective on a block the trim has to cut (5 rows in a 1-rank group: per = 5, no padding possible with one rank;
         # the padded form runs in the 2-rank gloo test)
         t = torch.arange(5 * 14 * 7, device="cuda").reshape(5, 14, 7)
         same = torch.equal(itf._allgather_batch(t), t)
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in itf.exchange_log]
         q.put(dict(ok=bool(torch.equal(got, ref)), n_exchange=len(ms), ms=ms, backend=dist.get_backend(), raw=same))
     finally:
         dist.destroy_process_group()
