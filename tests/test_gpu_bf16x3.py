@@ -203,3 +203,49 @@ def test_f16x2_probe_falls_back_on_activations_beyond_fp16_range(eng):
     ref = O.forward(sd, W.TINY_COARSE_DIMS, O.from_codes(sd, cb, codes))
     got = m.forward_codes(codes).cpu()
     assert torch.isfinite(got).all() and (got - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("precision", SPLIT_PRECISIONS)
+def test_folded_norm_matches_unfolded_and_oracle(precision):
+    """The split-plane models fold every RMSNorm into its consumer GEMM (engine.hip forward_folded: y W^T = r (.) (x (W (.) w)^T), the
+    residual GEMMs' epilogues write the planes and the sums of squares of the new rows).  A context created with VN_FOLD_NORM=0 runs
+    the norm kernels instead: both forms agree with each other and with the oracle at the fp32 tolerance, on a shape that takes the
+    one-round GEMM path and on one that splits the residual GEMMs along K (their reduce pass then writes planes + sums: vn_launch_rowprep),
+    and the tile heights of the folded form are bitwise equal to each other."""
+    import os
+    from vampnet_amd.engine import Engine, VampNetModel
+    dims = dict(W.TINY_COARSE_DIMS, n_layers=3)
+    cb, sd = W.synth_codebooks(), W.synth_state_dict(dict(W.TINY_COARSE_DIMS, n_layers=3), 4)
+    sd["transformer.layers.1.norm_3.weight"] *= 3.0                       # a norm weight far from 1: a forgotten fold would show
+    eng_f = Engine("cuda:0")
+    os.environ["VN_FOLD_NORM"] = "0"
+    try:
+        eng_u = Engine("cuda:0")
+    finally:
+        del os.environ["VN_FOLD_NORM"]
+    mf = VampNetModel(eng_f, sd, cb, max_batch=4, max_T=575, precision=precision, **model_kwargs(dims))
+    mu = VampNetModel(eng_u, sd, cb, max_batch=4, max_T=575, precision=precision, **model_kwargs(dims))
+    for B, T in ((4, 575), (1, 575), (2, 37), (1, 1)):
+        codes = W.synth_codes(B, 4, T, seed=12)
+        codes[:, :, ::3] = 1024
+        ref = TM.to_native(O.forward(sd, dims, O.from_codes(sd, cb, codes)), 4)
+        a, b = mf.forward_codes(codes, layout="native").cpu(), mu.forward_codes(codes, layout="native").cpu()
+        print(f"[{precision}] B={B} T={T}: folded vs oracle {(a - ref).abs().max():.3e}, unfolded vs oracle {(b - ref).abs().max():.3e}, "
+              f"folded vs unfolded {(a - b).abs().max():.3e}")
+        assert (a - ref).abs().max().item() <= TM.LOGIT_ATOL_TINY and (b - ref).abs().max().item() <= TM.LOGIT_ATOL_TINY
+    codes = W.synth_codes(3, 4, 300, seed=13)
+    outs = {}
+    try:
+        for bm in (128, 192, 256):
+            eng_f.lib.vn_debug_x3_config(eng_f.handle, bm, -1, -1)
+            outs[bm] = mf.forward_codes(codes).clone()
+        for sk in (2, 4):                                                  # forced k-splits of the residual GEMMs: the reduce pass writes planes + sums
+            eng_f.lib.vn_debug_x3_config(eng_f.handle, 128, sk, -1)
+            outs[f"sk{sk}"] = mf.forward_codes(codes).clone()
+    finally:
+        eng_f.lib.vn_debug_x3_config(eng_f.handle, 0, -1, -1)
+    assert torch.equal(outs[128], outs[192]) and torch.equal(outs[128], outs[256])
+    for sk in (2, 4):
+        d = (outs[f"sk{sk}"] - outs[128]).abs().max().item()
+        print(f"[{precision}] forced split {sk} vs one round: {d:.3e}")
+        assert d <= TM.LOGIT_ATOL_TINY

@@ -112,6 +112,72 @@ __global__ __launch_bounds__(256) void vn_splitk_reduce_rmsnorm_kernel(const flo
     vn_rmsnorm_row<VEC>(v, w, y, y16, plane16, row, D, eps, lane, sat);
 }
 
+// Folded RMSNorm, producer side for rows that do not come out of a GEMM epilogue: the reduce pass of a split RESIDUAL GEMM (nsplit >= 1:
+// x += sum of the split images in the fixed order of vn_splitk_reduce_kernel, written back) and the first layer's input (nsplit == 0: the
+// embedding's rows as they are).  Writes x16 = the split planes of the (raw, un-normalised) row and ssq[row][D / 128] = the sums of squares
+// of its 128-column groups — what the residual epilogue of gemm_x3.hip writes for rows it produces itself.  One wave per row; lane l
+// holds columns 4 (l + 64 i) .. + 3, i.e. group 2 i + (l >> 5), position l & 31 inside it.
+template <int VEC>
+__global__ __launch_bounds__(256) void vn_rowprep_kernel(const float* __restrict__ partial, int nsplit, float* __restrict__ x,
+                                                         uint16_t* __restrict__ x16, long plane16, float* __restrict__ ssq, int rows, int D,
+                                                         unsigned* sat) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long plane4 = (long)rows * (D >> 2);
+    const f32x4* pr = (const f32x4*)partial + (size_t)row * (D >> 2);
+    f32x4* xr = (f32x4*)(x + (size_t)row * D);
+    f32x4 v[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = xr[lane + 64 * i];
+    if (nsplit > 0) {
+        f32x4 part[4][VEC];
+        // every load of the row in flight before the first add (as in vn_splitk_reduce_rmsnorm_kernel); order: split 0, 1, .., residual
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp)
+            if (sp < nsplit) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) part[sp][i] = pr[lane + 64 * i + sp * plane4];
+            }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            f32x4 a = part[0][i];
+#pragma unroll
+            for (int sp = 1; sp < 4; ++sp)
+                if (sp < nsplit) { a[0] += part[sp][i][0]; a[1] += part[sp][i][1]; a[2] += part[sp][i][2]; a[3] += part[sp][i][3]; }
+            for (int sp = 4; sp < nsplit; ++sp) {
+                const f32x4 b = pr[lane + 64 * i + sp * plane4];
+                a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+            }
+            a[0] += v[i][0]; a[1] += v[i][1]; a[2] += v[i][2]; a[3] += v[i][3];
+            xr[lane + 64 * i] = a;
+            v[i] = a;
+        }
+    }
+    bool bad = false;
+    const int nt = D >> 7;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        vn_store_planes4(x16, plane16, row, 4 * (lane + 64 * i), D, v[i], bad);
+        const float s = vn_ssq128(v[i]);
+        if ((lane & 31) == 0) ssq[(size_t)row * nt + 2 * i + (lane >> 5)] = s;
+    }
+    vn_sat_report(sat, VN_SAT_OPERAND, bad);
+}
+
+int vn_launch_rowprep(vn_ctx* ctx, const float* partial, int nsplit, float* x, uint16_t* x16, long plane16, float* ssq, int rows, int D,
+                      hipStream_t s) {
+    if (rows <= 0) return VN_OK;
+    if (!x || !x16 || !ssq || !vn_planes_tiled(plane16) || (nsplit > 0 && !partial))
+        return vn_fail(ctx, VN_ERR_INVALID, "rowprep: needs x, tiled planes and the ssq buffer%s", "");
+    const dim3 grid(vn_cdiv(rows, 4)), block(256);
+    if (D == 1280) hipLaunchKernelGGL(vn_rowprep_kernel<5>, grid, block, 0, s, partial, nsplit, x, x16, plane16, ssq, rows, D, ctx->sat);
+    else if (D == 256) hipLaunchKernelGGL(vn_rowprep_kernel<1>, grid, block, 0, s, partial, nsplit, x, x16, plane16, ssq, rows, D, ctx->sat);
+    else return vn_fail(ctx, VN_ERR_UNSUPPORTED, "rowprep: D=%s%ld must be 256 or 1280", "", D);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
 // generic fallback (any D multiple of 4): strided loop, two passes over the row (second from L1/L2)
 __global__ __launch_bounds__(256) void vn_rmsnorm_generic_kernel(const float* __restrict__ x,
                                                                  const float* __restrict__ w,

@@ -111,6 +111,8 @@ void vn_tune_init(vn_tune* t) {
     t->attn_x3 = env_int("VN_ATTN_X3", -1);
     t->a_tiled = env_int("VN_X3_ATILED", 1) != 0;
     t->w_tiled = env_int("VN_X3_WTILED", 1) != 0;
+    // RMSNorms folded into their consumer GEMMs (split-plane precisions); needs the tiled operand layouts and the staged epilogues
+    t->fold_norm = env_int("VN_FOLD_NORM", 1) != 0 && t->a_tiled && t->w_tiled && t->x3_staged;
     t->epoch = 0;
 }
 
@@ -241,6 +243,8 @@ extern "C" void vn_model_destroy(vn_model* m) {
     (void)hipFree(m->w_h2);
     (void)hipFree(m->qk16);
     (void)hipFree(m->vt16);
+    (void)hipFree(m->x16);
+    (void)hipFree(m->ssq);
     delete m;
 }
 
@@ -298,6 +302,68 @@ extern "C" int vn_debug_attention_x3_force(vn_ctx* ctx, int on) {
     return VN_OK;
 }
 
+// The transformer stack + classifier with the RMSNorms FOLDED into their consumer GEMMs (split-plane precisions, m->folded):
+//   y W^T = r (.) (x (W (.) w)^T),   r = rsqrt(mean(x^2) + eps) per row  (transformer.py:55-58 followed by a Linear / the classifier)
+// The consumer weights hold W (.) w (set_bf16_planes / vn_model_set_f16x2).  The residual GEMMs (Wo, W2) write, from their epilogues,
+// the split planes of the NEW residual rows (x16) and the rows' sums of squares per 128-column group (ssq); QKV, W1 and the classifier
+// read x16 as their A operand and scale their accumulator rows by r in their epilogues.  No norm kernel runs: 41 launches and their
+// read of x + write of y per forward are gone (one vn_launch_rowprep for the embedding's rows instead); the rounding order differs
+// from norm-then-GEMM by what one fp32 rounding per weight and per output amounts to (NOTES.md: 9.2e-8 vs 9.2-9.9e-8 rms on the
+// model's shapes, the fp32 accumulation itself 3.5e-7).
+static int forward_folded(vn_model* m, int B, int T, float* logits, hipStream_t s) {
+    vn_ctx* ctx = m->ctx;
+    const int D = m->D, H = m->H, M = B * T;
+    const bool h2 = m->w_plane == VN_PLANES_TILED_H2;
+    const long ap = h2 ? VN_PLANES_TILED_H2 : VN_PLANES_TILED;
+    const long plane = (long)B * H * T * VN_DHEAD;
+    const int cus = vn_num_cus(ctx);
+    const int attn_np = h2 ? 2 : 3;
+    const bool attn_x3_fits = vn_attention_x3_lds_bytes(T, vn_attention_x3_plan(ctx, B, H, T, cus), attn_np) <= 160 * 1024;
+    const bool attn_x3 = attn_x3_fits && (ctx->tune.attn_x3 >= 0 ? ctx->tune.attn_x3 != 0 : true);
+    auto gemm = [&](const uint16_t* A16, int id, int layer, int Mr, int N, int K) {
+        vn_gemm_args a{};
+        a.A = (const float*)A16;
+        a.W = (const float*)((h2 ? m->w_h2 + 2 * vn_tensor_offset(&m->d, id, layer) : m->w_tiled + 3 * vn_tensor_offset(&m->d, id, layer)));
+        a.bf16 = h2 ? 3 : 2; a.a_plane = ap; a.w_plane = m->w_plane; a.w_tiled = 1;
+        a.M = Mr; a.N = N; a.K = K; a.ldc = N;
+        return a;
+    };
+    auto consumer = [&](vn_gemm_args& a) { a.ssq_in = m->ssq; a.fold_eps = m->d.eps; };
+    auto producer = [&](vn_gemm_args& a) { a.C = m->x; a.X16 = m->x16; a.x16_plane = ap; a.ssq_out = m->ssq; };
+    int rc;
+    if ((rc = vn_launch_rowprep(ctx, nullptr, 0, m->x, m->x16, ap, m->ssq, M, D, s))) return rc;     // the embedding's rows
+    for (int l = 0; l < m->L; ++l) {
+        vn_gemm_args a = gemm(m->x16, VN_W_QKV, l, M, 3 * D, D);                  // q, k, v of norm_1(x)
+        consumer(a);
+        a.T = T; a.H = H; a.qkv_plane = plane;
+        if (attn_x3) {
+            a.C16 = m->qk16; a.c_plane = m->qk_plane; a.V16 = m->vt16; a.v_plane = m->vt_plane;
+            if ((rc = vn_launch_gemm_f32(ctx, a, VN_EPI_QKV3, s))) return rc;
+            if ((rc = vn_launch_attention_x3(ctx, m->qk16, m->qk16 + plane, m->qk_plane, m->vt16, m->vt_plane, m->bias_full, nullptr,
+                                             m->y16, ap, B, H, T, cus, attn_np, s)))
+                return rc;
+        } else {
+            a.C = m->qkv;
+            if ((rc = vn_launch_gemm_f32(ctx, a, VN_EPI_QKV, s))) return rc;
+            if ((rc = vn_launch_attention(ctx, m->qkv, m->qkv + plane, m->qkv + 2 * plane, m->bias_full, m->y, B, H, T, s, m->y16, ap))) return rc;
+        }
+        vn_gemm_args o = gemm(m->y16, VN_W_WO, l, M, D, D);                       // x += attention output . Wo^T
+        producer(o);
+        if ((rc = vn_launch_gemm_f32(ctx, o, VN_EPI_RESIDUAL, s))) return rc;
+        vn_gemm_args f1 = gemm(m->x16, VN_W_W1, l, M, 4 * D, D);                  // g = p1 gelu(p2) of norm_3(x)
+        consumer(f1);
+        f1.C = m->g; f1.C16 = m->g16; f1.c_plane = ap; f1.ldc = 2 * D;
+        if ((rc = vn_launch_gemm_f32(ctx, f1, VN_EPI_GEGLU, s))) return rc;
+        vn_gemm_args f2 = gemm(m->g16, VN_W_W2, l, M, D, 2 * D);                  // x += g . W2^T
+        producer(f2);
+        if ((rc = vn_launch_gemm_f32(ctx, f2, VN_EPI_RESIDUAL, s))) return rc;
+    }
+    vn_gemm_args c = gemm(m->x16, VN_W_CLS_W, 0, M, m->Cp * m->d.vocab, D);       // classifier of the final norm
+    consumer(c);
+    c.bias = W(m, VN_W_CLS_B); c.C = logits;
+    return vn_launch_gemm_f32(ctx, c, VN_EPI_BIAS, s);
+}
+
 // forward on the int32 token buffer m->z -> m->logits   (layers.py:134-163 + transformer.py:617-639)
 static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logits, hipStream_t s) {
     vn_ctx* ctx = m->ctx;
@@ -307,6 +373,7 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
     if ((rc = vn_launch_embed(ctx, z, W(m, VN_W_EMB_TABLES), W(m, VN_W_EMB_WT), W(m, VN_W_EMB_B), m->x, B,
                               m->d.n_codebooks, T, m->d.vocab + 1, m->d.latent_dim, D, s)))
         return rc;
+    if (m->folded && m->blob16 && m->w_plane != 0 && m->x16 && m->ssq) return forward_folded(m, B, T, logits, s);
     const long plane = (long)B * H * T * VN_DHEAD;
     const bool bf = m->blob16 != nullptr;
     // bf16 fast mode: the four big GEMM operands (normalised rows, attention output, GEGLU output, weights) are bf16,
@@ -506,6 +573,10 @@ static int plane_buffers(vn_model* m, bool attention_planes) {
     const size_t rows16 = ((size_t)m->max_rows + 15) / 16 * 16;        // the tiled layout addresses rows in blocks of 16
     if (!m->y16 && (rc = dev_alloc(m->ctx, &m->y16, (size_t)3 * rows16 * m->D))) return rc;
     if (!m->g16 && (rc = dev_alloc(m->ctx, &m->g16, (size_t)3 * rows16 * 2 * m->D))) return rc;
+    if (attention_planes && m->ctx->tune.fold_norm) {     // folded RMSNorms: planes of the raw residual rows + their group sums of squares
+        if (!m->x16 && (rc = dev_alloc(m->ctx, &m->x16, (size_t)3 * rows16 * m->D))) return rc;
+        if (!m->ssq && (rc = dev_alloc(m->ctx, &m->ssq, (size_t)rows16 * (m->D / 128)))) return rc;
+    }
     if (attention_planes && (!m->qk16 || !m->vt16)) {   // attention operands as split planes (bf16x3: three, f16x2: two; sized for three)
         m->qk_plane = 2 * m->max_rows * (long)m->D;
         m->vt_plane = (long)m->H * ((m->max_rows + 31) / 32) * (VN_DHEAD * 32);
@@ -524,7 +595,7 @@ static int plane_buffers(vn_model* m, bool attention_planes) {
 }
 
 static int set_bf16_planes(vn_model* m, const void* blob16_dev, long w_plane) {
-    if (!blob16_dev) { m->blob16 = nullptr; m->w_plane = 0; return VN_OK; }          // back to exact fp32 MFMA
+    if (!blob16_dev) { m->blob16 = nullptr; m->w_plane = 0; m->folded = 0; return VN_OK; }          // back to exact fp32 MFMA
     if (m->D % 64) return vn_fail(m->ctx, VN_ERR_UNSUPPORTED, "bf16 modes need d_model %% 64 == 0%s", "");
     int rc;
     if ((rc = plane_buffers(m, w_plane > 0))) return rc;
@@ -537,16 +608,26 @@ static int set_bf16_planes(vn_model* m, const void* blob16_dev, long w_plane) {
         VN_HIP_CHECK(m->ctx, hipDeviceSynchronize());
         const uint16_t* planes = (const uint16_t*)blob16_dev;
         const long D = m->D;
-        auto tile = [&](int id, int layer, long rows, int K) {
+        const bool fold = m->ctx->tune.fold_norm != 0;
+        // `norm` != 0: a consumer of an RMSNorm in a model with folded norms — its planes are built from the fp32 blob with the norm
+        // weight multiplied into the columns (W' = W (.) w_norm, one fp32 rounding, then the exact split); the others are re-laid
+        // from the caller's planes
+        auto tile = [&](int id, int layer, long rows, int K, int norm_id = -1, int norm_layer = 0) {
             const long off = vn_tensor_offset(&m->d, id, layer);
+            if (fold && norm_id >= 0)
+                return vn_launch_fold_planes(m->ctx, m->blob + off, m->blob + vn_tensor_offset(&m->d, norm_id, norm_layer), m->w_tiled + 3 * off,
+                                             rows, K, VN_PLANES_TILED, nullptr);
             return vn_launch_tile_planes(m->ctx, planes + off, w_plane, m->w_tiled + 3 * off, rows, K, nullptr);
         };
         for (int l = 0; l < m->L; ++l)
-            if ((rc = tile(VN_W_QKV, l, 3 * D, (int)D)) || (rc = tile(VN_W_WO, l, D, (int)D)) || (rc = tile(VN_W_W1, l, 4 * D, (int)D)) ||
-                (rc = tile(VN_W_W2, l, D, (int)(2 * D))))
+            if ((rc = tile(VN_W_QKV, l, 3 * D, (int)D, VN_W_NORM1, l)) || (rc = tile(VN_W_WO, l, D, (int)D)) ||
+                (rc = tile(VN_W_W1, l, 4 * D, (int)D, VN_W_NORM3, l)) || (rc = tile(VN_W_W2, l, D, (int)(2 * D))))
                 return rc;
-        if ((rc = tile(VN_W_CLS_W, 0, (long)m->Cp * m->d.vocab, (int)D))) return rc;
+        if ((rc = tile(VN_W_CLS_W, 0, (long)m->Cp * m->d.vocab, (int)D, VN_W_FINAL_NORM, 0))) return rc;
         VN_HIP_CHECK(m->ctx, hipDeviceSynchronize());
+        m->folded = fold;
+    } else {
+        m->folded = 0;
     }
     m->blob16 = (const uint16_t*)blob16_dev;
     m->w_plane = w_plane;
@@ -581,16 +662,21 @@ extern "C" int vn_model_set_f16x2(vn_model* m, int on) {
         if (!m->w_h2 && (rc = dev_alloc(m->ctx, &m->w_h2, (size_t)2 * n))) return rc;
         VN_HIP_CHECK(m->ctx, hipDeviceSynchronize());          // a setup call: fence it against whatever stream wrote the blob
         const long D = m->D;
-        auto build = [&](int id, int layer, long rows, int K) {
+        const bool fold = m->ctx->tune.fold_norm != 0;
+        auto build = [&](int id, int layer, long rows, int K, int norm_id = -1, int norm_layer = 0) {      // norm_id: see set_bf16_planes
             const long off = vn_tensor_offset(&m->d, id, layer);
+            if (fold && norm_id >= 0)
+                return vn_launch_fold_planes(m->ctx, m->blob + off, m->blob + vn_tensor_offset(&m->d, norm_id, norm_layer), m->w_h2 + 2 * off,
+                                             rows, K, VN_PLANES_TILED_H2, nullptr);
             return vn_launch_split2h(m->ctx, m->blob + off, m->w_h2 + 2 * off, rows, K, VN_PLANES_TILED_H2, nullptr);
         };
         for (int l = 0; l < m->L && !rc; ++l)
-            (rc = build(VN_W_QKV, l, 3 * D, (int)D)) || (rc = build(VN_W_WO, l, D, (int)D)) || (rc = build(VN_W_W1, l, 4 * D, (int)D)) ||
-                (rc = build(VN_W_W2, l, D, (int)(2 * D)));
-        if (!rc) rc = build(VN_W_CLS_W, 0, (long)m->Cp * m->d.vocab, (int)D);
+            (rc = build(VN_W_QKV, l, 3 * D, (int)D, VN_W_NORM1, l)) || (rc = build(VN_W_WO, l, D, (int)D)) ||
+                (rc = build(VN_W_W1, l, 4 * D, (int)D, VN_W_NORM3, l)) || (rc = build(VN_W_W2, l, D, (int)(2 * D)));
+        if (!rc) rc = build(VN_W_CLS_W, 0, (long)m->Cp * m->d.vocab, (int)D, VN_W_FINAL_NORM, 0);
         if (rc) return rc;
         VN_HIP_CHECK(m->ctx, hipDeviceSynchronize());
+        m->folded = fold;
     }
     m->blob16 = m->w_h2;
     m->w_plane = VN_PLANES_TILED_H2;

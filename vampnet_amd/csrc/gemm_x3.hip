@@ -74,6 +74,9 @@
 
 #define X3_BN 128
 #define X3_KT 32                                  // bf16 per k-tile
+// staged epilogues: float offset of the folded norm's scale table = right behind the largest LDS image (QKV3's transposed V^T planes,
+// [3][128][RP + 8] 16-bit values; the fp32 image [RP][128] is smaller)
+#define X3_RS_OFF(RP) (3 * 128 * ((RP) + 8) / 2)
 #define X3_BPLANE (128 * 16)                      // floats of one W plane tile: 128 rows x 64 B
 
 // Geometry by tile configuration CFG: BM x 128 output tile, eight waves as WR x WC, a wave owns RI x CJ MFMA tiles of 32 x 32.
@@ -229,14 +232,30 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
     const int wm = wave / G::WC, wn = wave % G::WC, l31 = lane & 31, h = lane >> 5, tid = wave * 64 + lane;
     uint16_t* L16 = (uint16_t*)lds;
     bool bad = false;                     // saturation ledger (vn_common.h)
+    // Folded RMSNorm, consumer side (vn_common.h, vn_gemm_args::ssq_in): r = rsqrt(mean(x^2) + eps) of this tile's BM rows from the
+    // producers' group sums, once per tile, kept behind the largest image (X3_RS_OFF); 1.0 when nothing is folded (x * 1.0f == x
+    // exactly, so the unfolded results do not change)
+    constexpr bool FOLD_IN = EPI == VN_EPI_QKV3 || EPI == VN_EPI_QKV || EPI == VN_EPI_GEGLU || EPI == VN_EPI_BIAS;
+    float* rs = lds + X3_RS_OFF(RP);
+    const bool fold_in = FOLD_IN && p.ssq_in != nullptr;
+    if (fold_in) {
+        __syncthreads();                  // the k-loop's reads of the stages are done in every wave: the table may overwrite them
+        const int nt = p.K >> 7;
+        for (int rr = tid; rr < G::BM; rr += 512) {
+            const int row = m0 + rr;
+            rs[rr] = row < p.M ? vn_fold_rstd(p.ssq_in + (size_t)row * nt, nt, p.K, p.fold_eps) : 0.0f;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < RI; ++i) {
-        __syncthreads();                  // k-loop reads / the previous pass's read-out are done in every wave
+        __syncthreads();                  // k-loop reads / the previous pass's read-out are done in every wave (and rs is complete)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int R = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;                 // image row; tile row = (R >> 5) * 32 RI + 32 i + (R & 31)
+            // folded norm: the scale of accumulator row r (the plane kinds apply it here, before the split; fp32 kinds on read-out)
+            const float sc = (fold_in && (EPI == VN_EPI_GEGLU || EPI == VN_EPI_QKV3)) ? rs[wm * 32 * RI + 32 * i + (R & 31)] : 1.0f;
             if constexpr (EPI == VN_EPI_GEGLU) {
-                const float o = acc[i][0][r] * vn_gelu_tanh(acc[i][CJ - 1][r]);
+                const float o = (acc[i][0][r] * sc) * vn_gelu_tanh(acc[i][CJ - 1][r] * sc);
                 uint16_t* d = L16 + R * 64 + wn * 32 + l31;
                 if constexpr (FMT) {
                     uint16_t t0, t1;
@@ -253,7 +272,7 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
                     for (int j = 0; j < CJ; ++j) {
                         const int c = wn * 32 * CJ + j * 32 + l31;
                         uint16_t t0, t1, t2 = 0;
-                        const float qv = n0 < p.H * VN_DHEAD ? acc[i][j][r] * 0.125f : acc[i][j][r];              // q: x 1/sqrt(64)
+                        const float qv = n0 < p.H * VN_DHEAD ? (acc[i][j][r] * sc) * 0.125f : acc[i][j][r] * sc;    // q: x 1/sqrt(64)
                         if constexpr (FMT) vn_split2u(qv, t0, t1, bad);
                         else vn_split3(qv, t0, t1, t2);
                         uint16_t* d = L16 + R * 128 + c;
@@ -267,8 +286,9 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
                         uint16_t t[3][4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            if constexpr (FMT) vn_split2u(acc[i][j][r + e] * 16.0f, t[0][e], t[1][e], bad);
-                            else vn_split3(acc[i][j][r + e], t[0][e], t[1][e], t[2][e]);
+                            const float vv = acc[i][j][r + e] * (fold_in ? rs[wm * 32 * RI + 32 * i + (R & 31) + e] : 1.0f);     // rows R .. R + 3
+                            if constexpr (FMT) vn_split2u(vv * 16.0f, t[0][e], t[1][e], bad);
+                            else vn_split3(vv, t[0][e], t[1][e], t[2][e]);
                         }
 #pragma unroll
                         for (int q = 0; q < (FMT ? 2 : 3); ++q) {
@@ -362,24 +382,41 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
             for (int k = 0; k < RP * 32 / 512; ++k) {                               // RP rows x 32 pieces of 4 columns
                 const int idx = tid + 512 * k;
                 const int R = idx >> 5, c4 = (idx & 31) * 4;
-                const int row = m0 + (R >> 5) * 32 * RI + 32 * i + (R & 31), col = n0 + c4;
-                if (row >= p.M || col >= p.N) continue;
-                f32x4 v = *(const f32x4*)(lds + R * 128 + c4);
-                if constexpr (EPI == VN_EPI_QKV) {
-                    const int D = p.H * VN_DHEAD;
-                    const int which = col / D, rem = col - which * D;
-                    const int b = row / p.T, t = row - b * p.T;
-                    *(f32x4*)(p.C + which * p.qkv_plane + (((size_t)b * p.H + (rem >> 6)) * p.T + t) * VN_DHEAD + (rem & 63)) = v;
-                } else {
-                    float* c = p.C + (size_t)row * p.ldc + col;
-                    if constexpr (EPI == VN_EPI_BIAS) v += *(const f32x4*)(p.bias + col);
-                    if constexpr (EPI == VN_EPI_RESIDUAL) v += *(const f32x4*)c;
-                    *(f32x4*)c = v;
+                const int trow = (R >> 5) * 32 * RI + 32 * i + (R & 31);
+                const int row = m0 + trow, col = n0 + c4;
+                const bool ok = row < p.M && col < p.N;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) {
+                    v = *(const f32x4*)(lds + R * 128 + c4);
+                    if constexpr (FOLD_IN) {
+                        if (fold_in) { const float sc = rs[trow]; v[0] *= sc; v[1] *= sc; v[2] *= sc; v[3] *= sc; }
+                    }
+                    if constexpr (EPI == VN_EPI_QKV) {
+                        const int D = p.H * VN_DHEAD;
+                        const int which = col / D, rem = col - which * D;
+                        const int b = row / p.T, t = row - b * p.T;
+                        *(f32x4*)(p.C + which * p.qkv_plane + (((size_t)b * p.H + (rem >> 6)) * p.T + t) * VN_DHEAD + (rem & 63)) = v;
+                    } else {
+                        float* c = p.C + (size_t)row * p.ldc + col;
+                        if constexpr (EPI == VN_EPI_BIAS) v += *(const f32x4*)(p.bias + col);
+                        if constexpr (EPI == VN_EPI_RESIDUAL) v += *(const f32x4*)c;
+                        *(f32x4*)c = v;
+                        if constexpr (EPI == VN_EPI_RESIDUAL) {
+                            // folded norm, producer side: the planes of the new residual rows for the consumer GEMM
+                            if (p.X16) vn_store_planes4(p.X16, p.x16_plane, row, col, p.N, v, bad);
+                        }
+                    }
+                }
+                if constexpr (EPI == VN_EPI_RESIDUAL) {
+                    if (p.ssq_out) {        // uniform; the 32 threads of an image row are one half-wave (idx & 31 = its column group)
+                        const float s2 = vn_ssq128(v);
+                        if ((tid & 31) == 0 && row < p.M) p.ssq_out[(size_t)row * (p.N >> 7) + (n0 >> 7)] = s2;
+                    }
                 }
             }
         }
     }
-    if constexpr (FMT && (EPI == VN_EPI_GEGLU || EPI == VN_EPI_QKV3 || EPI == VN_EPI_CONV))
+    if constexpr (FMT && (EPI == VN_EPI_GEGLU || EPI == VN_EPI_QKV3 || EPI == VN_EPI_CONV || EPI == VN_EPI_RESIDUAL))
         vn_sat_report(p.sat, EPI == VN_EPI_QKV3 ? VN_SAT_ATTN : VN_SAT_OPERAND, bad);
 }
 
@@ -726,11 +763,13 @@ extern "C" int vn_debug_x3_config(vn_ctx* ctx, int bm, int splitk, int abl) {
     return VN_OK;
 }
 
-// the stages, or the largest image of a staged epilogue (the transposed V^T planes of QKV3: [3][128][RP + 8] bf16) if that is bigger
+// the stages, or the largest image of a staged epilogue (the transposed V^T planes of QKV3: [3][128][RP + 8] bf16) followed by the folded
+// norm's per-row scale table (BM <= 256 floats at X3_RS_OFF) if that is bigger
 template <int CFG, int NP = 3>
 static constexpr size_t x3_lds_bytes() {
     constexpr size_t stages = (size_t)x3_geo<CFG, NP>::STAGE * 4 * x3_geo<CFG, NP>::NBUF;
-    constexpr size_t image = (size_t)3 * 128 * (x3_geo<CFG, NP>::RP + 8) * 2;
+    constexpr int rp = x3_geo<CFG, NP>::RP;
+    constexpr size_t image = (size_t)X3_RS_OFF(rp) * 4 + 256 * 4;
     return stages > image ? stages : image;
 }
 
@@ -754,6 +793,8 @@ static int x3_go(vn_ctx* ctx, const vn_gemm_args& a_in, int nsplit, hipStream_t 
     vn_gemm_args a = a_in;
     a.staged = x3_staged_ok<EPI>(ctx, a);
     a.sat = ctx->sat;
+    if ((a.ssq_in || a.ssq_out || a.X16) && !a.staged && EPI != VN_EPI_CONV)
+        return vn_fail(ctx, VN_ERR_UNSUPPORTED, "gemm_x3: the folded-norm epilogues exist in the LDS-staged form only (alignment / VN_X3_STAGED)%s", "");
     a.group_m = ctx->tune.x3_group_m;                                  // tuning: rows of tiles per walk group (0 = 8)
     const int tiles_m = vn_cdiv(a.M, x3_geo<CFG>::BM), tiles_n = vn_cdiv(a.N, X3_BN);
     constexpr int NP = FMT ? 2 : 3;
@@ -782,6 +823,8 @@ extern "C" int vn_debug_x3_fuse_norm(vn_ctx* ctx, int on) {
 static bool x3_norm_fusable(const vn_ctx* ctx, const vn_gemm_args& a) {
     return ctx->tune.x3_fuse_norm && a.norm_w && a.norm_done && a.ldc == a.N && (a.N == 1280 || a.N == 256);
 }
+// folded norm: the reduce pass of a split RESIDUAL launch writes the planes and the group sums of squares (vn_launch_rowprep)
+static bool x3_fold_out(const vn_gemm_args& a) { return a.X16 != nullptr; }
 
 // Tile height and k-split of a launch, by a cost model in microseconds calibrated on the model's shapes (scripts/gemm_x3_plan_sweep.py,
 // profiles/r02_gemm_x3_plan_sweep.txt): a launch runs ceil(tiles ns / CUs) rounds of K / ns k-tiles; a k-tile of a 128-row tile
@@ -811,6 +854,7 @@ static x3_plan x3_choose(const vn_ctx* ctx, const vn_gemm_args& a, int cus, doub
         for (int ns = 1; ns <= (can_split ? 4 : 1); ns *= 2) {
             if (ns > 1) {
                 if (split_forced == 0 || split_forced == 1 || (a.N & 3) || (a.ldc & 3)) continue;
+                if (x3_fold_out(a) && !(a.ldc == a.N && (a.N == 1280 || a.N == 256))) continue;       // vn_launch_rowprep's widths
                 if (nk / ns < 8 || (double)ns * a.M * a.N > (double)X3_WS_FLOATS) continue;
             }
             if (split_forced > 1 && ns != split_forced && ns != 1) continue;
@@ -818,7 +862,7 @@ static x3_plan x3_choose(const vn_ctx* ctx, const vn_gemm_args& a, int cus, doub
             if (tiles * ns < cus) cost *= partial;           // a launch that leaves CUs idle runs at a higher clock (f16x2 sweep: x 0.8)
             if (ns > 1) {
                 cost += (ns + (residual ? 2 : 1)) * 4.0 * a.M * (double)a.N / 3.5e6;
-                if (residual && x3_norm_fusable(ctx, a)) cost -= 4.0 * a.M * (double)a.N / 3.5e6 + 1.5;
+                if (residual && (x3_norm_fusable(ctx, a) || x3_fold_out(a))) cost -= 4.0 * a.M * (double)a.N / 3.5e6 + 1.5;
                 if (split_forced > 1 && ns == split_forced) cost = -1.0 + 1e-3 * hi;       // forced split: keep the height order
             }
             if (cost < best_cost) { best_cost = cost; best = x3_plan{bm, ns}; }
@@ -864,7 +908,12 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
             vn_gemm_args q = a;                       // every split stores its raw image [M][N] into the workspace
             q.C = ctx->x3_ws;
             q.ldc = a.N;
+            q.X16 = nullptr; q.ssq_out = nullptr; q.ssq_in = nullptr;
             rc = x3_go_bm<VN_EPI_STORE, FMT>(ctx, q, ns, bm, s);
+            if (EPI == VN_EPI_RESIDUAL && x3_fold_out(a)) {
+                // folded norm: reduce + the planes and group sums of the new residual rows in one pass (part of THIS GEMM's work)
+                if (rc == VN_OK) rc = vn_launch_rowprep(ctx, ctx->x3_ws, ns, a.C, a.X16, a.x16_plane, a.ssq_out, a.M, a.N, s);
+            } else
             // while launches are being event-bracketed (pi >= 0) the two-kernel form runs, so that the GEMM's bracket holds the GEMM's
             // own work (split images + reduce) and nothing of the norm — the bitwise same result (tests/test_gpu_kernels.py)
             if (EPI == VN_EPI_RESIDUAL && x3_norm_fusable(ctx, a) && pi < 0) {
@@ -913,6 +962,11 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
         (!a.w_tiled && (a.w_plane <= 0 || (a.w_plane & 7))))
         return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: plane strides must be positive multiples of 8 elements (or the tiled layout of the format)%s", "");
     if (((uintptr_t)a.A | (uintptr_t)a.W) & 15) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: operands must be 16-byte aligned%s", "");
+    // folded RMSNorm: producers write 128-column group sums (N a multiple of 128, planes in the operands' tiled format), consumers read K / 128 of them
+    if ((a.ssq_out || a.X16) && (epilogue != VN_EPI_RESIDUAL || !a.ssq_out || !a.X16 || (a.N & 127) || a.ldc != a.N ||
+                                 a.x16_plane != (h2 ? VN_PLANES_TILED_H2 : VN_PLANES_TILED)))
+        return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: folded-norm outputs need the RESIDUAL epilogue, N %% 128 == 0, ldc == N, tiled planes + ssq%s", "");
+    if (a.ssq_in && (a.K & 127)) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: folded-norm input needs K %% 128 == 0%s", "");
     if (!(ctx->attr_mask & VN_ATTR_GEMM_X3)) {
         int rc;
         if ((rc = x3_attrs<VN_EPI_STORE>(ctx)) || (rc = x3_attrs<VN_EPI_BIAS>(ctx)) || (rc = x3_attrs<VN_EPI_RESIDUAL>(ctx)) ||
@@ -1033,6 +1087,32 @@ __global__ __launch_bounds__(256) void vn_split2h_kernel(const float* __restrict
         vn_store_planes4(dst, plane, row, col, K, ((const f32x4*)src)[i], bad);
     }
     vn_sat_report(sat, VN_SAT_WEIGHT, bad);
+}
+// fp32 [rows][K], every column k multiplied by scale[k] first (one fp32 rounding) -> TILED split planes of either format (plane =
+// VN_PLANES_TILED: three bf16 planes, VN_PLANES_TILED_H2: two fp16 planes): the consumer weights of a model with folded RMSNorms,
+// W' = W (.) w_norm (engine.hip).  rows % 16 == 0, K % 32 == 0.
+__global__ __launch_bounds__(256) void vn_fold_planes_kernel(const float* __restrict__ src, const float* __restrict__ scale,
+                                                             uint16_t* __restrict__ dst, long rows, int K, long plane, unsigned* sat) {
+    const long n4 = rows * (K >> 2);
+    bool bad = false;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
+        const long row = i / (K >> 2);
+        const int col = (int)(i - row * (K >> 2)) * 4;
+        f32x4 v = ((const f32x4*)src)[i];
+        const f32x4 sc = *(const f32x4*)(scale + col);
+        v[0] *= sc[0]; v[1] *= sc[1]; v[2] *= sc[2]; v[3] *= sc[3];
+        vn_store_planes4(dst, plane, row, col, K, v, bad);
+    }
+    vn_sat_report(sat, VN_SAT_WEIGHT, bad);
+}
+int vn_launch_fold_planes(vn_ctx* ctx, const float* src, const float* scale, uint16_t* dst, long rows, int K, long plane, hipStream_t s) {
+    if (rows <= 0 || K <= 0 || (rows & 15) || (K & 31) || !vn_planes_tiled(plane) || !scale)
+        return vn_fail(ctx, VN_ERR_INVALID, "fold_planes: tiled planes only (rows %% 16, K %% 32) (rows=%s%ld, K=%ld)", "", rows, K);
+    const long n4 = rows * (K >> 2);
+    const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(vn_fold_planes_kernel, dim3(blocks), dim3(256), 0, s, src, scale, dst, rows, K, plane, ctx->sat);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
 }
 int vn_launch_split2h(vn_ctx* ctx, const float* src, uint16_t* dst, long rows, int K, long plane, hipStream_t s) {
     if (rows <= 0 || K <= 0 || (K & 3) || !vn_planes_h2(plane) || (plane == VN_PLANES_TILED_H2 && ((rows & 15) || (K & 31))) ||

@@ -175,6 +175,27 @@ __device__ __forceinline__ void vn_store_planes4(uint16_t* base, long plane, lon
 #define VN_DHEAD 64
 
 #ifdef __HIPCC__
+// Folded RMSNorm (vn_gemm_args::ssq_out): the sum of squares of four values as ONE fma chain, then added over the 32 lanes of a
+// half-wave (xor 16, 8, 4, 2, 1) — the partial sum of a row's 128-column group when lane (l & 31) holds columns 4 (l & 31) .. + 3
+// of the group.  The same expression in every producer (GEMM epilogue, split-K reduce, layer-0 prep).
+__device__ __forceinline__ float vn_ssq128(const f32x4& v) {
+    float s = v[0] * v[0];
+    s = fmaf(v[1], v[1], s);
+    s = fmaf(v[2], v[2], s);
+    s = fmaf(v[3], v[3], s);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    return s;
+}
+// the consumer's side: r = 1 / sqrt(mean(x^2) + eps) of one row from its nt group sums, added in index order
+__device__ __forceinline__ float vn_fold_rstd(const float* __restrict__ ssq_row, int nt, int K, float eps) {
+    float s = ssq_row[0];
+    for (int t = 1; t < nt; ++t) s += ssq_row[t];
+    return 1.0f / sqrtf(s / (float)K + eps);            // exact div + sqrt, as vn_rmsnorm_row
+}
+#endif
+
+#ifdef __HIPCC__
 __device__ __forceinline__ uint4 vn_philox4x32_10(uint4 c, uint2 k) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
@@ -296,6 +317,7 @@ struct vn_tune {
     unsigned* ax_trace;
     // engine.hip: bf16x3 models take the split-plane attention path (-1 by shape / LDS fit, 0 never, 1 always); operand plane layouts
     int attn_x3, a_tiled, w_tiled;
+    int fold_norm;           // engine.hip: split-plane models fold the RMSNorms into their consumer GEMMs (VN_FOLD_NORM, default 1)
     unsigned epoch;
 };
 void vn_tune_init(vn_tune* t);
@@ -396,6 +418,18 @@ struct vn_gemm_args {
     long norm_plane;
     float norm_eps;
     int* norm_done;
+    // RMSNorm FOLDED into its consumer (engine.hip, models with m->folded): y W^T = r (.) (x (W (.) w)^T), r = rsqrt(mean(x^2) + eps) per row,
+    // the norm weight w multiplied into the consumer's weight columns when its planes are built.  No norm kernel runs:
+    //   PRODUCERS — the RESIDUAL epilogue (and the reduce pass of a split launch) also write X16 = the split planes of the NEW residual
+    //   rows (x16_plane: VN_PLANES_TILED / VN_PLANES_TILED_H2; row length N) and ssq_out[row][N / 128] = the sum of squares of the row's
+    //   128 columns of each column tile (a row's total is the sum of its N / 128 entries, added in index order by the consumer);
+    //   CONSUMERS — the QKV3 / QKV / GEGLU / BIAS epilogues multiply every accumulator row by r = 1 / sqrt(sum_t ssq_in[row][t] / K +
+    //   fold_eps) before anything else (K = the consumer's K = the residual width; K / 128 entries per row).
+    uint16_t* X16;
+    long x16_plane;
+    float* ssq_out;
+    const float* ssq_in;
+    float fold_eps;
     // CONV epilogue / operand (gemm_x3.hip): A = channels-last activation planes [3][B * T_in][C_in] (PLANAR, a_plane apart);
     // GEMM row m = (b, t') of M = B * T_rows reads input row t' * in_stride + j * dil - pad for tap j (k = j * C_in + c; rows outside
     // [0, T_in) come from the zero page); W = [C_out][taps * C_in] tiled planes; N = C_out, K = taps * C_in.
@@ -413,12 +447,18 @@ int vn_launch_gemm_f32(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStre
 int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStream_t s);      // a.bf16 == 2
 // planar split planes [3][rows][K] (plane elements apart) -> tiled planes [rows / 16][K / 32][3][16][32]; rows % 16 == 0, K % 32 == 0
 int vn_launch_tile_planes(vn_ctx* ctx, const uint16_t* planes, long plane, uint16_t* tiled, long rows, int K, hipStream_t s);
+// fp32 [rows][K] with column k scaled by scale[k] -> tiled split planes (plane = VN_PLANES_TILED or VN_PLANES_TILED_H2)
+int vn_launch_fold_planes(vn_ctx* ctx, const float* src, const float* scale, uint16_t* dst, long rows, int K, long plane, hipStream_t s);
 // fp32 [rows][K] -> f16x2 planes: plane = VN_PLANES_TILED_H2 (rows % 16 == 0, K % 32 == 0) or -(planar stride)
 int vn_launch_split2h(vn_ctx* ctx, const float* src, uint16_t* dst, long rows, int K, long plane, hipStream_t s);
 // C[M][N] (row stride ldc) (+)= sum over the nsplit partial images partial[s][M][N], in fixed order (gemm_f32.hip)
 int vn_launch_splitk_reduce(vn_ctx* ctx, const float* partial, int nsplit, float* C, int M, int N, int ldc, bool residual,
                             hipStream_t s);
 
+// folded-norm producers (elementwise.hip): x[rows][D] += sum of the nsplit images (nsplit = 0: x as it is, nothing written back), then
+// x16 = the split planes of the rows (plane16: tiled bf16x3 / f16x2) and ssq[row][D / 128] = sums of squares per 128-column group
+int vn_launch_rowprep(vn_ctx* ctx, const float* partial, int nsplit, float* x, uint16_t* x16, long plane16, float* ssq, int rows, int D,
+                      hipStream_t s);
 // x[rows][D] += sum of the nsplit images partial[s][rows][D] (fixed order), then y = RMSNorm(x) from the same registers (elementwise.hip)
 int vn_launch_splitk_reduce_rmsnorm(vn_ctx* ctx, const float* partial, int nsplit, float* x, const float* w, float* y, uint16_t* y16,
                                     long plane16, int rows, int D, float eps, hipStream_t s);

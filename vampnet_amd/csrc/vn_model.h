@@ -27,6 +27,12 @@ struct vn_model {
     // bf16 planes; f16x2: the first two planes hold the fp16 two-plane split (q / 8, k, 16 v; second plane unscaled: |v| < 4094)
     uint16_t *qk16, *vt16;
     long qk_plane, vt_plane;
+    // folded RMSNorms (split-plane precisions; engine.hip forward_i32): the consumer weights (QKV, W1, classifier) hold W (.) w_norm,
+    // x16 = the split planes of the raw residual stream (written by the residual GEMMs' epilogues / vn_launch_rowprep), ssq =
+    // [max_rows][D / 128] sums of squares per 128-column group of the same rows
+    int folded;
+    uint16_t* x16;
+    float* ssq;
     int bias_T;              // T the expanded bias table is currently built for (-1 = none)
     long max_rows;
     struct vn_fwd_graphs* graphs;   // captured hipGraphs of the forward pass, per (B, T, precision) (engine.hip)
