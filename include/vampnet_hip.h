@@ -433,6 +433,20 @@ int vn_build_mask(vn_ctx* ctx, const uint32_t* raw, const int64_t* onset, int64_
                   int n_prefix, int n_suffix, int period, int width, int64_t roll_word, int64_t drop_word, int n_drop,
                   int ncc, int upper, void* stream);
 
+/* ---- the exchange step of the batch-sharded vamp() (replaces nothing in the reference, which is single-GPU:
+ * vampnet/interface.py:491-562 runs the whole batch on one device) --------------------------------------------------------------
+ * The coarse and coarse-to-fine loops shard over the GPUs of a node by batch item with NO data-path collective; the one exchange is an
+ * all-gather of the finished (B / world, 14, T) int64 token blocks.  RCCL is bound at run time (dlopen; VN_RCCL_LIB overrides the
+ * library name), so a single-GPU host never loads it.  vn_comm_unique_id: 128 bytes made on ONE rank, passed to the others by the host
+ * (vampnet_amd/interface.py broadcasts them through torch.distributed); vn_comm_create: collective over the `world` ranks, binds to
+ * the context's device.  vn_allgather_tokens: every rank sends `count` int64 (equal on all ranks: the host pads the last block),
+ * recv_dev = [world][count]; enqueued on `stream`, no host synchronisation.                                                       */
+typedef struct vn_comm vn_comm;
+int  vn_comm_unique_id(vn_ctx* ctx, uint8_t* id128);
+int  vn_comm_create(vn_ctx* ctx, const uint8_t* id128, int rank, int world, vn_comm** out);
+void vn_comm_destroy(vn_comm* comm);
+int  vn_allgather_tokens(vn_comm* comm, const int64_t* send_dev, int64_t* recv_dev, int64_t count, void* stream);
+
 /* Tuning / test hooks (vn_debug_*) are NOT part of this interface: include/vampnet_hip_debug.h.  They act on ONE vn_ctx; nothing in
  * the library is process-global, so contexts are independent of each other (each must still be driven from one stream at a time). */
 

@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(port, q):
+def _worker(port, q, exchange="torch"):
     import torch.distributed as dist
     from oracle import vampnet_oracle as O, weights as W
     from tests.gpu_common import SynthCodec, model_kwargs
@@ -33,7 +33,7 @@ def _worker(port, q):
         cb = W.synth_codebooks()
         csd, fsd = W.synth_state_dict(W.TINY_COARSE_DIMS, 0), W.synth_state_dict(W.TINY_C2F_DIMS, 1)
         itf = Interface.from_state_dicts(SynthCodec(cb), csd, model_kwargs(W.TINY_COARSE_DIMS), fsd, model_kwargs(W.TINY_C2F_DIMS),
-                                         device="cuda:0", max_batch=3, process_group=dist.group.WORLD)
+                                         device="cuda:0", max_batch=3, process_group=dist.group.WORLD, exchange=exchange)
         itf.exchange_log = []
         z = W.synth_codes(3, 14, 200, seed=6)
         torch.manual_seed(3)
@@ -51,16 +51,19 @@ def _worker(port, q):
         dist.destroy_process_group()
 
 
-def test_vamp_exchange_on_one_rank_rccl_group():
+@pytest.mark.parametrize("exchange", ["torch", "c_abi"])
+def test_vamp_exchange_on_one_rank_rccl_group(exchange):
+    """exchange="torch": torch.distributed's all_gather_into_tensor on the nccl (= RCCL) group; "c_abi": the library's own RCCL
+    communicator behind vn_comm_create / vn_allgather_tokens (include/vampnet_hip.h), the unique id carried by the group"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_worker, args=(_free_port(), q))
+    p = ctx.Process(target=_worker, args=(_free_port(), q, exchange))
     p.start()
     res = q.get(timeout=600)
     p.join(timeout=120)
     assert p.exitcode == 0
-    print("one-rank RCCL exchange:", res)
+    print(f"one-rank RCCL exchange [{exchange}]:", res)
     assert res["backend"] == "nccl"
     assert res["ok"], "vamp() through the RCCL exchange differs from the oracle"
-    assert res["n_exchange"] == 2 and res["raw"]                 # one all-gather per vamp() (+ the raw call)
+    assert res["n_exchange"] == 2 and res["raw"]                 # one all-gather per vamp() + the raw call
     assert all(m >= 0.0 for m in res["ms"])

@@ -105,6 +105,10 @@ SYMBOLS = {
     "vn_torch_uniform_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, C.c_float, _P]),
     "vn_build_mask": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64,
                                C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
+    "vn_comm_unique_id": (C.c_int, [_P, _P]),
+    "vn_comm_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "vn_comm_destroy": (None, [_P]),
+    "vn_allgather_tokens": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "vn_debug_graph_replays": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "vn_debug_gemm_config": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "vn_debug_attention_x3_time": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),

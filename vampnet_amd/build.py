@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libvampnet_hip.so")
 SOURCES = ["engine.hip", "gemm_f32.hip", "attention_f32.hip", "elementwise.hip", "sampling.hip", "conv1d_f32.hip",
-           "train.hip", "train_kernels.hip", "attention_train.hip", "torch_rng.hip", "gemm_x3.hip", "attention_x3.hip"]
+           "train.hip", "train_kernels.hip", "attention_train.hip", "torch_rng.hip", "gemm_x3.hip", "attention_x3.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
@@ -35,7 +35,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
     if force or procs or not os.path.exists(OUT):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs, "-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -608,7 +608,7 @@ static int set_bf16_planes(vn_model* m, const void* blob16_dev, long w_plane) {
         VN_HIP_CHECK(m->ctx, hipDeviceSynchronize());
         const uint16_t* planes = (const uint16_t*)blob16_dev;
         const long D = m->D;
-        const bool fold = m->ctx->tune.fold_norm != 0;
+        const bool fold = m->ctx->tune.fold_norm != 0 && D <= 2048;          // (the consumers keep K / 128 <= 16 group sums in registers)
         // `norm` != 0: a consumer of an RMSNorm in a model with folded norms — its planes are built from the fp32 blob with the norm
         // weight multiplied into the columns (W' = W (.) w_norm, one fp32 rounding, then the exact split); the others are re-laid
         // from the caller's planes
@@ -662,7 +662,7 @@ extern "C" int vn_model_set_f16x2(vn_model* m, int on) {
         if (!m->w_h2 && (rc = dev_alloc(m->ctx, &m->w_h2, (size_t)2 * n))) return rc;
         VN_HIP_CHECK(m->ctx, hipDeviceSynchronize());          // a setup call: fence it against whatever stream wrote the blob
         const long D = m->D;
-        const bool fold = m->ctx->tune.fold_norm != 0;
+        const bool fold = m->ctx->tune.fold_norm != 0 && D <= 2048;
         auto build = [&](int id, int layer, long rows, int K, int norm_id = -1, int norm_layer = 0) {      // norm_id: see set_bf16_planes
             const long off = vn_tensor_offset(&m->d, id, layer);
             if (fold && norm_id >= 0)

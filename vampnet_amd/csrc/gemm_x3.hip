@@ -97,6 +97,9 @@ struct x3_geo {
     static constexpr int NBUF = (CFG == 1 || NP == 2) ? 3 : 2;      // resident stages (f16x2: 96 / 144 / 120 KiB)
     static constexpr int RP = 32 * WR;                              // rows of one pass of the staged epilogue's LDS image
     static constexpr int NPROD = NP == 3 ? 6 : 3;                   // matrix-core products per 16-wide k-step
+    // folded RMSNorm: float offset of the per-row scale table (BM floats) — behind the stages AND behind the largest epilogue image
+    // (QKV3's transposed V^T planes), so it survives from the kernel's prologue, where it is filled, to the epilogue that reads it
+    static constexpr int RS_OFF = NBUF * STAGE > X3_RS_OFF(RP) ? NBUF * STAGE : X3_RS_OFF(RP);
     static constexpr int NI = NP == 3 ? 4 : 2;                      // two-buffer schedule: DMA pieces issued between the products of k-step 0
 };
 static_assert(x3_geo<1>::BM == 128 && x3_geo<2>::BM == 256 && x3_geo<3>::BM == 192, "tile heights");
@@ -236,16 +239,8 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
     // producers' group sums, once per tile, kept behind the largest image (X3_RS_OFF); 1.0 when nothing is folded (x * 1.0f == x
     // exactly, so the unfolded results do not change)
     constexpr bool FOLD_IN = EPI == VN_EPI_QKV3 || EPI == VN_EPI_QKV || EPI == VN_EPI_GEGLU || EPI == VN_EPI_BIAS;
-    float* rs = lds + X3_RS_OFF(RP);
+    const float* rs = lds + x3_geo<CFG, FMT ? 2 : 3>::RS_OFF;      // filled by the kernel's prologue (x3_fold_load / x3_fold_table)
     const bool fold_in = FOLD_IN && p.ssq_in != nullptr;
-    if (fold_in) {
-        __syncthreads();                  // the k-loop's reads of the stages are done in every wave: the table may overwrite them
-        const int nt = p.K >> 7;
-        for (int rr = tid; rr < G::BM; rr += 512) {
-            const int row = m0 + rr;
-            rs[rr] = row < p.M ? vn_fold_rstd(p.ssq_in + (size_t)row * nt, nt, p.K, p.fold_eps) : 0.0f;
-        }
-    }
 #pragma unroll
     for (int i = 0; i < RI; ++i) {
         __syncthreads();                  // k-loop reads / the previous pass's read-out are done in every wave (and rs is complete)
@@ -538,6 +533,34 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             for (int j = 0; j < G::NPW; ++j) stage_piece(buf, k0, j);
         };
 
+        // Folded RMSNorm, consumer side: thread r < BM fetches the K / 128 group sums of squares of tile row r BEFORE the first DMA is
+        // issued (VMEM returns in order, so they have landed when the first stage has) and turns them into the row's scale right
+        // after the prologue's barrier; the table sits behind stages and images (x3_geo::RS_OFF) until the epilogue reads it.  Left to
+        // the epilogue these were K / 128 dependent L2 round trips per tile with nothing to hide them (measured: the whole gain of
+        // the fold).  Up to 16 groups (K <= 2048) live in registers; zeros pad the sum (s + 0 == s).
+        constexpr bool FOLD_IN = EPI == VN_EPI_QKV3 || EPI == VN_EPI_QKV || EPI == VN_EPI_GEGLU || EPI == VN_EPI_BIAS;
+        constexpr int FOLD_NT = 16;
+        float fold_sq[FOLD_IN ? FOLD_NT : 1];
+        const bool fold_in = FOLD_IN && p.ssq_in != nullptr;
+        if constexpr (FOLD_IN) {
+            if (fold_in && tid < G::BM) {
+                const int nt = p.K >> 7;
+                const int row = m0 + tid < p.M ? m0 + tid : p.M - 1;
+                const float* q = p.ssq_in + (size_t)row * nt;
+#pragma unroll
+                for (int t = 0; t < FOLD_NT; ++t) fold_sq[t] = t < nt ? q[t] : 0.0f;
+            }
+        }
+        auto fold_table = [&]() {
+            if constexpr (FOLD_IN) {
+                if (fold_in && tid < G::BM) {
+                    float s2 = fold_sq[0];
+#pragma unroll
+                    for (int t = 1; t < FOLD_NT; ++t) s2 += fold_sq[t];
+                    lds[G::RS_OFF + tid] = 1.0f / sqrtf(s2 / (float)p.K + p.fold_eps);       // exact div + sqrt, as vn_rmsnorm_row
+                }
+            }
+        };
         // f16x2: acc takes a0 b0, acc_lo takes a0 b1 + a1 b0 (both second planes carry 2^11) and joins acc times 2^-11 at the end
         f32x16 acc[RI][CJ], acc_lo[FMT ? RI : 1][FMT ? CJ : 1];
 #pragma unroll
@@ -613,6 +636,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             if (nk > 1) stage(1, X3_KT);
             if (nk > 1) X3_VMCNT(G::NPW); else X3_VMCNT(0);
             X3_BARRIER();                                   // tile 0 complete
+            fold_table();
             if (grp) X3_BARRIER();                          // group 1 runs one phase behind
             if constexpr (ABL & 2) { load_frags(f, 0, 0); load_frags(f1, 0, 1); }
             int b = 0;
@@ -656,6 +680,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             if (nk > 1) stage(1, X3_KT);
             if (nk > 1) X3_VMCNT(G::NPW); else X3_VMCNT(0);
             X3_BARRIER();                                   // tile 0 complete
+            fold_table();
             if (grp) X3_BARRIER();                          // group 1 runs one phase behind
             if constexpr (ABL & 2) load_frags(f, 0, 0);
             int b = 0;
@@ -699,6 +724,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             stage(0, 0);
             X3_VMCNT(0);
             X3_BARRIER();
+            fold_table();
             if (grp) X3_BARRIER();
             if constexpr (ABL & 2) load_frags(f, 0, 0);
             for (int kt = 0; kt < nk; ++kt) {
@@ -767,10 +793,7 @@ extern "C" int vn_debug_x3_config(vn_ctx* ctx, int bm, int splitk, int abl) {
 // norm's per-row scale table (BM <= 256 floats at X3_RS_OFF) if that is bigger
 template <int CFG, int NP = 3>
 static constexpr size_t x3_lds_bytes() {
-    constexpr size_t stages = (size_t)x3_geo<CFG, NP>::STAGE * 4 * x3_geo<CFG, NP>::NBUF;
-    constexpr int rp = x3_geo<CFG, NP>::RP;
-    constexpr size_t image = (size_t)X3_RS_OFF(rp) * 4 + 256 * 4;
-    return stages > image ? stages : image;
+    return ((size_t)x3_geo<CFG, NP>::RS_OFF + 256) * 4;
 }
 
 // may the epilogue go through LDS with 16-byte global accesses ?  (VN_X3_STAGED=0: never — A/B runs)
@@ -966,7 +989,7 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
     if ((a.ssq_out || a.X16) && (epilogue != VN_EPI_RESIDUAL || !a.ssq_out || !a.X16 || (a.N & 127) || a.ldc != a.N ||
                                  a.x16_plane != (h2 ? VN_PLANES_TILED_H2 : VN_PLANES_TILED)))
         return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: folded-norm outputs need the RESIDUAL epilogue, N %% 128 == 0, ldc == N, tiled planes + ssq%s", "");
-    if (a.ssq_in && (a.K & 127)) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: folded-norm input needs K %% 128 == 0%s", "");
+    if (a.ssq_in && ((a.K & 127) || a.K > 2048)) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: folded-norm input needs K %% 128 == 0 and K <= 2048%s", "");
     if (!(ctx->attr_mask & VN_ATTR_GEMM_X3)) {
         int rc;
         if ((rc = x3_attrs<VN_EPI_STORE>(ctx)) || (rc = x3_attrs<VN_EPI_BIAS>(ctx)) || (rc = x3_attrs<VN_EPI_RESIDUAL>(ctx)) ||

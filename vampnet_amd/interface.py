@@ -96,7 +96,7 @@ class Interface:
                  coarse2fine_lora_ckpt: str = None, codec_ckpt: str = None,
                  wavebeat_ckpt: str = None, device: str = "cuda:0", coarse_chunk_size_s: int = 10,
                  coarse2fine_chunk_size_s: int = 3, compile=True, *, codec=None, max_batch: int = 8,
-                 rng: str = "torch", process_group=None, precision: str = DEFAULT_PRECISION):
+                 rng: str = "torch", process_group=None, precision: str = DEFAULT_PRECISION, exchange: str = None):
         assert codec_ckpt is not None or codec is not None, "must provide a codec checkpoint"
         assert coarse_ckpt is not None, "must provide a coarse checkpoint"
         if codec is None:
@@ -111,7 +111,7 @@ class Interface:
             if coarse2fine_lora_ckpt is not None:
                 _load_lora(fsd, coarse2fine_lora_ckpt)
         self._init(codec, csd, ckw, fsd, fkw, device, coarse_chunk_size_s, coarse2fine_chunk_size_s, max_batch, rng,
-                   process_group, precision)
+                   process_group, precision, exchange)
         self.coarse_path = Path(coarse_ckpt)
         self.c2f_path = Path(coarse2fine_ckpt) if coarse2fine_ckpt is not None else None
         self.codec_path = Path(codec_ckpt) if codec_ckpt is not None else None
@@ -119,16 +119,16 @@ class Interface:
     @classmethod
     def from_state_dicts(cls, codec, coarse_sd, coarse_kwargs, c2f_sd=None, c2f_kwargs=None, device="cuda:0",
                          coarse_chunk_size_s=10, coarse2fine_chunk_size_s=3, max_batch=8, rng="torch",
-                         process_group=None, precision=DEFAULT_PRECISION):
+                         process_group=None, precision=DEFAULT_PRECISION, exchange=None):
         """Build from in-memory reference-format state_dicts (what the checkpoints hold)."""
         self = object.__new__(cls)
         self._init(codec, coarse_sd, coarse_kwargs, c2f_sd, c2f_kwargs, device, coarse_chunk_size_s,
-                   coarse2fine_chunk_size_s, max_batch, rng, process_group, precision)
+                   coarse2fine_chunk_size_s, max_batch, rng, process_group, precision, exchange)
         self.coarse_path = self.c2f_path = self.codec_path = None
         return self
 
     def _init(self, codec, csd, ckw, fsd, fkw, device, coarse_chunk_s, c2f_chunk_s, max_batch, rng, process_group,
-              precision=DEFAULT_PRECISION):
+              precision=DEFAULT_PRECISION, exchange=None):
         self.precision = precision
         self.codec = codec
         self.device = torch.device(device)
@@ -150,6 +150,15 @@ class Interface:
             self.rank, self.world = dist.get_rank(process_group), dist.get_world_size(process_group)
         else:
             self.rank, self.world = 0, 1
+        # the exchange step: "torch" (default) = torch.distributed's all_gather_into_tensor on the group ("nccl" IS RCCL on ROCm; gloo in the
+        # CPU tests); "c_abi" = the library's own RCCL communicator behind vn_allgather_tokens (include/vampnet_hip.h: what a host without
+        # torch.distributed binds) — the process group is then only the channel that carries the 128-byte unique id to the ranks
+        self.exchange = exchange or os.environ.get("VN_EXCHANGE", "torch")
+        if self.exchange not in ("torch", "c_abi"):
+            raise ValueError("exchange must be 'torch' or 'c_abi'")
+        self._comm = None
+        if process_group is not None and self.exchange == "c_abi":
+            self._comm = self._make_comm()
         self._codebooks = _codec_codebooks(codec)
         self.coarse = self._make_model(csd, ckw, coarse_chunk_s)
         # the coarse-to-fine chunks of one coarse chunk are batched into one launch: size its workspace for them
@@ -394,6 +403,29 @@ class Interface:
             outs.append(out)
         return outs
 
+    def _make_comm(self):
+        """vn_comm over the ranks of the process group: rank 0 makes the RCCL unique id, the group carries it to the others"""
+        import ctypes as C
+        import torch.distributed as dist
+        eng = self.engine
+        ident = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            eng.check(eng.lib.vn_comm_unique_id(eng.handle, ident), "vn_comm_unique_id")
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(self.pg, 0), group=self.pg)
+        ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        eng.check(eng.lib.vn_comm_create(eng.handle, ident, self.rank, self.world, C.byref(h)), "vn_comm_create")
+        return h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_comm", None):
+                self.engine.lib.vn_comm_destroy(self._comm)
+                self._comm = None
+        except Exception:
+            pass
+
     def _allgather_batch(self, z):
         """The single exchange step: every rank contributes its block of batch items (RCCL all-gather over xGMI).  Runs whenever a
         process group was given — also a one-rank group, so that the device collective (padding to `per * world` rows included) is the
@@ -412,7 +444,12 @@ class Interface:
         local = torch.zeros((per,) + tuple(z.shape[1:]), dtype=z.dtype, device=z.device)
         local[:b1 - b0] = z[b0:b1]
         full = torch.empty((per * self.world,) + tuple(z.shape[1:]), dtype=z.dtype, device=z.device)
-        dist.all_gather_into_tensor(full, local, group=self.pg)
+        if getattr(self, "_comm", None) is not None:          # the library's own RCCL communicator, enqueued on the current stream (no torch collective)
+            assert z.dtype == torch.int64 and z.is_cuda
+            self.engine.check(self.engine.lib.vn_allgather_tokens(self._comm, local.data_ptr(), full.data_ptr(), local.numel(),
+                                                                  self.engine.stream()), "vn_allgather_tokens")
+        else:
+            dist.all_gather_into_tensor(full, local, group=self.pg)
         out = full[:B].contiguous()
         if log is not None:
             ev1.record()
