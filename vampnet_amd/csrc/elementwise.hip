@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256) void vn_splitk_reduce_rmsnorm_kernel(const flo
 
 // Folded RMSNorm, producer side for rows that do not come out of a GEMM epilogue: the reduce pass of a split RESIDUAL GEMM (nsplit >= 1:
 // x += sum of the split images in the fixed order of vn_splitk_reduce_kernel, written back) and the first layer's input (nsplit == 0: the
-// embedding's rows as they are).  Writes x16 = the split planes of the (raw, un-normalised) row and ssq[row][D / 128] = the sums of squares
-// of its 128-column groups — what the residual epilogue of gemm_x3.hip writes for rows it produces itself.  One wave per row; lane l
+// embedding's rows as they are).  Writes x16 = the split planes of the (raw, un-normalised) row and ssq[t][row] (t < D / 128) = the sums of
+// squares of its 128-column groups — what the residual epilogue of gemm_x3.hip writes for rows it produces itself.  One wave per row; lane l
 // holds columns 4 (l + 64 i) .. + 3, i.e. group 2 i + (l >> 5), position l & 31 inside it.
 template <int VEC>
 __global__ __launch_bounds__(256) void vn_rowprep_kernel(const float* __restrict__ partial, int nsplit, float* __restrict__ x,
@@ -155,12 +155,11 @@ __global__ __launch_bounds__(256) void vn_rowprep_kernel(const float* __restrict
         }
     }
     bool bad = false;
-    const int nt = D >> 7;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
         vn_store_planes4(x16, plane16, row, 4 * (lane + 64 * i), D, v[i], bad);
-        const float s = vn_ssq128(v[i]);
-        if ((lane & 31) == 0) ssq[(size_t)row * nt + 2 * i + (lane >> 5)] = s;
+        const float s = vn_sum32_hi(vn_ssq4(v[i]));                         // valid in lanes 16-31 / 48-63
+        if ((lane & 31) == 16) ssq[(size_t)(2 * i + (lane >> 5)) * rows + row] = s;          // [group][row]
     }
     vn_sat_report(sat, VN_SAT_OPERAND, bad);
 }

@@ -372,6 +372,28 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
                     }
                 }
             }
+        } else if (EPI == VN_EPI_RESIDUAL && p.X16 != nullptr) {
+            // folded norm, producer side: x += acc, the split planes of the new rows and their sums of squares.  A thread owns EIGHT
+            // columns of a row (16-byte plane stores: the tile is 3 x 2 bytes per element on top of the fp32 row), the 16 threads of an
+            // image row are 16 consecutive lanes (DPP sum, no LDS round trip); N % 128 == 0 (launcher), so only rows are masked
+#pragma unroll
+            for (int k = 0; k < RP * 16 / 512; ++k) {                               // RP rows x 16 pieces of 8 columns
+                const int idx = tid + 512 * k;
+                const int R = idx >> 4, c8 = (idx & 15) * 8;
+                const int row = m0 + (R >> 5) * 32 * RI + 32 * i + (R & 31), col = n0 + c8;
+                f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (row < p.M) {
+                    float* c = p.C + (size_t)row * p.ldc + col;
+                    const f32x4 a0 = *(const f32x4*)(lds + R * 128 + c8) + *(const f32x4*)c;
+                    const f32x4 a1 = *(const f32x4*)(lds + R * 128 + c8 + 4) + *(const f32x4*)(c + 4);
+                    *(f32x4*)c = a0;
+                    *(f32x4*)(c + 4) = a1;
+                    v = f32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    vn_store_planes8_tiled(p.X16, p.x16_plane, row, col, p.N, v, bad);
+                }
+                const float s2 = vn_sum16(vn_ssq4(f32x4{v[4], v[5], v[6], v[7]}, vn_ssq4(f32x4{v[0], v[1], v[2], v[3]})));
+                if ((tid & 15) == 0 && row < p.M) p.ssq_out[(size_t)(n0 >> 7) * p.M + row] = s2;
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < RP * 32 / 512; ++k) {                               // RP rows x 32 pieces of 4 columns
@@ -396,16 +418,6 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
                         if constexpr (EPI == VN_EPI_BIAS) v += *(const f32x4*)(p.bias + col);
                         if constexpr (EPI == VN_EPI_RESIDUAL) v += *(const f32x4*)c;
                         *(f32x4*)c = v;
-                        if constexpr (EPI == VN_EPI_RESIDUAL) {
-                            // folded norm, producer side: the planes of the new residual rows for the consumer GEMM
-                            if (p.X16) vn_store_planes4(p.X16, p.x16_plane, row, col, p.N, v, bad);
-                        }
-                    }
-                }
-                if constexpr (EPI == VN_EPI_RESIDUAL) {
-                    if (p.ssq_out) {        // uniform; the 32 threads of an image row are one half-wave (idx & 31 = its column group)
-                        const float s2 = vn_ssq128(v);
-                        if ((tid & 31) == 0 && row < p.M) p.ssq_out[(size_t)row * (p.N >> 7) + (n0 >> 7)] = s2;
                     }
                 }
             }
@@ -546,9 +558,9 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             if (fold_in && tid < G::BM) {
                 const int nt = p.K >> 7;
                 const int row = m0 + tid < p.M ? m0 + tid : p.M - 1;
-                const float* q = p.ssq_in + (size_t)row * nt;
+                const float* q = p.ssq_in + row;                      // [group][row]: the lanes of a load read consecutive rows
 #pragma unroll
-                for (int t = 0; t < FOLD_NT; ++t) fold_sq[t] = t < nt ? q[t] : 0.0f;
+                for (int t = 0; t < FOLD_NT; ++t) fold_sq[t] = t < nt ? q[(size_t)t * p.M] : 0.0f;
             }
         }
         auto fold_table = [&]() {

@@ -175,23 +175,58 @@ __device__ __forceinline__ void vn_store_planes4(uint16_t* base, long plane, lon
 #define VN_DHEAD 64
 
 #ifdef __HIPCC__
-// Folded RMSNorm (vn_gemm_args::ssq_out): the sum of squares of four values as ONE fma chain, then added over the 32 lanes of a
-// half-wave (xor 16, 8, 4, 2, 1) — the partial sum of a row's 128-column group when lane (l & 31) holds columns 4 (l & 31) .. + 3
-// of the group.  The same expression in every producer (GEMM epilogue, split-K reduce, layer-0 prep).
-__device__ __forceinline__ float vn_ssq128(const f32x4& v) {
-    float s = v[0] * v[0];
+// eight consecutive columns col .. col + 7 (col % 8 == 0) of row `row` -> one 16-byte store per plane, TILED layouts only (the eight
+// columns sit in one 32-column block of the piece)
+__device__ __forceinline__ void vn_store_planes8_tiled(uint16_t* base, long plane, long row, int col, int ld, const f32x8& o, bool& bad) {
+    if (vn_planes_h2(plane)) {
+        uint16_t t[2][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vn_split2h(o[e], t[0][e], t[1][e], bad);
+        uint16_t* d = base + vn_tiled_off_np(row, col, ld, 2);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            u32x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = t[q][2 * e] | ((unsigned)t[q][2 * e + 1] << 16);
+            *(u32x4*)(d + 512 * q) = pk;
+        }
+        return;
+    }
+    bf16x8 p0, p1, p2;
+    vn_split3_x8(o, p0, p1, p2);
+    uint16_t* d = base + vn_tiled_off(row, col, ld);
+    *(u32x4*)d = __builtin_bit_cast(u32x4, p0);
+    *(u32x4*)(d + 512) = __builtin_bit_cast(u32x4, p1);
+    *(u32x4*)(d + 1024) = __builtin_bit_cast(u32x4, p2);
+}
+#endif
+
+#ifdef __HIPCC__
+// Cross-lane sums by DPP (one VALU instruction per step; a __shfl_xor is an LDS-crossbar round trip of ~100 cycles, and five of
+// them per row piece made the folded-norm epilogue cost what the norm kernel it replaced did).  Fixed order: deterministic.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float vn_dpp(float x) {     // lanes outside ROW_MASK receive 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xF, false));
+}
+// sum over each group of 16 consecutive lanes, left in every lane of the group: xor 1, xor 2 (quad_perm), row_half_mirror, row_mirror
+__device__ __forceinline__ float vn_sum16(float x) {
+    x += vn_dpp<0xB1>(x);
+    x += vn_dpp<0x4E>(x);
+    x += vn_dpp<0x141>(x);
+    x += vn_dpp<0x140>(x);
+    return x;
+}
+// sum over each half-wave of 32 lanes, VALID IN LANES 16-31 / 48-63 only (row_bcast:15 hands the first row's sum to the second)
+__device__ __forceinline__ float vn_sum32_hi(float x) {
+    x = vn_sum16(x);
+    return x + vn_dpp<0x142, 0xA>(x);
+}
+// Folded RMSNorm (vn_gemm_args::ssq_out): sums of squares as one fma chain per thread
+__device__ __forceinline__ float vn_ssq4(const f32x4& v, float s = 0.0f) {
+    s = fmaf(v[0], v[0], s);
     s = fmaf(v[1], v[1], s);
     s = fmaf(v[2], v[2], s);
-    s = fmaf(v[3], v[3], s);
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    return s;
-}
-// the consumer's side: r = 1 / sqrt(mean(x^2) + eps) of one row from its nt group sums, added in index order
-__device__ __forceinline__ float vn_fold_rstd(const float* __restrict__ ssq_row, int nt, int K, float eps) {
-    float s = ssq_row[0];
-    for (int t = 1; t < nt; ++t) s += ssq_row[t];
-    return 1.0f / sqrtf(s / (float)K + eps);            // exact div + sqrt, as vn_rmsnorm_row
+    return fmaf(v[3], v[3], s);
 }
 #endif
 
@@ -421,10 +456,11 @@ struct vn_gemm_args {
     // RMSNorm FOLDED into its consumer (engine.hip, models with m->folded): y W^T = r (.) (x (W (.) w)^T), r = rsqrt(mean(x^2) + eps) per row,
     // the norm weight w multiplied into the consumer's weight columns when its planes are built.  No norm kernel runs:
     //   PRODUCERS — the RESIDUAL epilogue (and the reduce pass of a split launch) also write X16 = the split planes of the NEW residual
-    //   rows (x16_plane: VN_PLANES_TILED / VN_PLANES_TILED_H2; row length N) and ssq_out[row][N / 128] = the sum of squares of the row's
-    //   128 columns of each column tile (a row's total is the sum of its N / 128 entries, added in index order by the consumer);
-    //   CONSUMERS — the QKV3 / QKV / GEGLU / BIAS epilogues multiply every accumulator row by r = 1 / sqrt(sum_t ssq_in[row][t] / K +
-    //   fold_eps) before anything else (K = the consumer's K = the residual width; K / 128 entries per row).
+    //   rows (x16_plane: VN_PLANES_TILED / VN_PLANES_TILED_H2; row length N) and ssq_out[t][row] (t < N / 128, leading dimension M) =
+    //   the sum of squares of the row's 128 columns of column tile t (a row's total is the sum over t, added in index order by the
+    //   consumer; group-major so that the consumer's lanes = rows read contiguously);
+    //   CONSUMERS — the QKV3 / QKV / GEGLU / BIAS epilogues multiply every accumulator row by r = 1 / sqrt(sum_t ssq_in[t][row] / K +
+    //   fold_eps) before anything else (K = the consumer's K = the residual width; K / 128 groups).
     uint16_t* X16;
     long x16_plane;
     float* ssq_out;
@@ -456,7 +492,7 @@ int vn_launch_splitk_reduce(vn_ctx* ctx, const float* partial, int nsplit, float
                             hipStream_t s);
 
 // folded-norm producers (elementwise.hip): x[rows][D] += sum of the nsplit images (nsplit = 0: x as it is, nothing written back), then
-// x16 = the split planes of the rows (plane16: tiled bf16x3 / f16x2) and ssq[row][D / 128] = sums of squares per 128-column group
+// x16 = the split planes of the rows (plane16: tiled bf16x3 / f16x2) and ssq[t][row] (t < D / 128) = sums of squares per 128-column group
 int vn_launch_rowprep(vn_ctx* ctx, const float* partial, int nsplit, float* x, uint16_t* x16, long plane16, float* ssq, int rows, int D,
                       hipStream_t s);
 // x[rows][D] += sum of the nsplit images partial[s][rows][D] (fixed order), then y = RMSNorm(x) from the same registers (elementwise.hip)
