@@ -487,8 +487,8 @@ def main():
             an, ams, afl, _ = prof["attention"]
             # fabric bytes per launch: NOT measured by this run — read from the committed rocprofv3 --pmc passes of this same command
             traffic = traffic_source = None
-            tname = next((n for n in {"f32": ["r01_traffic.json"], "bf16x3": ["r04_traffic_x3.json", "r03_traffic_x3.json"],
-                                      "f16x2": ["r04_traffic_h2.json", "r03_traffic_h2.json"]}.get(dtype, [])
+            tname = next((n for n in {"f32": ["history/r01_traffic.json"], "bf16x3": ["r04_traffic_x3.json", "history/r03_traffic_x3.json"],
+                                      "f16x2": ["r04_traffic_h2.json", "history/r03_traffic_h2.json"]}.get(dtype, [])
                           if os.path.exists(os.path.join(ROOT, "profiles", n))), "-")
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and world == 1 and args.batch_per_gpu == 8 and not args.coarse_only and not args.e2e:

@@ -306,6 +306,34 @@ int vn_rvq_encode_f32(vn_ctx* ctx, const float* z, const float* win, const float
 int vn_rvq_decode_f32(vn_ctx* ctx, const int64_t* codes, const float* cb, const float* wout, const float* bout,
                       float* zq, int B, int T, int L, int n_levels, int codebook_size, void* stream);
 
+/* ---- the codec as ONE call per direction (Interface.encode: vampnet/interface.py:219-224 -> codec.encode(...)["codes"];
+ * Interface.decode: vampnet/interface.py:203-204 -> VampNet.decode, vampnet/modules/transformer.py:661-684).  PARITY UNPINNED like the
+ * layer entry points above.  The host records the layer loop of one direction for one (batch, length, precision) as a PROGRAM: the
+ * ordered launches (each = one of the single-layer entry points above with its arguments) over device pointers the host owns — the
+ * weights and ONE activation arena planned from the buffers' live ranges (vampnet_amd/codec.py).  vn_codec_create copies the list;
+ * vn_dac_encode / vn_dac_decode walk it on `stream`: no allocation, no synchronisation, ~70 / ~150 launches per call instead of as
+ * many host round trips.  Argument slots of an op, in the order of the entry point it names: pointers -> p[], int -> i[], int64 ->
+ * l[], float -> f[]; the pointer values VN_CODEC_PTR_IN / VN_CODEC_PTR_OUT stand for the call's input / output.               */
+typedef struct vn_codec vn_codec;
+enum { VN_CODEC_OP_CONV1D_F32 = 0, VN_CODEC_OP_CONV1D_BF16X3 = 1, VN_CODEC_OP_CONV1D_F16X2 = 2, VN_CODEC_OP_CONV_IN = 3,
+       VN_CODEC_OP_CONV_OUT = 4, VN_CODEC_OP_RVQ_ENCODE = 5, VN_CODEC_OP_RVQ_DECODE = 6, VN_CODEC_OP_SPLIT3 = 7, VN_CODEC_OP_SPLIT2 = 8,
+       VN_CODEC_OP__COUNT = 9 };
+#define VN_CODEC_PTR_IN  1          /* pointer slot = the audio (encode) / the codes (decode) of the call     */
+#define VN_CODEC_PTR_OUT 2          /* pointer slot = the codes (encode) / the audio (decode) of the call     */
+typedef struct {
+    int32_t kind;                   /* VN_CODEC_OP_*                                                          */
+    int32_t i[16];
+    int64_t l[2];
+    float   f[2];
+    void*   p[12];
+} vn_codec_op;
+int  vn_codec_create(vn_ctx* ctx, const vn_codec_op* ops, int n_ops, int direction /* 0 encode, 1 decode */, vn_codec** out);
+void vn_codec_destroy(vn_codec* codec);
+/* audio dev f32 [B][L] (mono, L a multiple of the hop: codec.preprocess pads) -> codes dev int64 [B][n_codebooks][L / hop]   */
+int  vn_dac_encode(vn_codec* codec, const float* audio_dev, int64_t* codes_dev, void* stream);
+/* codes dev int64 [B][n_codebooks][T] -> audio dev f32 [B][T * hop]                                                           */
+int  vn_dac_decode(vn_codec* codec, const int64_t* codes_dev, float* audio_dev, void* stream);
+
 /* Synchronises `stream` and reports whether any stream-K GEMM of this process ever hit its bounded-spin give-up
  * (results would be wrong): VN_OK or VN_ERR_HIP.  The GEMM never hangs the GPU; this is how a caller finds out.   */
 int vn_health_check(vn_ctx* ctx, void* stream);

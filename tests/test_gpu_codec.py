@@ -249,3 +249,51 @@ def test_conv_transpose_phases_on_bf16x3(eng):
     err = (y.cpu().double() - ref).abs().max().item()
     print(f"transposed conv via {st} phases on the bf16x3 pipe: max err {err:.3e}")
     assert err <= 2e-5
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2", "f32"])
+@pytest.mark.parametrize("cfg,B,frames", [(D.DAC_TINY_CFG, 3, 21), (D.DAC_DEFAULT_CFG, 2, 9)])
+def test_one_call_per_direction_equals_the_layer_calls(eng, cfg, B, frames, precision):
+    """vn_dac_encode / vn_dac_decode (include/vampnet_hip.h; ONE C call walking the recorded layer loop over one planned arena) give
+    bitwise what the per-layer entry points give when the host issues them one by one (VN_CODEC_EAGER=1: the round-3 path): the same
+    launches in the same order — also when the program is run twice (the arena's recycled bytes carry nothing over) and for a second
+    shape next to the first (programs are cached per shape)."""
+    from vampnet_amd.codec import DacCodec
+    sd = D.synth_dac_state_dict(cfg, 0)
+    prog = DacCodec(sd, cfg, engine=eng, precision=precision)
+    eager = DacCodec(sd, cfg, engine=eng, precision=precision)
+    eager.use_program = False
+    assert prog.use_program
+    hop = D.hop_length(cfg)
+    for b, fr in ((B, frames), (1, frames + 2)):
+        audio = _audio(b, hop * fr, seed=fr)
+        a, e = prog.encode(audio, 44100), eager.encode(audio, 44100)
+        assert torch.equal(a["codes"], e["codes"]) and torch.equal(a["z"], e["z"])
+        again = prog.encode(audio, 44100)
+        assert torch.equal(again["codes"], e["codes"])
+        codes = e["codes"]
+        wa, we = prog.decode_codes(codes), eager.decode_codes(codes)
+        assert wa.shape == we.shape == (b, 1, hop * fr) and torch.equal(wa, we)
+        assert torch.equal(prog.decode_codes(codes), we)
+    assert len(prog._programs) == 4 and not eager._programs
+    p = prog._programs[(1, B, frames, precision)]
+    print(f"[{precision}] decode program B={B} T={frames}: {p['n_ops']} launches behind one call, arena {p['arena_bytes'] / 2**20:.1f} MiB")
+
+
+def test_codec_program_abi_errors(eng):
+    """the program entry points return a status + message on bad input (no crash, no exception across the ABI)"""
+    import ctypes as C
+    from vampnet_amd import _lib
+    lib = eng.lib
+    ops = (_lib.vn_codec_op * 1)()
+    ops[0].kind = 99
+    h = C.c_void_p()
+    assert lib.vn_codec_create(eng.handle, ops, 1, 0, C.byref(h)) != 0 and b"unknown kind" in lib.vn_last_error(eng.handle)
+    assert lib.vn_codec_create(eng.handle, ops, 0, 0, C.byref(h)) != 0
+    assert lib.vn_codec_create(eng.handle, ops, 1, 7, C.byref(h)) != 0
+    ops[0].kind = 6                                              # an rvq_decode with null pointers: the layer entry refuses it
+    assert lib.vn_codec_create(eng.handle, ops, 1, 1, C.byref(h)) == 0
+    x = torch.zeros(8, device="cuda")
+    assert lib.vn_dac_encode(h, x.data_ptr(), x.data_ptr(), None) != 0 and b"decodes" in lib.vn_last_error(eng.handle)
+    assert lib.vn_dac_decode(h, x.data_ptr(), x.data_ptr(), None) != 0 and b"codec program: op 0" in lib.vn_last_error(eng.handle)
+    lib.vn_codec_destroy(h)

@@ -393,7 +393,11 @@ def test_full_mode_resume_from_its_own_weights_file(engine, tmp_path):
     osd = torch.load(os.path.join(folder, "optimizer.pth"))
     assert len(osd["param_groups"][0]["params"]) == len(tr._all_param_names())
     sd_ck, _ = _load_checkpoint(os.path.join(folder, "vampnet", "weights.pth"))
-    assert sum("lora_" in k for k in sd_ck) == n_lora and all(float(v.abs().max()) == 0.0 for k, v in sd_ck.items() if "lora_" in k)
+    # fresh loralib adapters: lora_B = 0 (the saved function is the merged weights'), lora_A kaiming-uniform — NOT zeros, or a LoRA
+    # fine-tune started from this file could never move (tests/test_train_host.py::test_full_mode_save_writes_trainable_adapters)
+    assert sum("lora_" in k for k in sd_ck) == n_lora
+    assert all(float(v.abs().max()) == 0.0 for k, v in sd_ck.items() if k.endswith(".lora_B"))
+    assert all(float(v.abs().max()) > 0.0 for k, v in sd_ck.items() if k.endswith(".lora_A"))
     tr2 = _trainer(engine, dims, sd_ck, cb, **kw)            # template from the SAVED file
     tr2.load_checkpoint(folder)
     assert tr2.steps == 2
@@ -565,7 +569,7 @@ def test_training_trajectory_tracks_oracle(engine):
 def test_training_step_on_bf16x3_gemms():
     """Opt-in mode VN_TRAIN_X3=1: the same step-vs-oracle / determinism / full-size / trajectory tests with every training GEMM
     (forward, dX, dW) routed through gemm_x3.hip, operands split on the fly — same parity bars as the fp32-input MFMA default
-    (green on MI355X, profiles/r02_test_train_x3.log; 102.5 vs 99.6 ms per step: the two extra split passes per GEMM eat the
+    (green on MI355X, profiles/history/r02_test_train_x3.log; 102.5 vs 99.6 ms per step: the two extra split passes per GEMM eat the
     matrix-pipe gain, so it stays opt-in).  VN_TRAIN_X3 is read once per process, hence the child process."""
     import subprocess
     import sys

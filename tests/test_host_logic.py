@@ -825,3 +825,48 @@ def test_codec_routing_rule():
         assert c._fmt(conv(cout, cin, k)) == ("x3" if want else "f32")
     c.precision = "f32"
     assert not any(c._on_x3(conv(*key)) for key in table)
+
+
+def test_codec_program_arena_planner():
+    """vampnet_amd/codec.py _Recorder.plan: the arena offsets of a recorded codec program.  Two buffers may share bytes only if
+    their live ranges [first use, last use] are disjoint — an op's inputs are never handed to its outputs — pinned buffers are
+    never recycled, and the arena is smaller than the sum of the buffers (it exists to recycle)."""
+    import random
+    import torch
+    from vampnet_amd.codec import _FAKE_BASE, _PTR_IN, _PTR_OUT, _Recorder
+    rnd = random.Random(5)
+    for trial in range(20):
+        rec = _Recorder()
+        inp = rec.new((4, 100), torch.float32, io="in")
+        out = rec.new((4, 7), torch.int64, io="out")
+        assert inp.data_ptr() == _PTR_IN and out.data_ptr() == _PTR_OUT
+        live = [inp]
+        pinned = None
+        for k in range(40):
+            reads = rnd.sample(live, min(len(live), rnd.randint(1, 3)))
+            w = rec.new((rnd.randint(1, 9), rnd.randint(1, 300)), rnd.choice([torch.float32, torch.bfloat16, torch.float16]))
+            v = w.reshape(-1)                                   # a view keeps the buffer's identity
+            assert v.data_ptr() == w.data_ptr() and v.shape == (w.numel(),)
+            rec.emit(0, [("p", r.data_ptr()) for r in reads] + [("p", None), ("i", 3), ("p", v.data_ptr())])
+            live.append(w)
+            if len(live) > 5:
+                live.pop(rnd.randrange(len(live)))
+            if k == 17:
+                pinned = w
+                rec.bufs[w.bid]["pinned"] = True
+        rec.emit(0, [("p", live[-1].data_ptr()), ("p", out.data_ptr())])
+        off, total = rec.plan()
+        used = [i for i, b in enumerate(rec.bufs) if b["first"] is not None and b["io"] is None]
+        assert set(off) == set(used)
+        n_ops = len(rec.ops)
+        span = lambda i: (rec.bufs[i]["first"], n_ops if rec.bufs[i]["pinned"] else rec.bufs[i]["last"])
+        for a in used:
+            assert off[a] % 256 == 0 and off[a] + rec.bufs[a]["nbytes"] <= total
+            for b in used:
+                if a < b:
+                    (fa, la), (fb, lb) = span(a), span(b)
+                    overlap_time = not (la < fb or lb < fa)
+                    overlap_mem = not (off[a] + rec.bufs[a]["nbytes"] <= off[b] or off[b] + rec.bufs[b]["nbytes"] <= off[a])
+                    assert not (overlap_time and overlap_mem), (trial, a, b)
+        assert total < sum(-(-rec.bufs[i]["nbytes"] // 256) * 256 for i in used)
+        assert span(pinned.bid)[1] == n_ops

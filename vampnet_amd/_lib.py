@@ -25,6 +25,10 @@ class vn_sample_params(C.Structure):
                 ("global_batch", C.c_int32), ("step_events", C.POINTER(C.c_void_p))]
 
 
+class vn_codec_op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("i", C.c_int32 * 16), ("l", C.c_int64 * 2), ("f", C.c_float * 2), ("p", C.c_void_p * 12)]
+
+
 class vn_train_params(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("weight_decay", C.c_float), ("grad_clip", C.c_float), ("label_smoothing", C.c_float),
@@ -105,6 +109,10 @@ SYMBOLS = {
     "vn_torch_uniform_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, C.c_float, _P]),
     "vn_build_mask": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64,
                                C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
+    "vn_codec_create": (C.c_int, [_P, C.POINTER(vn_codec_op), C.c_int, C.c_int, C.POINTER(_P)]),
+    "vn_codec_destroy": (None, [_P]),
+    "vn_dac_encode": (C.c_int, [_P, _P, _P, _P]),
+    "vn_dac_decode": (C.c_int, [_P, _P, _P, _P]),
     "vn_comm_unique_id": (C.c_int, [_P, _P]),
     "vn_comm_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     "vn_comm_destroy": (None, [_P]),

@@ -16,6 +16,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
+from . import _lib
 from .engine import DEFAULT_PRECISION, Engine
 
 DEFAULT_CFG = dict(encoder_dim=64, encoder_rates=[2, 4, 8, 12], latent_dim=None, decoder_dim=1536,
@@ -198,6 +199,87 @@ def _fold(sd, key):
     return sd[key + ".weight"].float()
 
 
+_FAKE_BASE = 1 << 60            # "addresses" of program buffers while a program is being recorded (never dereferenced)
+_PTR_IN, _PTR_OUT = 1, 2        # include/vampnet_hip.h VN_CODEC_PTR_IN / VN_CODEC_PTR_OUT
+
+
+class _VBuf:
+    """A buffer of a codec program under construction: shape / dtype like a tensor, an id instead of memory."""
+    __slots__ = ("rec", "bid", "shape", "dtype")
+
+    def __init__(self, rec, bid, shape, dtype):
+        self.rec, self.bid, self.shape, self.dtype = rec, bid, tuple(int(v) for v in shape), dtype
+
+    def numel(self):
+        return int(np.prod(self.shape)) if self.shape else 1
+
+    def reshape(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        shape = list(shape)
+        if -1 in shape:
+            k = shape.index(-1)
+            rest = int(np.prod([v for j, v in enumerate(shape) if j != k])) or 1
+            shape[k] = self.numel() // rest
+        assert int(np.prod(shape)) == self.numel()
+        return _VBuf(self.rec, self.bid, shape, self.dtype)
+
+    def contiguous(self):
+        return self
+
+    def data_ptr(self):
+        return self.rec.ptr_of(self.bid)
+
+
+class _Recorder:
+    """Records the launches of one codec direction as a program (include/vampnet_hip.h vn_codec_op) and plans ONE arena for its
+    buffers from their live ranges: a buffer's bytes are handed to later buffers once its last reader has been recorded."""
+
+    def __init__(self):
+        self.bufs = []           # dict(nbytes, first, last, io, pinned)
+        self.ops = []            # (kind, [(type, value), ...])
+
+    def new(self, shape, dtype, io=None, pinned=False):
+        nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        self.bufs.append(dict(nbytes=nbytes, first=None, last=None, io=io, pinned=pinned))
+        return _VBuf(self, len(self.bufs) - 1, shape, dtype)
+
+    def ptr_of(self, bid):
+        io = self.bufs[bid]["io"]
+        return {None: _FAKE_BASE + bid, "in": _PTR_IN, "out": _PTR_OUT}[io]
+
+    def emit(self, kind, typed_args):
+        k = len(self.ops)
+        for t, v in typed_args:
+            if t == "p" and v is not None and v >= _FAKE_BASE:
+                b = self.bufs[v - _FAKE_BASE]
+                b["first"] = k if b["first"] is None else b["first"]
+                b["last"] = k
+        self.ops.append((kind, typed_args))
+
+    def plan(self, align=256):
+        """offsets of the buffers in one arena: first-fit over the blocks freed by buffers whose last use has passed"""
+        order = sorted((b["first"], i) for i, b in enumerate(self.bufs) if b["first"] is not None and b["io"] is None)
+        live, free, end, off = [], [], 0, {}
+        for first, i in order:
+            for item in [it for it in live if it[0] < first]:          # its last reader ran before this buffer's first op
+                live.remove(item)
+                free.append((item[1], item[2]))
+            need = -(-self.bufs[i]["nbytes"] // align) * align
+            free.sort()
+            slot = next((j for j, (o, sz) in enumerate(free) if sz >= need), None)
+            if slot is None:
+                o, end = end, end + need
+            else:
+                o, sz = free.pop(slot)
+                if sz > need:
+                    free.append((o + need, sz - need))
+            off[i] = o
+            last = len(self.ops) if self.bufs[i]["pinned"] else self.bufs[i]["last"]
+            live.append((last, o, need))
+        return off, end
+
+
 class _Act:
     """A channels-last activation [B][T][C] in the format(s) its consumer reads: `f32` for the fp32-input MFMA convolution
     (conv1d_f32.hip), `p16` = three exact split bf16 planes [3][B*T][C] for the bf16x3 pipe (gemm_x3.hip's implicit-GEMM mode)."""
@@ -210,7 +292,7 @@ class _Act:
 class DacCodec:
     # A convolution runs on the bf16x3 pipe (six bf16-MFMA products of exact operand splits: the transformer's GEMM kernel with the
     # A rows gathered per tap) where it is MFMA-bound there.  Measured per layer on the 44.1 kHz configuration at B = 8
-    # (profiles/r03_codec_kernel_trace_*.txt): k = 7 and strided / transposed convolutions with >= 128 output channels run 26-39 %
+    # (profiles/history/r03_codec_kernel_trace_*.txt): k = 7 and strided / transposed convolutions with >= 128 output channels run 26-39 %
     # faster than on the fp32-input MFMA kernel; the k = 1 tails below 512 channels are HBM-bound and LOSE (planes are 6 bytes per
     # element against 4), and 96 / 192 output channels fill only 75 % of the 128-wide tile.  Rule: >= 128 output channels and
     # K x (tile efficiency) >= 512, K = taps * C_in.  The 64- and 96-channel audio-rate blocks, the small k = 1 tails and the
@@ -231,6 +313,11 @@ class DacCodec:
         self.latent_dim = cfg["latent_dim"] or cfg["encoder_dim"] * 2 ** len(cfg["encoder_rates"])
         self.n_codebooks = cfg["n_codebooks"]
         self._sd = sd                              # kept (host tensors): a precision fallback re-lays the weights
+        # one C call per direction (vn_dac_encode / vn_dac_decode over a recorded program); VN_CODEC_EAGER=1: one ctypes call per layer
+        import os
+        self.use_program = os.environ.get("VN_CODEC_EAGER", "0") != "1"
+        self._rec = None
+        self._programs = {}
         if precision == "f16x2":
             self.engine.saturation(clear=True)
         self._build(precision)
@@ -261,6 +348,7 @@ class DacCodec:
         """(re)lay the weights for `precision` (device fp32 tensors + the split-plane images of the layers that run on the matrix-core pipe)"""
         sd, cfg = self._sd, self.cfg
         self.precision = precision
+        self._drop_programs()                      # they point at the previous weight images
         dev = self.device
 
         def conv(key):          # Conv1d (Cout, Cin, k) -> [Cout][k][Cin]
@@ -354,16 +442,95 @@ class DacCodec:
                   "vn_tile_planes_bf16x3")
         return tiled
 
+    # ---- launches: issued now (eager) or recorded into a program (the same code path builds both) ------------------------------
+    _OP_KIND = {"vn_conv1d_f32": 0, "vn_conv1d_bf16x3": 1, "vn_conv1d_f16x2": 2, "vn_dac_conv_in_f32": 3, "vn_dac_conv_out_f32": 4,
+                "vn_rvq_encode_f32": 5, "vn_rvq_decode_f32": 6, "vn_split3_f32": 7, "vn_split2_f16": 8}      # VN_CODEC_OP_*
+
+    def _new(self, shape, dtype=torch.float32, io=None):
+        """an activation buffer: a tensor (eager) or a program buffer (recording)"""
+        if self._rec is not None:
+            return self._rec.new(shape, dtype, io)
+        return torch.empty(*shape, device=self.device, dtype=dtype)
+
+    def _emit(self, name, *args):
+        """one launch of a single-layer entry point (arguments between ctx and stream)"""
+        if self._rec is None:
+            eng = self.engine
+            eng.check(getattr(self.lib, name)(eng.handle, *args, eng.stream()), name)
+            return
+        import ctypes as C
+        code = {C.c_void_p: "p", C.c_int: "i", C.c_int64: "l", C.c_float: "f"}
+        types = _lib.SYMBOLS[name][1][1:-1]
+        assert len(types) == len(args), name
+        self._rec.emit(self._OP_KIND[name], [(code[t], a) for t, a in zip(types, args)])
+
+    def _drop_programs(self):
+        for prog in getattr(self, "_programs", {}).values():
+            self.lib.vn_codec_destroy(prog["handle"])
+        self._programs = {}
+
+    def __del__(self):
+        try:
+            self._drop_programs()
+        except Exception:
+            pass
+
+    def _program(self, direction, B, n):
+        """the recorded program of one direction for batch B and length n (samples / tokens) in the current precision"""
+        import ctypes as C
+        key = (direction, B, n, self.precision)
+        if key in self._programs:
+            return self._programs[key]
+        rec = _Recorder()
+        self._rec = rec
+        try:
+            if direction == 0:
+                res = self._encode_layers(rec.new((B, n), torch.float32, io="in"), B, n)
+                rec.bufs[res["z"].bid]["pinned"] = True                      # the latents stay readable after the call
+                z = res["z"]
+            else:
+                self._decode_layers(rec.new((B, self.n_codebooks, n), torch.int64, io="in"), B, self.n_codebooks, n)
+                z = None
+        finally:
+            self._rec = None
+        off, total = rec.plan()
+        arena = torch.empty(max(total, 256), dtype=torch.uint8, device=self.device)
+        base = arena.data_ptr()
+        ops = (_lib.vn_codec_op * len(rec.ops))()
+        for k, (kind, typed) in enumerate(rec.ops):
+            op, cnt = ops[k], dict(p=0, i=0, l=0, f=0)
+            op.kind = kind
+            for t, v in typed:
+                j = cnt[t]
+                cnt[t] += 1
+                if t == "p":
+                    v = None if v is None else (base + off[v - _FAKE_BASE] if v >= _FAKE_BASE else v)
+                    op.p[j] = v
+                else:
+                    getattr(op, t)[j] = v
+        h = C.c_void_p()
+        self.engine.check(self.lib.vn_codec_create(self.engine.handle, ops, len(rec.ops), direction, C.byref(h)), "vn_codec_create")
+        prog = dict(handle=h, arena=arena, n_ops=len(rec.ops), arena_bytes=total,
+                    z=(off[z.bid], z.shape) if z is not None else None)
+        self._programs[key] = prog
+        return prog
+
     def _empty_planes(self, rows, cols):
         """planar split planes of a [rows][cols] activation in this codec's format: three bf16 or two fp16 planes"""
         if self.precision == "f16x2":
-            return torch.empty(2, rows, cols, device=self.device, dtype=torch.float16)
-        return torch.empty(3, rows, cols, device=self.device, dtype=torch.bfloat16)
+            return self._new((2, rows, cols), torch.float16)
+        return self._new((3, rows, cols), torch.bfloat16)
 
     def _planes(self, x):
         """fp32 [B][T][C] -> _Act with split planes (the few places where a producer outside the conv stack feeds the bf16x3 pipe)"""
         x2d = x.reshape(-1, x.shape[-1])
-        return _Act(f32=x, p16=self.engine.split2h(x2d) if self.precision == "f16x2" else self.engine.split3(x2d))
+        R, K = x2d.shape
+        out = self._empty_planes(R, K)
+        if self.precision == "f16x2":
+            self._emit("vn_split2_f16", x2d.data_ptr(), out.data_ptr(), R, K, R * K, 0)
+        else:
+            self._emit("vn_split3_f32", x2d.data_ptr(), out.data_ptr(), R * K, R * K)
+        return _Act(f32=x, p16=out)
 
     def _conv(self, x, c, *, T_in, T_rows, T_out, phase=None, taps=None, in_stride=1, dil=1, pad=0, out_stride=1, out_off=0,
               resid=None, alpha=None, want_raw=True, s_fmt=None, act=0, out=None):
@@ -379,10 +546,10 @@ class DacCodec:
         B = src.shape[0] if not x3 else src.shape[1] // T_in
         y, sn = out if out is not None else (None, None)
         if want_raw and y is None:
-            y = torch.empty(B, T_out, cout, device=self.device, dtype=torch.float32)
+            y = self._new((B, T_out, cout))
         if s_fmt is not None and sn is None:
             assert alpha is not None
-            sn = _Act(torch.empty(B, T_out, cout, device=self.device, dtype=torch.float32) if s_fmt in ("f32", "both") else None,
+            sn = _Act(self._new((B, T_out, cout)) if s_fmt in ("f32", "both") else None,
                       self._empty_planes(B * T_out, cout) if s_fmt in ("x3", "both") else None)
         p = lambda t: t.data_ptr() if t is not None else None
         y2, y216 = (sn.f32, sn.p16) if sn is not None else (None, None)
@@ -390,16 +557,14 @@ class DacCodec:
         h2 = self.precision == "f16x2"
         if x3:
             w16 = c["w16"] if phase is None else c["w16"][phase]
-            eng.check((self.lib.vn_conv1d_f16x2 if h2 else self.lib.vn_conv1d_bf16x3)(
-                eng.handle, src.data_ptr(), src.shape[1] * src.shape[2], w16.data_ptr(), c["b"].data_ptr(), p(resid), p(alpha),
-                p(y), p(y2), p(y216), plane, B, T_in, T_rows, T_out, cin, cout, taps, in_stride, dil, pad, out_stride, out_off, act,
-                eng.stream()), "vn_conv1d_f16x2" if h2 else "vn_conv1d_bf16x3")
+            self._emit("vn_conv1d_f16x2" if h2 else "vn_conv1d_bf16x3",
+                       src.data_ptr(), src.shape[1] * src.shape[2], w16.data_ptr(), c["b"].data_ptr(), p(resid), p(alpha),
+                       p(y), p(y2), p(y216), plane, B, T_in, T_rows, T_out, cin, cout, taps, in_stride, dil, pad, out_stride, out_off, act)
         else:
             w = c["w"] if phase is None else c["w"][phase]
-            eng.check(self.lib.vn_conv1d_f32(
-                eng.handle, src.data_ptr(), w.data_ptr(), c["b"].data_ptr(), p(resid), p(alpha), p(y), p(y2), p(y216),
-                -plane if h2 else plane,        # the fp32 kernel writes two fp16 planes when the stride is negative
-                B, T_in, T_rows, T_out, cin, cout, taps, in_stride, dil, pad, out_stride, out_off, act, eng.stream()), "vn_conv1d_f32")
+            self._emit("vn_conv1d_f32", src.data_ptr(), w.data_ptr(), c["b"].data_ptr(), p(resid), p(alpha), p(y), p(y2), p(y216),
+                       -plane if h2 else plane,        # the fp32 kernel writes two fp16 planes when the stride is negative
+                       B, T_in, T_rows, T_out, cin, cout, taps, in_stride, dil, pad, out_stride, out_off, act)
         return y, sn
 
     def _res_unit(self, x, s, r, dil, alpha_next, T, next_fmt):
@@ -428,13 +593,23 @@ class DacCodec:
         B, ch, L = x.shape
         assert ch == 1 and L % self.hop_length == 0, "mono audio padded by preprocess() expected"
         x = x.reshape(B, L).contiguous()
-        e, eng = self.enc, self.engine
+        if not self.use_program:
+            return self._encode_layers(x, B, L)
+        prog = self._program(0, B, L)                       # ONE C call: vn_dac_encode walks the recorded layer loop
+        codes = torch.empty(B, self.n_codebooks, L // self.hop_length, device=self.device, dtype=torch.int64)
+        self.engine.check(self.lib.vn_dac_encode(prog["handle"], x.data_ptr(), codes.data_ptr(), self.engine.stream()), "vn_dac_encode")
+        zo, zshape = prog["z"]
+        nz = int(np.prod(zshape)) * 4
+        return {"codes": codes, "z": prog["arena"][zo:zo + nz].view(torch.float32).view(*zshape)}     # z: valid until the next encode
+
+    def _encode_layers(self, x, B, L):
+        """the encoder's layer loop: x = [B][L] samples -> {"codes", "z"}; issues (or records) one launch per layer"""
+        e = self.enc
         C0 = e["stem"]["c"]
-        cur = torch.empty(B, L, C0, device=self.device)
-        s0 = torch.empty(B, L, C0, device=self.device)
-        eng.check(self.lib.vn_dac_conv_in_f32(eng.handle, x.data_ptr(), e["stem"]["w"].data_ptr(), e["stem"]["b"].data_ptr(),
-                                              e["blocks"][0]["res"][0]["a1"].data_ptr(), cur.data_ptr(), s0.data_ptr(), B, L, C0,
-                                              eng.stream()), "vn_dac_conv_in_f32")
+        cur = self._new((B, L, C0))
+        s0 = self._new((B, L, C0))
+        self._emit("vn_dac_conv_in_f32", x.data_ptr(), e["stem"]["w"].data_ptr(), e["stem"]["b"].data_ptr(),
+                   e["blocks"][0]["res"][0]["a1"].data_ptr(), cur.data_ptr(), s0.data_ptr(), B, L, C0)
         s = _Act(f32=s0) if self._fmt(e["blocks"][0]["res"][0]["c7"]) == "f32" else self._planes(s0)
         T = L
         nb = len(e["blocks"])
@@ -452,12 +627,10 @@ class DacCodec:
                                 want_raw=bi + 1 < nb, s_fmt=nxt)
             T = T_out
         z, _ = self._conv(s, e["out"], T_in=T, T_rows=T, T_out=T, pad=1)
-        codes = torch.empty(B, self.n_codebooks, T, device=self.device, dtype=torch.int64)
+        codes = self._new((B, self.n_codebooks, T), torch.int64, io="out")
         r = self.rvq
-        eng.check(self.lib.vn_rvq_encode_f32(eng.handle, z.data_ptr(), r["win"].data_ptr(), r["bin"].data_ptr(),
-                                             r["cb"].data_ptr(), r["wout"].data_ptr(), r["bout"].data_ptr(), codes.data_ptr(),
-                                             B, T, self.latent_dim, self.n_codebooks, self.cfg["codebook_size"], eng.stream()),
-                  "vn_rvq_encode_f32")
+        self._emit("vn_rvq_encode_f32", z.data_ptr(), r["win"].data_ptr(), r["bin"].data_ptr(), r["cb"].data_ptr(), r["wout"].data_ptr(),
+                   r["bout"].data_ptr(), codes.data_ptr(), B, T, self.latent_dim, self.n_codebooks, self.cfg["codebook_size"])
         return {"codes": codes, "z": z}
 
     @torch.inference_mode()
@@ -469,11 +642,19 @@ class DacCodec:
     def _decode_codes(self, codes):
         codes = codes.to(self.device, torch.int64).contiguous()
         B, n, T = codes.shape
-        eng, d, r = self.engine, self.dec, self.rvq
-        zq = torch.empty(B, T, self.latent_dim, device=self.device)
-        eng.check(self.lib.vn_rvq_decode_f32(eng.handle, codes.data_ptr(), r["cb"].data_ptr(), r["wout"].data_ptr(),
-                                             r["bout"].data_ptr(), zq.data_ptr(), B, T, self.latent_dim, n,
-                                             self.cfg["codebook_size"], eng.stream()), "vn_rvq_decode_f32")
+        if not self.use_program or n != self.n_codebooks:
+            return self._decode_layers(codes, B, n, T)
+        prog = self._program(1, B, T)                       # ONE C call: vn_dac_decode walks the recorded layer loop
+        audio = torch.empty(B, 1, T * self.hop_length, device=self.device, dtype=torch.float32)
+        self.engine.check(self.lib.vn_dac_decode(prog["handle"], codes.data_ptr(), audio.data_ptr(), self.engine.stream()), "vn_dac_decode")
+        return audio
+
+    def _decode_layers(self, codes, B, n, T):
+        """the decoder's layer loop: codes [B][n][T] -> audio [B][1][T * hop]; issues (or records) one launch per layer / phase"""
+        d, r = self.dec, self.rvq
+        zq = self._new((B, T, self.latent_dim))
+        self._emit("vn_rvq_decode_f32", codes.data_ptr(), r["cb"].data_ptr(), r["wout"].data_ptr(), r["bout"].data_ptr(), zq.data_ptr(),
+                   B, T, self.latent_dim, n, self.cfg["codebook_size"])
         zin = _Act(f32=zq) if self._fmt(d["in"]) == "f32" else self._planes(zq)
         _, s = self._conv(zin, d["in"], T_in=T, T_rows=T, T_out=T, pad=3, alpha=d["blocks"][0]["a"], want_raw=False,
                           s_fmt=self._fmt(d["blocks"][0]["up"], taps=2))
@@ -484,8 +665,8 @@ class DacCodec:
             pad = math.ceil(st / 2)
             T_out = (T - 1) * st - 2 * pad + 2 * st
             f0 = self._fmt(blk["res"][0]["c7"])
-            y = torch.empty(B, T_out, up["cout"], device=self.device)
-            y2 = _Act(torch.empty(B, T_out, up["cout"], device=self.device) if f0 == "f32" else None,
+            y = self._new((B, T_out, up["cout"]))
+            y2 = _Act(self._new((B, T_out, up["cout"])) if f0 == "f32" else None,
                       self._empty_planes(B * T_out, up["cout"]) if f0 == "x3" else None)
             for ph in range(st):        # polyphase: output rows t = t'*st + ph - pad read x[t'] and x[t'-1]
                 self._conv(s, up, phase=ph, taps=2, T_in=T, T_rows=T + 1, T_out=T_out, in_stride=1, dil=-1, pad=0,
@@ -500,9 +681,8 @@ class DacCodec:
                     a_next, nxt = d["a_out"], "f32"                  # the 1-channel head reads fp32
                 cur, s = self._res_unit(cur, s, blk["res"][j], dil, a_next, T, nxt)
         s = s.f32
-        audio = torch.empty(B, T, device=self.device)
-        eng.check(self.lib.vn_dac_conv_out_f32(eng.handle, s.data_ptr(), d["head_w"].data_ptr(), d["head_b"], audio.data_ptr(),
-                                               B, T, s.shape[-1], eng.stream()), "vn_dac_conv_out_f32")
+        audio = self._new((B, T), torch.float32, io="out")
+        self._emit("vn_dac_conv_out_f32", s.data_ptr(), d["head_w"].data_ptr(), d["head_b"], audio.data_ptr(), B, T, s.shape[-1])
         return audio.reshape(B, 1, T)
 
     def decode(self, z_or_codes):

@@ -23,7 +23,7 @@
 // VGPRs.  An unscaled remainder falls into fp16's subnormal range for |x| < 0.125 — exact to 2^-25 absolute there instead of 2^-22
 // relative — which moves a score by < 3e-7; the softmax weights (<= e^6) and V carry a factor 16 each (16 P < 6.5e3), divided out
 // with l at the end.  Measured against float64 (tests/test_gpu_kernels.py): 1.2e-6 max, the bf16x3 operands 1.1e-6, the fp32-input
-// kernel 2.6e-6.  B = 8: 58.8 us vs 86.5 us (profiles/r03_attention_f16x2_vs_bf16x3.txt).
+// kernel 2.6e-6.  B = 8: 58.8 us vs 86.5 us (profiles/history/r03_attention_f16x2_vs_bf16x3.txt).
 //
 // Per wave: 32 query columns.
 //   S^T[key][q] = K[key][:] . Q[q][:]      A = K tile rows (LDS), B = Q (registers, loaded once)
@@ -47,7 +47,7 @@
 //     kernel here: 39.6 us at B = 1).
 //
 // Softmax arithmetic (round 3; the PMC of round 2 showed 7.6 VALU instructions per MFMA against ~4 that ride along for free,
-// profiles/r02_final2_pmc_attention_x3.txt):
+// profiles/history/r02_final2_pmc_attention_x3.txt):
 //   * the S^T accumulator is INITIALISED with the bias row (the MFMAs add the products onto it) instead of adding it afterwards;
 //   * the running max is only raised when some score of the tile exceeds it by more than AX_THR (guide T13): P = exp(s - m_ref)
 //     may then be as large as e^AX_THR, which costs nothing here — P is split EXACTLY into three bf16 planes whatever its size
@@ -57,7 +57,7 @@
 //     fp32-grade accuracy as vn_exp_neg with one instruction less per score.
 // Algorithmic FLOPs: 4*T*T*64 per (b,h); executed on the bf16 pipe: 6x that.
 // History of measured-and-dropped variants (software-pipelined loop, start staggers, 96-query blocks, six-wave blocks, s_setprio):
-// DESIGN.md section 3 and profiles/r02_attention_x3_*.txt.
+// DESIGN.md section 3 and profiles/history/r02_attention_x3_*.txt.
 #include <type_traits>
 #include "vn_common.h"
 
@@ -183,7 +183,7 @@ __device__ __forceinline__ float ax_probs(const f32x16& sacc, f32x4 (&pf)[NP][2]
     if constexpr (NP == 2) {
         // fp16 planes: the weights carry a factor 16 (vn_common.h vn_split2u), which costs nothing when it rides in the exponent:
         // P' = 16 exp(s - m) = 2^(s log2 e + c), c = 4 - m log2 e once per tile — ONE fma and one v_exp_f32 per score instead of the
-        // six instructions of ax_exp (PMC: this kernel issues 9.9 VALU per MFMA, profiles/r03_h2_pmc_attention.txt).  The two
+        // six instructions of ax_exp (PMC: this kernel issues 9.9 VALU per MFMA, profiles/history/r03_h2_pmc_attention.txt).  The two
         // roundings (c and the fma) move the exponent by <= ulp(|m log2 e|) / 2 + ulp(|s log2 e + c|) / 2, i.e. a weight by a few
         // 1e-7 relative at |scores| ~ 10 — the size of the rounding the scores themselves carry out of their fp32 accumulation; c is
         // common to every weight formed under the same reference max, so it cancels between O and l.  A masked score (-inf) gives
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
         // at B = 8 that find no free slot) was starved by the two older full blocks of its CU: 88k cycles instead of the 52k it
         // takes alone, ending 15-40k cycles after every other CU was idle.  With priority the tail blocks of the first wave end at
         // ~75k, the late ones start at ~70k and end at ~130k — before the CUs that hold three full blocks (~160k) — and the launch
-        // is 7 % shorter (profiles/r03_attention_x3_timeline.txt).  When every block is resident from the start the priority only
+        // is 7 % shorter (profiles/history/r03_attention_x3_timeline.txt).  When every block is resident from the start the priority only
         // slows the full blocks that bound the launch (B = 3: 47.0 vs 41.9 us), hence the launcher's condition.
         if (tail_prio) __builtin_amdgcn_s_setprio(3);
         const int kh = wave >> 1, NH = (NT + 1) >> 1;
@@ -751,7 +751,7 @@ int vn_attention_x3_plan(const vn_ctx* ctx, int B, int H, int T, int cus) {
     // the key-split shape (two key halves per 32-query block: 52.6 KiB, three blocks per CU) halves the serial chain of tiles a
     // wave walks and wins while ALL its blocks are resident at once; from its second round on the shared-tile kernel (a quarter of
     // the blocks, K / V^T staged once per 128 queries, key-split tail blocks) is ahead (T = 575: B = 2 33.5 vs 35.4 us, B = 3
-    // 57.4 vs 40.9 us; T = 173: B = 4 15.2 vs 15.9, B = 8 25.5 vs 20.4 — profiles/r03_attention_x3_tail_role.txt)
+    // 57.4 vs 40.9 us; T = 173: B = 4 15.2 vs 15.9, B = 8 25.5 vs 20.4 — profiles/history/r03_attention_x3_tail_role.txt)
     if ((long)B * H * ((T + 31) / 32) <= 3L * cus) return 2;
     return 0;
 }

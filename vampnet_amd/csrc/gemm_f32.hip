@@ -516,7 +516,7 @@ static int launch_cfg(vn_ctx* ctx, const vn_gemm_args& a, bool streamk, hipStrea
     return VN_OK;
 }
 
-// Cost model, in units of (tile area / efficiency), calibrated on MI355X (profiles/r01_gemm_sweep.txt):
+// Cost model, in units of (tile area / efficiency), calibrated on MI355X (profiles/history/r01_gemm_sweep.txt):
 //   a CU retires one block-tile per (bm*bn/eff) whether it hosts 1 or 2 blocks (shared matrix pipes), so
 //   data-parallel costs ceil(blocks/256) rounds; stream-K costs the exact share + a fix-up overhead of about
 //   0.2 x (128x128 tile at K=1280) = ~16-20 us (slab write + read, pipeline refill per segment).

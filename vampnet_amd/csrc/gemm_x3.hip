@@ -23,13 +23,13 @@
 // UNSPLIT operands gives (2.5e-7), because the fp32 accumulation is the larger error in both (tests/test_gpu_f16x2.py,
 // tests/test_host_logic.py::test_f16x2_split_numerics_on_the_host) — at HALF the matrix work and 2/3 of the operand bytes of bf16x3:
 // the ceiling moves from 417 to 833 fp32-equivalent TFLOP/s, measured 1.5-1.7x on the model's shapes
-// (profiles/r03_gemm_f16x2_vs_bf16x3.txt).  No per-tensor scaling is needed (both planes keep 11 bits wherever the value sits in
+// (profiles/history/r03_gemm_f16x2_vs_bf16x3.txt).  No per-tensor scaling is needed (both planes keep 11 bits wherever the value sits in
 // fp16's range); what fp16 cannot hold is |x| > 65504 — no activation or weight of this model family comes near it (the reference
 // itself runs bf16 autocast on a GPU), and the split clamps instead of producing inf.  The backward GEMMs of training stay on
 // fp32 / bf16x3: gradients live far below fp16's range.
 // Geometry: a stage holds 2 x (BM + 128) rows = 32 / 48 / 40 KiB, THREE stages are resident for every tile height; schedule: one
 // phase per k-tile and wave group (fragments of both k-steps, 2 x 3 products; two barriers per k-tile) — see the k-loop.
-// Ablations (scripts/gemm_h2_ablation.py, profiles/r03_gemm_f16x2_ablation.txt): without the DMA -15 %, without the fragment reads
+// Ablations (scripts/gemm_h2_ablation.py, profiles/history/r03_gemm_f16x2_ablation.txt): without the DMA -15 %, without the fragment reads
 // -2.5 %, MFMAs + barriers alone 428 TF-eq = 1283 TF executed on the QKV shape — the same executed rate the bf16x3 kernel stops at;
 // moving the DMA issue between the phases or never waiting for it changes nothing: this format too runs at the chip's power limit,
 // and what is left to gain is bytes moved per flop, not schedule.
@@ -50,14 +50,14 @@
 //     is stored at slot s ^ ((r >> 2) & 3).  A ds_read_b128 is serviced in 16-lane groups whose rows are
 //     {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (+32): with 64-byte rows the four rows that share r % 4 (hence a
 //     256-byte bank-row quarter) have four different (r >> 2) & 3, so every group touches 16 distinct slots
-//     (SQ_LDS_BANK_CONFLICT = 0, profiles/r02_pmc_gemm_x3_pipe4.txt).
+//     (SQ_LDS_BANK_CONFLICT = 0, profiles/history/r02_pmc_gemm_x3_pipe4.txt).
 //   * Fragment of v_mfma_f32_32x32x16_bf16: lane l holds row l & 31, k = 8 (l >> 5) .. + 7 of the 16-wide step, i.e.
 //     slot 2 s + (l >> 5) of the row for sub-step s in {0, 1}.
 //   * "Ping-pong" schedule: the eight waves form two groups (waves 0-3 / 4-7: one wave of each group on every SIMD) that
 //     run the same step sequence ONE PHASE APART — while a group issues the 12 / 24 / 18 MFMAs of a k-step (s_setprio 1) the other
 //     reads its next fragments and issues LDS-DMA; two raw s_barriers per k-step keep the alternation, counted vmcnt keeps
 //     the DMA in flight across them (guide section 5, 8-phase template).  Round-1's lock-step schedule ran 7-12 % slower
-//     (profiles/r02_gemm_x3_schedules.txt).
+//     (profiles/history/r02_gemm_x3_schedules.txt).
 //   * Epilogues as in gemm_f32.hip (store / bias / residual / GEGLU gate / QKV head-major scatter); the GEGLU result is
 //     written as three planes again (it is only ever the A operand of the next GEMM).
 //   * rows >= M and columns >= N are clamped on load and masked on store.
@@ -67,7 +67,7 @@
 // whole tiles + k-split tail, deterministic two-pass fix-up) was built, verified and measured in round 2 and removed again:
 // with every CU busy the kernel sits at the chip's power limit (~1.75 GHz, GRBM_GUI_ACTIVE / duration) while a partly filled
 // last round runs at a higher clock, so the evenly balanced launch gained <= 2.5 % on the QKV shape, lost to its fix-up pass on
-// Wo / W1 / W2 and lost 3 ms of 55 on the B = 1 path (profiles/r02_gemm_x3_streamk_v2_vs_dp.txt, r02_c10_3_cfg1_*.json).
+// Wo / W1 / W2 and lost 3 ms of 55 on the B = 1 path (profiles/history/r02_gemm_x3_streamk_v2_vs_dp.txt, r02_c10_3_cfg1_*.json).
 // On the GPU the result is within 7.5e-6 of float64 at 4600 x 3840 x 1280 (the fp32-input MFMA kernel: 9e-6).
 #include <stdlib.h>
 #include "vn_common.h"
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             // Tile kt + 2 goes into the buffer of tile kt - 1 (last read in phase 2 kt - 1) and is first read in phase 2 kt + 4:
             // every wave issues its pieces after the fragment reads of its own load phase and waits for them at the end of its NEXT
             // load phase with the pieces of tile kt + 3 in flight (counted vmcnt) — two full phases between issue and wait.  (Issuing
-            // group 0's pieces between the MFMAs of its compute phase instead measured the same: profiles/r03_gemm_f16x2_ablation.txt.)
+            // group 0's pieces between the MFMAs of its compute phase instead measured the same: profiles/history/r03_gemm_f16x2_ablation.txt.)
             Frags f1;
             stage(0, 0);
             if (nk > 1) stage(1, X3_KT);
@@ -862,7 +862,7 @@ static bool x3_norm_fusable(const vn_ctx* ctx, const vn_gemm_args& a) {
 static bool x3_fold_out(const vn_gemm_args& a) { return a.X16 != nullptr; }
 
 // Tile height and k-split of a launch, by a cost model in microseconds calibrated on the model's shapes (scripts/gemm_x3_plan_sweep.py,
-// profiles/r02_gemm_x3_plan_sweep.txt): a launch runs ceil(tiles ns / CUs) rounds of K / ns k-tiles; a k-tile of a 128-row tile
+// profiles/history/r02_gemm_x3_plan_sweep.txt): a launch runs ceil(tiles ns / CUs) rounds of K / ns k-tiles; a k-tile of a 128-row tile
 // costs 1.45 us when every CU is busy, taller tiles proportionally more minus what their smaller operand traffic per flop gives
 // back (192 rows: -17 % DMA bytes per flop, 256 rows: -25 %); a split launch adds its reduce pass over (ns + 1 or 2) images of C
 // at ~3.5 TB/s, minus the RMSNorm read it absorbs when the norm is fused into that pass.  The 192-row tile is what fills whole
@@ -914,7 +914,7 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
     // algorithmic (fp32-equivalent) flops; the codec's convolutions are booked under class 2 like conv1d_f32.hip's
     const int pi = vn_prof_pre(ctx, EPI == VN_EPI_CONV ? 2 : 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);
     int rc = VN_OK;
-    // f16x2: half the matrix work per k-tile (profiles/r03_gemm_f16x2_plan_sweep.txt)
+    // f16x2: half the matrix work per k-tile (profiles/history/r03_gemm_f16x2_plan_sweep.txt)
     const x3_plan plan = FMT ? x3_choose<EPI>(ctx, a, vn_num_cus(ctx), 0.85, 0.8) : x3_choose<EPI>(ctx, a, vn_num_cus(ctx));
     const int bm = plan.bm;
     bool done = false;
