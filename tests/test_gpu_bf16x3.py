@@ -223,13 +223,21 @@ def test_folded_norm_matches_unfolded_and_oracle(precision):
         eng_u = Engine("cuda:0")
     finally:
         del os.environ["VN_FOLD_NORM"]
+    os.environ["VN_FOLD_X16ONLY"] = "0"
+    try:
+        eng_x = Engine("cuda:0")          # folded, but the residual stream also kept as an fp32 image (what f16x2 always does)
+    finally:
+        del os.environ["VN_FOLD_X16ONLY"]
     mf = VampNetModel(eng_f, sd, cb, max_batch=4, max_T=575, precision=precision, **model_kwargs(dims))
     mu = VampNetModel(eng_u, sd, cb, max_batch=4, max_T=575, precision=precision, **model_kwargs(dims))
+    mx = VampNetModel(eng_x, sd, cb, max_batch=4, max_T=575, precision=precision, **model_kwargs(dims))
     for B, T in ((4, 575), (1, 575), (2, 37), (1, 1)):
         codes = W.synth_codes(B, 4, T, seed=12)
         codes[:, :, ::3] = 1024
         ref = TM.to_native(O.forward(sd, dims, O.from_codes(sd, cb, codes)), 4)
         a, b = mf.forward_codes(codes, layout="native").cpu(), mu.forward_codes(codes, layout="native").cpu()
+        # bf16x3 planes sum to the fp32 value exactly: keeping the residual stream in the planes alone changes no bit
+        assert torch.equal(mx.forward_codes(codes, layout="native").cpu(), a)
         print(f"[{precision}] B={B} T={T}: folded vs oracle {(a - ref).abs().max():.3e}, unfolded vs oracle {(b - ref).abs().max():.3e}, "
               f"folded vs unfolded {(a - b).abs().max():.3e}")
         assert (a - ref).abs().max().item() <= TM.LOGIT_ATOL_TINY and (b - ref).abs().max().item() <= TM.LOGIT_ATOL_TINY

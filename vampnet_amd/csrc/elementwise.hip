@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void vn_splitk_reduce_rmsnorm_kernel(const flo
 // embedding's rows as they are).  Writes x16 = the split planes of the (raw, un-normalised) row and ssq[t][row] (t < D / 128) = the sums of
 // squares of its 128-column groups — what the residual epilogue of gemm_x3.hip writes for rows it produces itself.  One wave per row; lane l
 // holds columns 4 (l + 64 i) .. + 3, i.e. group 2 i + (l >> 5), position l & 31 inside it.
-template <int VEC>
+// FROM_PLANES (tiled bf16x3 planes, exact): the old row is read from x16 itself and x is neither read nor written (vn_gemm_args::x16_only)
+template <int VEC, bool FROM_PLANES = false>
 __global__ __launch_bounds__(256) void vn_rowprep_kernel(const float* __restrict__ partial, int nsplit, float* __restrict__ x,
                                                          uint16_t* __restrict__ x16, long plane16, float* __restrict__ ssq, int rows, int D,
                                                          unsigned* sat) {
@@ -129,7 +130,10 @@ __global__ __launch_bounds__(256) void vn_rowprep_kernel(const float* __restrict
     f32x4* xr = (f32x4*)(x + (size_t)row * D);
     f32x4 v[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) v[i] = xr[lane + 64 * i];
+    for (int i = 0; i < VEC; ++i) {
+        if constexpr (FROM_PLANES) v[i] = vn_load_planes4_bf16x3_tiled(x16, row, 4 * (lane + 64 * i), D);
+        else v[i] = xr[lane + 64 * i];
+    }
     if (nsplit > 0) {
         f32x4 part[4][VEC];
         // every load of the row in flight before the first add (as in vn_splitk_reduce_rmsnorm_kernel); order: split 0, 1, .., residual
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256) void vn_rowprep_kernel(const float* __restrict
                 a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
             }
             a[0] += v[i][0]; a[1] += v[i][1]; a[2] += v[i][2]; a[3] += v[i][3];
-            xr[lane + 64 * i] = a;
+            if constexpr (!FROM_PLANES) xr[lane + 64 * i] = a;
             v[i] = a;
         }
     }
@@ -165,12 +169,15 @@ __global__ __launch_bounds__(256) void vn_rowprep_kernel(const float* __restrict
 }
 
 int vn_launch_rowprep(vn_ctx* ctx, const float* partial, int nsplit, float* x, uint16_t* x16, long plane16, float* ssq, int rows, int D,
-                      hipStream_t s) {
+                      hipStream_t s, int from_planes) {
     if (rows <= 0) return VN_OK;
-    if (!x || !x16 || !ssq || !vn_planes_tiled(plane16) || (nsplit > 0 && !partial))
-        return vn_fail(ctx, VN_ERR_INVALID, "rowprep: needs x, tiled planes and the ssq buffer%s", "");
+    if ((!x && !from_planes) || !x16 || !ssq || !vn_planes_tiled(plane16) || (nsplit > 0 && !partial) ||
+        (from_planes && (plane16 != VN_PLANES_TILED || nsplit <= 0)))
+        return vn_fail(ctx, VN_ERR_INVALID, "rowprep: needs x (or exact planes to read it from), tiled planes and the ssq buffer%s", "");
     const dim3 grid(vn_cdiv(rows, 4)), block(256);
-    if (D == 1280) hipLaunchKernelGGL(vn_rowprep_kernel<5>, grid, block, 0, s, partial, nsplit, x, x16, plane16, ssq, rows, D, ctx->sat);
+    if (D == 1280 && from_planes) hipLaunchKernelGGL((vn_rowprep_kernel<5, true>), grid, block, 0, s, partial, nsplit, x, x16, plane16, ssq, rows, D, ctx->sat);
+    else if (D == 256 && from_planes) hipLaunchKernelGGL((vn_rowprep_kernel<1, true>), grid, block, 0, s, partial, nsplit, x, x16, plane16, ssq, rows, D, ctx->sat);
+    else if (D == 1280) hipLaunchKernelGGL(vn_rowprep_kernel<5>, grid, block, 0, s, partial, nsplit, x, x16, plane16, ssq, rows, D, ctx->sat);
     else if (D == 256) hipLaunchKernelGGL(vn_rowprep_kernel<1>, grid, block, 0, s, partial, nsplit, x, x16, plane16, ssq, rows, D, ctx->sat);
     else return vn_fail(ctx, VN_ERR_UNSUPPORTED, "rowprep: D=%s%ld must be 256 or 1280", "", D);
     VN_LAUNCH_CHECK(ctx);

@@ -113,6 +113,7 @@ void vn_tune_init(vn_tune* t) {
     t->w_tiled = env_int("VN_X3_WTILED", 1) != 0;
     // RMSNorms folded into their consumer GEMMs (split-plane precisions); needs the tiled operand layouts and the staged epilogues
     t->fold_norm = env_int("VN_FOLD_NORM", 1) != 0 && t->a_tiled && t->w_tiled && t->x3_staged;
+    t->fold_x16_only = env_int("VN_FOLD_X16ONLY", 1) != 0;
     t->epoch = 0;
 }
 
@@ -329,7 +330,9 @@ static int forward_folded(vn_model* m, int B, int T, float* logits, hipStream_t 
         return a;
     };
     auto consumer = [&](vn_gemm_args& a) { a.ssq_in = m->ssq; a.fold_eps = m->d.eps; };
-    auto producer = [&](vn_gemm_args& a) { a.C = m->x; a.X16 = m->x16; a.x16_plane = ap; a.ssq_out = m->ssq; };
+    // bf16x3: the planes are exact, so from the first layer on the residual stream lives in x16 alone (m->x is the embedding's output only)
+    const int x16_only = !h2 && ctx->tune.fold_x16_only;
+    auto producer = [&](vn_gemm_args& a) { a.C = m->x; a.X16 = m->x16; a.x16_plane = ap; a.ssq_out = m->ssq; a.x16_only = x16_only; };
     int rc;
     if ((rc = vn_launch_rowprep(ctx, nullptr, 0, m->x, m->x16, ap, m->ssq, M, D, s))) return rc;     // the embedding's rows
     for (int l = 0; l < m->L; ++l) {

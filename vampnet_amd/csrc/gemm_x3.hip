@@ -383,12 +383,20 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
                 const int row = m0 + (R >> 5) * 32 * RI + 32 * i + (R & 31), col = n0 + c8;
                 f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (row < p.M) {
-                    float* c = p.C + (size_t)row * p.ldc + col;
-                    const f32x4 a0 = *(const f32x4*)(lds + R * 128 + c8) + *(const f32x4*)c;
-                    const f32x4 a1 = *(const f32x4*)(lds + R * 128 + c8 + 4) + *(const f32x4*)(c + 4);
-                    *(f32x4*)c = a0;
-                    *(f32x4*)(c + 4) = a1;
-                    v = f32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    const f32x4 l0 = *(const f32x4*)(lds + R * 128 + c8), l1 = *(const f32x4*)(lds + R * 128 + c8 + 4);
+                    const f32x8 acc8 = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                    if (!FMT && p.x16_only) {
+                        // bf16x3: the planes ARE the residual stream (their sum is the fp32 value exactly): read the old row from them,
+                        // write the new one to them — 6 + 6 bytes per element instead of 4 + 4 + 6, and no fp32 image of x at all
+                        v = acc8 + vn_load_planes8_bf16x3_tiled(p.X16, row, col, p.N);
+                    } else {
+                        float* c = p.C + (size_t)row * p.ldc + col;
+                        const f32x4 a0 = l0 + *(const f32x4*)c;
+                        const f32x4 a1 = l1 + *(const f32x4*)(c + 4);
+                        *(f32x4*)c = a0;
+                        *(f32x4*)(c + 4) = a1;
+                        v = f32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    }
                     vn_store_planes8_tiled(p.X16, p.x16_plane, row, col, p.N, v, bad);
                 }
                 const float s2 = vn_sum16(vn_ssq4(f32x4{v[4], v[5], v[6], v[7]}, vn_ssq4(f32x4{v[0], v[1], v[2], v[3]})));
@@ -947,7 +955,7 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
             rc = x3_go_bm<VN_EPI_STORE, FMT>(ctx, q, ns, bm, s);
             if (EPI == VN_EPI_RESIDUAL && x3_fold_out(a)) {
                 // folded norm: reduce + the planes and group sums of the new residual rows in one pass (part of THIS GEMM's work)
-                if (rc == VN_OK) rc = vn_launch_rowprep(ctx, ctx->x3_ws, ns, a.C, a.X16, a.x16_plane, a.ssq_out, a.M, a.N, s);
+                if (rc == VN_OK) rc = vn_launch_rowprep(ctx, ctx->x3_ws, ns, a.C, a.X16, a.x16_plane, a.ssq_out, a.M, a.N, s, !FMT && a.x16_only);
             } else
             // while launches are being event-bracketed (pi >= 0) the two-kernel form runs, so that the GEMM's bracket holds the GEMM's
             // own work (split images + reduce) and nothing of the norm — the bitwise same result (tests/test_gpu_kernels.py)
@@ -1001,6 +1009,7 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
     if ((a.ssq_out || a.X16) && (epilogue != VN_EPI_RESIDUAL || !a.ssq_out || !a.X16 || (a.N & 127) || a.ldc != a.N ||
                                  a.x16_plane != (h2 ? VN_PLANES_TILED_H2 : VN_PLANES_TILED)))
         return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: folded-norm outputs need the RESIDUAL epilogue, N %% 128 == 0, ldc == N, tiled planes + ssq%s", "");
+    if (a.x16_only && (h2 || !a.X16)) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: x16_only needs exact (bf16x3) planes%s", "");
     if (a.ssq_in && ((a.K & 127) || a.K > 2048)) return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3: folded-norm input needs K %% 128 == 0 and K <= 2048%s", "");
     if (!(ctx->attr_mask & VN_ATTR_GEMM_X3)) {
         int rc;

@@ -175,6 +175,27 @@ __device__ __forceinline__ void vn_store_planes4(uint16_t* base, long plane, lon
 #define VN_DHEAD 64
 
 #ifdef __HIPCC__
+// the fp32 values of eight / four consecutive columns of a row from its TILED bf16x3 planes: p0 + p1 + p2, exact (vn_split3)
+__device__ __forceinline__ f32x8 vn_load_planes8_bf16x3_tiled(const uint16_t* base, long row, int col, int ld) {
+    const uint16_t* d = base + vn_tiled_off(row, col, ld);
+    const f32x8 a = vn_bf16x8_widen(__builtin_bit_cast(bf16x8, *(const u32x4*)d));
+    const f32x8 b = vn_bf16x8_widen(__builtin_bit_cast(bf16x8, *(const u32x4*)(d + 512)));
+    const f32x8 c = vn_bf16x8_widen(__builtin_bit_cast(bf16x8, *(const u32x4*)(d + 1024)));
+    return (a + b) + c;
+}
+__device__ __forceinline__ f32x4 vn_load_planes4_bf16x3_tiled(const uint16_t* base, long row, int col, int ld) {
+    const uint16_t* d = base + vn_tiled_off(row, col, ld);
+    f32x4 v;
+    const uint2 a = *(const uint2*)d, b = *(const uint2*)(d + 512), c = *(const uint2*)(d + 1024);
+    const unsigned aw[2] = {a.x, a.y}, bw[2] = {b.x, b.y}, cw[2] = {c.x, c.y};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        v[2 * i] = (__builtin_bit_cast(float, aw[i] << 16) + __builtin_bit_cast(float, bw[i] << 16)) + __builtin_bit_cast(float, cw[i] << 16);
+        v[2 * i + 1] = (__builtin_bit_cast(float, aw[i] & 0xffff0000u) + __builtin_bit_cast(float, bw[i] & 0xffff0000u)) +
+                       __builtin_bit_cast(float, cw[i] & 0xffff0000u);
+    }
+    return v;
+}
 // eight consecutive columns col .. col + 7 (col % 8 == 0) of row `row` -> one 16-byte store per plane, TILED layouts only (the eight
 // columns sit in one 32-column block of the piece)
 __device__ __forceinline__ void vn_store_planes8_tiled(uint16_t* base, long plane, long row, int col, int ld, const f32x8& o, bool& bad) {
@@ -353,6 +374,7 @@ struct vn_tune {
     // engine.hip: bf16x3 models take the split-plane attention path (-1 by shape / LDS fit, 0 never, 1 always); operand plane layouts
     int attn_x3, a_tiled, w_tiled;
     int fold_norm;           // engine.hip: split-plane models fold the RMSNorms into their consumer GEMMs (VN_FOLD_NORM, default 1)
+    int fold_x16_only;       // ... and bf16x3 models keep the residual stream in its (exact) planes only (VN_FOLD_X16ONLY, default 1)
     unsigned epoch;
 };
 void vn_tune_init(vn_tune* t);
@@ -463,6 +485,8 @@ struct vn_gemm_args {
     //   fold_eps) before anything else (K = the consumer's K = the residual width; K / 128 groups).
     uint16_t* X16;
     long x16_plane;
+    int x16_only;        // producers, bf16x3 planes only (their sum IS the fp32 value): the residual stream lives in X16 alone — the old
+                         // row is read back from its planes (p0 + p1 + p2, exact) and C is neither read nor written
     float* ssq_out;
     const float* ssq_in;
     float fold_eps;
@@ -493,8 +517,9 @@ int vn_launch_splitk_reduce(vn_ctx* ctx, const float* partial, int nsplit, float
 
 // folded-norm producers (elementwise.hip): x[rows][D] += sum of the nsplit images (nsplit = 0: x as it is, nothing written back), then
 // x16 = the split planes of the rows (plane16: tiled bf16x3 / f16x2) and ssq[t][row] (t < D / 128) = sums of squares per 128-column group
+// from_planes != 0 (tiled bf16x3 planes only): the old rows are read from x16 itself (exact) and x is not touched
 int vn_launch_rowprep(vn_ctx* ctx, const float* partial, int nsplit, float* x, uint16_t* x16, long plane16, float* ssq, int rows, int D,
-                      hipStream_t s);
+                      hipStream_t s, int from_planes = 0);
 // x[rows][D] += sum of the nsplit images partial[s][rows][D] (fixed order), then y = RMSNorm(x) from the same registers (elementwise.hip)
 int vn_launch_splitk_reduce_rmsnorm(vn_ctx* ctx, const float* partial, int nsplit, float* x, const float* w, float* y, uint16_t* y16,
                                     long plane16, int rows, int D, float eps, hipStream_t s);
