@@ -1,0 +1,100 @@
+// Micro-benchmark (tuning evidence, not product code): what limits v_mfma_f32_32x32x16_bf16 throughput on a full MI355X when NOTHING
+// but the matrix pipe works — no global / LDS traffic at all?  The split-plane GEMM stops at ~1.1-1.3 PF executed with the pipe ~50 %
+// busy (profiles/r04_model_clock.txt); the round-2/3 notes call that "the power limit" on the strength of clock readings.  This probe
+// separates the candidates: every wave holds NSETS operand register sets and walks them in a loop of MFMAs into four accumulators
+//   mode 0  ONE operand set whose values are a smooth ramp (what scripts/ubench/mfma_valu_coissue.hip measured: 2.32 PF)
+//   mode 1  ONE operand set of RANDOM bf16 bit patterns (exponents confined to 2^-4 .. 2^4)
+//   mode 2  EIGHT random operand sets used round-robin: consecutive MFMAs read different registers (operand buses toggle)
+//   mode 3  mode 2 + a raw s_barrier after every 12 MFMAs (the ping-pong GEMM's phase length), 8 waves per block
+// Each mode runs ~0.3 s (DVFS settles in milliseconds); prints executed TF and the shader clock from s_memtime / wall time.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned rnd(unsigned& s) { s = s * 1664525u + 1013904223u; return s; }
+__device__ __forceinline__ bf16x8 random_set(unsigned& s) {
+    u32x4 w;
+    for (int i = 0; i < 4; ++i) {
+        unsigned lo = rnd(s) >> 16, hi = rnd(s) >> 16;
+        // sign | exponent 123..131 (2^-4 .. 2^4) | 7 random mantissa bits
+        lo = (lo & 0x807fu) | ((123u + (lo >> 7) % 9u) << 7);
+        hi = (hi & 0x807fu) | ((123u + (hi >> 7) % 9u) << 7);
+        w[i] = lo | (hi << 16);
+    }
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, int iters) {
+    constexpr int NS = MODE >= 2 ? 8 : 1;
+    f32x16 acc[4] = {};
+    bf16x8 a[NS], b[NS];
+    unsigned s = 12345u + threadIdx.x * 977u + blockIdx.x * 131071u;
+    for (int q = 0; q < NS; ++q) {
+        if (MODE == 0) {
+            for (int i = 0; i < 8; ++i) { a[q][i] = (__bf16)(threadIdx.x * 0.001f + i); b[q][i] = (__bf16)(1.0f + i * 0.01f); }
+        } else {
+            a[q] = random_set(s);
+            b[q] = random_set(s);
+        }
+    }
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+            acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % NS], b[(u / 2) % NS], acc[u & 3], 0, 0, 0);
+            if (MODE == 3 && (u % 12) == 11) __builtin_amdgcn_s_barrier();
+        }
+        // keep the accumulators bounded without touching the operand registers: scale by 2^-k every so often (4 VALU per 24 MFMA x 16... rare)
+        if ((it & 63) == 63) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] *= 1.0e-6f;
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float r = 0.f;
+    for (int q = 0; q < 4; ++q) for (int i = 0; i < 16; ++i) r += acc[q][i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+}
+
+template <int MODE>
+static void run(const char* what, int blocks) {
+    float* out; unsigned long long* cyc;
+    hipMalloc(&out, (size_t)blocks * 512 * 4); hipMalloc(&cyc, 8);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    int iters = 2000;
+    hipLaunchKernelGGL((k<MODE>), dim3(blocks), dim3(512), 0, 0, out, cyc, iters);        // warm-up / calibration
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((k<MODE>), dim3(blocks), dim3(512), 0, 0, out, cyc, iters);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    iters = (int)(iters * 300.0f / ms);                                                   // ~0.3 s
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((k<MODE>), dim3(blocks), dim3(512), 0, 0, out, cyc, iters);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+    const double nm = iters * 24.0, waves = blocks * 8.0;
+    printf("mode %d  %-66s %6.1f ms  %7.0f TF executed  %5.1f ticks per MFMA per wave  %.3f GHz (s_memtime ticks / wall)\n", MODE, what, ms,
+           waves * nm * 32768.0 / (ms * 1e-3) / 1e12, (double)c / nm, (double)c / (ms * 1e6));
+    hipFree(out); hipFree(cyc);
+}
+int main() {
+    for (int blocks = 256; blocks <= 512; blocks += 256) {
+        printf("-- %d blocks of 8 waves (%d waves per SIMD)\n", blocks, blocks / 128);
+        run<0>("one smooth operand set", blocks);
+        run<1>("one RANDOM operand set", blocks);
+        run<2>("eight random operand sets, round-robin", blocks);
+        run<3>("eight random sets + s_barrier every 12 MFMAs", blocks);
+    }
+    return 0;
+}
