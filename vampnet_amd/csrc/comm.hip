@@ -67,7 +67,8 @@ extern "C" int vn_comm_unique_id(vn_ctx* ctx, uint8_t* id128) {
     const int st = api.GetUniqueId(&id);
     if (st != 0) rc = rccl_fail(ctx, api, "ncclGetUniqueId", st);
     else memcpy(id128, id.internal, 128);
-    dlclose(api.handle);                                   // reference-counted: a later vn_comm_create binds the same copy again
+    // the handle is deliberately NOT closed: ncclGetUniqueId starts RCCL's bootstrap thread, which must not lose its code; the loader
+    // reference-counts, so vn_comm_create binds the same copy again
     return rc;
 }
 
