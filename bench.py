@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 TOKENS_PER_CLIP = 14 * 575
 PEAK_F32_MFMA_TF = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
 PEAK_BF16_MFMA_TF = 2500.0         # dense bf16 MFMA (32x32x16)
+MEASURED_PIPE_LIMIT_TF = 1650.0    # what the matrix pipe sustains on random operand bits with NO data movement (profiles/r04_mfma_power_probe.txt)
 
 
 def _host_facts():
@@ -511,7 +512,13 @@ def main():
                         "achieved_over_bf16x3_ceiling": fl / (ms * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TF / 6.0) if ms else None,
                         # context: the same algorithmic rate against the fp32-input MFMA peak (157.3 TF), the
                         # ceiling of the exact-fp32 kernel this precision replaces
-                        "achieved_over_f32_mfma_peak": fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF if ms else None}
+                        "achieved_over_f32_mfma_peak": fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF if ms else None,
+                        # context, NOT `frac`: a pure matrix-pipe loop with no data movement sustains 1.62-1.68 PF on random operand bits
+                        # on this part (the firmware holds the socket at ~1.3 kW by lowering the clock; 2.42 PF on a smooth operand ramp) —
+                        # a committed measurement (profiles/r04_mfma_power_probe.txt), not a quantity of this run
+                        "executed_over_measured_pipe_limit": (nprod * fl / (ms * 1e-3) / 1e12) / MEASURED_PIPE_LIMIT_TF if ms else None,
+                        "measured_pipe_limit": {"tflops": MEASURED_PIPE_LIMIT_TF, "source": "profiles/r04_mfma_power_probe.txt: v_mfma_f32_32x32x16_bf16 on "
+                                                "register-resident RANDOM operands, no global / LDS traffic, 1.62-1.75 GHz at 1.28-1.30 kW"}}
                        if nprod else {}),
                     "event_stride": args.event_stride,        # launches / times above: the bracketed sample
                     "gemm_time_frac": args.event_stride * ms / (1e3 * elapsed) if elapsed else None,
