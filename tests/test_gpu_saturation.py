@@ -70,7 +70,7 @@ def test_ledger_gemm_epilogue_and_norm(eng):
         del os.environ["VN_F16X2_PROBE"]
     assert m.precision == "f16x2"
     codes = W.synth_codes(1, dims["n_codebooks"], 48, seed=5)
-    m.precision = "f32"                      # (host label only: skip forward_codes' own ledger handling, the engine stays on f16x2)
+    m._ledger_off = True                     # skip forward_codes' own ledger handling: the test reads the words itself
     eng.saturation(clear=True)
     m.forward_codes(codes)
     assert eng.saturation(clear=True) == (0, 0, 0, 0)
@@ -82,7 +82,7 @@ def test_ledger_gemm_epilogue_and_norm(eng):
         m2 = VampNetModel(eng, sd2, cb, max_batch=1, max_T=64, precision="f16x2", **model_kwargs(dims))
     finally:
         del os.environ["VN_F16X2_PROBE"]
-    m2.precision = "f32"
+    m2._ledger_off = True
     eng.saturation(clear=True)
     m2.forward_codes(codes)
     assert eng.saturation(clear=True)[0] == 1

@@ -443,6 +443,7 @@ class DacCodec:
         return tiled
 
     # ---- launches: issued now (eager) or recorded into a program (the same code path builds both) ------------------------------
+    MAX_PROGRAMS = 8         # cached (direction, batch, length, precision) programs; the oldest goes first
     _OP_KIND = {"vn_conv1d_f32": 0, "vn_conv1d_bf16x3": 1, "vn_conv1d_f16x2": 2, "vn_dac_conv_in_f32": 3, "vn_dac_conv_out_f32": 4,
                 "vn_rvq_encode_f32": 5, "vn_rvq_decode_f32": 6, "vn_split3_f32": 7, "vn_split2_f16": 8}      # VN_CODEC_OP_*
 
@@ -512,6 +513,9 @@ class DacCodec:
         self.engine.check(self.lib.vn_codec_create(self.engine.handle, ops, len(rec.ops), direction, C.byref(h)), "vn_codec_create")
         prog = dict(handle=h, arena=arena, n_ops=len(rec.ops), arena_bytes=total,
                     z=(off[z.bid], z.shape) if z is not None else None)
+        while len(self._programs) >= self.MAX_PROGRAMS:       # every program owns an arena: keep the most recent shapes only
+            old = self._programs.pop(next(iter(self._programs)))
+            self.lib.vn_codec_destroy(old["handle"])
         self._programs[key] = prog
         return prog
 

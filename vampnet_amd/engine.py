@@ -381,8 +381,11 @@ class VampNetModel:
         g = torch.Generator().manual_seed(0)
         codes = torch.randint(0, self.vocab_size, (1, self.n_codebooks, T), generator=g)
         codes[:, self.n_conditioning_codebooks:, ::2] = self.vocab_size                 # MASK tokens, as inside generate()
-        self.precision = "f32"                                                          # (no ledger handling inside the probe itself)
-        logits = self.forward_codes(codes, layout="native")
+        self._ledger_off = True                                                         # the probe reads the ledger itself
+        try:
+            logits = self.forward_codes(codes, layout="native")
+        finally:
+            self._ledger_off = False
         sat = self.engine.saturation(clear=True)
         if any(sat):
             return f"a probe forward left fp16's range (saturation ledger: operands {sat[0]}, attention {sat[1]})"
@@ -412,7 +415,7 @@ class VampNetModel:
         logits = torch.empty(B, T, self.n_predict_codebooks, self.vocab_size, device=self.device, dtype=torch.float32)
         self.engine.check(self.lib.vn_forward(self.handle, codes.data_ptr(), B, T, logits.data_ptr(),
                                               self.engine.stream()), "vn_forward")
-        if self.precision == "f16x2":
+        if self.precision == "f16x2" and not getattr(self, "_ledger_off", False):
             sat = self.engine.saturation(clear=True)
             if any(sat):                    # a clamped value never reaches the caller: repeat the forward on bf16x3
                 self._fall_back(f"a forward left fp16's range (saturation ledger: operands {sat[0]}, attention {sat[1]})")
