@@ -6,7 +6,7 @@ from ._lib import VnError, LIB_PATH  # noqa: F401
 
 
 def __getattr__(name):
-    if name in ("Engine", "VampNetModel"):
+    if name in ("Engine", "VampNetModel", "DEFAULT_PRECISION", "PrecisionFallbackWarning"):
         from . import engine
         return getattr(engine, name)
     if name == "Interface":
