@@ -870,3 +870,53 @@ def test_codec_program_arena_planner():
                     assert not (overlap_time and overlap_mem), (trial, a, b)
         assert total < sum(-(-rec.bufs[i]["nbytes"] // 256) * 256 for i in used)
         assert span(pinned.bid)[1] == n_ops
+
+
+def test_f16x2_generate_wrapper_repeats_a_saturated_call_from_the_same_generator_state():
+    """VampNetModel.generate in precision "f16x2" (host logic, no GPU): the saturation ledger is read after the call; if a word is
+    set the result is discarded, the model moves to bf16x3 with a PrecisionFallbackWarning, torch's generator is put back where the
+    call started and the call is repeated with the same arguments; a clean ledger returns the first result untouched."""
+    import warnings
+    import torch
+    from vampnet_amd.engine import PrecisionFallbackWarning, VampNetModel
+
+    class _Eng:
+        def __init__(self, flags):
+            self.flags = list(flags)
+
+        def saturation(self, clear=True):
+            return self.flags.pop(0) if self.flags else (0, 0, 0, 0)
+
+    class _Model(VampNetModel):
+        def __init__(self, flags):                       # no device: only what the wrapper touches
+            self.engine, self.precision, self.calls = _Eng(flags), "f16x2", []
+
+        def set_precision(self, precision):
+            self.precision = precision
+
+        def _generate(self, **kw):
+            draw = float(torch.rand(1))                  # what a seed-less call would draw its noise / device seed from
+            self.calls.append((self.precision, draw, kw["_sampling_steps"], kw["temperature"]))
+            return (self.precision, draw)
+
+    torch.manual_seed(123)
+    want = float(torch.rand(1))
+    after_one_call = torch.get_rng_state()
+    # saturated: repeated on bf16x3 from the same generator state, generator left where ONE call leaves it
+    m = _Model([(0, 1, 0, 0)])
+    torch.manual_seed(123)
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        out = m.generate(_sampling_steps=5, temperature=0.7)
+    assert [w.category for w in wl] == [PrecisionFallbackWarning] and "attention 1" in str(wl[0].message)
+    assert out == ("bf16x3", want) and m.precision == "bf16x3"
+    assert m.calls == [("f16x2", want, 5, 0.7), ("bf16x3", want, 5, 0.7)]
+    assert torch.equal(torch.get_rng_state(), after_one_call)
+    assert m.generate(_sampling_steps=2, temperature=1.0)[0] == "bf16x3" and len(m.calls) == 3      # stays there, no ledger read
+    # clean ledger: one call, no warning, precision kept
+    m = _Model([(0, 0, 0, 0)])
+    torch.manual_seed(123)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        out = m.generate(_sampling_steps=5, temperature=0.7)
+    assert out == ("f16x2", want) and m.precision == "f16x2" and len(m.calls) == 1
