@@ -421,16 +421,17 @@ def test_split3_is_exact(eng):
     assert torch.equal(p[0], x.to(torch.bfloat16).float())          # plane 0 = RNE bf16 of x (== torch's cast)
 
 
-X3_CONFIGS = [128, 192, 256, 0]
+X3_CONFIGS = [128, 192, 256, 96, 0]
 
 
 def _x3_cfg(eng, bm=0, split=-1, abl=-1):
     eng.check(eng.lib.vn_debug_x3_config(eng.handle, bm, split, abl), "vn_debug_x3_config")
 
 
-@pytest.fixture(params=X3_CONFIGS, ids=["bm128", "bm192", "bm256", "auto"])
+@pytest.fixture(params=X3_CONFIGS, ids=["bm128", "bm192", "bm256", "bm96", "auto"])
 def x3_pipe(eng, request):
-    """the three tile heights of gemm_x3.hip (and the by-shape default) through the same bodies (tuning hook of the test's context; reset afterwards)"""
+    """the tile heights of gemm_x3.hip — 128 / 192 / 256 rows and the 96-row k-split tile (bf16x3 operands; the f16x2 entries fall back
+    to 128 rows) — and the by-shape default through the same bodies (tuning hook of the test's context; reset afterwards)"""
     _x3_cfg(eng, request.param)
     yield request.param
     _x3_cfg(eng)
@@ -462,15 +463,17 @@ def test_gemm_bf16x3_fp32_grade(eng, x3_pipe, M, N, K):
 
 
 def test_gemm_bf16x3_tiles_agree_bitwise_and_are_race_free(eng):
-    """All tile heights add the same products in the same order: bitwise-equal outputs, through the direct and the LDS-staged
-    epilogue alike; 20 back-to-back launches of each under a concurrently streaming kernel reproduce the same bits (LDS-DMA /
-    barrier protocol of the ping-pong schedule, LDS image of the staged epilogue)."""
+    """The 128 / 192 / 256-row tiles add the same products in the same order: bitwise-equal outputs, through the direct and the
+    LDS-staged epilogue alike; 20 back-to-back launches of each under a concurrently streaming kernel reproduce the same bits (LDS-DMA /
+    barrier protocol of the ping-pong schedule, LDS image of the staged epilogue).  The 96-row tile splits the k-steps of a k-tile
+    between its two wave groups (two partial sums per element, added in the epilogue): reproducible bit for bit too, and within the
+    fp32 re-association noise of the others."""
     M, N, K = 4600, 3840, 1280
     a3, w3 = eng.split3(_rand((M, K), 13).cuda()), eng.split3((_rand((N, K), 14) / np.sqrt(K)).cuda())
     outs = {}
     junk = torch.empty(64 << 20, device="cuda")
     side = torch.cuda.Stream()
-    for bm in (128, 192, 256):
+    for bm in (128, 192, 256, 96):
         _x3_cfg(eng, bm, 1)
         outs[bm] = eng.gemm_bf16x3(a3, w3).clone()
         for it in range(20):
@@ -481,8 +484,17 @@ def test_gemm_bf16x3_tiles_agree_bitwise_and_are_race_free(eng):
     _x3_cfg(eng)
     torch.cuda.synchronize()
     assert torch.equal(outs[128], outs[256]) and torch.equal(outs[128], outs[192])
+    d96 = (outs[96] - outs[128]).abs().max().item()
+    print(f"96-row k-split tile vs 128 rows: max |d| = {d96:.3e}")
+    assert d96 <= 2e-5
     odd = torch.empty(M * N + 1, device="cuda")[1:].view(M, N)       # base 4 bytes off a 16-byte boundary -> the direct epilogue
     eng.gemm_bf16x3(a3, w3, out=odd)
+    assert torch.equal(odd, outs[128])
+    _x3_cfg(eng, 96, 1)                                               # ... where the 96-row tile is not offered: falls back to 128 rows
+    try:
+        eng.gemm_bf16x3(a3, w3, out=odd)
+    finally:
+        _x3_cfg(eng)
     assert torch.equal(odd, outs[128])
 
 
@@ -531,8 +543,8 @@ def test_two_contexts_tune_independently(eng):
     a, w = _rand((M, K), 50).cuda(), (_rand((N, K), 51) / np.sqrt(K)).cuda()
     a3, w3 = eng.split3(a), eng.split3(w)
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-    eng.check(eng.lib.vn_debug_x3_config(eng.handle, 128, -1, -1), "vn_debug_x3_config")
-    eng2.check(eng2.lib.vn_debug_x3_config(eng2.handle, 256, -1, -1), "vn_debug_x3_config")
+    eng.check(eng.lib.vn_debug_x3_config(eng.handle, 128, 1, -1), "vn_debug_x3_config")       # (k-split off: the cost model may split the
+    eng2.check(eng2.lib.vn_debug_x3_config(eng2.handle, 256, 1, -1), "vn_debug_x3_config")     # two heights differently at this shape)
     try:
         torch.cuda.synchronize()
         outs1, outs2 = [], []

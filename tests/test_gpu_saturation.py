@@ -54,6 +54,33 @@ def test_ledger_words(eng):
     assert eng.saturation(clear=True) == (0, 0, 0, 0)
 
 
+def test_codec_on_the_models_engine_leaves_the_models_flags_alone(eng):
+    """The ledger is per context.  A DacCodec built on a model's engine runs INSIDE that model's generate(return_signal=True): whatever
+    the ledger holds when the codec call starts is the model's — the codec must neither take it for its own (a spurious fall-back to
+    bf16x3) nor clear it (the model's check after the call would see zeros and return clamped tokens)."""
+    from oracle import dac_oracle as D
+    from vampnet_amd.codec import DacCodec
+    from vampnet_amd.engine import PrecisionFallbackWarning
+    cfg = D.DAC_TINY_CFG
+    codec = DacCodec(D.synth_dac_state_dict(cfg, 0), cfg, engine=eng, precision="f16x2")
+    assert codec.precision == "f16x2"
+    codes = torch.randint(0, 1024, (2, cfg["n_codebooks"], 24))
+    clean = codec.decode_codes(codes).clone()
+    eng.saturation(clear=True)
+    x = torch.randn(64, 128, device="cuda")
+    x[3, 5] = 7.0e4
+    eng.split2h(x)                                                           # "the model" leaves a flag behind (word 2 here)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", PrecisionFallbackWarning)
+        audio = codec.decode_codes(codes)                                    # the codec's own call: in range
+        enc = codec.encode(torch.zeros(1, 1, 4 * codec.hop_length, device="cuda"))
+    assert codec.precision == "f16x2" and torch.equal(audio, clean)
+    assert enc["codes"].shape[-1] == 4
+    assert eng.saturation(clear=False) == (0, 0, 1, 0)                       # still there for its owner
+    assert eng.saturation(clear=True) == (0, 0, 1, 0)
+    assert eng.saturation(clear=True) == (0, 0, 0, 0)
+
+
 def test_ledger_gemm_epilogue_and_norm(eng):
     """the plane-writing producers of the model path: RMSNorm rows and the GEGLU epilogue (direct and LDS-staged forms)"""
     from vampnet_amd import _lib

@@ -424,6 +424,9 @@ def _zero_worker(rank, world, port, q):
     assert lone, "optimizer_state_dict() without consolidate() has to refuse, not start a collective on one rank"
     tr.consolidate()                                       # the collective, on every rank
     osd = tr.optimizer_state_dict()                        # ... after which any rank may build the dict alone
+    if rank == 0:                                          # ... as often as it likes for this step: the reference writes 'latest',
+        again = tr.optimizer_state_dict()                  # 'Nk' and 'best' from ONE consolidate (train.py:376-378, :408-420)
+        assert all(torch.equal(again["state"][i]["exp_avg"], e["exp_avg"]) for i, e in osd["state"].items())
     lo, hi = tr.shard_range()
     q.put((rank, outs, {k: v.numpy() for k, v in tr.state_dict().items()}, (lo, hi, tr.n_total, tr.shard_len),
            {i: e["exp_avg"].numpy() for i, e in osd["state"].items()}))

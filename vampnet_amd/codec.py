@@ -334,14 +334,21 @@ class DacCodec:
         self._build("bf16x3")
 
     def _guarded(self, fn, what):
-        """run fn(); in precision "f16x2" read the saturation ledger afterwards and, if an activation was clamped, repeat on bf16x3"""
+        """run fn(); in precision "f16x2" read the saturation ledger afterwards and, if an activation was clamped, repeat on bf16x3.
+        The ledger is per context: whatever it holds BEFORE the call belongs to somebody else (an f16x2 model on the same engine whose
+        generate(return_signal=True) decodes through this codec) — it is set aside first and handed back afterwards."""
         if self.precision != "f16x2":
             return fn()
-        out = fn()
-        sat = self.engine.saturation(clear=True)
-        if any(sat):
-            self._fall_back(f"{what} left fp16's range (saturation ledger: operands {sat[0]})")
+        foreign = self.engine.saturation(clear=True)
+        try:
             out = fn()
+            sat = self.engine.saturation(clear=True)
+            if any(sat):
+                self._fall_back(f"{what} left fp16's range (saturation ledger: operands {sat[0]})")
+                out = fn()
+                self.engine.saturation(clear=True)         # (bf16x3 writers do not report; keep the ledger clean of this call)
+        finally:
+            self.engine.saturation_restore(foreign)
         return out
 
     def _build(self, precision):
@@ -602,9 +609,10 @@ class DacCodec:
         prog = self._program(0, B, L)                       # ONE C call: vn_dac_encode walks the recorded layer loop
         codes = torch.empty(B, self.n_codebooks, L // self.hop_length, device=self.device, dtype=torch.int64)
         self.engine.check(self.lib.vn_dac_encode(prog["handle"], x.data_ptr(), codes.data_ptr(), self.engine.stream()), "vn_dac_encode")
+        prog["arena"].record_stream(torch.cuda.current_stream(self.device))   # an evicted program's arena must outlive this stream's kernels
         zo, zshape = prog["z"]
         nz = int(np.prod(zshape)) * 4
-        return {"codes": codes, "z": prog["arena"][zo:zo + nz].view(torch.float32).view(*zshape)}     # z: valid until the next encode
+        return {"codes": codes, "z": prog["arena"][zo:zo + nz].view(torch.float32).view(*zshape).clone()}  # owned (the arena is re-used)
 
     def _encode_layers(self, x, B, L):
         """the encoder's layer loop: x = [B][L] samples -> {"codes", "z"}; issues (or records) one launch per layer"""
@@ -651,6 +659,7 @@ class DacCodec:
         prog = self._program(1, B, T)                       # ONE C call: vn_dac_decode walks the recorded layer loop
         audio = torch.empty(B, 1, T * self.hop_length, device=self.device, dtype=torch.float32)
         self.engine.check(self.lib.vn_dac_decode(prog["handle"], codes.data_ptr(), audio.data_ptr(), self.engine.stream()), "vn_dac_decode")
+        prog["arena"].record_stream(torch.cuda.current_stream(self.device))
         return audio
 
     def _decode_layers(self, codes, B, n, T):

@@ -104,6 +104,7 @@ void vn_tune_init(vn_tune* t) {
     t->x3_fuse_norm = env_int("VN_X3_FUSE_NORM", 1) != 0;
     t->x3_staged = env_int("VN_X3_STAGED", 1) != 0;
     t->x3_group_m = env_int("VN_X3_GROUPM", 0);
+    t->x3_tile96 = env_int("VN_X3_TILE96", 1) != 0;
     t->ax_split = env_int("VN_ATTN_X3_SPLIT", -1);
     t->ax_lds = 0;
     t->ax_stagger = env_int("VN_ATTN_X3_STAGGER", 0);
@@ -376,7 +377,17 @@ static int forward_i32(vn_model* m, const int32_t* z, int B, int T, float* logit
     if ((rc = vn_launch_embed(ctx, z, W(m, VN_W_EMB_TABLES), W(m, VN_W_EMB_WT), W(m, VN_W_EMB_B), m->x, B,
                               m->d.n_codebooks, T, m->d.vocab + 1, m->d.latent_dim, D, s)))
         return rc;
-    if (m->folded && m->blob16 && m->w_plane != 0 && m->x16 && m->ssq) return forward_folded(m, B, T, logits, s);
+    if (m->folded && m->blob16 && m->w_plane != 0 && m->x16 && m->ssq) {
+        // the folded classifier writes its logits through the LDS-staged epilogue (16-byte stores): a caller's buffer that is not
+        // 16-byte aligned gets them through the model's own logits buffer instead of failing (the unfolded schedule cannot take
+        // over: the consumer weights hold W (.) w)
+        if (((uintptr_t)logits & 15) && logits != m->logits) {
+            if ((rc = forward_folded(m, B, T, m->logits, s))) return rc;
+            VN_HIP_CHECK(ctx, hipMemcpyAsync(logits, m->logits, (size_t)M * m->Cp * m->d.vocab * sizeof(float), hipMemcpyDeviceToDevice, s));
+            return VN_OK;
+        }
+        return forward_folded(m, B, T, logits, s);
+    }
     const long plane = (long)B * H * T * VN_DHEAD;
     const bool bf = m->blob16 != nullptr;
     // bf16 fast mode: the four big GEMM operands (normalised rows, attention output, GEGLU output, weights) are bf16,
@@ -611,7 +622,9 @@ static int set_bf16_planes(vn_model* m, const void* blob16_dev, long w_plane) {
         VN_HIP_CHECK(m->ctx, hipDeviceSynchronize());
         const uint16_t* planes = (const uint16_t*)blob16_dev;
         const long D = m->D;
-        const bool fold = m->ctx->tune.fold_norm != 0 && D <= 2048;          // (the consumers keep K / 128 <= 16 group sums in registers)
+        // fold only what every folded launch can run: vn_launch_rowprep's widths (256 / 1280; K / 128 <= 16 group sums per consumer row);
+        // other widths keep the norm kernels (decided ONCE, here: folded consumer weights cannot serve the unfolded schedule)
+        const bool fold = m->ctx->tune.fold_norm != 0 && (D == 256 || D == 1280);
         // `norm` != 0: a consumer of an RMSNorm in a model with folded norms — its planes are built from the fp32 blob with the norm
         // weight multiplied into the columns (W' = W (.) w_norm, one fp32 rounding, then the exact split); the others are re-laid
         // from the caller's planes
@@ -665,7 +678,7 @@ extern "C" int vn_model_set_f16x2(vn_model* m, int on) {
         if (!m->w_h2 && (rc = dev_alloc(m->ctx, &m->w_h2, (size_t)2 * n))) return rc;
         VN_HIP_CHECK(m->ctx, hipDeviceSynchronize());          // a setup call: fence it against whatever stream wrote the blob
         const long D = m->D;
-        const bool fold = m->ctx->tune.fold_norm != 0 && D <= 2048;
+        const bool fold = m->ctx->tune.fold_norm != 0 && (D == 256 || D == 1280);      // as set_bf16_planes
         auto build = [&](int id, int layer, long rows, int K, int norm_id = -1, int norm_layer = 0) {      // norm_id: see set_bf16_planes
             const long off = vn_tensor_offset(&m->d, id, layer);
             if (fold && norm_id >= 0)

@@ -88,13 +88,15 @@
 // NP = planes per operand: 3 (bf16x3, six products per k-step) or 2 (f16x2, three products; vn_common.h vn_split2h).
 template <int CFG, int NP = 3>
 struct x3_geo {
-    static constexpr int RI = CFG == 3 ? 3 : CFG, CJ = CFG == 3 ? 1 : 2, WR = CFG == 3 ? 2 : 4, WC = CFG == 3 ? 4 : 2;
+    static constexpr int RI = (CFG == 3 || CFG == 4) ? 3 : CFG, CJ = (CFG == 3 || CFG == 4) ? 1 : 2;
+    static constexpr int WR = CFG == 4 ? 1 : CFG == 3 ? 2 : 4, WC = (CFG == 3 || CFG == 4) ? 4 : 2;
+    static constexpr int KG = CFG == 4 ? 2 : 1;                     // wave groups that split the k-steps of a k-tile between them (CFG 4)
     static constexpr int BM = 32 * RI * WR;
     static constexpr int APLANE = BM * 16;                          // floats
-    static constexpr int STAGE = NP * (APLANE + X3_BPLANE);         // floats: 48 / 72 / 60 KiB (NP = 2: 32 / 48 / 40)
-    static constexpr int NQ = NP * (BM + 128) / 16;                 // 1 KiB DMA wave-instructions per stage: 48 / 72 / 60 (32 / 48 / 40)
-    static constexpr int NPW = (NQ + 7) / 8;                        // per wave: 6 / 9 / 8 (CFG 3, NP 3: the last one only in waves 0-3); 4 / 6 / 5
-    static constexpr int NBUF = (CFG == 1 || NP == 2) ? 3 : 2;      // resident stages (f16x2: 96 / 144 / 120 KiB)
+    static constexpr int STAGE = NP * (APLANE + X3_BPLANE);         // floats: 48 / 72 / 60 / 42 KiB (NP = 2: 32 / 48 / 40)
+    static constexpr int NQ = NP * (BM + 128) / 16;                 // 1 KiB DMA wave-instructions per stage: 48 / 72 / 60 / 42 (32 / 48 / 40)
+    static constexpr int NPW = (NQ + 7) / 8;                        // per wave: 6 / 9 / 8 (CFG 3, NP 3: the last one only in waves 0-3) / 6 (CFG 4: the last one only in waves 0-1); 4 / 6 / 5
+    static constexpr int NBUF = (CFG == 1 || CFG == 4 || NP == 2) ? 3 : 2;      // resident stages (f16x2: 96 / 144 / 120 KiB)
     static constexpr int RP = 32 * WR;                              // rows of one pass of the staged epilogue's LDS image
     static constexpr int NPROD = NP == 3 ? 6 : 3;                   // matrix-core products per 16-wide k-step
     // folded RMSNorm: float offset of the per-row scale table (BM floats) — behind the stages AND behind the largest epilogue image
@@ -102,7 +104,8 @@ struct x3_geo {
     static constexpr int RS_OFF = NBUF * STAGE > X3_RS_OFF(RP) ? NBUF * STAGE : X3_RS_OFF(RP);
     static constexpr int NI = NP == 3 ? 4 : 2;                      // two-buffer schedule: DMA pieces issued between the products of k-step 0
 };
-static_assert(x3_geo<1>::BM == 128 && x3_geo<2>::BM == 256 && x3_geo<3>::BM == 192, "tile heights");
+static_assert(x3_geo<1>::BM == 128 && x3_geo<2>::BM == 256 && x3_geo<3>::BM == 192 && x3_geo<4>::BM == 96, "tile heights");
+static_assert(x3_geo<4>::KG * x3_geo<4>::BM * 128 <= x3_geo<4>::RS_OFF && x3_geo<3>::BM * 128 <= x3_geo<3>::RS_OFF, "the image epilogue's fp32 tile images end in front of the scale table");
 
 __device__ __forceinline__ int x3_xcd_remap(int bid, int nwg) {
     const int xcd = bid & 7, idx = bid >> 3;
@@ -435,6 +438,166 @@ __device__ __forceinline__ void x3_epilogue_staged(const vn_gemm_args& p, const 
         vn_sat_report(p.sat, EPI == VN_EPI_QKV3 ? VN_SAT_ATTN : VN_SAT_OPERAND, bad);
 }
 
+// Epilogues of the k-split tile (CFG 4) through ONE fp32 image of the whole tile per wave group: every wave drops its accumulators at
+// their tile coordinates into its group's image [BM][128] (KG images: the stages are free after the k-loop), one barrier, then all 512
+// threads read the images back in 16-byte pieces, ADD the groups' partial sums in group order (deterministic) and run the epilogue on
+// the sums — so the k-split's reduction costs one more LDS read per element and no second pass.  The arithmetic of every epilogue is
+// the expression of x3_epilogue_staged (results of a KG = 1 geometry would be bitwise the staged ones); plane kinds form the planes
+// from the fp32 image on the way out (16-byte global stores), so no second image and no second barrier exist.  bf16x3 operands only.
+template <int EPI, int CFG, int FMT = 0>
+__device__ __forceinline__ void x3_epilogue_image(const vn_gemm_args& p, const f32x16 (&acc)[x3_geo<CFG>::RI][x3_geo<CFG>::CJ], int m0, int n0,
+                                                  int wave, int lane, float* lds) {
+    using G = x3_geo<CFG>;
+    constexpr int RI = G::RI, CJ = G::CJ, BM = G::BM, KG = G::KG, IMG = BM * 128;
+    static_assert(!FMT && EPI != VN_EPI_CONV, "image epilogue: bf16x3 operands, no convolution epilogue");
+    const int wq = wave % (G::WR * G::WC), kg = wave / (G::WR * G::WC);
+    const int wm = wq / G::WC, wn = wq % G::WC, l31 = lane & 31, h = lane >> 5, tid = wave * 64 + lane;
+    {
+        float* img = lds + kg * IMG;
+#pragma unroll
+        for (int i = 0; i < RI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int R = wm * 32 * RI + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;       // tile row
+#pragma unroll
+                for (int j = 0; j < CJ; ++j) img[R * 128 + wn * 32 * CJ + j * 32 + l31] = acc[i][j][r];
+            }
+    }
+    __syncthreads();
+    auto ld4 = [&](int R, int c) {
+        f32x4 v = *(const f32x4*)(lds + R * 128 + c);
+#pragma unroll
+        for (int g = 1; g < KG; ++g) v += *(const f32x4*)(lds + g * IMG + R * 128 + c);
+        return v;
+    };
+    auto ld1 = [&](int R, int c) {
+        float v = lds[R * 128 + c];
+#pragma unroll
+        for (int g = 1; g < KG; ++g) v += lds[g * IMG + R * 128 + c];
+        return v;
+    };
+    constexpr bool FOLD_IN = EPI == VN_EPI_QKV3 || EPI == VN_EPI_QKV || EPI == VN_EPI_GEGLU || EPI == VN_EPI_BIAS;
+    const float* rs = lds + G::RS_OFF;                   // folded norm: per-row scales (kernel prologue)
+    const bool fold_in = FOLD_IN && p.ssq_in != nullptr;
+    bool bad = false;
+    if constexpr (EPI == VN_EPI_GEGLU) {
+        // the tile's 128 packed columns = 2 x (32 value, 32 gate); a thread forms four consecutive outputs of a row
+#pragma unroll
+        for (int k = 0; k < BM * 16 / 512; ++k) {
+            const int idx = tid + 512 * k;
+            const int R = idx >> 4, c4 = (idx & 15) * 4;
+            const int vcol = (c4 >> 5) * 64 + (c4 & 31);
+            const int row = m0 + R, ocol = n0 / 2 + c4;
+            if (row >= p.M || 2 * ocol >= p.N) continue;
+            const f32x4 val = ld4(R, vcol), gate = ld4(R, vcol + 32);
+            const float sc = fold_in ? rs[R] : 1.0f;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (val[e] * sc) * vn_gelu_tanh(gate[e] * sc);
+            if (p.C16) {
+                vn_store_planes4(p.C16, p.c_plane, row, ocol, p.ldc, o, bad);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p.C[(size_t)row * p.ldc + ocol + e] = o[e];
+            }
+        }
+    } else if constexpr (EPI == VN_EPI_QKV3) {
+        const int D = p.H * VN_DHEAD;
+        if (n0 < 2 * D) {                                                       // q / k tile: eight consecutive head features of a token
+#pragma unroll
+            for (int k = 0; k < BM * 16 / 512; ++k) {
+                const int idx = tid + 512 * k;
+                const int R = idx >> 4, b8 = (idx & 15) * 8;
+                const int row = m0 + R, col = n0 + b8;
+                if (row >= p.M || col >= p.N) continue;
+                const f32x4 l0 = ld4(R, b8), l1 = ld4(R, b8 + 4);
+                const float sc = fold_in ? rs[R] : 1.0f;
+                f32x8 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = l0[e] * sc; v[4 + e] = l1[e] * sc; }
+                if (n0 < D) {                                                   // q: x 1/sqrt(64)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] * 0.125f;
+                }
+                bf16x8 p0, p1, p2;
+                vn_split3_x8(v, p0, p1, p2);
+                const int which = col >= D ? 1 : 0, rem = col - which * D;
+                const int b = row / p.T, t = row - b * p.T;
+                uint16_t* dst = p.C16 + which * p.qkv_plane + (((size_t)b * p.H + (rem >> 6)) * p.T + t) * VN_DHEAD + (rem & 63);
+                *(u32x4*)dst = __builtin_bit_cast(u32x4, p0);
+                *(u32x4*)(dst + p.c_plane) = __builtin_bit_cast(u32x4, p1);
+                *(u32x4*)(dst + 2 * p.c_plane) = __builtin_bit_cast(u32x4, p2);
+            }
+        } else {                                                                // v tile: eight consecutive tokens of one head feature (V^T)
+#pragma unroll
+            for (int k = 0; k < 128 * (BM / 8) / 512; ++k) {
+                const int idx = tid + 512 * k;
+                const int a = idx & 127, b8 = (idx >> 7) * 8;
+                const int row = m0 + b8, f = n0 + a - 2 * D;
+                if (row >= p.M || n0 + a >= p.N) continue;
+                f32x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = ld1(b8 + e, a) * (fold_in ? rs[b8 + e] : 1.0f);
+                bf16x8 p0, p1, p2;
+                vn_split3_x8(v, p0, p1, p2);
+                uint16_t* dst = p.V16 + (((size_t)(f >> 6) * ((p.M + 31) >> 5) + (row >> 5)) * VN_DHEAD + (f & 63)) * 32 + (row & 31);
+                *(u32x4*)dst = __builtin_bit_cast(u32x4, p0);
+                *(u32x4*)(dst + p.v_plane) = __builtin_bit_cast(u32x4, p1);
+                *(u32x4*)(dst + 2 * p.v_plane) = __builtin_bit_cast(u32x4, p2);
+            }
+        }
+    } else if (EPI == VN_EPI_RESIDUAL && p.X16 != nullptr) {
+        // folded norm, producer side (as x3_epilogue_staged): the 16 threads of a row are 16 consecutive lanes
+#pragma unroll
+        for (int k = 0; k < BM * 16 / 512; ++k) {
+            const int idx = tid + 512 * k;
+            const int R = idx >> 4, c8 = (idx & 15) * 8;
+            const int row = m0 + R, col = n0 + c8;
+            f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (row < p.M) {
+                const f32x4 l0 = ld4(R, c8), l1 = ld4(R, c8 + 4);
+                const f32x8 acc8 = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                if (p.x16_only) {
+                    v = acc8 + vn_load_planes8_bf16x3_tiled(p.X16, row, col, p.N);
+                } else {
+                    float* c = p.C + (size_t)row * p.ldc + col;
+                    const f32x4 a0 = l0 + *(const f32x4*)c;
+                    const f32x4 a1 = l1 + *(const f32x4*)(c + 4);
+                    *(f32x4*)c = a0;
+                    *(f32x4*)(c + 4) = a1;
+                    v = f32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                }
+                vn_store_planes8_tiled(p.X16, p.x16_plane, row, col, p.N, v, bad);
+            }
+            const float s2 = vn_sum16(vn_ssq4(f32x4{v[4], v[5], v[6], v[7]}, vn_ssq4(f32x4{v[0], v[1], v[2], v[3]})));
+            if ((tid & 15) == 0 && row < p.M) p.ssq_out[(size_t)(n0 >> 7) * p.M + row] = s2;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < BM * 32 / 512; ++k) {                                   // BM rows x 32 pieces of 4 columns
+            const int idx = tid + 512 * k;
+            const int R = idx >> 5, c4 = (idx & 31) * 4;
+            const int row = m0 + R, col = n0 + c4;
+            if (row >= p.M || col >= p.N) continue;
+            f32x4 v = ld4(R, c4);
+            if constexpr (FOLD_IN) {
+                if (fold_in) { const float sc = rs[R]; v[0] *= sc; v[1] *= sc; v[2] *= sc; v[3] *= sc; }
+            }
+            if constexpr (EPI == VN_EPI_QKV) {
+                const int D = p.H * VN_DHEAD;
+                const int which = col / D, rem = col - which * D;
+                const int b = row / p.T, t = row - b * p.T;
+                *(f32x4*)(p.C + which * p.qkv_plane + (((size_t)b * p.H + (rem >> 6)) * p.T + t) * VN_DHEAD + (rem & 63)) = v;
+            } else {
+                float* c = p.C + (size_t)row * p.ldc + col;
+                if constexpr (EPI == VN_EPI_BIAS) v += *(const f32x4*)(p.bias + col);
+                if constexpr (EPI == VN_EPI_RESIDUAL) v += *(const f32x4*)c;
+                *(f32x4*)c = v;
+            }
+        }
+    }
+}
+
 // one block per output tile (gridDim.y > 1: split-K images, store epilogue only)
 // ABL (tuning only, results invalid): bit 0 = no DMA inside the k-loop, bit 1 = no fragment reads inside the k-loop, bit 2 =
 // every DMA instruction fetches 8 rows x 128 B (whole cache lines, same volume) instead of 16 rows x 64 B
@@ -449,7 +612,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / G::WC, wn = wave % G::WC;
+    const int wm = (wave % (G::WR * G::WC)) / G::WC, wn = wave % G::WC;      // CFG 4: waves w and w + 4 own the same 96 x 32 sub-tile
     const int grp = wave >> 2;                        // waves w and w + 4 share a SIMD: one of each group per SIMD
     const uint16_t* A16 = (const uint16_t*)p.A;
     const uint16_t* W16 = (const uint16_t*)p.W;
@@ -473,7 +636,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         // per-lane DMA sources: instruction q fills 16 rows of one plane tile at LDS offset q KiB of the stage (A planes first: q <
         // 3 BM / 16, plane q / (BM / 16)).  CFG 1 / 2: a wave owns NPW consecutive instructions; CFG 3 (60 instructions): instruction
         // 8 j + wave, so waves 0-3 issue eight and waves 4-7 seven
-        auto piece_q = [&](int j) { return CFG == 3 ? 8 * j + wave : wave * G::NPW + j; };
+        auto piece_q = [&](int j) { return (CFG == 3 || CFG == 4) ? 8 * j + wave : wave * G::NPW + j; };
         constexpr int NA_PIECES = NP * (G::BM / 16);                // DMA instructions of a stage that fetch A
         constexpr bool CONV = EPI == VN_EPI_CONV;
         const uint16_t* src[G::NPW];
@@ -689,6 +852,43 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                 if (!(last && grp)) X3_BARRIER();           // group 1's last compute phase has no partner phase
                 b = b == 2 ? 0 : b + 1;
             }
+        } else if constexpr (CFG == 4) {
+            // 96 x 128 tile, the K SPLIT INSIDE THE BLOCK: wave group g (waves 4 g .. 4 g + 3, a 96 x 32 sub-tile each) owns k-step g of
+            // every k-tile, so a k-tile is ONE load phase and ONE compute phase (18 MFMAs) per group, the groups one phase apart as in the
+            // other schedules (two barriers per k-tile instead of four), and the two partial sums meet in the epilogue's LDS images
+            // (x3_epilogue_image).  What it buys: M = 575 / 576 rows are 6 x 96 exactly (4.5 x 128: a tenth of the matrix work of the
+            // 128-row tiles multiplies padding), the one-sequence launches become 180 / 240 tiles of 0.75 of the k-loop of a 128-row
+            // tile, and 12 MFMA tiles of 32 x 32 do not divide over eight waves any other way.
+            // Three buffers, tile kt in buffer kt % 3, interval I_j between consecutive barriers: group 0 reads tile kt in I_2kt,
+            // group 1 in I_2kt+1 (both end with lgkmcnt(0) before their barrier).  Tile kt + 2 goes into the buffer of tile kt - 1 (last
+            // read in I_2kt-1): every wave issues its pieces in its own load phase of tile kt (I_2kt / I_2kt+1) and waits for them at
+            // the end of its load phase of tile kt + 1 with the pieces of tile kt + 3 in flight (counted vmcnt: waves 0-1 issue six
+            // pieces per stage, the others five) — one barrier later, at the earliest, group 0 reads the tile in I_2kt+4.
+            const bool six = wave < G::NQ % 8;
+            auto wait_for_all_but_one_stage = [&]() {
+                if (six) X3_VMCNT(G::NPW);
+                else X3_VMCNT(G::NPW - 1);
+            };
+            stage(0, 0);
+            if (nk > 1) { stage(1, X3_KT); wait_for_all_but_one_stage(); }
+            else X3_VMCNT(0);
+            X3_BARRIER();                                   // tile 0 complete
+            fold_table();
+            if (grp) X3_BARRIER();                          // group 1 runs one phase behind
+            int b = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                const int b2 = b == 0 ? 2 : b - 1;          // buffer of tile kt + 2 (= the one tile kt - 1 used)
+                const bool more = kt + 2 < nk;
+                const bool last = kt + 1 == nk;
+                load_frags(f, b, grp);
+                if (more) { stage(b2, (kt + 2) * X3_KT); wait_for_all_but_one_stage(); }   // tile kt + 1 landed (this wave's pieces)
+                else X3_VMCNT(0);
+                X3_LGKM0();
+                X3_BARRIER();
+                compute();
+                if (!(last && grp)) X3_BARRIER();           // group 1's last compute phase has no partner phase
+                b = b == 2 ? 0 : b + 1;
+            }
         } else if constexpr (CFG == 1) {
             // three buffers; tile kt lives in buffer kt % 3.  Phase intervals I_j between consecutive barriers: group 0 loads
             // step i in I_2i and computes it in I_2i+1, group 1 one interval later.  Tile kt is read in I_4kt .. I_4kt+3 (every
@@ -786,7 +986,9 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
 #pragma unroll
                 for (int j = 0; j < CJ; ++j) acc[i][j] += acc_lo[i][j] * VN_H2_INV_SCALE;
         }
-        if constexpr (EPI == VN_EPI_CONV) {
+        if constexpr (CFG == 4) {
+            x3_epilogue_image<EPI, CFG, FMT>(p, acc, m0, n0, wave, lane, lds);       // the launcher guarantees the staged forms' alignment
+        } else if constexpr (EPI == VN_EPI_CONV) {
             x3_epilogue_staged<EPI, CFG, FMT>(p, acc, m0, n0, wave, lane, lds);      // the launcher guarantees the alignment it needs
         } else {
             if (p.staged) x3_epilogue_staged<EPI, CFG, FMT>(p, acc, m0, n0, wave, lane, lds);
@@ -797,11 +999,11 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
 
 #define X3_WS_FLOATS (32L << 20)          // 128 MiB of split-K partial images, allocated once (graph-safe: never re-allocated)
 
-// tuning / test hook of ONE context: tile height 128 / 192 / 256 (0 = by shape), forced split-K (0 / 1 off, 2 / 4 forced, < 0 =
+// tuning / test hook of ONE context: tile height 96 / 128 / 192 / 256 (0 = by shape; 96 = the k-split tile, bf16x3 operands), forced split-K (0 / 1 off, 2 / 4 forced, < 0 =
 // cost model), ablation bits (tuning only: results invalid; < 0 or 0 = none)
 extern "C" int vn_debug_x3_config(vn_ctx* ctx, int bm, int splitk, int abl) {
     if (!ctx) return VN_ERR_INVALID;
-    if (bm != 0 && bm != 128 && bm != 192 && bm != 256) return vn_fail(ctx, VN_ERR_INVALID, "x3 tile height %s%ld is not 0 / 128 / 192 / 256", "", bm);
+    if (bm != 0 && bm != 96 && bm != 128 && bm != 192 && bm != 256) return vn_fail(ctx, VN_ERR_INVALID, "x3 tile height %s%ld is not 0 / 96 / 128 / 192 / 256", "", bm);
     ctx->tune.x3_bm = bm;
     ctx->tune.x3_split = splitk < 0 ? -2 : splitk;
     ctx->tune.x3_abl = abl < 0 ? 0 : (abl & 7);
@@ -851,6 +1053,9 @@ static int x3_go_bm(vn_ctx* ctx, const vn_gemm_args& a, int nsplit, int bm, hipS
     if constexpr (EPI != VN_EPI_GEGLU) {
         if (bm == 192) return x3_go<EPI, 3, 0, FMT>(ctx, a, nsplit, s);
     }
+    if constexpr (EPI != VN_EPI_CONV && !FMT) {
+        if (bm == 96) return x3_go<EPI, 4, 0, FMT>(ctx, a, nsplit, s);       // x3_choose offers it only where x3_tile96_ok holds
+    }
     return bm == 256 ? x3_go<EPI, 2, 0, FMT>(ctx, a, nsplit, s) : x3_go<EPI, 1, 0, FMT>(ctx, a, nsplit, s);
 }
 
@@ -878,20 +1083,32 @@ static bool x3_fold_out(const vn_gemm_args& a) { return a.X16 != nullptr; }
 // classifier 768 = 3.0 rounds; 256 rows stay best for W1 + GEGLU (720 tiles = 2.8 rounds; the GEGLU epilogue needs the 64-wide
 // wave tile); one or two sequences keep 128 rows (more tiles) and split the N = 1280 projections.
 struct x3_plan { int bm, ns; };
+// may a launch use the 96-row k-split tile (CFG 4) ?  bf16x3 operands, no convolution, and the alignment of the LDS-staged epilogues
+// (its image epilogue issues the same 16-byte global accesses); VN_X3_TILE96=0 / vn_tune::x3_tile96 switches it off (A/B runs)
+template <int EPI, int FMT>
+static bool x3_tile96_ok(const vn_ctx* ctx, const vn_gemm_args& a) {
+    if constexpr (FMT || EPI == VN_EPI_CONV) return false;
+    else return ctx->tune.x3_tile96 && x3_staged_ok<EPI>(ctx, a) != 0;
+}
 template <int EPI>
-static x3_plan x3_choose(const vn_ctx* ctx, const vn_gemm_args& a, int cus, double kt_us = 1.45, double partial = 1.0) {
-    const int bm_forced = ctx->tune.x3_bm;                   // 0 = by shape
+static x3_plan x3_choose(const vn_ctx* ctx, const vn_gemm_args& a, int cus, double kt_us = 1.45, double partial = 1.0, bool allow96 = false) {
+    int bm_forced = ctx->tune.x3_bm;                         // 0 = by shape
+    if (bm_forced == 96 && !allow96) bm_forced = 128;
     const int split_forced = ctx->tune.x3_split == -2 ? -1 : ctx->tune.x3_split;      // 0 / 1 off, 2 / 4 forced, -1 cost model
     constexpr bool can_split = EPI == VN_EPI_STORE || EPI == VN_EPI_RESIDUAL;
     constexpr bool residual = EPI == VN_EPI_RESIDUAL;
     const int nk = a.K / X3_KT;
     x3_plan best{128, 1};
     double best_cost = 1e300;
-    static const int heights[3] = {128, 192, 256};
-    static const double rel[3] = {1.0, 1.5 * 0.97, 2.0 * 0.95};
-    for (int hi = 0; hi < 3; ++hi) {
+    static const int heights[4] = {128, 192, 256, 96};
+    // 96 rows (k-split inside the block): 0.75 of a 128-row tile's matrix work per k-tile, + 17 % DMA bytes per flop; its two-image
+    // epilogue adds ~1 us per launch (fixed[])
+    static const double rel[4] = {1.0, 1.5 * 0.97, 2.0 * 0.95, 0.75 * 1.03};
+    static const double fixed[4] = {0.0, 0.0, 0.0, 1.0};
+    for (int hi = 0; hi < 4; ++hi) {
         const int bm = heights[hi];
         if (bm == 192 && EPI == VN_EPI_GEGLU) continue;
+        if (bm == 96 && !allow96) continue;
         if (bm_forced && bm != bm_forced && !(bm_forced == 192 && EPI == VN_EPI_GEGLU && bm == 128)) continue;
         const long tiles = (long)vn_cdiv(a.M, bm) * vn_cdiv(a.N, X3_BN);
         for (int ns = 1; ns <= (can_split ? 4 : 1); ns *= 2) {
@@ -901,8 +1118,16 @@ static x3_plan x3_choose(const vn_ctx* ctx, const vn_gemm_args& a, int cus, doub
                 if (nk / ns < 8 || (double)ns * a.M * a.N > (double)X3_WS_FLOATS) continue;
             }
             if (split_forced > 1 && ns != split_forced && ns != 1) continue;
-            double cost = (double)((tiles * ns + cus - 1) / cus) * (nk / (double)ns) * kt_us * rel[hi];
-            if (tiles * ns < cus) cost *= partial;           // a launch that leaves CUs idle runs at a higher clock (f16x2 sweep: x 0.8)
+            // a ONE-ROUND launch that leaves CUs idle runs its k-tiles faster — measured on this kernel (profiles/r05_gemm_underfill_ab.txt,
+            // relative to 240 of 256 CUs busy): 0.72 at 30 tiles, 0.80 at 120, 0.83 at 150, 0.86 at 180, 0.96 at 210.  Piecewise linear
+            // in the fill; the f16x2 calibration keeps its own single factor (`partial` < 1)
+            const long blocks = tiles * ns, rounds = (blocks + cus - 1) / cus;
+            double cost = (double)rounds * (nk / (double)ns) * kt_us * rel[hi] + fixed[hi];
+            if (blocks < cus) {
+                const double fill = (double)blocks / cus;
+                const double under = fill <= 0.6 ? 0.70 + 0.20 * fill : 0.82 + 0.53 * (fill - 0.6);
+                cost *= partial < 1.0 ? partial : (under < 1.0 ? under : 1.0);
+            }
             if (ns > 1) {
                 cost += (ns + (residual ? 2 : 1)) * 4.0 * a.M * (double)a.N / 3.5e6;
                 if (residual && (x3_norm_fusable(ctx, a) || x3_fold_out(a))) cost -= 4.0 * a.M * (double)a.N / 3.5e6 + 1.5;
@@ -923,7 +1148,8 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
     const int pi = vn_prof_pre(ctx, EPI == VN_EPI_CONV ? 2 : 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);
     int rc = VN_OK;
     // f16x2: half the matrix work per k-tile (profiles/history/r03_gemm_f16x2_plan_sweep.txt)
-    const x3_plan plan = FMT ? x3_choose<EPI>(ctx, a, vn_num_cus(ctx), 0.85, 0.8) : x3_choose<EPI>(ctx, a, vn_num_cus(ctx));
+    const x3_plan plan = FMT ? x3_choose<EPI>(ctx, a, vn_num_cus(ctx), 0.85, 0.8)
+                             : x3_choose<EPI>(ctx, a, vn_num_cus(ctx), 1.45, 1.0, x3_tile96_ok<EPI, FMT>(ctx, a));
     const int bm = plan.bm;
     bool done = false;
     if constexpr (EPI == VN_EPI_STORE) {
@@ -987,6 +1213,9 @@ static int x3_attrs(vn_ctx* ctx) {
     if (!rc) rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 2, 0, FMT>, x3_lds_bytes<2, NP>());
     if constexpr (EPI != VN_EPI_GEGLU) {
         if (!rc) rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 3, 0, FMT>, x3_lds_bytes<3, NP>());
+    }
+    if constexpr (EPI != VN_EPI_CONV && !FMT) {
+        if (!rc) rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 4, 0, FMT>, x3_lds_bytes<4, NP>());
     }
     return rc;
 }

@@ -367,6 +367,7 @@ struct vn_tune {
     // gemm_x3.hip: forced tile height (0 = by shape), forced k-split (-2 = cost model), ablation bits (0 = none; results INVALID,
     // settable only through vn_debug_x3_config), fused reduce + norm, LDS-staged epilogues, tile-walk group height (0 = 8)
     int x3_bm, x3_split, x3_abl, x3_fuse_norm, x3_staged, x3_group_m;
+    int x3_tile96;           // gemm_x3.hip: the planner may pick the 96-row k-split tile (VN_X3_TILE96, default 1; bf16x3 operands)
     // attention_x3.hip: decomposition (-1 by shape, 0 shared tiles, 1 / 2 / 4 key-split waves), dynamic-LDS override of the shared
     // kernel (occupancy probe), start stagger, phase-trace buffer (device)
     int ax_split, ax_lds, ax_stagger;

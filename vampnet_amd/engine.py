@@ -73,10 +73,22 @@ class Engine:
 
     def saturation(self, clear=True):
         """The context's saturation ledger (include/vampnet_hip.h vn_saturation_flags): (GEMM-operand planes, attention operands,
-        weight planes, reserved) — non-zero where an fp16 plane writer had to clamp a value since the last clear.  Synchronises."""
+        weight planes, reserved) — non-zero where an fp16 plane writer had to clamp a value since the last clear.  Synchronises.
+        The device words are per CONTEXT; flags that one consumer set aside for another (saturation_restore) are OR-ed in."""
         fl = (C.c_uint32 * 4)()
         self.check(self.lib.vn_saturation_flags(self.handle, fl, 1 if clear else 0, self.stream()), "vn_saturation_flags")
-        return tuple(int(v) for v in fl)
+        carry = getattr(self, "_sat_carry", (0, 0, 0, 0))
+        out = tuple(int(v) | int(c) for v, c in zip(fl, carry))
+        if clear:
+            self._sat_carry = (0, 0, 0, 0)
+        return out
+
+    def saturation_restore(self, flags):
+        """Hand flags back to the ledger that a nested consumer read-and-cleared but does not own: a codec that shares the engine of an
+        f16x2 model runs INSIDE that model's generate(return_signal=True) — it sets the model's words aside before its own call and
+        restores them afterwards, so the model's check still sees them (and the codec does not fall back on the model's account)."""
+        carry = getattr(self, "_sat_carry", (0, 0, 0, 0))
+        self._sat_carry = tuple(int(c) | (1 if f else 0) for c, f in zip(carry, flags))
 
     def health_check(self):
         """Synchronise and raise if a stream-K GEMM ever gave up waiting for a partial tile (never expected)."""

@@ -320,7 +320,7 @@ class Trainer:
         train.py:376-378 `consolidate_state_dict`).  No-op without ZeRO-1."""
         if getattr(self, "zero1", False):
             # kept on the HOST (2 x n_total fp32 = 2.7 GB for the coarse model would otherwise sit on every rank's GPU and undo the
-            # ZeRO-1 saving) and dropped again by the optimizer_state_dict() that consumes it
+            # ZeRO-1 saving), usable by every optimizer_state_dict() / save_checkpoint() of this step count, dropped by the next update()
             self._consolidated = (self.steps, tuple(t.cpu() for t in self.consolidate_state()))
 
     def update(self):
@@ -333,6 +333,7 @@ class Trainer:
             lr = noam_lr(step, self.D, *self.noam) if self.noam else self.hp["lr"]
             self._update_zero1(step, lr)
             self.steps = step
+            self._consolidated = None            # the gathered moments of the previous step are stale now
             self.last_lr = lr
             return self.grad_norm
         if self.pg is not None:
@@ -424,8 +425,9 @@ class Trainer:
             if cons is None or cons[0] != self.steps:
                 raise RuntimeError("ZeRO-1: call Trainer.consolidate() on EVERY rank (a collective) before optimizer_state_dict() / "
                                    "save_checkpoint() of this step; save_checkpoint(all_ranks=True) does it when every rank calls it")
+            # NOT dropped here: the reference consolidates once and then writes every tag of the step ('latest', 'Nk', 'best' —
+            # train.py:376-378, :408-420) from rank 0; the host copy lives until the next update() makes it stale
             m, v = (exp(t) for t in cons[1])
-            self._consolidated = None            # consumed: the next save of another step needs a fresh consolidate()
         else:
             m, v = exp(self.adam_m), exp(self.adam_v)
         index = {k: i for i, k in enumerate(self._all_param_names())}
