@@ -579,13 +579,20 @@ class VampNetModel:
                                                            batch_offset, B, overlap=True)
             else:
                 exp, unif = self.draw_noise(global_batch or B, T, steps, sample_cutoff, batch_offset, B)
-            exp = exp.to(self.device, non_blocking=True)
-            unif = unif.to(self.device, non_blocking=True)
+            noise_on_host = not (exp.is_cuda and unif.is_cuda)
+            if noise_on_host:
+                exp = exp.to(self.device, non_blocking=True)
+                unif = unif.to(self.device, non_blocking=True)
+            else:
+                cur_s = torch.cuda.current_stream(self.device)
+                exp.record_stream(cur_s)
+                unif.record_stream(cur_s)
             exp_p, unif_p = exp.data_ptr(), unif.data_ptr()
             dseed = 0
         elif rng == "device":
             exp = unif = None
             exp_p = unif_p = None
+            noise_on_host = False
             dseed = device_seed if device_seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
         else:
             raise ValueError("rng must be 'torch', 'torch_device' or 'device'")
@@ -600,7 +607,10 @@ class VampNetModel:
                           "vn_generate")
         if step_events is not None:
             self.engine.torch_rng().store_to_torch()        # waits for the side stream only; the model keeps running
-        if exp is not None:      # keep the noise alive until the enqueued work has consumed it
+        if exp is not None and (noise_on_host or not exp.is_cuda):
+            # host-drawn noise travels through pinned staging buffers: keep them alive until the enqueued work has consumed them.
+            # Device-drawn ledgers (rng="torch_device") are ordinary stream-ordered tensors (record_stream'd on this stream by their
+            # producer): no host synchronisation — the caller goes on to enqueue the next stage (and its noise) right away
             torch.cuda.current_stream(self.device).synchronize()
         if cfg_guidance is not None:
             out = out[:nb_ret].contiguous()                                   # transformer.py:940-941

@@ -364,21 +364,27 @@ class Interface:
         b0, b1 = self._shard(Bg)
         nb = b1 - b0
         n0s, exps, unifs, zs, ms = [], [], [], [], []
+        noise = None
+        if rng == "torch_device":
+            # seed-exact at device speed: the words of ALL these calls are generated on the generator's side stream, straight into the
+            # batch's ledger, BEFORE anything below asks the device for a value (the N0 counts wait for the previous stage) — the
+            # draw shapes are static, so the c2f stage's noise is produced underneath the coarse stage's forwards
+            from .torch_rng import draw_noise_device_calls
+            noise = draw_noise_device_calls(self.engine.torch_rng(), nC, Bg, starts[0].shape[-1] * model.n_predict_codebooks,
+                                            model.vocab_size, steps, cutoff, b0, nb)
         for st, mk in zip(starts, masks_):
             if mk is None:
                 mk = torch.ones_like(st)
                 mk[:, :model.n_conditioning_codebooks, :] = 0
             n0 = int(((mk != 0) | (st == model.mask_token)).sum().item())              # GLOBAL batch of this call
             n0s += [n0] * nb
-            if rng in ("torch", "torch_device"):
-                e, u = model.draw_noise(Bg, st.shape[-1], steps, cutoff, b0, nb, pin=False, **(
-                    {"on_device": True} if rng == "torch_device" else {}))
+            if rng == "torch":
+                e, u = model.draw_noise(Bg, st.shape[-1], steps, cutoff, b0, nb, pin=False)
                 exps.append(e)
                 unifs.append(u)
             zs.append(st[b0:b1])
             ms.append(mk[b0:b1])
-        noise = None
-        if rng in ("torch", "torch_device"):
+        if rng == "torch":
             N = unifs[0].shape[-1]
             exp = torch.stack([e.view(steps, nb, N, -1) for e in exps], dim=1).reshape(steps, nC * nb * N, -1)
             unif = torch.stack(unifs, dim=1).reshape(steps, nC * nb, N)

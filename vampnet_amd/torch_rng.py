@@ -217,13 +217,14 @@ def draw_noise_device(rng: DeviceTorchRng, B, N, V, steps, sample_cutoff, b0=0, 
 
     overlap=False: produced on the current stream, torch's generator updated before returning -> (exp, unif).
     overlap=True : produced on the rng's side stream with one event per step -> (exp, unif, events); the caller makes its
-    consumer wait on events[i] and calls rng.store_to_torch() AFTER enqueueing its own work."""
+    consumer wait on events[i] and calls rng.store_to_torch() AFTER enqueueing its own work.  The side stream does NOT wait for the
+    caller's stream: the draw shapes are static and every earlier use of the generator ended with
+    store_to_torch(), which returns only when its mt19937 kernels have run — so the words of this call are generated underneath
+    whatever the caller's stream still has queued (the previous stage's forwards)."""
     nb = B if nb is None else nb
     dev = rng.engine.device
     cur = torch.cuda.current_stream(dev)
     side = rng.side_stream() if overlap else cur
-    if overlap:
-        side.wait_stream(cur)
     events = []
     rng._producer = side
     with torch.cuda.stream(side):
@@ -246,4 +247,36 @@ def draw_noise_device(rng: DeviceTorchRng, B, N, V, steps, sample_cutoff, b0=0, 
         exp.record_stream(cur)
         unif.record_stream(cur)
         return exp, unif, events
+    return exp, unif
+
+
+def draw_noise_device_calls(rng: DeviceTorchRng, n_calls, B, N, V, steps, sample_cutoff, b0=0, nb=None):
+    """The noise of `n_calls` consecutive reference generate() calls of identical shape (Interface.coarse_to_fine's chunks,
+    interface.py:360-374), drawn call after call in the reference's order, written STRAIGHT into the ledger of the one device batch
+    that runs them: exp [steps, n_calls * nb * N, V], unif [steps, n_calls * nb, N] (call c = rows [c nb, (c + 1) nb) of every step).
+    Produced on the rng's side stream without waiting for the caller's stream (see draw_noise_device): while the coarse stage still
+    runs, the c2f stage's words are already being generated.  The caller's stream waits for the ledger (one event); torch's
+    generator is advanced before returning (the host waits for the side stream only)."""
+    nb = B if nb is None else nb
+    dev = rng.engine.device
+    cur = torch.cuda.current_stream(dev)
+    side = rng.side_stream()
+    rng._producer = side
+    with torch.cuda.stream(side):
+        exp = torch.zeros(steps, n_calls * nb * N, V, dtype=torch.float32, device=dev)
+        unif = torch.empty(steps, n_calls * nb, N, dtype=torch.float32, device=dev)
+        rng.load_from_torch()
+        for c in range(n_calls):
+            for i in range(steps):
+                if (i / steps) <= sample_cutoff:
+                    rng.exponential_block_(exp[i, c * nb * N:(c + 1) * nb * N], 2 * b0 * N * V, 2 * B * N * V)
+                rng.skip(b0 * N)
+                rng.uniform_(unif[i, c * nb:(c + 1) * nb], 1e-20, 1.0)
+                rng.skip((B - b0 - nb) * N)
+        done = torch.cuda.Event()
+        done.record(side)
+        rng.store_to_torch()
+    exp.record_stream(cur)
+    unif.record_stream(cur)
+    cur.wait_event(done)
     return exp, unif
