@@ -182,6 +182,9 @@ def bench_train(args, rank, world, device, pg, barrier):
     if rank != 0:
         return
     tokens = world * Bg * 4 * T * args.steps
+    # the step's GEMMs (forward, dX, dW) run on the split-plane pipe unless VN_TRAIN_X3=0 (csrc/train.hip): bf16x3 = three exact bf16
+    # planes per operand, six bf16-MFMA products, fp32 accumulation — not narrower than the reference's fp32 (amp: false)
+    train_dtype = "f32" if os.environ.get("VN_TRAIN_X3") == "0" else "bf16x3"
     fwd_gflop = 416.76                                     # coarse forward per item
     # forward + dX + dW of every product; LoRA-only skips the dW products (the rank-8 gradients are HBM-bound passes)
     step_tflop = (2.0 if args.lora_only else 3.0) * fwd_gflop * Bg / 1e3
@@ -189,19 +192,25 @@ def bench_train(args, rank, world, device, pg, barrier):
                      + " (coarse model)", "value": tokens / elapsed,
            "unit": "codec-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32", "data": "synthetic (random-init weights of the real architecture, random DAC tokens, r ~ U(0,1))",
+           "dtype": train_dtype, "data": "synthetic (random-init weights of the real architecture, random DAC tokens, r ~ U(0,1))",
            "config": {"workload": "BASELINE configs[4]: conf/vampnet.yml training step, coarse VampNet (20 layers, d=1280), "
                                   f"batch {Bg}/GPU x T=575 x 4 codebooks, dropout 0.1, label smoothing 0.1, clip 5.0, "
-                                  "AdamW + Noam, fp32 (amp: false)",
+                                  "AdamW + Noam, fp32-grade arithmetic (amp: false): " +
+                                  ("GEMMs as six bf16-MFMA products of exact three-way operand splits" if train_dtype == "bf16x3"
+                                   else "fp32-input MFMA"),
                       "global_batch": world * Bg, "parallelism": f"dp{world}" if world > 1 else "single GPU",
                       "step_tflop_per_gpu": step_tflop, "achieved_tflops_per_gpu": step_tflop / (elapsed / args.steps),
                       "final_loss": loss}}
     if prof is not None:
         n, ms, fl, by = prof["gemm"]
         an, ams, afl, _ = prof["attention"]
-        res["roofline"] = {"bound": "mfma", "kernel": "vn_gemm_f32[_sk]_kernel", "achieved": fl / (ms * 1e-3) / 1e12 if ms else None,
-                           "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                           "frac": fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF if ms else None, "traffic": None,
+        peak = PEAK_BF16_MFMA_TF / 6.0 if train_dtype == "bf16x3" else PEAK_F32_MFMA_TF
+        res["roofline"] = {"bound": "mfma", "kernel": "vn_gemm_x3_kernel" if train_dtype == "bf16x3" else "vn_gemm_f32[_sk]_kernel",
+                           "achieved": fl / (ms * 1e-3) / 1e12 if ms else None,
+                           "peak": peak, "unit": "TFLOP/s",
+                           "peak_basis": "2500 TF dense bf16 MFMA / 6 plane products per fp32-grade product" if train_dtype == "bf16x3"
+                                         else "fp32-input MFMA",
+                           "frac": fl / (ms * 1e-3) / 1e12 / peak if ms else None, "traffic": None,
                            "algorithmic_bytes_per_launch": by / n if n else None, "launches": int(n),
                            "avg_launch_us": 1e3 * ms / n if n else None, "event_stride": args.event_stride,
                            "gemm_time_frac": args.event_stride * ms / (1e3 * elapsed) if elapsed else None,

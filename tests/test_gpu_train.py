@@ -565,15 +565,16 @@ def test_training_trajectory_tracks_oracle(engine):
     assert out["loss"].item() < 7.0          # and it learns (starts at ~7.1 = ln(1024) + smoothing)
 
 
-@pytest.mark.skipif(os.environ.get("VN_TRAIN_X3") == "1", reason="this IS the child process")
-def test_training_step_on_bf16x3_gemms():
-    """Opt-in mode VN_TRAIN_X3=1: the same step-vs-oracle / determinism / full-size / trajectory tests with every training GEMM
-    (forward, dX, dW) routed through gemm_x3.hip, operands split on the fly — same parity bars as the fp32-input MFMA default
-    (green on MI355X, profiles/history/r02_test_train_x3.log; 102.5 vs 99.6 ms per step: the two extra split passes per GEMM eat the
-    matrix-pipe gain, so it stays opt-in).  VN_TRAIN_X3 is read once per process, hence the child process."""
+@pytest.mark.skipif(os.environ.get("VN_TRAIN_X3") == "0", reason="this IS the child process")
+def test_training_step_on_the_fp32_input_mfma():
+    """Since round 5 every training GEMM (forward, dX, dW) runs on the split-plane pipe by default (gemm_x3.hip, bf16x3: weights and
+    their transposes split once per update, activations split / transposed straight into tiled planes — csrc/train.hip); the tests of
+    this file therefore exercise THAT path.  This one repeats the step-vs-oracle / determinism / full-size / trajectory tests with
+    VN_TRAIN_X3=0, the fp32-input MFMA kernel — same parity bars.  The switch is read when a trainer is created; a child process keeps
+    the two runs apart."""
     import subprocess
     import sys
-    env = dict(os.environ, VN_TRAIN_X3="1")
+    env = dict(os.environ, VN_TRAIN_X3="0")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_train.py", "-x", "-q", "-m", "gpu", "-k",
                         "train_step_vs_oracle or deterministic or full_size_train_step or trajectory"],

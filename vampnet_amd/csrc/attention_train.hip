@@ -387,22 +387,30 @@ __global__ __launch_bounds__(256) void vn_attention_bwd_dq_kernel(
     }
 }
 
-// dbias[bucket][h] (+)= sum over the slots (b, h, q-block) of n_slabs consecutive slabs (layers), in order
-__global__ void vn_dbias_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dbias, int n_slabs, long slab_floats,
-                                       int B, int H, int nqb, int nbuckets, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// dbias[bucket][h] (+)= sum over the slots (b, h, q-block) of n_slabs consecutive slabs (layers).  One wave per output: lane i adds the
+// terms i, i + 64, ... (term index = (slab, b, q-block) in that order), then the 64 lane sums meet in a fixed xor tree — deterministic
+// (run to run and for any launch geometry), and ~50x shorter than the one-thread-per-output walk of 1440 strided terms it replaces
+// (0.69 ms of a 76 ms step at B = 8)
+__global__ __launch_bounds__(64) void vn_dbias_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dbias, int n_slabs,
+                                                            long slab_floats, int B, int H, int nqb, int nbuckets, int accumulate) {
+    const int i = blockIdx.x;
     if (i >= nbuckets * H) return;
     const int bkt = i / H, h = i - bkt * H;
+    const int per_slab = B * nqb, total = n_slabs * per_slab;
     float a = 0.f;
-    for (int l = 0; l < n_slabs; ++l)
-        for (int b = 0; b < B; ++b)
-            for (int qb = 0; qb < nqb; ++qb) a += partial[l * slab_floats + (((size_t)b * H + h) * nqb + qb) * 64 + bkt];
-    dbias[i] = accumulate ? dbias[i] + a : a;
+    for (int n = threadIdx.x; n < total; n += 64) {
+        const int l = n / per_slab, r = n - l * per_slab;
+        const int b = r / nqb, qb = r - b * nqb;
+        a += partial[l * slab_floats + (((size_t)b * H + h) * nqb + qb) * 64 + bkt];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (threadIdx.x == 0) dbias[i] = accumulate ? dbias[i] + a : a;
 }
 
 int vn_launch_dbias_reduce(vn_ctx* ctx, const float* partial, float* dbias, int n_slabs, long slab_floats, int B, int H, int T,
                            int nbuckets, bool accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(vn_dbias_reduce_kernel, dim3(vn_cdiv(nbuckets * H, 64)), dim3(64), 0, s, partial, dbias, n_slabs, slab_floats, B, H,
+    hipLaunchKernelGGL(vn_dbias_reduce_kernel, dim3(nbuckets * H), dim3(64), 0, s, partial, dbias, n_slabs, slab_floats, B, H,
                        vn_cdiv(T, 64), nbuckets, accumulate ? 1 : 0);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;

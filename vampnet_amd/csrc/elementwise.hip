@@ -11,7 +11,7 @@
 template <int VEC>
 __device__ __forceinline__ void vn_rmsnorm_row(const f32x4 (&v)[VEC], const float* __restrict__ w, float* __restrict__ y,
                                                uint16_t* __restrict__ y16, long plane16, int row, int D, float eps, int lane,
-                                               unsigned* sat) {
+                                               unsigned* sat, bool both = false) {
     bool bad = false;         // fp16 planes: saturation ledger (vn_common.h)
     float ss = 0.f;           // explicit fma chain: nothing is left to the compiler's contraction choices, which differ between kernels
 #pragma unroll
@@ -34,8 +34,9 @@ __device__ __forceinline__ void vn_rmsnorm_row(const f32x4 (&v)[VEC], const floa
         o[1] = ww[1] * (v[i][1] * rstd);
         o[2] = ww[2] * (v[i][2] * rstd);
         o[3] = ww[3] * (v[i][3] * rstd);
-        if (y16) {     // bf16 / bf16x3 modes: the normalised row is only ever a GEMM A operand
+        if (y16) {     // bf16 / bf16x3 modes: the normalised row is only ever a GEMM A operand (training: `both`, the backward reads y)
             vn_store_planes4(y16, plane16, row, 4 * (lane + 64 * i), D, o, bad);
+            if (both) yr[lane + 64 * i] = o;
         } else {
             yr[lane + 64 * i] = o;
         }
@@ -46,7 +47,7 @@ __device__ __forceinline__ void vn_rmsnorm_row(const f32x4 (&v)[VEC], const floa
 template <int VEC>   // VEC = float4 per lane = D / 256
 __global__ __launch_bounds__(256) void vn_rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          float* __restrict__ y, uint16_t* __restrict__ y16, long plane16,
-                                                         int rows, int D, float eps, unsigned* sat) {
+                                                         int rows, int D, float eps, unsigned* sat, int both) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void vn_rmsnorm_kernel(const float* __restrict
     f32x4 v[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) v[i] = xr[lane + 64 * i];
-    vn_rmsnorm_row<VEC>(v, w, y, y16, plane16, row, D, eps, lane, sat);
+    vn_rmsnorm_row<VEC>(v, w, y, y16, plane16, row, D, eps, lane, sat, both != 0);
 }
 
 // Split-K reduce of a RESIDUAL GEMM fused with the RMSNorm that follows it in the layer (x += sum of the split images, in the
@@ -215,12 +216,12 @@ __global__ __launch_bounds__(256) void vn_rmsnorm_generic_kernel(const float* __
 }
 
 int vn_launch_rmsnorm(vn_ctx* ctx, const float* x, const float* w, float* y, int rows, int D, float eps,
-                      hipStream_t s, uint16_t* y16, long plane16) {
+                      hipStream_t s, uint16_t* y16, long plane16, bool both) {
     if (rows <= 0) return VN_OK;
     if (D % 4) return vn_fail(ctx, VN_ERR_INVALID, "rmsnorm: D=%s%ld must be a multiple of 4", "", D);
     const dim3 grid(vn_cdiv(rows, 4)), block(256);
-    if (D == 1280) hipLaunchKernelGGL(vn_rmsnorm_kernel<5>, grid, block, 0, s, x, w, y, y16, plane16, rows, D, eps, ctx->sat);
-    else if (D == 256) hipLaunchKernelGGL(vn_rmsnorm_kernel<1>, grid, block, 0, s, x, w, y, y16, plane16, rows, D, eps, ctx->sat);
+    if (D == 1280) hipLaunchKernelGGL(vn_rmsnorm_kernel<5>, grid, block, 0, s, x, w, y, y16, plane16, rows, D, eps, ctx->sat, both ? 1 : 0);
+    else if (D == 256) hipLaunchKernelGGL(vn_rmsnorm_kernel<1>, grid, block, 0, s, x, w, y, y16, plane16, rows, D, eps, ctx->sat, both ? 1 : 0);
     else if (y16) return vn_fail(ctx, VN_ERR_UNSUPPORTED, "rmsnorm: bf16 output needs D in {256, 1280}%s", "");
     else hipLaunchKernelGGL(vn_rmsnorm_generic_kernel, grid, block, 0, s, x, w, y, rows, D, eps);
     VN_LAUNCH_CHECK(ctx);

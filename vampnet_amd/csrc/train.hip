@@ -51,6 +51,11 @@ struct vn_train {
     float lora_scale;
     float *lora_params, *w_base, *h8, *dh8;
     long n_lora;
+    // The GEMMs of the step on the split-plane pipe (gemm_x3.hip; VN_TRAIN_X3, default on): tiled bf16x3 planes of the GEMM weights
+    // and of their transposes (rebuilt by vn_train_sync after every update, same offsets x 3 as params / wT), and scratch planes for
+    // the activation operand of a forward / dX GEMM (a16) and the two transposed operands of a dW GEMM (at16, bt16)
+    bool x3;
+    uint16_t *w16, *wT16, *a16, *at16, *bt16;
 };
 
 enum { LORA_Q = 0, LORA_V = 1, LORA_FC = 2, LORA_W1 = 3, LORA_W2 = 4 };
@@ -141,6 +146,8 @@ extern "C" void vn_train_destroy(vn_train* t) {
     (void)hipFree(t->w_base);
     (void)hipFree(t->h8);
     (void)hipFree(t->dh8);
+    uint16_t* c[] = {t->w16, t->wT16, t->a16, t->at16, t->bt16};
+    for (uint16_t* p : c) (void)hipFree(p);
     delete t;
 }
 
@@ -158,6 +165,8 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
     t->m = m; t->params = params;
     t->lora = false; t->lora_params = t->w_base = t->h8 = t->dh8 = nullptr; t->n_lora = 0; t->lora_scale = 0.f;
     t->dbias_partial = nullptr;
+    t->w16 = t->wT16 = t->a16 = t->at16 = t->bt16 = nullptr;
+    { const char* e = getenv("VN_TRAIN_X3"); t->x3 = !(e && e[0] == '0'); }
     const vn_dims& d = m->d;
     const long D = m->D, L = m->L, rows = m->max_rows;
     t->NV = m->Cp * d.vocab;
@@ -193,6 +202,14 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
     A(&t->delta, (size_t)d.max_batch * m->H * d.max_T); A(&t->scal, 16);
     t->dbias_slab = (long)d.max_batch * m->H * vn_cdiv(d.max_T, 64) * 64;
     A(&t->dbias_partial, (size_t)t->dbias_slab * L);
+    if (t->x3) {
+        const size_t rows16 = ((size_t)rows + 15) & ~(size_t)15;
+        if (rc == VN_OK) rc = talloc(ctx, &t->w16, (size_t)3 * w);
+        if (rc == VN_OK) rc = talloc(ctx, &t->wT16, (size_t)3 * ((size_t)t->wT_layer * L + (size_t)t->NV * D));
+        if (rc == VN_OK) rc = talloc(ctx, &t->a16, (size_t)3 * rows16 * (size_t)wide);
+        if (rc == VN_OK) rc = talloc(ctx, &t->at16, (size_t)3 * wide * t->Mp_max);
+        if (rc == VN_OK) rc = talloc(ctx, &t->bt16, (size_t)3 * 2 * D * t->Mp_max);
+    }
     if (rc == VN_OK) rc = talloc(ctx, &t->npartial, 1024);
     if (rc == VN_OK) rc = talloc(ctx, &t->t32, (size_t)rows * m->Cp);
     if (rc == VN_OK) rc = talloc(ctx, &t->n_valid, 4);
@@ -211,6 +228,31 @@ extern "C" int vn_train_sync(vn_train* t, void* stream) {
     int rc;
     float* clsW = t->params + vn_tensor_offset(&m->d, VN_W_CLS_W, 0);
     if ((rc = vn_launch_weight_norm_fold(ctx, t->params + t->off_g, t->params + t->off_v, clsW, t->NV, D, s))) return rc;
+    // every dX GEMM on the split-plane pipe (D and NV multiples of 64): the fp32 W^T copies are never read — their planes come straight
+    // from W through the transposing splitter; otherwise (odd widths, VN_TRAIN_X3=0) the fp32 copies feed the fp32 kernel
+    const bool all_x3 = t->x3 && !(D & 63) && !(t->NV & 63);
+    if (all_x3) {
+        auto planes = [&](const float* w, uint16_t* dst, int rows, int K) { return vn_launch_split3_tiled(ctx, w, dst, rows, K, K, s); };
+        auto planesT = [&](const float* w, uint16_t* dst, int rows, int K) {        // planes of w^T [K][rows] from w [rows][K]
+            return vn_launch_transpose_split3_tiled(ctx, w, dst, rows, K, K, rows, s);
+        };
+        for (int l = 0; l < m->L; ++l) {
+            uint16_t* b16 = t->wT16 + 3 * (t->wT_layer * l);
+            const float *wq = P(t, VN_W_QKV, l), *wo = P(t, VN_W_WO, l), *w1 = P(t, VN_W_W1, l), *w2 = P(t, VN_W_W2, l);
+            if ((rc = planes(wq, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_QKV, l), 3 * D, D)) ||
+                (rc = planes(wo, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_WO, l), D, D)) ||
+                (rc = planes(w1, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_W1, l), 4 * D, D)) ||
+                (rc = planes(w2, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_W2, l), D, 2 * D)) ||
+                (rc = planesT(wq, b16, 3 * D, D)) || (rc = planesT(wo, b16 + 3 * (3L * D * D), D, D)) ||
+                (rc = planesT(w1, b16 + 3 * (4L * D * D), 4 * D, D)) || (rc = planesT(w2, b16 + 3 * (8L * D * D), D, 2 * D)))
+                return rc;
+        }
+        if ((rc = planes(clsW, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_CLS_W, 0), t->NV, D)) ||
+            (rc = planesT(clsW, t->wT16 + 3 * t->wT_cls, t->NV, D)))
+            return rc;
+        m->bias_T = -1;
+        return VN_OK;
+    }
     for (int l = 0; l < m->L; ++l) {
         float* base = t->wT + t->wT_layer * l;
         if ((rc = vn_launch_transpose(ctx, P(t, VN_W_QKV, l), base, 3 * D, D, D, 3 * D, s))) return rc;
@@ -219,6 +261,26 @@ extern "C" int vn_train_sync(vn_train* t, void* stream) {
         if ((rc = vn_launch_transpose(ctx, P(t, VN_W_W2, l), base + 8L * D * D, D, 2 * D, 2 * D, D, s))) return rc;
     }
     if ((rc = vn_launch_transpose(ctx, clsW, t->wT + t->wT_cls, t->NV, D, D, t->NV, s))) return rc;
+    if (t->x3) {
+        // the split planes of every GEMM weight and of its transpose, in the tiled layout (gemm_x3.hip): 10 bytes of traffic per
+        // weight and copy, ~2 ms per update of the coarse model — what lets a forward / dX GEMM of the step split only its activation
+        auto planes = [&](const float* w, uint16_t* dst, int rows, int K) { return vn_launch_split3_tiled(ctx, w, dst, rows, K, K, s); };
+        for (int l = 0; l < m->L; ++l) {
+            const float* base = t->wT + t->wT_layer * l;
+            uint16_t* b16 = t->wT16 + 3 * (t->wT_layer * l);
+            if ((rc = planes(P(t, VN_W_QKV, l), t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_QKV, l), 3 * D, D)) ||
+                (rc = planes(P(t, VN_W_WO, l), t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_WO, l), D, D)) ||
+                (rc = planes(P(t, VN_W_W1, l), t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_W1, l), 4 * D, D)) ||
+                (rc = planes(P(t, VN_W_W2, l), t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_W2, l), D, 2 * D)) ||
+                (rc = planes(base, b16, D, 3 * D)) || (rc = planes(base + 3L * D * D, b16 + 3 * (3L * D * D), D, D)) ||
+                (rc = planes(base + 4L * D * D, b16 + 3 * (4L * D * D), D, 4 * D)) ||
+                (rc = planes(base + 8L * D * D, b16 + 3 * (8L * D * D), 2 * D, D)))
+                return rc;
+        }
+        if ((rc = planes(clsW, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_CLS_W, 0), t->NV, D)) ||
+            (rc = planes(t->wT + t->wT_cls, t->wT16 + 3 * t->wT_cls, D, t->NV)))
+            return rc;
+    }
     m->bias_T = -1;                 // the relative-position table is a parameter too
     return VN_OK;
 }
@@ -233,48 +295,40 @@ static vn_drop make_drop(const vn_train_params* p, int layer, int site, long row
     return d;
 }
 
-// Opt-in (VN_TRAIN_X3=1; parity-green on MI355X, tests/test_gpu_train.py::test_training_step_on_bf16x3_gemms; 102.5 vs 99.6 ms
-// per step, so not the default): route every GEMM of the training step — forward, dX and dW —
-// through the bf16x3 kernel (gemm_x3.hip, verified on the inference path).  Both fp32 operands are split into their three
-// exact bf16 planes on the fly (vn_split3_f32: two extra HBM passes per GEMM, ~10 % of its time), so nothing else in
-// the step changes; bf16 keeps fp32's exponent range, which the tiny dlogits / dY magnitudes of the backward pass need
-// (an fp16-based split would not).  Scratch planes are per process and grow on demand (hipFree synchronises).
-static bool train_x3() {
-    static const bool on = [] { const char* e = getenv("VN_TRAIN_X3"); return e && e[0] == '1'; }();
-    return on;
+// The GEMMs of the training step — forward, dX and dW — on the split-plane pipe (gemm_x3.hip, bf16x3: six bf16-MFMA products of
+// exact three-way operand splits, fp32 accumulation: fp32-grade, and bf16 keeps fp32's exponent range, which the tiny dlogits / dY
+// magnitudes of the backward pass need; an fp16-based split would not).  Default since round 5 (VN_TRAIN_X3=0: the fp32-input MFMA
+// kernel).  Round 2's opt-in form split BOTH fp32 operands of every GEMM on the fly into planar planes (two extra HBM passes per GEMM)
+// and came out slower than the fp32 kernel; now
+//   * the weights and their transposes are split ONCE per update, into the tiled layout (vn_train_sync),
+//   * a forward / dX GEMM splits only its activation operand (one pass, tiled: vn_launch_split3_tiled),
+//   * a dW GEMM gets both operands from the transposes it needed anyway, which now write tiled planes instead of fp32
+//     (vn_launch_transpose_split3_tiled: 6 instead of 4 bytes written per element, no separate split pass).
+// Shapes the kernel does not take (N % 64, K % 32) stay on the fp32 kernel.
+static const uint16_t* weight_planes(const vn_train* t, const float* W) {
+    if (W >= t->params && W < t->params + t->wsize) return t->w16 + 3 * (W - t->params);
+    const long wT_total = t->wT_layer * t->m->L + (long)t->NV * t->m->D;
+    if (W >= t->wT && W < t->wT + wT_total) return t->wT16 + 3 * (W - t->wT);
+    return nullptr;
 }
-static uint16_t* x3_scratch(int which, size_t elems) {
-    static uint16_t* buf[2] = {nullptr, nullptr};
-    static size_t cap[2] = {0, 0};
-    if (cap[which] < elems) {
-        if (buf[which]) (void)hipFree(buf[which]);
-        buf[which] = nullptr; cap[which] = 0;
-        const size_t want = elems + elems / 4;
-        if (hipMalloc((void**)&buf[which], want * sizeof(uint16_t)) != hipSuccess) return nullptr;
-        cap[which] = want;
-    }
-    return buf[which];
-}
-static int gemm_x3_on_the_fly(vn_ctx* ctx, vn_gemm_args a, int epi, hipStream_t s) {
-    if ((a.N & 63) || (a.K & 31)) return vn_launch_gemm_f32(ctx, a, epi, s);          // shapes the x3 kernel does not take
-    const long na = (long)a.M * a.K, nw = (long)a.N * a.K;
-    const long pa = (na + 63) & ~63L, pw = (nw + 63) & ~63L;
-    uint16_t* A3 = x3_scratch(0, (size_t)3 * pa);
-    uint16_t* W3 = x3_scratch(1, (size_t)3 * pw);
-    if (!A3 || !W3) return vn_fail(ctx, VN_ERR_OOM, "training bf16x3: scratch planes%s", "");
+// a: an fp32 GEMM (A [M][K] row-major, W one of the step's weight tensors or transposes)
+// can this GEMM shape run on the split-plane pipe ?  (its producer may then write the planes of A into t->a16 itself: a_ready)
+static bool x3_shape(const vn_train* t, int N, int K) { return t->x3 && !(N & 63) && !(K & 31); }
+static int gemm_args(vn_train* t, vn_gemm_args a, int epi, hipStream_t s, bool a_ready = false) {
+    vn_ctx* ctx = t->m->ctx;
+    const uint16_t* w16 = t->x3 ? weight_planes(t, a.W) : nullptr;
+    if (!w16 || !x3_shape(t, a.N, a.K)) return vn_launch_gemm_f32(ctx, a, epi, s);
     int rc;
-    if ((rc = vn_split3_f32(ctx, a.A, A3, na, pa, s))) return rc;
-    if ((rc = vn_split3_f32(ctx, a.W, W3, nw, pw, s))) return rc;
-    a.A = (const float*)A3; a.W = (const float*)W3; a.bf16 = 2; a.a_plane = pa; a.w_plane = pw;
+    if (!a_ready && (rc = vn_launch_split3_tiled(ctx, a.A, t->a16, a.M, a.K, a.K, s))) return rc;
+    a.A = (const float*)t->a16; a.W = (const float*)w16; a.bf16 = 2; a.a_plane = VN_PLANES_TILED; a.w_plane = VN_PLANES_TILED; a.w_tiled = 1;
     return vn_launch_gemm_x3(ctx, a, epi, s);
 }
 
-static int gemm(vn_ctx* ctx, const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int epi,
-                hipStream_t s) {
+static int gemm(vn_train* t, const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int epi,
+                hipStream_t s, bool a_ready = false) {
     vn_gemm_args a{};
     a.A = A; a.W = W; a.bias = bias; a.C = C; a.M = M; a.N = N; a.K = K; a.ldc = N;
-    if (train_x3()) return gemm_x3_on_the_fly(ctx, a, epi, s);
-    return vn_launch_gemm_f32(ctx, a, epi, s);
+    return gemm_args(t, a, epi, s, a_ready);
 }
 
 static int params_ok(vn_ctx* ctx, const vn_train_params* p) {
@@ -396,24 +450,29 @@ static int forward_train(vn_train* t, int B, int T, const vn_train_params* p, hi
     for (int l = 0; l < L; ++l) {
         vn_layer_stash& S = t->st[l];
         float* x_out = l + 1 < L ? t->st[l + 1].x_in : t->x_last;
-        if ((rc = vn_launch_rmsnorm(ctx, S.x_in, P(t, VN_W_NORM1, l), S.y1, M, D, m->d.eps, s))) return rc;
+        // producers write the tiled planes of the next GEMM's A operand from the registers that hold the values (t->a16) where the kernel
+        // can (RMSNorm: D in {256, 1280}; GEGLU) — no split pass for those operands
+        const bool n16 = (D == 256 || D == 1280) && x3_shape(t, 3 * D, D);
+        if ((rc = vn_launch_rmsnorm(ctx, S.x_in, P(t, VN_W_NORM1, l), S.y1, M, D, m->d.eps, s, n16 ? t->a16 : nullptr, VN_PLANES_TILED, true))) return rc;
         vn_gemm_args a{};
         a.A = S.y1; a.W = P(t, VN_W_QKV, l); a.C = S.qkv; a.M = M; a.N = 3 * D; a.K = D; a.ldc = 3 * D;
         a.T = T; a.H = H; a.qkv_plane = plane;
-        if ((rc = train_x3() ? gemm_x3_on_the_fly(ctx, a, VN_EPI_QKV, s) : vn_launch_gemm_f32(ctx, a, VN_EPI_QKV, s))) return rc;
+        if ((rc = gemm_args(t, a, VN_EPI_QKV, s, n16))) return rc;
         if ((rc = vn_launch_attention_train_fwd(ctx, S.qkv, S.qkv + plane, S.qkv + 2 * plane, m->bias_full, S.a, S.lse, B, H, T,
                                                 make_drop(p, l, SITE_ATTN, r_att), s)))
             return rc;
-        if ((rc = gemm(ctx, S.a, P(t, VN_W_WO, l), nullptr, t->tmp, M, D, D, VN_EPI_STORE, s))) return rc;
+        if ((rc = gemm(t, S.a, P(t, VN_W_WO, l), nullptr, t->tmp, M, D, D, VN_EPI_STORE, s))) return rc;
         if ((rc = vn_launch_resid_dropout(ctx, S.x_in, t->tmp, S.x_mid, M, D, make_drop(p, l, SITE_RES1, r_tok), s))) return rc;
-        if ((rc = vn_launch_rmsnorm(ctx, S.x_mid, P(t, VN_W_NORM3, l), S.y3, M, D, m->d.eps, s))) return rc;
-        if ((rc = gemm(ctx, S.y3, P(t, VN_W_W1, l), nullptr, S.u, M, 4 * D, D, VN_EPI_STORE, s))) return rc;
-        if ((rc = vn_launch_geglu_train(ctx, S.u, nullptr, S.g, M, 2 * D, make_drop(p, l, SITE_FFN, r_tok), false, s))) return rc;
-        if ((rc = gemm(ctx, S.g, P(t, VN_W_W2, l), nullptr, t->tmp, M, D, 2 * D, VN_EPI_STORE, s))) return rc;
+        if ((rc = vn_launch_rmsnorm(ctx, S.x_mid, P(t, VN_W_NORM3, l), S.y3, M, D, m->d.eps, s, n16 ? t->a16 : nullptr, VN_PLANES_TILED, true))) return rc;
+        if ((rc = gemm(t, S.y3, P(t, VN_W_W1, l), nullptr, S.u, M, 4 * D, D, VN_EPI_STORE, s, n16))) return rc;
+        const bool g16 = x3_shape(t, D, 2 * D);
+        if ((rc = vn_launch_geglu_train(ctx, S.u, nullptr, S.g, M, 2 * D, make_drop(p, l, SITE_FFN, r_tok), false, s, g16 ? t->a16 : nullptr))) return rc;
+        if ((rc = gemm(t, S.g, P(t, VN_W_W2, l), nullptr, t->tmp, M, D, 2 * D, VN_EPI_STORE, s, g16))) return rc;
         if ((rc = vn_launch_resid_dropout(ctx, S.x_mid, t->tmp, x_out, M, D, make_drop(p, l, SITE_RES2, r_tok), s))) return rc;
     }
-    if ((rc = vn_launch_rmsnorm(ctx, t->x_last, P(t, VN_W_FINAL_NORM), t->y_f, M, D, m->d.eps, s))) return rc;
-    return gemm(ctx, t->y_f, P(t, VN_W_CLS_W), P(t, VN_W_CLS_B), m->logits, M, t->NV, D, VN_EPI_BIAS, s);
+    const bool f16 = (D == 256 || D == 1280) && x3_shape(t, t->NV, D);
+    if ((rc = vn_launch_rmsnorm(ctx, t->x_last, P(t, VN_W_FINAL_NORM), t->y_f, M, D, m->d.eps, s, f16 ? t->a16 : nullptr, VN_PLANES_TILED, true))) return rc;
+    return gemm(t, t->y_f, P(t, VN_W_CLS_W), P(t, VN_W_CLS_B), m->logits, M, t->NV, D, VN_EPI_BIAS, s, f16);
 }
 
 // dW[N][K] = dY^T X   (dY [M][N], X [M][K]) through the two transposes
@@ -421,9 +480,20 @@ static int grad_weight(vn_train* t, const float* dY, const float* X, float* dW, 
     vn_ctx* ctx = t->m->ctx;
     const int Mp = (M + 31) & ~31;
     int rc;
+    if (t->x3 && !(N & 15) && !(K & 63)) {
+        // both operands as tiled planes straight out of the transposes: A = dY^T [N][Mp], W = X^T [K][Mp], contraction over the tokens
+        if ((rc = vn_launch_transpose_split3_tiled(ctx, dY, t->at16, M, N, N, Mp, s))) return rc;
+        if ((rc = vn_launch_transpose_split3_tiled(ctx, X, t->bt16, M, K, K, Mp, s))) return rc;
+        vn_gemm_args a{};
+        a.A = (const float*)t->at16; a.W = (const float*)t->bt16; a.C = dW; a.M = N; a.N = K; a.K = Mp; a.ldc = K;
+        a.bf16 = 2; a.a_plane = VN_PLANES_TILED; a.w_plane = VN_PLANES_TILED; a.w_tiled = 1;
+        return vn_launch_gemm_x3(ctx, a, VN_EPI_STORE, s);
+    }
     if ((rc = vn_launch_transpose(ctx, dY, t->At, M, N, N, Mp, s))) return rc;
     if ((rc = vn_launch_transpose(ctx, X, t->Bt, M, K, K, Mp, s))) return rc;
-    return gemm(ctx, t->At, t->Bt, nullptr, dW, N, K, Mp, VN_EPI_STORE, s);
+    vn_gemm_args a{};
+    a.A = t->At; a.W = t->Bt; a.C = dW; a.M = N; a.N = K; a.K = Mp; a.ldc = K;
+    return vn_launch_gemm_f32(ctx, a, VN_EPI_STORE, s);
 }
 
 // Backward over the stages hi >= ... >= lo of the stashed forward: stage L = classifier + final norm, stages L-1 .. 0 =
@@ -446,7 +516,7 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
     float* dx2 = t->dxb;
     if (hi >= L) {
     // ---- classifier (WNConv1d 1x1, transformer.py:596-604) + final norm
-    if ((rc = gemm(ctx, dlog, t->wT + t->wT_cls, nullptr, t->dy, M, D, NV, VN_EPI_STORE, s))) return rc;
+    if ((rc = gemm(t, dlog, t->wT + t->wT_cls, nullptr, t->dy, M, D, NV, VN_EPI_STORE, s))) return rc;
     if (!lora) {
         float* dWc = G(t, grads, VN_W_CLS_W);
         if ((rc = grad_weight(t, dlog, t->y_f, dWc, M, NV, D, s))) return rc;
@@ -470,12 +540,13 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
         if (lora) rc = lora_grads(t, S.g, 2 * D, dh, D, l, LORA_W2, grads, M, s);
         else rc = grad_weight(t, dh, S.g, G(t, grads, VN_W_W2, l), M, D, 2 * D, s);
         if (rc) return rc;
-        if ((rc = gemm(ctx, dh, wTl + 8L * D * D, nullptr, t->dg, M, 2 * D, D, VN_EPI_STORE, s))) return rc;
-        if ((rc = vn_launch_geglu_train(ctx, S.u, t->dg, t->du, M, 2 * D, make_drop(p, l, SITE_FFN, r_tok), true, s))) return rc;
+        if ((rc = gemm(t, dh, wTl + 8L * D * D, nullptr, t->dg, M, 2 * D, D, VN_EPI_STORE, s))) return rc;
+        const bool du16 = x3_shape(t, D, 4 * D);       // du's planes for the dX GEMM below (grad_weight in between uses at16 / bt16 only)
+        if ((rc = vn_launch_geglu_train(ctx, S.u, t->dg, t->du, M, 2 * D, make_drop(p, l, SITE_FFN, r_tok), true, s, du16 ? t->a16 : nullptr))) return rc;
         if (lora) rc = lora_grads(t, S.y3, D, t->du, 4 * D, l, LORA_W1, grads, M, s);
         else rc = grad_weight(t, t->du, S.y3, G(t, grads, VN_W_W1, l), M, 4 * D, D, s);
         if (rc) return rc;
-        if ((rc = gemm(ctx, t->du, wTl + 4L * D * D, nullptr, t->dy, M, D, 4 * D, VN_EPI_STORE, s))) return rc;
+        if ((rc = gemm(t, t->du, wTl + 4L * D * D, nullptr, t->dy, M, D, 4 * D, VN_EPI_STORE, s, du16))) return rc;
         if ((rc = vn_launch_rmsnorm_bwd(ctx, S.x_mid, P(t, VN_W_NORM3, l), t->dy, dx, dx2, lora ? junk : G(t, grads, VN_W_NORM3, l),
                                         t->partial, M, D, m->d.eps, s)))
             return rc;
@@ -486,7 +557,7 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
         if (lora) rc = lora_grads(t, S.a, D, dh2, D, l, LORA_FC, grads, M, s);
         else rc = grad_weight(t, dh2, S.a, G(t, grads, VN_W_WO, l), M, D, D, s);
         if (rc) return rc;
-        if ((rc = gemm(ctx, dh2, wTl + 3L * D * D, nullptr, t->da, M, D, D, VN_EPI_STORE, s))) return rc;
+        if ((rc = gemm(t, dh2, wTl + 3L * D * D, nullptr, t->da, M, D, D, VN_EPI_STORE, s))) return rc;
         if ((rc = vn_launch_attention_bwd(ctx, S.qkv, S.qkv + plane, S.qkv + 2 * plane, m->bias_full, m->lut, S.a, t->da, S.lse,
                                           t->delta, t->dqkv, lora ? nullptr : t->dbias_partial + t->dbias_slab * l, B, H, T,
                                           m->d.num_buckets,
@@ -499,7 +570,7 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
             rc = grad_weight(t, t->dqkv, S.y1, G(t, grads, VN_W_QKV, l), M, 3 * D, D, s);
         }
         if (rc) return rc;
-        if ((rc = gemm(ctx, t->dqkv, wTl, nullptr, t->dy, M, D, 3 * D, VN_EPI_STORE, s))) return rc;
+        if ((rc = gemm(t, t->dqkv, wTl, nullptr, t->dy, M, D, 3 * D, VN_EPI_STORE, s))) return rc;
         if ((rc = vn_launch_rmsnorm_bwd(ctx, S.x_in, P(t, VN_W_NORM1, l), t->dy, dx2, dx, lora ? junk : G(t, grads, VN_W_NORM1, l),
                                         t->partial, M, D, m->d.eps, s)))
             return rc;

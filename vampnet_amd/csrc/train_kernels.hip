@@ -103,14 +103,18 @@ __device__ __forceinline__ float vn_gelu_tanh_grad(float x) {
     return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x2);
 }
 
+// out16 (optional): the result once more as TILED bf16x3 planes — the A operand of the GEMM that consumes it on the split-plane pipe
+// (forward: g [M][D2] -> W2; backward: du [M][2 D2] -> dX of W1), written from the registers that hold it instead of by a split pass
 template <bool BWD>
 __global__ __launch_bounds__(256) void vn_geglu_train_kernel(const float* __restrict__ u, const float* __restrict__ dg,
-                                                             float* __restrict__ out, int M, int D2, vn_drop d) {
+                                                             float* __restrict__ out, uint16_t* __restrict__ out16, int M, int D2, vn_drop d) {
     const int n4 = D2 / 4;
     const long total = (long)M * n4;
+    bool bad = false;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
         const int row = (int)(i / n4), o = 4 * (int)(i - (long)row * n4);
-        const size_t ub = (size_t)row * 2 * D2 + 64 * (o >> 5) + (o & 31);
+        const int uc = 64 * (o >> 5) + (o & 31);
+        const size_t ub = (size_t)row * 2 * D2 + uc;
         const f32x4 val = *(const f32x4*)(u + ub);
         const f32x4 gate = *(const f32x4*)(u + ub + 32);
         f32x4 m = {1.f, 1.f, 1.f, 1.f};
@@ -125,6 +129,7 @@ __global__ __launch_bounds__(256) void vn_geglu_train_kernel(const float* __rest
 #pragma unroll
             for (int e = 0; e < 4; ++e) r[e] = val[e] * vn_gelu_tanh(gate[e]) * m[e];
             *(f32x4*)(out + (size_t)row * D2 + o) = r;
+            if (out16) vn_store_planes4(out16, VN_PLANES_TILED, row, o, D2, r, bad);
         } else {
             const f32x4 g = *(const f32x4*)(dg + (size_t)row * D2 + o);
             f32x4 dv, dgt;
@@ -136,18 +141,22 @@ __global__ __launch_bounds__(256) void vn_geglu_train_kernel(const float* __rest
             }
             *(f32x4*)(out + ub) = dv;
             *(f32x4*)(out + ub + 32) = dgt;
+            if (out16) {
+                vn_store_planes4(out16, VN_PLANES_TILED, row, uc, 2 * D2, dv, bad);
+                vn_store_planes4(out16, VN_PLANES_TILED, row, uc + 32, 2 * D2, dgt, bad);
+            }
         }
     }
 }
 
 int vn_launch_geglu_train(vn_ctx* ctx, const float* u, const float* dg, float* out, int M, int D2, const vn_drop& d,
-                          bool bwd, hipStream_t s) {
+                          bool bwd, hipStream_t s, uint16_t* out16) {
     if (M <= 0) return VN_OK;
     if (D2 % 32) return vn_fail(ctx, VN_ERR_INVALID, "geglu: width %s%ld must be a multiple of 32", "", D2);
     const long total = (long)M * (D2 / 4);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (bwd) hipLaunchKernelGGL(vn_geglu_train_kernel<true>, dim3(blocks), dim3(256), 0, s, u, dg, out, M, D2, d);
-    else hipLaunchKernelGGL(vn_geglu_train_kernel<false>, dim3(blocks), dim3(256), 0, s, u, dg, out, M, D2, d);
+    if (bwd) hipLaunchKernelGGL(vn_geglu_train_kernel<true>, dim3(blocks), dim3(256), 0, s, u, dg, out, out16, M, D2, d);
+    else hipLaunchKernelGGL(vn_geglu_train_kernel<false>, dim3(blocks), dim3(256), 0, s, u, dg, out, out16, M, D2, d);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
 }
@@ -317,6 +326,90 @@ int vn_launch_transpose(vn_ctx* ctx, const float* src, float* dst, int R, int C,
     if (R <= 0 || C <= 0) return VN_OK;
     if (ldd % 4 || ldd < R) return vn_fail(ctx, VN_ERR_INVALID, "transpose: bad destination stride %s%ld", "", ldd);
     hipLaunchKernelGGL(vn_transpose_kernel, dim3(vn_cdiv(ldd, 64), vn_cdiv(C, 64)), dim3(256), 0, s, src, dst, R, C, lds_, ldd);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Operands of the training GEMMs on the split-plane pipe (gemm_x3.hip, train.hip): fp32 matrices -> TILED bf16x3 planes
+// ([row / 16][k / 32][plane][16][32], the layout the kernel's LDS-DMA fetches in whole 1 KiB pieces).
+//   vn_split3_tiled_kernel            src [R][K] (row stride lds_) -> planes of the same matrix; one wave per 16 x 32 piece: lane
+//                                     (row r = lane / 4, 8 k's) reads 32 contiguous bytes and writes 16 bytes per plane, the wave's
+//                                     stores are the piece's contiguous 1 KiB.  Rows >= R of the last row block are written as zeros.
+//   vn_transpose_split3_tiled_kernel  src [R][C] -> planes of its TRANSPOSE [C][Rp] (Rp = R rounded up to 32, zero filled): the dW
+//                                     GEMMs contract over the token axis.  64 x 64 tiles through LDS (as vn_transpose_kernel), then
+//                                     each wave writes two 16 x 32 pieces.  C % 16 == 0.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vn_split3_tiled_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int R, int K,
+                                                              int lds_) {
+    const int lane = threadIdx.x & 63;
+    const long piece = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int kblocks = K >> 5;
+    const long n_pieces = (long)((R + 15) >> 4) * kblocks;
+    if (piece >= n_pieces) return;
+    const int rb = (int)(piece / kblocks), kb = (int)(piece - (long)rb * kblocks);
+    const int row = rb * 16 + (lane >> 2), col = kb * 32 + (lane & 3) * 8;
+    f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (row < R) {
+        const f32x4 a = *(const f32x4*)(src + (size_t)row * lds_ + col), b = *(const f32x4*)(src + (size_t)row * lds_ + col + 4);
+        v = f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    }
+    bool bad = false;
+    vn_store_planes8_tiled(dst, VN_PLANES_TILED, row, col, K, v, bad);
+}
+
+int vn_launch_split3_tiled(vn_ctx* ctx, const float* src, uint16_t* dst, int R, int K, int lds_, hipStream_t s) {
+    if (R <= 0 || K <= 0) return VN_OK;
+    if ((K & 31) || (lds_ & 3) || (((uintptr_t)src | (uintptr_t)dst) & 15))
+        return vn_fail(ctx, VN_ERR_INVALID, "split3_tiled: K %% 32, row stride %% 4 and 16-byte aligned operands (K=%s%ld, ld=%ld)", "", K, lds_);
+    const long n_pieces = (long)((R + 15) >> 4) * (K >> 5);
+    hipLaunchKernelGGL(vn_split3_tiled_kernel, dim3((unsigned)((n_pieces + 3) / 4)), dim3(256), 0, s, src, dst, R, K, lds_);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+__global__ __launch_bounds__(256) void vn_transpose_split3_tiled_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int R,
+                                                                        int C, int lds_, int Rp) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;     // 16 x 16 threads, float4 each, 4 passes
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = r0 + ty + 16 * p, c = c0 + 4 * tx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < R) {
+            if (c + 3 < C) v = *(const f32x4*)(src + (size_t)r * lds_ + c);
+            else
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < C) v[e] = src[(size_t)r * lds_ + c + e];
+        }
+        tile[ty + 16 * p][4 * tx + 0] = v[0];
+        tile[ty + 16 * p][4 * tx + 1] = v[1];
+        tile[ty + 16 * p][4 * tx + 2] = v[2];
+        tile[ty + 16 * p][4 * tx + 3] = v[3];
+    }
+    __syncthreads();
+    // output rows = c (64 of them: four blocks of 16), output k = r (64: two blocks of 32); wave w writes the pieces (cb = w, kb = 0 / 1)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cl = wave * 16 + (lane >> 2);                     // column of the tile = output row
+    if (c0 + wave * 16 >= C) return;                            // C % 16 == 0: whole row blocks
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int rl = kb * 32 + (lane & 3) * 8;                // first of this lane's eight tile rows = output k
+        if (r0 + kb * 32 >= Rp) continue;
+        f32x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tile[rl + e][cl];    // rows >= R were loaded as zeros
+        bool bad = false;
+        vn_store_planes8_tiled(dst, VN_PLANES_TILED, c0 + cl, r0 + rl, Rp, v, bad);
+    }
+}
+
+int vn_launch_transpose_split3_tiled(vn_ctx* ctx, const float* src, uint16_t* dst, int R, int C, int lds_, int Rp, hipStream_t s) {
+    if (R <= 0 || C <= 0) return VN_OK;
+    if ((Rp & 31) || Rp < R || (C & 15) || ((uintptr_t)dst & 15))
+        return vn_fail(ctx, VN_ERR_INVALID, "transpose_split3_tiled: Rp %% 32, Rp >= R, C %% 16 (Rp=%s%ld, C=%ld)", "", Rp, C);
+    hipLaunchKernelGGL(vn_transpose_split3_tiled_kernel, dim3(vn_cdiv(Rp, 64), vn_cdiv(C, 64)), dim3(256), 0, s, src, dst, R, C, lds_, Rp);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
 }

@@ -526,8 +526,9 @@ int vn_launch_splitk_reduce_rmsnorm(vn_ctx* ctx, const float* partial, int nspli
                                     long plane16, int rows, int D, float eps, hipStream_t s);
 
 // y16 / out16: bf16 image of the output for the next GEMM; plane16 == 0 one plane, > 0 three split planes that far apart
+// both: write y (fp32) AND y16 (a y16 alone replaces y: the inference path's normalised rows are only ever a GEMM operand)
 int vn_launch_rmsnorm(vn_ctx* ctx, const float* x, const float* w, float* y, int rows, int D, float eps, hipStream_t s,
-                      uint16_t* y16 = nullptr, long plane16 = 0);
+                      uint16_t* y16 = nullptr, long plane16 = 0, bool both = false);
 int vn_launch_embed(vn_ctx* ctx, const int32_t* codes, const float* tables, const float* wt, const float* b,
                     float* x, int B, int C, int T, int V1, int latent, int D, hipStream_t s);
 int vn_launch_attention(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* relbias_full,

@@ -14,12 +14,15 @@ int vn_launch_resid_dropout(vn_ctx* ctx, const float* x_in, const float* y, floa
 int vn_launch_dropout_bwd(vn_ctx* ctx, const float* dy, float* out, int M, int N, const vn_drop& d, hipStream_t s);
 int vn_launch_dropout_mask(vn_ctx* ctx, uint8_t* out, long rows, int cols, const vn_drop& d, hipStream_t s);
 int vn_launch_geglu_train(vn_ctx* ctx, const float* u, const float* dg, float* out, int M, int D2, const vn_drop& d,
-                          bool bwd, hipStream_t s);
+                          bool bwd, hipStream_t s, uint16_t* out16 = nullptr);     // out16: the result also as tiled bf16x3 planes
 int vn_rmsnorm_bwd_blocks(int rows);
 int vn_launch_rmsnorm_bwd(vn_ctx* ctx, const float* x, const float* w, const float* dy, const float* dres, float* dx,
                           float* dw, float* partial, int rows, int D, float eps, hipStream_t s);
 int vn_launch_reduce_rows(vn_ctx* ctx, const float* partial, int nb, int C, float* out, hipStream_t s);
 int vn_launch_transpose(vn_ctx* ctx, const float* src, float* dst, int R, int C, int lds_, int ldd, hipStream_t s);
+// fp32 -> tiled bf16x3 planes (operands of the training GEMMs on the split-plane pipe): the matrix itself / its transpose [C][Rp]
+int vn_launch_split3_tiled(vn_ctx* ctx, const float* src, uint16_t* dst, int R, int K, int lds_, hipStream_t s);
+int vn_launch_transpose_split3_tiled(vn_ctx* ctx, const float* src, uint16_t* dst, int R, int C, int lds_, int Rp, hipStream_t s);
 int vn_launch_colsum(vn_ctx* ctx, const float* src, int R, int C, float* partial, float* out, hipStream_t s);
 int vn_launch_cross_entropy(vn_ctx* ctx, float* logits, const int64_t* target, int32_t* t32, long rows, int V, float ls,
                             int32_t* n_valid, float* row_loss, float* loss, hipStream_t s);
