@@ -445,6 +445,38 @@ def main():
     if args.e2e:                                          # one more, untimed pass with a device sync around every stage
         stages = []
         run(args.steps, sync=stages)
+    if rank == 0 and args.dtype in ("bf16x3", "f32", "f16x2") and not args.e2e:
+        # what the other kinds of hot swap cost (the reference app may swap per request, app.py:181), after everything that is timed:
+        # (1) adapters only, on the resident models: device merge of rank-8 adapters on the five LoRA'd linears of every layer + planes;
+        # (2) back to a model that is still resident: a dictionary lookup
+        from vampnet_amd.engine import LORA_KEYS
+        gl = torch.Generator().manual_seed(5)
+
+        def adapters(dims):
+            sd, D = {}, dims["d_model"]
+            shp = {"self_attn.w_qs": (D, D), "self_attn.w_vs": (D, D), "self_attn.fc": (D, D), "feed_forward.w_1": (4 * D, D),
+                   "feed_forward.w_2": (D, 2 * D)}
+            for l in range(dims["n_layers"]):
+                for k in LORA_KEYS:
+                    o, i = shp[k]
+                    sd[f"transformer.layers.{l}.{k}.lora_A"] = torch.randn(8, i, generator=gl) * 0.01
+                    sd[f"transformer.layers.{l}.{k}.lora_B"] = torch.randn(o, 8, generator=gl) * 0.01
+            return sd
+        la, lb = adapters(W.COARSE_DIMS), adapters(W.C2F_DIMS)
+        itf.coarse.apply_lora(la)                                  # first use: snapshots the un-merged blob (one-off)
+        torch.cuda.synchronize()
+        t_l = time.perf_counter()
+        itf.coarse.apply_lora(la)
+        itf.c2f.apply_lora(lb)
+        torch.cuda.synchronize()
+        setup_s["adapter swap on the resident models (both: pack 8-rank adapters, upload, device merge, planes)"] = round(time.perf_counter() - t_l, 4)
+        itf.coarse.apply_lora(None)
+        itf.c2f.apply_lora(None)
+        itf._resident_put("coarse", "resident://a", itf.coarse)
+        t_c = time.perf_counter()
+        hit = itf._resident_get("coarse", "resident://a")
+        setup_s["swap to a model that is still resident (LRU lookup)"] = round(time.perf_counter() - t_c, 6)
+        assert hit is itf.coarse
 
     if rank == 0:
         tokens = B * (4 * 575 if args.coarse_only else TOKENS_PER_CLIP) * args.steps

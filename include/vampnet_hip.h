@@ -417,6 +417,14 @@ int  vn_lora_param_offset(const vn_dims* dims, int layer, int which, int ab, int
 int  vn_train_enable_lora(vn_train* tr, float* lora_params, float scaling, void* stream);
 /* after changing `lora_params` from outside (checkpoint load): blob <- W + s B A, then vn_train_sync                    */
 int  vn_train_lora_merge(vn_train* tr, void* stream);
+/* Inference-side adapter hot-swap (replaces re-running interface.py:37-46 `_load_model(ckpt, lora_ckpt)` — a whole checkpoint
+ * load, merge and upload — when only the adapters change, app.py:181): blob <- base + s B A for the five LoRA'd linears of every
+ * layer, on the device.  `base_blob` = the model's packed blob with the UN-merged weights (same layout; may not alias the model's
+ * blob), `lora` = an adapter vector in the layout of vn_lora_param_size / _offset (absent adapters: zeros — the merge is then
+ * exact, w + 0).  The model's blob (given at vn_model_create) is OVERWRITTEN in its GEMM-weight regions; the caller then rebuilds
+ * the planes of the precision in use (vn_model_set_bf16x3 / vn_model_set_f16x2 / vn_model_set_bf16 — their buffers keep their
+ * addresses, so captured forward graphs stay valid).  Asynchronous on `stream`.                                              */
+int  vn_model_apply_lora(vn_model* m, const float* base_blob, const float* lora, float scaling, void* stream);
 
 /* The keep-mask the kernels use at one dropout site (site 0: attention probabilities, rows = (b, h, query), cols = keys;
  * 1: attention residual, 2: GEGLU output, 3: FFN residual; rows = (b, t)); out dev u8 [rows][cols].  For parity tests. */

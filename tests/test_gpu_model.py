@@ -428,6 +428,18 @@ def test_interface_from_checkpoint_files_reload_and_lora(eng, tmp_path):
                              coarse_chunk_s=0.05, c2f_chunk_s=0.02)
     assert torch.equal(itf.vamp(z, mask, batch_size=1, seed=2, _sampling_steps=2).cpu(),
                        O.vamp(models2, z, mask, batch_size=1, seed=2, _sampling_steps=2))
+    # ... and back: the first checkpoint is still RESIDENT (packed, uploaded, split): the same object returns, same tokens
+    itf.reload(coarse_ckpt=str(tmp_path / "coarse.pth"))
+    assert itf.coarse is old
+    assert torch.equal(itf.vamp(z, mask, batch_size=2, seed=7, _sampling_steps=3).cpu(), ref)
+    # adapters only, on the resident model: merged on the device, planes rebuilt — the tokens of a FRESH load with that LoRA file;
+    # removing them again gives the base model's tokens
+    fresh_l = itf_l.vamp(z, mask, batch_size=1, seed=7, _sampling_steps=3).cpu()
+    itf.load_lora(coarse_lora_ckpt=str(tmp_path / "lora.pth"))
+    assert torch.equal(itf.vamp(z, mask, batch_size=1, seed=7, _sampling_steps=3).cpu(), fresh_l)
+    assert torch.equal(itf.coarse.blob, itf_l.coarse.blob)                 # same kernel, same bits as the fresh load's merge
+    itf.load_lora(coarse_lora_ckpt="")
+    assert torch.equal(itf.vamp(z, mask, batch_size=2, seed=7, _sampling_steps=3).cpu(), ref)
 
 
 def test_interface_vamp_time_stretch_feedback_gpu(tiny, itf):

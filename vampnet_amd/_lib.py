@@ -98,6 +98,7 @@ SYMBOLS = {
     "vn_lora_param_offset": (C.c_int, [C.POINTER(vn_dims), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "vn_train_enable_lora": (C.c_int, [_P, _P, C.c_float, _P]),
     "vn_train_lora_merge": (C.c_int, [_P, _P]),
+    "vn_model_apply_lora": (C.c_int, [_P, _P, _P, C.c_float, _P]),
     "vn_dropout_keep_mask": (C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int64, C.c_int64,
                                        C.c_int, _P, _P]),
     "vn_attention_train_f32": (C.c_int, [_P] * 10 + [C.c_int] * 5 + [C.c_float, C.c_uint64, _P]),

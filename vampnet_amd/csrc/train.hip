@@ -416,6 +416,28 @@ extern "C" int vn_train_lora_merge(vn_train* t, void* stream) {
     return rc ? rc : vn_train_sync(t, stream);
 }
 
+// inference-side adapter swap (include/vampnet_hip.h): blob <- base + s B A on the five LoRA'd linears of every layer
+extern "C" int vn_model_apply_lora(vn_model* m, const float* base_blob, const float* lora, float scaling, void* stream) {
+    if (!m || !base_blob || !lora) return VN_ERR_INVALID;
+    vn_ctx* ctx = m->ctx;
+    if (base_blob == m->blob) return vn_fail(ctx, VN_ERR_INVALID, "vn_model_apply_lora: the base blob may not alias the model's blob%s", "");
+    if (m->D % 4) return vn_fail(ctx, VN_ERR_UNSUPPORTED, "vn_model_apply_lora: d_model %% 4%s", "");
+    const vn_dims* d = &m->d;
+    const long D = m->D;
+    float* blob = const_cast<float*>(m->blob);           // caller-owned and writable: the model's weights are swapped in place
+    for (int l = 0; l < m->L; ++l)
+        for (int w = 0; w < 5; ++w) {
+            long K, N;
+            lora_shape(d, w, &K, &N);
+            const int id = w <= LORA_V ? VN_W_QKV : w == LORA_FC ? VN_W_WO : w == LORA_W1 ? VN_W_W1 : VN_W_W2;
+            const long off = vn_tensor_offset(d, id, l) + (w == LORA_V ? 2 * D * D : 0);
+            int rc = vn_launch_lora_merge(ctx, base_blob + off, lora + lora_offset(d, l, w, 1), lora + lora_offset(d, l, w, 0), blob + off,
+                                          (int)N, (int)K, scaling, (hipStream_t)stream);
+            if (rc) return rc;
+        }
+    return VN_OK;
+}
+
 // gradients of one LoRA'd linear y = x W^T + s (x At) B^T given X [M][K] (row stride ldx) and dY [M][N] (row stride ldy)
 static int lora_grads(vn_train* t, const float* X, int ldx, const float* dY, int ldy, int l, int which, float* grads, int M,
                       hipStream_t s) {

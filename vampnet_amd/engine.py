@@ -288,6 +288,40 @@ def pack_weights(lib, dims: vn_dims, sd: dict, codebooks: torch.Tensor, merge_lo
     return blob
 
 
+LORA_KEYS = ("self_attn.w_qs", "self_attn.w_vs", "self_attn.fc", "feed_forward.w_1", "feed_forward.w_2")     # transformer.py:67-68, :109-114
+LORA_R = 8                                                                                                     # transformer.py:22
+
+
+def pack_lora_vector(lib, dims: vn_dims, sd: dict) -> torch.Tensor:
+    """loralib tensors of a state_dict (name.lora_A (r, in), name.lora_B (out, r)) -> the engine's adapter vector (include/vampnet_hip.h
+    vn_lora_param_size / _offset: per layer and LoRA'd linear A TRANSPOSED [in][8] then B [out][8], w_1's B rows in the packed order
+    of VN_W_W1).  Linears without adapters in `sd` stay zero: their merge is w + 0."""
+    n = C.c_int64()
+    if lib.vn_lora_param_size(C.byref(dims), C.byref(n)) != 0:
+        raise VnError("vn_lora_param_size rejected the dims")
+    out = torch.zeros(n.value, dtype=torch.float32)
+    D = dims.d_model
+    val = torch.arange(2 * D).view(2 * D // 32, 32)
+    w1_perm = torch.stack([val, val + 2 * D], 1).reshape(-1)
+    off, cnt = C.c_int64(), C.c_int64()
+    for l in range(dims.n_layers):
+        for w, key in enumerate(LORA_KEYS):
+            name = f"transformer.layers.{l}.{key}"
+            a, b = sd.get(name + ".lora_A"), sd.get(name + ".lora_B")
+            if a is None or b is None:
+                continue
+            if a.shape[0] != LORA_R or b.shape[1] != LORA_R:
+                raise VnError(f"{name}: adapters of rank {a.shape[0]} (the engine merges rank-{LORA_R} adapters, transformer.py:22)")
+            a, b = a.float(), b.float()
+            if key == "feed_forward.w_1":
+                b = b[w1_perm]
+            for ab, t in ((0, a.t().contiguous()), (1, b.contiguous())):
+                if lib.vn_lora_param_offset(C.byref(dims), l, w, ab, C.byref(off), C.byref(cnt)) != 0 or t.numel() != cnt.value:
+                    raise VnError(f"{name}: adapter shape {tuple(t.shape)} does not fit the model")
+                out[off.value:off.value + cnt.value] = t.reshape(-1)
+    return out
+
+
 def draw_noise_host(B, N, V, steps, sample_cutoff, b0=0, nb=None, pin=False):
     """torch-CPU noise ledger of one generate() call for a global batch B; returns the rows of items
     [b0, b0+nb): exp [steps, nb*N, V] (zeros on non-sampling steps), unif [steps, nb, N]."""
@@ -327,8 +361,17 @@ class VampNetModel:
         self.chunk_size_s = chunk_size_s
         self.dims = vn_dims(n_layers, n_heads, embedding_dim, n_codebooks, n_conditioning_codebooks, vocab_size,
                             latent_dim, 32, 128, 1e-6, max_batch, max_T)
+        self.blob_base = None        # the packed blob with UN-merged weights, once adapters are (or have been) applied on the device
+        lora_vec = None
         if _blob is not None:        # vampnet_amd.train.Trainer: the model lives on the prefix of the train vector
             self.blob = _blob
+        elif any(".lora_" in k for k in sd):
+            # loralib adapters (interface.py:37-46 + the eval-mode merge): W + (B A) / r is formed ON THE DEVICE from the un-merged
+            # blob — the same kernel a later adapter swap (apply_lora) runs, so a swapped model and a freshly loaded one hold the
+            # same bits
+            self.blob_base = pack_weights(self.lib, self.dims, sd, codebooks, merge_lora=False).to(engine.device)
+            self.blob = self.blob_base.clone()
+            lora_vec = pack_lora_vector(self.lib, self.dims, sd)
         else:
             self.blob = pack_weights(self.lib, self.dims, sd, codebooks).to(engine.device)   # must outlive the vn_model
         h = C.c_void_p()
@@ -338,7 +381,39 @@ class VampNetModel:
         self.blob16 = None
         self.blob3 = None
         self.precision = "f32"
+        if lora_vec is not None:
+            self._merge_lora_vector(lora_vec)
         self.set_precision(precision)
+
+    def _merge_lora_vector(self, vec: torch.Tensor):
+        """blob <- blob_base + (B A) / r on the device (vn_model_apply_lora); planes are NOT refreshed here"""
+        vec = vec.to(self.device, non_blocking=False)
+        self.engine.check(self.lib.vn_model_apply_lora(self.handle, self.blob_base.data_ptr(), vec.data_ptr(), 1.0 / LORA_R,
+                                                       self.engine.stream()), "vn_model_apply_lora")
+        torch.cuda.current_stream(self.device).synchronize()       # `vec` is dropped on return
+
+    def apply_lora(self, lora_sd: dict = None):
+        """Adapter hot-swap on a RESIDENT model (the reference reloads the whole checkpoint for this: interface.py:27-50 via
+        app.py:181): merge the loralib adapters of `lora_sd` (name.lora_A / name.lora_B; None or {} = no adapters) into the un-merged
+        weights on the device and rebuild the planes of the precision in use — tens of milliseconds instead of a checkpoint load,
+        pack and upload.  Captured forward graphs stay valid (every buffer keeps its address)."""
+        if self.blob_base is None:
+            self.blob_base = self.blob.clone()              # no adapters merged so far: the blob IS the base
+        vec = pack_lora_vector(self.lib, self.dims, lora_sd or {})
+        self._merge_lora_vector(vec)
+        self._refresh_planes()
+
+    def _refresh_planes(self):
+        """the fp32 blob changed in place: rebuild the 16-bit images of the precision in use"""
+        want = self.precision
+        if want == "bf16":
+            self.blob16 = None
+        if want == "bf16x3" and self.blob3 is not None:
+            n = self.blob.numel()
+            self.engine.check(self.lib.vn_split3_f32(self.engine.handle, self.blob.data_ptr(), self.blob3.data_ptr(), n, n,
+                                                     self.engine.stream()), "vn_split3_f32")
+        if want != "f32":
+            self.set_precision(want)
 
     def set_precision(self, precision: str):
         """"f32": exact-fp32 MFMA.  "bf16x3" (default): fp32-grade GEMMs evaluated as six bf16 MFMA products of exact three-way

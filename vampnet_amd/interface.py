@@ -115,6 +115,58 @@ class Interface:
         self.coarse_path = Path(coarse_ckpt)
         self.c2f_path = Path(coarse2fine_ckpt) if coarse2fine_ckpt is not None else None
         self.codec_path = Path(codec_ckpt) if codec_ckpt is not None else None
+        self._resident_put("coarse", self.coarse_path, self.coarse)
+        if self.c2f is not None:
+            self._resident_put("c2f", self.c2f_path, self.c2f)
+
+    # ---- resident models: what a hot swap costs -------------------------------------------------------------------------
+    # The reference app swaps models per request (app.py:181 -> load_finetuned -> reload, interface.py:134-174): every swap there is a
+    # checkpoint read + .to(device).  Here a model that was loaded before STAYS packed, uploaded and split on the device (HBM is 288 GB;
+    # a coarse model with its planes and workspace is ~6 GB), keyed by (role, file path, mtime, size): swapping back to it is a
+    # dictionary lookup.  The least recently used entries beyond `max_resident` per role (VN_RESIDENT_MODELS, default 4) are dropped.
+    @staticmethod
+    def _ckpt_key(path):
+        p = Path(path)
+        try:
+            st = p.stat()
+            return (str(p.resolve()), st.st_mtime_ns, st.st_size)
+        except OSError:
+            return (str(p), 0, 0)
+
+    def _resident_put(self, role, path, model):
+        import collections
+        import os
+        if not hasattr(self, "_resident"):
+            self._resident = {"coarse": collections.OrderedDict(), "c2f": collections.OrderedDict()}
+            self.max_resident = max(1, int(os.environ.get("VN_RESIDENT_MODELS", "4")))
+        d = self._resident[role]
+        key = self._ckpt_key(path)
+        d[key] = model
+        d.move_to_end(key)
+        while len(d) > self.max_resident:
+            d.popitem(last=False)
+
+    def _resident_get(self, role, path):
+        d = getattr(self, "_resident", {}).get(role)
+        if not d:
+            return None
+        key = self._ckpt_key(path)
+        m = d.get(key)
+        if m is not None:
+            d.move_to_end(key)
+        return m
+
+    def load_lora(self, coarse_lora_ckpt: str = None, coarse2fine_lora_ckpt: str = None):
+        """Swap the loralib ADAPTERS of the resident models (the constructor's `coarse_lora_ckpt` / `coarse2fine_lora_ckpt`,
+        interface.py:55-67 + :37-46) without touching the base checkpoints: the adapters are merged into the un-merged weights on the
+        device and the planes rebuilt (VampNetModel.apply_lora) — tens of milliseconds.  "" removes a model's adapters."""
+        for model, ck in ((self.coarse, coarse_lora_ckpt), (self.c2f, coarse2fine_lora_ckpt)):
+            if ck is None or model is None:
+                continue
+            sd = {}
+            if ck != "":
+                _load_lora(sd, ck)
+            model.apply_lora(sd)
 
     @classmethod
     def from_state_dicts(cls, codec, coarse_sd, coarse_kwargs, c2f_sd=None, c2f_kwargs=None, device="cuda:0",
@@ -213,13 +265,25 @@ class Interface:
     def reload(self, coarse_ckpt: str = None, c2f_ckpt: str = None):
         """Hot-swap weights (interface.py:146-174); no-op when the path is already loaded."""
         if coarse_ckpt is not None and self.coarse_path != Path(coarse_ckpt):
-            sd, kw = _load_checkpoint(coarse_ckpt)
-            self.coarse = self._make_model(sd, kw, self.coarse.chunk_size_s)
+            hit = self._resident_get("coarse", coarse_ckpt)
+            if hit is not None:                            # loaded before and still resident: nothing to read, pack, upload or split
+                hit.chunk_size_s = self.coarse.chunk_size_s
+                self.coarse = hit
+            else:
+                sd, kw = _load_checkpoint(coarse_ckpt)
+                self.coarse = self._make_model(sd, kw, self.coarse.chunk_size_s)
+                self._resident_put("coarse", coarse_ckpt, self.coarse)
             self.coarse_path = Path(coarse_ckpt)
         if c2f_ckpt is not None and self.c2f_path != Path(c2f_ckpt):
-            sd, kw = _load_checkpoint(c2f_ckpt)
             chunk_s = self.c2f.chunk_size_s if self.c2f is not None else 3
-            self.c2f = self._make_model(sd, kw, chunk_s, self._c2f_max_batch(self.coarse.chunk_size_s, chunk_s))
+            hit = self._resident_get("c2f", c2f_ckpt)
+            if hit is not None:
+                hit.chunk_size_s = chunk_s
+                self.c2f = hit
+            else:
+                sd, kw = _load_checkpoint(c2f_ckpt)
+                self.c2f = self._make_model(sd, kw, chunk_s, self._c2f_max_batch(self.coarse.chunk_size_s, chunk_s))
+                self._resident_put("c2f", c2f_ckpt, self.c2f)
             self.c2f_path = Path(c2f_ckpt)
 
     # ---- unit conversion (interface.py:176-189) -------------------------------------------------
