@@ -329,6 +329,32 @@ typedef struct {
 } vn_codec_op;
 int  vn_codec_create(vn_ctx* ctx, const vn_codec_op* ops, int n_ops, int direction /* 0 encode, 1 decode */, vn_codec** out);
 void vn_codec_destroy(vn_codec* codec);
+/* The same program built WITHOUT a Python host (csrc/codec_plan.hip): the library re-lays the weights (channels-last convolution
+ * weights, the phases of the transposed convolutions, tiled split planes of the layers that run on the matrix-core pipe), records the
+ * layer loop of `direction` for batch B and length n (encode: samples per item, a multiple of the hop; decode: tokens per item) and plans
+ * the arena; the returned vn_codec owns all of it.  `blob_dev`: the codec's tensors as one flat fp32 device blob (256-byte aligned), each
+ * under its state_dict name with weight-norm already folded (`<conv>.weight` = g v / ||v||), in PyTorch's layouts — Conv1d (C_out, C_in,
+ * k), ConvTranspose1d (C_in, C_out, 2 s), alpha (1, C, 1); vn_codec_tensor_name enumerates (name, offset, count), vn_codec_tensor_offset
+ * looks one up.  Names (the lac / DAC module tree as vampnet's call sites use it): encoder.block.0, encoder.block.<1+i>
+ * .block.<j>.block.{0.alpha, 1, 2.alpha, 3}, encoder.block.<1+i>.block.{3.alpha, 4}, encoder.block.<n+1>.alpha, encoder.block.<n+2>,
+ * quantizer.quantizers.<l>.{in_proj, codebook, out_proj}, decoder.model.0, decoder.model.<1+i>.block.{0.alpha, 1, <2+j>...},
+ * decoder.model.<n+1>.alpha, decoder.model.<n+2>.  precision: 0 = fp32-input MFMA everywhere, 2 = bf16x3, 3 = f16x2 (the routing rule
+ * of the Python host: the MFMA-bound convolutions on the split-plane pipe).  Synchronises the device (a setup call).              */
+typedef struct vn_codec_cfg {
+    int32_t encoder_dim;            /* 64                                                                     */
+    int32_t n_rates;                /* number of encoder / decoder blocks (<= 8)                               */
+    int32_t encoder_rates[8];       /* 2, 4, 8, 12 ...                                                         */
+    int32_t decoder_dim;            /* 1536                                                                   */
+    int32_t decoder_rates[8];       /* 12, 8, 4, 2 ...                                                         */
+    int32_t n_codebooks, codebook_size, codebook_dim;
+    int32_t latent_dim;             /* 0: encoder_dim * 2^n_rates                                              */
+} vn_codec_cfg;
+int  vn_codec_weights_size(const vn_codec_cfg* cfg, int64_t* n_floats);
+int  vn_codec_tensor_count(const vn_codec_cfg* cfg, int* n_tensors);
+int  vn_codec_tensor_name(const vn_codec_cfg* cfg, int index, char* name, int name_len, int64_t* offset, int64_t* count);
+int  vn_codec_tensor_offset(const vn_codec_cfg* cfg, const char* name, int64_t* offset, int64_t* count);
+int  vn_codec_create_from_weights(vn_ctx* ctx, const vn_codec_cfg* cfg, const float* blob_dev, int direction, int B, int n,
+                                  int precision, vn_codec** out);
 /* audio dev f32 [B][L] (mono, L a multiple of the hop: codec.preprocess pads) -> codes dev int64 [B][n_codebooks][L / hop]   */
 int  vn_dac_encode(vn_codec* codec, const float* audio_dev, int64_t* codes_dev, void* stream);
 /* codes dev int64 [B][n_codebooks][T] -> audio dev f32 [B][T * hop]                                                           */

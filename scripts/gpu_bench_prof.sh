@@ -10,7 +10,7 @@ cd /tmp
 rm -rf /tmp/px3 /tmp/pf /tmp/pw
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/px3 -o vamp -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/$O/bench_under_rocprof.json 2> $R/$O/trace.err
 for f in $(find /tmp/px3 -name "*kernel_stats.csv"); do cp $f $R/$O/kernel_stats.csv; done
-for f in $(find /tmp/px3 -name "*kernel_trace.csv"); do python $R/scripts/kstats_last_step.py $f vn_embed_kernel 24 14 > $R/$O/last_vamp_kernel_stats.txt 2>&1; done
+for f in $(find /tmp/px3 -name "*kernel_trace.csv"); do python $R/scripts/kstats_last_step.py $f vn_embed_kernel 24 vamp > $R/$O/last_vamp_kernel_stats.txt 2>&1; done
 timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o fetch -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-events > /dev/null 2> $R/$O/pmc_fetch.err
 timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o write -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-events > /dev/null 2> $R/$O/pmc_write.err
 cd $R

@@ -280,6 +280,52 @@ def test_one_call_per_direction_equals_the_layer_calls(eng, cfg, B, frames, prec
     print(f"[{precision}] decode program B={B} T={frames}: {p['n_ops']} launches behind one call, arena {p['arena_bytes'] / 2**20:.1f} MiB")
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2", "f32"])
+@pytest.mark.parametrize("cfg,B,frames", [(D.DAC_TINY_CFG, 3, 21), (D.DAC_DEFAULT_CFG, 2, 9)])
+def test_program_planned_in_c_equals_the_python_recorder(eng, cfg, B, frames, precision):
+    """vn_codec_create_from_weights (csrc/codec_plan.hip: weights re-laid, layer loop recorded and arena planned IN C from a flat blob
+    of state_dict tensors — what a host without Python calls) builds the program the Python recorder builds: vn_dac_encode /
+    vn_dac_decode on it give bitwise the codes / the audio of DacCodec, in every precision, also when run twice; the tensor table
+    covers exactly the tensors the codec reads."""
+    import ctypes as C
+    from vampnet_amd.codec import DacCodec, codec_cfg_struct, pack_codec_blob
+    lib = eng.lib
+    sd = D.synth_dac_state_dict(cfg, 0)
+    ref = DacCodec(sd, cfg, engine=eng, precision=precision)
+    cs = codec_cfg_struct(cfg)
+    blob = pack_codec_blob(lib, cs, sd).cuda()
+    n = C.c_int()
+    assert lib.vn_codec_tensor_count(C.byref(cs), C.byref(n)) == 0 and n.value > 50
+    off, cnt = C.c_int64(), C.c_int64()
+    assert lib.vn_codec_tensor_offset(C.byref(cs), b"decoder.model.0.weight", C.byref(off), C.byref(cnt)) == 0
+    assert cnt.value == sd["decoder.model.0.weight_v"].numel()
+    assert lib.vn_codec_tensor_offset(C.byref(cs), b"no.such.tensor", C.byref(off), C.byref(cnt)) != 0
+    hop = D.hop_length(cfg)
+    pcode = {"f32": 0, "bf16x3": 2, "f16x2": 3}[precision]
+    audio = _audio(B, hop * frames, seed=frames).cuda().reshape(B, hop * frames).contiguous()
+    want = ref.encode(audio.reshape(B, 1, -1), 44100)["codes"]
+    enc, dec = C.c_void_p(), C.c_void_p()
+    eng.check(lib.vn_codec_create_from_weights(eng.handle, C.byref(cs), blob.data_ptr(), 0, B, hop * frames, pcode, C.byref(enc)), "create enc")
+    eng.check(lib.vn_codec_create_from_weights(eng.handle, C.byref(cs), blob.data_ptr(), 1, B, frames, pcode, C.byref(dec)), "create dec")
+    try:
+        for _ in range(2):
+            codes = torch.empty(B, cfg["n_codebooks"], frames, dtype=torch.int64, device="cuda")
+            eng.check(lib.vn_dac_encode(enc, audio.data_ptr(), codes.data_ptr(), eng.stream()), "vn_dac_encode")
+            assert torch.equal(codes, want)
+            wave = torch.empty(B, hop * frames, device="cuda")
+            eng.check(lib.vn_dac_decode(dec, want.data_ptr(), wave.data_ptr(), eng.stream()), "vn_dac_decode")
+            assert torch.equal(wave.reshape(B, 1, -1), ref.decode_codes(want))
+        # a program checks its direction; bad arguments are refused with a message
+        assert lib.vn_dac_decode(enc, want.data_ptr(), wave.data_ptr(), eng.stream()) != 0
+        bad = C.c_void_p()
+        assert lib.vn_codec_create_from_weights(eng.handle, C.byref(cs), blob.data_ptr(), 0, B, hop * frames + 1, pcode, C.byref(bad)) != 0
+        assert b"hop" in lib.vn_last_error(eng.handle)
+        assert lib.vn_codec_create_from_weights(eng.handle, C.byref(cs), blob.data_ptr(), 0, B, hop, 1, C.byref(bad)) != 0
+    finally:
+        lib.vn_codec_destroy(enc)
+        lib.vn_codec_destroy(dec)
+
+
 def test_codec_program_abi_errors(eng):
     """the program entry points return a status + message on bad input (no crash, no exception across the ABI)"""
     import ctypes as C

@@ -29,6 +29,12 @@ class vn_codec_op(C.Structure):
     _fields_ = [("kind", C.c_int32), ("i", C.c_int32 * 16), ("l", C.c_int64 * 2), ("f", C.c_float * 2), ("p", C.c_void_p * 12)]
 
 
+class vn_codec_cfg(C.Structure):
+    _fields_ = [("encoder_dim", C.c_int32), ("n_rates", C.c_int32), ("encoder_rates", C.c_int32 * 8), ("decoder_dim", C.c_int32),
+                ("decoder_rates", C.c_int32 * 8), ("n_codebooks", C.c_int32), ("codebook_size", C.c_int32), ("codebook_dim", C.c_int32),
+                ("latent_dim", C.c_int32)]
+
+
 class vn_train_params(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("weight_decay", C.c_float), ("grad_clip", C.c_float), ("label_smoothing", C.c_float),
@@ -112,6 +118,11 @@ SYMBOLS = {
                                C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
     "vn_codec_create": (C.c_int, [_P, C.POINTER(vn_codec_op), C.c_int, C.c_int, C.POINTER(_P)]),
     "vn_codec_destroy": (None, [_P]),
+    "vn_codec_weights_size": (C.c_int, [C.POINTER(vn_codec_cfg), C.POINTER(C.c_int64)]),
+    "vn_codec_tensor_count": (C.c_int, [C.POINTER(vn_codec_cfg), C.POINTER(C.c_int)]),
+    "vn_codec_tensor_name": (C.c_int, [C.POINTER(vn_codec_cfg), C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "vn_codec_tensor_offset": (C.c_int, [C.POINTER(vn_codec_cfg), C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "vn_codec_create_from_weights": (C.c_int, [_P, C.POINTER(vn_codec_cfg), _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "vn_dac_encode": (C.c_int, [_P, _P, _P, _P]),
     "vn_dac_decode": (C.c_int, [_P, _P, _P, _P]),
     "vn_comm_unique_id": (C.c_int, [_P, _P]),

@@ -62,6 +62,45 @@ def validate_codec_state_dict(sd: dict, cfg: dict):
         raise ValueError(f"decoder stem is {shape('decoder.model.0')}, kwargs say decoder_dim={cfg['decoder_dim']}, latent {latent}")
 
 
+def codec_cfg_struct(cfg: dict):
+    """kwargs of a DAC-family codec -> the vn_codec_cfg a C host hands to vn_codec_create_from_weights (include/vampnet_hip.h)"""
+    cfg = dict(DEFAULT_CFG, **(cfg or {}))
+    c = _lib.vn_codec_cfg()
+    c.encoder_dim, c.decoder_dim = int(cfg["encoder_dim"]), int(cfg["decoder_dim"])
+    c.n_rates = len(cfg["encoder_rates"])
+    assert len(cfg["decoder_rates"]) == c.n_rates <= 8
+    for i, (a, b) in enumerate(zip(cfg["encoder_rates"], cfg["decoder_rates"])):
+        c.encoder_rates[i], c.decoder_rates[i] = int(a), int(b)
+    c.n_codebooks, c.codebook_size, c.codebook_dim = int(cfg["n_codebooks"]), int(cfg["codebook_size"]), int(cfg["codebook_dim"])
+    c.latent_dim = int(cfg["latent_dim"] or 0)
+    return c
+
+
+def pack_codec_blob(lib, cfg_struct, sd: dict) -> torch.Tensor:
+    """The flat fp32 blob vn_codec_create_from_weights reads (host tensor): every tensor the library names (vn_codec_tensor_name) copied
+    from the state_dict under that name, weight-norm folded (`<conv>.weight` = g v / ||v|| where the file holds weight_g / weight_v) —
+    the only arithmetic a C host has to do itself; layouts stay PyTorch's."""
+    import ctypes as C
+    n, cnt = C.c_int64(), C.c_int()
+    if lib.vn_codec_weights_size(C.byref(cfg_struct), C.byref(n)) or lib.vn_codec_tensor_count(C.byref(cfg_struct), C.byref(cnt)):
+        raise ValueError("vn_codec_weights_size rejected the configuration")
+    blob = torch.zeros(n.value, dtype=torch.float32)
+    name = C.create_string_buffer(256)
+    off, num = C.c_int64(), C.c_int64()
+    for i in range(cnt.value):
+        if lib.vn_codec_tensor_name(C.byref(cfg_struct), i, name, 256, C.byref(off), C.byref(num)):
+            raise ValueError(f"vn_codec_tensor_name({i}) failed")
+        key = name.value.decode()
+        if key.endswith(".weight") and key not in sd:
+            t = _fold(sd, key[:-len(".weight")])
+        else:
+            t = sd[key].float()
+        if t.numel() != num.value:
+            raise ValueError(f"codec tensor {key}: the checkpoint holds {tuple(t.shape)}, the configuration expects {num.value} values")
+        blob[off.value:off.value + num.value] = t.contiguous().reshape(-1)
+    return blob
+
+
 class AudioSignal:
     """Minimal stand-in for audiotools.AudioSignal (not installed): samples (B, C, T) + sample_rate."""
 

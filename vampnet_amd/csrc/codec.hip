@@ -18,7 +18,19 @@ struct vn_codec {
     vn_ctx* ctx;
     int direction;                         // 0 = encode (audio -> codes), 1 = decode (codes -> audio)
     std::vector<vn_codec_op> ops;
+    std::vector<void*> owned;              // device allocations the program owns (vn_codec_create_from_weights: re-laid weights + arena)
 };
+
+// a program whose weights and arena were built in C (codec_plan.hip): takes the op list and the device allocations over
+vn_codec* vn_codec_adopt(vn_ctx* ctx, int direction, std::vector<vn_codec_op>&& ops, std::vector<void*>&& owned) {
+    vn_codec* c = new (std::nothrow) vn_codec();
+    if (!c) return nullptr;
+    c->ctx = ctx;
+    c->direction = direction;
+    c->ops = std::move(ops);
+    c->owned = std::move(owned);
+    return c;
+}
 
 extern "C" int vn_codec_create(vn_ctx* ctx, const vn_codec_op* ops, int n_ops, int direction, vn_codec** out) {
     if (!ctx || !ops || n_ops <= 0 || !out || (direction != 0 && direction != 1)) return VN_ERR_INVALID;
@@ -34,7 +46,11 @@ extern "C" int vn_codec_create(vn_ctx* ctx, const vn_codec_op* ops, int n_ops, i
     return VN_OK;
 }
 
-extern "C" void vn_codec_destroy(vn_codec* c) { delete c; }
+extern "C" void vn_codec_destroy(vn_codec* c) {
+    if (!c) return;
+    for (void* p : c->owned) (void)hipFree(p);     // hipFree waits for the device: no launch of this program is in flight afterwards
+    delete c;
+}
 
 // pointer slot of an op: the program's own pointers are absolute device addresses; VN_CODEC_PTR_IN / _OUT stand for the call's arguments
 static inline void* bind(void* p, const void* in, void* out) {
