@@ -370,8 +370,10 @@ def main():
 
     stages = None
     if args.e2e:
-        # the whole request of hello.py on resident inputs: 10 s of 44.1 kHz audio per item (already resampled / loudness-normalised:
-        # Interface._preprocess is host scipy code and stays outside) -> DAC encode + RVQ -> build_mask -> vamp -> DAC decode
+        # the whole request of hello.py on resident inputs: 10 s of 44.1 kHz audio per item -> Interface._preprocess (BS.1770 loudness,
+        # gain, peak limit, pad: csrc/preprocess.hip; only a resample of input at another rate would still run on the host) -> DAC
+        # encode + RVQ -> build_mask -> vamp -> DAC decode
+        from vampnet_amd.codec import AudioSignal
         audio = 0.1 * torch.randn(B, 1, 575 * codec.hop_length, device=device, generator=torch.Generator(device=device).manual_seed(7))
 
         def run(seed, sync=None):
@@ -386,7 +388,8 @@ def main():
                 torch.cuda.synchronize()
                 st.append((name, round(1e3 * (time.perf_counter() - t), 3)))
                 return o
-            c = stage("encode", lambda: codec.encode(audio)["codes"])
+            sig = stage("preprocess", lambda: itf._preprocess(AudioSignal(audio, codec.sample_rate)))     # loudness -> gain -> peak limit -> pad, on the device
+            c = stage("encode", lambda: codec.encode(sig.samples)["codes"])
             m = stage("build_mask", lambda: itf.build_mask(c))
             z = stage("vamp", lambda: itf.vamp(c, m, **seed_kw(seed), **kw))
             stage("decode", lambda: itf.decode(z))
@@ -405,14 +408,19 @@ def main():
         barrier()
         if itf.exchange_log is not None:
             del itf.exchange_log[:]
+        codec_eng = getattr(codec, "engine", None) if args.e2e else None
         if not args.no_kernel_events:
             itf.engine.profile_begin(4000 * max(args.steps, 1), stride=args.event_stride)
+            if codec_eng is not None and codec_eng is not itf.engine:       # the codec's convolutions: every launch bracketed (few, long)
+                codec_eng.profile_begin(600 * max(args.steps, 1), stride=1)
         t0 = time.perf_counter()
         for i in range(args.steps):
             out = run(i)
         barrier()
         el = time.perf_counter() - t0
         pr = itf.engine.profile_end() if not args.no_kernel_events else None
+        if pr is not None and codec_eng is not None and codec_eng is not itf.engine:
+            pr["codec_conv1d"] = codec_eng.profile_end()["conv1d"]
         if world > 1:
             import torch.distributed as dist
             t = torch.tensor([el], device=device, dtype=torch.float64)
@@ -484,7 +492,7 @@ def main():
                    "torch_device": "seed-exact parity mode: torch's mt19937 stream continued on the GPU (rng=torch_device)"}[args.rng]
         res = {
             "metric": "codec-tokens/s, coarse vamp (4 codebooks), 10 s clips" if args.coarse_only else
-                      ("codec-tokens/s, whole request: DAC encode + build_mask + coarse+c2f vamp() + DAC decode, 10 s clips" if args.e2e
+                      ("codec-tokens/s, whole request: _preprocess + DAC encode + build_mask + coarse+c2f vamp() + DAC decode, 10 s clips" if args.e2e
                        else "codec-tokens/s, coarse+c2f vamp(), 10 s clips"), "value": tokens / elapsed,
             "unit": "codec-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -502,8 +510,8 @@ def main():
                                 "outside the timed region (tokens in, tokens out); DAC encode/decode parity is UNPINNED "
                                 "(lac sources and weights absent) and no codec figure is part of this line",
                        **({"codec_parity": "unpinned", "stages_ms": dict(stages), "stages_note": "one extra pass with a device "
-                           "synchronise around every stage (the timed passes have none); Interface._preprocess (host resample / LUFS) "
-                           "is outside"} if args.e2e else {}),
+                           "synchronise around every stage (the timed passes have none); Interface._preprocess runs on the device "
+                           "inside the timed region (its parity with audiotools is unpinned like the codec's)"} if args.e2e else {}),
                        "rng": args.rng,
                        "global_batch": B, "coarse_steps": args.coarse_steps,
                        "parallelism": f"batch-shard x{world}" if world > 1 else "single GPU",
@@ -568,6 +576,20 @@ def main():
 
         if prof is not None:
             res["roofline"] = roofline_of(args.dtype, prof, elapsed)
+            if prof.get("codec_conv1d") and prof["codec_conv1d"][0]:
+                # the codec's convolutions (both directions; hipEvents around EVERY launch of the timed region): algorithmic flops =
+                # 2 x MACs of each convolution as launched (the phases of a transposed convolution count their own taps); mixed pipes —
+                # the MFMA-bound layers on the split-plane pipe (ceiling 2500 / 6), the audio-rate 64 / 96-channel layers and the k = 1
+                # tails on the fp32-input MFMA kernel, HBM-bound — so the fraction below is against the split-plane ceiling and is a
+                # LOWER bound on how well the matrix-pipe layers do; parity of every one of these kernels is unpinned
+                cn, cms, cfl, cby = prof["codec_conv1d"]
+                res["codec_roofline"] = {"bound": "mfma (matrix-pipe layers) / hbm (audio-rate and k = 1 layers)", "kernel": "vn_gemm_x3_kernel<CONV> + vn_conv1d_f32_kernel",
+                                         "launches": int(cn), "ms_per_step": cms / args.steps, "achieved": cfl / (cms * 1e-3) / 1e12 if cms else None,
+                                         "unit": "TFLOP/s", "peak": PEAK_BF16_MFMA_TF / 6.0,
+                                         "frac": cfl / (cms * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TF / 6.0) if cms else None,
+                                         "algorithmic_tflop_per_step": cfl / args.steps / 1e12,
+                                         "algorithmic_gbytes_per_step": cby / args.steps / 1e9,
+                                         "achieved_gbytes_per_s": cby / (cms * 1e-3) / 1e9 if cms else None, "codec_parity": "unpinned"}
         res["setup_s"] = setup_s
         res["devices"] = {"world_size": world, "device_count": torch.cuda.device_count(),
                           "exchange_ms": exchange_ms,            # event-timed Interface._allgather_batch, mean per vamp() (None at N = 1)

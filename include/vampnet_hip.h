@@ -360,6 +360,18 @@ int  vn_dac_encode(vn_codec* codec, const float* audio_dev, int64_t* codes_dev, 
 /* codes dev int64 [B][n_codebooks][T] -> audio dev f32 [B][T * hop]                                                           */
 int  vn_dac_decode(vn_codec* codec, const int64_t* codes_dev, float* audio_dev, void* stream);
 
+/* Interface._preprocess on the device (vampnet/interface.py:206-217: normalize(-24 LUFS) -> ensure_max_of_audio(1.0) -> codec.preprocess's
+ * right-pad), for B mono signals already at the codec's sample rate: x dev f32 [B][T] -> y dev f32 [B][Tp] (Tp >= T, zero padded).
+ * ITU-R BS.1770-4 gated integrated loudness in float64 (K-weighting biquads evaluated in parallel over 100 ms chunks through their
+ * state-space form; csrc/preprocess.hip), gain to `target_lufs` (items at or below -70 LUFS keep their level), then the peak limit.
+ * kw12 = the two K-weighting biquads for `sample_rate` (b1[3], a1[3], b2[3], a2[3], a[0] = 1), pow16 = the 4 x 4 state-transition matrix
+ * of their cascade raised to the chunk length sample_rate / 10 (row major) — HOST pointers to float64 values the caller computes
+ * (vampnet_amd/codec.py).  workspace: device scratch of vn_preprocess_workspace bytes.  lufs_out: dev f32 [B] or NULL.  Resampling and
+ * the mono mix stay with the caller.  PARITY UNPINNED (audiotools is not part of the reference tree).                              */
+int vn_preprocess_workspace(int B, int T, int sample_rate, int64_t* n_bytes);
+int vn_preprocess_f32(vn_ctx* ctx, const float* x, float* y, int B, int T, int Tp, int sample_rate, float target_lufs,
+                      const double* kw12, const double* pow16, void* workspace, float* lufs_out, void* stream);
+
 /* Synchronises `stream` and reports whether any stream-K GEMM of this process ever hit its bounded-spin give-up
  * (results would be wrong): VN_OK or VN_ERR_HIP.  The GEMM never hangs the GPU; this is how a caller finds out.   */
 int vn_health_check(vn_ctx* ctx, void* stream);

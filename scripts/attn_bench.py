@@ -30,13 +30,13 @@ def x3(q, k, v, table, out, split, iters=30, np=3):
 
 
 H = 20
-for (B, T) in [(1, 575), (2, 575), (3, 575), (4, 575), (8, 575), (4, 173), (8, 173), (32, 173)]:
+for (B, T) in [(1, 575), (2, 575), (3, 575), (4, 575), (4, 173), (8, 173)]:
     q, k, v = (torch.randn(B, H, T, 64, device="cuda") for _ in range(3))
     table = torch.randn(32, H, device="cuda")
     out = torch.empty(B, T, H * 64, device="cuda")
     fl = 4.0 * T * T * 64 * H * B
-    res = {name: x3(q, k, v, table, out, split) for name, split in (("auto", -1), ("shared", 0), ("ks1", 1), ("ks2", 2), ("ks4", 4))}
-    res2 = {name: x3(q, k, v, table, out, split, np=2) for name, split in (("auto", -1), ("shared", 0), ("ks2", 2))}
+    res = {name: x3(q, k, v, table, out, split) for name, split in (("auto", -1), ("shared", 0), ("ks1", 1), ("ks2", 2), ("ks4", 4), ("pair8", 8))}
+    res2 = {name: x3(q, k, v, table, out, split, np=2) for name, split in (("auto", -1), ("shared", 0), ("ks2", 2), ("pair8", 8))}
     eng.attention(q, k, v, table)                  # fp32-input kernel through its single-op entry (allocates + frees per call)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

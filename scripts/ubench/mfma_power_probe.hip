@@ -6,6 +6,10 @@
 //   mode 1  ONE operand set of RANDOM bf16 bit patterns (exponents confined to 2^-4 .. 2^4)
 //   mode 2  EIGHT random operand sets used round-robin: consecutive MFMAs read different registers (operand buses toggle)
 //   mode 3  mode 2 + a raw s_barrier after every 12 MFMAs (the ping-pong GEMM's phase length), 8 waves per block
+//   mode 4  (round 5) the operands the bf16x3 GEMM really multiplies: the THREE exact split planes (vn_split3: 8 + 8 + 8 significand bits)
+//           of Gaussian activations (sigma 1) and weights (sigma 1 / sqrt(1280)), walked in the kernel's six-product order (A0 W2, A2 W0,
+//           A1 W1, A0 W1, A1 W0, A0 W0) — plane 0 has a narrow exponent field, planes 1 / 2 are residuals 2^-8 / 2^-16 below it with
+//           random mantissas: where between "smooth" (2.4 PF) and "uniformly random words" (1.65 PF) do real planes put the wall?
 // Each mode runs ~0.3 s (DVFS settles in milliseconds); prints executed TF and the shader clock from s_memtime / wall time.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -27,13 +31,42 @@ __device__ __forceinline__ bf16x8 random_set(unsigned& s) {
     return __builtin_bit_cast(bf16x8, w);
 }
 
+__device__ __forceinline__ float gauss(unsigned& s) {          // Box-Muller from two LCG draws
+    const float u1 = ((rnd(s) >> 8) + 1) * (1.0f / 16777217.0f), u2 = (rnd(s) >> 8) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);
+}
+__device__ __forceinline__ unsigned short bf16_rne(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ float bf16_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+// eight Gaussian values (sigma) -> their three exact split planes, as vn_common.h vn_split3
+__device__ __forceinline__ void plane_sets(unsigned& s, float sigma, bf16x8 (&p)[3]) {
+    unsigned short q[3][8];
+    for (int i = 0; i < 8; ++i) {
+        const float x = sigma * gauss(s);
+        q[0][i] = bf16_rne(x);
+        const float r1 = x - bf16_f32(q[0][i]);
+        q[1][i] = bf16_rne(r1);
+        q[2][i] = bf16_rne(r1 - bf16_f32(q[1][i]));
+    }
+    for (int t = 0; t < 3; ++t) {
+        u32x4 w;
+        for (int i = 0; i < 4; ++i) w[i] = q[t][2 * i] | ((unsigned)q[t][2 * i + 1] << 16);
+        p[t] = __builtin_bit_cast(bf16x8, w);
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, int iters) {
-    constexpr int NS = MODE >= 2 ? 8 : 1;
+    constexpr int NS = MODE == 4 ? 3 : MODE >= 2 ? 8 : 1;
     f32x16 acc[4] = {};
     bf16x8 a[NS], b[NS];
     unsigned s = 12345u + threadIdx.x * 977u + blockIdx.x * 131071u;
-    for (int q = 0; q < NS; ++q) {
+    if (MODE == 4) {
+        bf16x8 pa[3], pb[3];
+        plane_sets(s, 1.0f, pa);
+        plane_sets(s, 0.02795f, pb);
+        for (int q = 0; q < 3; ++q) { a[q % NS] = pa[q]; b[q % NS] = pb[q]; }
+    }
+    for (int q = 0; q < NS && MODE != 4; ++q) {
         if (MODE == 0) {
             for (int i = 0; i < 8; ++i) { a[q][i] = (__bf16)(threadIdx.x * 0.001f + i); b[q][i] = (__bf16)(1.0f + i * 0.01f); }
         } else {
@@ -45,6 +78,10 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 24; ++u) {
+            if (MODE == 4) {                                  // the six plane products of a k-step, smallest terms first (gemm_x3.hip: mac_prod)
+                constexpr int QA[6] = {0, 2, 1, 0, 1, 0}, QB[6] = {2, 0, 1, 1, 0, 0};
+                acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[QA[u % 6] % NS], b[QB[u % 6] % NS], acc[u & 3], 0, 0, 0);
+            } else
             acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % NS], b[(u / 2) % NS], acc[u & 3], 0, 0, 0);
             if (MODE == 3 && (u % 12) == 11) __builtin_amdgcn_s_barrier();
         }
@@ -95,6 +132,7 @@ int main() {
         run<1>("one RANDOM operand set", blocks);
         run<2>("eight random operand sets, round-robin", blocks);
         run<3>("eight random sets + s_barrier every 12 MFMAs", blocks);
+        run<4>("the three split planes of Gaussian activations x weights, six-product order", blocks);
     }
     return 0;
 }

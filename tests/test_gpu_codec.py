@@ -326,6 +326,56 @@ def test_program_planned_in_c_equals_the_python_recorder(eng, cfg, B, frames, pr
         lib.vn_codec_destroy(dec)
 
 
+def test_preprocess_on_the_device_equals_the_host_twin(eng):
+    """Interface._preprocess (interface.py:206-217) on the device (csrc/preprocess.hip: BS.1770-4 loudness with the K-weighting IIR
+    filters evaluated in parallel over 100 ms chunks through their state-space form, gain, peak limit, pad) against the all-host
+    twin (scipy lfilter in float64): loudness to 1e-6 LU, samples to 1e-6 relative — a normal clip, a quiet one, one that the gain
+    pushes over full scale (peak limit), silence (stays silent), a clip shorter than one 400 ms block, stereo and a length that is
+    not a multiple of anything.  Both are restatements of audiotools' chain: parity with the reference is UNPINNED."""
+    import ctypes as C
+    from vampnet_amd.codec import AudioSignal, DacCodec, integrated_loudness
+    cfg = D.DAC_TINY_CFG
+    codec = DacCodec(D.synth_dac_state_dict(cfg, 0), cfg, engine=eng, precision="f32")
+    sr = codec.sample_rate
+    g = np.random.default_rng(3)
+    T = 3 * sr + 1234
+    t = np.arange(T) / sr
+    clips = [0.2 * np.sin(2 * np.pi * 220 * t) + 0.05 * g.standard_normal(T),          # normal
+             1e-3 * g.standard_normal(T),                                               # quiet: a large gain
+             0.02 * np.sin(2 * np.pi * 90 * t) + 0.9 * (np.abs(t - 1.5) < 2e-3),        # a click: the gain drives it over full scale
+             np.zeros(T),                                                               # silence
+             0.3 * g.standard_normal(T) * (t > 2.0)]                                    # gated: two thirds of the blocks are silent
+    x = torch.from_numpy(np.stack(clips).astype(np.float32))[:, None, :]
+    x = torch.cat([x, 0.5 * x.flip(0)], dim=1)                                           # stereo: to_mono first
+    for sig in (AudioSignal(x, sr), AudioSignal(x[:2, :, :sr // 5], sr), AudioSignal(x[:1, :1, :7], sr)):
+        dev = codec.preprocess_signal(sig)
+        host = codec.preprocess_signal_host(sig)
+        assert dev.samples.is_cuda and dev.samples.shape == host.samples.shape
+        assert dev.samples.shape[-1] % codec.hop_length == 0
+        d, h = dev.samples.cpu(), host.samples
+        scale = h.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-30)
+        err = ((d - h).abs() / scale).max().item()
+        print(f"T = {sig.samples.shape[-1]}: max relative sample error {err:.2e}; peaks {h.abs().amax(dim=(1, 2)).tolist()}")
+        assert err <= 1e-6
+        assert float(h.abs().max()) <= 1.0 + 1e-6
+    # the loudness figure itself
+    mono = x.mean(dim=1)
+    B, Tn = mono.shape
+    nbytes = C.c_int64()
+    eng.check(eng.lib.vn_preprocess_workspace(B, Tn, sr, C.byref(nbytes)), "ws")
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device="cuda")
+    y = torch.empty(B, Tn, device="cuda")
+    lufs = torch.empty(B, device="cuda")
+    kw = codec._kw_cache
+    eng.check(eng.lib.vn_preprocess_f32(eng.handle, mono.cuda().contiguous().data_ptr(), y.data_ptr(), B, Tn, Tn, sr, -24.0, kw[0], kw[1],
+                                        ws.data_ptr(), lufs.data_ptr(), eng.stream()), "vn_preprocess_f32")
+    want = [integrated_loudness(mono[b:b + 1].numpy(), sr) for b in range(B)]
+    print("LUFS device", lufs.cpu().tolist(), "host", want)
+    assert max(abs(a - b) for a, b in zip(lufs.cpu().tolist(), want)) <= 2e-5          # fp32 output of a float64 figure
+    assert eng.lib.vn_preprocess_f32(eng.handle, mono.cuda().data_ptr(), y.data_ptr(), B, Tn, Tn, 11025, -24.0, kw[0], kw[1], ws.data_ptr(),
+                                     None, eng.stream()) != 0
+
+
 def test_codec_program_abi_errors(eng):
     """the program entry points return a status + message on bad input (no crash, no exception across the ABI)"""
     import ctypes as C

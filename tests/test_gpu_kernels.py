@@ -123,10 +123,12 @@ def _attention_ref(q, k, v, table):
 
 
 # attention_x3.hip has two work decompositions: 128-query blocks that share their K / V^T tiles ("x3/shared") and 32-query blocks
-# whose KS waves walk disjoint key tiles and merge through LDS ("x3/ks1", "x3/ks2", "x3/ks4"); "bf16x3" = the launcher's own choice
+# whose KS waves walk disjoint key tiles and merge through LDS ("x3/ks1", "x3/ks2", "x3/ks4"), and 64-query blocks of eight waves = two
+# query sub-blocks x four key parts sharing their tiles ("x3/pair": the one- / two-sequence shape); "bf16x3" = the launcher's own choice
 ATTN_FORMS = {"f32": ("f32", None), "bf16x3": ("bf16x3", -1), "x3/shared": ("bf16x3", 0), "x3/ks1": ("bf16x3", 1),
-              "x3/ks2": ("bf16x3", 2), "x3/ks4": ("bf16x3", 4),
-              "f16x2": ("f16x2", -1), "h2/shared": ("f16x2", 0), "h2/ks1": ("f16x2", 1), "h2/ks2": ("f16x2", 2), "h2/ks4": ("f16x2", 4)}
+              "x3/ks2": ("bf16x3", 2), "x3/ks4": ("bf16x3", 4), "x3/pair": ("bf16x3", 8),
+              "f16x2": ("f16x2", -1), "h2/shared": ("f16x2", 0), "h2/ks1": ("f16x2", 1), "h2/ks2": ("f16x2", 2), "h2/ks4": ("f16x2", 4),
+              "h2/pair": ("f16x2", 8)}
 
 
 def _attention(eng, form, q, k, v, table):
@@ -163,10 +165,10 @@ def test_attention_x3_decompositions_agree(eng):
     table = _rand((32, H), 43).cuda()
     outs = {}
     for fam in ("x3", "h2"):
-        for form in (f"{fam}/shared", f"{fam}/ks1", f"{fam}/ks2", f"{fam}/ks4"):
+        for form in (f"{fam}/shared", f"{fam}/ks1", f"{fam}/ks2", f"{fam}/ks4", f"{fam}/pair"):
             outs[form] = _attention(eng, form, q, k, v, table)
             assert torch.equal(outs[form], _attention(eng, form, q, k, v, table)), form
-        for form in (f"{fam}/ks1", f"{fam}/ks2", f"{fam}/ks4"):
+        for form in (f"{fam}/ks1", f"{fam}/ks2", f"{fam}/ks4", f"{fam}/pair"):
             d = (outs[form] - outs[f"{fam}/shared"]).abs().max().item()
             print(f"{form} vs shared tiles: max |d| = {d:.3e}")
             assert d < 2e-6

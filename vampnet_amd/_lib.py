@@ -125,6 +125,9 @@ SYMBOLS = {
     "vn_codec_create_from_weights": (C.c_int, [_P, C.POINTER(vn_codec_cfg), _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "vn_dac_encode": (C.c_int, [_P, _P, _P, _P]),
     "vn_dac_decode": (C.c_int, [_P, _P, _P, _P]),
+    "vn_preprocess_workspace": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "vn_preprocess_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    _P, _P, _P]),
     "vn_comm_unique_id": (C.c_int, [_P, _P]),
     "vn_comm_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     "vn_comm_destroy": (None, [_P]),

@@ -198,6 +198,21 @@ def _k_weighting(sr):
     return (b1, a1), (b2, a2)
 
 
+def kweight_state_power(sr, n):
+    """The cascade of the two K-weighting biquads (direct form II transposed, as scipy.signal.lfilter evaluates them) as a linear
+    system s' = A s + B x with s = (z1a, z2a, z1b, z2b): returns A^n (4 x 4, float64) — what lets the device evaluate the IIR filters
+    chunk by chunk in parallel (csrc/preprocess.hip)."""
+    (b1, a1), (b2, a2) = _k_weighting(sr)
+
+    def step(s):            # one sample with x = 0
+        y1 = s[0]
+        n0, n1 = -a1[1] * y1 + s[1], -a1[2] * y1
+        y2 = b2[0] * y1 + s[2]
+        return [n0, n1, b2[1] * y1 - a2[1] * y2 + s[3], b2[2] * y1 - a2[2] * y2]
+    A = np.array([step([1.0 if i == j else 0.0 for i in range(4)]) for j in range(4)], dtype=np.float64).T
+    return np.linalg.matrix_power(A, int(n))
+
+
 def integrated_loudness(x, sr):
     """BS.1770-4 gated integrated loudness (LUFS) of x (C, T) on the host — what audiotools' `normalize(-24)`
     measures [UNVERIFIED-DEP]."""
@@ -748,7 +763,38 @@ class DacCodec:
 
     def preprocess_signal(self, signal, loudness=-24.0):
         """Interface._preprocess (interface.py:206-217): clone -> resample(codec rate) -> to_mono -> normalize(loudness) ->
-        ensure_max_of_audio(1.0) -> codec.preprocess (right-pad to the hop); returns a new AudioSignal."""
+        ensure_max_of_audio(1.0) -> codec.preprocess (right-pad to the hop); returns a new AudioSignal whose samples live ON THE DEVICE:
+        the loudness measurement (BS.1770-4, float64), the gain, the peak limit and the pad run in csrc/preprocess.hip
+        (vn_preprocess_f32).  Resampling (only when the input is not at the codec's rate) stays on the host (scipy).
+        VN_PREPROCESS_HOST=1 / preprocess_signal_host: the all-host twin the tests compare against.  Parity with audiotools: unpinned."""
+        import ctypes as C
+        import os
+        if os.environ.get("VN_PREPROCESS_HOST") == "1":
+            return self.preprocess_signal_host(signal, loudness)
+        x, sr = signal.samples.float(), signal.sample_rate
+        if sr != self.sample_rate:
+            from scipy.signal import resample_poly
+            g = math.gcd(sr, self.sample_rate)
+            x = torch.from_numpy(resample_poly(x.cpu().numpy(), self.sample_rate // g, sr // g, axis=-1).astype(np.float32))
+        x = x.to(self.device).mean(dim=1).contiguous()                               # to_mono: (B, T)
+        B, T = x.shape
+        Tp = math.ceil(T / self.hop_length) * self.hop_length
+        kw = getattr(self, "_kw_cache", None)
+        if kw is None:
+            (b1, a1), (b2, a2) = _k_weighting(self.sample_rate)
+            kw = ((C.c_double * 12)(*b1, *a1, *b2, *a2), (C.c_double * 16)(*kweight_state_power(self.sample_rate, self.sample_rate // 10).reshape(-1)))
+            self._kw_cache = kw
+        nbytes = C.c_int64()
+        self.engine.check(self.lib.vn_preprocess_workspace(B, T, self.sample_rate, C.byref(nbytes)), "vn_preprocess_workspace")
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+        y = torch.empty(B, 1, Tp, dtype=torch.float32, device=self.device)
+        self.engine.check(self.lib.vn_preprocess_f32(self.engine.handle, x.data_ptr(), y.data_ptr(), B, T, Tp, self.sample_rate, float(loudness),
+                                                     kw[0], kw[1], ws.data_ptr(), None, self.engine.stream()), "vn_preprocess_f32")
+        ws.record_stream(torch.cuda.current_stream(self.device))
+        return AudioSignal(y, self.sample_rate)
+
+    def preprocess_signal_host(self, signal, loudness=-24.0):
+        """the same chain entirely on the host (numpy / scipy): the twin of the device path"""
         x, sr = signal.samples.float().cpu().clone(), signal.sample_rate
         if sr != self.sample_rate:
             from scipy.signal import resample_poly

@@ -735,13 +735,176 @@ __global__ __launch_bounds__(KS * 64, 2) void vn_attention_x3_split_kernel(const
     }
 }
 
+// ---- pair-split kernel (round 5; one or two sequences): block = 2 KH waves = 2 query sub-blocks of 32 x KH key parts ------------------
+// The key-split kernel above gives every wave a private stage (24 KiB), so a CU holds six waves at most and a wave's chain of
+// dependent tiles is 19 / 2 long at its best occupancy: 28 us at B = 1 for 4.5 us of matrix work, the chip 70 % empty (0.7 waves per
+// SIMD).  Here the two query sub-blocks of a 64-query block SHARE the tile of their key part (the shared kernel's tail role, with KH
+// parts instead of two halves): KH = 4 -> eight waves = two per SIMD on one CU, 4 x 24 KiB of single-buffered stages, a chain of
+// ceil(19 / 4) = 5 tiles per wave.  All waves run the same four-barrier iteration (K landed / K read / V^T landed / V^T read), the DMA of
+// the next iteration's K is issued right after the S^T products and flies under the softmax, the next V^T after PV.  Waves w and w ^ 1
+// share key part w >> 1; wave w stages piece (w & 3) of every plane tile of two stages (waves 0-3: parts 0 / 1, waves 4-7: parts 2 / 3),
+// so every wave issues 2 NP K and 2 NP V^T pieces per iteration and the counted vmcnt is exact.  The KH partial (m, l, O) triples of a
+// query sub-block are merged through LDS in the fixed order 0 .. KH - 1 (deterministic), each wave finishing 8 / KH column groups.
+template <int KH, int NP = 3>
+__global__ __launch_bounds__(2 * KH * 64) void vn_attention_x3_pair_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
+                                                                          long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
+                                                                          const float* __restrict__ bias_full, float* __restrict__ out,
+                                                                          uint16_t* __restrict__ out16, long plane16, int B, int H, int T) {
+    static_assert(KH == 2 || KH == 4, "two stages per staging wave group, 8 / KH column groups per wave in the merge");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // a key part's LDS: TWO K buffers (tile i in buffer i & 1) and one V^T buffer — the K tile of iteration i + 2 is issued as soon as
+    // QK(i) has read its buffer and has two iterations to land; V^T(i + 1) follows PV(i) and flies under QK + softmax of the next one
+    constexpr int KB = NP * AX_PLANE_FLOATS, AXS = 3 * KB, NW = 2 * KH;
+    float* bt = smem + KH * AXS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const ax_lane L = ax_lane_init(lane);
+    const int nqb = (T + 63) / 64;
+    const int lid = ax_walk(blockIdx.x, gridDim.x);
+    const int qb = lid % nqb, hbi = lid / nqb;
+    const int h = hbi % H, b = hbi / H;
+    const int m_lo = b * T;
+    const int g_lo = m_lo / AX_KT, NT = (m_lo + T - 1) / AX_KT - g_lo + 1;
+    const int MT = (B * T + AX_KT - 1) / AX_KT;
+    const size_t head = (size_t)b * H + h;
+    const uint16_t* Qp = q16 + head * (size_t)T * VN_DHEAD;
+    const int qs = wave & 1, kh = wave >> 1;
+    const int q0 = qb * 64 + qs * 32;
+    const bool active = q0 < T;                         // the second sub-block of a head's last block may be empty: it only stages
+    const int qrow = q0 + L.l31;
+    const int qrow_c = qrow < T ? qrow : T - 1;
+
+    const int nb = 2 * T - 1;
+    for (int i = tid; i < nb; i += NW * 64) bt[i] = bias_full[(size_t)h * nb + i];
+
+    f32x4 qf[NP][4];
+    ax_load_q<NP>(qf, Qp, plane_qk, qrow_c, L.hh);
+
+    const int pw = wave & 3, sA = 2 * (wave >> 2);      // piece of every plane tile / first of the two stages this wave fills
+    const int krow = 8 * pw + (lane >> 3), vrow = 16 * pw + (lane >> 2);
+    const unsigned kvoff = (unsigned)(krow * VN_DHEAD + ((lane & 7) ^ ((krow >> 1) & 7)) * 8) * 2u;
+    const unsigned vvoff = (unsigned)(vrow * AX_KT + ((lane & 3) ^ ((vrow >> 2) & 3)) * 8) * 2u;
+    const ax_src src = ax_src_init(k16, vt16, plane_qk, plane_vt, b, h, H, T, m_lo, g_lo, MT);
+    const int NH = (NT + KH - 1) / KH;
+    auto stage_op = [&](int i, bool v_op) {             // iteration i: tiles sA NH + i and (sA + 1) NH + i (clamped: re-fetch the last tile)
+        int kt0 = sA * NH + i, kt1 = (sA + 1) * NH + i;
+        kt0 = kt0 < NT ? kt0 : NT - 1;
+        kt1 = kt1 < NT ? kt1 : NT - 1;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float* d0 = smem + sA * AXS + pw * 256 + (v_op ? 2 * KB : (i & 1) * KB) + 4 * p * 256;
+            if (v_op) {
+                ax_dma(src.vrs, d0, vvoff, src.v0 + p * src.vplane + kt0 * (VN_DHEAD * AX_KT * 2));
+                ax_dma(src.vrs, d0 + AXS, vvoff, src.v0 + p * src.vplane + kt1 * (VN_DHEAD * AX_KT * 2));
+            } else {
+                ax_dma(src.krs, d0, kvoff, src.k0 + p * src.kplane + kt0 * (AX_KT * VN_DHEAD * 2));
+                ax_dma(src.krs, d0 + AXS, kvoff, src.k0 + p * src.kplane + kt1 * (AX_KT * VN_DHEAD * 2));
+            }
+        }
+    };
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+
+    stage_op(0, false);
+    stage_op(0, true);
+    if (NH > 1) stage_op(1, false);
+    const float* Vs = smem + kh * AXS + 2 * KB;
+    for (int i = 0; i < NH; ++i) {
+        const float* Ks = smem + kh * AXS + (i & 1) * KB;
+        const int kt = kh * NH + i;
+        const bool valid = active && kt < NT, more = i + 1 < NH;
+        const int key0 = (g_lo + kt) * AX_KT - m_lo;
+        const bool full = key0 >= 0 && key0 + AX_KT <= T;
+        f32x16 sacc;
+        f32x4 pf[NP][2];
+        // K(i) landed.  Issue order of a wave's batches (2 NP pieces each): K(0), V^T(0), K(1) [prologue]; K(2), V^T(1) [iteration 0]; K(3),
+        // V^T(2) [iteration 1]; ...  Iteration 0: V^T(0) and K(1) are younger than K(0).  Iteration 1: K(1) is YOUNGER than V^T(0), so the
+        // wait for V^T(0) did not cover it — K(2) (if issued) and V^T(1) are behind it.  From iteration 2 on K(i) is older than V^T(i - 1),
+        // which iteration i - 1 waited for.  lgkmcnt: first time round, this wave's part of the bias table
+        if (i == 0) {
+            if (NH > 1) { if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); }
+            else { if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }
+        } else if (i == 1) {
+            if (NH > 2) { if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+            else { if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        }
+        AX_RAW_BARRIER();
+        if (valid) {
+            if (full) ax_bias_init<true>(sacc, bt, key0, L.hh, qrow_c, T);
+            else ax_bias_init<false>(sacc, bt, key0, L.hh, qrow_c, T);
+            ax_qk<NP, true>(sacc, Ks, qf, L);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        AX_RAW_BARRIER();                                        // this K buffer has been read by both of its waves
+        const bool more2 = i + 2 < NH;
+        if (more2) stage_op(i + 2, false);
+        if (valid) ax_softmax<NP>(sacc, pf, m_run, l_run, o, key0, L.hh, T, full);
+        // V^T(i) landed.  Younger than it in the queue: K(i + 1) if it was issued BEFORE V^T(i)... it was not: the issue order is
+        // K(i + 1) [iteration i - 1], V^T(i) [end of iteration i - 1], K(i + 2) [just now] — only K(i + 2) may still fly.  (Iteration 0:
+        // K(0), V^T(0), K(1), K(2): K(1) and K(2) are younger.)
+        if (i == 0) {
+            const int young = (NH > 1 ? 1 : 0) + (more2 ? 1 : 0);
+            if (young == 2) { if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+            else if (young == 1) { if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (more2) {
+            if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        AX_RAW_BARRIER();
+        if (valid) ax_pv<NP, true>(o, Vs, pf, L);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        AX_RAW_BARRIER();                                        // every V^T stage has been read
+        if (more) stage_op(i + 1, true);
+    }
+    // merge the KH key parts of each query sub-block (fixed order).  Image per wave in the (free) stages: 8 groups of 64 lanes x 16 B, m, l
+    float* mine = smem + wave * 2304;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *(f32x4*)(mine + ((dt * 4 + g) * 64 + lane) * 4) = f32x4{o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
+    mine[2048 + lane] = m_run;
+    mine[2112 + lane] = l_run;
+    __syncthreads();
+    float m_all = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KH; ++k) m_all = fmaxf(m_all, smem[(qs + 2 * k) * 2304 + 2048 + lane]);
+    float sc[KH], l_all = 0.f;
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {                               // a part without tiles holds m = -inf, l = 0: scale 0
+        sc[k] = vn_exp_neg(smem[(qs + 2 * k) * 2304 + 2048 + lane] - m_all);
+        l_all += smem[(qs + 2 * k) * 2304 + 2112 + lane] * sc[k];
+    }
+    const float l_tot = (l_all + __shfl_xor(l_all, 32)) * (NP == 2 ? 16.0f : 1.0f);           // f16: l' = 16 l, O' = 256 O
+    if (active && qrow < T) {
+#pragma unroll
+        for (int i = 0; i < 8 / KH; ++i) {
+            const int G = kh * (8 / KH) + i;                     // uniform: this wave finishes 8 / KH of the eight column groups
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < KH; ++k) a += *(const f32x4*)(smem + (qs + 2 * k) * 2304 + (G * 64 + lane) * 4) * sc[k];
+            ax_store4(a, l_tot, out, out16, plane16, (long)b * T + qrow, h, H, L.hh, G >> 2, G & 3);
+        }
+    }
+}
+
 // LDS bytes of the two decompositions; the launcher (and the engine's choice of attention kernel) need them to fit the CU
 size_t vn_attention_x3_lds_bytes(int T, int key_split, int np) {
+    // key_split: 0 shared tiles (two stages), 1 / 2 / 4 key-split waves (a private stage each), 8 = the pair-split kernel (four shared stages)
     const size_t stages = key_split > 0 ? (size_t)key_split : 2;
-    const size_t bytes = (stages * AX_STAGE_FLOATS_NP(np) + 2 * (size_t)T - 1 + 3) * sizeof(float);
+    // pair-split: four key parts of two K buffers + one V^T buffer = six stages' worth
+    const size_t bytes = ((key_split == 8 ? 6 : stages) * AX_STAGE_FLOATS_NP(np) + 2 * (size_t)T - 1 + 3) * sizeof(float);
     // shared tiles: the tail blocks merge their key halves through four 9 KiB images laid over the stages (and, for two-plane
-    // stages and a short bias table, past them)
-    const size_t merge = key_split > 0 ? 0 : 4 * 2304 * sizeof(float);
+    // stages and a short bias table, past them); pair-split: eight such images
+    const size_t merge = key_split == 8 ? 8 * 2304 * sizeof(float) : key_split > 0 ? 0 : 4 * 2304 * sizeof(float);
     return bytes > merge ? bytes : merge;
 }
 
@@ -752,6 +915,11 @@ int vn_attention_x3_plan(const vn_ctx* ctx, int B, int H, int T, int cus) {
     // wave walks and wins while ALL its blocks are resident at once; from its second round on the shared-tile kernel (a quarter of
     // the blocks, K / V^T staged once per 128 queries, key-split tail blocks) is ahead (T = 575: B = 2 33.5 vs 35.4 us, B = 3
     // 57.4 vs 40.9 us; T = 173: B = 4 15.2 vs 15.9, B = 8 25.5 vs 20.4 — profiles/history/r03_attention_x3_tail_role.txt)
+    // one sequence (or the four c2f chunks of one): the pair-split kernel (64-query blocks of eight waves, four key parts: a chain of
+    // ceil(NT / 4) tiles per wave at two waves per SIMD) while ALL its blocks are resident at once, one per CU — measured
+    // (profiles/r05_attention_pair_split.txt): T = 575, B = 1: 23.3 vs 28.1 us for the key-split pair; T = 173, B = 4: 13.3 vs 15.0; from
+    // its second round on it loses (B = 2, T = 575: 44.1 vs 34.0).  VN_ATTN_X3_PAIR=0: off
+    if (ctx->tune.ax_pair && (long)B * H * ((T + 63) / 64) <= (long)cus && vn_attention_x3_lds_bytes(T, 8, 3) <= 160 * 1024) return 8;
     if ((long)B * H * ((T + 31) / 32) <= 3L * cus) return 2;
     return 0;
 }
@@ -778,6 +946,8 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_split_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_split_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_split_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_pair_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_pair_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->attr_mask |= VN_ATTR_ATTN_X3;
     }
     const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
@@ -793,6 +963,10 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
         if (ctx->tune.ax_trace) { if (np == 3) AX_SHARED_GO(true, 3); else AX_SHARED_GO(true, 2); }
         else { if (np == 3) AX_SHARED_GO(false, 3); else AX_SHARED_GO(false, 2); }
 #undef AX_SHARED_GO
+    } else if (ks == 8) {
+        const dim3 grid(vn_cdiv(T, 64) * H * B);
+        if (np == 3) hipLaunchKernelGGL((vn_attention_x3_pair_kernel<4, 3>), grid, dim3(512), lds, s, q16, k16, plane_qk, vt16, plane_vt, relbias_full, out, out16, plane16, B, H, T);
+        else hipLaunchKernelGGL((vn_attention_x3_pair_kernel<4, 2>), grid, dim3(512), lds, s, q16, k16, plane_qk, vt16, plane_vt, relbias_full, out, out16, plane16, B, H, T);
     } else {
         const dim3 grid(vn_cdiv(T, 32) * H * B);
 #define AX_SPLIT_GO(KS, NP) hipLaunchKernelGGL((vn_attention_x3_split_kernel<KS, NP>), grid, dim3(KS * 64), lds, s, q16, k16, plane_qk, vt16, \
@@ -816,8 +990,8 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
 // tuning hook of one context (scripts/attn_probe.py; include/vampnet_hip_debug.h)
 extern "C" int vn_debug_attention_x3_config(vn_ctx* ctx, int split, int lds_bytes, int stagger, void* trace_dev) {
     if (!ctx) return VN_ERR_INVALID;
-    if (split != -1 && split != 0 && split != 1 && split != 2 && split != 4)
-        return vn_fail(ctx, VN_ERR_INVALID, "attention_x3: key split %s%ld is not -1 / 0 / 1 / 2 / 4", "", split);
+    if (split != -1 && split != 0 && split != 1 && split != 2 && split != 4 && split != 8)
+        return vn_fail(ctx, VN_ERR_INVALID, "attention_x3: key split %s%ld is not -1 / 0 / 1 / 2 / 4 / 8 (8 = the pair-split kernel)", "", split);
     ctx->tune.ax_split = split;
     ctx->tune.ax_lds = lds_bytes;
     if (stagger >= 0) ctx->tune.ax_stagger = stagger;

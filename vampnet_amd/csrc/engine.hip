@@ -107,6 +107,7 @@ void vn_tune_init(vn_tune* t) {
     t->x3_tile96 = env_int("VN_X3_TILE96", 1) != 0;
     t->ax_split = env_int("VN_ATTN_X3_SPLIT", -1);
     t->ax_lds = 0;
+    t->ax_pair = env_int("VN_ATTN_X3_PAIR", 1) != 0;
     t->ax_stagger = env_int("VN_ATTN_X3_STAGGER", 0);
     t->ax_trace = nullptr;
     t->attn_x3 = env_int("VN_ATTN_X3", -1);

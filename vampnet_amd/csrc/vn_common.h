@@ -371,6 +371,7 @@ struct vn_tune {
     // attention_x3.hip: decomposition (-1 by shape, 0 shared tiles, 1 / 2 / 4 key-split waves), dynamic-LDS override of the shared
     // kernel (occupancy probe), start stagger, phase-trace buffer (device)
     int ax_split, ax_lds, ax_stagger;
+    int ax_pair;             // attention_x3.hip: the by-shape plan may pick the pair-split kernel for one or two sequences (VN_ATTN_X3_PAIR, default 1)
     unsigned* ax_trace;
     // engine.hip: bf16x3 models take the split-plane attention path (-1 by shape / LDS fit, 0 never, 1 always); operand plane layouts
     int attn_x3, a_tiled, w_tiled;
