@@ -29,7 +29,8 @@ sys.path.insert(0, ROOT)
 TOKENS_PER_CLIP = 14 * 575
 PEAK_F32_MFMA_TF = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
 PEAK_BF16_MFMA_TF = 2500.0         # dense bf16 MFMA (32x32x16)
-MEASURED_PIPE_LIMIT_TF = 1650.0    # what the matrix pipe sustains on random operand bits with NO data movement (profiles/r04_mfma_power_probe.txt)
+MEASURED_PIPE_LIMIT_TF = 1790.0    # what the matrix pipe sustains with NO data movement on the split planes of Gaussian operands in the
+                                   # kernel's six-product order (profiles/r05_mfma_power_probe.txt, mode 4; 1.69-1.74 PF on uniformly random words)
 
 
 def _host_facts():
@@ -471,6 +472,9 @@ def main():
                     sd[f"transformer.layers.{l}.{k}.lora_B"] = torch.randn(o, 8, generator=gl) * 0.01
             return sd
         la, lb = adapters(W.COARSE_DIMS), adapters(W.C2F_DIMS)
+        for m_ in (itf.coarse, itf.c2f):                           # (the `alt` block left the models in f16x2: time the swap at the headline precision)
+            if m_.precision != args.dtype:
+                m_.set_precision(args.dtype)
         itf.coarse.apply_lora(la)                                  # first use: snapshots the un-merged blob (one-off)
         torch.cuda.synchronize()
         t_l = time.perf_counter()
@@ -537,8 +541,8 @@ def main():
             an, ams, afl, _ = prof["attention"]
             # fabric bytes per launch: NOT measured by this run — read from the committed rocprofv3 --pmc passes of this same command
             traffic = traffic_source = None
-            tname = next((n for n in {"f32": ["history/r01_traffic.json"], "bf16x3": ["r04_traffic_x3.json", "history/r03_traffic_x3.json"],
-                                      "f16x2": ["r04_traffic_h2.json", "history/r03_traffic_h2.json"]}.get(dtype, [])
+            tname = next((n for n in {"f32": ["history/r01_traffic.json"], "bf16x3": ["r05_traffic_x3.json", "history/r04_traffic_x3.json"],
+                                      "f16x2": ["r05_traffic_h2.json", "history/r03_traffic_h2.json"]}.get(dtype, [])
                           if os.path.exists(os.path.join(ROOT, "profiles", n))), "-")
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and world == 1 and args.batch_per_gpu == 8 and not args.coarse_only and not args.e2e:
@@ -562,12 +566,13 @@ def main():
                         # context: the same algorithmic rate against the fp32-input MFMA peak (157.3 TF), the
                         # ceiling of the exact-fp32 kernel this precision replaces
                         "achieved_over_f32_mfma_peak": fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF if ms else None,
-                        # context, NOT `frac`: a pure matrix-pipe loop with no data movement sustains 1.62-1.68 PF on random operand bits
-                        # on this part (the firmware holds the socket at ~1.3 kW by lowering the clock; 2.42 PF on a smooth operand ramp) —
-                        # a committed measurement (profiles/r04_mfma_power_probe.txt), not a quantity of this run
+                        # context, NOT `frac`: a pure matrix-pipe loop with no data movement sustains 1.79 PF on the real split planes of
+                        # Gaussian operands (1.69-1.74 PF on uniformly random words, 2.42 PF on a smooth ramp: the firmware holds the socket
+                        # at ~1.3 kW by lowering the clock) — a committed measurement (profiles/r05_mfma_power_probe.txt), not of this run
                         "executed_over_measured_pipe_limit": (nprod * fl / (ms * 1e-3) / 1e12) / MEASURED_PIPE_LIMIT_TF if ms else None,
-                        "measured_pipe_limit": {"tflops": MEASURED_PIPE_LIMIT_TF, "source": "profiles/r04_mfma_power_probe.txt: v_mfma_f32_32x32x16_bf16 on "
-                                                "register-resident RANDOM operands, no global / LDS traffic, 1.62-1.75 GHz at 1.28-1.30 kW"}}
+                        "measured_pipe_limit": {"tflops": MEASURED_PIPE_LIMIT_TF, "source": "profiles/r05_mfma_power_probe.txt mode 4: v_mfma_f32_32x32x16_bf16 on "
+                                                "register-resident split planes of Gaussian activations x weights, six-product order, no global / LDS "
+                                                "traffic, socket at ~1.26 kW"}}
                        if nprod else {}),
                     "event_stride": args.event_stride,        # launches / times above: the bracketed sample
                     "gemm_time_frac": args.event_stride * ms / (1e3 * elapsed) if elapsed else None,

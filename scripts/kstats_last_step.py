@@ -47,6 +47,11 @@ i0 = starts[-nth]
 while i0 > 0 and ("fillBuffer" in rows[i0 - 1]["Kernel_Name"] or "i64_to_i32" in rows[i0 - 1]["Kernel_Name"]):
     i0 -= 1
 step = rows[i0:]
+# what bench.py runs AFTER its timed region (the adapter-swap cost measurement: merges, plane builds) is not part of the step
+for j, r in enumerate(step):
+    if "vn_lora_merge_kernel" in r["Kernel_Name"]:
+        step = step[:j]
+        break
 agg = defaultdict(lambda: [0, 0])
 for r in step:
     a = agg[r["Kernel_Name"]]

@@ -1,6 +1,6 @@
 // Micro-benchmark (tuning evidence, not product code): what limits v_mfma_f32_32x32x16_bf16 throughput on a full MI355X when NOTHING
 // but the matrix pipe works — no global / LDS traffic at all?  The split-plane GEMM stops at ~1.1-1.3 PF executed with the pipe ~50 %
-// busy (profiles/r04_model_clock.txt); the round-2/3 notes call that "the power limit" on the strength of clock readings.  This probe
+// busy (profiles/history/r04_model_clock.txt); the round-2/3 notes call that "the power limit" on the strength of clock readings.  This probe
 // separates the candidates: every wave holds NSETS operand register sets and walks them in a loop of MFMAs into four accumulators
 //   mode 0  ONE operand set whose values are a smooth ramp (what scripts/ubench/mfma_valu_coissue.hip measured: 2.32 PF)
 //   mode 1  ONE operand set of RANDOM bf16 bit patterns (exponents confined to 2^-4 .. 2^4)

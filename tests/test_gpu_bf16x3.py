@@ -160,13 +160,22 @@ def test_split_plane_attention_path_at_every_tile_height(eng, prec, dims, B, T):
             plains[bm] = m.forward_codes(codes).clone()
         lib.vn_debug_x3_config(eng.handle, 0, -1, -1)
         plain = m.forward_codes(codes).clone()
-        assert torch.equal(plains[128], plains[192]) and torch.equal(plains[128], plains[256])
+        assert torch.equal(plains[128], plains[256])
+        # 192 rows: bf16x3 runs W1 + GEGLU on it through the tile-image epilogue (value and gate columns of a 96 x 32 wave tile live in
+        # different waves) — the same sums, but gelu's expression is contracted differently there: fp32 noise, not bits; f16x2 keeps
+        # 128 rows for the GEGLU launch and stays bitwise
+        if prec == "f16x2":
+            assert torch.equal(plains[128], plains[192])
+        assert (plains[192] - plains[128]).abs().max().item() <= TM.LOGIT_ATOL_TINY
         # the by-shape choice mixes heights per GEMM (the 96-row tile adds its two k-halves in its epilogue): fp32 noise from any one
         assert (plain - plains[128]).abs().max().item() <= TM.LOGIT_ATOL_TINY
     finally:
         lib.vn_debug_attention_x3_force(eng.handle, -1)
         lib.vn_debug_x3_config(eng.handle, 0, -1, -1)
-    assert torch.equal(outs[128], outs[192]) and torch.equal(outs[128], outs[256])
+    assert torch.equal(outs[128], outs[256])
+    if prec == "f16x2":
+        assert torch.equal(outs[128], outs[192])
+    assert (outs[192] - outs[128]).abs().max().item() <= TM.LOGIT_ATOL_TINY
     if 96 in outs:
         d = (outs[96] - outs[128]).abs().max().item()
         print(f"96-row k-split tile vs 128 rows: logits max |d| = {d:.3e}")
@@ -259,7 +268,10 @@ def test_folded_norm_matches_unfolded_and_oracle(precision):
             outs[f"sk{sk}"] = mf.forward_codes(codes).clone()
     finally:
         eng_f.lib.vn_debug_x3_config(eng_f.handle, 0, -1, -1)
-    assert torch.equal(outs[128], outs[192]) and torch.equal(outs[128], outs[256])
+    assert torch.equal(outs[128], outs[256])
+    if precision == "f16x2":
+        assert torch.equal(outs[128], outs[192])
+    assert (outs[192] - outs[128]).abs().max().item() <= TM.LOGIT_ATOL_TINY      # bf16x3: W1 + GEGLU of the 192-row tile = the image epilogue
     if precision == "bf16x3":                                             # the 96-row k-split tile: every folded-norm epilogue through its image form
         try:
             eng_f.lib.vn_debug_x3_config(eng_f.handle, 96, -1, -1)

@@ -920,3 +920,136 @@ def test_f16x2_generate_wrapper_repeats_a_saturated_call_from_the_same_generator
         warnings.simplefilter("error")
         out = m.generate(_sampling_steps=5, temperature=0.7)
     assert out == ("f16x2", want) and m.precision == "f16x2" and len(m.calls) == 1
+
+
+# ----------------------------------------------------------------------------- round 5: host pieces of the new C entries
+def test_codec_tensor_table_matches_the_state_dict_names():
+    """vn_codec_tensor_name / _offset / vn_codec_weights_size (csrc/codec_plan.hip: what a host without Python fills before
+    vn_codec_create_from_weights) enumerate exactly the tensors of a DAC-family state_dict — names, element counts, non-overlapping
+    256-byte aligned slots, the level-stacked quantizer regions — and pack_codec_blob places every folded tensor where the table says."""
+    from oracle import dac_oracle as D
+    from vampnet_amd.codec import codec_cfg_struct, pack_codec_blob, _fold
+    lib = _lib.load()
+    for cfg in (D.DAC_TINY_CFG, D.DAC_DEFAULT_CFG):
+        sd = D.synth_dac_state_dict(cfg, 0)
+        cs = codec_cfg_struct(cfg)
+        n, cnt = C.c_int64(), C.c_int()
+        assert lib.vn_codec_weights_size(C.byref(cs), C.byref(n)) == 0 and lib.vn_codec_tensor_count(C.byref(cs), C.byref(cnt)) == 0
+        name = C.create_string_buffer(256)
+        off, num = C.c_int64(), C.c_int64()
+        seen, spans = set(), []
+        for i in range(cnt.value):
+            assert lib.vn_codec_tensor_name(C.byref(cs), i, name, 256, C.byref(off), C.byref(num)) == 0
+            key = name.value.decode()
+            t = _fold(sd, key[:-7]) if key.endswith(".weight") and key not in sd else sd[key]
+            assert t.numel() == num.value, key
+            o2, n2 = C.c_int64(), C.c_int64()
+            assert lib.vn_codec_tensor_offset(C.byref(cs), key.encode(), C.byref(o2), C.byref(n2)) == 0 and (o2.value, n2.value) == (off.value, num.value)
+            seen.add(key)
+            spans.append((off.value, off.value + num.value))
+        folded = {k[:-9] + ".weight" if k.endswith(".weight_v") else k for k in sd if not k.endswith(".weight_g")}
+        assert seen == folded, seen ^ folded
+        spans.sort()
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] <= n.value
+        lat = cfg["latent_dim"] or cfg["encoder_dim"] * 2 ** len(cfg["encoder_rates"])
+        o0, o1 = C.c_int64(), C.c_int64()
+        lib.vn_codec_tensor_offset(C.byref(cs), b"quantizer.quantizers.0.in_proj.bias", C.byref(o0), C.byref(num))
+        lib.vn_codec_tensor_offset(C.byref(cs), b"quantizer.quantizers.1.in_proj.bias", C.byref(o1), C.byref(num))
+        assert o1.value - o0.value == cfg["codebook_dim"]                       # stacked level after level: the RVQ kernels' layout
+        blob = pack_codec_blob(lib, cs, sd)
+        lib.vn_codec_tensor_offset(C.byref(cs), b"decoder.model.0.weight", C.byref(off), C.byref(num))
+        assert torch.equal(blob[off.value:off.value + num.value], _fold(sd, "decoder.model.0").reshape(-1))
+        assert num.value == cfg["decoder_dim"] * lat * 7
+    bad = codec_cfg_struct(D.DAC_TINY_CFG)
+    bad.n_rates = 0
+    assert lib.vn_codec_weights_size(C.byref(bad), C.byref(n)) != 0
+
+
+def test_kweighting_state_space_power_reproduces_lfilter():
+    """csrc/preprocess.hip evaluates the K-weighting IIR cascade chunk by chunk: S_(j+1) = A^CH S_j + e_j.  The host side of that
+    (codec.kweight_state_power) against scipy.signal.lfilter over the whole signal, in float64."""
+    from scipy.signal import lfilter
+    from vampnet_amd.codec import _k_weighting, kweight_state_power
+    sr, CH = 44100, 441
+    x = np.random.default_rng(0).standard_normal(5 * CH)
+    want = x.copy()
+    for b, a in _k_weighting(sr):
+        want = lfilter(b, a, want)
+    (b1, a1), (b2, a2) = _k_weighting(sr)
+
+    def run(s, xs):
+        s, out = list(s), []
+        for xv in xs:
+            y1 = b1[0] * xv + s[0]
+            s[0], s[1] = b1[1] * xv - a1[1] * y1 + s[1], b1[2] * xv - a1[2] * y1
+            y2 = b2[0] * y1 + s[2]
+            s[2], s[3] = b2[1] * y1 - a2[1] * y2 + s[3], b2[2] * y1 - a2[2] * y2
+            out.append(y2)
+        return np.array(out), np.array(s)
+    P = kweight_state_power(sr, CH)
+    S, got = np.zeros(4), []
+    for j in range(5):
+        chunk = x[j * CH:(j + 1) * CH]
+        e = run(np.zeros(4), chunk)[1]
+        got.append(run(S, chunk)[0])
+        S = P @ S + e
+    assert np.abs(np.concatenate(got) - want).max() < 1e-10
+
+
+def test_pack_lora_vector_layout():
+    """engine.pack_lora_vector: loralib tensors -> the adapter vector vn_model_apply_lora reads (At [in][8] then B [out][8] per layer
+    and LoRA'd linear, w_1's B rows in the packed value / gate order of VN_W_W1); absent adapters stay zero."""
+    from vampnet_amd.engine import LORA_KEYS, pack_lora_vector
+    from vampnet_amd._lib import vn_dims
+    lib = _lib.load()
+    d = W.TINY_COARSE_DIMS
+    dims = vn_dims(d["n_layers"], d["n_heads"], d["d_model"], d["n_codebooks"], d["n_cond"], 1024, 8, 32, 128, 1e-6, 2, 64)
+    D_ = d["d_model"]
+    g = torch.Generator().manual_seed(1)
+    sd = {"transformer.layers.1.feed_forward.w_1.lora_A": torch.randn(8, D_, generator=g),
+          "transformer.layers.1.feed_forward.w_1.lora_B": torch.randn(4 * D_, 8, generator=g),
+          "transformer.layers.0.self_attn.w_vs.lora_A": torch.randn(8, D_, generator=g),
+          "transformer.layers.0.self_attn.w_vs.lora_B": torch.randn(D_, 8, generator=g)}
+    vec = pack_lora_vector(lib, dims, sd)
+    off, cnt = C.c_int64(), C.c_int64()
+
+    def slot(l, w, ab):
+        assert lib.vn_lora_param_offset(C.byref(dims), l, w, ab, C.byref(off), C.byref(cnt)) == 0
+        return vec[off.value:off.value + cnt.value]
+    w1 = LORA_KEYS.index("feed_forward.w_1")
+    assert torch.equal(slot(1, w1, 0).view(D_, 8), sd["transformer.layers.1.feed_forward.w_1.lora_A"].t())
+    b = sd["transformer.layers.1.feed_forward.w_1.lora_B"]
+    packed = torch.stack([b[:2 * D_].view(2 * D_ // 32, 32, 8), b[2 * D_:].view(2 * D_ // 32, 32, 8)], dim=1).reshape(4 * D_, 8)
+    assert torch.equal(slot(1, w1, 1).view(4 * D_, 8), packed)
+    wv = LORA_KEYS.index("self_attn.w_vs")
+    assert torch.equal(slot(0, wv, 1).view(D_, 8), sd["transformer.layers.0.self_attn.w_vs.lora_B"])
+    used = sum(v.numel() for v in sd.values())
+    assert int((vec != 0).sum()) == used                                          # every other adapter slot is zero: w + 0 on merge
+    with pytest.raises(_lib.VnError):
+        pack_lora_vector(lib, dims, {"transformer.layers.0.self_attn.fc.lora_A": torch.zeros(4, D_),
+                                     "transformer.layers.0.self_attn.fc.lora_B": torch.zeros(D_, 4)})
+
+
+def test_interface_resident_model_lru(tmp_path):
+    """Interface's resident-model cache (what makes reload() to an earlier checkpoint a lookup): keyed by path + mtime + size, least
+    recently used entries dropped beyond max_resident"""
+    from vampnet_amd.interface import Interface
+    itf = object.__new__(Interface)
+    paths = []
+    for i in range(6):
+        p = tmp_path / f"m{i}.pth"
+        p.write_bytes(b"x" * (i + 1))
+        paths.append(p)
+    os.environ["VN_RESIDENT_MODELS"] = "3"
+    try:
+        for i, p in enumerate(paths[:3]):
+            itf._resident_put("coarse", p, f"model{i}")
+    finally:
+        del os.environ["VN_RESIDENT_MODELS"]
+    assert itf._resident_get("coarse", paths[0]) == "model0"                      # refreshes m0
+    itf._resident_put("coarse", paths[3], "model3")                               # evicts the least recently used: m1
+    assert itf._resident_get("coarse", paths[1]) is None
+    assert itf._resident_get("coarse", paths[0]) == "model0" and itf._resident_get("coarse", paths[3]) == "model3"
+    assert itf._resident_get("c2f", paths[0]) is None                             # roles are separate
+    paths[0].write_bytes(b"changed")                                              # a rewritten file is another model
+    assert itf._resident_get("coarse", paths[0]) is None

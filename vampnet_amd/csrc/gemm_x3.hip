@@ -986,11 +986,12 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
 #pragma unroll
                 for (int j = 0; j < CJ; ++j) acc[i][j] += acc_lo[i][j] * VN_H2_INV_SCALE;
         }
-        if constexpr (CFG == 4) {
+        if constexpr (CFG == 4 || (CFG == 3 && EPI == VN_EPI_GEGLU && !FMT)) {
+            // (CFG 3 + GEGLU: the 96 x 32 wave tile holds value and gate columns in different waves — they meet in the tile image)
             x3_epilogue_image<EPI, CFG, FMT>(p, acc, m0, n0, wave, lane, lds);       // the launcher guarantees the staged forms' alignment
         } else if constexpr (EPI == VN_EPI_CONV) {
             x3_epilogue_staged<EPI, CFG, FMT>(p, acc, m0, n0, wave, lane, lds);      // the launcher guarantees the alignment it needs
-        } else {
+        } else if constexpr (!(EPI == VN_EPI_GEGLU && x3_geo<CFG>::CJ != 2)) {
             if (p.staged) x3_epilogue_staged<EPI, CFG, FMT>(p, acc, m0, n0, wave, lane, lds);
             else x3_epilogue<EPI, CFG, FMT>(p, acc, m0, n0, wm, wn, lane);
         }
@@ -1050,8 +1051,8 @@ static int x3_go(vn_ctx* ctx, const vn_gemm_args& a_in, int nsplit, hipStream_t 
 }
 template <int EPI, int FMT = 0>
 static int x3_go_bm(vn_ctx* ctx, const vn_gemm_args& a, int nsplit, int bm, hipStream_t s) {
-    if constexpr (EPI != VN_EPI_GEGLU) {
-        if (bm == 192) return x3_go<EPI, 3, 0, FMT>(ctx, a, nsplit, s);
+    if constexpr (EPI != VN_EPI_GEGLU || !FMT) {
+        if (bm == 192) return x3_go<EPI, 3, 0, FMT>(ctx, a, nsplit, s);      // (GEGLU: bf16x3 operands + plane output only, see x3_choose)
     }
     if constexpr (EPI != VN_EPI_CONV && !FMT) {
         if (bm == 96) return x3_go<EPI, 4, 0, FMT>(ctx, a, nsplit, s);       // x3_choose offers it only where x3_tile96_ok holds
@@ -1107,9 +1108,12 @@ static x3_plan x3_choose(const vn_ctx* ctx, const vn_gemm_args& a, int cus, doub
     static const double fixed[4] = {0.0, 0.0, 0.0, 1.0};
     for (int hi = 0; hi < 4; ++hi) {
         const int bm = heights[hi];
-        if (bm == 192 && EPI == VN_EPI_GEGLU) continue;
+        // GEGLU on the 192-row tile goes through the tile-image epilogue (value and gate columns sit in different waves): the same
+        // conditions as the 96-row tile (bf16x3 operands, staged alignment = plane output)
+        const bool geglu192 = EPI == VN_EPI_GEGLU && allow96;
+        if (bm == 192 && EPI == VN_EPI_GEGLU && !geglu192) continue;
         if (bm == 96 && !allow96) continue;
-        if (bm_forced && bm != bm_forced && !(bm_forced == 192 && EPI == VN_EPI_GEGLU && bm == 128)) continue;
+        if (bm_forced && bm != bm_forced && !(bm_forced == 192 && EPI == VN_EPI_GEGLU && !geglu192 && bm == 128)) continue;
         const long tiles = (long)vn_cdiv(a.M, bm) * vn_cdiv(a.N, X3_BN);
         for (int ns = 1; ns <= (can_split ? 4 : 1); ns *= 2) {
             if (ns > 1) {
@@ -1211,7 +1215,7 @@ static int x3_attrs(vn_ctx* ctx) {
     constexpr int NP = FMT ? 2 : 3;
     int rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 1, 0, FMT>, x3_lds_bytes<1, NP>());
     if (!rc) rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 2, 0, FMT>, x3_lds_bytes<2, NP>());
-    if constexpr (EPI != VN_EPI_GEGLU) {
+    if constexpr (EPI != VN_EPI_GEGLU || !FMT) {
         if (!rc) rc = x3_attr(ctx, vn_gemm_x3_kernel<EPI, 3, 0, FMT>, x3_lds_bytes<3, NP>());
     }
     if constexpr (EPI != VN_EPI_CONV && !FMT) {
