@@ -814,6 +814,15 @@ __global__ __launch_bounds__(2 * KH * 64) void vn_attention_x3_pair_kernel(const
     stage_op(0, true);
     if (NH > 1) stage_op(1, false);
     const float* Vs = smem + kh * AXS + 2 * KB;
+    // The two waves of a SIMD are w and w + 4.  With all eight waves in lock-step their matrix phases (QK, PV) coincide and so do their
+    // VALU phases (softmax): the pipe idles through every softmax.  Waves 4-7 (key parts 2 / 3: their own stages, their own DMA) therefore
+    // run ONE barrier slot behind waves 0-3 — while one wave of a SIMD is in its softmax the other issues MFMAs — by passing one extra
+    // barrier here (waves 0-3 pass one more after the loop); the waves that share a stage are in the same group.
+    const bool late = KH == 4 && wave >= 4;
+    if (late) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's part of the bias table is written
+        AX_RAW_BARRIER();
+    }
     for (int i = 0; i < NH; ++i) {
         const float* Ks = smem + kh * AXS + (i & 1) * KB;
         const int kt = kh * NH + i;
@@ -864,6 +873,9 @@ __global__ __launch_bounds__(2 * KH * 64) void vn_attention_x3_pair_kernel(const
         AX_RAW_BARRIER();                                        // every V^T stage has been read
         if (more) stage_op(i + 1, true);
     }
+    // the early group passes the late group's last barrier with it: nobody writes a merge image (they overlay the stages) before every
+    // wave of the block has read its last V^T fragments
+    if (KH == 4 && !late) AX_RAW_BARRIER();
     // merge the KH key parts of each query sub-block (fixed order).  Image per wave in the (free) stages: 8 groups of 64 lanes x 16 B, m, l
     float* mine = smem + wave * 2304;
 #pragma unroll

@@ -1126,7 +1126,11 @@ static x3_plan x3_choose(const vn_ctx* ctx, const vn_gemm_args& a, int cus, doub
             // relative to 240 of 256 CUs busy): 0.72 at 30 tiles, 0.80 at 120, 0.83 at 150, 0.86 at 180, 0.96 at 210.  Piecewise linear
             // in the fill; the f16x2 calibration keeps its own single factor (`partial` < 1)
             const long blocks = tiles * ns, rounds = (blocks + cus - 1) / cus;
-            double cost = (double)rounds * (nk / (double)ns) * kt_us * rel[hi] + fixed[hi];
+            // (the 96-row tile moves 17 % more operand bytes per flop: with every CU busy — several rounds — a k-tile costs 0.85 of a
+            // 128-row tile's, measured at M = 4600 (profiles/r05_gemm_tile96_check_and_sweep.txt: 243 vs 239 us for 6 vs 5 rounds); the
+            // 0.77 of the table is the one-round figure)
+            const double relh = (bm == 96 && rounds > 1) ? 0.85 : rel[hi];
+            double cost = (double)rounds * (nk / (double)ns) * kt_us * relh + fixed[hi];
             if (blocks < cus) {
                 const double fill = (double)blocks / cus;
                 const double under = fill <= 0.6 ? 0.70 + 0.20 * fill : 0.82 + 0.53 * (fill - 0.6);
