@@ -475,7 +475,8 @@ def main():
         for m_ in (itf.coarse, itf.c2f):                           # (the `alt` block left the models in f16x2: time the swap at the headline precision)
             if m_.precision != args.dtype:
                 m_.set_precision(args.dtype)
-        itf.coarse.apply_lora(la)                                  # first use: snapshots the un-merged blob (one-off)
+        itf.coarse.apply_lora(la)                                  # first use: snapshots the un-merged blob (one-off, 1.1-1.3 GB clone each)
+        itf.c2f.apply_lora(lb)
         torch.cuda.synchronize()
         t_l = time.perf_counter()
         itf.coarse.apply_lora(la)

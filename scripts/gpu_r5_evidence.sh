@@ -49,7 +49,13 @@ for f in $(find /tmp/pt -name "*kernel_trace.csv"); do python $R/scripts/kstats_
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o fetch -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-events --no-alt > /dev/null 2> $R/$O/pmc_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o write -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-events --no-alt > /dev/null 2> $R/$O/pmc_write.err
 timeout 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d /tmp/psq -o sq -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-events --no-alt > /dev/null 2> $R/$O/pmc_sq.err
+rm -rf /tmp/pfh /tmp/pwh
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pfh -o fetch -- python $R/bench.py --dtype f16x2 --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-events > /dev/null 2> $R/$O/pmc_fetch_h2.err
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pwh -o write -- python $R/bench.py --dtype f16x2 --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-events > /dev/null 2> $R/$O/pmc_write_h2.err
 cd $R
+python scripts/pmc_summary.py /tmp/pfh FETCH_SIZE > $O/pmc_fetch_size_h2.txt 2>&1
+python scripts/pmc_summary.py /tmp/pwh WRITE_SIZE > $O/pmc_write_size_h2.txt 2>&1
+python scripts/traffic_from_pmc.py $O/pmc_fetch_size_h2.txt $O/pmc_write_size_h2.txt vn_gemm_x3 $O/traffic_h2.json > /dev/null 2>&1
 python scripts/pmc_summary.py /tmp/pf FETCH_SIZE > $O/pmc_fetch_size.txt 2>&1
 python scripts/pmc_summary.py /tmp/pw WRITE_SIZE > $O/pmc_write_size.txt 2>&1
 python scripts/traffic_from_pmc.py $O/pmc_fetch_size.txt $O/pmc_write_size.txt vn_gemm_x3 $O/traffic_x3.json > /dev/null 2>&1
@@ -58,3 +64,4 @@ head -14 $O/last_vamp_kernel_stats.txt; cat $O/traffic_x3.json | head -12; head 
 bash scripts/gpu_model_clock.sh $TAG/clock --no-alt > $O/clock.txt 2>&1; tail -12 $O/clock.txt
 timeout 200 python scripts/power_trace.py $O/power_probe -- scripts/ubench/mfma_power_probe > $O/mfma_power_probe.txt 2>&1; cat $O/mfma_power_probe.txt | grep -E "^mode|^--" ; tail -5 $O/power_probe.txt
 grep -v "^  +" $O/config1_forward_timeline.txt | head -16
+bash scripts/gpu_codec_trace.sh $TAG/codec bf16x3 > $O/codec_trace.log 2>&1; tail -3 $O/codec_trace.log

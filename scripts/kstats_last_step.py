@@ -52,6 +52,12 @@ for j, r in enumerate(step):
     if "vn_lora_merge_kernel" in r["Kernel_Name"]:
         step = step[:j]
         break
+# ... and neither is anything that follows a long host-side pause behind the last forward (the process going on to something else)
+last_marker = max((j for j, r in enumerate(step) if marker in r["Kernel_Name"]), default=0)
+for j in range(last_marker + 1, len(step)):
+    if int(step[j]["Start_Timestamp"]) - int(step[j - 1]["End_Timestamp"]) > 10_000_000:        # 10 ms
+        step = step[:j]
+        break
 agg = defaultdict(lambda: [0, 0])
 for r in step:
     a = agg[r["Kernel_Name"]]
