@@ -476,6 +476,11 @@ int  vn_dropout_keep_mask(vn_ctx* ctx, uint64_t seed, int64_t step, int layer, i
 int  vn_attention_train_f32(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
                             float* out, float* lse, const float* dout, float* dqkv, float* dbias, int B, int H, int T,
                             int num_buckets, int max_distance, float dropout, uint64_t seed, void* stream);
+/* The same op on the split-plane pipe (what the training step runs when its GEMMs do: six bf16-MFMA products of exact three-way
+ * operand splits per product; the same dropout stream and the same deterministic bias gradient).                         */
+int  vn_attention_train_bf16x3(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                               float* out, float* lse, const float* dout, float* dqkv, float* dbias, int B, int H, int T,
+                               int num_buckets, int max_distance, float dropout, uint64_t seed, void* stream);
 
 /* dst [C][ldd] = transpose(src [R][C]), columns R..ldd-1 zero-filled (ldd % 4 == 0): the layout pass in front of the
  * weight-gradient GEMMs; exposed for tests and tuning.                                                              */

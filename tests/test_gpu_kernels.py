@@ -237,10 +237,12 @@ def test_gemm_bf16_fast_mode(eng, M, N, K):
 
 
 # ----------------------------------------------------------------------------- training kernels
-@pytest.mark.parametrize("B,H,T,p", [(1, 2, 575, 0.1), (2, 3, 37, 0.0), (1, 1, 64, 0.1), (2, 2, 130, 0.1)])
-def test_attention_train_fwd_bwd_vs_autograd(eng, B, H, T, p):
-    """vn_attention_train_fwd / _bwd_dq / _bwd_dkv against torch CPU autograd of transformer.py:234-254 with the engine's
-    own dropout keep-mask injected.  Tolerances: out 2e-6 abs, gradients 2e-5 of their max-abs."""
+@pytest.mark.parametrize("entry", ["vn_attention_train_f32", "vn_attention_train_bf16x3"])
+@pytest.mark.parametrize("B,H,T,p", [(1, 2, 575, 0.1), (2, 3, 37, 0.0), (1, 1, 64, 0.1), (2, 2, 130, 0.1), (3, 2, 291, 0.1)])
+def test_attention_train_fwd_bwd_vs_autograd(eng, B, H, T, p, entry):
+    """vn_attention_train_fwd / _bwd_dq / _bwd_dkv (fp32-input MFMA) and their split-plane counterparts (attention_x3.hip TRAIN forward,
+    attention_train_x3.hip backward) against torch CPU autograd of transformer.py:234-254 with the engine's own dropout keep-mask
+    injected.  Tolerances: out 2e-6 abs, gradients 2e-5 of their max-abs."""
     import ctypes as C
     from oracle import vampnet_oracle as O
     lib = eng.lib
@@ -255,9 +257,9 @@ def test_attention_train_fwd_bwd_vs_autograd(eng, B, H, T, p):
     dqkv = torch.zeros(B * T, 3 * H * 64, device="cuda")
     dbias = torch.zeros(32, H, device="cuda")
     seed = 77
-    eng.check(lib.vn_attention_train_f32(eng.handle, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), rd.data_ptr(),
-                                            out.data_ptr(), lse.data_ptr(), dd.data_ptr(), dqkv.data_ptr(), dbias.data_ptr(),
-                                            B, H, T, 32, 128, p, seed, eng.stream()), "vn_attention_train_f32")
+    eng.check(getattr(lib, entry)(eng.handle, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), rd.data_ptr(),
+                                  out.data_ptr(), lse.data_ptr(), dd.data_ptr(), dqkv.data_ptr(), dbias.data_ptr(),
+                                  B, H, T, 32, 128, p, seed, eng.stream()), entry)
     keep = torch.ones(B * H * T, T)
     if p > 0:
         m8 = torch.empty(B * H * T, T, dtype=torch.uint8, device="cuda")

@@ -108,6 +108,7 @@ SYMBOLS = {
     "vn_dropout_keep_mask": (C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int64, C.c_int64,
                                        C.c_int, _P, _P]),
     "vn_attention_train_f32": (C.c_int, [_P] * 10 + [C.c_int] * 5 + [C.c_float, C.c_uint64, _P]),
+    "vn_attention_train_bf16x3": (C.c_int, [_P] * 10 + [C.c_int] * 5 + [C.c_float, C.c_uint64, _P]),
     "vn_transpose_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "vn_mt19937_generate": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P]),
     "vn_mt19937_jump": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P]),

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libvampnet_hip.so")
 SOURCES = ["engine.hip", "gemm_f32.hip", "attention_f32.hip", "elementwise.hip", "sampling.hip", "conv1d_f32.hip",
-           "train.hip", "train_kernels.hip", "attention_train.hip", "torch_rng.hip", "gemm_x3.hip", "attention_x3.hip", "comm.hip", "codec.hip", "codec_plan.hip", "preprocess.hip"]
+           "train.hip", "train_kernels.hip", "attention_train.hip", "torch_rng.hip", "gemm_x3.hip", "attention_x3.hip", "attention_train_x3.hip", "comm.hip", "codec.hip", "codec_plan.hip", "preprocess.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
@@ -19,7 +19,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    deps = [os.path.join(CSRC, h) for h in ("vn_common.h", "vn_model.h", "vn_train.h")] + [
+    deps = [os.path.join(CSRC, h) for h in ("vn_common.h", "vn_model.h", "vn_train.h", "attention_x3_dev.h")] + [
         os.path.join(HERE, "..", "include", "vampnet_hip.h"), os.path.join(HERE, "..", "include", "vampnet_hip_debug.h")]
     objs, procs = [], []
     for src in SOURCES:

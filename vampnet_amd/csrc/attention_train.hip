@@ -408,10 +408,10 @@ __global__ __launch_bounds__(64) void vn_dbias_reduce_kernel(const float* __rest
     if (threadIdx.x == 0) dbias[i] = accumulate ? dbias[i] + a : a;
 }
 
-int vn_launch_dbias_reduce(vn_ctx* ctx, const float* partial, float* dbias, int n_slabs, long slab_floats, int B, int H, int T,
+int vn_launch_dbias_reduce(vn_ctx* ctx, const float* partial, float* dbias, int n_slabs, long slab_floats, int B, int H, int nqb,
                            int nbuckets, bool accumulate, hipStream_t s) {
     hipLaunchKernelGGL(vn_dbias_reduce_kernel, dim3(nbuckets * H), dim3(64), 0, s, partial, dbias, n_slabs, slab_floats, B, H,
-                       vn_cdiv(T, 64), nbuckets, accumulate ? 1 : 0);
+                       nqb, nbuckets, accumulate ? 1 : 0);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
 }

@@ -1,0 +1,556 @@
+// Training-mode self-attention BACKWARD on the bf16 matrix cores at fp32 grade ("bf16x3"), for gfx950 — the split-plane counterpart of
+// attention_train.hip's two fp32-MFMA kernels (same math, same dropout stream, same deterministic bias gradient), used by the training
+// step when its GEMMs run on the split-plane pipe (train.hip, VN_TRAIN_ATTN_X3).  The forward is the TRAIN instantiation of the
+// inference kernel (attention_x3.hip: dropout + log-sum-exp).
+//
+// Reference semantics (vampnet/modules/transformer.py:234-254), per (b, h), with delta[q] = sum_d dO[q][d] O[q][d]:
+//   S = (q / 8) k^T + bias ; P = exp(S - lse) ; Pd = keep * scale * P ;
+//   dPd = dO v^T ; dS = P o (keep * scale * dPd - delta) ;
+//   dv = Pd^T dO ; dq = dS k / 8 ; dk = dS^T (q / 8) ; dbias[h][bucket(key - query)] += dS
+// Every product is SIX v_mfma_f32_32x32x16_bf16 products of exact three-way bf16 splits (attention_x3_dev.h); P, Pd and dS are
+// split in the registers that hold them.  An MFMA contracts over the index that is contiguous per lane in BOTH operands, so
+//   * products over d (S, dPd) take ROW-major [token][64] tiles: q16 / k16 as the QKV GEMM wrote them, v16 and do16 from the prep
+//     kernels below;
+//   * products over tokens (dq = dS k, dv = Pd^T dO, dk = dS^T q) take TRANSPOSED tiles [64 d][32 tokens]: kt16, dot16, qt16, blocked
+//     per (b, h) by 32-token tiles (zero beyond T), also from the prep kernels (bf16 plane transposes; the sum of the three planes
+//     of an element is its fp32 value in either layout).
+// Two kernels, both 4 waves x 32 lane-local columns, stages single-buffered and refilled by LDS-DMA as soon as every wave has
+// read them (four raw barriers per tile; two blocks per CU overlap each other's waits):
+//   dq kernel : block = 128 queries; per key tile  S^T = K Q^T, dPd^T = V dO^T (A = K / V tile, B = Q / dO fragments in registers),
+//               dS^T in registers, dQ^T += K^T dS^T; the bias gradient as in attention_train.hip (per-wave tables over key - query,
+//               diagonal sums through a wave-private LDS scratch, single-bucket tiles summed in registers; no atomics);
+//   dkv kernel: block = 128 keys; per query tile  S = Q K^T, dPd = dO V^T (A = Q / dO tile, B = K / V fragments in registers),
+//               dV^T += dO^T Pd, dK^T += Q^T dS.
+// Outputs token-major [B*T][3D] (dq | dk | dv), the A operand of the w_qkv backward GEMMs.
+// Algorithmic FLOPs per (b, h): 10 T T 64 (executed 14: S and dPd twice), x 6 plane products on the bf16 pipe.
+#include "attention_x3_dev.h"
+#include "vn_train.h"
+
+#define AB_PLANE 1024                    // floats of one plane tile (4 KiB)
+
+// ---- prep: transposed / row-major plane images ----------------------------------------------------------------------------------
+// row-major planes [which][b h][T][64] (q16 / k16, plane stride ps)  ->  blocked transposes dst[which] [3][b h][NTt][64][32]
+__global__ __launch_bounds__(256) void vn_ax_bwd_prep_t_kernel(const uint16_t* __restrict__ src, long ps, long which_stride,
+                                                               uint16_t* __restrict__ dst0, uint16_t* __restrict__ dst1, long pd, int T,
+                                                               int NTt) {
+    __shared__ uint16_t lt[32][72];
+    const int tile = blockIdx.x, bh = blockIdx.y, p = blockIdx.z % 3, which = blockIdx.z / 3;
+    const int tid = threadIdx.x;
+    {
+        const int tk = tid >> 3, d8 = (tid & 7) * 8, t = tile * 32 + tk;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (t < T) v = *(const u32x4*)(src + which * which_stride + p * ps + ((size_t)bh * T + t) * VN_DHEAD + d8);
+        *(u32x4*)(&lt[tk][d8]) = v;
+    }
+    __syncthreads();
+    const int dd = tid >> 2, k8 = (tid & 3) * 8;
+    uint16_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = lt[k8 + i][dd];
+    const u32x4 o = {e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16), e[6] | ((unsigned)e[7] << 16)};
+    uint16_t* dst = which ? dst1 : dst0;
+    *(u32x4*)(dst + p * pd + (((size_t)bh * NTt + tile) * VN_DHEAD + dd) * 32 + k8) = o;
+}
+
+// V^T blocked by 32 GLOBAL token rows (the forward's operand) -> row-major planes v16 [3][b h][T][64]
+__global__ __launch_bounds__(256) void vn_ax_bwd_prep_v_kernel(const uint16_t* __restrict__ vt16, long plane_vt, uint16_t* __restrict__ v16,
+                                                               long pv, int B, int H, int T, int MT) {
+    __shared__ uint16_t lt[64][40];
+    const int mt = blockIdx.x, h = blockIdx.y, p = blockIdx.z, tid = threadIdx.x;
+    {
+        const int dd = tid >> 2, k8 = (tid & 3) * 8;
+        *(u32x4*)(&lt[dd][k8]) = *(const u32x4*)(vt16 + p * plane_vt + (((size_t)h * MT + mt) * VN_DHEAD + dd) * 32 + k8);
+    }
+    __syncthreads();
+    const int tk = tid >> 3, d8 = (tid & 7) * 8;
+    const long m = (long)mt * 32 + tk;
+    if (m >= (long)B * T) return;
+    const int b = (int)(m / T), t = (int)(m - (long)b * T);
+    uint16_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = lt[d8 + i][tk];
+    const u32x4 o = {e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16), e[6] | ((unsigned)e[7] << 16)};
+    *(u32x4*)(v16 + p * pv + (((size_t)b * H + h) * T + t) * VN_DHEAD + d8) = o;
+}
+
+// dO (fp32, token-major [B*T][H*64]) -> do16 row-major planes [3][b h][T][64], dot16 blocked transposes, delta[b][h][t] = sum_d dO O
+__global__ __launch_bounds__(256) void vn_ax_bwd_prep_do_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                                uint16_t* __restrict__ do16, long pdo, uint16_t* __restrict__ dot16,
+                                                                long pdt, float* __restrict__ delta, int H, int T, int NTt) {
+    __shared__ uint16_t lt[3][32][72];
+    const int tile = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const size_t bh = (size_t)b * H + h;
+    {
+        const int tk = tid >> 3, d8 = (tid & 7) * 8, t = tile * 32 + tk;
+        f32x8 g = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float dl = 0.f;
+        if (t < T) {
+            const size_t off = ((size_t)b * T + t) * ((size_t)H * VN_DHEAD) + h * VN_DHEAD + d8;
+            const f32x4 g0 = *(const f32x4*)(dout + off), g1 = *(const f32x4*)(dout + off + 4);
+            const f32x4 o0 = *(const f32x4*)(out + off), o1 = *(const f32x4*)(out + off + 4);
+            g = f32x8{g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dl += g0[e] * o0[e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dl += g1[e] * o1[e];
+        }
+        dl += __shfl_xor(dl, 1);
+        dl += __shfl_xor(dl, 2);
+        dl += __shfl_xor(dl, 4);
+        bf16x8 p0, p1, p2;
+        vn_split3_x8(g, p0, p1, p2);
+        const u32x4 w0 = __builtin_bit_cast(u32x4, p0), w1 = __builtin_bit_cast(u32x4, p1), w2 = __builtin_bit_cast(u32x4, p2);
+        *(u32x4*)(&lt[0][tk][d8]) = w0;
+        *(u32x4*)(&lt[1][tk][d8]) = w1;
+        *(u32x4*)(&lt[2][tk][d8]) = w2;
+        if (t < T) {
+            const size_t o = (bh * T + t) * VN_DHEAD + d8;
+            *(u32x4*)(do16 + o) = w0;
+            *(u32x4*)(do16 + pdo + o) = w1;
+            *(u32x4*)(do16 + 2 * pdo + o) = w2;
+            if ((tid & 7) == 0) delta[bh * T + t] = dl;
+        }
+    }
+    __syncthreads();
+    const int dd = tid >> 2, k8 = (tid & 3) * 8;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        uint16_t e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = lt[p][k8 + i][dd];
+        const u32x4 o = {e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16), e[6] | ((unsigned)e[7] << 16)};
+        *(u32x4*)(dot16 + p * pdt + ((bh * NTt + tile) * VN_DHEAD + dd) * 32 + k8) = o;
+    }
+}
+
+// ---- shared pieces of the two backward kernels ----------------------------------------------------------------------------------
+// DMA of piece `wave` of the three plane tiles of one operand tile (4 KiB per plane) into LDS at dst (floats; + wave * 256 added here)
+__device__ __forceinline__ void ab_stage3(__amdgpu_buffer_rsrc_t rs, float* dst, int wave, unsigned voff, unsigned soff, unsigned plane_bytes) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) ax_dma(rs, dst + p * AB_PLANE + wave * 256, voff, soff + p * plane_bytes);
+}
+// store one accumulator pair acc[2] (C map of the 32x32 MFMA: rows d, column = this lane's token) x scale to row `row` of dqkv at col0
+__device__ __forceinline__ void ab_store(const f32x16 (&acc)[2], float scale, float* __restrict__ dqkv, size_t row, int ld, int col0, int hh) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = {acc[dt][4 * g] * scale, acc[dt][4 * g + 1] * scale, acc[dt][4 * g + 2] * scale, acc[dt][4 * g + 3] * scale};
+            *(f32x4*)(dqkv + row * (size_t)ld + col0 + 32 * dt + 8 * g + 4 * hh) = v;
+        }
+}
+// the three bf16 planes of a 32 x 32 accumulator tile as the B operand of the next product (two 16-row steps)
+__device__ __forceinline__ void ab_planes(const f32x16& a, f32x4 (&pf)[3][2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const f32x8 x = {a[8 * s], a[8 * s + 1], a[8 * s + 2], a[8 * s + 3], a[8 * s + 4], a[8 * s + 5], a[8 * s + 6], a[8 * s + 7]};
+        bf16x8 p0, p1, p2;
+        vn_split3_x8(x, p0, p1, p2);
+        pf[0][s] = __builtin_bit_cast(f32x4, p0); pf[1][s] = __builtin_bit_cast(f32x4, p1); pf[2][s] = __builtin_bit_cast(f32x4, p2);
+    }
+}
+__device__ __forceinline__ void ab_zero(f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+// ---- dq (+ bias gradient) -------------------------------------------------------------------------------------------------------
+// LDS (floats): stage [K 3 planes | V 3 planes | K^T 3 planes] = 9216, bias table nb, per-wave d(bias) tables 4 x tn (tn = 2 near_r + 1:
+// key - query offsets of the tiles that are NOT inside one bucket, train.hip derives near_r from the LUT), far sums 4 x 64, per-wave
+// diagonal scratch 4 x [32 queries][64].
+// arguments of the backward launch (one kernel, two block roles: see vn_attention_x3_bwd_kernel)
+struct ab_args {
+    const uint16_t *q16, *k16, *v16, *kt16, *qt16, *do16, *dot16;
+    long plane_qk, plane_r, plane_t;
+    const float *bias_full, *lse, *delta;
+    const int32_t* lut;
+    float *dqkv, *dbias_partial;
+    int B, H, T, nbuckets, near_r;
+    vn_drop d;
+};
+
+template <bool DBIAS>
+__device__ __forceinline__ void ab_dq_block(const ab_args& A, const int bid, const int nwg) {
+    const uint16_t* __restrict__ q16 = A.q16; const uint16_t* __restrict__ k16 = A.k16; const uint16_t* __restrict__ v16 = A.v16;
+    const uint16_t* __restrict__ kt16 = A.kt16; const uint16_t* __restrict__ do16 = A.do16;
+    const long plane_qk = A.plane_qk, plane_r = A.plane_r, plane_t = A.plane_t;
+    const float* __restrict__ bias_full = A.bias_full; const int32_t* __restrict__ lut = A.lut;
+    const float* __restrict__ lse = A.lse; const float* __restrict__ delta = A.delta;
+    float* __restrict__ dqkv = A.dqkv; float* __restrict__ dbias_partial = A.dbias_partial;
+    const int H = A.H, T = A.T, nbuckets = A.nbuckets, near_r = A.near_r;
+    const vn_drop d = A.d;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nb = 2 * T - 1, tn = 2 * near_r + 1;
+    float* Ks = smem;
+    float* Vs = smem + 3 * AB_PLANE;
+    float* KTs = smem + 6 * AB_PLANE;
+    float* bt = smem + 9 * AB_PLANE;
+    float* dbt_all = bt + nb;
+    float* bk_all = dbt_all + 4 * tn;
+    float* wscr_all = bk_all + 256;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const ax_lane L = ax_lane_init(lane);
+    const int nqb = (T + 127) / 128, NT = (T + 31) / 32;
+    const int lid = ax_walk(bid, nwg);
+    const int qb = lid % nqb, hbi = lid / nqb, h = hbi % H, b = hbi / H;
+    const size_t head = (size_t)b * H + h;
+    const int Dm = H * VN_DHEAD;
+    const int q0 = qb * 128 + wave * 32;
+    const bool active = q0 < T;
+    const int qrow = q0 + L.l31, qrow_c = qrow < T ? qrow : T - 1;
+    const bool qok = qrow < T;
+
+    for (int i = tid; i < nb; i += 256) bt[i] = bias_full[(size_t)h * nb + i];
+    if constexpr (DBIAS) {
+        for (int i = tid; i < 4 * tn + 256; i += 256) dbt_all[i] = 0.f;          // the four tables and, contiguous, the far sums
+        for (int i = tid; i < 4 * 2048; i += 256) wscr_all[i] = 0.f;             // slots outside a tile's diagonals stay 0
+    }
+    float* wscr = wscr_all + wave * 2048;
+    float* dbt = dbt_all + wave * tn;
+    float* bk = bk_all + wave * 64;
+
+    f32x4 qf[3][4], dof[3][4];
+    ax_load_q<3>(qf, q16 + head * (size_t)T * VN_DHEAD, plane_qk, qrow_c, L.hh);
+    ax_load_q<3>(dof, do16 + head * (size_t)T * VN_DHEAD, plane_r, qrow_c, L.hh);
+    const float my_lse = lse[head * T + qrow_c], dl = delta[head * T + qrow_c];
+    const uint32_t rk = vn_drop_rowkey(d, (long)head * T + qrow_c);
+
+    const int krow = 8 * wave + (lane >> 3), vrow = 16 * wave + (lane >> 2);
+    const unsigned kvoff = (unsigned)(krow * VN_DHEAD + ((lane & 7) ^ ((krow >> 1) & 7)) * 8) * 2u;
+    const unsigned vvoff = (unsigned)(vrow * AX_KT + ((lane & 3) ^ ((vrow >> 2) & 3)) * 8) * 2u;
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)k16, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)v16, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)kt16, 0, 0x7fffffff, 0x00020000);
+    const unsigned r0 = (unsigned)(head * (size_t)T * VN_DHEAD * 2), t0 = (unsigned)(head * (size_t)NT * (VN_DHEAD * AX_KT) * 2);
+    const unsigned kpl = (unsigned)(plane_qk * 2), vpl = (unsigned)(plane_r * 2), tpl = (unsigned)(plane_t * 2);
+    auto stage_kv = [&](int kt) {
+        ab_stage3(krs, Ks, wave, kvoff, r0 + kt * (AX_KT * VN_DHEAD * 2), kpl);
+        ab_stage3(vrs, Vs, wave, kvoff, r0 + kt * (AX_KT * VN_DHEAD * 2), vpl);
+    };
+    auto stage_t = [&](int kt) { ab_stage3(trs, KTs, wave, vvoff, t0 + kt * (VN_DHEAD * AX_KT * 2), tpl); };
+
+    f32x16 o[2];
+    ab_zero(o[0]); ab_zero(o[1]);
+    stage_kv(0);
+    stage_t(0);
+    for (int kt = 0; kt < NT; ++kt) {
+        const int key0 = kt * AX_KT;
+        const bool more = kt + 1 < NT, full = key0 + AX_KT <= T;
+        // bias gradient: a wave tile whose whole key - query range lies in ONE bucket is summed in registers (wave-uniform test)
+        bool far = false;
+        int far_bucket = 0;
+        if constexpr (DBIAS) {
+            const int rel_lo = key0 - (q0 + 31), rel_hi = key0 + 31 - q0;
+            const int lo_c = rel_lo < -(T - 1) ? -(T - 1) : rel_lo, hi_c = rel_hi > T - 1 ? T - 1 : rel_hi;
+            far_bucket = __builtin_amdgcn_readfirstlane(lut[lo_c + T - 1]);
+            far = (rel_lo > 0 || rel_hi < 0) && far_bucket == __builtin_amdgcn_readfirstlane(lut[hi_c + T - 1]);
+        }
+        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");         // this wave's K / V pieces landed (K^T may fly)
+        AX_RAW_BARRIER();
+        f32x16 sacc, dpacc;
+        if (active) {
+            if (full) ax_bias_init<true>(sacc, bt, key0, L.hh, qrow_c, T);
+            else ax_bias_init<false>(sacc, bt, key0, L.hh, qrow_c, T);
+            ab_zero(dpacc);
+            ax_qk<3>(sacc, Ks, qf, L);
+            ax_qk<3>(dpacc, Vs, dof, L);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        AX_RAW_BARRIER();                                                    // K and V have been read by everybody
+        if (more) stage_kv(kt + 1);
+        f32x4 dsf[3][2];
+        if (active) {
+            float far_sum = 0.f;
+            float dsv[16];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float mul[8];
+                if (d.thresh16) ax_drop8(d, rk, key0 + 16 * s + 8 * L.hh, mul);
+                f32x8 pe;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = 8 * s + e, key = key0 + 16 * s + 8 * L.hh + e;
+                    const float p = (key < T && qok) ? ax_exp<false>(sacc[r] - my_lse) : 0.f;
+                    const float ds = p * (dpacc[r] * (d.thresh16 ? mul[e] : 1.0f) - dl);
+                    pe[e] = ds;
+                    dsv[r] = ds;
+                    far_sum += ds;
+                }
+                bf16x8 p0, p1, p2;
+                vn_split3_x8(pe, p0, p1, p2);
+                dsf[0][s] = __builtin_bit_cast(f32x4, p0); dsf[1][s] = __builtin_bit_cast(f32x4, p1); dsf[2][s] = __builtin_bit_cast(f32x4, p2);
+            }
+            if constexpr (DBIAS) {
+                if (far) {
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) far_sum += __shfl_xor(far_sum, off);
+                    if (lane == 0) bk[far_bucket] += far_sum;
+                } else {
+                    // near-diagonal tile: the wave's 32 queries x 32 keys of dS through its scratch [query j][key - j + 31] (row pitch 64:
+                    // the column index already moves with j, so both the writes and the column reads are conflict-free), then lane dg
+                    // sums diagonal dg and makes ONE plain update of the wave's table (lanes own distinct diagonals)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) wscr[L.l31 * 64 + (16 * (r >> 3) + 8 * L.hh + (r & 7)) - L.l31 + 31] = dsv[r];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane < 63) {
+                        float a = 0.f;
+#pragma unroll
+                        for (int jj = 0; jj < 32; ++jj) a += wscr[jj * 64 + lane];
+                        const int idx = key0 - q0 - 31 + lane + near_r;
+                        if (idx >= 0 && idx < tn) dbt[idx] += a;
+                    }
+                }
+            }
+        }
+        if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // K^T of this tile landed (the next K / V fly)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        AX_RAW_BARRIER();
+        if (active) ax_pv<3>(o, KTs, dsf, L);                               // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        AX_RAW_BARRIER();                                                    // K^T has been read by everybody
+        if (more) stage_t(kt + 1);
+    }
+    if (active && qok) ab_store(o, 0.125f, dqkv, (size_t)b * T + qrow, 3 * Dm, h * VN_DHEAD, L.hh);
+    if constexpr (DBIAS) {
+        // the block's bias gradient in a fixed order: wave tables 0 + 1 + 2 + 3; every table entry goes to its bucket (LUT); eight
+        // threads per bucket sum strided slices, combined 0..7, plus the waves' far sums -> the block's slot of dbias_partial
+        __syncthreads();
+        int* lut_s = (int*)smem;                                             // the stages are dead
+        float* red = smem + tn;                                              // [64 buckets][8]
+        for (int i = tid; i < tn; i += 256) {
+            dbt_all[i] = ((dbt_all[i] + dbt_all[tn + i]) + dbt_all[2 * tn + i]) + dbt_all[3 * tn + i];
+            const int rel = i - near_r;
+            lut_s[i] = (rel > -T && rel < T) ? lut[rel + T - 1] : -1;
+        }
+        __syncthreads();
+        for (int bkt = tid >> 3; bkt < nbuckets; bkt += 32) {
+            float a = 0.f;
+            for (int i = (tid & 7); i < tn; i += 8) a += lut_s[i] == bkt ? dbt_all[i] : 0.f;
+            red[bkt * 8 + (tid & 7)] = a;
+        }
+        __syncthreads();
+        if (tid < nbuckets) {
+            float a = 0.f;
+#pragma unroll
+            for (int pth = 0; pth < 8; ++pth) a += red[tid * 8 + pth];
+            a += ((bk_all[tid] + bk_all[64 + tid]) + bk_all[128 + tid]) + bk_all[192 + tid];
+            dbias_partial[(head * nqb + qb) * 64 + tid] = a;
+        }
+    }
+}
+
+// ---- dk, dv ---------------------------------------------------------------------------------------------------------------------
+// LDS (floats): stage [Q | dO | Q^T | dO^T] x 3 planes = 12288, then lse / delta / dropout row keys of the tile's 32 queries (two
+// buffers each), then the bias table.
+__device__ __forceinline__ void ab_dkv_block(const ab_args& A, const int bid, const int nwg) {
+    const uint16_t* __restrict__ q16 = A.q16; const uint16_t* __restrict__ k16 = A.k16; const uint16_t* __restrict__ v16 = A.v16;
+    const uint16_t* __restrict__ qt16 = A.qt16; const uint16_t* __restrict__ dot16 = A.dot16; const uint16_t* __restrict__ do16 = A.do16;
+    const long plane_qk = A.plane_qk, plane_r = A.plane_r, plane_t = A.plane_t;
+    const float* __restrict__ bias_full = A.bias_full; const float* __restrict__ lse = A.lse; const float* __restrict__ delta = A.delta;
+    float* __restrict__ dqkv = A.dqkv;
+    const int H = A.H, T = A.T;
+    const vn_drop d = A.d;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nb = 2 * T - 1;
+    float* Qs = smem;
+    float* dOs = smem + 3 * AB_PLANE;
+    float* QTs = smem + 6 * AB_PLANE;
+    float* dOTs = smem + 9 * AB_PLANE;
+    float* lse_s = smem + 12 * AB_PLANE;         // [2][32]
+    float* del_s = lse_s + 64;
+    uint32_t* rk_s = (uint32_t*)(del_s + 64);
+    float* bt = del_s + 128;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const ax_lane L = ax_lane_init(lane);
+    const int nkb = (T + 127) / 128, NT = (T + 31) / 32;
+    const int lid = ax_walk(bid, nwg);
+    const int kb = lid % nkb, hbi = lid / nkb, h = hbi % H, b = hbi / H;
+    const size_t head = (size_t)b * H + h;
+    const int Dm = H * VN_DHEAD;
+    const int k0 = kb * 128 + wave * 32;
+    const bool active = k0 < T;
+    const int krow = k0 + L.l31, krow_c = krow < T ? krow : T - 1;
+    const bool kok = krow < T;
+
+    for (int i = tid; i < nb; i += 256) bt[i] = bias_full[(size_t)h * nb + i];
+    f32x4 kf[3][4], vf[3][4];
+    ax_load_q<3>(kf, k16 + head * (size_t)T * VN_DHEAD, plane_qk, krow_c, L.hh);
+    ax_load_q<3>(vf, v16 + head * (size_t)T * VN_DHEAD, plane_r, krow_c, L.hh);
+
+    const int rrow = 8 * wave + (lane >> 3), trow = 16 * wave + (lane >> 2);
+    const unsigned rvoff = (unsigned)(rrow * VN_DHEAD + ((lane & 7) ^ ((rrow >> 1) & 7)) * 8) * 2u;
+    const unsigned tvoff = (unsigned)(trow * AX_KT + ((lane & 3) ^ ((trow >> 2) & 3)) * 8) * 2u;
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc((void*)q16, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)do16, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qtrs = __builtin_amdgcn_make_buffer_rsrc((void*)qt16, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dtrs = __builtin_amdgcn_make_buffer_rsrc((void*)dot16, 0, 0x7fffffff, 0x00020000);
+    const unsigned r0 = (unsigned)(head * (size_t)T * VN_DHEAD * 2), t0 = (unsigned)(head * (size_t)NT * (VN_DHEAD * AX_KT) * 2);
+    const unsigned qpl = (unsigned)(plane_qk * 2), dpl = (unsigned)(plane_r * 2), tpl = (unsigned)(plane_t * 2);
+    auto stage_r = [&](int qt) {
+        ab_stage3(qrs, Qs, wave, rvoff, r0 + qt * (AX_KT * VN_DHEAD * 2), qpl);
+        ab_stage3(drs, dOs, wave, rvoff, r0 + qt * (AX_KT * VN_DHEAD * 2), dpl);
+    };
+    auto stage_t = [&](int qt) {
+        ab_stage3(qtrs, QTs, wave, tvoff, t0 + qt * (VN_DHEAD * AX_KT * 2), tpl);
+        ab_stage3(dtrs, dOTs, wave, tvoff, t0 + qt * (VN_DHEAD * AX_KT * 2), tpl);
+    };
+    // per-query scalars of a tile (wave 0, lanes 0..31): loaded one tile ahead, written to the other buffer
+    float n_lse = 0.f, n_del = 0.f;
+    uint32_t n_rk = 0;
+    auto row_load = [&](int qt) {
+        if (wave == 0 && lane < 32) {
+            const int qq = qt * AX_KT + lane, qc = qq < T ? qq : T - 1;
+            n_lse = lse[head * T + qc];
+            n_del = delta[head * T + qc];
+            n_rk = vn_drop_rowkey(d, (long)head * T + qc);
+        }
+    };
+    auto row_write = [&](int buf) {
+        if (wave == 0 && lane < 32) { lse_s[buf * 32 + lane] = n_lse; del_s[buf * 32 + lane] = n_del; rk_s[buf * 32 + lane] = n_rk; }
+    };
+
+    f32x16 accK[2], accV[2];
+    ab_zero(accK[0]); ab_zero(accK[1]); ab_zero(accV[0]); ab_zero(accV[1]);
+    row_load(0);
+    row_write(0);
+    stage_r(0);
+    stage_t(0);
+    for (int qt = 0; qt < NT; ++qt) {
+        const int qq0 = qt * AX_KT, buf = qt & 1;
+        const bool more = qt + 1 < NT;
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");         // this wave's Q / dO pieces landed (the transposes may fly)
+        AX_RAW_BARRIER();
+        f32x16 sacc, dpacc;
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qq = qq0 + 16 * (r >> 3) + 8 * L.hh + (r & 7), qc = qq < T ? qq : T - 1;
+                sacc[r] = bt[krow_c - qc + (T - 1)];
+            }
+            ab_zero(dpacc);
+            ax_qk<3>(sacc, Qs, kf, L);                                      // S[q][key] = Q K^T (+ bias)
+            ax_qk<3>(dpacc, dOs, vf, L);                                    // dPd[q][key] = dO V^T
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        AX_RAW_BARRIER();                                                    // Q and dO have been read by everybody
+        if (more) { row_load(qt + 1); stage_r(qt + 1); }
+        // Pd and dS stay in the registers of S and dPd (fp32) until their product runs: their planes are formed one after the other
+        // behind the next barrier (both plane sets live at once cost 45 spilled VGPRs at the 256 of two waves per SIMD)
+        if (active) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int ql = 16 * s + 8 * L.hh;
+                const f32x4 la = *(const f32x4*)(lse_s + buf * 32 + ql), lb = *(const f32x4*)(lse_s + buf * 32 + ql + 4);
+                const f32x4 da = *(const f32x4*)(del_s + buf * 32 + ql), db = *(const f32x4*)(del_s + buf * 32 + ql + 4);
+                const u32x4 ra = *(const u32x4*)(rk_s + buf * 32 + ql), rb = *(const u32x4*)(rk_s + buf * 32 + ql + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = 8 * s + e, qq = qq0 + ql + e;
+                    const float lq = e < 4 ? la[e & 3] : lb[e & 3], dq_ = e < 4 ? da[e & 3] : db[e & 3];
+                    const uint32_t rq = e < 4 ? ra[e & 3] : rb[e & 3];
+                    const float p = (qq < T && kok) ? ax_exp<false>(sacc[r] - lq) : 0.f;
+                    const float mul = d.thresh16 ? vn_drop_mul(d, vn_drop_bits(rq, krow_c), krow_c) : 1.0f;
+                    sacc[r] = p * mul;                                       // Pd
+                    dpacc[r] = p * (dpacc[r] * mul - dq_);                   // dS
+                }
+            }
+        }
+        if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // the transposes of this tile landed (the next Q / dO fly)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (more) row_write(buf ^ 1);
+        AX_RAW_BARRIER();
+        if (active) {
+            f32x4 pf[3][2];
+            ab_planes(sacc, pf);
+            ax_pv<3>(accV, dOTs, pf, L);                                    // dV^T[d][key] += dO^T[d][q] Pd[q][key]
+            ab_planes(dpacc, pf);
+            ax_pv<3>(accK, QTs, pf, L);                                     // dK^T[d][key] += Q^T[d][q] dS[q][key]
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        AX_RAW_BARRIER();                                                    // the transposes have been read by everybody
+        if (more) stage_t(qt + 1);
+    }
+    if (active && kok) {
+        ab_store(accK, 1.0f, dqkv, (size_t)b * T + krow, 3 * Dm, Dm + h * VN_DHEAD, L.hh);      // q planes carry the 1 / 8
+        ab_store(accV, 1.0f, dqkv, (size_t)b * T + krow, 3 * Dm, 2 * Dm + h * VN_DHEAD, L.hh);
+    }
+}
+
+// ONE launch, two block roles: blocks [0, n_kv) run the dk / dv role, the rest the dq role.  Launched separately each kernel ends with a
+// round in which a good part of the two-per-CU slots idle (T = 575, B = 8: 800 blocks on 512 slots, twice); in one launch the dq blocks
+// fill the slots the dk / dv blocks (the longer ones: dispatched first) leave, as they free up.
+template <bool DBIAS>
+__global__ __launch_bounds__(256, 2) void vn_attention_x3_bwd_kernel(ab_args A, int n_kv) {
+    if ((int)blockIdx.x < n_kv) ab_dkv_block(A, blockIdx.x, n_kv);
+    else ab_dq_block<DBIAS>(A, blockIdx.x - n_kv, gridDim.x - n_kv);
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------------------------------
+// workspace (uint16 elements): v16, do16 [3][n + 2048], qt16, kt16, dot16 [3][B H NTt 2048];  n = B H T 64
+void vn_attention_x3_bwd_ws_layout(int B, int H, int T, vn_ax_bwd_ws* w) {
+    const long n = (long)B * H * T * VN_DHEAD, NTt = (T + 31) / 32;
+    w->plane_r = n + 32 * VN_DHEAD;               // a last key / query tile reads up to 31 rows past T (masked): keep them in the buffer
+    w->plane_t = (long)B * H * NTt * (VN_DHEAD * 32);
+    w->off_v16 = 0;
+    w->off_do16 = 3 * w->plane_r;
+    w->off_qt16 = 6 * w->plane_r;
+    w->off_kt16 = w->off_qt16 + 3 * w->plane_t;
+    w->off_dot16 = w->off_kt16 + 3 * w->plane_t;
+    w->total = w->off_dot16 + 3 * w->plane_t;
+}
+
+// smallest r such that the bucket LUT is constant on [r, T - 1] and on [-(T - 1), -r], + 62 (a 32 x 32 wave tile spans 63 offsets):
+// every tile that is NOT inside one bucket lies within +-near_r of the diagonal
+int vn_attention_x3_near_r(const int32_t* lut_host, int T) {
+    int rp = T - 1, rn = T - 1;
+    while (rp > 1 && lut_host[(rp - 1) + T - 1] == lut_host[2 * T - 2]) --rp;
+    while (rn > 1 && lut_host[-(rn - 1) + T - 1] == lut_host[0]) --rn;
+    const int r = (rp > rn ? rp : rn) + 62;
+    return r < T - 1 ? r : T - 1;
+}
+
+size_t vn_attention_x3_bwd_dq_lds(int T, int near_r) { return (size_t)(9 * AB_PLANE + 2 * T - 1 + 4 * (2 * near_r + 1) + 256 + 4 * 2048 + 4) * sizeof(float); }
+
+int vn_launch_attention_x3_bwd(vn_ctx* ctx, const uint16_t* qk16, long plane_qk, const uint16_t* vt16, long plane_vt, uint16_t* ws,
+                               const float* relbias_full, const int32_t* lut_dev, int near_r, const float* out, const float* dout,
+                               const float* lse, float* delta, float* dqkv, float* dbias_partial, int B, int H, int T, int nbuckets,
+                               const vn_drop& d, hipStream_t s) {
+    if (B <= 0 || T <= 0) return VN_OK;
+    if (nbuckets > 64) return vn_fail(ctx, VN_ERR_UNSUPPORTED, "attention backward: num_buckets=%s%ld > 64", "", nbuckets);
+    vn_ax_bwd_ws w;
+    vn_attention_x3_bwd_ws_layout(B, H, T, &w);
+    const long n = (long)B * H * T * VN_DHEAD;
+    if (3 * plane_qk * 2 >= (1L << 31) || 3 * w.plane_r * 2 >= (1L << 31) || 3 * w.plane_t * 2 >= (1L << 31))
+        return vn_fail(ctx, VN_ERR_UNSUPPORTED, "attention backward (bf16x3): %s%ld elements per plane exceed the 32-bit DMA offsets", "", n);
+    const size_t lds_dq = vn_attention_x3_bwd_dq_lds(T, near_r);
+    const size_t lds_kv = (size_t)(12 * AB_PLANE + 192 + 2 * T - 1 + 4) * sizeof(float);
+    if (lds_dq > 160 * 1024) return vn_fail(ctx, VN_ERR_INVALID, "attention backward (bf16x3): T=%s%ld too long", "", T);
+    if (!(ctx->attr_mask & VN_ATTR_ATTN_X3_BWD)) {
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ctx->attr_mask |= VN_ATTR_ATTN_X3_BWD;
+    }
+    uint16_t *v16 = ws + w.off_v16, *do16 = ws + w.off_do16, *qt16 = ws + w.off_qt16, *kt16 = ws + w.off_kt16, *dot16 = ws + w.off_dot16;
+    const int NTt = (T + 31) / 32, MT = (int)(((long)B * T + 31) / 32);
+    hipLaunchKernelGGL(vn_ax_bwd_prep_t_kernel, dim3(NTt, B * H, 6), dim3(256), 0, s, qk16, plane_qk, n, qt16, kt16, w.plane_t, T, NTt);
+    hipLaunchKernelGGL(vn_ax_bwd_prep_v_kernel, dim3(MT, H, 3), dim3(256), 0, s, vt16, plane_vt, v16, w.plane_r, B, H, T, MT);
+    hipLaunchKernelGGL(vn_ax_bwd_prep_do_kernel, dim3(NTt, H, B), dim3(256), 0, s, dout, out, do16, w.plane_r, dot16, w.plane_t, delta, H, T, NTt);
+    ab_args A;
+    A.q16 = qk16; A.k16 = qk16 + n; A.v16 = v16; A.kt16 = kt16; A.qt16 = qt16; A.do16 = do16; A.dot16 = dot16;
+    A.plane_qk = plane_qk; A.plane_r = w.plane_r; A.plane_t = w.plane_t;
+    A.bias_full = relbias_full; A.lse = lse; A.delta = delta; A.lut = lut_dev; A.dqkv = dqkv; A.dbias_partial = dbias_partial;
+    A.B = B; A.H = H; A.T = T; A.nbuckets = nbuckets; A.near_r = near_r; A.d = d;
+    const int nblk = vn_cdiv(T, 128) * H * B;
+    const size_t lds = lds_dq > lds_kv ? lds_dq : lds_kv;
+    const double fl = 2.0 * T * (double)T * VN_DHEAD * H * B;     // one T x T x 64 product; 7 executed (S and dPd twice)
+    const int pi = vn_prof_pre(ctx, 1, 7.0 * fl, s, 52.0 * T * VN_DHEAD * (double)H * B);
+    if (dbias_partial) hipLaunchKernelGGL((vn_attention_x3_bwd_kernel<true>), dim3(2 * nblk), dim3(256), lds, s, A, nblk);
+    else hipLaunchKernelGGL((vn_attention_x3_bwd_kernel<false>), dim3(2 * nblk), dim3(256), lds, s, A, nblk);
+    vn_prof_post(ctx, pi, s);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}

@@ -882,6 +882,13 @@ __global__ void vn_attn_x3_prep_kernel(const float* __restrict__ q, const float*
     vn_sat_report(sat, VN_SAT_ATTN, bad);
 }
 
+int vn_launch_attn_x3_prep(vn_ctx* ctx, const float* q, const float* k, const float* v, uint16_t* qk16, long plane_qk, uint16_t* vt16,
+                           long plane_vt, long heads, int H, int T, hipStream_t s) {
+    hipLaunchKernelGGL(vn_attn_x3_prep_kernel, dim3(1024), dim3(256), 0, s, q, k, v, qk16, plane_qk, vt16, plane_vt, heads, H, T, 3, ctx->sat);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
 // shared by the single-op entry and the timing hook: scratch, bias table, plane images; *launches of the kernel only
 static int attention_x3_run(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias, float* out, int B,
                             int H, int T, int num_buckets, int max_distance, int iters, float* avg_us, int np, hipStream_t s) {

@@ -25,6 +25,7 @@ enum { SITE_ATTN = 0, SITE_RES1 = 1, SITE_FFN = 2, SITE_RES2 = 3 };
 
 struct vn_layer_stash {
     float *x_in, *y1, *qkv, *lse, *a, *x_mid, *y3, *u, *g;
+    uint16_t *qk16, *vt16;         // attention on the split-plane pipe (vn_train::ax3): the q / k planes and the blocked V^T planes instead of qkv
 };
 
 struct vn_train {
@@ -56,6 +57,13 @@ struct vn_train {
     // the activation operand of a forward / dX GEMM (a16) and the two transposed operands of a dW GEMM (at16, bt16)
     bool x3;
     uint16_t *w16, *wT16, *a16, *at16, *bt16;
+    // ... and the attention of the step as well (attention_x3.hip TRAIN forward, attention_train_x3.hip backward; VN_TRAIN_ATTN_X3, default
+    // on with x3 when D % 128 == 0 and max_T fits the backward's LDS): the QKV GEMM writes the attention operands' planes (its
+    // inference epilogue) into the layer's stash — no fp32 q / k / v exist; ax_ws = the backward's transposed / row-major plane images
+    bool ax3;
+    uint16_t* ax_ws;
+    long qk_plane, vt_plane;
+    int near_T, near_r;            // near_r (attention_train_x3.hip) of the T it was derived for
 };
 
 enum { LORA_Q = 0, LORA_V = 1, LORA_FC = 2, LORA_W1 = 3, LORA_W2 = 4 };
@@ -134,6 +142,7 @@ static int talloc(vn_ctx* ctx, T** p, size_t n) {
 extern "C" void vn_train_destroy(vn_train* t) {
     if (!t) return;
     for (auto& s : t->st) {
+        (void)hipFree(s.qk16); (void)hipFree(s.vt16);
         float* a[] = {s.x_in, s.y1, s.qkv, s.lse, s.a, s.x_mid, s.y3, s.u, s.g};
         for (float* p : a) (void)hipFree(p);
     }
@@ -146,7 +155,7 @@ extern "C" void vn_train_destroy(vn_train* t) {
     (void)hipFree(t->w_base);
     (void)hipFree(t->h8);
     (void)hipFree(t->dh8);
-    uint16_t* c[] = {t->w16, t->wT16, t->a16, t->at16, t->bt16};
+    uint16_t* c[] = {t->w16, t->wT16, t->a16, t->at16, t->bt16, t->ax_ws};
     for (uint16_t* p : c) (void)hipFree(p);
     delete t;
 }
@@ -169,6 +178,19 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
     { const char* e = getenv("VN_TRAIN_X3"); t->x3 = !(e && e[0] == '0'); }
     const vn_dims& d = m->d;
     const long D = m->D, L = m->L, rows = m->max_rows;
+    t->ax_ws = nullptr; t->near_T = 0; t->near_r = 0;
+    {
+        const char* e = getenv("VN_TRAIN_ATTN_X3");
+        t->ax3 = t->x3 && !(e && e[0] == '0') && !(D & 127) && d.num_buckets <= 64 &&
+                 vn_attention_x3_bwd_dq_lds(d.max_T, d.max_T - 1) <= 160 * 1024 && vn_attention_x3_lds_bytes(d.max_T, 0, 3) <= 160 * 1024;
+        if (t->ax3) {       // the DMA descriptors of the backward address a plane set with 32-bit byte offsets
+            vn_ax_bwd_ws w;
+            vn_attention_x3_bwd_ws_layout(d.max_batch, m->H, d.max_T, &w);
+            if (3 * (2 * rows * D) * 2 >= (1L << 31) || 3 * w.plane_r * 2 >= (1L << 31) || 3 * w.plane_t * 2 >= (1L << 31)) t->ax3 = false;
+        }
+    }
+    t->qk_plane = 2 * rows * D;
+    t->vt_plane = (long)m->H * ((rows + 31) / 32) * (VN_DHEAD * 32);
     t->NV = m->Cp * d.vocab;
     int64_t w = 0, n = 0;
     vn_weights_size(&d, &w);
@@ -183,7 +205,15 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
     t->st.resize(L);
     for (auto& s : t->st) {
         memset(&s, 0, sizeof(s));
-        A(&s.x_in, rows * D); A(&s.y1, rows * D); A(&s.qkv, 3 * rows * D); A(&s.lse, (size_t)d.max_batch * m->H * d.max_T);
+        A(&s.x_in, rows * D); A(&s.y1, rows * D); A(&s.lse, (size_t)d.max_batch * m->H * d.max_T);
+        if (!t->ax3) A(&s.qkv, 3 * rows * D);
+        else {
+            // masked rows / keys of a last tile are read as they are (and multiplied by P = 0): they must be finite, so start from zeros
+            const size_t nqk = (size_t)3 * t->qk_plane + 32 * VN_DHEAD, nvt = (size_t)3 * t->vt_plane;
+            if (rc == VN_OK) rc = talloc(ctx, &s.qk16, nqk);
+            if (rc == VN_OK) rc = talloc(ctx, &s.vt16, nvt);
+            if (rc == VN_OK && (hipMemset(s.qk16, 0, nqk * 2) != hipSuccess || hipMemset(s.vt16, 0, nvt * 2) != hipSuccess)) rc = VN_ERR_HIP;
+        }
         A(&s.a, rows * D); A(&s.x_mid, rows * D); A(&s.y3, rows * D); A(&s.u, 4 * rows * D); A(&s.g, 2 * rows * D);
     }
     const long wide = 4 * D > t->NV ? 4 * D : t->NV;
@@ -209,6 +239,12 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
         if (rc == VN_OK) rc = talloc(ctx, &t->a16, (size_t)3 * rows16 * (size_t)wide);
         if (rc == VN_OK) rc = talloc(ctx, &t->at16, (size_t)3 * wide * t->Mp_max);
         if (rc == VN_OK) rc = talloc(ctx, &t->bt16, (size_t)3 * 2 * D * t->Mp_max);
+    }
+    if (t->ax3) {
+        vn_ax_bwd_ws w;
+        vn_attention_x3_bwd_ws_layout(d.max_batch, m->H, d.max_T, &w);
+        if (rc == VN_OK) rc = talloc(ctx, &t->ax_ws, (size_t)w.total);
+        if (rc == VN_OK && hipMemset(t->ax_ws, 0, (size_t)w.total * 2) != hipSuccess) rc = VN_ERR_HIP;
     }
     if (rc == VN_OK) rc = talloc(ctx, &t->npartial, 1024);
     if (rc == VN_OK) rc = talloc(ctx, &t->t32, (size_t)rows * m->Cp);
@@ -466,6 +502,12 @@ static int forward_train(vn_train* t, int B, int T, const vn_train_params* p, hi
     const long r_tok = (long)p->batch_offset * T, r_att = (long)p->batch_offset * H * T;
     int rc;
     if ((rc = vn_model_ensure_bias(m, T, s))) return rc;
+    if (t->ax3 && t->near_T != T) {            // which key - query offsets the backward's per-wave bias-gradient tables must cover
+        std::vector<int32_t> lut(2 * T - 1);
+        vn_bucket_lut_host(T, m->d.num_buckets, m->d.max_distance, lut.data());
+        t->near_r = vn_attention_x3_near_r(lut.data(), T);
+        t->near_T = T;
+    }
     if ((rc = vn_launch_embed(ctx, m->z, P(t, VN_W_EMB_TABLES), P(t, VN_W_EMB_WT), P(t, VN_W_EMB_B), t->st[0].x_in, B,
                               m->d.n_codebooks, T, m->d.vocab + 1, m->d.latent_dim, D, s)))
         return rc;
@@ -479,10 +521,17 @@ static int forward_train(vn_train* t, int B, int T, const vn_train_params* p, hi
         vn_gemm_args a{};
         a.A = S.y1; a.W = P(t, VN_W_QKV, l); a.C = S.qkv; a.M = M; a.N = 3 * D; a.K = D; a.ldc = 3 * D;
         a.T = T; a.H = H; a.qkv_plane = plane;
-        if ((rc = gemm_args(t, a, VN_EPI_QKV, s, n16))) return rc;
-        if ((rc = vn_launch_attention_train_fwd(ctx, S.qkv, S.qkv + plane, S.qkv + 2 * plane, m->bias_full, S.a, S.lse, B, H, T,
-                                                make_drop(p, l, SITE_ATTN, r_att), s)))
-            return rc;
+        if (t->ax3) {
+            a.C = nullptr; a.C16 = S.qk16; a.c_plane = t->qk_plane; a.V16 = S.vt16; a.v_plane = t->vt_plane;
+            if ((rc = gemm_args(t, a, VN_EPI_QKV3, s, n16))) return rc;
+            rc = vn_launch_attention_x3_train_fwd(ctx, S.qk16, S.qk16 + plane, t->qk_plane, S.vt16, t->vt_plane, m->bias_full, S.a, S.lse, B, H,
+                                                  T, vn_num_cus(ctx), make_drop(p, l, SITE_ATTN, r_att), s);
+        } else {
+            if ((rc = gemm_args(t, a, VN_EPI_QKV, s, n16))) return rc;
+            rc = vn_launch_attention_train_fwd(ctx, S.qkv, S.qkv + plane, S.qkv + 2 * plane, m->bias_full, S.a, S.lse, B, H, T,
+                                               make_drop(p, l, SITE_ATTN, r_att), s);
+        }
+        if (rc) return rc;
         if ((rc = gemm(t, S.a, P(t, VN_W_WO, l), nullptr, t->tmp, M, D, D, VN_EPI_STORE, s))) return rc;
         if ((rc = vn_launch_resid_dropout(ctx, S.x_in, t->tmp, S.x_mid, M, D, make_drop(p, l, SITE_RES1, r_tok), s))) return rc;
         if ((rc = vn_launch_rmsnorm(ctx, S.x_mid, P(t, VN_W_NORM3, l), S.y3, M, D, m->d.eps, s, n16 ? t->a16 : nullptr, VN_PLANES_TILED, true))) return rc;
@@ -580,11 +629,15 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
         else rc = grad_weight(t, dh2, S.a, G(t, grads, VN_W_WO, l), M, D, D, s);
         if (rc) return rc;
         if ((rc = gemm(t, dh2, wTl + 3L * D * D, nullptr, t->da, M, D, D, VN_EPI_STORE, s))) return rc;
-        if ((rc = vn_launch_attention_bwd(ctx, S.qkv, S.qkv + plane, S.qkv + 2 * plane, m->bias_full, m->lut, S.a, t->da, S.lse,
-                                          t->delta, t->dqkv, lora ? nullptr : t->dbias_partial + t->dbias_slab * l, B, H, T,
-                                          m->d.num_buckets,
-                                          make_drop(p, l, SITE_ATTN, r_att), s)))
-            return rc;
+        if (t->ax3)
+            rc = vn_launch_attention_x3_bwd(ctx, S.qk16, t->qk_plane, S.vt16, t->vt_plane, t->ax_ws, m->bias_full, m->lut, t->near_r, S.a, t->da,
+                                            S.lse, t->delta, t->dqkv, lora ? nullptr : t->dbias_partial + t->dbias_slab * l, B, H, T,
+                                            m->d.num_buckets, make_drop(p, l, SITE_ATTN, r_att), s);
+        else
+            rc = vn_launch_attention_bwd(ctx, S.qkv, S.qkv + plane, S.qkv + 2 * plane, m->bias_full, m->lut, S.a, t->da, S.lse,
+                                         t->delta, t->dqkv, lora ? nullptr : t->dbias_partial + t->dbias_slab * l, B, H, T,
+                                         m->d.num_buckets, make_drop(p, l, SITE_ATTN, r_att), s);
+        if (rc) return rc;
         if (lora) {          // w_qs and w_vs carry adapters, w_ks is a plain nn.Linear (transformer.py:109-111)
             if ((rc = lora_grads(t, S.y1, D, t->dqkv, 3 * D, l, LORA_Q, grads, M, s))) return rc;
             rc = lora_grads(t, S.y1, D, t->dqkv + 2 * D, 3 * D, l, LORA_V, grads, M, s);
@@ -598,8 +651,8 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
             return rc;
     }
     if (!lora && lo <= 0 && hi >= 0) {          // layer 0 is done: every layer's slab of the shared bias-table gradient is final
-        if ((rc = vn_launch_dbias_reduce(ctx, t->dbias_partial, G(t, grads, VN_W_REL_BIAS), L, t->dbias_slab, B, H, T,
-                                         m->d.num_buckets, false, s)))
+        if ((rc = vn_launch_dbias_reduce(ctx, t->dbias_partial, G(t, grads, VN_W_REL_BIAS), L, t->dbias_slab, B, H,
+                                         vn_cdiv(T, t->ax3 ? 128 : 64), m->d.num_buckets, false, s)))
             return rc;
     }
     if (lora || lo >= 0) return VN_OK;          // LoRA: embedding parameters are frozen
@@ -814,11 +867,57 @@ extern "C" int vn_attention_train_f32(vn_ctx* ctx, const float* q, const float* 
     if (rc == VN_OK && dout && hipMalloc((void**)&part, (size_t)slab * sizeof(float)) != hipSuccess) rc = VN_ERR_OOM;
     if (rc == VN_OK && dout)
         rc = vn_launch_attention_bwd(ctx, q, k, v, full, lut_d, out, dout, lse, delta, dqkv, part, B, H, T, num_buckets, d, s);
-    if (rc == VN_OK && dout) rc = vn_launch_dbias_reduce(ctx, part, dbias, 1, slab, B, H, T, num_buckets, true, s);
+    if (rc == VN_OK && dout) rc = vn_launch_dbias_reduce(ctx, part, dbias, 1, slab, B, H, vn_cdiv(T, 64), num_buckets, true, s);
     (void)hipStreamSynchronize(s);
     (void)hipFree(full);
     (void)hipFree(lut_d);
     (void)hipFree(delta);
     (void)hipFree(part);
+    return rc;
+}
+
+// the same on the split-plane pipe (attention_x3.hip TRAIN forward, attention_train_x3.hip backward): fp32 q, k, v are split /
+// transposed here exactly as the QKV GEMM's plane epilogue does (engine.hip vn_attn_x3_prep_kernel)
+extern "C" int vn_attention_train_bf16x3(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                                         float* out, float* lse, const float* dout, float* dqkv, float* dbias, int B, int H, int T,
+                                         int num_buckets, int max_distance, float dropout, uint64_t seed, void* stream) {
+    if (!ctx || !q || !k || !v || !rel_bias || !out || !lse || T <= 0 || H <= 0 || B <= 0) return VN_ERR_INVALID;
+    if (dout && (!dqkv || !dbias)) return VN_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const long heads = (long)B * H, n = heads * T * VN_DHEAD;
+    const long plane_qk = 2 * n, plane_vt = (long)H * (((long)B * T + 31) / 32) * (VN_DHEAD * 32);
+    const int nb = 2 * T - 1;
+    float *full = nullptr, *delta = nullptr, *part = nullptr;
+    int32_t* lut_d = nullptr;
+    uint16_t *qk16 = nullptr, *vt16 = nullptr, *ws = nullptr;
+    vn_ax_bwd_ws w;
+    vn_attention_x3_bwd_ws_layout(B, H, T, &w);
+    const long slab = heads * vn_cdiv(T, 128) * 64;
+    int rc = VN_OK;
+    if (hipMalloc((void**)&full, (size_t)H * nb * sizeof(float)) != hipSuccess || hipMalloc((void**)&lut_d, (size_t)nb * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void**)&delta, (size_t)heads * T * sizeof(float)) != hipSuccess || hipMalloc((void**)&part, (size_t)slab * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&qk16, ((size_t)3 * plane_qk + 32 * VN_DHEAD) * 2) != hipSuccess || hipMalloc((void**)&vt16, (size_t)3 * plane_vt * 2) != hipSuccess ||
+        hipMalloc((void**)&ws, (size_t)w.total * 2) != hipSuccess)
+        rc = vn_fail(ctx, VN_ERR_OOM, "vn_attention_train_bf16x3: scratch allocation failed%s", "");
+    std::vector<int32_t> lut(nb);
+    vn_bucket_lut_host(T, num_buckets, max_distance, lut.data());
+    const int near_r = vn_attention_x3_near_r(lut.data(), T);
+    if (rc == VN_OK && hipMemcpy(lut_d, lut.data(), nb * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) rc = VN_ERR_HIP;
+    if (rc == VN_OK && (hipMemsetAsync(vt16, 0, (size_t)3 * plane_vt * 2, s) != hipSuccess ||
+                        hipMemsetAsync(qk16, 0, ((size_t)3 * plane_qk + 32 * VN_DHEAD) * 2, s) != hipSuccess ||
+                        hipMemsetAsync(ws, 0, (size_t)w.total * 2, s) != hipSuccess))
+        rc = VN_ERR_HIP;
+    if (rc == VN_OK) rc = vn_launch_bias_expand(ctx, rel_bias, lut_d, full, H, T, s);
+    vn_train_params tp{};
+    tp.seed = seed; tp.step = 1; tp.dropout = dropout;
+    const vn_drop d = make_drop(&tp, 0, SITE_ATTN, 0);
+    if (rc == VN_OK) rc = vn_launch_attn_x3_prep(ctx, q, k, v, qk16, plane_qk, vt16, plane_vt, heads, H, T, s);
+    if (rc == VN_OK) rc = vn_launch_attention_x3_train_fwd(ctx, qk16, qk16 + n, plane_qk, vt16, plane_vt, full, out, lse, B, H, T, vn_num_cus(ctx), d, s);
+    if (rc == VN_OK && dout)
+        rc = vn_launch_attention_x3_bwd(ctx, qk16, plane_qk, vt16, plane_vt, ws, full, lut_d, near_r, out, dout, lse, delta, dqkv, part, B, H, T,
+                                        num_buckets, d, s);
+    if (rc == VN_OK && dout) rc = vn_launch_dbias_reduce(ctx, part, dbias, 1, slab, B, H, vn_cdiv(T, 128), num_buckets, true, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(full); (void)hipFree(lut_d); (void)hipFree(delta); (void)hipFree(part); (void)hipFree(qk16); (void)hipFree(vt16); (void)hipFree(ws);
     return rc;
 }

@@ -399,7 +399,8 @@ struct vn_ctx {
     // process may hold contexts on several)
     unsigned attr_mask;
 };
-enum { VN_ATTR_ATTN = 1u, VN_ATTR_ATTN_TRAIN = 2u, VN_ATTR_REMASK = 4u, VN_ATTR_MT_JUMP = 8u, VN_ATTR_GEMM_X3 = 16u, VN_ATTR_ATTN_X3 = 32u };
+enum { VN_ATTR_ATTN = 1u, VN_ATTR_ATTN_TRAIN = 2u, VN_ATTR_REMASK = 4u, VN_ATTR_MT_JUMP = 8u, VN_ATTR_GEMM_X3 = 16u, VN_ATTR_ATTN_X3 = 32u, VN_ATTR_ATTN_X3_TRAIN = 64u,
+       VN_ATTR_ATTN_X3_BWD = 128u };
 
 // bracket a launch with events when profiling is on (no-ops otherwise)
 static inline int vn_prof_pre(vn_ctx* ctx, int cls, double flops, hipStream_t s, double bytes = 0.0) {

@@ -48,8 +48,28 @@ int vn_launch_attention_train_fwd(vn_ctx* ctx, const float* q, const float* k, c
 int vn_launch_attention_bwd(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* relbias_full,
                             const int32_t* lut_dev, const float* out, const float* dout, const float* lse, float* delta,
                             float* dqkv, float* dbias_partial, int B, int H, int T, int nbuckets, const vn_drop& d, hipStream_t s);
-int vn_launch_dbias_reduce(vn_ctx* ctx, const float* partial, float* dbias, int n_slabs, long slab_floats, int B, int H, int T,
+// nqb = q-blocks per (b, h) of the kernel that wrote the slabs (ceil(T / 64) for the fp32 kernel, ceil(T / 128) for the split-plane one)
+int vn_launch_dbias_reduce(vn_ctx* ctx, const float* partial, float* dbias, int n_slabs, long slab_floats, int B, int H, int nqb,
                            int nbuckets, bool accumulate, hipStream_t s);
+
+// attention_x3.hip (TRAIN instantiation of the shared-tile kernel) / attention_train_x3.hip: the same forward / backward on the split-plane
+// pipe.  Operands: the planes the QKV GEMM's plane epilogue writes (qk16: q planes then, n = B H T 64 elements later, k planes; vt16: V^T
+// blocked by 32 global token rows).  ws: vn_attention_x3_bwd_ws_layout(...).total uint16 elements, zero-filled once.
+struct vn_ax_bwd_ws { long plane_r, plane_t, off_v16, off_do16, off_qt16, off_kt16, off_dot16, total; };
+void vn_attention_x3_bwd_ws_layout(int B, int H, int T, vn_ax_bwd_ws* w);
+int vn_attention_x3_near_r(const int32_t* lut_host, int T);
+size_t vn_attention_x3_bwd_dq_lds(int T, int near_r);
+size_t vn_attention_x3_lds_bytes(int T, int key_split, int np);
+int vn_launch_attention_x3_train_fwd(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16, long plane_qk, const uint16_t* vt16, long plane_vt,
+                                     const float* relbias_full, float* out, float* lse, int B, int H, int T, int cus, const vn_drop& d,
+                                     hipStream_t s);
+int vn_launch_attention_x3_bwd(vn_ctx* ctx, const uint16_t* qk16, long plane_qk, const uint16_t* vt16, long plane_vt, uint16_t* ws,
+                               const float* relbias_full, const int32_t* lut_dev, int near_r, const float* out, const float* dout,
+                               const float* lse, float* delta, float* dqkv, float* dbias_partial, int B, int H, int T, int nbuckets,
+                               const vn_drop& d, hipStream_t s);
+// engine.hip: fp32 q, k, v [B][H][T][64] -> the attention operands' planes, exactly as the QKV GEMM's plane epilogue writes them (tests)
+int vn_launch_attn_x3_prep(vn_ctx* ctx, const float* q, const float* k, const float* v, uint16_t* qk16, long plane_qk, uint16_t* vt16,
+                           long plane_vt, long heads, int H, int T, hipStream_t s);
 
 // LoRA fine-tuning helpers (rank 8; every rank-r operand is [C][8] row-major, A stored transposed)
 int vn_launch_lora_down(vn_ctx* ctx, const float* Y, int ldy, const float* P, float* H, int M, int Cn, float scale, hipStream_t s);
