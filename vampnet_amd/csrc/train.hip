@@ -268,24 +268,20 @@ extern "C" int vn_train_sync(vn_train* t, void* stream) {
     // from W through the transposing splitter; otherwise (odd widths, VN_TRAIN_X3=0) the fp32 copies feed the fp32 kernel
     const bool all_x3 = t->x3 && !(D & 63) && !(t->NV & 63);
     if (all_x3) {
-        auto planes = [&](const float* w, uint16_t* dst, int rows, int K) { return vn_launch_split3_tiled(ctx, w, dst, rows, K, K, s); };
-        auto planesT = [&](const float* w, uint16_t* dst, int rows, int K) {        // planes of w^T [K][rows] from w [rows][K]
-            return vn_launch_transpose_split3_tiled(ctx, w, dst, rows, K, K, rows, s);
+        // planes of w [rows][K] (dst) and of w^T [K][rows] (dstT) in ONE pass over w (the transposing splitter writes both from its tile)
+        auto both = [&](const float* w, uint16_t* dst, uint16_t* dstT, int rows, int K) {
+            return vn_launch_transpose_split3_tiled(ctx, w, dstT, rows, K, K, rows, s, dst);
         };
         for (int l = 0; l < m->L; ++l) {
             uint16_t* b16 = t->wT16 + 3 * (t->wT_layer * l);
             const float *wq = P(t, VN_W_QKV, l), *wo = P(t, VN_W_WO, l), *w1 = P(t, VN_W_W1, l), *w2 = P(t, VN_W_W2, l);
-            if ((rc = planes(wq, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_QKV, l), 3 * D, D)) ||
-                (rc = planes(wo, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_WO, l), D, D)) ||
-                (rc = planes(w1, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_W1, l), 4 * D, D)) ||
-                (rc = planes(w2, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_W2, l), D, 2 * D)) ||
-                (rc = planesT(wq, b16, 3 * D, D)) || (rc = planesT(wo, b16 + 3 * (3L * D * D), D, D)) ||
-                (rc = planesT(w1, b16 + 3 * (4L * D * D), 4 * D, D)) || (rc = planesT(w2, b16 + 3 * (8L * D * D), D, 2 * D)))
+            if ((rc = both(wq, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_QKV, l), b16, 3 * D, D)) ||
+                (rc = both(wo, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_WO, l), b16 + 3 * (3L * D * D), D, D)) ||
+                (rc = both(w1, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_W1, l), b16 + 3 * (4L * D * D), 4 * D, D)) ||
+                (rc = both(w2, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_W2, l), b16 + 3 * (8L * D * D), D, 2 * D)))
                 return rc;
         }
-        if ((rc = planes(clsW, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_CLS_W, 0), t->NV, D)) ||
-            (rc = planesT(clsW, t->wT16 + 3 * t->wT_cls, t->NV, D)))
-            return rc;
+        if ((rc = both(clsW, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_CLS_W, 0), t->wT16 + 3 * t->wT_cls, t->NV, D))) return rc;
         m->bias_T = -1;
         return VN_OK;
     }
@@ -547,13 +543,18 @@ static int forward_train(vn_train* t, int B, int T, const vn_train_params* p, hi
 }
 
 // dW[N][K] = dY^T X   (dY [M][N], X [M][K]) through the two transposes
-static int grad_weight(vn_train* t, const float* dY, const float* X, float* dW, int M, int N, int K, hipStream_t s) {
+// dy_planes (out, optional): the transposer of dY has ALSO left dY's own tiled planes in t->a16 — the A operand of the dX GEMM the caller
+// runs next on the same dY (one read of dY instead of two; nothing else may write t->a16 in between)
+static int grad_weight(vn_train* t, const float* dY, const float* X, float* dW, int M, int N, int K, hipStream_t s, bool* dy_planes = nullptr) {
     vn_ctx* ctx = t->m->ctx;
     const int Mp = (M + 31) & ~31;
     int rc;
+    if (dy_planes) *dy_planes = false;
     if (t->x3 && !(N & 15) && !(K & 63)) {
         // both operands as tiled planes straight out of the transposes: A = dY^T [N][Mp], W = X^T [K][Mp], contraction over the tokens
-        if ((rc = vn_launch_transpose_split3_tiled(ctx, dY, t->at16, M, N, N, Mp, s))) return rc;
+        const bool both = dy_planes && !(N & 31);
+        if ((rc = vn_launch_transpose_split3_tiled(ctx, dY, t->at16, M, N, N, Mp, s, both ? t->a16 : nullptr))) return rc;
+        if (both) *dy_planes = true;
         if ((rc = vn_launch_transpose_split3_tiled(ctx, X, t->bt16, M, K, K, Mp, s))) return rc;
         vn_gemm_args a{};
         a.A = (const float*)t->at16; a.W = (const float*)t->bt16; a.C = dW; a.M = N; a.N = K; a.K = Mp; a.ldc = K;
@@ -587,10 +588,11 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
     float* dx2 = t->dxb;
     if (hi >= L) {
     // ---- classifier (WNConv1d 1x1, transformer.py:596-604) + final norm
-    if ((rc = gemm(t, dlog, t->wT + t->wT_cls, nullptr, t->dy, M, D, NV, VN_EPI_STORE, s))) return rc;
+    bool dl16 = false;
+    if (!lora && (rc = grad_weight(t, dlog, t->y_f, G(t, grads, VN_W_CLS_W), M, NV, D, s, &dl16))) return rc;
+    if ((rc = gemm(t, dlog, t->wT + t->wT_cls, nullptr, t->dy, M, D, NV, VN_EPI_STORE, s, dl16 && x3_shape(t, D, NV)))) return rc;
     if (!lora) {
         float* dWc = G(t, grads, VN_W_CLS_W);
-        if ((rc = grad_weight(t, dlog, t->y_f, dWc, M, NV, D, s))) return rc;
         if ((rc = vn_launch_colsum(ctx, dlog, M, NV, t->partial, G(t, grads, VN_W_CLS_B), s))) return rc;
         if ((rc = vn_launch_weight_norm_bwd(ctx, t->params + t->off_g, t->params + t->off_v, dWc, grads + t->off_g,
                                             grads + t->off_v, NV, D, s)))
@@ -606,12 +608,13 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
         const float* wTl = t->wT + t->wT_layer * l;
         // ---- feed-forward branch (transformer.py:72-85, :360-367)
         const vn_drop d2 = make_drop(p, l, SITE_RES2, r_tok);
+        bool dy16 = false;                             // grad_weight left dY's planes in t->a16 for the dX GEMM that follows it
         const float* dh = dx;
         if (d2.thresh16) { if ((rc = vn_launch_dropout_bwd(ctx, dx, t->dh, M, D, d2, s))) return rc; dh = t->dh; }
         if (lora) rc = lora_grads(t, S.g, 2 * D, dh, D, l, LORA_W2, grads, M, s);
-        else rc = grad_weight(t, dh, S.g, G(t, grads, VN_W_W2, l), M, D, 2 * D, s);
+        else rc = grad_weight(t, dh, S.g, G(t, grads, VN_W_W2, l), M, D, 2 * D, s, &dy16);
         if (rc) return rc;
-        if ((rc = gemm(t, dh, wTl + 8L * D * D, nullptr, t->dg, M, 2 * D, D, VN_EPI_STORE, s))) return rc;
+        if ((rc = gemm(t, dh, wTl + 8L * D * D, nullptr, t->dg, M, 2 * D, D, VN_EPI_STORE, s, dy16 && x3_shape(t, 2 * D, D)))) return rc;
         const bool du16 = x3_shape(t, D, 4 * D);       // du's planes for the dX GEMM below (grad_weight in between uses at16 / bt16 only)
         if ((rc = vn_launch_geglu_train(ctx, S.u, t->dg, t->du, M, 2 * D, make_drop(p, l, SITE_FFN, r_tok), true, s, du16 ? t->a16 : nullptr))) return rc;
         if (lora) rc = lora_grads(t, S.y3, D, t->du, 4 * D, l, LORA_W1, grads, M, s);
@@ -625,10 +628,11 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
         const vn_drop d1 = make_drop(p, l, SITE_RES1, r_tok);
         const float* dh2 = dx2;
         if (d1.thresh16) { if ((rc = vn_launch_dropout_bwd(ctx, dx2, t->dh, M, D, d1, s))) return rc; dh2 = t->dh; }
+        dy16 = false;
         if (lora) rc = lora_grads(t, S.a, D, dh2, D, l, LORA_FC, grads, M, s);
-        else rc = grad_weight(t, dh2, S.a, G(t, grads, VN_W_WO, l), M, D, D, s);
+        else rc = grad_weight(t, dh2, S.a, G(t, grads, VN_W_WO, l), M, D, D, s, &dy16);
         if (rc) return rc;
-        if ((rc = gemm(t, dh2, wTl + 3L * D * D, nullptr, t->da, M, D, D, VN_EPI_STORE, s))) return rc;
+        if ((rc = gemm(t, dh2, wTl + 3L * D * D, nullptr, t->da, M, D, D, VN_EPI_STORE, s, dy16 && x3_shape(t, D, D)))) return rc;
         if (t->ax3)
             rc = vn_launch_attention_x3_bwd(ctx, S.qk16, t->qk_plane, S.vt16, t->vt_plane, t->ax_ws, m->bias_full, m->lut, t->near_r, S.a, t->da,
                                             S.lse, t->delta, t->dqkv, lora ? nullptr : t->dbias_partial + t->dbias_slab * l, B, H, T,
@@ -638,14 +642,15 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
                                          t->delta, t->dqkv, lora ? nullptr : t->dbias_partial + t->dbias_slab * l, B, H, T,
                                          m->d.num_buckets, make_drop(p, l, SITE_ATTN, r_att), s);
         if (rc) return rc;
+        dy16 = false;
         if (lora) {          // w_qs and w_vs carry adapters, w_ks is a plain nn.Linear (transformer.py:109-111)
             if ((rc = lora_grads(t, S.y1, D, t->dqkv, 3 * D, l, LORA_Q, grads, M, s))) return rc;
             rc = lora_grads(t, S.y1, D, t->dqkv + 2 * D, 3 * D, l, LORA_V, grads, M, s);
         } else {
-            rc = grad_weight(t, t->dqkv, S.y1, G(t, grads, VN_W_QKV, l), M, 3 * D, D, s);
+            rc = grad_weight(t, t->dqkv, S.y1, G(t, grads, VN_W_QKV, l), M, 3 * D, D, s, &dy16);
         }
         if (rc) return rc;
-        if ((rc = gemm(t, t->dqkv, wTl, nullptr, t->dy, M, D, 3 * D, VN_EPI_STORE, s))) return rc;
+        if ((rc = gemm(t, t->dqkv, wTl, nullptr, t->dy, M, D, 3 * D, VN_EPI_STORE, s, dy16 && x3_shape(t, D, 3 * D)))) return rc;
         if ((rc = vn_launch_rmsnorm_bwd(ctx, S.x_in, P(t, VN_W_NORM1, l), t->dy, dx2, dx, lora ? junk : G(t, grads, VN_W_NORM1, l),
                                         t->partial, M, D, m->d.eps, s)))
             return rc;

@@ -368,8 +368,11 @@ int vn_launch_split3_tiled(vn_ctx* ctx, const float* src, uint16_t* dst, int R, 
     return VN_OK;
 }
 
+// rows16 != nullptr: ALSO the tiled planes of the matrix itself ([R rounded up to 16][C], C % 32 == 0) from the same LDS tile — the dY of a
+// layer is the A operand of its dX GEMM (row-major planes) and of its dW GEMM (transposed planes), a weight is needed both ways after
+// every update: one read of the fp32 matrix instead of two
 __global__ __launch_bounds__(256) void vn_transpose_split3_tiled_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int R,
-                                                                        int C, int lds_, int Rp) {
+                                                                        int C, int lds_, int Rp, uint16_t* __restrict__ rows16) {
     __shared__ float tile[64][65];
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;     // 16 x 16 threads, float4 each, 4 passes
@@ -392,24 +395,41 @@ __global__ __launch_bounds__(256) void vn_transpose_split3_tiled_kernel(const fl
     // output rows = c (64 of them: four blocks of 16), output k = r (64: two blocks of 32); wave w writes the pieces (cb = w, kb = 0 / 1)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int cl = wave * 16 + (lane >> 2);                     // column of the tile = output row
-    if (c0 + wave * 16 >= C) return;                            // C % 16 == 0: whole row blocks
+    if (c0 + wave * 16 < C) {                                   // C % 16 == 0: whole row blocks
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const int rl = kb * 32 + (lane & 3) * 8;                // first of this lane's eight tile rows = output k
-        if (r0 + kb * 32 >= Rp) continue;
-        f32x8 v;
+        for (int kb = 0; kb < 2; ++kb) {
+            const int rl = kb * 32 + (lane & 3) * 8;            // first of this lane's eight tile rows = output k
+            if (r0 + kb * 32 >= Rp) continue;
+            f32x8 v;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = tile[rl + e][cl];    // rows >= R were loaded as zeros
-        bool bad = false;
-        vn_store_planes8_tiled(dst, VN_PLANES_TILED, c0 + cl, r0 + rl, Rp, v, bad);
+            for (int e = 0; e < 8; ++e) v[e] = tile[rl + e][cl];    // rows >= R were loaded as zeros
+            bool bad = false;
+            vn_store_planes8_tiled(dst, VN_PLANES_TILED, c0 + cl, r0 + rl, Rp, v, bad);
+        }
+    }
+    if (rows16 && r0 + wave * 16 < ((R + 15) & ~15)) {         // the matrix itself: wave w writes row block w, k blocks 0 / 1
+        const int rl = wave * 16 + (lane >> 2);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int cc = kb * 32 + (lane & 3) * 8;
+            if (c0 + kb * 32 >= C) continue;
+            f32x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[rl][cc + e];
+            bool bad = false;
+            vn_store_planes8_tiled(rows16, VN_PLANES_TILED, r0 + rl, c0 + cc, C, v, bad);
+        }
     }
 }
 
-int vn_launch_transpose_split3_tiled(vn_ctx* ctx, const float* src, uint16_t* dst, int R, int C, int lds_, int Rp, hipStream_t s) {
+int vn_launch_transpose_split3_tiled(vn_ctx* ctx, const float* src, uint16_t* dst, int R, int C, int lds_, int Rp, hipStream_t s,
+                                     uint16_t* rows16) {
     if (R <= 0 || C <= 0) return VN_OK;
     if ((Rp & 31) || Rp < R || (C & 15) || ((uintptr_t)dst & 15))
         return vn_fail(ctx, VN_ERR_INVALID, "transpose_split3_tiled: Rp %% 32, Rp >= R, C %% 16 (Rp=%s%ld, C=%ld)", "", Rp, C);
-    hipLaunchKernelGGL(vn_transpose_split3_tiled_kernel, dim3(vn_cdiv(Rp, 64), vn_cdiv(C, 64)), dim3(256), 0, s, src, dst, R, C, lds_, Rp);
+    if (rows16 && ((C & 31) || ((uintptr_t)rows16 & 15)))
+        return vn_fail(ctx, VN_ERR_INVALID, "transpose_split3_tiled: the row-major planes need C %% 32 == 0 (C=%s%ld)", "", C);
+    hipLaunchKernelGGL(vn_transpose_split3_tiled_kernel, dim3(vn_cdiv(Rp, 64), vn_cdiv(C, 64)), dim3(256), 0, s, src, dst, R, C, lds_, Rp, rows16);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
 }

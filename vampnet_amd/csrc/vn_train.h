@@ -22,7 +22,8 @@ int vn_launch_reduce_rows(vn_ctx* ctx, const float* partial, int nb, int C, floa
 int vn_launch_transpose(vn_ctx* ctx, const float* src, float* dst, int R, int C, int lds_, int ldd, hipStream_t s);
 // fp32 -> tiled bf16x3 planes (operands of the training GEMMs on the split-plane pipe): the matrix itself / its transpose [C][Rp]
 int vn_launch_split3_tiled(vn_ctx* ctx, const float* src, uint16_t* dst, int R, int K, int lds_, hipStream_t s);
-int vn_launch_transpose_split3_tiled(vn_ctx* ctx, const float* src, uint16_t* dst, int R, int C, int lds_, int Rp, hipStream_t s);
+int vn_launch_transpose_split3_tiled(vn_ctx* ctx, const float* src, uint16_t* dst, int R, int C, int lds_, int Rp, hipStream_t s,
+                                     uint16_t* rows16 = nullptr);   // rows16: also the tiled planes of src itself (C % 32 == 0)
 int vn_launch_colsum(vn_ctx* ctx, const float* src, int R, int C, float* partial, float* out, hipStream_t s);
 int vn_launch_cross_entropy(vn_ctx* ctx, float* logits, const int64_t* target, int32_t* t32, long rows, int V, float ls,
                             int32_t* n_valid, float* row_loss, float* loss, hipStream_t s);
