@@ -726,7 +726,7 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
 // the training step's forward (train.hip): always the shared-tile decomposition; dropout stream d, lse[b][h][t] out
 int vn_launch_attention_x3_train_fwd(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16, long plane_qk, const uint16_t* vt16, long plane_vt,
                                      const float* relbias_full, float* out, float* lse, int B, int H, int T, int cus, const vn_drop& d,
-                                     hipStream_t s) {
+                                     hipStream_t s, uint16_t* out16, long plane16) {
     if (B <= 0 || T <= 0) return VN_OK;
     const size_t lds = vn_attention_x3_lds_bytes(T, 0, 3);
     if (lds > 160 * 1024) return vn_fail(ctx, VN_ERR_INVALID, "attention_x3 (training): T=%s%ld too long for the LDS bias table", "", T);
@@ -740,7 +740,7 @@ int vn_launch_attention_x3_train_fwd(vn_ctx* ctx, const uint16_t* q16, const uin
     const long per_cu = (long)(160 * 1024 / lds) < 3 ? (long)(160 * 1024 / lds) : 3;
     const int knobs = (long)grid.x > per_cu * cus ? 0x10000 : 0;
     hipLaunchKernelGGL((vn_attention_x3_kernel<4, false, 3, true>), grid, dim3(256), lds, s, q16, k16, plane_qk, vt16, plane_vt, relbias_full, out,
-                       (uint16_t*)nullptr, 0L, B, H, T, knobs, (unsigned*)nullptr, lse, d);
+                       out16, plane16, B, H, T, knobs, (unsigned*)nullptr, lse, d);
     vn_prof_post(ctx, pi, s);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;

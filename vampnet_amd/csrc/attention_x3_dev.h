@@ -365,6 +365,7 @@ __device__ __forceinline__ void ax_store4(const f32x4& acc, float l_tot, float* 
     // fp16 planes: O is a convex combination of the values, and a value beyond 4094 (16 v >= 65504) is already on the saturation
     // ledger from the QKV epilogue that wrote V^T — nothing new can saturate here, so the flag is not reported
     bool bad = false;
+    // inference passes ONE of the two; the training forward both (fp32 for the backward, planes for the Wo GEMM that follows)
     if (out16) vn_store_planes4(out16, plane16, row, col, H * VN_DHEAD, ov, bad);
-    else *(f32x4*)(out + (size_t)row * ((size_t)H * VN_DHEAD) + col) = ov;
+    if (out) *(f32x4*)(out + (size_t)row * ((size_t)H * VN_DHEAD) + col) = ov;
 }

@@ -517,18 +517,20 @@ static int forward_train(vn_train* t, int B, int T, const vn_train_params* p, hi
         vn_gemm_args a{};
         a.A = S.y1; a.W = P(t, VN_W_QKV, l); a.C = S.qkv; a.M = M; a.N = 3 * D; a.K = D; a.ldc = 3 * D;
         a.T = T; a.H = H; a.qkv_plane = plane;
+        bool a16o = false;
         if (t->ax3) {
             a.C = nullptr; a.C16 = S.qk16; a.c_plane = t->qk_plane; a.V16 = S.vt16; a.v_plane = t->vt_plane;
             if ((rc = gemm_args(t, a, VN_EPI_QKV3, s, n16))) return rc;
+            a16o = x3_shape(t, D, D);             // the attention writes the planes of its output for the Wo GEMM as well
             rc = vn_launch_attention_x3_train_fwd(ctx, S.qk16, S.qk16 + plane, t->qk_plane, S.vt16, t->vt_plane, m->bias_full, S.a, S.lse, B, H,
-                                                  T, vn_num_cus(ctx), make_drop(p, l, SITE_ATTN, r_att), s);
+                                                  T, vn_num_cus(ctx), make_drop(p, l, SITE_ATTN, r_att), s, a16o ? t->a16 : nullptr, VN_PLANES_TILED);
         } else {
             if ((rc = gemm_args(t, a, VN_EPI_QKV, s, n16))) return rc;
             rc = vn_launch_attention_train_fwd(ctx, S.qkv, S.qkv + plane, S.qkv + 2 * plane, m->bias_full, S.a, S.lse, B, H, T,
                                                make_drop(p, l, SITE_ATTN, r_att), s);
         }
         if (rc) return rc;
-        if ((rc = gemm(t, S.a, P(t, VN_W_WO, l), nullptr, t->tmp, M, D, D, VN_EPI_STORE, s))) return rc;
+        if ((rc = gemm(t, S.a, P(t, VN_W_WO, l), nullptr, t->tmp, M, D, D, VN_EPI_STORE, s, a16o))) return rc;
         if ((rc = vn_launch_resid_dropout(ctx, S.x_in, t->tmp, S.x_mid, M, D, make_drop(p, l, SITE_RES1, r_tok), s))) return rc;
         if ((rc = vn_launch_rmsnorm(ctx, S.x_mid, P(t, VN_W_NORM3, l), S.y3, M, D, m->d.eps, s, n16 ? t->a16 : nullptr, VN_PLANES_TILED, true))) return rc;
         if ((rc = gemm(t, S.y3, P(t, VN_W_W1, l), nullptr, S.u, M, 4 * D, D, VN_EPI_STORE, s, n16))) return rc;

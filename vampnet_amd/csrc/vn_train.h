@@ -63,7 +63,7 @@ size_t vn_attention_x3_bwd_dq_lds(int T, int near_r);
 size_t vn_attention_x3_lds_bytes(int T, int key_split, int np);
 int vn_launch_attention_x3_train_fwd(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16, long plane_qk, const uint16_t* vt16, long plane_vt,
                                      const float* relbias_full, float* out, float* lse, int B, int H, int T, int cus, const vn_drop& d,
-                                     hipStream_t s);
+                                     hipStream_t s, uint16_t* out16 = nullptr, long plane16 = 0);   // out16: also the planes of out (e.g. tiled)
 int vn_launch_attention_x3_bwd(vn_ctx* ctx, const uint16_t* qk16, long plane_qk, const uint16_t* vt16, long plane_vt, uint16_t* ws,
                                const float* relbias_full, const int32_t* lut_dev, int near_r, const float* out, const float* dout,
                                const float* lse, float* delta, float* dqkv, float* dbias_partial, int B, int H, int T, int nbuckets,
