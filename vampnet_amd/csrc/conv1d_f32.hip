@@ -259,33 +259,47 @@ extern "C" int vn_conv1d_f32(vn_ctx* ctx, const float* x, const float* w, const 
 // Encoder stem: WNConv1d(1 -> C, k = 7, pad 3) on the raw waveform (K = 7: not MFMA-shaped, HBM-bound on the write).
 //   y[b][t][c] = bias[c] + sum_j w[c][j] * x[b][t + j - 3] ; y2 = snake(y, alpha)
 // ---------------------------------------------------------------------------------------------
+// A thread owns FOUR consecutive channels of one sample (C % 4 == 0): the seven waveform taps are loaded once for the four, the weights as
+// their 28 scalars, and both outputs go out as 16-byte stores (one channel per thread issued seven loads and a 64-bit division per 4-byte
+// store: 1.5 ms for the 0.9 + 0.9 GB it writes at B = 8 — profiles/r05_codec_kernel_trace_bf16x3.txt).
 __global__ __launch_bounds__(256) void vn_dac_conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ alpha, float* __restrict__ y,
                                                              float* __restrict__ y2, int B, int T, int C) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // over B*T*C, c fastest (coalesced writes)
-    if (i >= (long)B * T * C) return;
-    const int c = (int)(i % C);
-    const long bt = i / C;
+    const int c4n = C >> 2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // over B*T*(C/4), channel group fastest (coalesced writes)
+    if (i >= (long)B * T * c4n) return;
+    const int c = (int)(i % c4n) * 4;
+    const long bt = i / c4n;
     const int t = (int)(bt % T);
     const float* xb = x + (bt - t);
-    float v = bias[c];
+    float xv[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
         const int ti = t + j - 3;
-        if (ti >= 0 && ti < T) v = fmaf(w[c * 7 + j], xb[ti], v);
+        xv[j] = (ti >= 0 && ti < T) ? xb[ti] : 0.f;
     }
-    if (y) y[i] = v;
+    f32x4 v = *(const f32x4*)(bias + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) v[e] = fmaf(w[(c + e) * 7 + j], xv[j], v[e]);      // taps outside the clip multiply a zero: same sum
+    if (y) *(f32x4*)(y + bt * C + c) = v;
     if (y2) {
-        const float al = alpha[c];
-        y2[i] = vn_snake(v, al, 1.0f / (al + 1e-9f));
+        const f32x4 al = *(const f32x4*)(alpha + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = vn_snake(v[e], al[e], 1.0f / (al[e] + 1e-9f));
+        *(f32x4*)(y2 + bt * C + c) = o;
     }
 }
 
 extern "C" int vn_dac_conv_in_f32(vn_ctx* ctx, const float* x, const float* w, const float* bias, const float* alpha,
                                   float* y, float* y2, int B, int T, int C, void* stream) {
     if (!ctx || !x || !w || !bias || (!y && !y2) || (y2 && !alpha)) return VN_ERR_INVALID;
-    const long n = (long)B * T * C;
+    if ((C & 3) || (((uintptr_t)bias | (uintptr_t)alpha | (uintptr_t)y | (uintptr_t)y2) & 15))
+        return vn_fail(ctx, VN_ERR_INVALID, "conv_in: C=%s%ld must be a multiple of 4 and bias / alpha / outputs 16-byte aligned", "", C);
+    const long n = (long)B * T * (C >> 2);
     hipLaunchKernelGGL(vn_dac_conv_in_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w,
                        bias, alpha, y, y2, B, T, C);
     VN_LAUNCH_CHECK(ctx);
@@ -298,22 +312,30 @@ extern "C" int vn_dac_conv_in_f32(vn_ctx* ctx, const float* x, const float* w, c
 // 64 + 6 rows in LDS).  w packed [7][C].
 // ---------------------------------------------------------------------------------------------
 #define COUT_T 64
+// LDS rows are C + 4 floats apart: lane (sample o, part p) reads 16 bytes at (o + j) (C + 4) + 16 i + 4 p — for C = 96 the sixteen samples
+// of a wave start 36 banks apart (all distinct multiples of 4), so a wave's read covers the 64 banks once (row pitch C: 32 o mod 64 — the
+// wave hit 8 banks, and the kernel took 1.9 ms for the 1.35 GB it reads at B = 8)
 __global__ __launch_bounds__(256) void vn_dac_conv_out_kernel(const float* __restrict__ xs, const float* __restrict__ w,
                                                               float bias, float* __restrict__ y, int B, int T, int C) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];      // [(COUT_T + 6)][C]
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [(COUT_T + 6)][C + 4]
     const int b = blockIdx.y, t0 = blockIdx.x * COUT_T;
-    const int rows = COUT_T + 6;
-    for (int i = threadIdx.x; i < rows * C; i += 256) {
-        const int r = i / C, c = i - r * C;
+    const int rows = COUT_T + 6, c4n = C >> 2, CP = C + 4;
+    for (int i = threadIdx.x; i < rows * c4n; i += 256) {
+        const int r = i / c4n, c = (i - r * c4n) * 4;
         const int t = t0 + r - 3;
-        sm[i] = (t >= 0 && t < T) ? xs[((size_t)b * T + t) * C + c] : 0.f;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t >= 0 && t < T) v = *(const f32x4*)(xs + ((size_t)b * T + t) * C + c);
+        *(f32x4*)(sm + r * CP + c) = v;
     }
     __syncthreads();
-    // 4 lanes per output sample: each sums a quarter of the 7*C products, then a 2-step shuffle reduce
+    // 4 lanes per output sample: each sums a quarter of the 7*C products (16-byte pieces 4 p, 4 p + 16, ...), then a 2-step shuffle reduce
     const int o = threadIdx.x >> 2, part = threadIdx.x & 3;
     float acc = 0.f;
-    const int n = 7 * C;
-    for (int k = part; k < n; k += 4) acc = fmaf(w[k], sm[o * C + k], acc);      // rows o..o+6 are contiguous in sm
+    for (int j = 0; j < 7; ++j)
+        for (int c = 4 * part; c < C; c += 16) {
+            const f32x4 xv = *(const f32x4*)(sm + (o + j) * CP + c), wv = *(const f32x4*)(w + j * C + c);
+            acc = fmaf(wv[0], xv[0], acc); acc = fmaf(wv[1], xv[1], acc); acc = fmaf(wv[2], xv[2], acc); acc = fmaf(wv[3], xv[3], acc);
+        }
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
     if (part == 0 && t0 + o < T) y[(size_t)b * T + t0 + o] = tanhf(acc + bias);
@@ -322,7 +344,8 @@ __global__ __launch_bounds__(256) void vn_dac_conv_out_kernel(const float* __res
 extern "C" int vn_dac_conv_out_f32(vn_ctx* ctx, const float* xs, const float* w, float bias, float* y, int B, int T,
                                    int C, void* stream) {
     if (!ctx || !xs || !w || !y) return VN_ERR_INVALID;
-    const size_t lds = (size_t)(COUT_T + 6) * C * sizeof(float);
+    if ((C & 3) || (((uintptr_t)xs | (uintptr_t)w) & 15)) return vn_fail(ctx, VN_ERR_INVALID, "conv_out: C=%s%ld must be a multiple of 4, operands 16-byte aligned", "", C);
+    const size_t lds = (size_t)(COUT_T + 6) * (C + 4) * sizeof(float);
     if (lds > 64 * 1024) return vn_fail(ctx, VN_ERR_INVALID, "conv_out: C=%s%ld too wide", "", C);
     hipLaunchKernelGGL(vn_dac_conv_out_kernel, dim3(vn_cdiv(T, COUT_T), B), dim3(256), lds, (hipStream_t)stream, xs, w,
                        bias, y, B, T, C);
