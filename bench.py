@@ -197,7 +197,8 @@ def bench_train(args, rank, world, device, pg, barrier):
            "config": {"workload": "BASELINE configs[4]: conf/vampnet.yml training step, coarse VampNet (20 layers, d=1280), "
                                   f"batch {Bg}/GPU x T=575 x 4 codebooks, dropout 0.1, label smoothing 0.1, clip 5.0, "
                                   "AdamW + Noam, fp32-grade arithmetic (amp: false): " +
-                                  ("GEMMs as six bf16-MFMA products of exact three-way operand splits" if train_dtype == "bf16x3"
+                                  (("GEMMs" + ("" if os.environ.get("VN_TRAIN_ATTN_X3") == "0" else " and attention (forward + backward)") +
+                                    " as six bf16-MFMA products of exact three-way operand splits") if train_dtype == "bf16x3"
                                    else "fp32-input MFMA"),
                       "global_batch": world * Bg, "parallelism": f"dp{world}" if world > 1 else "single GPU",
                       "step_tflop_per_gpu": step_tflop, "achieved_tflops_per_gpu": step_tflop / (elapsed / args.steps),
