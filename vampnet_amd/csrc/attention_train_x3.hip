@@ -231,6 +231,19 @@ __device__ __forceinline__ void ab_dq_block(const ab_args& A, const int bid, con
     };
     auto stage_t = [&](int kt) { ab_stage3(trs, KTs, wave, vvoff, t0 + kt * (VN_DHEAD * AX_KT * 2), tpl); };
 
+    // bias gradient: a wave tile whose whole key - query range lies in ONE bucket is summed in registers.  The test needs two LUT entries per
+    // tile; lane i decides tile i once, here (read back with v_readlane): a vector load inside the loop makes the compiler wait for
+    // vmcnt(0) in front of its use, i.e. for the K^T DMA that was issued a moment earlier to fly under the whole S / dPd phase
+    auto far_info = [&](int key0) {
+        const int rel_lo = key0 - (q0 + 31), rel_hi = key0 + 31 - q0;
+        const int lo_c = rel_lo < -(T - 1) ? -(T - 1) : rel_lo, hi_c = rel_hi > T - 1 ? T - 1 : rel_hi;
+        const int b_lo = lut[lo_c + T - 1];
+        return ((rel_lo > 0 || rel_hi < 0) && b_lo == lut[hi_c + T - 1]) ? (b_lo | 0x100) : 0;
+    };
+    int far_tbl = 0;
+    if constexpr (DBIAS) {
+        if (NT <= 64) far_tbl = far_info((lane < NT ? lane : NT - 1) * AX_KT);
+    }
     f32x16 o[2];
     ab_zero(o[0]); ab_zero(o[1]);
     stage_kv(0);
@@ -242,10 +255,9 @@ __device__ __forceinline__ void ab_dq_block(const ab_args& A, const int bid, con
         bool far = false;
         int far_bucket = 0;
         if constexpr (DBIAS) {
-            const int rel_lo = key0 - (q0 + 31), rel_hi = key0 + 31 - q0;
-            const int lo_c = rel_lo < -(T - 1) ? -(T - 1) : rel_lo, hi_c = rel_hi > T - 1 ? T - 1 : rel_hi;
-            far_bucket = __builtin_amdgcn_readfirstlane(lut[lo_c + T - 1]);
-            far = (rel_lo > 0 || rel_hi < 0) && far_bucket == __builtin_amdgcn_readfirstlane(lut[hi_c + T - 1]);
+            const int info = NT <= 64 ? __builtin_amdgcn_readlane(far_tbl, kt) : far_info(key0);
+            far = (info & 0x100) != 0;
+            far_bucket = info & 0xff;
         }
         asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");         // this wave's K / V pieces landed (K^T may fly)
         AX_RAW_BARRIER();
@@ -398,25 +410,22 @@ __device__ __forceinline__ void ab_dkv_block(const ab_args& A, const int bid, co
         ab_stage3(qtrs, QTs, wave, tvoff, t0 + qt * (VN_DHEAD * AX_KT * 2), tpl);
         ab_stage3(dtrs, dOTs, wave, tvoff, t0 + qt * (VN_DHEAD * AX_KT * 2), tpl);
     };
-    // per-query scalars of a tile (wave 0, lanes 0..31): loaded one tile ahead, written to the other buffer
-    float n_lse = 0.f, n_del = 0.f;
-    uint32_t n_rk = 0;
-    auto row_load = [&](int qt) {
+    // per-query scalars of a tile (wave 0, lanes 0..31), fetched one tile ahead into the other buffer: loaded and written in one go right
+    // after barrier B — the only vector-memory results in the loop, so the wait in front of the LDS write covers nothing but transposes
+    // that were issued a whole phase earlier (values kept in registers until the next barrier cost three VGPRs of a kernel that sits at
+    // the 256 of two waves per SIMD and spills: a spill reload inside the loop waits for vmcnt(0), i.e. for every DMA in flight)
+    auto row_fetch = [&](int qt) {
         if (wave == 0 && lane < 32) {
-            const int qq = qt * AX_KT + lane, qc = qq < T ? qq : T - 1;
-            n_lse = lse[head * T + qc];
-            n_del = delta[head * T + qc];
-            n_rk = vn_drop_rowkey(d, (long)head * T + qc);
+            const int qq = qt * AX_KT + lane, qc = qq < T ? qq : T - 1, bf = (qt & 1) * 32;
+            lse_s[bf + lane] = lse[head * T + qc];
+            del_s[bf + lane] = delta[head * T + qc];
+            rk_s[bf + lane] = vn_drop_rowkey(d, (long)head * T + qc);
         }
-    };
-    auto row_write = [&](int buf) {
-        if (wave == 0 && lane < 32) { lse_s[buf * 32 + lane] = n_lse; del_s[buf * 32 + lane] = n_del; rk_s[buf * 32 + lane] = n_rk; }
     };
 
     f32x16 accK[2], accV[2];
     ab_zero(accK[0]); ab_zero(accK[1]); ab_zero(accV[0]); ab_zero(accV[1]);
-    row_load(0);
-    row_write(0);
+    row_fetch(0);
     stage_r(0);
     stage_t(0);
     for (int qt = 0; qt < NT; ++qt) {
@@ -426,10 +435,16 @@ __device__ __forceinline__ void ab_dkv_block(const ab_args& A, const int bid, co
         AX_RAW_BARRIER();
         f32x16 sacc, dpacc;
         if (active) {
+            if (qq0 + AX_KT <= T) {                                          // every query of the tile exists: one base, constant offsets
+                const float* brow = bt + (krow_c - qq0 - 8 * L.hh + (T - 1));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qq = qq0 + 16 * (r >> 3) + 8 * L.hh + (r & 7), qc = qq < T ? qq : T - 1;
-                sacc[r] = bt[krow_c - qc + (T - 1)];
+                for (int r = 0; r < 16; ++r) sacc[r] = brow[-(16 * (r >> 3) + (r & 7))];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qq = qq0 + 16 * (r >> 3) + 8 * L.hh + (r & 7), qc = qq < T ? qq : T - 1;
+                    sacc[r] = bt[krow_c - qc + (T - 1)];
+                }
             }
             ab_zero(dpacc);
             ax_qk<3>(sacc, Qs, kf, L);                                      // S[q][key] = Q K^T (+ bias)
@@ -437,31 +452,27 @@ __device__ __forceinline__ void ab_dkv_block(const ab_args& A, const int bid, co
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         AX_RAW_BARRIER();                                                    // Q and dO have been read by everybody
-        if (more) { row_load(qt + 1); stage_r(qt + 1); }
+        if (more) { row_fetch(qt + 1); stage_r(qt + 1); }
         // Pd and dS stay in the registers of S and dPd (fp32) until their product runs: their planes are formed one after the other
         // behind the next barrier (both plane sets live at once cost 45 spilled VGPRs at the 256 of two waves per SIMD)
         if (active) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int ql = 16 * s + 8 * L.hh;
-                const f32x4 la = *(const f32x4*)(lse_s + buf * 32 + ql), lb = *(const f32x4*)(lse_s + buf * 32 + ql + 4);
-                const f32x4 da = *(const f32x4*)(del_s + buf * 32 + ql), db = *(const f32x4*)(del_s + buf * 32 + ql + 4);
-                const u32x4 ra = *(const u32x4*)(rk_s + buf * 32 + ql), rb = *(const u32x4*)(rk_s + buf * 32 + ql + 4);
+            for (int g4 = 0; g4 < 4; ++g4) {                                 // four query rows at a time: rows 16 (g4 >> 1) + 8 hh + 4 (g4 & 1) ..
+                const int ql = 16 * (g4 >> 1) + 8 * L.hh + 4 * (g4 & 1);
+                const f32x4 l4 = *(const f32x4*)(lse_s + buf * 32 + ql), d4 = *(const f32x4*)(del_s + buf * 32 + ql);
+                const u32x4 r4 = *(const u32x4*)(rk_s + buf * 32 + ql);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int r = 8 * s + e, qq = qq0 + ql + e;
-                    const float lq = e < 4 ? la[e & 3] : lb[e & 3], dq_ = e < 4 ? da[e & 3] : db[e & 3];
-                    const uint32_t rq = e < 4 ? ra[e & 3] : rb[e & 3];
-                    const float p = (qq < T && kok) ? ax_exp<false>(sacc[r] - lq) : 0.f;
-                    const float mul = d.thresh16 ? vn_drop_mul(d, vn_drop_bits(rq, krow_c), krow_c) : 1.0f;
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e, qq = qq0 + ql + e;
+                    const float p = (qq < T && kok) ? ax_exp<false>(sacc[r] - l4[e]) : 0.f;
+                    const float mul = d.thresh16 ? vn_drop_mul(d, vn_drop_bits(r4[e], krow_c), krow_c) : 1.0f;
                     sacc[r] = p * mul;                                       // Pd
-                    dpacc[r] = p * (dpacc[r] * mul - dq_);                   // dS
+                    dpacc[r] = p * (dpacc[r] * mul - d4[e]);                 // dS
                 }
             }
         }
         if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // the transposes of this tile landed (the next Q / dO fly)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (more) row_write(buf ^ 1);
         AX_RAW_BARRIER();
         if (active) {
             f32x4 pf[3][2];

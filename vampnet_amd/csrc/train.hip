@@ -521,7 +521,8 @@ static int forward_train(vn_train* t, int B, int T, const vn_train_params* p, hi
         if (t->ax3) {
             a.C = nullptr; a.C16 = S.qk16; a.c_plane = t->qk_plane; a.V16 = S.vt16; a.v_plane = t->vt_plane;
             if ((rc = gemm_args(t, a, VN_EPI_QKV3, s, n16))) return rc;
-            a16o = x3_shape(t, D, D);             // the attention writes the planes of its output for the Wo GEMM as well
+            // (the kernel can also write the planes of its output for the Wo GEMM — a16o = x3_shape(t, D, D), t->a16 below — but its 8-byte
+            // scattered plane stores cost 13 us per layer against the 10.6 us of the split pass they replace: left off)
             rc = vn_launch_attention_x3_train_fwd(ctx, S.qk16, S.qk16 + plane, t->qk_plane, S.vt16, t->vt_plane, m->bias_full, S.a, S.lse, B, H,
                                                   T, vn_num_cus(ctx), make_drop(p, l, SITE_ATTN, r_att), s, a16o ? t->a16 : nullptr, VN_PLANES_TILED);
         } else {
