@@ -481,6 +481,10 @@ int  vn_attention_train_f32(vn_ctx* ctx, const float* q, const float* k, const f
 int  vn_attention_train_bf16x3(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
                                float* out, float* lse, const float* dout, float* dqkv, float* dbias, int B, int H, int T,
                                int num_buckets, int max_distance, float dropout, uint64_t seed, void* stream);
+/* Pure host query (no GPU needed): the relative-position bucket LUT the attention kernels index with key - query + T - 1
+ * (lut_out[2 T - 1] or NULL; transformer.py:123-170) and *near_r = the half-width of the per-wave bias-gradient tables of the
+ * split-plane backward: every 32 x 32 wave tile whose offsets do NOT all fall into one bucket lies within +- near_r of the diagonal. */
+int  vn_attention_bwd_table_span(int T, int num_buckets, int max_distance, int32_t* lut_out, int* near_r);
 
 /* dst [C][ldd] = transpose(src [R][C]), columns R..ldd-1 zero-filled (ldd % 4 == 0): the layout pass in front of the
  * weight-gradient GEMMs; exposed for tests and tuning.                                                              */

@@ -1053,3 +1053,30 @@ def test_interface_resident_model_lru(tmp_path):
     assert itf._resident_get("c2f", paths[0]) is None                             # roles are separate
     paths[0].write_bytes(b"changed")                                              # a rewritten file is another model
     assert itf._resident_get("coarse", paths[0]) is None
+
+
+@pytest.mark.parametrize("T,nb,md", [(37, 32, 128), (64, 32, 128), (575, 32, 128), (1024, 32, 128), (300, 16, 64), (130, 64, 512)])
+def test_attention_backward_bias_tables_cover_every_mixed_bucket_tile(T, nb, md):
+    """Host side of the split-plane attention backward (csrc/attention_train_x3.hip): the bucket LUT the kernels index with
+    key - query + T - 1 is the oracle's relative_position_bucket, and near_r — the half-width of the per-wave bias-gradient tables —
+    covers every 32 x 32 wave tile that is NOT summed in registers: a tile is "far" when its whole offset range lies on one side of the
+    diagonal inside ONE bucket; for every other tile all offsets of real (query, key) pairs must satisfy |key - query| <= near_r."""
+    lib = _lib.load()
+    lut = np.zeros(2 * T - 1, dtype=np.int32)
+    nr = C.c_int()
+    assert lib.vn_attention_bwd_table_span(T, nb, md, lut.ctypes.data_as(C.c_void_p), C.byref(nr)) == 0
+    rel = torch.arange(-(T - 1), T)
+    assert np.array_equal(lut, O.relative_position_bucket(rel, nb, md).numpy().astype(np.int32))
+    near_r = nr.value
+    assert 0 < near_r <= T - 1
+    for q0 in range(0, T, 32):
+        for k0 in range(0, T, 32):
+            lo, hi = k0 - (q0 + 31), k0 + 31 - q0
+            lo_c, hi_c = max(lo, -(T - 1)), min(hi, T - 1)
+            far = (lo > 0 or hi < 0) and lut[lo_c + T - 1] == lut[hi_c + T - 1]
+            if far:
+                assert len(set(lut[lo_c + T - 1:hi_c + T])) == 1        # monotone on each side: the ends decide the whole range
+                continue
+            qs = np.arange(q0, min(q0 + 32, T))[:, None]
+            ks = np.arange(k0, min(k0 + 32, T))[None, :]
+            assert np.abs(ks - qs).max() <= near_r, (q0, k0, near_r)

@@ -138,6 +138,7 @@ SYMBOLS = {
     "vn_debug_attention_x3_time": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
     "vn_debug_x3_config": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "vn_debug_x3_fuse_norm": (C.c_int, [_P, C.c_int]),
+    "vn_attention_bwd_table_span": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P]),
     "vn_debug_attention_x3_force": (C.c_int, [_P, C.c_int]),
     "vn_debug_splitk_reduce_rmsnorm": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int, _P]),
     "vn_debug_attention_x3_config": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),

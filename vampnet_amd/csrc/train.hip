@@ -884,6 +884,17 @@ extern "C" int vn_attention_train_f32(vn_ctx* ctx, const float* q, const float* 
     return rc;
 }
 
+// host-only (no GPU needed; tests/test_host_logic.py): the relative-position bucket LUT of length 2 T - 1 (index key - query + T - 1) as the
+// kernels use it, and the half-width of the per-wave bias-gradient tables the split-plane backward derives from it
+extern "C" int vn_attention_bwd_table_span(int T, int num_buckets, int max_distance, int32_t* lut_out, int* near_r) {
+    if (T <= 0 || num_buckets <= 0 || max_distance <= 0 || !near_r) return VN_ERR_INVALID;
+    std::vector<int32_t> lut(2 * T - 1);
+    vn_bucket_lut_host(T, num_buckets, max_distance, lut.data());
+    if (lut_out) memcpy(lut_out, lut.data(), lut.size() * sizeof(int32_t));
+    *near_r = vn_attention_x3_near_r(lut.data(), T);
+    return VN_OK;
+}
+
 // the same on the split-plane pipe (attention_x3.hip TRAIN forward, attention_train_x3.hip backward): fp32 q, k, v are split /
 // transposed here exactly as the QKV GEMM's plane epilogue does (engine.hip vn_attn_x3_prep_kernel)
 extern "C" int vn_attention_train_bf16x3(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
