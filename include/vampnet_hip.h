@@ -502,6 +502,12 @@ int vn_mt19937_generate(vn_ctx* ctx, uint32_t* state624, int32_t* pos, uint32_t*
  * then walks n_chunks such states in parallel, chunk c writing words [c*chunk_words, min((c+1)*chunk_words, total_words)).       */
 int vn_mt19937_jump(vn_ctx* ctx, const uint32_t* state624, const int32_t* pos, const uint32_t* polys, int n_targets,
                     uint32_t* out_states, void* stream);
+/* Second level of a two-level plan: target b = the state poly_index[b] steps-polynomial ahead of base_states[base_index[b]] (dev u32
+ * [..][624], each AT POSITION 0: the outputs of a first vn_mt19937_jump).  All the draws of a whole generate() call are then known
+ * from one generator state with (steps + 1) + (chunks per step) polynomials instead of steps x chunks: one jump launch for the
+ * starts of the sampling steps, one for every step's chunk starts, one walk for all chunks.                                          */
+int vn_mt19937_jump_indexed(vn_ctx* ctx, const uint32_t* base_states, const int32_t* base_index, const uint32_t* polys,
+                            const int32_t* poly_index, int n_targets, uint32_t* out_states, void* stream);
 int vn_mt19937_generate_chunks(vn_ctx* ctx, const uint32_t* states, int n_chunks, uint32_t* out_raw, int64_t chunk_words,
                                int64_t total_words, void* stream);
 int vn_torch_exponential_f32(vn_ctx* ctx, const uint32_t* raw, float* out, int64_t n, void* stream);

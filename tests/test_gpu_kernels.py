@@ -386,6 +386,39 @@ def test_torch_rng_on_device(eng):
     assert torch.equal(u2.cpu(), ref_u)
 
 
+@pytest.mark.parametrize("B,N,b0,nb,pattern", [(2, 1150, 0, 2, (1, 1, 1)),          # 4.7 M words per step: three chunks of 2 M
+                                                 (3, 300, 1, 1, (1, 0, 1, 1)),        # a rank's rows of a sharded batch, a non-sampling step
+                                                 (1, 37, 0, 1, (1, 1))])              # tiny: one short chunk per step
+def test_torch_rng_whole_call_plan_equals_torch(eng, B, N, b0, nb, pattern):
+    """torch_rng.draw_units — every draw of a whole generate() call planned from ONE generator state (two-level jump-ahead, all chunks
+    walked at once) — gives, step for step, the tensors torch draws on the host in the reference's order (exponential_ over (B N, V) when
+    the step samples, then uniform_ over (B, N)), for the rows [b0, b0 + nb) of a sharded batch, and leaves torch's generator where
+    the reference's would be."""
+    from vampnet_amd.torch_rng import DeviceTorchRng, draw_units
+    V = 1024
+    rng = DeviceTorchRng(eng)
+    torch.manual_seed(1234)
+    _ = torch.rand(5)
+    blob = torch.get_rng_state()
+    want = []
+    for s_ in pattern:
+        e = torch.empty(B * N, V).exponential_(1) if s_ else None
+        u = torch.zeros(B, N).uniform_(1e-20, 1)
+        want.append((e, u))
+    tail = torch.rand(6)
+    torch.set_rng_state(blob)
+    rng.load_from_torch()
+    exp = torch.zeros(len(pattern), nb * N, V, device="cuda")
+    unif = torch.empty(len(pattern), nb, N, device="cuda")
+    draw_units(rng, [(exp[i] if s_ else None, unif[i]) for i, s_ in enumerate(pattern)], B, N, V, b0, nb)
+    rng.store_to_torch()
+    for i, (e, u) in enumerate(want):
+        if e is not None:
+            assert torch.equal(exp[i].cpu(), e[b0 * N:(b0 + nb) * N]), f"exponentials of step {i}"
+        assert torch.equal(unif[i].cpu(), u[b0:b0 + nb]), f"uniforms of step {i}"
+    assert torch.equal(torch.rand(6), tail)
+
+
 @pytest.mark.parametrize("rows,lead_rows,total_rows,chunk", [(600, 0, 600, 1 << 16), (500, 70, 640, 1 << 16), (2300, 0, 2300, None)])
 def test_torch_rng_jump_ahead_path(eng, rows, lead_rows, total_rows, chunk):
     """The parallel (jump-ahead) production of a block of torch's exponential_ stream equals the serial one and torch itself:

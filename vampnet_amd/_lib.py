@@ -112,6 +112,7 @@ SYMBOLS = {
     "vn_transpose_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "vn_mt19937_generate": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P]),
     "vn_mt19937_jump": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P]),
+    "vn_mt19937_jump_indexed": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "vn_mt19937_generate_chunks": (C.c_int, [_P, _P, C.c_int, _P, C.c_int64, C.c_int64, _P]),
     "vn_torch_exponential_f32": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "vn_torch_uniform_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, C.c_float, _P]),

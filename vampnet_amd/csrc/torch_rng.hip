@@ -119,10 +119,16 @@ extern "C" int vn_mt19937_generate_chunks(vn_ctx* ctx, const uint32_t* states, i
 // The result is a state array at position 0.
 // ---------------------------------------------------------------------------------------------------------------------
 #define MT_JUMP_BLOCKS 34
+// base_index / poly_index (both or neither): target b starts from the state array base_index[b] of `state` AT POSITION 0 and applies
+// polynomial poly_index[b] — the second level of a two-level plan (vn_mt19937_jump_indexed: first the states at the starts of all
+// sampling steps of a call from the generator's state, then every step's chunk starts from ITS state with the polynomials of the
+// chunk offsets, which are the same for every step)
 __global__ __launch_bounds__(256) void vn_mt19937_jump_kernel(const uint32_t* __restrict__ state, const int32_t* __restrict__ pos,
-                                                              const uint32_t* __restrict__ polys, uint32_t* __restrict__ out_states) {
+                                                              const uint32_t* __restrict__ polys, uint32_t* __restrict__ out_states,
+                                                              const int32_t* __restrict__ base_index, const int32_t* __restrict__ poly_index) {
     extern __shared__ uint32_t Y[];                       // [MT_JUMP_BLOCKS][624]
     const int tid = threadIdx.x;
+    if (base_index) state += (size_t)base_index[blockIdx.x] * MT_N;
     for (int i = tid; i < MT_N; i += 256) Y[i] = state[i];
     __syncthreads();
     for (int blk = 0; blk + 1 < MT_JUMP_BLOCKS; ++blk) {
@@ -140,8 +146,8 @@ __global__ __launch_bounds__(256) void vn_mt19937_jump_kernel(const uint32_t* __
         }
         __syncthreads();
     }
-    const uint32_t* poly = polys + (size_t)blockIdx.x * MT_N;
-    const uint32_t* x = Y + *pos;                         // x_0 = state[pos]; pos == 624 starts at block 1
+    const uint32_t* poly = polys + (size_t)(poly_index ? poly_index[blockIdx.x] : blockIdx.x) * MT_N;
+    const uint32_t* x = Y + (base_index ? 0 : *pos);      // x_0 = state[pos]; pos == 624 starts at block 1
     uint32_t a0 = 0, a1 = 0, a2 = 0;
     const bool has2 = tid + 512 < MT_N;
     for (int wd = 0; wd < MT_N; ++wd) {
@@ -168,7 +174,22 @@ extern "C" int vn_mt19937_jump(vn_ctx* ctx, const uint32_t* state624, const int3
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_mt19937_jump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->attr_mask |= VN_ATTR_MT_JUMP;
     }
-    hipLaunchKernelGGL(vn_mt19937_jump_kernel, dim3(n_targets), dim3(256), lds, (hipStream_t)stream, state624, pos, polys, out_states);
+    hipLaunchKernelGGL(vn_mt19937_jump_kernel, dim3(n_targets), dim3(256), lds, (hipStream_t)stream, state624, pos, polys, out_states,
+                       (const int32_t*)nullptr, (const int32_t*)nullptr);
+    VN_LAUNCH_CHECK(ctx);
+    return VN_OK;
+}
+
+extern "C" int vn_mt19937_jump_indexed(vn_ctx* ctx, const uint32_t* base_states, const int32_t* base_index, const uint32_t* polys,
+                                       const int32_t* poly_index, int n_targets, uint32_t* out_states, void* stream) {
+    if (!ctx || !base_states || !base_index || !polys || !poly_index || !out_states || n_targets <= 0) return VN_ERR_INVALID;
+    const size_t lds = (size_t)MT_JUMP_BLOCKS * MT_N * sizeof(uint32_t);
+    if (!(ctx->attr_mask & VN_ATTR_MT_JUMP)) {
+        VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)vn_mt19937_jump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ctx->attr_mask |= VN_ATTR_MT_JUMP;
+    }
+    hipLaunchKernelGGL(vn_mt19937_jump_kernel, dim3(n_targets), dim3(256), lds, (hipStream_t)stream, base_states, (const int32_t*)nullptr, polys,
+                       out_states, base_index, poly_index);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
 }

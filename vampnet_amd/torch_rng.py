@@ -211,6 +211,81 @@ class DeviceTorchRng:
         return out
 
 
+RAW_WORDS_PER_ROUND = 160 << 20     # raw mt19937 words held at once by draw_units (640 MB): the exponentials of a call are produced in rounds
+
+
+def draw_units(rng: DeviceTorchRng, units, B, N, V, b0, nb):
+    """All the draws of one or more generate() calls from ONE generator state, on the current stream.
+
+    `units` = the sampling steps in the reference's draw order, each (exp_dst or None, unif_dst): a step consumes
+    `exponential_` over (B*N, V) when it samples (two words per element; rows [b0*N, (b0+nb)*N) land in exp_dst) and then
+    `uniform_` over (B, N) (rows [b0, b0+nb) land in unif_dst).  Every offset is known before anything runs (static shapes), so the plan
+    is two jump launches and two walks for the whole call instead of one jump + one walk per step, each waiting for the previous
+    step's end state:
+      level 1: the generator states at the start of every unit and at the end of the call, from (state, pos) — one polynomial per unit;
+      level 2: from each unit's state, its chunk starts and the start of its uniform block — the SAME polynomials for every unit
+               (vn_mt19937_jump_indexed);
+      walks  : every chunk of every unit in one launch per round (RAW_WORDS_PER_ROUND), the uniform blocks in one more.
+    The rng kernels of the per-step form were active during 95 ms of a 245 ms vamp() on ~19 CUs and slowed the GEMMs they shared CUs
+    with by 5 ms in all (profiles/r05_rng_kernel_time.txt); this form has the same work done in a few milliseconds of the side stream.
+    The generator is left at the end of the last unit."""
+    from . import mt_jump
+    eng, lib, dev = rng.engine, rng.lib, rng.engine.device
+    st = eng.stream()
+    E, U = 2 * B * N * V, B * N
+    length, lead = 2 * nb * N * V, 2 * b0 * N * V
+    chunk = rng.CHUNK_WORDS if length >= rng.CHUNK_WORDS else max(1024, -(-length // 1024) * 1024)
+    nc = max(1, -(-length // chunk))
+    samp = [u for u, (e, _) in enumerate(units) if e is not None]
+    n_units, n_samp = len(units), len(samp)
+    key = ("units", tuple(e is not None for e, _ in units), B, N, V, b0, nb, chunk)
+    cache = rng.__dict__.setdefault("_plan_cache", {})
+    if key not in cache:
+        starts, off = [], 0
+        for e, _ in units:
+            starts.append(off)
+            off += (E if e is not None else 0) + U
+        # the end of the call as (state array one block back, position = what is left of it): torch's generator cannot hold "position 0 of a
+        # fresh block" (at::mt19937 regenerates and consumes in one step: left = 625 is rejected by set_state)
+        end_base = max(off - _N, 0)
+        polys1 = np.stack([mt_jump.jump_poly_words(o) for o in starts + [end_base]])
+        rel = [lead + k * chunk for k in range(nc)] + [E + b0 * N, b0 * N]      # chunk starts; uniform start of a sampling / non-sampling unit
+        polys2 = np.stack([mt_jump.jump_poly_words(o) for o in rel])
+        base_idx = [u for u in samp for _ in range(nc)] + list(range(n_units))
+        poly_idx = [k for _ in samp for k in range(nc)] + [nc if units[u][0] is not None else nc + 1 for u in range(n_units)]
+        as_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+        cache[key] = (as_dev(polys1), as_dev(polys2), torch.tensor(base_idx, dtype=torch.int32, device=dev),
+                      torch.tensor(poly_idx, dtype=torch.int32, device=dev), off - end_base)
+    polys1, polys2, base_idx, poly_idx, end_pos = cache[key]
+    states1 = torch.empty(n_units + 1, _N, dtype=torch.int32, device=dev)
+    eng.check(lib.vn_mt19937_jump(eng.handle, rng.state.data_ptr(), rng.pos.data_ptr(), polys1.data_ptr(), n_units + 1,
+                                  states1.data_ptr(), st), "vn_mt19937_jump")
+    n2 = n_samp * nc + n_units
+    states2 = torch.empty(n2, _N, dtype=torch.int32, device=dev)
+    eng.check(lib.vn_mt19937_jump_indexed(eng.handle, states1.data_ptr(), base_idx.data_ptr(), polys2.data_ptr(), poly_idx.data_ptr(), n2,
+                                          states2.data_ptr(), st), "vn_mt19937_jump_indexed")
+    per_round = max(1, RAW_WORDS_PER_ROUND // (nc * chunk))
+    for r0 in range(0, n_samp, per_round):
+        g = min(per_round, n_samp - r0)
+        raw = rng._scratch(g * nc * chunk)
+        eng.check(lib.vn_mt19937_generate_chunks(eng.handle, states2[r0 * nc:].data_ptr(), g * nc, raw.data_ptr(), chunk, g * nc * chunk, st),
+                  "vn_mt19937_generate_chunks")
+        for j in range(g):
+            dst = units[samp[r0 + j]][0]
+            assert dst.is_contiguous() and dst.numel() * 2 == length
+            eng.check(lib.vn_torch_exponential_f32(eng.handle, raw[j * nc * chunk:].data_ptr(), dst.data_ptr(), length // 2, st),
+                      "vn_torch_exponential_f32")
+    nu = nb * N
+    raw_u = torch.empty(n_units * nu, dtype=torch.int32, device=dev)
+    eng.check(lib.vn_mt19937_generate_chunks(eng.handle, states2[n_samp * nc:].data_ptr(), n_units, raw_u.data_ptr(), nu, n_units * nu, st),
+              "vn_mt19937_generate_chunks")
+    for u, (_, udst) in enumerate(units):
+        assert udst.is_contiguous() and udst.numel() == nu
+        eng.check(lib.vn_torch_uniform_f32(eng.handle, raw_u[u * nu:].data_ptr(), udst.data_ptr(), nu, 1e-20, 1.0, st), "vn_torch_uniform_f32")
+    rng.state.copy_(states1[n_units])
+    rng.pos.fill_(end_pos)
+
+
 def draw_noise_device(rng: DeviceTorchRng, B, N, V, steps, sample_cutoff, b0=0, nb=None, overlap=False):
     """Device twin of engine.draw_noise_host: the same ledger (exp [steps, nb*N, V], zeros on non-sampling steps; unif
     [steps, nb, N]) for items [b0, b0+nb) of a global batch B, produced from — and advancing — torch's CPU generator.
@@ -231,17 +306,19 @@ def draw_noise_device(rng: DeviceTorchRng, B, N, V, steps, sample_cutoff, b0=0, 
         exp = torch.zeros(steps, nb * N, V, dtype=torch.float32, device=dev)
         unif = torch.empty(steps, nb, N, dtype=torch.float32, device=dev)
         rng.load_from_torch()
-        for i in range(steps):
-            if (i / steps) <= sample_cutoff:                      # transformer.py:852-855
-                rng.exponential_block_(exp[i], 2 * b0 * N * V, 2 * B * N * V)
-            rng.skip(b0 * N)
-            rng.uniform_(unif[i], 1e-20, 1.0)
-            rng.skip((B - b0 - nb) * N)
-            if overlap:
-                ev = torch.cuda.Event()
-                ev.record(side)
-                events.append(ev)
-        if not overlap:
+        if overlap:
+            # the whole call's draws as one plan (draw_units): ready a few milliseconds into the first forward; every step waits on the one event
+            draw_units(rng, [(exp[i] if (i / steps) <= sample_cutoff else None, unif[i]) for i in range(steps)], B, N, V, b0, nb)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            events = [ev] * steps
+        else:
+            for i in range(steps):
+                if (i / steps) <= sample_cutoff:                      # transformer.py:852-855
+                    rng.exponential_block_(exp[i], 2 * b0 * N * V, 2 * B * N * V)
+                rng.skip(b0 * N)
+                rng.uniform_(unif[i], 1e-20, 1.0)
+                rng.skip((B - b0 - nb) * N)
             rng.store_to_torch()
     if overlap:
         exp.record_stream(cur)
@@ -266,13 +343,8 @@ def draw_noise_device_calls(rng: DeviceTorchRng, n_calls, B, N, V, steps, sample
         exp = torch.zeros(steps, n_calls * nb * N, V, dtype=torch.float32, device=dev)
         unif = torch.empty(steps, n_calls * nb, N, dtype=torch.float32, device=dev)
         rng.load_from_torch()
-        for c in range(n_calls):
-            for i in range(steps):
-                if (i / steps) <= sample_cutoff:
-                    rng.exponential_block_(exp[i, c * nb * N:(c + 1) * nb * N], 2 * b0 * N * V, 2 * B * N * V)
-                rng.skip(b0 * N)
-                rng.uniform_(unif[i, c * nb:(c + 1) * nb], 1e-20, 1.0)
-                rng.skip((B - b0 - nb) * N)
+        draw_units(rng, [(exp[i, c * nb * N:(c + 1) * nb * N] if (i / steps) <= sample_cutoff else None, unif[i, c * nb:(c + 1) * nb])
+                         for c in range(n_calls) for i in range(steps)], B, N, V, b0, nb)
         done = torch.cuda.Event()
         done.record(side)
         rng.store_to_torch()
