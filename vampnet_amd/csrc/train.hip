@@ -209,7 +209,9 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
         if (!t->ax3) A(&s.qkv, 3 * rows * D);
         else {
             // masked rows / keys of a last tile are read as they are (and multiplied by P = 0): they must be finite, so start from zeros
-            const size_t nqk = (size_t)3 * t->qk_plane + 32 * VN_DHEAD, nvt = (size_t)3 * t->vt_plane;
+            // (+ 4096 elements of slack each: the kernels' last tiles read whole 4 KiB pieces whatever T is, all inside the 32-row pad by
+            // construction — the slack keeps an allocation's last piece off the edge of its mapping regardless)
+            const size_t nqk = (size_t)3 * t->qk_plane + 32 * VN_DHEAD + 4096, nvt = (size_t)3 * t->vt_plane + 4096;
             if (rc == VN_OK) rc = talloc(ctx, &s.qk16, nqk);
             if (rc == VN_OK) rc = talloc(ctx, &s.vt16, nvt);
             if (rc == VN_OK && (hipMemset(s.qk16, 0, nqk * 2) != hipSuccess || hipMemset(s.vt16, 0, nvt * 2) != hipSuccess)) rc = VN_ERR_HIP;
@@ -243,8 +245,8 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
     if (t->ax3) {
         vn_ax_bwd_ws w;
         vn_attention_x3_bwd_ws_layout(d.max_batch, m->H, d.max_T, &w);
-        if (rc == VN_OK) rc = talloc(ctx, &t->ax_ws, (size_t)w.total);
-        if (rc == VN_OK && hipMemset(t->ax_ws, 0, (size_t)w.total * 2) != hipSuccess) rc = VN_ERR_HIP;
+        if (rc == VN_OK) rc = talloc(ctx, &t->ax_ws, (size_t)w.total + 4096);
+        if (rc == VN_OK && hipMemset(t->ax_ws, 0, ((size_t)w.total + 4096) * 2) != hipSuccess) rc = VN_ERR_HIP;
     }
     if (rc == VN_OK) rc = talloc(ctx, &t->npartial, 1024);
     if (rc == VN_OK) rc = talloc(ctx, &t->t32, (size_t)rows * m->Cp);
@@ -915,16 +917,16 @@ extern "C" int vn_attention_train_bf16x3(vn_ctx* ctx, const float* q, const floa
     int rc = VN_OK;
     if (hipMalloc((void**)&full, (size_t)H * nb * sizeof(float)) != hipSuccess || hipMalloc((void**)&lut_d, (size_t)nb * sizeof(int32_t)) != hipSuccess ||
         hipMalloc((void**)&delta, (size_t)heads * T * sizeof(float)) != hipSuccess || hipMalloc((void**)&part, (size_t)slab * sizeof(float)) != hipSuccess ||
-        hipMalloc((void**)&qk16, ((size_t)3 * plane_qk + 32 * VN_DHEAD) * 2) != hipSuccess || hipMalloc((void**)&vt16, (size_t)3 * plane_vt * 2) != hipSuccess ||
-        hipMalloc((void**)&ws, (size_t)w.total * 2) != hipSuccess)
+        hipMalloc((void**)&qk16, ((size_t)3 * plane_qk + 32 * VN_DHEAD + 4096) * 2) != hipSuccess ||
+        hipMalloc((void**)&vt16, ((size_t)3 * plane_vt + 4096) * 2) != hipSuccess || hipMalloc((void**)&ws, ((size_t)w.total + 4096) * 2) != hipSuccess)
         rc = vn_fail(ctx, VN_ERR_OOM, "vn_attention_train_bf16x3: scratch allocation failed%s", "");
     std::vector<int32_t> lut(nb);
     vn_bucket_lut_host(T, num_buckets, max_distance, lut.data());
     const int near_r = vn_attention_x3_near_r(lut.data(), T);
     if (rc == VN_OK && hipMemcpy(lut_d, lut.data(), nb * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) rc = VN_ERR_HIP;
-    if (rc == VN_OK && (hipMemsetAsync(vt16, 0, (size_t)3 * plane_vt * 2, s) != hipSuccess ||
-                        hipMemsetAsync(qk16, 0, ((size_t)3 * plane_qk + 32 * VN_DHEAD) * 2, s) != hipSuccess ||
-                        hipMemsetAsync(ws, 0, (size_t)w.total * 2, s) != hipSuccess))
+    if (rc == VN_OK && (hipMemsetAsync(vt16, 0, ((size_t)3 * plane_vt + 4096) * 2, s) != hipSuccess ||
+                        hipMemsetAsync(qk16, 0, ((size_t)3 * plane_qk + 32 * VN_DHEAD + 4096) * 2, s) != hipSuccess ||
+                        hipMemsetAsync(ws, 0, ((size_t)w.total + 4096) * 2, s) != hipSuccess))
         rc = VN_ERR_HIP;
     if (rc == VN_OK) rc = vn_launch_bias_expand(ctx, rel_bias, lut_d, full, H, T, s);
     vn_train_params tp{};
