@@ -241,22 +241,9 @@ int vn_split2_f16(vn_ctx* ctx, const float* src, void* dst16, int64_t rows, int 
 int vn_gemm_f16x2(vn_ctx* ctx, const void* A2, int64_t a_plane, const void* W2, int64_t w_plane, const float* bias,
                   float* C, int M, int N, int K, int epilogue, void* stream);
 
-/* The same op in the bf16x3 precision (attention_x3.hip: both products as six bf16-MFMA products of exact three-way operand
- * splits, fp32 softmax): same arguments and output as vn_attention_f32.                                                  */
-int vn_attention_bf16x3(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
-                        float* out, int B, int H, int T, int num_buckets, int max_distance, void* stream);
-/* ... and in the f16x2 precision: q / 8, k and 16 v as fp16 two-plane splits (h0 = fp16(x), h1 = fp16(x - h0)), the softmax weights
- * (times 16) split the same way in registers, THREE fp16-MFMA products per step into the one accumulator (attention_x3.hip, NP = 2). */
-int vn_attention_f16x2(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
-                       float* out, int B, int H, int T, int num_buckets, int max_distance, void* stream);
-
-/* Self-attention core (transformer.py:229-254): q,k,v dev f32 [B][H][T][64];
- * rel_bias dev f32 [num_buckets][H]; out dev f32 [B][T][H*64].                                */
-int vn_attention_f32(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
-                     float* out, int B, int H, int T, int num_buckets, int max_distance, void* stream);
-/* fast-mode variant: bf16 MFMA products, fp32 softmax; out16 = bf16 [B][T][H*64] (NOT bit-exact)                      */
-int vn_attention_bf16(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
-                      void* out16, int B, int H, int T, int num_buckets, int max_distance, void* stream);
+/* The self-attention core as a SINGLE OP (fp32 q, k, v in, scratch allocated and freed inside, synchronous) is a test entry, not
+ * part of the boundary: vn_attention_f32 / _bf16 / _bf16x3 / _f16x2 and the training pair live in vampnet_hip_debug.h.  The path
+ * itself runs attention inside vn_forward / vn_generate / vn_train_* on the workspace of vn_model_create / vn_train_create.  */
 
 /* ---- DAC codec layers (Interface.encode / Interface.decode; PARITY UNPINNED: the codec source
  * `lac` is not part of the reference tree) -------------------------------------------------------------------
@@ -469,18 +456,6 @@ int  vn_model_apply_lora(vn_model* m, const float* base_blob, const float* lora,
 int  vn_dropout_keep_mask(vn_ctx* ctx, uint64_t seed, int64_t step, int layer, int site, float p, int64_t row0,
                           int64_t rows, int cols, uint8_t* out, void* stream);
 
-/* Training attention as a single op (tests / tuning): forward with probability dropout (keep-mask = site 0, layer 0,
- * step 1 of vn_dropout_keep_mask) writing out [B][T][H*64] and lse [B][H][T]; when `dout` is non-NULL also the backward:
- * dqkv [B*T][3*H*64] (dq | dk | dv, head-major inside each third) and dbias [num_buckets][H] ACCUMULATED into (fixed order).
- * Synchronous.  (transformer.py:234-254 and its autograd.)                                                          */
-int  vn_attention_train_f32(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
-                            float* out, float* lse, const float* dout, float* dqkv, float* dbias, int B, int H, int T,
-                            int num_buckets, int max_distance, float dropout, uint64_t seed, void* stream);
-/* The same op on the split-plane pipe (what the training step runs when its GEMMs do: six bf16-MFMA products of exact three-way
- * operand splits per product; the same dropout stream and the same deterministic bias gradient).                         */
-int  vn_attention_train_bf16x3(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
-                               float* out, float* lse, const float* dout, float* dqkv, float* dbias, int B, int H, int T,
-                               int num_buckets, int max_distance, float dropout, uint64_t seed, void* stream);
 /* Pure host query (no GPU needed): the relative-position bucket LUT the attention kernels index with key - query + T - 1
  * (lut_out[2 T - 1] or NULL; transformer.py:123-170) and *near_r = the half-width of the per-wave bias-gradient tables of the
  * split-plane backward: every 32 x 32 wave tile whose offsets do NOT all fall into one bucket lies within +- near_r of the diagonal. */

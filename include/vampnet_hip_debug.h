@@ -43,6 +43,59 @@ int vn_debug_attention_x3_time(vn_ctx* ctx, const float* q, const float* k, cons
  * context's default); trace_dev = uint32 [blocks][8] per-block phase-cycle sums + entry / exit time of the shared-tile kernel (NULL = none)          */
 int vn_debug_attention_x3_config(vn_ctx* ctx, int split, int lds_bytes, int stagger, void* trace_dev);
 
+
+/* ---- single-op test entries that ALLOCATE AND SYNCHRONISE (moved here in round 6: the boundary header promises "no allocation
+ * after *_create, nothing synchronises the device") ---------------------------------------------------------------------------
+ * Each call allocates its scratch (expanded bias table, operand planes, backward workspace) with the library's allocator, runs the
+ * op and waits for it (hipStreamSynchronize), frees the scratch.  For parity tests and tuning only.                               */
+/* The same op in the bf16x3 precision (attention_x3.hip: both products as six bf16-MFMA products of exact three-way operand
+ * splits, fp32 softmax): same arguments and output as vn_attention_f32.                                                  */
+int vn_attention_bf16x3(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                        float* out, int B, int H, int T, int num_buckets, int max_distance, void* stream);
+/* ... and in the f16x2 precision: q / 8, k and 16 v as fp16 two-plane splits (h0 = fp16(x), h1 = fp16(x - h0)), the softmax weights
+ * (times 16) split the same way in registers, THREE fp16-MFMA products per step into the one accumulator (attention_x3.hip, NP = 2). */
+int vn_attention_f16x2(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                       float* out, int B, int H, int T, int num_buckets, int max_distance, void* stream);
+
+/* Self-attention core (transformer.py:229-254): q,k,v dev f32 [B][H][T][64];
+ * rel_bias dev f32 [num_buckets][H]; out dev f32 [B][T][H*64].                                */
+int vn_attention_f32(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                     float* out, int B, int H, int T, int num_buckets, int max_distance, void* stream);
+/* fast-mode variant: bf16 MFMA products, fp32 softmax; out16 = bf16 [B][T][H*64] (NOT bit-exact)                      */
+int vn_attention_bf16(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                      void* out16, int B, int H, int T, int num_buckets, int max_distance, void* stream);
+
+/* Training attention as a single op (tests / tuning): forward with probability dropout (keep-mask = site 0, layer 0,
+ * step 1 of vn_dropout_keep_mask) writing out [B][T][H*64] and lse [B][H][T]; when `dout` is non-NULL also the backward:
+ * dqkv [B*T][3*H*64] (dq | dk | dv, head-major inside each third) and dbias [num_buckets][H] ACCUMULATED into (fixed order).
+ * Synchronous.  (transformer.py:234-254 and its autograd.)                                                          */
+int  vn_attention_train_f32(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                            float* out, float* lse, const float* dout, float* dqkv, float* dbias, int B, int H, int T,
+                            int num_buckets, int max_distance, float dropout, uint64_t seed, void* stream);
+/* The same op on the split-plane pipe (what the training step runs when its GEMMs do: six bf16-MFMA products of exact three-way
+ * operand splits per product; the same dropout stream and the same deterministic bias gradient).                         */
+int  vn_attention_train_bf16x3(vn_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_bias,
+                               float* out, float* lse, const float* dout, float* dqkv, float* dbias, int B, int H, int T,
+                               int num_buckets, int max_distance, float dropout, uint64_t seed, void* stream);
+
+/* ---- guard-page harness (csrc/devmem.hip; tests/test_gpu_guard.py) -------------------------------------------------------------
+ * Every device allocation of the library goes through one allocator.  In guard mode a buffer is its own virtual-memory reservation
+ * whose mapped pages are flanked by UNMAPPED granules: mode 1 ("end") puts the buffer's last 16-byte unit against the unmapped
+ * granule behind it, mode 2 ("start") its first byte on the first byte of its first page.  An access outside the buffer is then a
+ * GPU memory fault that ends the process, instead of a silent read of a neighbour.  VN_GUARD_ALLOC=end|start sets the mode at the
+ * first allocation; vn_guard_mode sets it explicitly (0 = plain hipMalloc).  The modes hold for allocations made afterwards. */
+int  vn_guard_mode(int mode);
+/* returns the current mode; allocations = guard blocks ever made, live = mapped now (count and bytes incl. granule rounding)      */
+int  vn_guard_stats(int64_t* allocations, int64_t* live, int64_t* live_bytes);
+int  vn_guard_alloc(int64_t bytes, int mode, void** out);
+int  vn_guard_free(void* p);
+/* the harness's own known-answer test: one lane reads (write = 0, into *sink) or writes the 32-bit word at p + offset_bytes and the
+ * call waits for it.  Past the end of a mode-1 block this must kill the process.                                                  */
+int  vn_guard_poke(void* p, int64_t offset_bytes, int write, void* sink, void* stream);
+/* the same allocator in torch.cuda.memory.CUDAPluggableAllocator's signature: every torch tensor of the process a guard block      */
+void *vn_guard_torch_alloc(long size, int device, void* stream);
+void vn_guard_torch_free(void* p, long size, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

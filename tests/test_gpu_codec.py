@@ -367,12 +367,13 @@ def test_preprocess_on_the_device_equals_the_host_twin(eng):
     y = torch.empty(B, Tn, device="cuda")
     lufs = torch.empty(B, device="cuda")
     kw = codec._kw_cache
-    eng.check(eng.lib.vn_preprocess_f32(eng.handle, mono.cuda().contiguous().data_ptr(), y.data_ptr(), B, Tn, Tn, sr, -24.0, kw[0], kw[1],
+    mono_d = mono.cuda().contiguous()      # a temporary here is a use after free: its block is released before the call is even made
+    eng.check(eng.lib.vn_preprocess_f32(eng.handle, mono_d.data_ptr(), y.data_ptr(), B, Tn, Tn, sr, -24.0, kw[0], kw[1],
                                         ws.data_ptr(), lufs.data_ptr(), eng.stream()), "vn_preprocess_f32")
     want = [integrated_loudness(mono[b:b + 1].numpy(), sr) for b in range(B)]
     print("LUFS device", lufs.cpu().tolist(), "host", want)
     assert max(abs(a - b) for a, b in zip(lufs.cpu().tolist(), want)) <= 2e-5          # fp32 output of a float64 figure
-    assert eng.lib.vn_preprocess_f32(eng.handle, mono.cuda().data_ptr(), y.data_ptr(), B, Tn, Tn, 11025, -24.0, kw[0], kw[1], ws.data_ptr(),
+    assert eng.lib.vn_preprocess_f32(eng.handle, mono_d.data_ptr(), y.data_ptr(), B, Tn, Tn, 11025, -24.0, kw[0], kw[1], ws.data_ptr(),
                                      None, eng.stream()) != 0
 
 

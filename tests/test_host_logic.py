@@ -19,7 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # ------------------------------------------------------------------------------------------ C ABI
 def test_library_exports_every_declared_symbol():
     """The shared library loads on a GPU-less host and exports exactly what include/vampnet_hip.h (the boundary) and
-    include/vampnet_hip_debug.h (tuning / test hooks, every one of them per vn_ctx or per vn_model) declare."""
+    include/vampnet_hip_debug.h (tuning / test hooks, every vn_debug_* of them per vn_ctx or per vn_model; the vn_guard_* allocator
+    harness is per PROCESS, as an allocator is) declare."""
     hdr = open(os.path.join(ROOT, "include", "vampnet_hip.h")).read()
     dbg = open(os.path.join(ROOT, "include", "vampnet_hip_debug.h")).read()
     assert not re.search(r"\bvn_debug_\w+\s*\(", hdr), "debug hooks belong in vampnet_hip_debug.h"

@@ -147,6 +147,13 @@ SYMBOLS = {
     "vn_attention_bf16x3": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vn_attention_f16x2": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vn_attention_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "vn_guard_mode": (C.c_int, [C.c_int]),
+    "vn_guard_stats": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "vn_guard_alloc": (C.c_int, [C.c_int64, C.c_int, C.POINTER(_P)]),
+    "vn_guard_free": (C.c_int, [_P]),
+    "vn_guard_poke": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P]),
+    "vn_guard_torch_alloc": (_P, [C.c_long, C.c_int, _P]),
+    "vn_guard_torch_free": (None, [_P, C.c_long, C.c_int, _P]),
 }
 
 _lib = None

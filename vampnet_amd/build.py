@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libvampnet_hip.so")
 SOURCES = ["engine.hip", "gemm_f32.hip", "attention_f32.hip", "elementwise.hip", "sampling.hip", "conv1d_f32.hip",
-           "train.hip", "train_kernels.hip", "attention_train.hip", "torch_rng.hip", "gemm_x3.hip", "attention_x3.hip", "attention_train_x3.hip", "comm.hip", "codec.hip", "codec_plan.hip", "preprocess.hip"]
+           "train.hip", "train_kernels.hip", "attention_train.hip", "torch_rng.hip", "gemm_x3.hip", "attention_x3.hip", "attention_train_x3.hip", "comm.hip", "codec.hip", "codec_plan.hip", "preprocess.hip", "devmem.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
                                                                     const float* __restrict__ bias_full, float* __restrict__ out,
                                                                     uint16_t* __restrict__ out16, long plane16, int B, int H, int T,
                                                                     int stagger, unsigned* __restrict__ trace, float* __restrict__ lse,
-                                                                    vn_drop drop) {
+                                                                    vn_drop drop, unsigned k_bytes, unsigned v_bytes) {
     static_assert(!TRAIN || NP == 3, "the training forward runs on bf16x3 operands");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int AXS = AX_STAGE_FLOATS_NP(NP);          // floats of one stage: NP K plane tiles, then NP V^T plane tiles
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(NW * 64, 3) void vn_attention_x3_kernel(const uint1
     const int krow = 8 * wave + (lane >> 3), vrow = 16 * wave + (lane >> 2);
     const unsigned kvoff = (unsigned)(krow * VN_DHEAD + ((lane & 7) ^ ((krow >> 1) & 7)) * 8) * 2u;      // bytes inside a K tile
     const unsigned vvoff = (unsigned)(vrow * AX_KT + ((lane & 3) ^ ((vrow >> 2) & 3)) * 8) * 2u;         // bytes inside a V^T tile
-    const ax_src src = ax_src_init(k16, vt16, plane_qk, plane_vt, b, h, H, T, m_lo, g_lo, MT);
+    const ax_src src = ax_src_init(k16, vt16, plane_qk, plane_vt, b, h, H, T, m_lo, g_lo, MT, k_bytes, v_bytes);
     auto stage = [&](int buf, int kt) {                       // tile kt -> stage buf
         if (kt >= NT) return;
         float* base = smem + buf * AXS + wave * 256;
@@ -319,7 +319,8 @@ template <int KS, int NP = 3>
 __global__ __launch_bounds__(KS * 64, 2) void vn_attention_x3_split_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
                                                                           long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
                                                                           const float* __restrict__ bias_full, float* __restrict__ out,
-                                                                          uint16_t* __restrict__ out16, long plane16, int B, int H, int T) {
+                                                                          uint16_t* __restrict__ out16, long plane16, int B, int H, int T,
+                                                                          unsigned k_bytes, unsigned v_bytes) {
     static_assert(KS == 1 || KS == 2 || KS == 4, "the merge hands 8 / KS column groups to every wave");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int AXS = AX_STAGE_FLOATS_NP(NP);
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(KS * 64, 2) void vn_attention_x3_split_kernel(const
     const unsigned kvoff_e = (unsigned)(kr0 * VN_DHEAD + ((lane & 7) ^ ((kr0 >> 1) & 7)) * 8) * 2u;
     const unsigned kvoff_o = (unsigned)(kr0 * VN_DHEAD + ((lane & 7) ^ (((kr0 >> 1) + 4) & 7)) * 8) * 2u;
     const unsigned vvoff = (unsigned)(vr0 * AX_KT + ((lane & 3) ^ ((vr0 >> 2) & 3)) * 8) * 2u;
-    const ax_src src = ax_src_init(k16, vt16, plane_qk, plane_vt, b, h, H, T, m_lo, g_lo, MT);
+    const ax_src src = ax_src_init(k16, vt16, plane_qk, plane_vt, b, h, H, T, m_lo, g_lo, MT, k_bytes, v_bytes);
     float* mine = smem + wave * AXS;
     auto stage_k = [&](int kt) {
 #pragma unroll
@@ -473,7 +474,8 @@ template <int KH, int NP = 3>
 __global__ __launch_bounds__(2 * KH * 64) void vn_attention_x3_pair_kernel(const uint16_t* __restrict__ q16, const uint16_t* __restrict__ k16,
                                                                           long plane_qk, const uint16_t* __restrict__ vt16, long plane_vt,
                                                                           const float* __restrict__ bias_full, float* __restrict__ out,
-                                                                          uint16_t* __restrict__ out16, long plane16, int B, int H, int T) {
+                                                                          uint16_t* __restrict__ out16, long plane16, int B, int H, int T,
+                                                                          unsigned k_bytes, unsigned v_bytes) {
     static_assert(KH == 2 || KH == 4, "two stages per staging wave group, 8 / KH column groups per wave in the merge");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // a key part's LDS: TWO K buffers (tile i in buffer i & 1) and one V^T buffer — the K tile of iteration i + 2 is issued as soon as
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(2 * KH * 64) void vn_attention_x3_pair_kernel(const
     const int krow = 8 * pw + (lane >> 3), vrow = 16 * pw + (lane >> 2);
     const unsigned kvoff = (unsigned)(krow * VN_DHEAD + ((lane & 7) ^ ((krow >> 1) & 7)) * 8) * 2u;
     const unsigned vvoff = (unsigned)(vrow * AX_KT + ((lane & 3) ^ ((vrow >> 2) & 3)) * 8) * 2u;
-    const ax_src src = ax_src_init(k16, vt16, plane_qk, plane_vt, b, h, H, T, m_lo, g_lo, MT);
+    const ax_src src = ax_src_init(k16, vt16, plane_qk, plane_vt, b, h, H, T, m_lo, g_lo, MT, k_bytes, v_bytes);
     const int NH = (NT + KH - 1) / KH;
     auto stage_op = [&](int i, bool v_op) {             // iteration i: tiles sA NH + i and (sA + 1) NH + i (clamped: re-fetch the last tile)
         int kt0 = sA * NH + i, kt1 = (sA + 1) * NH + i;
@@ -686,6 +688,9 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_pair_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->attr_mask |= VN_ATTR_ATTN_X3;
     }
+    if (3 * plane_qk * 2 + AX_K_PAD * 2 >= (1L << 31) || 3 * plane_vt * 2 >= (1L << 31))
+        return vn_fail(ctx, VN_ERR_UNSUPPORTED, "attention_x3: %s%ld elements per plane exceed the 32-bit buffer descriptors", "", plane_qk);
+    const unsigned kb = ax_k_extent(q16, k16, plane_qk), vb = (unsigned)(3 * plane_vt * 2);      // true extents (attention_x3_dev.h)
     const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
     if (ks == 0) {
         // four waves (128 queries) per block, three blocks per CU (LDS: 2 x 24 KiB stages + the bias table)
@@ -695,18 +700,18 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
         const long slots = per_cu * cus;
         const int knobs = (ctx->tune.ax_stagger & 0xffff) | ((long)grid.x > slots && !(ctx->tune.ax_stagger >> 16) ? 0x10000 : 0);
 #define AX_SHARED_GO(TR, NP) hipLaunchKernelGGL((vn_attention_x3_kernel<4, TR, NP>), grid, dim3(256), lds, s, q16, k16, plane_qk, vt16, plane_vt, \
-                                                relbias_full, out, out16, plane16, B, H, T, knobs, TR ? ctx->tune.ax_trace : (unsigned*)nullptr, (float*)nullptr, vn_drop{})
+                                                relbias_full, out, out16, plane16, B, H, T, knobs, TR ? ctx->tune.ax_trace : (unsigned*)nullptr, (float*)nullptr, vn_drop{}, kb, vb)
         if (ctx->tune.ax_trace) { if (np == 3) AX_SHARED_GO(true, 3); else AX_SHARED_GO(true, 2); }
         else { if (np == 3) AX_SHARED_GO(false, 3); else AX_SHARED_GO(false, 2); }
 #undef AX_SHARED_GO
     } else if (ks == 8) {
         const dim3 grid(vn_cdiv(T, 64) * H * B);
-        if (np == 3) hipLaunchKernelGGL((vn_attention_x3_pair_kernel<4, 3>), grid, dim3(512), lds, s, q16, k16, plane_qk, vt16, plane_vt, relbias_full, out, out16, plane16, B, H, T);
-        else hipLaunchKernelGGL((vn_attention_x3_pair_kernel<4, 2>), grid, dim3(512), lds, s, q16, k16, plane_qk, vt16, plane_vt, relbias_full, out, out16, plane16, B, H, T);
+        if (np == 3) hipLaunchKernelGGL((vn_attention_x3_pair_kernel<4, 3>), grid, dim3(512), lds, s, q16, k16, plane_qk, vt16, plane_vt, relbias_full, out, out16, plane16, B, H, T, kb, vb);
+        else hipLaunchKernelGGL((vn_attention_x3_pair_kernel<4, 2>), grid, dim3(512), lds, s, q16, k16, plane_qk, vt16, plane_vt, relbias_full, out, out16, plane16, B, H, T, kb, vb);
     } else {
         const dim3 grid(vn_cdiv(T, 32) * H * B);
 #define AX_SPLIT_GO(KS, NP) hipLaunchKernelGGL((vn_attention_x3_split_kernel<KS, NP>), grid, dim3(KS * 64), lds, s, q16, k16, plane_qk, vt16, \
-                                               plane_vt, relbias_full, out, out16, plane16, B, H, T)
+                                               plane_vt, relbias_full, out, out16, plane16, B, H, T, kb, vb)
         if (np == 3) {
             if (ks == 1) AX_SPLIT_GO(1, 3);
             else if (ks == 2) AX_SPLIT_GO(2, 3);
@@ -734,13 +739,16 @@ int vn_launch_attention_x3_train_fwd(vn_ctx* ctx, const uint16_t* q16, const uin
         VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)(vn_attention_x3_kernel<4, false, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->attr_mask |= VN_ATTR_ATTN_X3_TRAIN;
     }
+    if (3 * plane_qk * 2 + AX_K_PAD * 2 >= (1L << 31) || 3 * plane_vt * 2 >= (1L << 31))
+        return vn_fail(ctx, VN_ERR_UNSUPPORTED, "attention_x3 (training): %s%ld elements per plane exceed the 32-bit buffer descriptors", "", plane_qk);
+    const unsigned kb = ax_k_extent(q16, k16, plane_qk), vb = (unsigned)(3 * plane_vt * 2);
     const int pi = vn_prof_pre(ctx, 1, 4.0 * T * (double)T * VN_DHEAD * H * B, s, 16.0 * T * VN_DHEAD * (double)H * B);
     const int nqbf = T / 128, rq = T - 128 * nqbf;
     const dim3 grid((nqbf + (rq > 0 ? 1 : 0)) * H * B);
     const long per_cu = (long)(160 * 1024 / lds) < 3 ? (long)(160 * 1024 / lds) : 3;
     const int knobs = (long)grid.x > per_cu * cus ? 0x10000 : 0;
     hipLaunchKernelGGL((vn_attention_x3_kernel<4, false, 3, true>), grid, dim3(256), lds, s, q16, k16, plane_qk, vt16, plane_vt, relbias_full, out,
-                       out16, plane16, B, H, T, knobs, (unsigned*)nullptr, lse, d);
+                       out16, plane16, B, H, T, knobs, (unsigned*)nullptr, lse, d, kb, vb);
     vn_prof_post(ctx, pi, s);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;

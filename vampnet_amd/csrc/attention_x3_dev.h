@@ -315,15 +315,19 @@ __device__ __forceinline__ void ax_tile(const float* Ks, const float* Vs, const 
 // LDS-DMA sources as buffer loads: descriptors over the k planes and the V^T planes, byte offsets of this block's tile 0 in plane 0
 // and the plane strides (all uniform -> SGPRs).  Tile 0 of an item starts at global token row 32 g_lo <= b T: for b > 0 that is
 // inside the previous item's rows of the same head-major image, never in front of the k planes (offset >= 0 for every b, h).
+// The descriptors carry the TRUE extents of the two buffers (k_bytes from k16 to the end of the q / k allocation including its
+// 32-row pad, v_bytes = the three V^T planes): a last tile's deliberate over-read of up to 31 rows stays inside the pad the
+// allocation owns (ax_k_extent below), and anything beyond would read 0 instead of faulting (round 6; before, num_records was
+// 0x7fffffff, i.e. the hardware's range check was off).
 struct ax_src {
     __amdgpu_buffer_rsrc_t krs, vrs;
     unsigned k0, v0, kplane, vplane;
 };
 __device__ __forceinline__ ax_src ax_src_init(const uint16_t* k16, const uint16_t* vt16, long plane_qk, long plane_vt, int b, int h, int H,
-                                              int T, int m_lo, int g_lo, int MT) {
+                                              int T, int m_lo, int g_lo, int MT, unsigned k_bytes, unsigned v_bytes) {
     ax_src s;
-    s.krs = __builtin_amdgcn_make_buffer_rsrc((void*)k16, 0, 0x7fffffff, 0x00020000);
-    s.vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vt16, 0, 0x7fffffff, 0x00020000);
+    s.krs = __builtin_amdgcn_make_buffer_rsrc((void*)k16, 0, (int)k_bytes, 0x00020000);
+    s.vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vt16, 0, (int)v_bytes, 0x00020000);
     s.k0 = (unsigned)((((long)b * H + h) * T + (g_lo * AX_KT - m_lo)) * (VN_DHEAD * 2));
     s.v0 = (unsigned)(((long)h * MT + g_lo) * (VN_DHEAD * AX_KT * 2));
     s.kplane = (unsigned)(plane_qk * 2);

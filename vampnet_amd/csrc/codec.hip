@@ -48,7 +48,7 @@ extern "C" int vn_codec_create(vn_ctx* ctx, const vn_codec_op* ops, int n_ops, i
 
 extern "C" void vn_codec_destroy(vn_codec* c) {
     if (!c) return;
-    for (void* p : c->owned) (void)hipFree(p);     // hipFree waits for the device: no launch of this program is in flight afterwards
+    for (void* p : c->owned) (void)vn_dev_free(p);     // hipFree waits for the device: no launch of this program is in flight afterwards
     delete c;
 }
 

@@ -160,7 +160,7 @@ struct Builder {
     template <typename X>
     X* dev(size_t n) {
         void* p = nullptr;
-        if (hipMalloc(&p, n * sizeof(X) + 256) != hipSuccess) { rc = vn_fail(ctx, VN_ERR_OOM, "codec: hipMalloc of %s%ld bytes", "", (long)(n * sizeof(X))); return nullptr; }
+        if (vn_dev_malloc(&p, n * sizeof(X)) != hipSuccess) { rc = vn_fail(ctx, VN_ERR_OOM, "codec: hipMalloc of %s%ld bytes", "", (long)(n * sizeof(X))); return nullptr; }
         owned.push_back(p);
         return (X*)p;
     }
@@ -392,7 +392,7 @@ extern "C" int vn_codec_create_from_weights(vn_ctx* ctx, const vn_codec_cfg* cfg
     bd.ctx = ctx; bd.cfg = cfg; bd.blob = blob_dev; bd.lay = make_layout(cfg); bd.precision = precision;
     auto fail = [&](int rc) {
         (void)hipDeviceSynchronize();
-        for (void* p : bd.owned) (void)hipFree(p);
+        for (void* p : bd.owned) (void)vn_dev_free(p);
         return rc;
     };
     const float* win = bd.T("quantizer.quantizers.0.in_proj.weight");

@@ -219,7 +219,7 @@ static int launch_conv(vn_ctx* ctx, const vn_conv_args& a_in, hipStream_t s) {
 
 static int zero_page(vn_ctx* ctx) {
     if (ctx->zero_page) return VN_OK;
-    VN_HIP_CHECK(ctx, hipMalloc((void**)&ctx->zero_page, 1024));
+    VN_HIP_CHECK(ctx, vn_dev_malloc((void**)&ctx->zero_page, 1024));
     VN_HIP_CHECK(ctx, hipMemset(ctx->zero_page, 0, 1024));
     return VN_OK;
 }

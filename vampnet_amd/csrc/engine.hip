@@ -135,9 +135,9 @@ extern "C" int vn_ctx_create(int device, vn_ctx** out) {
     if (hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->cus <= 0) c->cus = 256;
     if (hipSetDevice(device) != hipSuccess) { delete c; return VN_ERR_HIP; }
     // the saturation ledger of the fp16 plane writers (vn_common.h): sticky words, read + cleared by vn_saturation_flags
-    if (hipMalloc((void**)&c->sat, VN_SAT_WORDS * sizeof(unsigned)) != hipSuccess ||
+    if (vn_dev_malloc((void**)&c->sat, VN_SAT_WORDS * sizeof(unsigned)) != hipSuccess ||
         hipMemset(c->sat, 0, VN_SAT_WORDS * sizeof(unsigned)) != hipSuccess) {
-        (void)hipFree(c->sat);
+        (void)vn_dev_free(c->sat);
         delete c;
         return VN_ERR_OOM;
     }
@@ -166,11 +166,11 @@ static void prof_free(vn_ctx* ctx) {
 extern "C" void vn_ctx_destroy(vn_ctx* ctx) {
     if (!ctx) return;
     prof_free(ctx);
-    (void)hipFree(ctx->sk_slabs);
-    (void)hipFree(ctx->sk_flags);
-    (void)hipFree(ctx->zero_page);
-    (void)hipFree(ctx->x3_ws);
-    (void)hipFree(ctx->sat);
+    (void)vn_dev_free(ctx->sk_slabs);
+    (void)vn_dev_free(ctx->sk_flags);
+    (void)vn_dev_free(ctx->zero_page);
+    (void)vn_dev_free(ctx->x3_ws);
+    (void)vn_dev_free(ctx->sat);
     delete ctx;
 }
 
@@ -223,7 +223,7 @@ extern "C" const char* vn_last_error(const vn_ctx* ctx) { return ctx ? ctx->err 
 template <typename T>
 static int dev_alloc(vn_ctx* ctx, T** p, size_t n) {
     void* q = nullptr;
-    if (hipMalloc(&q, n * sizeof(T) + 256) != hipSuccess) {
+    if (vn_dev_malloc(&q, n * sizeof(T)) != hipSuccess) {
         vn_fail(ctx, VN_ERR_OOM, "hipMalloc of %s%ld bytes failed", "", (long)(n * sizeof(T)));
         return VN_ERR_OOM;
     }
@@ -236,18 +236,18 @@ extern "C" void vn_model_destroy(vn_model* m) {
     if (!m) return;
     graphs_free(m);
     float* fb[] = {m->x, m->y, m->qkv, m->g, m->logits, m->bias_full, m->psel};
-    for (float* p : fb) (void)hipFree(p);
+    for (float* p : fb) (void)vn_dev_free(p);
     int32_t* ib[] = {m->z, m->z_sampled, m->sampled, m->count, m->lut};
-    for (int32_t* p : ib) (void)hipFree(p);
-    (void)hipFree(m->ksched);
-    (void)hipFree(m->y16);
-    (void)hipFree(m->g16);
-    (void)hipFree(m->w_tiled);
-    (void)hipFree(m->w_h2);
-    (void)hipFree(m->qk16);
-    (void)hipFree(m->vt16);
-    (void)hipFree(m->x16);
-    (void)hipFree(m->ssq);
+    for (int32_t* p : ib) (void)vn_dev_free(p);
+    (void)vn_dev_free(m->ksched);
+    (void)vn_dev_free(m->y16);
+    (void)vn_dev_free(m->g16);
+    (void)vn_dev_free(m->w_tiled);
+    (void)vn_dev_free(m->w_h2);
+    (void)vn_dev_free(m->qk16);
+    (void)vn_dev_free(m->vt16);
+    (void)vn_dev_free(m->x16);
+    (void)vn_dev_free(m->ssq);
     delete m;
 }
 
@@ -597,8 +597,8 @@ static int plane_buffers(vn_model* m, bool attention_planes) {
         m->vt_plane = (long)m->H * ((m->max_rows + 31) / 32) * (VN_DHEAD * 32);
         // each buffer on its own null check: a failed second allocation must not leave a half-initialised pair behind
         if (!m->qk16) {
-            if ((rc = dev_alloc(m->ctx, &m->qk16, (size_t)3 * m->qk_plane + 32 * VN_DHEAD))) return rc;
-            VN_HIP_CHECK(m->ctx, hipMemset(m->qk16, 0, ((size_t)3 * m->qk_plane + 32 * VN_DHEAD) * sizeof(uint16_t)));
+            if ((rc = dev_alloc(m->ctx, &m->qk16, ax_qk_elems(3, m->qk_plane)))) return rc;
+            VN_HIP_CHECK(m->ctx, hipMemset(m->qk16, 0, (ax_qk_elems(3, m->qk_plane)) * sizeof(uint16_t)));
         }
         if (!m->vt16) {
             if ((rc = dev_alloc(m->ctx, &m->vt16, (size_t)3 * m->vt_plane))) return rc;
@@ -829,9 +829,9 @@ extern "C" int vn_attention_bf16(vn_ctx* ctx, const float* q, const float* k, co
     float* full = nullptr;
     int32_t* lut_d = nullptr;
     const int n = 2 * T - 1;
-    VN_HIP_CHECK(ctx, hipMalloc((void**)&full, (size_t)H * n * sizeof(float)));
-    if (hipMalloc((void**)&lut_d, (size_t)n * sizeof(int32_t)) != hipSuccess) {
-        (void)hipFree(full);
+    VN_HIP_CHECK(ctx, vn_dev_malloc((void**)&full, (size_t)H * n * sizeof(float)));
+    if (vn_dev_malloc((void**)&lut_d, (size_t)n * sizeof(int32_t)) != hipSuccess) {
+        (void)vn_dev_free(full);
         return vn_fail(ctx, VN_ERR_OOM, "hipMalloc of the bucket table failed%s", "");
     }
     std::vector<int32_t> lut(n);
@@ -841,8 +841,8 @@ extern "C" int vn_attention_bf16(vn_ctx* ctx, const float* q, const float* k, co
     if (rc == VN_OK) rc = vn_launch_bias_expand(ctx, rel_bias, lut_d, full, H, T, s);
     if (rc == VN_OK) rc = vn_launch_attention(ctx, q, k, v, full, nullptr, B, H, T, s, (uint16_t*)out16);
     (void)hipStreamSynchronize(s);
-    (void)hipFree(full);
-    (void)hipFree(lut_d);
+    (void)vn_dev_free(full);
+    (void)vn_dev_free(lut_d);
     return rc;
 }
 
@@ -899,14 +899,14 @@ static int attention_x3_run(vn_ctx* ctx, const float* q, const float* k, const f
     uint16_t *qk16 = nullptr, *vt16 = nullptr;
     const int nb = 2 * T - 1;
     int rc = VN_OK;
-    if (hipMalloc((void**)&full, (size_t)H * nb * sizeof(float)) != hipSuccess || hipMalloc((void**)&lut_d, (size_t)nb * sizeof(int32_t)) != hipSuccess ||
-        hipMalloc((void**)&qk16, ((size_t)3 * plane_qk + 32 * VN_DHEAD) * 2) != hipSuccess || hipMalloc((void**)&vt16, (size_t)3 * plane_vt * 2) != hipSuccess)
+    if (vn_dev_malloc((void**)&full, (size_t)H * nb * sizeof(float)) != hipSuccess || vn_dev_malloc((void**)&lut_d, (size_t)nb * sizeof(int32_t)) != hipSuccess ||
+        vn_dev_malloc((void**)&qk16, ax_qk_elems(3, plane_qk) * 2) != hipSuccess || vn_dev_malloc((void**)&vt16, (size_t)3 * plane_vt * 2) != hipSuccess)
         rc = vn_fail(ctx, VN_ERR_OOM, "attention_bf16x3: scratch allocation failed%s", "");
     std::vector<int32_t> lut(nb);
     vn_bucket_lut_host(T, num_buckets, max_distance, lut.data());
     if (rc == VN_OK && hipMemcpy(lut_d, lut.data(), nb * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) rc = VN_ERR_HIP;
     if (rc == VN_OK && (hipMemsetAsync(vt16, 0, (size_t)3 * plane_vt * 2, s) != hipSuccess ||
-                        hipMemsetAsync(qk16, 0, ((size_t)3 * plane_qk + 32 * VN_DHEAD) * 2, s) != hipSuccess))
+                        hipMemsetAsync(qk16, 0, ax_qk_elems(3, plane_qk) * 2, s) != hipSuccess))
         rc = VN_ERR_HIP;
     if (rc == VN_OK) rc = vn_launch_bias_expand(ctx, rel_bias, lut_d, full, H, T, s);
     if (rc == VN_OK) {
@@ -927,7 +927,7 @@ static int attention_x3_run(vn_ctx* ctx, const float* q, const float* k, const f
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
     (void)hipStreamSynchronize(s);
-    (void)hipFree(full); (void)hipFree(lut_d); (void)hipFree(qk16); (void)hipFree(vt16);
+    (void)vn_dev_free(full); (void)vn_dev_free(lut_d); (void)vn_dev_free(qk16); (void)vn_dev_free(vt16);
     return rc;
 }
 
@@ -988,9 +988,9 @@ extern "C" int vn_attention_f32(vn_ctx* ctx, const float* q, const float* k, con
     float* full = nullptr;
     int32_t* lut_d = nullptr;
     const int n = 2 * T - 1;
-    VN_HIP_CHECK(ctx, hipMalloc((void**)&full, (size_t)H * n * sizeof(float)));
-    if (hipMalloc((void**)&lut_d, (size_t)n * sizeof(int32_t)) != hipSuccess) {
-        (void)hipFree(full);
+    VN_HIP_CHECK(ctx, vn_dev_malloc((void**)&full, (size_t)H * n * sizeof(float)));
+    if (vn_dev_malloc((void**)&lut_d, (size_t)n * sizeof(int32_t)) != hipSuccess) {
+        (void)vn_dev_free(full);
         return vn_fail(ctx, VN_ERR_OOM, "hipMalloc of the bucket table failed%s", "");
     }
     std::vector<int32_t> lut(n);
@@ -1000,7 +1000,7 @@ extern "C" int vn_attention_f32(vn_ctx* ctx, const float* q, const float* k, con
     if (rc == VN_OK) rc = vn_launch_bias_expand(ctx, rel_bias, lut_d, full, H, T, s);
     if (rc == VN_OK) rc = vn_launch_attention(ctx, q, k, v, full, out, B, H, T, s);
     (void)hipStreamSynchronize(s);
-    (void)hipFree(full);
-    (void)hipFree(lut_d);
+    (void)vn_dev_free(full);
+    (void)vn_dev_free(lut_d);
     return rc;
 }

@@ -472,8 +472,8 @@ extern "C" int vn_debug_gemm_config(vn_ctx* ctx, int bm, int bn, int order) {
 // per-context workspace: ctx->sk_flags = [SK_MAX_BLOCKS] flags + [1] error word
 static int sk_workspace(vn_ctx* ctx) {
     if (ctx->sk_slabs) return VN_OK;
-    VN_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sk_slabs, (size_t)SK_MAX_BLOCKS * 128 * 128 * sizeof(float)));
-    VN_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sk_flags, (SK_MAX_BLOCKS + 64) * sizeof(unsigned)));
+    VN_HIP_CHECK(ctx, vn_dev_malloc((void**)&ctx->sk_slabs, (size_t)SK_MAX_BLOCKS * 128 * 128 * sizeof(float)));
+    VN_HIP_CHECK(ctx, vn_dev_malloc((void**)&ctx->sk_flags, (SK_MAX_BLOCKS + 64) * sizeof(unsigned)));
     VN_HIP_CHECK(ctx, hipMemset(ctx->sk_flags, 0, (SK_MAX_BLOCKS + 64) * sizeof(unsigned)));
     return VN_OK;
 }

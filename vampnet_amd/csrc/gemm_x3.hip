@@ -1181,7 +1181,7 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
     if constexpr (EPI == VN_EPI_STORE || EPI == VN_EPI_RESIDUAL) {
         const int ns = done ? 1 : plan.ns;
         if (ns > 1) {
-            if (!ctx->x3_ws) VN_HIP_CHECK(ctx, hipMalloc((void**)&ctx->x3_ws, (size_t)X3_WS_FLOATS * sizeof(float)));
+            if (!ctx->x3_ws) VN_HIP_CHECK(ctx, vn_dev_malloc((void**)&ctx->x3_ws, (size_t)X3_WS_FLOATS * sizeof(float)));
             vn_gemm_args q = a;                       // every split stores its raw image [M][N] into the workspace
             q.C = ctx->x3_ws;
             q.ldc = a.N;
@@ -1438,7 +1438,7 @@ static int conv1d_planes(vn_ctx* ctx, int h2, const void* x16, int64_t x_plane, 
     if (B <= 0 || T_rows <= 0 || C_out <= 0 || taps <= 0 || C_in <= 0) return vn_fail(ctx, VN_ERR_INVALID, "conv1d_bf16x3: empty problem%s", "");
     if ((long)B * T_rows > 0x7fffffffL) return vn_fail(ctx, VN_ERR_INVALID, "conv1d_bf16x3: too many rows%s", "");
     if (!ctx->zero_page) {
-        VN_HIP_CHECK(ctx, hipMalloc((void**)&ctx->zero_page, 1024));
+        VN_HIP_CHECK(ctx, vn_dev_malloc((void**)&ctx->zero_page, 1024));
         VN_HIP_CHECK(ctx, hipMemset(ctx->zero_page, 0, 1024));
     }
     vn_gemm_args a{};

@@ -131,7 +131,7 @@ extern "C" int vn_train_param_offset(const vn_dims* dims, int which, int64_t* of
 template <typename T>
 static int talloc(vn_ctx* ctx, T** p, size_t n) {
     void* q = nullptr;
-    if (hipMalloc(&q, n * sizeof(T) + 256) != hipSuccess) {
+    if (vn_dev_malloc(&q, n * sizeof(T)) != hipSuccess) {
         vn_fail(ctx, VN_ERR_OOM, "hipMalloc of %s%ld bytes failed (training workspace)", "", (long)(n * sizeof(T)));
         return VN_ERR_OOM;
     }
@@ -142,21 +142,21 @@ static int talloc(vn_ctx* ctx, T** p, size_t n) {
 extern "C" void vn_train_destroy(vn_train* t) {
     if (!t) return;
     for (auto& s : t->st) {
-        (void)hipFree(s.qk16); (void)hipFree(s.vt16);
+        (void)vn_dev_free(s.qk16); (void)vn_dev_free(s.vt16);
         float* a[] = {s.x_in, s.y1, s.qkv, s.lse, s.a, s.x_mid, s.y3, s.u, s.g};
-        for (float* p : a) (void)hipFree(p);
+        for (float* p : a) (void)vn_dev_free(p);
     }
     float* b[] = {t->wT, t->x_last, t->y_f, t->tmp, t->dxa, t->dxb, t->dh, t->dg, t->du, t->dy, t->dqkv, t->da, t->At, t->Bt,
                   t->partial, t->row_loss, t->delta, t->scal, t->dbias_partial};
-    for (float* p : b) (void)hipFree(p);
-    (void)hipFree(t->npartial);
-    (void)hipFree(t->t32);
-    (void)hipFree(t->n_valid);
-    (void)hipFree(t->w_base);
-    (void)hipFree(t->h8);
-    (void)hipFree(t->dh8);
+    for (float* p : b) (void)vn_dev_free(p);
+    (void)vn_dev_free(t->npartial);
+    (void)vn_dev_free(t->t32);
+    (void)vn_dev_free(t->n_valid);
+    (void)vn_dev_free(t->w_base);
+    (void)vn_dev_free(t->h8);
+    (void)vn_dev_free(t->dh8);
     uint16_t* c[] = {t->w16, t->wT16, t->a16, t->at16, t->bt16, t->ax_ws};
-    for (uint16_t* p : c) (void)hipFree(p);
+    for (uint16_t* p : c) (void)vn_dev_free(p);
     delete t;
 }
 
@@ -208,10 +208,11 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
         A(&s.x_in, rows * D); A(&s.y1, rows * D); A(&s.lse, (size_t)d.max_batch * m->H * d.max_T);
         if (!t->ax3) A(&s.qkv, 3 * rows * D);
         else {
-            // masked rows / keys of a last tile are read as they are (and multiplied by P = 0): they must be finite, so start from zeros
-            // (+ 4096 elements of slack each: the kernels' last tiles read whole 4 KiB pieces whatever T is, all inside the 32-row pad by
-            // construction — the slack keeps an allocation's last piece off the edge of its mapping regardless)
-            const size_t nqk = (size_t)3 * t->qk_plane + 32 * VN_DHEAD + 4096, nvt = (size_t)3 * t->vt_plane + 4096;
+            // masked rows / keys of a last tile are read as they are (and multiplied by P = 0): they must be finite, so start from zeros.
+            // Exact sizes: the k planes own a 32-row pad (a last key tile reads up to 31 rows past T), the V^T planes are tile-exact;
+            // the kernels' buffer descriptors carry these extents (an access past them would return 0, not fault) and the whole step
+            // runs under guard pages in tests/test_gpu_guard.py
+            const size_t nqk = ax_qk_elems(3, t->qk_plane), nvt = (size_t)3 * t->vt_plane;
             if (rc == VN_OK) rc = talloc(ctx, &s.qk16, nqk);
             if (rc == VN_OK) rc = talloc(ctx, &s.vt16, nvt);
             if (rc == VN_OK && (hipMemset(s.qk16, 0, nqk * 2) != hipSuccess || hipMemset(s.vt16, 0, nvt * 2) != hipSuccess)) rc = VN_ERR_HIP;
@@ -245,8 +246,8 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
     if (t->ax3) {
         vn_ax_bwd_ws w;
         vn_attention_x3_bwd_ws_layout(d.max_batch, m->H, d.max_T, &w);
-        if (rc == VN_OK) rc = talloc(ctx, &t->ax_ws, (size_t)w.total + 4096);
-        if (rc == VN_OK && hipMemset(t->ax_ws, 0, ((size_t)w.total + 4096) * 2) != hipSuccess) rc = VN_ERR_HIP;
+        if (rc == VN_OK) rc = talloc(ctx, &t->ax_ws, (size_t)w.total);
+        if (rc == VN_OK && hipMemset(t->ax_ws, 0, (size_t)w.total * 2) != hipSuccess) rc = VN_ERR_HIP;
     }
     if (rc == VN_OK) rc = talloc(ctx, &t->npartial, 1024);
     if (rc == VN_OK) rc = talloc(ctx, &t->t32, (size_t)rows * m->Cp);
@@ -860,9 +861,9 @@ extern "C" int vn_attention_train_f32(vn_ctx* ctx, const float* q, const float* 
     int32_t* lut_d = nullptr;
     const int n = 2 * T - 1;
     int rc = VN_OK;
-    if (hipMalloc((void**)&full, (size_t)H * n * sizeof(float)) != hipSuccess ||
-        hipMalloc((void**)&lut_d, (size_t)n * sizeof(int32_t)) != hipSuccess ||
-        hipMalloc((void**)&delta, (size_t)B * H * T * sizeof(float)) != hipSuccess)
+    if (vn_dev_malloc((void**)&full, (size_t)H * n * sizeof(float)) != hipSuccess ||
+        vn_dev_malloc((void**)&lut_d, (size_t)n * sizeof(int32_t)) != hipSuccess ||
+        vn_dev_malloc((void**)&delta, (size_t)B * H * T * sizeof(float)) != hipSuccess)
         rc = vn_fail(ctx, VN_ERR_OOM, "vn_attention_train_f32: scratch allocation failed%s", "");
     std::vector<int32_t> lut(n);
     vn_bucket_lut_host(T, num_buckets, max_distance, lut.data());
@@ -874,15 +875,15 @@ extern "C" int vn_attention_train_f32(vn_ctx* ctx, const float* q, const float* 
     if (rc == VN_OK) rc = vn_launch_attention_train_fwd(ctx, q, k, v, full, out, lse, B, H, T, d, s);
     float* part = nullptr;
     const long slab = (long)B * H * vn_cdiv(T, 64) * 64;
-    if (rc == VN_OK && dout && hipMalloc((void**)&part, (size_t)slab * sizeof(float)) != hipSuccess) rc = VN_ERR_OOM;
+    if (rc == VN_OK && dout && vn_dev_malloc((void**)&part, (size_t)slab * sizeof(float)) != hipSuccess) rc = VN_ERR_OOM;
     if (rc == VN_OK && dout)
         rc = vn_launch_attention_bwd(ctx, q, k, v, full, lut_d, out, dout, lse, delta, dqkv, part, B, H, T, num_buckets, d, s);
     if (rc == VN_OK && dout) rc = vn_launch_dbias_reduce(ctx, part, dbias, 1, slab, B, H, vn_cdiv(T, 64), num_buckets, true, s);
     (void)hipStreamSynchronize(s);
-    (void)hipFree(full);
-    (void)hipFree(lut_d);
-    (void)hipFree(delta);
-    (void)hipFree(part);
+    (void)vn_dev_free(full);
+    (void)vn_dev_free(lut_d);
+    (void)vn_dev_free(delta);
+    (void)vn_dev_free(part);
     return rc;
 }
 
@@ -915,18 +916,18 @@ extern "C" int vn_attention_train_bf16x3(vn_ctx* ctx, const float* q, const floa
     vn_attention_x3_bwd_ws_layout(B, H, T, &w);
     const long slab = heads * vn_cdiv(T, 128) * 64;
     int rc = VN_OK;
-    if (hipMalloc((void**)&full, (size_t)H * nb * sizeof(float)) != hipSuccess || hipMalloc((void**)&lut_d, (size_t)nb * sizeof(int32_t)) != hipSuccess ||
-        hipMalloc((void**)&delta, (size_t)heads * T * sizeof(float)) != hipSuccess || hipMalloc((void**)&part, (size_t)slab * sizeof(float)) != hipSuccess ||
-        hipMalloc((void**)&qk16, ((size_t)3 * plane_qk + 32 * VN_DHEAD + 4096) * 2) != hipSuccess ||
-        hipMalloc((void**)&vt16, ((size_t)3 * plane_vt + 4096) * 2) != hipSuccess || hipMalloc((void**)&ws, ((size_t)w.total + 4096) * 2) != hipSuccess)
+    if (vn_dev_malloc((void**)&full, (size_t)H * nb * sizeof(float)) != hipSuccess || vn_dev_malloc((void**)&lut_d, (size_t)nb * sizeof(int32_t)) != hipSuccess ||
+        vn_dev_malloc((void**)&delta, (size_t)heads * T * sizeof(float)) != hipSuccess || vn_dev_malloc((void**)&part, (size_t)slab * sizeof(float)) != hipSuccess ||
+        vn_dev_malloc((void**)&qk16, ax_qk_elems(3, plane_qk) * 2) != hipSuccess ||
+        vn_dev_malloc((void**)&vt16, (size_t)3 * plane_vt * 2) != hipSuccess || vn_dev_malloc((void**)&ws, (size_t)w.total * 2) != hipSuccess)
         rc = vn_fail(ctx, VN_ERR_OOM, "vn_attention_train_bf16x3: scratch allocation failed%s", "");
     std::vector<int32_t> lut(nb);
     vn_bucket_lut_host(T, num_buckets, max_distance, lut.data());
     const int near_r = vn_attention_x3_near_r(lut.data(), T);
     if (rc == VN_OK && hipMemcpy(lut_d, lut.data(), nb * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) rc = VN_ERR_HIP;
-    if (rc == VN_OK && (hipMemsetAsync(vt16, 0, ((size_t)3 * plane_vt + 4096) * 2, s) != hipSuccess ||
-                        hipMemsetAsync(qk16, 0, ((size_t)3 * plane_qk + 32 * VN_DHEAD + 4096) * 2, s) != hipSuccess ||
-                        hipMemsetAsync(ws, 0, ((size_t)w.total + 4096) * 2, s) != hipSuccess))
+    if (rc == VN_OK && (hipMemsetAsync(vt16, 0, (size_t)3 * plane_vt * 2, s) != hipSuccess ||
+                        hipMemsetAsync(qk16, 0, ax_qk_elems(3, plane_qk) * 2, s) != hipSuccess ||
+                        hipMemsetAsync(ws, 0, (size_t)w.total * 2, s) != hipSuccess))
         rc = VN_ERR_HIP;
     if (rc == VN_OK) rc = vn_launch_bias_expand(ctx, rel_bias, lut_d, full, H, T, s);
     vn_train_params tp{};
@@ -939,6 +940,6 @@ extern "C" int vn_attention_train_bf16x3(vn_ctx* ctx, const float* q, const floa
                                         num_buckets, d, s);
     if (rc == VN_OK && dout) rc = vn_launch_dbias_reduce(ctx, part, dbias, 1, slab, B, H, vn_cdiv(T, 128), num_buckets, true, s);
     (void)hipStreamSynchronize(s);
-    (void)hipFree(full); (void)hipFree(lut_d); (void)hipFree(delta); (void)hipFree(part); (void)hipFree(qk16); (void)hipFree(vt16); (void)hipFree(ws);
+    (void)vn_dev_free(full); (void)vn_dev_free(lut_d); (void)vn_dev_free(delta); (void)vn_dev_free(part); (void)vn_dev_free(qk16); (void)vn_dev_free(vt16); (void)vn_dev_free(ws);
     return rc;
 }

@@ -543,6 +543,18 @@ int vn_launch_attention_x3(vn_ctx* ctx, const uint16_t* q16, const uint16_t* k16
 // decomposition it will use (0 = shared 128-query tiles, KS = key-split waves per 32-query block) and the dynamic LDS that needs
 int vn_attention_x3_plan(const vn_ctx* ctx, int B, int H, int T, int cus);
 size_t vn_attention_x3_lds_bytes(int T, int key_split, int np);
+// The q / k planes of a call: [planes][q: n | k: n | rest of the plane stride] + AX_K_PAD elements behind the last plane — every
+// allocation of them is made with ax_qk_elems() (engine.hip, train.hip), and the kernels' descriptors are derived from the same two
+// numbers, so the pad a last key tile over-reads into is owned by the buffer by construction.
+#define AX_K_PAD (32 * VN_DHEAD)
+static inline size_t ax_qk_elems(int planes, long plane_qk) { return (size_t)planes * (size_t)plane_qk + AX_K_PAD; }
+// bytes from k16 (= q16 + n) to the end of that allocation; planes = 3 (the f16x2 format's two planes live in a three-plane buffer)
+static inline unsigned ax_k_extent(const uint16_t* q16, const uint16_t* k16, long plane_qk) {
+    return (unsigned)((ax_qk_elems(3, plane_qk) - (size_t)(k16 - q16)) * 2);
+}
+// every device allocation of the library (devmem.hip): plain hipMalloc / hipFree, or guard blocks when VN_GUARD_ALLOC / vn_debug_guard_mode say so
+hipError_t vn_dev_malloc(void** p, size_t bytes);
+void vn_dev_free(void* p);
 static inline int vn_num_cus(const vn_ctx* ctx) { return ctx->cus > 0 ? ctx->cus : 256; }
 // expands [num_buckets][H] into per-head tables over rel = key - query in [-(T-1), T-1]: out[h][rel + T - 1]
 void vn_bucket_lut_host(int T, int num_buckets, int max_distance, int32_t* lut /* [2T-1] */);

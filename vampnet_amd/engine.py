@@ -222,7 +222,8 @@ class Engine:
         B, H, T, dh = q.shape
         out = torch.empty(B, T, H * dh, device=q.device, dtype=torch.float32)
         fn = {"f32": self.lib.vn_attention_f32, "bf16x3": self.lib.vn_attention_bf16x3, "f16x2": self.lib.vn_attention_f16x2}[precision]
-        self.check(fn(self.handle, q.contiguous().data_ptr(), k.contiguous().data_ptr(), v.contiguous().data_ptr(),
+        q, k, v, rel_bias = (t.contiguous() for t in (q, k, v, rel_bias))    # held in locals: a temporary's block is gone before the call runs
+        self.check(fn(self.handle, q.data_ptr(), k.data_ptr(), v.data_ptr(),
                       rel_bias.data_ptr(), out.data_ptr(), B, H, T, num_buckets, max_distance, self.stream()),
                    "vn_attention_" + precision)
         return out
