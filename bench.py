@@ -45,6 +45,96 @@ def _host_facts():
     return {"os_cpu_count": os.cpu_count(), "cpu_model": model}
 
 
+def _gemm_source_sha():
+    """sha256 of csrc/gemm_x3.hip: the committed PMC traffic figure is only quoted for the kernel revision it was captured on"""
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, "vampnet_amd", "csrc", "gemm_x3.hip"), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def _numa_bind(dev_index):
+    """Pin this rank's host threads to the CPUs of its GPU's NUMA node (PCI bus id -> /sys/bus/pci/devices/<bdf>/numa_node ->
+    /sys/devices/system/node/nodeN/cpulist): the launch thread of rank r then does not wander over the other socket while it feeds
+    GPU r.  Returns what was done (goes into devices.numa_binding of the JSON line); never raises."""
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read().strip())
+        if node < 0:
+            return {"device": dev_index, "pci": bdf, "numa_node": None, "bound": False, "why": "the platform reports no NUMA node for the device"}
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = cpus & os.sched_getaffinity(0)
+        if not allowed:
+            return {"device": dev_index, "pci": bdf, "numa_node": node, "bound": False, "why": "no CPU of that node is in this process's affinity mask"}
+        os.sched_setaffinity(0, allowed)
+        return {"device": dev_index, "pci": bdf, "numa_node": node, "bound": True, "cpus": len(allowed)}
+    except Exception as e:                                   # no sysfs, no attribute, no permission: run unbound
+        return {"device": dev_index, "numa_node": None, "bound": False, "why": f"{type(e).__name__}: {e}"}
+
+
+def _with_deadline(what, seconds, fn, rank=0):
+    """run fn(); if it has not returned after `seconds`, say what hung and end the process (a collective that cannot complete —
+    one rank missing, a wrong interface, a dead link — otherwise blocks inside RCCL for ever and the driver learns nothing)"""
+    import threading
+    done = threading.Event()
+
+    def dog():
+        if not done.wait(seconds):
+            sys.stderr.write(f"bench.py rank {rank}: {what} did not finish within {seconds:.0f} s — check that all ranks started "
+                             f"(WORLD_SIZE={os.environ.get('WORLD_SIZE')}), MASTER_ADDR/PORT={os.environ.get('MASTER_ADDR')}:"
+                             f"{os.environ.get('MASTER_PORT')}, HSA_ENABLE_IPC_MODE_LEGACY=0, and NCCL_DEBUG=INFO for RCCL's own account\n")
+            sys.stderr.flush()
+            os._exit(3)
+    threading.Thread(target=dog, daemon=True).start()
+    try:
+        return fn()
+    finally:
+        done.set()
+
+
+def _rccl_preflight(itf, device, world, rank):
+    """What RCCL itself says before anything is timed: ncclCommCount / ncclCommUserRank of a communicator of the library (the one the
+    "c_abi" exchange uses, or a throw-away one when the exchange goes through torch.distributed — torch does not expose its own) and
+    one all-gather of the rank ids through the exchange that will be used, counted.  All under a deadline."""
+    import ctypes as C
+    import torch.distributed as dist
+    out = {}
+
+    def count():
+        comm, own = getattr(itf, "_comm", None), False
+        if comm is None:
+            comm, own = itf._make_comm(), True
+        n, r = C.c_int(-1), C.c_int(-1)
+        itf.engine.check(itf.engine.lib.vn_comm_count(comm, C.byref(n), C.byref(r)), "vn_comm_count")
+        probe = torch.full((4,), rank, dtype=torch.int64, device=device)
+        got = torch.empty(4 * world, dtype=torch.int64, device=device)
+        itf.engine.check(itf.engine.lib.vn_allgather_tokens(comm, probe.data_ptr(), got.data_ptr(), 4, itf.engine.stream()), "vn_allgather_tokens")
+        torch.cuda.synchronize()
+        if own:
+            itf.engine.lib.vn_comm_destroy(comm)
+        return n.value, r.value, sorted(set(got.cpu().tolist()))
+    n, r, seen = _with_deadline("creating the library's RCCL communicator (vn_comm_create) + first all-gather", 180, count, rank)
+    out["rccl_nranks"] = n                                    # ncclCommCount
+    out["rccl_user_rank"] = r
+    out["c_abi_allgather_ranks_seen"] = len(seen)
+
+    def torch_gather():
+        got = torch.empty(world, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(got, torch.tensor([rank], dtype=torch.int64, device=device))
+        torch.cuda.synchronize()
+        return len(set(got.cpu().tolist()))
+    out["torch_allgather_ranks_seen"] = _with_deadline("torch.distributed all_gather_into_tensor on the nccl (= RCCL) group", 180, torch_gather, rank)
+    ok = n == world and out["c_abi_allgather_ranks_seen"] == world and out["torch_allgather_ranks_seen"] == world
+    if not ok:
+        raise SystemExit(f"bench.py rank {rank}: RCCL preflight failed: {out} for WORLD_SIZE={world}")
+    return out
+
+
 def _ref_models():
     """The reference's OWN modules (vampnet.modules.transformer.VampNet + vampnet.interface.Interface through the import shim),
     when /root/reference is mounted (this container; never on the GPU box) -> callable(z, mask) running Interface.vamp."""
@@ -63,7 +153,7 @@ def _ref_models():
         return None
 
 
-def cpu_baseline(threads=None, coarse_only=False):
+def cpu_baseline(threads=None, coarse_only=False, b8=True):
     """The CPU path timed on the host cores over ONE WHOLE 10 s clip (12 coarse steps + 4 x 2 c2f steps, B = 1; coarse_only:
     the 12 coarse steps of configs[1]) after a one-step warm-up of each model.  kind = "reference": the reference's own
     modules through oracle/ref_shim.py (only where /root/reference is mounted); kind = "port": the oracle, a port of the
@@ -99,7 +189,8 @@ def cpu_baseline(threads=None, coarse_only=False):
             best = min(best, (dt, n))
         torch.set_num_threads(best[1])
     cores = torch.get_num_threads()
-    ref = None if coarse_only else _ref_models()       # the coarse-only line is timed through the port in every environment
+    # the coarse-only line is timed through the port in every environment; VN_BENCH_CPU_KIND=port forces the port where the reference is mounted
+    ref = None if coarse_only or os.environ.get("VN_BENCH_CPU_KIND") == "port" else _ref_models()
     kind = "reference" if ref is not None else "port"
     models = O.OracleModels(csd, W.COARSE_DIMS, fsd, W.C2F_DIMS, cb)
     warm()
@@ -115,10 +206,43 @@ def cpu_baseline(threads=None, coarse_only=False):
         tokens = TOKENS_PER_CLIP
     clip_s = time.perf_counter() - t0
     what = "12 coarse steps (B=1, T=575)" if coarse_only else "12 coarse steps (T=575) + 4 chunks x 2 c2f steps (T=173), B=1"
-    return {"value": tokens / clip_s, "unit": "codec-tokens/s", "cores": cores, "kind": kind,
-            "sample": f"one whole clip, not extrapolated: {what} = {clip_s:.2f} s after a 1-step warm-up of each model; "
-                      f"torch {torch.__version__} CPU fp32, {cores} threads (coarse-step probe, s per step: {probe})",
-            **_host_facts()}
+    res = {"value": tokens / clip_s, "unit": "codec-tokens/s", "cores": cores, "kind": kind,
+           "sample": f"one whole clip, not extrapolated: {what} = {clip_s:.2f} s after a 1-step warm-up of each model; "
+                     f"torch {torch.__version__} CPU fp32, {cores} threads (coarse-step probe, s per step: {probe})",
+           # like-for-like notes: the GPU line is B = 8, so `batch8` below times the same batch on the host; and the port
+           # does not EXECUTE typical_filter (the reference computes the filter and discards its result, transformer.py:989-993: ~6 % of
+           # the reference's own wall on 8 threads) — so kind "port" flatters the CPU; the calibration against the reference's own
+           # Python, run in the build container (8 threads, no GPU box ever holds /root/reference), is profiles/r06_cpu_reference_in_container.json
+           "port_skips": None if kind == "reference" else "typical_filter (executed and discarded by the reference): the port is the FASTER of the two",
+           "calibration": "profiles/r06_cpu_reference_in_container.json (kind = reference, this repository's build container)",
+           **_host_facts()}
+    if not coarse_only and b8:
+        # B = 8 on the host, bounded: one coarse sampling step (T = 575) and one c2f sampling step over the 4 x 8 chunks of the batch
+        # (T = 173, B = 32 — how the reference's loop would batch them at best), at the thread counts of the probe; a clip costs 12 of
+        # the first and 2 of the second: tokens/s = 8 clips x 8050 tokens / (12 t_coarse + 2 t_c2f)
+        z8 = W.synth_codes(8, 14, 575, seed=2)
+        mask8 = O.build_mask(z8)
+        zc = torch.cat([z8[:, :, i * 173:(i + 1) * 173] for i in range(3)] + [torch.nn.functional.pad(z8[:, :, 519:], (0, 117))])
+        mc = torch.ones(32, 14, 173, dtype=torch.long)
+        mc[:, :4] = 0
+        sweep = []
+        for n in sorted({min(os.cpu_count() or 8, c) for c in (16, 32)}):
+            torch.set_num_threads(n)
+            t0 = time.perf_counter()
+            O.generate(csd, W.COARSE_DIMS, cb, z8[:, :4], mask8[:, :4], sampling_steps=1, seed=0)
+            tc = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            O.generate(fsd, W.C2F_DIMS, cb, zc, mc, sampling_steps=1, seed=0)
+            tf = time.perf_counter() - t0
+            sweep.append({"threads": n, "coarse_step_s": round(tc, 3), "c2f_step_s": round(tf, 3),
+                          "tokens_per_s": round(8 * TOKENS_PER_CLIP / (12 * tc + 2 * tf), 1)})
+        best8 = max(sweep, key=lambda r: r["tokens_per_s"])
+        res["batch8"] = {"value": best8["tokens_per_s"], "unit": "codec-tokens/s", "cores": best8["threads"], "kind": "port",
+                         "sample": "bounded: ONE coarse sampling step (B=8, T=575) and ONE c2f sampling step (the batch's 32 chunks, T=173) "
+                                   "per thread count, composed as 12 coarse + 2 c2f steps per 8 clips (no warm-up run: the B=1 pass above "
+                                   "warmed both models)", "thread_sweep": sweep}
+        torch.set_num_threads(cores)
+    return res
 
 
 def cpu_baseline_train(threads=16):
@@ -256,12 +380,19 @@ def main():
                     help="time the whole request encode -> build_mask -> vamp -> decode (DAC codec with seeded synthetic weights; "
                          "codec parity is UNPINNED) instead of vamp() alone, with per-stage ms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true",
+                    help="print the cpu_baseline object alone (no GPU needed): how profiles/r06_cpu_reference_in_container.json was made")
+    ap.add_argument("--no-sharded-check", action="store_true",
+                    help="N = 1 only: skip the extra timed region that runs the same steps through the sharded code path (a one-rank RCCL group)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--event-stride", type=int, default=8,
                     help="bracket ~1 of every N MFMA launches with hipEvents (1 = all: +2.3 %% step time at B=8)")
     args = ap.parse_args()
     if args.config == 1:
         args.coarse_only, args.batch_per_gpu = True, 1
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(coarse_only=args.coarse_only)), flush=True)
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1) and hand
@@ -291,20 +422,26 @@ def main():
     dev_index = 0 if one_gpu else local_rank
     torch.cuda.set_device(dev_index)
     device = f"cuda:{dev_index}"
+    numa = _numa_bind(dev_index) if world > 1 and not one_gpu else None      # one process per GPU, each on its GPU's socket
     pg = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device(device))     # "nccl" is RCCL on ROCm
+
+        def _init():
+            if one_gpu:
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
+            else:
+                dist.init_process_group("nccl", device_id=torch.device(device), timeout=datetime.timedelta(seconds=300))     # "nccl" is RCCL on ROCm
+            # build the communicator (rings over xGMI) now, outside any timed region, whatever --warmup is
+            _t = torch.ones(1, device=device) if not one_gpu else torch.ones(1)
+            dist.all_reduce(_t)
+            torch.cuda.synchronize()
+            return int(_t.item())
+        n_seen = _with_deadline(f"torch.distributed init + first all-reduce over {world} ranks", 240, _init, rank)
         pg = dist.group.WORLD
-        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
-        # build the communicator (rings over xGMI) now, outside any timed region, whatever --warmup is
-        _t = torch.ones(1, device=device) if not one_gpu else torch.ones(1)
-        dist.all_reduce(_t)
-        torch.cuda.synchronize()
+        assert dist.get_world_size() == args.gpus and n_seen == world, (dist.get_world_size(), n_seen, args.gpus)
 
     if args.workload == "train":
         def _barrier():
@@ -340,6 +477,7 @@ def main():
     # what a hot-swap costs (the reference app reloads weights per request, app.py:181): pack + upload + plane build of both models
     setup_s = {args.dtype: round(time.perf_counter() - t_setup, 3)}
     itf.exchange_log = [] if world > 1 else None
+    preflight = _rccl_preflight(itf, device, world, rank) if world > 1 and not one_gpu else None
     B = args.batch_per_gpu * world
     codes = W.synth_codes(B, 14, 575, seed=2).to(device)
     torch.manual_seed(0)
@@ -436,6 +574,39 @@ def main():
         return el, pr, ex_ms
 
     elapsed, prof, exchange_ms = timed_region()
+    # ---- N = 1: the SAME steps once more through the sharded code path (a one-rank RCCL group: _shard, the padded local block, the device
+    # all-gather through the exchange in use) — the code every rank of an N-GPU run executes; its rate must be the plain line's (1 %)
+    sharded_n1 = None
+    if world == 1 and not args.e2e and not args.no_sharded_check and os.environ.get("VN_BENCH_SHARDED_CHECK", "1") != "0":
+        try:
+            import datetime
+            import socket
+            import torch.distributed as dist
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port1 = sk.getsockname()[1]; sk.close()
+
+            def _init1():
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port1}", rank=0, world_size=1,
+                                        device_id=torch.device(device), timeout=datetime.timedelta(seconds=120))
+                dist.all_reduce(torch.ones(1, device=device))
+                torch.cuda.synchronize()
+            _with_deadline("one-rank RCCL group for the sharded-path check", 150, _init1)
+            itf.pg, itf.rank, itf.world = dist.group.WORLD, 0, 1
+            pf = _rccl_preflight(itf, device, 1, 0)
+            save_ev, args.no_kernel_events = args.no_kernel_events, True
+            itf.exchange_log = []
+            s_el, _, s_ex = timed_region()
+            args.no_kernel_events = save_ev
+            itf.pg, itf.exchange_log = None, None
+            dist.destroy_process_group()
+            ratio = s_el / elapsed
+            sharded_n1 = {"ms_per_step": 1e3 * s_el / args.steps, "ratio_vs_plain": ratio, "within_1pct": abs(ratio - 1.0) <= 0.01,
+                          "exchange_ms": s_ex, **pf,
+                          "note": "the timed region again with a one-rank RCCL process group attached (kernel event brackets off: they are "
+                                  "on in the plain region and cost it ~0.3 %)"}
+            if not sharded_n1["within_1pct"]:
+                sys.stderr.write(f"bench.py: the sharded code path at N = 1 runs at {ratio:.4f} x the plain step time (> 1 % apart)\n")
+        except Exception as e:                                # a box without a usable RCCL must still produce the N = 1 line
+            sharded_n1 = {"error": f"{type(e).__name__}: {e}"}
     # ---- secondary block: the opt-in fast precision on the SAME inputs, timed after (never inside) the primary region
     alt = None
     if args.dtype in ("bf16x3", "f32") and not args.no_alt and not args.e2e:
@@ -543,13 +714,20 @@ def main():
             an, ams, afl, _ = prof["attention"]
             # fabric bytes per launch: NOT measured by this run — read from the committed rocprofv3 --pmc passes of this same command
             traffic = traffic_source = None
-            tname = next((n for n in {"f32": ["history/r01_traffic.json"], "bf16x3": ["r05_traffic_x3.json", "history/r04_traffic_x3.json"],
-                                      "f16x2": ["r05_traffic_h2.json", "history/r03_traffic_h2.json"]}.get(dtype, [])
+            tname = next((n for n in {"f32": ["history/r01_traffic.json"], "bf16x3": ["r06_traffic_x3.json", "r05_traffic_x3.json"],
+                                      "f16x2": ["r06_traffic_h2.json", "r05_traffic_h2.json"]}.get(dtype, [])
                           if os.path.exists(os.path.join(ROOT, "profiles", n))), "-")
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and world == 1 and args.batch_per_gpu == 8 and not args.coarse_only and not args.e2e:
-                traffic = json.load(open(tpath))["bytes_per_launch"]
-                traffic_source = f"profiles/{tname} (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command; a constant, not this run)"
+                tj = json.load(open(tpath))
+                sha_now, sha_then = _gemm_source_sha(), tj.get("gemm_x3_sha256_16")
+                if sha_then is not None and sha_then == sha_now:
+                    traffic = tj["bytes_per_launch"]
+                    traffic_source = (f"profiles/{tname} (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command on gemm_x3.hip "
+                                      f"sha256 {sha_then}: the kernel source of THIS build; a committed capture, not this run)")
+                else:       # the capture belongs to another revision of the kernel: do not quote it for this one
+                    traffic_source = (f"null: profiles/{tname} was captured on gemm_x3.hip sha256 {sha_then}, this build is {sha_now} "
+                                      "(re-run scripts/gpu_pmc_x3.sh)")
             # bf16x3: `achieved` stays ALGORITHMIC (2MNK per GEMM, fp32-equivalent); every such flop costs six bf16-MFMA flops,
             # so the ceiling of this algorithm is the dense bf16 MFMA peak / 6 (the kernel executes 6 x achieved on the pipe)
             # f16x2: three fp16-MFMA flops per algorithmic flop: ceiling = dense fp16 MFMA peak (= the bf16 one) / 3
@@ -600,7 +778,12 @@ def main():
         res["setup_s"] = setup_s
         res["devices"] = {"world_size": world, "device_count": torch.cuda.device_count(),
                           "exchange_ms": exchange_ms,            # event-timed Interface._allgather_batch, mean per vamp() (None at N = 1)
-                          "exchange": "RCCL all_gather_into_tensor of the (B,14,T) int64 tokens" if world > 1 and not one_gpu else None}
+                          "exchange": (("the library's RCCL communicator (vn_allgather_tokens)" if itf.exchange == "c_abi" else
+                                        "RCCL all_gather_into_tensor (torch.distributed 'nccl')") + " of the (B,14,T) int64 tokens")
+                                      if world > 1 and not one_gpu else None,
+                          # what RCCL ITSELF reports (ncclCommCount) + how many distinct ranks one all-gather saw through each exchange:
+                          # a record with rccl_nranks == n_gpus shows the collective library ran with N ranks, not just N processes
+                          **(preflight or {}), "numa_binding": numa, "sharded_path_at_n1": sharded_n1}
         if alt is not None:
             a_el = alt["elapsed"]
             res["alt"] = {"dtype": "f16x2", "value": tokens / a_el, "unit": "codec-tokens/s", "ms_per_step": 1e3 * a_el / args.steps,

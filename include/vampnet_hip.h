@@ -509,6 +509,9 @@ typedef struct vn_comm vn_comm;
 int  vn_comm_unique_id(vn_ctx* ctx, uint8_t* id128);
 int  vn_comm_create(vn_ctx* ctx, const uint8_t* id128, int rank, int world, vn_comm** out);
 void vn_comm_destroy(vn_comm* comm);
+/* what RCCL itself reports for the communicator (ncclCommCount, ncclCommUserRank): bench.py prints it as devices.rccl_nranks so that
+ * a multi-GPU record shows the collective library saw N ranks, not just that N processes were started                               */
+int  vn_comm_count(vn_comm* comm, int* nranks, int* rank);
 int  vn_allgather_tokens(vn_comm* comm, const int64_t* send_dev, int64_t* recv_dev, int64_t count, void* stream);
 
 /* Tuning / test hooks (vn_debug_*) are NOT part of this interface: include/vampnet_hip_debug.h.  They act on ONE vn_ctx; nothing in

@@ -4,7 +4,7 @@
 mode=${1:-both}; shift
 mkdir -p gpurun_out
 run() {
-  VN_GUARD_ALLOC=$1 timeout 2400 python -m pytest tests -m gpu -x -q -s -p no:cacheprovider --deselect tests/test_gpu_guard.py "${@:2}" \
+  VN_GUARD_ALLOC=$1 timeout 2400 python -m pytest tests -m gpu -q -s -p no:cacheprovider --deselect tests/test_gpu_guard.py "${@:2}" \
      > gpurun_out/r06_guard_full_$1.log 2>&1
   echo "guard $1: rc=$?"; tail -4 gpurun_out/r06_guard_full_$1.log
 }

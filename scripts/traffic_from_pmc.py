@@ -3,7 +3,9 @@ profiles/<out>.json: fabric bytes per launch of the dominant kernel family, corr
 (FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at half size: x2).  These are L2-miss
 requests to the fabric: Infinity-Cache (MALL) hits are included, so this is an UPPER bound on HBM bytes.
 usage: traffic_from_pmc.py <fetch_summary.txt> <write_summary.txt> <kernel substring> <out.json>"""
+import hashlib
 import json
+import os
 import re
 import sys
 
@@ -22,7 +24,10 @@ fetch, write, pat, out_path = sys.argv[1:5]
 f, nf = parse(fetch, pat)
 w, nw = parse(write, pat)
 assert nf == nw and nf > 0, (nf, nw)
-out = {"kernel": pat, "launches": nf, "fetch_kib_raw": f, "write_kib_raw": w,
+_src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vampnet_amd", "csrc", "gemm_x3.hip")
+out = {"kernel": pat, "launches": nf,
+       # the revision of the kernel source the counters belong to: bench.py quotes this capture only for a build of the same source
+       "gemm_x3_sha256_16": hashlib.sha256(open(_src, "rb").read()).hexdigest()[:16], "fetch_kib_raw": f, "write_kib_raw": w,
        "bytes_per_launch": (2 * f + w) * 1024 / nf, "read_bytes_per_launch": 2 * f * 1024 / nf,
        "write_bytes_per_launch": w * 1024 / nf,
        "note": "L2->fabric traffic incl. Infinity-Cache hits (FETCH_SIZE x2 gfx950 correction), averaged over the GEMM launches "

@@ -10,6 +10,14 @@
 //           of Gaussian activations (sigma 1) and weights (sigma 1 / sqrt(1280)), walked in the kernel's six-product order (A0 W2, A2 W0,
 //           A1 W1, A0 W1, A1 W0, A0 W0) — plane 0 has a narrow exponent field, planes 1 / 2 are residuals 2^-8 / 2^-16 below it with
 //           random mantissas: where between "smooth" (2.4 PF) and "uniformly random words" (1.65 PF) do real planes put the wall?
+//   modes 5-7 (round 6, VERDICT r5 probe (c)): the SAME six products of the SAME planes in three other orders — does the wall move when
+//           consecutive MFMAs share an operand register (the source operand does not toggle)?
+//           5 grouped by A plane   A0W2 A0W1 A0W0 A1W1 A1W0 A2W0      (A changes twice per k-step, W every time)
+//           6 grouped by W plane   A2W0 A1W0 A0W0 A1W1 A0W1 A0W2      (W changes twice per k-step)
+//           7 both operands change on every instruction   A0W2 A1W1 A2W0 A0W1 A1W0 A0W0
+//           (mode 4, the kernel's order A0W2 A2W0 A1W1 A0W1 A1W0 A0W0, changes both on 4 of 6)
+//           Already known from modes 1 / 2: ONE random set reused by every MFMA (nothing toggles between instructions) 1746 TF, eight
+//           sets round-robin 1686 TF — the order is worth <= 3 %; what costs is the bit activity INSIDE a product, not between products.
 // Each mode runs ~0.3 s (DVFS settles in milliseconds); prints executed TF and the shader clock from s_memtime / wall time.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -56,17 +64,17 @@ __device__ __forceinline__ void plane_sets(unsigned& s, float sigma, bf16x8 (&p)
 
 template <int MODE>
 __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, int iters) {
-    constexpr int NS = MODE == 4 ? 3 : MODE >= 2 ? 8 : 1;
+    constexpr int NS = MODE >= 4 ? 3 : MODE >= 2 ? 8 : 1;
     f32x16 acc[4] = {};
     bf16x8 a[NS], b[NS];
     unsigned s = 12345u + threadIdx.x * 977u + blockIdx.x * 131071u;
-    if (MODE == 4) {
+    if (MODE >= 4) {
         bf16x8 pa[3], pb[3];
         plane_sets(s, 1.0f, pa);
         plane_sets(s, 0.02795f, pb);
         for (int q = 0; q < 3; ++q) { a[q % NS] = pa[q]; b[q % NS] = pb[q]; }
     }
-    for (int q = 0; q < NS && MODE != 4; ++q) {
+    for (int q = 0; q < NS && MODE < 4; ++q) {
         if (MODE == 0) {
             for (int i = 0; i < 8; ++i) { a[q][i] = (__bf16)(threadIdx.x * 0.001f + i); b[q][i] = (__bf16)(1.0f + i * 0.01f); }
         } else {
@@ -78,9 +86,11 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 24; ++u) {
-            if (MODE == 4) {                                  // the six plane products of a k-step, smallest terms first (gemm_x3.hip: mac_prod)
-                constexpr int QA[6] = {0, 2, 1, 0, 1, 0}, QB[6] = {2, 0, 1, 1, 0, 0};
-                acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[QA[u % 6] % NS], b[QB[u % 6] % NS], acc[u & 3], 0, 0, 0);
+            if (MODE >= 4) {                                  // the six plane products of a k-step; mode 4 = gemm_x3.hip's order (mac_prod)
+                constexpr int QA[4][6] = {{0, 2, 1, 0, 1, 0}, {0, 0, 0, 1, 1, 2}, {2, 1, 0, 1, 0, 0}, {0, 1, 2, 0, 1, 0}};
+                constexpr int QB[4][6] = {{2, 0, 1, 1, 0, 0}, {2, 1, 0, 1, 0, 0}, {0, 0, 0, 1, 1, 2}, {2, 1, 0, 1, 0, 0}};
+                constexpr int O = MODE - 4;
+                acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[QA[O][u % 6] % NS], b[QB[O][u % 6] % NS], acc[u & 3], 0, 0, 0);
             } else
             acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % NS], b[(u / 2) % NS], acc[u & 3], 0, 0, 0);
             if (MODE == 3 && (u % 12) == 11) __builtin_amdgcn_s_barrier();
@@ -133,6 +143,9 @@ int main() {
         run<2>("eight random operand sets, round-robin", blocks);
         run<3>("eight random sets + s_barrier every 12 MFMAs", blocks);
         run<4>("the three split planes of Gaussian activations x weights, six-product order", blocks);
+        run<5>("same planes, products grouped by A plane (A0W2 A0W1 A0W0 A1W1 A1W0 A2W0)", blocks);
+        run<6>("same planes, products grouped by W plane (A2W0 A1W0 A0W0 A1W1 A0W1 A0W2)", blocks);
+        run<7>("same planes, both operands change every MFMA (A0W2 A1W1 A2W0 A0W1 A1W0 A0W0)", blocks);
     }
     return 0;
 }

@@ -388,7 +388,8 @@ def test_torch_rng_on_device(eng):
 
 @pytest.mark.parametrize("B,N,b0,nb,pattern", [(2, 1150, 0, 2, (1, 1, 1)),          # 4.7 M words per step: three chunks of 2 M
                                                  (3, 300, 1, 1, (1, 0, 1, 1)),        # a rank's rows of a sharded batch, a non-sampling step
-                                                 (1, 37, 0, 1, (1, 1))])              # tiny: one short chunk per step
+                                                 (1, 37, 0, 1, (1, 1)),               # tiny: one short chunk per step
+                                                 (2, 64, 2, 0, (1, 0, 1))])           # a rank WITHOUT items (world > batch): only the generator moves
 def test_torch_rng_whole_call_plan_equals_torch(eng, B, N, b0, nb, pattern):
     """torch_rng.draw_units — every draw of a whole generate() call planned from ONE generator state (two-level jump-ahead, all chunks
     walked at once) — gives, step for step, the tensors torch draws on the host in the reference's order (exponential_ over (B N, V) when

@@ -440,6 +440,18 @@ def test_interface_from_checkpoint_files_reload_and_lora(eng, tmp_path):
     assert torch.equal(itf.coarse.blob, itf_l.coarse.blob)                 # same kernel, same bits as the fresh load's merge
     itf.load_lora(coarse_lora_ckpt="")
     assert torch.equal(itf.vamp(z, mask, batch_size=2, seed=7, _sampling_steps=3).cpu(), ref)
+    # a resident entry IS the plain checkpoint (reload() has no adapter argument: interface.py:146-174 -> _load_model(ckpt)): a model that
+    # carries adapters when it is swapped out — merged by load_lora() or by the constructor's coarse_lora_ckpt — comes back without them
+    # (the cache key holds no adapter identity, so the cached object must not carry call history)
+    itf.load_lora(coarse_lora_ckpt=str(tmp_path / "lora.pth"))
+    itf.reload(coarse_ckpt=str(tmp_path / "coarse2.pth"))
+    itf.reload(coarse_ckpt=str(tmp_path / "coarse.pth"))
+    assert itf.coarse is old
+    assert torch.equal(itf.vamp(z, mask, batch_size=2, seed=7, _sampling_steps=3).cpu(), ref)
+    itf_l.reload(coarse_ckpt=str(tmp_path / "coarse2.pth"))
+    itf_l.reload(coarse_ckpt=str(tmp_path / "coarse.pth"))
+    assert torch.equal(itf_l.vamp(z, mask, batch_size=2, seed=7, _sampling_steps=3).cpu(), ref)
+    assert torch.equal(itf_l.coarse.blob, itf.coarse.blob)
 
 
 def test_interface_vamp_time_stretch_feedback_gpu(tiny, itf):

@@ -150,12 +150,12 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, B, T, q):
+def _worker(rank, world, port, B, T, q, c2f_max_batch=16):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
-    itf, _ = make_interface(dist.group.WORLD)
+    itf, _ = make_interface(dist.group.WORLD, c2f_max_batch=c2f_max_batch)
     z = W.synth_codes(B, 14, T, seed=6)
     torch.manual_seed(3)
     mask = itf.build_mask(z)
@@ -165,12 +165,12 @@ def _worker(rank, world, port, B, T, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B", [4, 3])
-def test_batch_shard_two_ranks_gloo(B):
+@pytest.mark.parametrize("B,T,c2f_max_batch", [(4, 200, 16), (3, 200, 16), (16, 120, 8)])
+def test_batch_shard_two_ranks_gloo(B, T, c2f_max_batch):
     """Every rank holds the global batch, computes its contiguous block of items with the GLOBAL N0 and the global
     noise stream, then one all-gather: the result on every rank equals the unsharded oracle vamp()
-    (B = 3: ragged shards 2 + 1)."""
-    T = 200
+    (B = 3: ragged shards 2 + 1; B = 16 with a c2f workspace of 8: the per-rank shape of BASELINE configs[3] — 8 items per rank,
+    the coarse-to-fine chunks of a rank's items cut into launches of at most 8 — at a length the CPU finishes in seconds)."""
     _, models = make_interface()
     z = W.synth_codes(B, 14, T, seed=6)
     torch.manual_seed(3)
@@ -179,7 +179,7 @@ def test_batch_shard_two_ranks_gloo(B):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, T, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, T, q, c2f_max_batch)) for r in range(2)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=300) for _ in range(2))

@@ -134,6 +134,7 @@ SYMBOLS = {
     "vn_comm_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     "vn_comm_destroy": (None, [_P]),
     "vn_allgather_tokens": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "vn_comm_count": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vn_debug_graph_replays": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "vn_debug_gemm_config": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "vn_debug_attention_x3_time": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),

@@ -771,6 +771,11 @@ class DacCodec:
         import os
         if os.environ.get("VN_PREPROCESS_HOST") == "1":
             return self.preprocess_signal_host(signal, loudness)
+        # what the device kernels do not take (csrc/preprocess.hip): a codec rate at which a 400 ms block is not four 100 ms hops
+        # (int(0.4 sr) != 4 (sr // 10): any rate that is not a multiple of 10), and an empty signal — the host twin handles both
+        if int(0.4 * self.sample_rate) != 4 * (self.sample_rate // 10) or signal.samples.shape[-1] == 0:
+            out = self.preprocess_signal_host(signal, loudness)
+            return AudioSignal(out.samples.to(self.device), out.sample_rate)
         x, sr = signal.samples.float(), signal.sample_rate
         if sr != self.sample_rate:
             from scipy.signal import resample_poly

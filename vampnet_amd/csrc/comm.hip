@@ -22,6 +22,8 @@ struct vn_rccl_api {
     int (*CommDestroy)(vn_nccl_comm);
     int (*AllGather)(const void*, void*, size_t, int, vn_nccl_comm, hipStream_t);
     const char* (*GetErrorString)(int);
+    int (*CommCount)(const vn_nccl_comm, int*);            // optional (bench.py's preflight): what RCCL itself says about the communicator
+    int (*CommUserRank)(const vn_nccl_comm, int*);
 };
 
 struct vn_comm {
@@ -45,6 +47,8 @@ static int rccl_bind(vn_ctx* ctx, vn_rccl_api* api) {
     api->CommDestroy = (int (*)(vn_nccl_comm))dlsym(api->handle, "ncclCommDestroy");
     api->AllGather = (int (*)(const void*, void*, size_t, int, vn_nccl_comm, hipStream_t))dlsym(api->handle, "ncclAllGather");
     api->GetErrorString = (const char* (*)(int))dlsym(api->handle, "ncclGetErrorString");
+    api->CommCount = (int (*)(const vn_nccl_comm, int*))dlsym(api->handle, "ncclCommCount");
+    api->CommUserRank = (int (*)(const vn_nccl_comm, int*))dlsym(api->handle, "ncclCommUserRank");
     if (!api->GetUniqueId || !api->CommInitRank || !api->CommDestroy || !api->AllGather || !api->GetErrorString) {
         dlclose(api->handle);
         api->handle = nullptr;
@@ -99,6 +103,16 @@ extern "C" void vn_comm_destroy(vn_comm* c) {
     if (c->comm) (void)c->api.CommDestroy(c->comm);
     if (c->api.handle) dlclose(c->api.handle);
     delete c;
+}
+
+// what RCCL reports for this communicator (ncclCommCount / ncclCommUserRank) — not what the host asked for
+extern "C" int vn_comm_count(vn_comm* c, int* nranks, int* rank) {
+    if (!c || !nranks) return VN_ERR_INVALID;
+    if (!c->api.CommCount) return vn_fail(c->ctx, VN_ERR_UNSUPPORTED, "vn_comm_count: this RCCL has no ncclCommCount%s", "");
+    int st = c->api.CommCount(c->comm, nranks);
+    if (st != 0) return rccl_fail(c->ctx, c->api, "ncclCommCount", st);
+    if (rank && c->api.CommUserRank && (st = c->api.CommUserRank(c->comm, rank)) != 0) return rccl_fail(c->ctx, c->api, "ncclCommUserRank", st);
+    return VN_OK;
 }
 
 // every rank contributes `count` int64 values (its block of batch items, all ranks the same count: the host pads); recv = [world][count]

@@ -397,18 +397,27 @@ class VampNetModel:
         """Adapter hot-swap on a RESIDENT model (the reference reloads the whole checkpoint for this: interface.py:27-50 via
         app.py:181): merge the loralib adapters of `lora_sd` (name.lora_A / name.lora_B; None or {} = no adapters) into the un-merged
         weights on the device and rebuild the planes of the precision in use — tens of milliseconds instead of a checkpoint load,
-        pack and upload.  Captured forward graphs stay valid (every buffer keeps its address)."""
+        pack and upload.  Every buffer the model points at keeps its address (the fp32 blob is rewritten in place, the bf16x3 planes
+        and the single-plane bf16 image are re-filled in place), so nothing dangles and captured forward graphs stay valid.  Memory:
+        the first swap keeps one extra copy of the fp32 blob (`blob_base`, the un-merged weights: 1.3 GB for the coarse model)."""
         if self.blob_base is None:
             self.blob_base = self.blob.clone()              # no adapters merged so far: the blob IS the base
         vec = pack_lora_vector(self.lib, self.dims, lora_sd or {})
         self._merge_lora_vector(vec)
+        self._has_adapters = bool(lora_sd)
         self._refresh_planes()
+
+    def drop_adapters(self):
+        """back to the plain checkpoint (what Interface.reload returns: interface.py:146-174 loads without lora_ckpt); no-op for a model
+        that never carried adapters or has none merged right now"""
+        if self.blob_base is not None and getattr(self, "_has_adapters", True):
+            self.apply_lora({})
 
     def _refresh_planes(self):
         """the fp32 blob changed in place: rebuild the 16-bit images of the precision in use"""
         want = self.precision
-        if want == "bf16":
-            self.blob16 = None
+        if want == "bf16" and self.blob16 is not None:
+            self.blob16.copy_(self.blob)                    # in place: the model keeps pointing at this tensor (RNE, like .to(bfloat16))
         if want == "bf16x3" and self.blob3 is not None:
             n = self.blob.numel()
             self.engine.check(self.lib.vn_split3_f32(self.engine.handle, self.blob.data_ptr(), self.blob3.data_ptr(), n, n,

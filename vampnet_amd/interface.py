@@ -122,8 +122,11 @@ class Interface:
     # ---- resident models: what a hot swap costs -------------------------------------------------------------------------
     # The reference app swaps models per request (app.py:181 -> load_finetuned -> reload, interface.py:134-174): every swap there is a
     # checkpoint read + .to(device).  Here a model that was loaded before STAYS packed, uploaded and split on the device (HBM is 288 GB;
-    # a coarse model with its planes and workspace is ~6 GB), keyed by (role, file path, mtime, size): swapping back to it is a
-    # dictionary lookup.  The least recently used entries beyond `max_resident` per role (VN_RESIDENT_MODELS, default 4) are dropped.
+    # a coarse model with its planes and workspace is ~6 GB, ~7.3 GB once an adapter swap keeps its un-merged blob), keyed by (role, file
+    # path, mtime, size): swapping back to it is a dictionary lookup.  The least recently used entries beyond `max_resident` per role
+    # (VN_RESIDENT_MODELS, default 4) are dropped.  An entry IS the plain checkpoint: reload() takes no adapter argument in the reference
+    # either (interface.py:146-174 -> _load_model(ckpt) without lora_ckpt), so a resident model that carries adapters — from the
+    # constructor's *_lora_ckpt or from load_lora() — has them removed on the device when a reload() hands it out again (tens of ms).
     @staticmethod
     def _ckpt_key(path):
         p = Path(path)
@@ -268,6 +271,7 @@ class Interface:
             hit = self._resident_get("coarse", coarse_ckpt)
             if hit is not None:                            # loaded before and still resident: nothing to read, pack, upload or split
                 hit.chunk_size_s = self.coarse.chunk_size_s
+                hit.drop_adapters()
                 self.coarse = hit
             else:
                 sd, kw = _load_checkpoint(coarse_ckpt)
@@ -279,6 +283,7 @@ class Interface:
             hit = self._resident_get("c2f", c2f_ckpt)
             if hit is not None:
                 hit.chunk_size_s = chunk_s
+                hit.drop_adapters()
                 self.c2f = hit
             else:
                 sd, kw = _load_checkpoint(c2f_ckpt)

@@ -10,7 +10,8 @@ the stream.  `csrc/torch_rng.hip: vn_mt19937_jump_kernel` evaluates that with on
 serial walk through torch's CPU stream (`rng="torch_device"`) into independent 2 M-word chunks, one per compute unit.
 
 g is computed here with Python integers as GF(2)[x] bit vectors (squaring = bit spreading, reduction by the sparse phi);
-~40 ms per offset, cached.  PHI_EXPONENTS was obtained with Berlekamp-Massey on the generator's own output
+~0.1-0.16 s per offset the first time an offset is seen (a whole-call plan of torch_rng.draw_units needs one per sampling step + one
+per chunk: 34 for the coarse stage at B = 8), cached in memory and under vampnet_amd/.cache/.  PHI_EXPONENTS was obtained with Berlekamp-Massey on the generator's own output
 (tests/test_host_logic.py::test_mt19937_characteristic_polynomial recomputes it).
 """
 import functools

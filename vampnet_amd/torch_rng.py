@@ -260,6 +260,12 @@ def draw_units(rng: DeviceTorchRng, units, B, N, V, b0, nb):
     states1 = torch.empty(n_units + 1, _N, dtype=torch.int32, device=dev)
     eng.check(lib.vn_mt19937_jump(eng.handle, rng.state.data_ptr(), rng.pos.data_ptr(), polys1.data_ptr(), n_units + 1,
                                   states1.data_ptr(), st), "vn_mt19937_jump")
+    if nb == 0 or N == 0:
+        # a rank without items (world > batch): nothing to draw, but torch's generator still has to end where the unsharded call leaves
+        # it — the level-1 jump alone gives that state (the chunk / uniform walks would be launches of zero words, which the C entries reject)
+        rng.state.copy_(states1[n_units])
+        rng.pos.fill_(end_pos)
+        return
     n2 = n_samp * nc + n_units
     states2 = torch.empty(n2, _N, dtype=torch.int32, device=dev)
     eng.check(lib.vn_mt19937_jump_indexed(eng.handle, states1.data_ptr(), base_idx.data_ptr(), polys2.data_ptr(), poly_idx.data_ptr(), n2,
