@@ -267,7 +267,7 @@ def cpu_baseline_train(threads=16):
             "sample": f"oracle train step (forward+CE+autograd backward+clip+AdamW), coarse model, B=1, T=575: {times[-1]:.2f} s"}
 
 
-def bench_train(args, rank, world, device, pg, barrier):
+def bench_train(args, rank, world, device, pg, barrier, result_out=sys.stdout):
     """BASELINE configs[4]: conf/vampnet.yml training step of the coarse model on synthetic DAC tokens, batch 8 per GPU,
     gradient all-reduce on RCCL.  A "step" = mask -> forward (dropout 0.1) -> CE(label_smoothing 0.1) -> backward ->
     all-reduce -> clip 5.0 -> AdamW -> Noam.  value = masked-LM tokens consumed per second over all ranks."""
@@ -347,7 +347,8 @@ def bench_train(args, rank, world, device, pg, barrier):
         res["config"]["workload"] += "; LoRA-only (r=8 adapters on w_qs, w_vs, fc, w_1, w_2; everything else frozen)"
     if not args.no_cpu_baseline and not args.lora_only:
         res["cpu_baseline"] = cpu_baseline_train()
-    print(json.dumps(res), flush=True)
+    result_out.write(json.dumps(res) + "\n")
+    result_out.flush()
 
 
 def main():
@@ -412,6 +413,12 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
                "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd, env=env))
+    # ONE JSON line on stdout, whatever the libraries underneath print: RCCL writes a version banner to fd 1 when its first communicator
+    # is made (rank 0 of every multi-GPU run, and the one-rank group of the sharded-path check).  From here on fd 1 IS stderr; the result
+    # line goes to the saved descriptor.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -450,7 +457,7 @@ def main():
                 import torch.distributed as dist
                 dist.barrier()
             torch.cuda.synchronize()
-        bench_train(args, rank, world, device, pg, _barrier)
+        bench_train(args, rank, world, device, pg, _barrier, result_out)
         if world > 1:
             import torch.distributed as dist
             dist.destroy_process_group()
@@ -796,7 +803,8 @@ def main():
                           **({"roofline": roofline_of("f16x2", alt["prof"], a_el)} if alt["prof"] is not None else {})}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(coarse_only=args.coarse_only)
-        print(json.dumps(res), flush=True)
+        result_out.write(json.dumps(res) + "\n")
+        result_out.flush()
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -8,6 +8,11 @@
 //     arm 1   256 x 128, k-tile 32, 8 waves 4 x 2 (wave tile 64 x 64),   2 stages x 72 KiB   [gemm_x3.hip CFG 2]
 //     arm 2   256 x 256, k-tile 16, 8 waves 2 x 4 (wave tile 128 x 64),  3 stages x 48 KiB   [probe (a)]
 //     arm 3   256 x 256, k-tile 16, 4 waves 2 x 2 (wave tile 128 x 128), 3 stages x 48 KiB   [probe (b): one wave per SIMD, 512 VGPRs]
+//     arm 4/5 288 x 256 / 192 x 256 "column strips": 8 waves 1 x 8, a wave owns ALL BM rows of 32 columns; only A goes through LDS
+//             (k-tile 32, 2 stages x 54 / 36 KiB), a wave's W fragments are its own and come straight from L2 into registers.
+//             288 rows make ONE round of the model's B = 8 shapes: M = 4600 -> 16 x 288: QKV 240 tiles, classifier 256 tiles on 256 CUs
+//             (256 x 256 leaves 1.05 / 1.12 rounds); W1 (20 column tiles) would need 384 rows = 192 accumulator registers per lane, which
+//             does not fit two waves per SIMD — its arm is 192 x 256: 480 tiles = 1.88 rounds, the fill 256 x 128 has today (2.81).
 // Same arithmetic as the product (three exact bf16 planes per operand, six v_mfma_f32_32x32x16_bf16 products per 16-wide k-step in the
 // kernel's order, fp32 accumulation), same transport (LDS-DMA of contiguous 1 KiB pieces from a tiled plane image, source-side bank
 // swizzle, raw s_barrier + counted vmcnt, prefetch distance stages - 1), plain fp32 store epilogue.  The schedule is the simple
@@ -152,6 +157,106 @@ __global__ __launch_bounds__(G::NW * 64, G::NW == 4 ? 1 : 2) void gemm_probe(con
     }
 }
 
+// ---- arm 4 / 5: column strips (see the header).  W image as in arms 0 / 1 (k-tile 32 layout); lane l of wave w holds W row
+// n0 + 32 w + (l & 31), k = 16 s + 8 (l >> 5) .. + 7 of every plane: 6 x 16-byte loads per k-tile, fetched one k-tile ahead
+template <int BM>
+__global__ __launch_bounds__(512, 2) void gemm_strip(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, float* __restrict__ C,
+                                                     int M, int N, int K, int store) {
+    constexpr int RI = BM / 32, APL = BM * 64, STAGE = 3 * APL, NPIECE = STAGE / 1024, PW = (NPIECE + 7) / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_m = M / BM, tiles_n = N / 256, nwg = tiles_m * tiles_n, nk = K / 32;
+    int t;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = t % tiles_m, tn = t / tiles_m;         // a column of tiles shares its W strip in the XCD's L2
+    const size_t kpieces = (size_t)nk * 3;
+    auto issue = [&](int kt) {
+        char* st = smem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            int pi = wave + j * 8;
+            pi = pi < NPIECE ? pi : NPIECE - 1;          // BM = 288: 54 pieces over 8 waves — the last slots re-fetch the last piece
+            const int q = pi / (APL / 1024), pp = pi % (APL / 1024);
+            const uint16_t* src = A + (((size_t)(tm * (BM / 16) + pp) * kpieces + (size_t)kt * 3 + q) * 512) + lane * 8;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                             (void __attribute__((address_space(3)))*)(st + q * APL + pp * 1024), 16, 0, 0);
+        }
+    };
+    // W fragments by buffer loads: descriptor + ONE 32-bit per-lane offset per k-step (row and swizzled slot) + a uniform offset for
+    // (k-tile, plane) — six 64-bit per-lane pointers were what the register allocator spilled first
+    const int wrow = tn * 256 + wave * 32 + l31;
+    const int wsw = ((wrow & 15) >> 2) & 3;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)((size_t)N * K * 6), 0x00020000);
+    const unsigned wv0 = (unsigned)(((size_t)(wrow >> 4) * kpieces) * 1024 + (wrow & 15) * 64 + (((0 + hh) ^ wsw) << 4));
+    const unsigned wv1 = (unsigned)(((size_t)(wrow >> 4) * kpieces) * 1024 + (wrow & 15) * 64 + (((2 + hh) ^ wsw) << 4));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto load_w = [&](int kt, bf16x8 (&wf)[3][2]) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const unsigned so = (unsigned)((kt * 3 + q) * 1024);
+            wf[q][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wv0, so, 0));
+            wf[q][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wv1, so, 0));
+        }
+    };
+    f32x16 acc[RI];
+#pragma unroll
+    for (int i = 0; i < RI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    bf16x8 wa[3][2], wb[3][2];
+    issue(0);
+    load_w(0, wa);
+    // A fragments one row block ahead (two register sets, names fixed by the full unroll); the sched_barrier after each block's six
+    // products keeps hipcc from hoisting every ds_read of the k-tile to the top (27-36 fragments = 108-144 VGPRs: it spilled 118)
+    auto compute = [&](int kt, const bf16x8 (&wf)[3][2]) {
+        const char* st = smem + (kt & 1) * STAGE;
+        constexpr int QA[6] = {0, 2, 1, 0, 1, 0}, QB[6] = {2, 0, 1, 1, 0, 0};
+        bf16x8 af[2][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) af[0][q] = *(const bf16x8*)(st + q * APL + frag_off<32>(l31, hh));
+#pragma unroll
+        for (int x = 0; x < 2 * RI; ++x) {
+            const int s = x / RI, i = x % RI;
+            if (x + 1 < 2 * RI) {
+                const int s1 = (x + 1) / RI, i1 = (x + 1) % RI;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) af[(x + 1) & 1][q] = *(const bf16x8*)(st + q * APL + frag_off<32>(32 * i1 + l31, 2 * s1 + hh));
+            }
+#pragma unroll
+            for (int p = 0; p < 6; ++p) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[x & 1][QA[p]], wf[QB[p]][s], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // ONE copy of the MFMA phase in the loop body (two copies — one per W register set — made hipcc keep two images of the
+    // accumulators: 118-174 spilled VGPRs); the W set of the next k-tile moves into place with 24 v_mov per 6 RI x 2 MFMAs
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RAW_BARRIER();
+        if (kt + 1 < nk) { issue(kt + 1); load_w(kt + 1, wb); }
+        compute(kt, wa);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { wa[q][0] = wb[q][0]; wa[q][1] = wb[q][1]; }
+    }
+    const int m0 = tm * BM, n0 = tn * 256 + wave * 32;
+    if (store) {
+#pragma unroll
+        for (int i = 0; i < RI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) C[(size_t)(m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hh) * N + n0 + l31] = acc[i][r];
+    } else {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < RI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc += acc[i][r];
+        C[(size_t)(m0 + l31) * N + n0 + hh] = sacc;
+    }
+}
+
 // ---- host ---------------------------------------------------------------------------------------------------------------------------
 static uint16_t bf16_rne(float f) {
     uint32_t u; memcpy(&u, &f, 4);
@@ -181,14 +286,16 @@ static void make_image(const std::vector<float>& X, int rows, int K, int KT, std
 
 struct arm_info { const char* name; int BM, BN, KT; };
 
+typedef void (*kern_t)(const uint16_t*, const uint16_t*, float*, int, int, int, int);
 template <class G>
 static double run_arm(const char* name, const uint16_t* dA, const uint16_t* dW, float* dC, int M, int N, int K, int store, int iters,
-                      const std::vector<float>* hA, const std::vector<float>* hW) {
-    if (M % G::BM || N % G::BN || K % G::KT) { printf("  %-44s skipped (shape not a multiple of the tile)\n", name); return 0; }
-    const int nwg = (M / G::BM) * (N / G::BN);
-    const size_t lds = (size_t)G::NST * G::STAGE;
-    CHECK(hipFuncSetAttribute((const void*)gemm_probe<G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL((gemm_probe<G>), dim3(nwg), dim3(G::NW * 64), lds, 0, dA, dW, dC, M, N, K, 1);
+                      const std::vector<float>* hA, const std::vector<float>* hW);
+static double run_kernel(const char* name, kern_t kern, int BM, int BN, int KT, int threads, size_t lds, const uint16_t* dA, const uint16_t* dW,
+                         float* dC, int M, int N, int K, int store, int iters, const std::vector<float>* hA, const std::vector<float>* hW) {
+    if (M % BM || N % BN || K % (2 * KT)) { printf("  %-44s skipped (shape not a multiple of the tile)\n", name); return 0; }
+    const int nwg = (M / BM) * (N / BN);
+    CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(threads), lds, 0, dA, dW, dC, M, N, K, 1);
     CHECK(hipDeviceSynchronize());
     if (hA) {                                            // sampled check against float64 of the logical operands
         std::vector<float> C((size_t)M * N);
@@ -205,9 +312,9 @@ static double run_arm(const char* name, const uint16_t* dA, const uint16_t* dW, 
     }
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_probe<G>), dim3(nwg), dim3(G::NW * 64), lds, 0, dA, dW, dC, M, N, K, store);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(nwg), dim3(threads), lds, 0, dA, dW, dC, M, N, K, store);
     CHECK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_probe<G>), dim3(nwg), dim3(G::NW * 64), lds, 0, dA, dW, dC, M, N, K, store);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(nwg), dim3(threads), lds, 0, dA, dW, dC, M, N, K, store);
     CHECK(hipEventRecord(e1, 0));
     CHECK(hipDeviceSynchronize());
     float ms = 0;
@@ -217,6 +324,11 @@ static double run_arm(const char* name, const uint16_t* dA, const uint16_t* dW, 
            store ? "with the fp32 store" : "k-loop only");
     CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
     return us;
+}
+template <class G>
+static double run_arm(const char* name, const uint16_t* dA, const uint16_t* dW, float* dC, int M, int N, int K, int store, int iters,
+                      const std::vector<float>* hA, const std::vector<float>* hW) {
+    return run_kernel(name, gemm_probe<G>, G::BM, G::BN, G::KT, G::NW * 64, (size_t)G::NST * G::STAGE, dA, dW, dC, M, N, K, store, iters, hA, hW);
 }
 
 int main(int argc, char** argv) {
@@ -231,7 +343,7 @@ int main(int argc, char** argv) {
         {4608, 4096, 1280, "classifier at B = 8"},
     };
     for (const shape& sh : shapes) {
-        if (only >= 0 && &sh != &shapes[0]) break;
+        if (only >= 0 && &sh != &shapes[only >= 4 ? 5 : 0]) continue;
         const int M = sh.M, N = sh.N, K = sh.K;
         std::vector<float> hA((size_t)M * K), hW((size_t)N * K);
         uint32_t s = 12345u;
@@ -260,6 +372,8 @@ int main(int argc, char** argv) {
             if (only < 0 || only == 1) run_arm<geo<256, 128, 32, 8, 4, 2>>("arm 1  256 x 128  k32  8 waves (64 x 64)", dA32, dW32, dC, M, N, K, store, iters, pa, pw);
             if (only < 0 || only == 2) run_arm<geo<256, 256, 16, 8, 2, 3>>("arm 2  256 x 256  k16  8 waves (128 x 64)", dA16, dW16, dC, M, N, K, store, iters, pa, pw);
             if (only < 0 || only == 3) run_arm<geo<256, 256, 16, 4, 2, 3>>("arm 3  256 x 256  k16  4 waves (128 x 128)", dA16, dW16, dC, M, N, K, store, iters, pa, pw);
+            if (only < 0 || only == 4) run_kernel("arm 4  288 x 256  k32  8 strips (288 x 32), W in regs", gemm_strip<288>, 288, 256, 32, 512, 2 * 3 * 288 * 64, dA32, dW32, dC, M, N, K, store, iters, pa, pw);
+            if (only < 0 || only == 5) run_kernel("arm 5  192 x 256  k32  8 strips (192 x 32), W in regs", gemm_strip<192>, 192, 256, 32, 512, 2 * 3 * 192 * 64, dA32, dW32, dC, M, N, K, store, iters, pa, pw);
             if (only >= 0) break;
         }
         CHECK(hipFree(dA32)); CHECK(hipFree(dW32)); CHECK(hipFree(dA16)); CHECK(hipFree(dW16)); CHECK(hipFree(dC));
