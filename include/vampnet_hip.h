@@ -118,8 +118,10 @@ const char* vn_version(void);
 /* ---- kernel timing (bench.py's roofline leg) ------------------------------------------------
  * While enabled, every launch of the MFMA kernels (vn_gemm_f32[_sk]_kernel, vn_attention_kernel,
  * vn_conv1d_f32_kernel) made through this ctx is bracketed by hipEvents on the launch stream.
- * vn_profile_end synchronises the recorded events and returns, per class c in {0: gemm f32, 1: attention, 2: conv1d,
- * 3: gemm bf16}:
+ * vn_profile_end synchronises the recorded events and returns, per class c in {0: GEMMs of the precision in use, 1: attention,
+ * 2: codec convolutions bound by the split-plane matrix pipe, 3: gemm bf16 (fast mode), 4: codec convolutions bound by the fp32-input
+ * MFMA, 5: codec convolutions bound by their operand BYTES (arithmetic intensity below the ridge of the pipe they run on: the
+ * audio-rate and k = 1 layers)} — 6 classes x 4 doubles:
  *   stats[4c+0] = launches, stats[4c+1] = total kernel time in ms, stats[4c+2] = algorithmic FLOPs
  *   (2*M*N*K per GEMM / conv launch; 4*T*T*64 per (b,h) for attention), stats[4c+3] = algorithmic operand bytes
  *   (every fp32 operand read once + every result written once).                                  */
@@ -128,7 +130,7 @@ int vn_profile_begin(vn_ctx* ctx, int max_launches);
  * periodic schedule is sampled): two hipEventRecords cost ~7 us of stream time per bracketed launch (2.3 % of a B = 8
  * vamp() step, 11 % at B = 1 with stride 1).  The returned statistics then cover the sampled launches only.       */
 int vn_profile_set_stride(vn_ctx* ctx, int stride);
-int vn_profile_end(vn_ctx* ctx, double* stats16);
+int vn_profile_end(vn_ctx* ctx, double* stats24);
 
 /* ---- weights ------------------------------------------------------------------------------ */
 /* total number of floats in the packed blob */

@@ -210,7 +210,8 @@ static int launch_conv(vn_ctx* ctx, const vn_conv_args& a_in, hipStream_t s) {
     constexpr int LDS = 2 * (BM + BN) * BK * 4;
     const double bytes = 4.0 * ((double)a.B * a.T_in * a.C_in + (double)a.C_out * a.taps * a.C_in +
                                 (double)M * a.C_out * ((a.y ? 1 : 0) + (a.y2 ? 1 : 0) + (a.y2_16 ? 1.5 : 0) + (a.resid ? 1 : 0)));
-    const int pi = vn_prof_pre(ctx, 2, 2.0 * M * (double)a.C_out * a.taps * a.C_in, s, bytes);
+    const double fl = 2.0 * M * (double)a.C_out * a.taps * a.C_in;
+    const int pi = vn_prof_pre(ctx, vn_conv_class(fl, bytes, VN_PROF_CONV_F32, 157.3), fl, s, bytes);
     hipLaunchKernelGGL((vn_conv1d_f32_kernel<BM, BN, WM>), dim3(tiles_m * tiles_n), dim3(256), LDS, s, a, tiles_m, tiles_n);
     vn_prof_post(ctx, pi, s);
     VN_LAUNCH_CHECK(ctx);

@@ -202,7 +202,7 @@ extern "C" int vn_profile_set_stride(vn_ctx* ctx, int stride) {
 extern "C" int vn_profile_end(vn_ctx* ctx, double* st) {
     if (!ctx || !st) return VN_ERR_INVALID;
     vn_prof& p = ctx->prof;
-    for (int i = 0; i < 16; ++i) st[i] = 0.0;
+    for (int i = 0; i < 4 * VN_PROF_CLASSES; ++i) st[i] = 0.0;
     p.on = false;
     for (int i = 0; i < p.n; ++i) {
         VN_HIP_CHECK(ctx, hipEventSynchronize(p.ev[2 * i + 1]));

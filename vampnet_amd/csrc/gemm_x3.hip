@@ -1152,8 +1152,17 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
     const double n_out = (EPI == VN_EPI_GEGLU) ? a.N / 2 : a.N;
     const double bytes = (FMT ? 4.0 : 6.0) * ((double)a.M * a.K + (double)a.N * a.K) +
                          ((EPI == VN_EPI_GEGLU && a.C16) ? (FMT ? 4.0 : 6.0) : 4.0) * (double)a.M * n_out * (EPI == VN_EPI_RESIDUAL ? 2 : 1);
-    // algorithmic (fp32-equivalent) flops; the codec's convolutions are booked under class 2 like conv1d_f32.hip's
-    const int pi = vn_prof_pre(ctx, EPI == VN_EPI_CONV ? 2 : 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);
+    // algorithmic (fp32-equivalent) flops.  The codec's convolutions are booked by what BOUNDS them (vn_conv_class): their own operand
+    // bytes — the activation planes are read once, not once per tap — against the ridge of this pipe (2500 / 6 TF over 8 TB/s)
+    int cls = 0;
+    double pbytes = bytes;
+    if constexpr (EPI == VN_EPI_CONV) {
+        const double rows_in = (double)(a.M / (a.conv_trows > 0 ? a.conv_trows : 1)) * a.conv_tin;
+        pbytes = (FMT ? 4.0 : 6.0) * (rows_in * a.conv_cin + (double)a.N * a.K) +
+                 (double)a.M * a.N * ((a.C ? 4.0 : 0.0) + (a.Y2 ? 4.0 : 0.0) + (a.C16 ? (FMT ? 4.0 : 6.0) : 0.0) + (a.resid ? 4.0 : 0.0));
+        cls = vn_conv_class(2.0 * a.M * (double)a.N * a.K, pbytes, VN_PROF_CONV_X3, 2500.0 / (FMT ? 3.0 : 6.0));
+    }
+    const int pi = vn_prof_pre(ctx, cls, 2.0 * a.M * (double)a.N * a.K, s, pbytes);
     int rc = VN_OK;
     // f16x2: half the matrix work per k-tile (profiles/history/r03_gemm_f16x2_plan_sweep.txt)
     const x3_plan plan = FMT ? x3_choose<EPI>(ctx, a, vn_num_cus(ctx), 0.85, 0.8)

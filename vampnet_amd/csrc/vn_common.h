@@ -352,7 +352,7 @@ struct vn_prof {
     int cap = 0, n = 0;
     unsigned stride = 1, seen = 0; // vn_profile_set_stride: bracket ~1 of every `stride` launches (hash-selected)
     hipEvent_t* ev = nullptr;      // 2 events per launch
-    int* cls = nullptr;            // class per launch (0 gemm, 1 attention)
+    int* cls = nullptr;            // class per launch (VN_PROF_*)
     double* flops = nullptr;
     double* bytes = nullptr;       // algorithmic operand bytes of the launch
 };
@@ -401,6 +401,16 @@ struct vn_ctx {
 };
 enum { VN_ATTR_ATTN = 1u, VN_ATTR_ATTN_TRAIN = 2u, VN_ATTR_REMASK = 4u, VN_ATTR_MT_JUMP = 8u, VN_ATTR_GEMM_X3 = 16u, VN_ATTR_ATTN_X3 = 32u, VN_ATTR_ATTN_X3_TRAIN = 64u,
        VN_ATTR_ATTN_X3_BWD = 128u };
+
+// launch classes of vn_profile_end (four doubles each: launches, ms, algorithmic flops, algorithmic bytes).  The codec's convolutions
+// are booked by the roofline that bounds them: arithmetic intensity (flops / operand bytes) at or above the ridge of the pipe the layer
+// runs on (split-plane pipe: 2500 / 6 TF over 8 TB/s = 52 flop / B; fp32-input MFMA: 157.3 TF over 8 TB/s = 19.7) -> that pipe's class,
+// below it -> the HBM class, whichever kernel runs it
+enum { VN_PROF_GEMM = 0, VN_PROF_ATTN = 1, VN_PROF_CONV_X3 = 2, VN_PROF_GEMM_BF16 = 3, VN_PROF_CONV_F32 = 4, VN_PROF_CONV_HBM = 5, VN_PROF_CLASSES = 6 };
+static inline int vn_conv_class(double flops, double bytes, int pipe_class, double pipe_peak_tf) {
+    const double ridge = pipe_peak_tf * 1e12 / 8.0e12;
+    return bytes > 0.0 && flops / bytes < ridge ? VN_PROF_CONV_HBM : pipe_class;
+}
 
 // bracket a launch with events when profiling is on (no-ops otherwise)
 static inline int vn_prof_pre(vn_ctx* ctx, int cls, double flops, hipStream_t s, double bytes = 0.0) {

@@ -100,11 +100,15 @@ class Engine:
         self.check(self.lib.vn_profile_begin(self.handle, max_launches), "vn_profile_begin")
 
     def profile_end(self):
-        """{'gemm': (launches, ms, flops, bytes), 'attention': (...), 'conv1d': (...)} since profile_begin."""
-        st = (C.c_double * 16)()
+        """{'gemm': (launches, ms, flops, bytes), 'attention': (...), ...} since profile_begin.  The codec's convolutions come in three
+        classes by what bounds them (csrc/vn_common.h VN_PROF_*): 'conv_x3' / 'conv_f32' = matrix-pipe-bound layers on the split-plane
+        pipe / on the fp32-input MFMA, 'conv_hbm' = layers whose operand bytes bound them (audio-rate and k = 1 layers); 'conv1d' = all."""
+        st = (C.c_double * 24)()
         self.check(self.lib.vn_profile_end(self.handle, st), "vn_profile_end")
-        return {"gemm": tuple(st[0:4]), "attention": tuple(st[4:8]), "conv1d": tuple(st[8:12]),
-                "gemm_bf16": tuple(st[12:16])}
+        out = {"gemm": tuple(st[0:4]), "attention": tuple(st[4:8]), "conv_x3": tuple(st[8:12]), "gemm_bf16": tuple(st[12:16]),
+               "conv_f32": tuple(st[16:20]), "conv_hbm": tuple(st[20:24])}
+        out["conv1d"] = tuple(sum(v) for v in zip(out["conv_x3"], out["conv_f32"], out["conv_hbm"]))
+        return out
 
     def __del__(self):
         try:
