@@ -11,7 +11,7 @@ echo "== (a), (b) block tile A/B"
 timeout 900 scripts/ubench/gemm_x3_tile_probe > $O/r06_gemm_tile_probe.txt 2>&1; echo rc=$?
 cat $O/r06_gemm_tile_probe.txt
 export TMPDIR=/tmp; cd /tmp
-for arm in 0 1 2 3; do
+for arm in 0 1 2 3 4 5; do
   rm -rf /tmp/pf$arm
   timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf$arm -o f -- $R/scripts/ubench/gemm_x3_tile_probe $arm 5 > /dev/null 2> $O/r06_tile_probe_pmc_err_$arm.txt
   python $R/scripts/pmc_summary.py /tmp/pf$arm FETCH_SIZE > $O/r06_tile_probe_fetch_arm$arm.txt 2>&1

@@ -57,7 +57,7 @@ GUARDED = ["tests/test_gpu_guard_cases.py", "tests/test_gpu_kernels.py"]
 def test_guarded_child_suite(mode):
     if os.environ.get("VN_GUARD_ALLOC"):
         pytest.skip("this IS a guarded child")
-    out = _child(["-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + GUARDED, {"VN_GUARD_ALLOC": mode}, timeout=1500)
+    out = _child(["-m", "pytest", "-x", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider"] + GUARDED, {"VN_GUARD_ALLOC": mode}, timeout=1500)
     tail = out.stdout[-3000:] + out.stderr[-3000:]
     assert out.returncode == 0, tail
     m = re.search(r"GUARD mode=(\d) blocks=(\d+)", out.stdout)
