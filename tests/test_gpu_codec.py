@@ -153,6 +153,9 @@ CONV_CASES = [  # (B, T_in, C_in, C_out, taps, in_stride, dil, pad, note)
     (2, 240, 128, 256, 8, 4, 1, 2, "strided down-sampling k = 2 s, s = 4"),
     (3, 100, 512, 192, 1, 1, 1, 0, "k = 1 tail"),
     (1, 33, 1024, 1024, 3, 1, 1, 1, "final encoder conv"),
+    (2, 301, 192, 192, 7, 1, 3, 9, "192 channels, k7 dilation 3: the channels-on-rows form (CONVT), ragged positions"),
+    (3, 130, 96, 96, 7, 1, 9, 27, "96 channels, k7 dilation 9: CONVT on the 96-row k-split tile"),
+    (1, 64, 384, 192, 2, 1, 1, 0, "two taps, 384 -> 192 (the shape of a transposed convolution's phase)"),
 ]
 
 
@@ -221,6 +224,56 @@ def test_conv1d_bf16x3_vs_torch_and_f32_kernel(eng, B, T, cin, cout, taps, strid
         back = planes[0].double() + planes[1].double() / 2048.0
         d = (back.reshape(B, T_out, cout) - dense.double()).abs()
         assert bool((d <= dense.double().abs() * 2.0 ** -22 + 2.0 ** -24).all()), name
+
+
+@pytest.mark.parametrize("B,T,cin,cout,taps,dil", [(2, 301, 192, 192, 7, 3), (1, 1000, 384, 192, 2, 1), (3, 130, 96, 96, 7, 9), (2, 257, 256, 96, 7, 1)])
+def test_conv_channels_on_rows_equals_the_column_tile_form(B, T, cin, cout, taps, dil):
+    """Round 6: 96- / 192-channel convolutions run with the output channels on the tile's ROW axis (gemm_x3.hip CONVT: Y^T = W X^T, the tap
+    gather on the W side, a transposed epilogue) — exactly one tile of rows instead of 128-wide column tiles that are three quarters full.
+    Against the column-tile form of the same entry (a context created with VN_X3_CONVT=0): 192 channels BITWISE (the same products in the
+    same order: one accumulator per output element, k-tiles in sequence), 96 channels to fp32 re-association noise (its 96-row tile splits
+    the k-steps of a k-tile between two wave groups and adds the halves); raw, snake fp32 and snake planes, bias + residual."""
+    import os
+    from vampnet_amd.codec import DacCodec
+    from vampnet_amd.engine import Engine
+    g = torch.Generator().manual_seed(cout + taps)
+    pad = dil * (taps - 1) // 2
+    x = torch.randn(B, T, cin, generator=g)
+    w = torch.randn(cout, taps, cin, generator=g) / math.sqrt(taps * cin)
+    bias, alpha = torch.randn(cout, generator=g), torch.rand(cout, generator=g) + 0.5
+    T_out = T + 2 * pad - dil * (taps - 1)
+    resid = torch.randn(B, T_out, cout, generator=g)
+    outs = []
+    for flag in ("1", "0"):
+        old = os.environ.get("VN_X3_CONVT")
+        os.environ["VN_X3_CONVT"] = flag
+        try:
+            e = Engine("cuda:0")                       # the switch is read when the context is created
+        finally:
+            if old is None:
+                os.environ.pop("VN_X3_CONVT", None)
+            else:
+                os.environ["VN_X3_CONVT"] = old
+        xd, wd, bd, ad, rd = (t.cuda().contiguous() for t in (x, w, bias, alpha, resid))
+        codec = DacCodec.__new__(DacCodec)
+        codec.engine, codec.lib, codec.device, codec.precision = e, e.lib, e.device, "bf16x3"
+        x16, w16 = e.split3(xd.reshape(-1, cin)), codec._tile_planes(wd.reshape(cout, -1))
+        y, y2 = torch.full((B, T_out, cout), float("nan"), device="cuda"), torch.full((B, T_out, cout), float("nan"), device="cuda")
+        y216 = torch.zeros(3, B * T_out, cout, device="cuda", dtype=torch.bfloat16)
+        e.check(e.lib.vn_conv1d_bf16x3(e.handle, x16.data_ptr(), B * T * cin, w16.data_ptr(), bd.data_ptr(), rd.data_ptr(), ad.data_ptr(),
+                                       y.data_ptr(), y2.data_ptr(), y216.data_ptr(), B * T_out * cout, B, T, T_out, T_out, cin, cout, taps,
+                                       1, dil, pad, 1, 0, 0, e.stream()), "vn_conv1d_bf16x3")
+        torch.cuda.synchronize()
+        outs.append((y.cpu(), y2.cpu(), y216.cpu()))
+    (ya, y2a, pa), (yb, y2b, pb) = outs
+    assert bool(torch.isfinite(ya).all()) and bool(torch.isfinite(y2a).all())
+    if cout == 192:
+        assert torch.equal(ya, yb) and torch.equal(y2a, y2b) and torch.equal(pa, pb)
+    else:
+        scale = yb.abs().max().item()
+        assert (ya - yb).abs().max().item() <= 2e-6 * scale and (y2a - y2b).abs().max().item() <= 4e-6 * max(1.0, y2b.abs().max().item())
+        p = pa.float()
+        assert torch.equal((p[0] + p[1] + p[2]).reshape(B, T_out, cout), y2a)
 
 
 def test_conv_transpose_phases_on_bf16x3(eng):

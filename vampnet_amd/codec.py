@@ -484,6 +484,10 @@ class DacCodec:
         taps = c.get("k", 2) if taps is None else taps
         cout = c["cout"]
         eff = cout / (128.0 * math.ceil(cout / 128))                   # fraction of the 128-wide column tiles that is real output
+        if self.precision == "bf16x3" and cout in (96, 192) and c["cin"] % 32 == 0:
+            # round 6: these run with the output channels on the tile's ROW axis (gemm_x3.hip CONVT: exactly one 96- / 192-row tile, nothing
+            # multiplies padding) — the same rule in csrc/codec_plan.hip (on_x3)
+            return taps * c["cin"] >= self.X3_MIN_WORK
         return (self.precision in ("bf16x3", "f16x2") and cout >= self.X3_MIN_COUT and cout % 16 == 0 and c["cin"] % 32 == 0
                 and taps * c["cin"] * eff >= self.X3_MIN_WORK)
 

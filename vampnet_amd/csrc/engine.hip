@@ -105,6 +105,7 @@ void vn_tune_init(vn_tune* t) {
     t->x3_staged = env_int("VN_X3_STAGED", 1) != 0;
     t->x3_group_m = env_int("VN_X3_GROUPM", 0);
     t->x3_tile96 = env_int("VN_X3_TILE96", 1) != 0;
+    t->x3_convt = env_int("VN_X3_CONVT", 1) != 0;
     t->ax_split = env_int("VN_ATTN_X3_SPLIT", -1);
     t->ax_lds = 0;
     t->ax_pair = env_int("VN_ATTN_X3_PAIR", 1) != 0;

@@ -598,6 +598,72 @@ __device__ __forceinline__ void x3_epilogue_image(const vn_gemm_args& p, const f
     }
 }
 
+// Epilogue of the CONVT mode (rows = output channels, columns = positions; CFG 3: 192 channels, CFG 4: 96 channels with the k-steps
+// split between the two wave groups).  Every wave drops its accumulators TRANSPOSED into its group's image [128 positions][BM + 4]
+// (a lane holds four consecutive channels of one position per register quad: 16-byte LDS stores, pitch BM + 4 floats = conflict-free),
+// one barrier, then the threads read whole position rows back — a thread keeps ONE group of four channels (bias, alpha, 1 / alpha in
+// registers), consecutive threads consecutive channel groups of one position: 16-byte global accesses that cover a position's channels
+// contiguously — add the groups in group order and run conv1d_f32.hip's epilogue expression (bias, residual, tanh, the next layer's Snake).
+template <int CFG>
+__device__ __forceinline__ void x3_epilogue_convt(const vn_gemm_args& p, const f32x16 (&acc)[x3_geo<CFG>::RI][x3_geo<CFG>::CJ], int n0,
+                                                  int wave, int lane, float* lds) {
+    using G = x3_geo<CFG>;
+    constexpr int RI = G::RI, CJ = G::CJ, BM = G::BM, KG = G::KG, PITCH = BM + 4, IMG = 128 * PITCH;
+    static_assert(KG * IMG <= G::NBUF * G::STAGE, "the transposed images fit in the stages");
+    const int wq = wave % (G::WR * G::WC), kg = wave / (G::WR * G::WC);
+    const int wm = wq / G::WC, wn = wq % G::WC, l31 = lane & 31, h = lane >> 5, tid = wave * 64 + lane;
+    __syncthreads();                                          // the k-loop's fragment reads are done in every wave
+    {
+        float* img = lds + kg * IMG;
+#pragma unroll
+        for (int i = 0; i < RI; ++i)
+#pragma unroll
+            for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int R0 = wm * 32 * RI + 32 * i + 8 * g4 + 4 * h;          // channels R0 .. R0 + 3 = registers 4 g4 .. 4 g4 + 3
+                    const f32x4 v = {acc[i][j][4 * g4], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]};
+                    *(f32x4*)(img + (wn * 32 * CJ + 32 * j + l31) * PITCH + R0) = v;
+                }
+    }
+    __syncthreads();
+    constexpr int NG = BM / 4, PPP = 512 / NG;                // channel groups of a position, positions per pass
+    if (tid >= NG * PPP) return;
+    const int c4 = (tid % NG) * 4;                            // this thread's four channels, for the whole tile
+    if (c4 >= p.M) return;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, al = {1.f, 1.f, 1.f, 1.f}, inv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4 = *(const f32x4*)(p.bias + c4);
+    if (p.Y2 || p.C16) {
+        al = *(const f32x4*)(p.alpha + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) inv[e] = 1.0f / (al[e] + 1e-9f);
+    }
+    bool bad = false;
+#pragma nounroll
+    for (int pos = tid / NG; pos < 128; pos += PPP) {
+        const int row = n0 + pos;                             // GEMM column = output position (b, t')
+        if (row >= p.N) break;
+        f32x4 v = *(const f32x4*)(lds + pos * PITCH + c4);
+#pragma unroll
+        for (int g = 1; g < KG; ++g) v += *(const f32x4*)(lds + g * IMG + pos * PITCH + c4);
+        v += bias4;
+        const int b = row / p.conv_trows, tq = row - b * p.conv_trows;
+        const int t_out = tq * p.conv_out_stride + p.conv_out_off;
+        if (t_out < 0 || t_out >= p.conv_tout) continue;
+        const long orow = (long)b * p.conv_tout + t_out;
+        const size_t o = (size_t)orow * p.M + c4;
+        if (p.resid) v += *(const f32x4*)(p.resid + o);
+        if (p.conv_act == 1) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
+        if (p.C) *(f32x4*)(p.C + o) = v;
+        if (p.Y2 || p.C16) {
+            const f32x4 w4 = {vn_snake(v[0], al[0], inv[0]), vn_snake(v[1], al[1], inv[1]), vn_snake(v[2], al[2], inv[2]),
+                              vn_snake(v[3], al[3], inv[3])};
+            if (p.Y2) *(f32x4*)(p.Y2 + o) = w4;
+            if (p.C16) vn_store_planes4(p.C16, p.c_plane, orow, c4, p.M, w4, bad);
+        }
+    }
+}
+
 // one block per output tile (gridDim.y > 1: split-K images, store epilogue only)
 // ABL (tuning only, results invalid): bit 0 = no DMA inside the k-loop, bit 1 = no fragment reads inside the k-loop, bit 2 =
 // every DMA instruction fetches 8 rows x 128 B (whole cache lines, same volume) instead of 16 rows x 64 B
@@ -639,9 +705,10 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         auto piece_q = [&](int j) { return (CFG == 3 || CFG == 4) ? 8 * j + wave : wave * G::NPW + j; };
         constexpr int NA_PIECES = NP * (G::BM / 16);                // DMA instructions of a stage that fetch A
         constexpr bool CONV = EPI == VN_EPI_CONV;
+        constexpr bool CONVT = EPI == VN_EPI_CONVT;         // the gather on the W side (rows of the W operand = output positions)
         const uint16_t* src[G::NPW];
         int kadv[G::NPW];                                   // elements per k-tile: 32 along a planar row, 3 x 512 between tiled pieces
-        int t0v[CONV ? G::NPW : 1];                         // CONV: input row of tap 0 for this lane's A row (may be < 0 / >= T_in)
+        int t0v[(CONV || CONVT) ? G::NPW : 1];              // CONV / CONVT: input row of tap 0 for this lane's gathered row (may be < 0 / >= T_in)
 #pragma unroll
         for (int j = 0; j < G::NPW; ++j) {
             const int q = piece_q(j);
@@ -667,6 +734,12 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                 const int pt = qb >> 3, row = (qb & 7) * 16 + drow;
                 int g = n0 + row;
                 g = g < p.N ? g : p.N - 1;
+                if constexpr (CONVT) {
+                    // W row g = output position (b, t'): the activation planes [B T_in][C_in] (planar, w_plane apart), gathered per tap
+                    const int b = g / p.conv_trows, tq = g - b * p.conv_trows;
+                    t0v[j] = tq * p.conv_in_stride - p.conv_pad;
+                    src[j] = W16 + (size_t)pt * p.w_plane + ((long)b * p.conv_tin + t0v[j]) * (long)p.conv_cin + dslot * 8;
+                } else
                 if (p.w_tiled && !((ABL & 4) && !FMT)) {          // piece = the contiguous 1 KiB of (row block g / 16, k-tile, plane pt)
                     src[j] = W16 + (((size_t)(g >> 4) * nk_all + kb) * NP + pt) * 512 + (g & 15) * 32 + dslot * 8;
                     kadv[j] = NP * 512;
@@ -699,9 +772,9 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
             }
             float* base = lds + buf * G::STAGE + piece_q(j) * 256;
             const uint16_t* from;
-            if (CONV && piece_q(j) < NA_PIECES) {    // an A piece of the implicit GEMM: the tap's row, or zeros outside the signal
+            if ((CONV && piece_q(j) < NA_PIECES) || (CONVT && piece_q(j) >= NA_PIECES)) {    // a gathered piece of the implicit GEMM: the tap's row, or zeros outside the signal
                 conv_tile(kb + k0 / X3_KT);
-                const bool ok = (unsigned)(t0v[CONV ? j : 0] + cv_dt) < (unsigned)p.conv_tin;
+                const bool ok = (unsigned)(t0v[(CONV || CONVT) ? j : 0] + cv_dt) < (unsigned)p.conv_tin;
                 from = ok ? src[j] + cv_off : p.zeros16 + dslot * 8;
             } else {
                 if constexpr ((ABL & 4) && !FMT) k0 = (2 * k0) % p.K;     // a fresh 128-byte line per k-tile (probe: K % 64 == 0, data-parallel form)
@@ -784,7 +857,10 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                         else acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc_lo[i][j], 0, 0, 0);
                     }
             } else {
-                const int qa = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0, qb = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
+                // CONVT swaps the operands' roles (A = weights, W = activations): the plane PAIRS are taken in the mirrored order, so that
+                // every output element sees the same products in the same sequence as in the CONV form — bitwise the same sums
+                const int qa0 = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0, qb0 = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
+                const int qa = EPI == VN_EPI_CONVT ? qb0 : qa0, qb = EPI == VN_EPI_CONVT ? qa0 : qb0;
 #pragma unroll
                 for (int i = 0; i < RI; ++i)
 #pragma unroll
@@ -986,7 +1062,9 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
 #pragma unroll
                 for (int j = 0; j < CJ; ++j) acc[i][j] += acc_lo[i][j] * VN_H2_INV_SCALE;
         }
-        if constexpr (CFG == 4 || (CFG == 3 && EPI == VN_EPI_GEGLU && !FMT)) {
+        if constexpr (EPI == VN_EPI_CONVT) {
+            x3_epilogue_convt<CFG>(p, acc, n0, wave, lane, lds);
+        } else if constexpr (CFG == 4 || (CFG == 3 && EPI == VN_EPI_GEGLU && !FMT)) {
             // (CFG 3 + GEGLU: the 96 x 32 wave tile holds value and gate columns in different waves — they meet in the tile image)
             x3_epilogue_image<EPI, CFG, FMT>(p, acc, m0, n0, wave, lane, lds);       // the launcher guarantees the staged forms' alignment
         } else if constexpr (EPI == VN_EPI_CONV) {
@@ -1433,6 +1511,30 @@ extern "C" int vn_gemm_f16x2(vn_ctx* ctx, const void* A2, int64_t a_plane, const
     return vn_launch_gemm_x3(ctx, a, epilogue, (hipStream_t)stream);
 }
 
+// ---- CONVT: a convolution whose OUTPUT CHANNELS are the tile's rows (vn_common.h VN_EPI_CONVT).  Offered for C_out = 192 (CFG 3, one
+// 192-row tile) and C_out = 96 (CFG 4, one 96-row tile with the k-steps split between the wave groups), bf16x3 operands.  a.A = the tiled
+// weight planes [C_out][taps C_in], a.W = the planar activation planes (w_plane apart), M = C_out, N = B T_rows, K = taps C_in.
+static bool x3_convt_shape(int h2, int C_out, int C_in, int taps) {
+    return !h2 && (C_out == 192 || C_out == 96) && C_in % X3_KT == 0 && taps > 0;
+}
+static int x3_launch_convt(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
+    if (!(ctx->attr_mask & VN_ATTR_GEMM_X3_CONVT)) {
+        int rc;
+        if ((rc = x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_CONVT, 3, 0, 0>, x3_lds_bytes<3, 3>())) ||
+            (rc = x3_attr(ctx, vn_gemm_x3_kernel<VN_EPI_CONVT, 4, 0, 0>, x3_lds_bytes<4, 3>())))
+            return rc;
+        ctx->attr_mask |= VN_ATTR_GEMM_X3_CONVT;
+    }
+    const double fl = 2.0 * a.M * (double)a.N * a.K;
+    const double rows_in = (double)(a.N / a.conv_trows) * a.conv_tin;
+    const double pbytes = 6.0 * (rows_in * a.conv_cin + (double)a.M * a.K) +
+                          (double)a.M * a.N * ((a.C ? 4.0 : 0.0) + (a.Y2 ? 4.0 : 0.0) + (a.C16 ? 6.0 : 0.0) + (a.resid ? 4.0 : 0.0));
+    const int pi = vn_prof_pre(ctx, vn_conv_class(fl, pbytes, VN_PROF_CONV_X3, 2500.0 / 6.0), fl, s, pbytes);
+    const int rc = a.M == 192 ? x3_go<VN_EPI_CONVT, 3, 0, 0>(ctx, a, 1, s) : x3_go<VN_EPI_CONVT, 4, 0, 0>(ctx, a, 1, s);
+    vn_prof_post(ctx, pi, s);
+    return rc;
+}
+
 // ---- the DAC convolutions on the bf16x3 pipe (codec rows a18 / a19; PARITY UNPINNED like conv1d_f32.hip) -------------------------
 // y[b][t_out][co] = act(bias[co] + sum_{j < taps} sum_ci w[co][j][ci] x[b][t' in_stride + j dil - pad][ci] (+ resid)), t_out = t'
 // out_stride + out_off — conv1d_f32.hip's operator with the products on the bf16 matrix cores at fp32 grade: x16 = three split planes
@@ -1449,6 +1551,21 @@ static int conv1d_planes(vn_ctx* ctx, int h2, const void* x16, int64_t x_plane, 
     if (!ctx->zero_page) {
         VN_HIP_CHECK(ctx, vn_dev_malloc((void**)&ctx->zero_page, 1024));
         VN_HIP_CHECK(ctx, hipMemset(ctx->zero_page, 0, 1024));
+    }
+    if (x3_convt_shape(h2, C_out, C_in, taps) && ctx->tune.x3_convt) {
+        // output channels on the tile's row axis: exactly one 192- / 96-row tile instead of 128-wide column tiles that are 3/4 full
+        if ((((uintptr_t)y | (uintptr_t)y2 | (uintptr_t)resid | (uintptr_t)bias | (uintptr_t)alpha) & 15) || ((uintptr_t)y2_16 & 7) ||
+            (y2_16 && (y2_plane <= 0 || (y2_plane & 3))) || x_plane <= 0 || (x_plane & 7) || (((uintptr_t)x16 | (uintptr_t)w_tiled) & 15) ||
+            ((y2 || y2_16) && !alpha) || T_in <= 0 || T_out <= 0)
+            return vn_fail(ctx, VN_ERR_INVALID, "conv1d_bf16x3: outputs / bias / alpha must be 16-byte aligned, planes planar%s", "");
+        vn_gemm_args t{};
+        t.A = (const float*)w_tiled; t.W = (const float*)x16; t.bias = bias; t.C = y; t.C16 = (uint16_t*)y2_16; t.c_plane = y2_plane;
+        t.bf16 = 2; t.a_plane = VN_PLANES_TILED; t.w_plane = x_plane; t.w_tiled = 0;
+        t.M = C_out; t.N = B * T_rows; t.K = taps * C_in; t.ldc = C_out;
+        t.conv_taps = taps; t.conv_cin = C_in; t.conv_tin = T_in; t.conv_trows = T_rows; t.conv_in_stride = in_stride; t.conv_dil = dil;
+        t.conv_pad = pad; t.conv_tout = T_out; t.conv_out_stride = out_stride; t.conv_out_off = out_off; t.conv_act = act;
+        t.zeros16 = (const uint16_t*)ctx->zero_page; t.resid = resid; t.alpha = alpha; t.Y2 = y2;
+        return x3_launch_convt(ctx, t, (hipStream_t)stream);
     }
     vn_gemm_args a{};
     a.A = (const float*)x16; a.W = (const float*)w_tiled; a.bias = bias; a.C = y; a.C16 = (uint16_t*)y2_16;

@@ -368,6 +368,7 @@ struct vn_tune {
     // settable only through vn_debug_x3_config), fused reduce + norm, LDS-staged epilogues, tile-walk group height (0 = 8)
     int x3_bm, x3_split, x3_abl, x3_fuse_norm, x3_staged, x3_group_m;
     int x3_tile96;           // gemm_x3.hip: the planner may pick the 96-row k-split tile (VN_X3_TILE96, default 1; bf16x3 operands)
+    int x3_convt;            // gemm_x3.hip: 96- / 192-channel convolutions with the channels on the tile's row axis (VN_X3_CONVT, default 1)
     // attention_x3.hip: decomposition (-1 by shape, 0 shared tiles, 1 / 2 / 4 key-split waves), dynamic-LDS override of the shared
     // kernel (occupancy probe), start stagger, phase-trace buffer (device)
     int ax_split, ax_lds, ax_stagger;
@@ -400,7 +401,7 @@ struct vn_ctx {
     unsigned attr_mask;
 };
 enum { VN_ATTR_ATTN = 1u, VN_ATTR_ATTN_TRAIN = 2u, VN_ATTR_REMASK = 4u, VN_ATTR_MT_JUMP = 8u, VN_ATTR_GEMM_X3 = 16u, VN_ATTR_ATTN_X3 = 32u, VN_ATTR_ATTN_X3_TRAIN = 64u,
-       VN_ATTR_ATTN_X3_BWD = 128u };
+       VN_ATTR_ATTN_X3_BWD = 128u, VN_ATTR_GEMM_X3_CONVT = 256u };
 
 // launch classes of vn_profile_end (four doubles each: launches, ms, algorithmic flops, algorithmic bytes).  The codec's convolutions
 // are booked by the roofline that bounds them: arithmetic intensity (flops / operand bytes) at or above the ridge of the pipe the layer
@@ -455,7 +456,10 @@ static inline int vn_cdiv(int a, int b) { return (a + b - 1) / b; }
 // V TRANSPOSED (through the epilogue's LDS image) and blocked by tiles of 32 global token rows
 // CONV (gemm_x3.hip only): implicit-GEMM 1-D convolution of the DAC stacks — A rows gathered per tap, epilogue = bias (+ residual)
 // (+ tanh) -> y, snake(y) -> y2 as fp32 and / or split planes (conv1d_f32.hip's epilogue on the bf16x3 pipe)
-enum { VN_EPI_STORE = 0, VN_EPI_BIAS = 1, VN_EPI_RESIDUAL = 2, VN_EPI_GEGLU = 3, VN_EPI_QKV = 4, VN_EPI_QKV3 = 5, VN_EPI_CONV = 6 };
+// CONVT (gemm_x3.hip only, round 6): the same convolution with the operands' roles swapped — Y^T[C_out][positions] = W [C_out][taps C_in] X^T:
+// the OUTPUT CHANNELS are the tile's rows (M = C_out = exactly one 96- or 192-row tile: nothing multiplies padding, where 128-wide column
+// tiles waste a quarter of a 192-channel layer), the positions its columns; the tap gather runs on the W side, the epilogue transposes
+enum { VN_EPI_STORE = 0, VN_EPI_BIAS = 1, VN_EPI_RESIDUAL = 2, VN_EPI_GEGLU = 3, VN_EPI_QKV = 4, VN_EPI_QKV3 = 5, VN_EPI_CONV = 6, VN_EPI_CONVT = 7 };
 
 struct vn_gemm_args {
     const float* A;      // [M][K] row-major, lda = K
