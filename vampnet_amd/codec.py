@@ -11,6 +11,7 @@ vn_conv1d_f32 (exact-f32 MFMA implicit GEMM with fused bias / residual / next-la
 vn_rvq_encode/decode.  Activations are channels-last [B][T][C] fp32 on the device.
 """
 import math
+import os
 from pathlib import Path
 
 import numpy as np
@@ -352,6 +353,9 @@ class DacCodec:
     # K x (tile efficiency) >= 512, K = taps * C_in.  The 64- and 96-channel audio-rate blocks, the small k = 1 tails and the
     # 1-channel stem / head stay on the fp32 kernels; every epilogue writes its Snake output in the format its consumer reads.
     X3_MIN_COUT, X3_MIN_WORK = 128, 512
+    # 96 / 192-channel layers (channels-on-rows form): taps x C_in from which the layer runs on the split-plane pipe; csrc/codec_plan.hip reads
+    # the same variable
+    X3_MIN_WORK_CONVT = int(os.environ.get("VN_CODEC_CONVT_MIN_WORK", "512"))
 
     def __init__(self, sd: dict, cfg: dict = None, device="cuda:0", engine: Engine = None, precision: str = DEFAULT_PRECISION):
         cfg = dict(DEFAULT_CFG, **(cfg or {}))
@@ -487,7 +491,7 @@ class DacCodec:
         if self.precision == "bf16x3" and cout in (96, 192) and c["cin"] % 32 == 0:
             # round 6: these run with the output channels on the tile's ROW axis (gemm_x3.hip CONVT: exactly one 96- / 192-row tile, nothing
             # multiplies padding) — the same rule in csrc/codec_plan.hip (on_x3)
-            return taps * c["cin"] >= self.X3_MIN_WORK
+            return taps * c["cin"] >= self.X3_MIN_WORK_CONVT
         return (self.precision in ("bf16x3", "f16x2") and cout >= self.X3_MIN_COUT and cout % 16 == 0 and c["cin"] % 32 == 0
                 and taps * c["cin"] * eff >= self.X3_MIN_WORK)
 

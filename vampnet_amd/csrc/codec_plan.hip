@@ -167,7 +167,10 @@ struct Builder {
     // the routing rule of vampnet_amd/codec.py (_on_x3): on the split-plane pipe where that is MFMA-bound
     bool on_x3(const Conv& c, int taps) const {
         const double eff = c.cout / (128.0 * ceil(c.cout / 128.0));
-        if (precision == 2 && (c.cout == 96 || c.cout == 192) && c.cin % 32 == 0) return taps * c.cin >= 512;     // CONVT (gemm_x3.hip): no padding
+        if (precision == 2 && (c.cout == 96 || c.cout == 192) && c.cin % 32 == 0) {     // CONVT (gemm_x3.hip): no padding
+            static const int min_work = [] { const char* e = getenv("VN_CODEC_CONVT_MIN_WORK"); return e && *e ? atoi(e) : 512; }();
+            return taps * c.cin >= min_work;
+        }
         return (precision == 2 || precision == 3) && c.cout >= 128 && c.cout % 16 == 0 && c.cin % 32 == 0 && taps * c.cin * eff >= 512;
     }
     const uint16_t* tile_planes(const float* w2d, long rows, int K) {
