@@ -231,6 +231,11 @@ int vn_gemm_bf16(vn_ctx* ctx, const void* A16, const void* W16, const float* bia
  * producers write it directly).                                                                                         */
 int vn_gemm_bf16x3(vn_ctx* ctx, const void* A3, int64_t a_plane, const void* W3, int64_t w_plane, const float* bias,
                    float* C, int M, int N, int K, int epilogue, void* stream);
+/* The same kernel in its TN operand mode: C [M][N] = At^T Wt with BOTH operands token-major, At [tokens][M] and Wt [tokens][N], given
+ * as their TILED planes ([token / 16][column / 32][plane][16][32]: the layout every activation operand already has).  The weight
+ * gradients of training (dW = dY^T X, train.hip) use it: no transposing pass, the fragment reads transpose in LDS (ds_read_b64_tr_b16).
+ * M % 32 == 0, N % 64 == 0; rows past `tokens` inside the last 16-row block must be zero.                                  */
+int vn_gemm_bf16x3_tn(vn_ctx* ctx, const void* At3, const void* Wt3, float* C, int M, int N, int tokens, void* stream);
 
 /* "f16x2": the second fp32-grade operand format of the same kernel (gemm_x3.hip).  An operand is TWO fp16 planes, h0 = fp16(x)
  * and h1 = fp16((x - h0) * 2^11): x = h0 + 2^-11 h1 to within 2^-22 |x| (four times fp32's own representation error, random in

@@ -555,6 +555,34 @@ def test_gemm_bf16x3_tiled_operands_equal_planar(eng, x3_pipe, M, N, K):
     assert torch.equal(o1, o2)
 
 
+@pytest.mark.parametrize("M,N,tokens", [(1280, 3840, 4600), (5120, 1280, 575), (1280, 2560, 2300), (256, 128, 130), (32, 64, 1), (96, 192, 47),
+                                        (160, 320, 291), (4096, 1280, 1150)])
+def test_gemm_bf16x3_token_major_operands_equal_the_transposed_ones(eng, M, N, tokens):
+    """TN operand mode (round 6; the dW GEMMs of training): C = At^T Wt read straight from the token-major tiled planes — the LDS transposing
+    read builds the fragments — against the NT kernel on the explicitly transposed matrices: the same products in the same order, so
+    BITWISE equal at every tile height, with and without the k-split; ragged token counts (the zero page stands in for the missing
+    16-token block, the zero rows of the last block contribute exact zeros); asymmetric inputs (a transposed C or swapped operands
+    cannot pass)."""
+    at = (_rand((tokens, M), 71) * torch.linspace(0.5, 2.0, M)).cuda()
+    wt = (_rand((tokens, N), 72) / np.sqrt(tokens)).cuda()
+    at_t, wt_t = eng.tile3(eng.split3(at)), eng.tile3(eng.split3(wt))            # tile3 zero-pads the rows to 16
+    Kp = (tokens + 31) // 32 * 32
+    pad = lambda x: torch.cat([x, x.new_zeros(Kp - tokens, x.shape[1])], 0).t().contiguous()
+    a3, w3 = eng.split3(pad(at)), eng.split3(pad(wt))                            # [3][M][Kp], [3][N][Kp]
+    for bm, split in [(128, 1), (192, 1), (256, 1), (128, 2), (0, -1)]:
+        _x3_cfg(eng, bm, split)
+        try:
+            got = eng.gemm_bf16x3_tn(at_t, wt_t, M, N, tokens)
+            if bm:
+                want = eng.gemm_bf16x3(a3, w3)
+                assert torch.equal(got, want), (bm, split, (got - want).abs().max().item())
+            else:                                                                # by-shape plan: the NT side may pick the 96-row k-split tile
+                ref = at.double().t() @ wt.double()
+                assert (got.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-30     # fp32 accumulation over up to 4600 tokens
+        finally:
+            _x3_cfg(eng)
+
+
 def test_gemm_bf16x3_identity_and_geglu(eng, x3_pipe):
     from vampnet_amd import _lib
     K = N = 256

@@ -565,6 +565,38 @@ def test_training_trajectory_tracks_oracle(engine):
     assert out["loss"].item() < 7.0          # and it learns (starts at ~7.1 = ln(1024) + smoothing)
 
 
+@pytest.mark.parametrize("B,T", [(2, 32), (3, 29), (1, 575)])
+def test_weight_gradients_without_transposes_equal_the_transposed_form(engine, monkeypatch, B, T):
+    """Round 6: the dW GEMMs read dY's and X's token-major tiled planes directly (gemm_x3.hip TN operand mode; X's planes are the ones the
+    forward GEMM read, kept per layer) — against VN_TRAIN_TN=0, the form that transposes both into fresh planes first.  Same six plane
+    products over the same tokens; the two may pick different tile heights / k-splits (the transposed form also has the 96-row tile), so
+    the bar is 2e-6 of each tensor's largest gradient, loss bitwise (the forward pass is the same kernels on the same planes).  Ragged
+    token counts (B T % 16, % 32 != 0: the zero page and the zero pad rows of the stash), and a SECOND step with fewer tokens on the same
+    trainer (the pad rows of the earlier shape must not leak into the contraction)."""
+    dims = W.TINY_COARSE_DIMS if T < 100 else W.COARSE_DIMS
+    sd, cb = W.synth_state_dict(dims, 0), W.synth_codebooks()
+    out = {}
+    for tn in ("1", "0"):
+        monkeypatch.setenv("VN_TRAIN_TN", tn)
+        tr = _trainer(engine, dims, sd, cb, max_batch=B, max_T=T, dropout=0.1 if T < 100 else 0.0, seed=5)
+        res = []
+        for (b, t_) in ([(B, T), (B, T - 5), (B, T)] if T < 100 else [(B, T)]):
+            z = W.synth_codes(b, 4 if T < 100 else dims["n_codebooks"], t_, seed=9 + t_)
+            mask = TO.make_training_mask(z, torch.linspace(0.3, 0.9, b), 0, generator=torch.Generator().manual_seed(2))
+            z_mask, target = tr.make_batch(z, mask=mask)
+            loss = tr.forward_backward(z_mask, target).clone()
+            res.append((loss.cpu(), tr.grads.clone().cpu()))
+        out[tn] = res
+        del tr
+    for (la, ga), (lb, gb) in zip(out["1"], out["0"]):
+        assert torch.equal(la, lb)
+        assert torch.isfinite(ga).all()
+        assert (ga - gb).abs().max().item() <= 2e-6 * gb.abs().max().item()
+        assert float(((ga - gb).double().norm() / gb.double().norm())) < 1e-6
+    if len(out["1"]) > 1:
+        assert not torch.equal(out["1"][0][1], out["1"][1][1])          # (the shorter batch is a different problem, not a cached result)
+
+
 @pytest.mark.skipif(os.environ.get("VN_TRAIN_X3") == "0", reason="this IS the child process")
 def test_training_step_on_the_fp32_input_mfma():
     """Since round 5 every training GEMM (forward, dX, dW) runs on the split-plane pipe by default (gemm_x3.hip, bf16x3: weights and

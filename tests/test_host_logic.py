@@ -810,7 +810,8 @@ def test_attention_x3_key_split_dma_addressing():
 
 def test_codec_routing_rule():
     """DacCodec._on_x3: which convolutions of the published 44.1 kHz DAC configuration run on the bf16x3 pipe — the table behind
-    DESIGN.md section 3 (>= 128 output channels and K x tile efficiency >= 512), and nothing at all in the f32 pipe."""
+    DESIGN.md section 3 (>= 128 output channels and K x tile efficiency >= 512; round 6: the 96- / 192-channel layers with taps x C_in >= 512 in
+    the channels-on-rows form, bf16x3 operands only), and nothing at all in the f32 pipe."""
     from vampnet_amd.codec import DacCodec
     c = DacCodec.__new__(DacCodec)
     c.precision = "bf16x3"
@@ -819,11 +820,13 @@ def test_codec_routing_rule():
         (64, 64, 7): False, (128, 64, 4): False, (128, 128, 7): True, (128, 128, 1): False, (256, 128, 8): True, (256, 256, 7): True,
         (256, 256, 1): False, (512, 256, 16): True, (512, 512, 7): True, (512, 512, 1): True, (1024, 512, 24): True, (1024, 1024, 3): True,
         (1536, 1024, 7): True, (768, 1536, 2): True, (768, 768, 7): True, (768, 768, 1): True, (384, 768, 2): True, (384, 384, 7): True,
-        (384, 384, 1): False, (192, 384, 2): True, (192, 192, 7): True, (192, 192, 1): False, (96, 192, 2): False, (96, 96, 7): False,
+        (384, 384, 1): False, (192, 384, 2): True, (192, 192, 7): True, (192, 192, 1): False, (96, 192, 2): False, (96, 96, 7): True,
         (96, 96, 1): False}
     for (cout, cin, k), want in table.items():
         assert c._on_x3(conv(cout, cin, k)) == want, (cout, cin, k)
         assert c._fmt(conv(cout, cin, k)) == ("x3" if want else "f32")
+    c.precision = "f16x2"                                     # the channels-on-rows form exists for bf16x3 operands only
+    assert not c._on_x3(conv(96, 96, 7)) and c._on_x3(conv(192, 192, 7)) and c._on_x3(conv(384, 384, 7))
     c.precision = "f32"
     assert not any(c._on_x3(conv(*key)) for key in table)
 

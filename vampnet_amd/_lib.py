@@ -68,6 +68,7 @@ SYMBOLS = {
     "vn_saturation_flags": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int, _P]),
     "vn_split3_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _P]),
     "vn_gemm_bf16x3": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "vn_gemm_bf16x3_tn": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "vn_split2_f16": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int64, C.c_int, _P]),
     "vn_gemm_f16x2": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vn_gemm_bf16": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

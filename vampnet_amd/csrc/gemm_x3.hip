@@ -124,6 +124,22 @@ __device__ __forceinline__ void x3_tile_coords(int t, int tiles_m, int tiles_n, 
     tn = in_grp / gsz;
 }
 
+// Operand mode bit of the kernel's ABL parameter (the other bits are tuning ablations): TN — C[M][N] = A^T W with BOTH operands given
+// token-major, A [K][M] and W [K][N], as the tiled planes [k / 16][row / 32][plane][16][32] — which is, byte for byte, the tiled layout
+// [token / 16][feature / 32][plane][16][32] of an activation matrix [tokens][features] that the NT form reads as its A operand.  The dW
+// GEMMs of training (dW = dY^T X, contraction over the tokens) therefore read the planes that dX's GEMM and the forward pass already
+// made — no transposing pass (round 6; train.hip grad_weight).  The DMA copies the same 1 KiB pieces; only the fragment read differs:
+// ds_read_b64_tr_b16, the LDS transposing read of gfx950 (two per fragment instead of one ds_read_b128).
+#define X3_MODE_TN 8
+typedef short x3_s16x4 __attribute__((ext_vector_type(4)));
+typedef float x3_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 x3_tr_frag(const float* at) {
+    const auto* q = (const __attribute__((address_space(3))) x3_s16x4*)at;
+    const x3_f32x2 lo = __builtin_bit_cast(x3_f32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) x3_s16x4*)q));
+    const x3_f32x2 hi = __builtin_bit_cast(x3_f32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) x3_s16x4*)(q + 32)));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
 #define X3_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define X3_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 // raw barrier (no implied vmcnt(0): LDS-DMA stays in flight across it); the asm fences keep hipcc from moving LDS accesses over it
@@ -706,6 +722,7 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         constexpr int NA_PIECES = NP * (G::BM / 16);                // DMA instructions of a stage that fetch A
         constexpr bool CONV = EPI == VN_EPI_CONV;
         constexpr bool CONVT = EPI == VN_EPI_CONVT;         // the gather on the W side (rows of the W operand = output positions)
+        constexpr bool TN = (ABL & X3_MODE_TN) != 0;        // both operands token-major (the dW GEMMs of training): see X3_MODE_TN
         const uint16_t* src[G::NPW];
         int kadv[G::NPW];                                   // elements per k-tile: 32 along a planar row, 3 x 512 between tiled pieces
         int t0v[(CONV || CONVT) ? G::NPW : 1];              // CONV / CONVT: input row of tap 0 for this lane's gathered row (may be < 0 / >= T_in)
@@ -713,6 +730,17 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         for (int j = 0; j < G::NPW; ++j) {
             const int q = piece_q(j);
             kadv[j] = X3_KT;
+            if constexpr (TN) {
+                // piece q = (plane pt, 32-row block r >> 1 of the tile, k-step r & 1 = q & 1): the contiguous 1 KiB [16 tokens][32 rows] of the
+                // token-major tiled planes, copied lane-linearly (16 bytes per lane)
+                int pt, r, fb, nfb;
+                const uint16_t* base;
+                if (q < NA_PIECES) { pt = q / (G::BM / 16); r = q % (G::BM / 16); fb = (m0 >> 5) + (r >> 1); nfb = p.M >> 5; base = A16; }
+                else { const int qb = (q - NA_PIECES) % (8 * NP); pt = qb >> 3; r = qb & 7; fb = (n0 >> 5) + (r >> 1); nfb = p.N >> 5; base = W16; }
+                fb = fb < nfb ? fb : nfb - 1;
+                src[j] = base + (((size_t)(2 * kb + (r & 1)) * nfb + fb) * NP + pt) * 512 + lane * 8;
+                kadv[j] = 2 * nfb * NP * 512;
+            } else
             if (q < NA_PIECES) {
                 const int pt = q / (G::BM / 16), row = (q % (G::BM / 16)) * 16 + drow;
                 int g = m0 + row;
@@ -776,6 +804,10 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
                 conv_tile(kb + k0 / X3_KT);
                 const bool ok = (unsigned)(t0v[(CONV || CONVT) ? j : 0] + cv_dt) < (unsigned)p.conv_tin;
                 from = ok ? src[j] + cv_off : p.zeros16 + dslot * 8;
+            } else if constexpr (TN) {
+                // token block 2 (kb + k-tile) + k-step of the piece; blocks past the last token come from the zero page
+                const bool ok = 2 * (kb + k0 / X3_KT) + (piece_q(j) & 1) < p.tn_blocks;
+                from = ok ? src[j] + (size_t)(k0 / X3_KT) * kadv[j] : p.zeros16 + lane * 8;
             } else {
                 if constexpr ((ABL & 4) && !FMT) k0 = (2 * k0) % p.K;     // a fresh 128-byte line per k-tile (probe: K % 64 == 0, data-parallel form)
                 else k0 = (k0 / X3_KT) * kadv[j];
@@ -833,6 +865,21 @@ __global__ __launch_bounds__(512, 2) void vn_gemm_x3_kernel(vn_gemm_args p, int 
         auto load_frags = [&](Frags& f, int buf, int s) {
             const float* sA = lds + buf * G::STAGE;
             const float* sB = sA + NP * G::APLANE;
+            if constexpr (TN) {
+                // a piece is [16 k][32 rows] with 64-byte k-rows: the transposing read hands lane l the k's 8 (l >> 5) + 4 c .. + 3 (c = 0, 1:
+                // two reads 256 bytes apart) of row l & 31 — exactly the MFMA fragment (scripts/ubench/tr_read_probe.hip,
+                // profiles/r06_tr_read_probe.txt); each 16-lane group reads [4 k][16 rows], lane (l & 15) supplying k-row (l & 15) >> 2,
+                // rows 4 (l & 3) .. + 3 of its half
+                const int trl = (8 * h + ((lane & 15) >> 2)) * 16 + ((lane >> 4) & 1) * 8 + (lane & 3) * 2;     // floats
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                    for (int i = 0; i < RI; ++i) f.a[q][i] = x3_tr_frag(sA + q * G::APLANE + ((wm * RI + i) * 2 + s) * 256 + trl);
+#pragma unroll
+                    for (int j = 0; j < CJ; ++j) f.b[q][j] = x3_tr_frag(sB + q * X3_BPLANE + ((wn * CJ + j) * 2 + s) * 256 + trl);
+                }
+                return;
+            }
             const int off = ((2 * s + h) ^ sw) * 4;
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
@@ -1170,7 +1217,8 @@ static bool x3_tile96_ok(const vn_ctx* ctx, const vn_gemm_args& a) {
     else return ctx->tune.x3_tile96 && x3_staged_ok<EPI>(ctx, a) != 0;
 }
 template <int EPI>
-static x3_plan x3_choose(const vn_ctx* ctx, const vn_gemm_args& a, int cus, double kt_us = 1.45, double partial = 1.0, bool allow96 = false) {
+static x3_plan x3_choose(const vn_ctx* ctx, const vn_gemm_args& a, int cus, double kt_us = 1.45, double partial = 1.0, bool allow96 = false,
+                          double rel128 = 1.0) {
     int bm_forced = ctx->tune.x3_bm;                         // 0 = by shape
     if (bm_forced == 96 && !allow96) bm_forced = 128;
     const int split_forced = ctx->tune.x3_split == -2 ? -1 : ctx->tune.x3_split;      // 0 / 1 off, 2 / 4 forced, -1 cost model
@@ -1207,7 +1255,7 @@ static x3_plan x3_choose(const vn_ctx* ctx, const vn_gemm_args& a, int cus, doub
             // (the 96-row tile moves 17 % more operand bytes per flop: with every CU busy — several rounds — a k-tile costs 0.85 of a
             // 128-row tile's, measured at M = 4600 (profiles/r05_gemm_tile96_check_and_sweep.txt: 243 vs 239 us for 6 vs 5 rounds); the
             // 0.77 of the table is the one-round figure)
-            const double relh = (bm == 96 && rounds > 1) ? 0.85 : rel[hi];
+            const double relh = (bm == 96 && rounds > 1) ? 0.85 : bm == 128 ? rel[hi] * rel128 : rel[hi];
             double cost = (double)rounds * (nk / (double)ns) * kt_us * relh + fixed[hi];
             if (blocks < cus) {
                 const double fill = (double)blocks / cus;
@@ -1296,6 +1344,38 @@ static int x3_launch(vn_ctx* ctx, const vn_gemm_args& a, hipStream_t s) {
     return rc;
 }
 
+// TN operand mode (X3_MODE_TN): the planner's tile height and k-split, the token-major kernels
+static int x3_launch_tn(vn_ctx* ctx, const vn_gemm_args& a_in, hipStream_t s) {
+    vn_gemm_args a = a_in;
+    if (!ctx->zero_page) {
+        VN_HIP_CHECK(ctx, vn_dev_malloc((void**)&ctx->zero_page, 1024));
+        VN_HIP_CHECK(ctx, hipMemset(ctx->zero_page, 0, 1024));
+    }
+    a.zeros16 = (const uint16_t*)ctx->zero_page;
+    const double bytes = 6.0 * ((double)a.M * a.K + (double)a.N * a.K) + 4.0 * (double)a.M * a.N;
+    const int pi = vn_prof_pre(ctx, 0, 2.0 * a.M * (double)a.N * a.K, s, bytes);
+    // (the 128-row tile's short phases — 12 MFMAs per k-step — hide the 18 transposing reads of a step worse than the 9 wide ones of the NT
+    // form: + 18 % per launch where the taller tiles measure the same as NT, profiles/r06_train_tn_vs_transposes.txt)
+    const x3_plan plan = x3_choose<VN_EPI_STORE>(ctx, a, vn_num_cus(ctx), 1.45, 1.0, false, 1.18);
+    auto go = [&](const vn_gemm_args& q, int ns) {
+        return plan.bm == 192 ? x3_go<VN_EPI_STORE, 3, X3_MODE_TN>(ctx, q, ns, s)
+             : plan.bm == 256 ? x3_go<VN_EPI_STORE, 2, X3_MODE_TN>(ctx, q, ns, s) : x3_go<VN_EPI_STORE, 1, X3_MODE_TN>(ctx, q, ns, s);
+    };
+    int rc;
+    if (plan.ns > 1) {
+        if (!ctx->x3_ws) VN_HIP_CHECK(ctx, vn_dev_malloc((void**)&ctx->x3_ws, (size_t)X3_WS_FLOATS * sizeof(float)));
+        vn_gemm_args q = a;
+        q.C = ctx->x3_ws;
+        q.ldc = a.N;
+        rc = go(q, plan.ns);
+        if (rc == VN_OK) rc = vn_launch_splitk_reduce(ctx, ctx->x3_ws, plan.ns, a.C, a.M, a.N, a.ldc, false, s);
+    } else {
+        rc = go(a, 1);
+    }
+    vn_prof_post(ctx, pi, s);
+    return rc;
+}
+
 template <typename K>
 static int x3_attr(vn_ctx* ctx, K kernel, size_t bytes) {
     VN_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -1355,7 +1435,14 @@ int vn_launch_gemm_x3(vn_ctx* ctx, const vn_gemm_args& a, int epilogue, hipStrea
             (rc = x3_attrs_abl<3, 1, 1>(ctx)) || (rc = x3_attrs_abl<3, 2, 1>(ctx)) || (rc = x3_attrs_abl<3, 3, 1>(ctx)) ||
             (rc = x3_attrs_abl<1, 4, 1>(ctx)) || (rc = x3_attrs_abl<2, 4, 1>(ctx)) || (rc = x3_attrs_abl<3, 4, 1>(ctx)))
             return rc;
+        if ((rc = x3_attrs_abl<1, X3_MODE_TN>(ctx)) || (rc = x3_attrs_abl<2, X3_MODE_TN>(ctx)) || (rc = x3_attrs_abl<3, X3_MODE_TN>(ctx))) return rc;
         ctx->attr_mask |= VN_ATTR_GEMM_X3;
+    }
+    if (a.tn_blocks > 0) {
+        if (epilogue != VN_EPI_STORE || h2 || a.a_plane != VN_PLANES_TILED || !a.w_tiled || (a.M & 31) || (a.ldc & 3) || !a.C ||
+            a.tn_blocks > a.K / 16 || a.tn_blocks <= a.K / 16 - 2)
+            return vn_fail(ctx, VN_ERR_INVALID, "gemm_x3/TN: STORE epilogue on tiled bf16x3 planes, M %% 32 == 0, K = the token count rounded up to 32 (M=%s%ld, K=%ld)", "", a.M, a.K);
+        return x3_launch_tn(ctx, a, s);
     }
     switch (epilogue) {
         case VN_EPI_STORE: return h2 ? x3_launch<VN_EPI_STORE, 1>(ctx, a, s) : x3_launch<VN_EPI_STORE>(ctx, a, s);
@@ -1441,6 +1528,17 @@ extern "C" int vn_gemm_bf16x3(vn_ctx* ctx, const void* A3, int64_t a_plane, cons
     a.bf16 = 2; a.a_plane = a_plane; a.w_plane = w_plane;
     a.w_tiled = w_plane == VN_PLANES_TILED;               // -1 for either stride: that operand is given in the tiled layout
     return vn_launch_gemm_x3(ctx, a, epilogue, (hipStream_t)stream);
+}
+
+// single-op entry of the TN operand mode (tests / tuning): At3 / Wt3 = TILED bf16x3 planes of the token-major matrices [tokens][M] / [tokens][N]
+// (rows past `tokens` inside the last 16-row block zero), C [M][N] = At^T Wt
+extern "C" int vn_gemm_bf16x3_tn(vn_ctx* ctx, const void* At3, const void* Wt3, float* C, int M, int N, int tokens, void* stream) {
+    if (!ctx || !At3 || !Wt3 || !C || tokens <= 0) return VN_ERR_INVALID;
+    vn_gemm_args a{};
+    a.A = (const float*)At3; a.W = (const float*)Wt3; a.C = C; a.M = M; a.N = N; a.K = (tokens + 31) & ~31; a.ldc = N;
+    a.bf16 = 2; a.a_plane = VN_PLANES_TILED; a.w_plane = VN_PLANES_TILED; a.w_tiled = 1;
+    a.tn_blocks = (tokens + 15) >> 4;
+    return vn_launch_gemm_x3(ctx, a, VN_EPI_STORE, (hipStream_t)stream);
 }
 
 // ---- f16x2 (vn_common.h vn_split2h): plane builders and the single-op entry -------------------------------------------------------

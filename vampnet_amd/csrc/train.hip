@@ -13,7 +13,10 @@
 // operands contiguous along the contraction axis, so
 //   dX: A = dY [M][N], B = W^T [K][N]     -> W^T copies of all GEMM weights, refreshed once per update (vn_train_sync)
 //   dW: A = dY^T [N][Mp], B = X^T [K][Mp] -> 64x64 LDS transposes of the two activations, Mp = M rounded up to 32 (zero
-//                                            filled), ~4 % of a step's time.
+//                                            filled), ~7 % of a step's time — the fp32 kernel and VN_TRAIN_TN=0.
+//   dW on the split-plane pipe (round 6, default): NO transposes.  gemm_x3.hip's TN operand mode contracts over the token axis of the
+//   token-major tiled planes themselves — dY's planes are the ones its dX GEMM reads anyway, X's planes are the ones the forward GEMM
+//   read, now kept in the layer's stash instead of a shared scratch buffer (vn_layer_stash::*_16).
 #include <new>
 #include <stdlib.h>
 #include <vector>
@@ -26,6 +29,9 @@ enum { SITE_ATTN = 0, SITE_RES1 = 1, SITE_FFN = 2, SITE_RES2 = 3 };
 struct vn_layer_stash {
     float *x_in, *y1, *qkv, *lse, *a, *x_mid, *y3, *u, *g;
     uint16_t *qk16, *vt16;         // attention on the split-plane pipe (vn_train::ax3): the q / k planes and the blocked V^T planes instead of qkv
+    // vn_train::tn: the tiled planes of the A operands of the layer's four forward GEMMs (y1 -> QKV, a -> Wo, y3 -> W1, g -> W2), kept for
+    // the dW GEMMs of the backward pass; rows past the token count inside the last 16-row block stay ZERO (vn_train::tn_rows)
+    uint16_t *y1_16, *a_16, *y3_16, *g_16;
 };
 
 struct vn_train {
@@ -57,6 +63,12 @@ struct vn_train {
     // the activation operand of a forward / dX GEMM (a16) and the two transposed operands of a dW GEMM (at16, bt16)
     bool x3;
     uint16_t *w16, *wT16, *a16, *at16, *bt16;
+    // dW without transposes (gemm_x3.hip X3_MODE_TN; VN_TRAIN_TN, default on with x3): yf16 = the planes of the final norm's output (the
+    // classifier's A operand), the layers' in vn_layer_stash.  tn_rows = the token count whose pad rows are known to be zero in all of them
+    // (a forward with another token count clears the buffers first)
+    bool tn;
+    uint16_t* yf16;
+    int tn_rows;
     // ... and the attention of the step as well (attention_x3.hip TRAIN forward, attention_train_x3.hip backward; VN_TRAIN_ATTN_X3, default
     // on with x3 when D % 128 == 0 and max_T fits the backward's LDS): the QKV GEMM writes the attention operands' planes (its
     // inference epilogue) into the layer's stash — no fp32 q / k / v exist; ax_ws = the backward's transposed / row-major plane images
@@ -141,8 +153,10 @@ static int talloc(vn_ctx* ctx, T** p, size_t n) {
 
 extern "C" void vn_train_destroy(vn_train* t) {
     if (!t) return;
+    (void)vn_dev_free(t->yf16);
     for (auto& s : t->st) {
         (void)vn_dev_free(s.qk16); (void)vn_dev_free(s.vt16);
+        (void)vn_dev_free(s.y1_16); (void)vn_dev_free(s.a_16); (void)vn_dev_free(s.y3_16); (void)vn_dev_free(s.g_16);
         float* a[] = {s.x_in, s.y1, s.qkv, s.lse, s.a, s.x_mid, s.y3, s.u, s.g};
         for (float* p : a) (void)vn_dev_free(p);
     }
@@ -176,6 +190,8 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
     t->dbias_partial = nullptr;
     t->w16 = t->wT16 = t->a16 = t->at16 = t->bt16 = nullptr;
     { const char* e = getenv("VN_TRAIN_X3"); t->x3 = !(e && e[0] == '0'); }
+    { const char* e = getenv("VN_TRAIN_TN"); t->tn = t->x3 && !(e && e[0] == '0'); }
+    t->yf16 = nullptr; t->tn_rows = 0;
     const vn_dims& d = m->d;
     const long D = m->D, L = m->L, rows = m->max_rows;
     t->ax_ws = nullptr; t->near_T = 0; t->near_r = 0;
@@ -240,8 +256,19 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
         if (rc == VN_OK) rc = talloc(ctx, &t->w16, (size_t)3 * w);
         if (rc == VN_OK) rc = talloc(ctx, &t->wT16, (size_t)3 * ((size_t)t->wT_layer * L + (size_t)t->NV * D));
         if (rc == VN_OK) rc = talloc(ctx, &t->a16, (size_t)3 * rows16 * (size_t)wide);
+        // (a TN GEMM contracts over the pad rows of a last 16-token block too: zero in the stash planes, and FINITE here — start from zeros)
+        if (rc == VN_OK && hipMemset(t->a16, 0, (size_t)3 * rows16 * (size_t)wide * 2) != hipSuccess) rc = VN_ERR_HIP;
         if (rc == VN_OK) rc = talloc(ctx, &t->at16, (size_t)3 * wide * t->Mp_max);
         if (rc == VN_OK) rc = talloc(ctx, &t->bt16, (size_t)3 * 2 * D * t->Mp_max);
+        if (t->tn) {
+            const size_t nd = (size_t)3 * rows16 * D;
+            auto Z = [&](uint16_t** p, size_t cnt) {
+                if (rc == VN_OK) rc = talloc(ctx, p, cnt);
+                if (rc == VN_OK && hipMemset(*p, 0, cnt * 2) != hipSuccess) rc = VN_ERR_HIP;
+            };
+            for (auto& st : t->st) { Z(&st.y1_16, nd); Z(&st.a_16, nd); Z(&st.y3_16, nd); Z(&st.g_16, 2 * nd); }
+            Z(&t->yf16, nd);
+        }
     }
     if (t->ax3) {
         vn_ax_bwd_ws w;
@@ -349,21 +376,23 @@ static const uint16_t* weight_planes(const vn_train* t, const float* W) {
 // a: an fp32 GEMM (A [M][K] row-major, W one of the step's weight tensors or transposes)
 // can this GEMM shape run on the split-plane pipe ?  (its producer may then write the planes of A into t->a16 itself: a_ready)
 static bool x3_shape(const vn_train* t, int N, int K) { return t->x3 && !(N & 63) && !(K & 31); }
-static int gemm_args(vn_train* t, vn_gemm_args a, int epi, hipStream_t s, bool a_ready = false) {
+// a16: where the planes of A live / go (default: the shared scratch t->a16; the forward pass of vn_train::tn names the layer's stash)
+static int gemm_args(vn_train* t, vn_gemm_args a, int epi, hipStream_t s, bool a_ready = false, uint16_t* a16 = nullptr) {
     vn_ctx* ctx = t->m->ctx;
     const uint16_t* w16 = t->x3 ? weight_planes(t, a.W) : nullptr;
     if (!w16 || !x3_shape(t, a.N, a.K)) return vn_launch_gemm_f32(ctx, a, epi, s);
+    if (!a16) a16 = t->a16;
     int rc;
-    if (!a_ready && (rc = vn_launch_split3_tiled(ctx, a.A, t->a16, a.M, a.K, a.K, s))) return rc;
-    a.A = (const float*)t->a16; a.W = (const float*)w16; a.bf16 = 2; a.a_plane = VN_PLANES_TILED; a.w_plane = VN_PLANES_TILED; a.w_tiled = 1;
+    if (!a_ready && (rc = vn_launch_split3_tiled(ctx, a.A, a16, a.M, a.K, a.K, s))) return rc;
+    a.A = (const float*)a16; a.W = (const float*)w16; a.bf16 = 2; a.a_plane = VN_PLANES_TILED; a.w_plane = VN_PLANES_TILED; a.w_tiled = 1;
     return vn_launch_gemm_x3(ctx, a, epi, s);
 }
 
 static int gemm(vn_train* t, const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int epi,
-                hipStream_t s, bool a_ready = false) {
+                hipStream_t s, bool a_ready = false, uint16_t* a16 = nullptr) {
     vn_gemm_args a{};
     a.A = A; a.W = W; a.bias = bias; a.C = C; a.M = M; a.N = N; a.K = K; a.ldc = N;
-    return gemm_args(t, a, epi, s, a_ready);
+    return gemm_args(t, a, epi, s, a_ready, a16);
 }
 
 static int params_ok(vn_ctx* ctx, const vn_train_params* p) {
@@ -507,55 +536,83 @@ static int forward_train(vn_train* t, int B, int T, const vn_train_params* p, hi
         t->near_r = vn_attention_x3_near_r(lut.data(), T);
         t->near_T = T;
     }
+    if (t->tn && t->tn_rows != M) {
+        // the producers below write rows < M only; the dW GEMMs contract over whole 16-token blocks, so what an earlier forward with
+        // another token count left in the last block's pad rows must go (shape changes only)
+        const size_t nd = (size_t)3 * (((size_t)m->max_rows + 15) & ~(size_t)15) * D * 2;
+        for (auto& st : t->st) {
+            VN_HIP_CHECK(ctx, hipMemsetAsync(st.y1_16, 0, nd, s)); VN_HIP_CHECK(ctx, hipMemsetAsync(st.a_16, 0, nd, s));
+            VN_HIP_CHECK(ctx, hipMemsetAsync(st.y3_16, 0, nd, s)); VN_HIP_CHECK(ctx, hipMemsetAsync(st.g_16, 0, 2 * nd, s));
+        }
+        VN_HIP_CHECK(ctx, hipMemsetAsync(t->yf16, 0, nd, s));
+        t->tn_rows = M;
+    }
     if ((rc = vn_launch_embed(ctx, m->z, P(t, VN_W_EMB_TABLES), P(t, VN_W_EMB_WT), P(t, VN_W_EMB_B), t->st[0].x_in, B,
                               m->d.n_codebooks, T, m->d.vocab + 1, m->d.latent_dim, D, s)))
         return rc;
     for (int l = 0; l < L; ++l) {
         vn_layer_stash& S = t->st[l];
         float* x_out = l + 1 < L ? t->st[l + 1].x_in : t->x_last;
+        // where the planes of the four A operands go: the layer's stash (kept for the dW GEMMs) or the shared scratch
+        uint16_t* const y1_16 = t->tn ? S.y1_16 : t->a16, * const a_16 = t->tn ? S.a_16 : t->a16, * const y3_16 = t->tn ? S.y3_16 : t->a16,
+                * const g_16 = t->tn ? S.g_16 : t->a16;
         // producers write the tiled planes of the next GEMM's A operand from the registers that hold the values (t->a16) where the kernel
         // can (RMSNorm: D in {256, 1280}; GEGLU) — no split pass for those operands
         const bool n16 = (D == 256 || D == 1280) && x3_shape(t, 3 * D, D);
-        if ((rc = vn_launch_rmsnorm(ctx, S.x_in, P(t, VN_W_NORM1, l), S.y1, M, D, m->d.eps, s, n16 ? t->a16 : nullptr, VN_PLANES_TILED, true))) return rc;
+        if ((rc = vn_launch_rmsnorm(ctx, S.x_in, P(t, VN_W_NORM1, l), S.y1, M, D, m->d.eps, s, n16 ? y1_16 : nullptr, VN_PLANES_TILED, true))) return rc;
         vn_gemm_args a{};
         a.A = S.y1; a.W = P(t, VN_W_QKV, l); a.C = S.qkv; a.M = M; a.N = 3 * D; a.K = D; a.ldc = 3 * D;
         a.T = T; a.H = H; a.qkv_plane = plane;
         bool a16o = false;
         if (t->ax3) {
             a.C = nullptr; a.C16 = S.qk16; a.c_plane = t->qk_plane; a.V16 = S.vt16; a.v_plane = t->vt_plane;
-            if ((rc = gemm_args(t, a, VN_EPI_QKV3, s, n16))) return rc;
+            if ((rc = gemm_args(t, a, VN_EPI_QKV3, s, n16, y1_16))) return rc;
             // (the kernel can also write the planes of its output for the Wo GEMM — a16o = x3_shape(t, D, D), t->a16 below — but its 8-byte
             // scattered plane stores cost 13 us per layer against the 10.6 us of the split pass they replace: left off)
             rc = vn_launch_attention_x3_train_fwd(ctx, S.qk16, S.qk16 + plane, t->qk_plane, S.vt16, t->vt_plane, m->bias_full, S.a, S.lse, B, H,
-                                                  T, vn_num_cus(ctx), make_drop(p, l, SITE_ATTN, r_att), s, a16o ? t->a16 : nullptr, VN_PLANES_TILED);
+                                                  T, vn_num_cus(ctx), make_drop(p, l, SITE_ATTN, r_att), s, a16o ? a_16 : nullptr, VN_PLANES_TILED);
         } else {
-            if ((rc = gemm_args(t, a, VN_EPI_QKV, s, n16))) return rc;
+            if ((rc = gemm_args(t, a, VN_EPI_QKV, s, n16, y1_16))) return rc;
             rc = vn_launch_attention_train_fwd(ctx, S.qkv, S.qkv + plane, S.qkv + 2 * plane, m->bias_full, S.a, S.lse, B, H, T,
                                                make_drop(p, l, SITE_ATTN, r_att), s);
         }
         if (rc) return rc;
-        if ((rc = gemm(t, S.a, P(t, VN_W_WO, l), nullptr, t->tmp, M, D, D, VN_EPI_STORE, s, a16o))) return rc;
+        if ((rc = gemm(t, S.a, P(t, VN_W_WO, l), nullptr, t->tmp, M, D, D, VN_EPI_STORE, s, a16o, a_16))) return rc;
         if ((rc = vn_launch_resid_dropout(ctx, S.x_in, t->tmp, S.x_mid, M, D, make_drop(p, l, SITE_RES1, r_tok), s))) return rc;
-        if ((rc = vn_launch_rmsnorm(ctx, S.x_mid, P(t, VN_W_NORM3, l), S.y3, M, D, m->d.eps, s, n16 ? t->a16 : nullptr, VN_PLANES_TILED, true))) return rc;
-        if ((rc = gemm(t, S.y3, P(t, VN_W_W1, l), nullptr, S.u, M, 4 * D, D, VN_EPI_STORE, s, n16))) return rc;
+        if ((rc = vn_launch_rmsnorm(ctx, S.x_mid, P(t, VN_W_NORM3, l), S.y3, M, D, m->d.eps, s, n16 ? y3_16 : nullptr, VN_PLANES_TILED, true))) return rc;
+        if ((rc = gemm(t, S.y3, P(t, VN_W_W1, l), nullptr, S.u, M, 4 * D, D, VN_EPI_STORE, s, n16, y3_16))) return rc;
         const bool g16 = x3_shape(t, D, 2 * D);
-        if ((rc = vn_launch_geglu_train(ctx, S.u, nullptr, S.g, M, 2 * D, make_drop(p, l, SITE_FFN, r_tok), false, s, g16 ? t->a16 : nullptr))) return rc;
-        if ((rc = gemm(t, S.g, P(t, VN_W_W2, l), nullptr, t->tmp, M, D, 2 * D, VN_EPI_STORE, s, g16))) return rc;
+        if ((rc = vn_launch_geglu_train(ctx, S.u, nullptr, S.g, M, 2 * D, make_drop(p, l, SITE_FFN, r_tok), false, s, g16 ? g_16 : nullptr))) return rc;
+        if ((rc = gemm(t, S.g, P(t, VN_W_W2, l), nullptr, t->tmp, M, D, 2 * D, VN_EPI_STORE, s, g16, g_16))) return rc;
         if ((rc = vn_launch_resid_dropout(ctx, S.x_mid, t->tmp, x_out, M, D, make_drop(p, l, SITE_RES2, r_tok), s))) return rc;
     }
     const bool f16 = (D == 256 || D == 1280) && x3_shape(t, t->NV, D);
-    if ((rc = vn_launch_rmsnorm(ctx, t->x_last, P(t, VN_W_FINAL_NORM), t->y_f, M, D, m->d.eps, s, f16 ? t->a16 : nullptr, VN_PLANES_TILED, true))) return rc;
-    return gemm(t, t->y_f, P(t, VN_W_CLS_W), P(t, VN_W_CLS_B), m->logits, M, t->NV, D, VN_EPI_BIAS, s, f16);
+    uint16_t* const yf16 = t->tn ? t->yf16 : t->a16;
+    if ((rc = vn_launch_rmsnorm(ctx, t->x_last, P(t, VN_W_FINAL_NORM), t->y_f, M, D, m->d.eps, s, f16 ? yf16 : nullptr, VN_PLANES_TILED, true))) return rc;
+    return gemm(t, t->y_f, P(t, VN_W_CLS_W), P(t, VN_W_CLS_B), m->logits, M, t->NV, D, VN_EPI_BIAS, s, f16, yf16);
 }
 
 // dW[N][K] = dY^T X   (dY [M][N], X [M][K]) through the two transposes
 // dy_planes (out, optional): the transposer of dY has ALSO left dY's own tiled planes in t->a16 — the A operand of the dX GEMM the caller
 // runs next on the same dY (one read of dY instead of two; nothing else may write t->a16 in between)
-static int grad_weight(vn_train* t, const float* dY, const float* X, float* dW, int M, int N, int K, hipStream_t s, bool* dy_planes = nullptr) {
+// X16 (vn_train::tn): the tiled planes of X the forward GEMM read (the layer's stash); dy_ready: dY's tiled planes are in t->a16 already.
+// Then nothing is transposed: both operands go to the kernel token-major (gemm_x3.hip X3_MODE_TN), dY's planes — written here by one
+// split pass unless they exist — serve the dX GEMM that follows as before.
+static int grad_weight(vn_train* t, const float* dY, const float* X, float* dW, int M, int N, int K, hipStream_t s, bool* dy_planes = nullptr,
+                       const uint16_t* X16 = nullptr, bool dy_ready = false) {
     vn_ctx* ctx = t->m->ctx;
     const int Mp = (M + 31) & ~31;
     int rc;
     if (dy_planes) *dy_planes = false;
+    if (t->tn && X16 && x3_shape(t, N, K) && !(K & 63)) {      // x3_shape(N, K): the forward GEMM of this weight ran on the pipe and filled X16
+        if (!dy_ready && (rc = vn_launch_split3_tiled(ctx, dY, t->a16, M, N, N, s))) return rc;
+        if (dy_planes) *dy_planes = true;
+        vn_gemm_args a{};
+        a.A = (const float*)t->a16; a.W = (const float*)X16; a.C = dW; a.M = N; a.N = K; a.K = Mp; a.ldc = K;
+        a.bf16 = 2; a.a_plane = VN_PLANES_TILED; a.w_plane = VN_PLANES_TILED; a.w_tiled = 1;
+        a.tn_blocks = (M + 15) >> 4;
+        return vn_launch_gemm_x3(ctx, a, VN_EPI_STORE, s);
+    }
     if (t->x3 && !(N & 15) && !(K & 63)) {
         // both operands as tiled planes straight out of the transposes: A = dY^T [N][Mp], W = X^T [K][Mp], contraction over the tokens
         const bool both = dy_planes && !(N & 31);
@@ -595,7 +652,7 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
     if (hi >= L) {
     // ---- classifier (WNConv1d 1x1, transformer.py:596-604) + final norm
     bool dl16 = false;
-    if (!lora && (rc = grad_weight(t, dlog, t->y_f, G(t, grads, VN_W_CLS_W), M, NV, D, s, &dl16))) return rc;
+    if (!lora && (rc = grad_weight(t, dlog, t->y_f, G(t, grads, VN_W_CLS_W), M, NV, D, s, &dl16, t->yf16))) return rc;
     if ((rc = gemm(t, dlog, t->wT + t->wT_cls, nullptr, t->dy, M, D, NV, VN_EPI_STORE, s, dl16 && x3_shape(t, D, NV)))) return rc;
     if (!lora) {
         float* dWc = G(t, grads, VN_W_CLS_W);
@@ -616,15 +673,17 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
         const vn_drop d2 = make_drop(p, l, SITE_RES2, r_tok);
         bool dy16 = false;                             // grad_weight left dY's planes in t->a16 for the dX GEMM that follows it
         const float* dh = dx;
-        if (d2.thresh16) { if ((rc = vn_launch_dropout_bwd(ctx, dx, t->dh, M, D, d2, s))) return rc; dh = t->dh; }
-        if (lora) rc = lora_grads(t, S.g, 2 * D, dh, D, l, LORA_W2, grads, M, s);
-        else rc = grad_weight(t, dh, S.g, G(t, grads, VN_W_W2, l), M, D, 2 * D, s, &dy16);
+        // (vn_train::tn: the mask kernel writes dh's tiled planes into t->a16 as well — both GEMMs below read them, no split pass)
+        const bool dh16 = t->tn && d2.thresh16 && x3_shape(t, 2 * D, D);
+        if (d2.thresh16) { if ((rc = vn_launch_dropout_bwd(ctx, dx, t->dh, M, D, d2, s, dh16 ? t->a16 : nullptr))) return rc; dh = t->dh; }
+        if (lora) { rc = lora_grads(t, S.g, 2 * D, dh, D, l, LORA_W2, grads, M, s); dy16 = dh16; }
+        else rc = grad_weight(t, dh, S.g, G(t, grads, VN_W_W2, l), M, D, 2 * D, s, &dy16, S.g_16, dh16);
         if (rc) return rc;
         if ((rc = gemm(t, dh, wTl + 8L * D * D, nullptr, t->dg, M, 2 * D, D, VN_EPI_STORE, s, dy16 && x3_shape(t, 2 * D, D)))) return rc;
         const bool du16 = x3_shape(t, D, 4 * D);       // du's planes for the dX GEMM below (grad_weight in between uses at16 / bt16 only)
         if ((rc = vn_launch_geglu_train(ctx, S.u, t->dg, t->du, M, 2 * D, make_drop(p, l, SITE_FFN, r_tok), true, s, du16 ? t->a16 : nullptr))) return rc;
         if (lora) rc = lora_grads(t, S.y3, D, t->du, 4 * D, l, LORA_W1, grads, M, s);
-        else rc = grad_weight(t, t->du, S.y3, G(t, grads, VN_W_W1, l), M, 4 * D, D, s);
+        else rc = grad_weight(t, t->du, S.y3, G(t, grads, VN_W_W1, l), M, 4 * D, D, s, nullptr, S.y3_16, du16);
         if (rc) return rc;
         if ((rc = gemm(t, t->du, wTl + 4L * D * D, nullptr, t->dy, M, D, 4 * D, VN_EPI_STORE, s, du16))) return rc;
         if ((rc = vn_launch_rmsnorm_bwd(ctx, S.x_mid, P(t, VN_W_NORM3, l), t->dy, dx, dx2, lora ? junk : G(t, grads, VN_W_NORM3, l),
@@ -633,10 +692,11 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
         // ---- attention branch (transformer.py:211-257, :336-347)
         const vn_drop d1 = make_drop(p, l, SITE_RES1, r_tok);
         const float* dh2 = dx2;
-        if (d1.thresh16) { if ((rc = vn_launch_dropout_bwd(ctx, dx2, t->dh, M, D, d1, s))) return rc; dh2 = t->dh; }
+        const bool dh216 = t->tn && d1.thresh16 && x3_shape(t, D, D);
+        if (d1.thresh16) { if ((rc = vn_launch_dropout_bwd(ctx, dx2, t->dh, M, D, d1, s, dh216 ? t->a16 : nullptr))) return rc; dh2 = t->dh; }
         dy16 = false;
-        if (lora) rc = lora_grads(t, S.a, D, dh2, D, l, LORA_FC, grads, M, s);
-        else rc = grad_weight(t, dh2, S.a, G(t, grads, VN_W_WO, l), M, D, D, s, &dy16);
+        if (lora) { rc = lora_grads(t, S.a, D, dh2, D, l, LORA_FC, grads, M, s); dy16 = dh216; }
+        else rc = grad_weight(t, dh2, S.a, G(t, grads, VN_W_WO, l), M, D, D, s, &dy16, S.a_16, dh216);
         if (rc) return rc;
         if ((rc = gemm(t, dh2, wTl + 3L * D * D, nullptr, t->da, M, D, D, VN_EPI_STORE, s, dy16 && x3_shape(t, D, D)))) return rc;
         if (t->ax3)
@@ -653,7 +713,7 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
             if ((rc = lora_grads(t, S.y1, D, t->dqkv, 3 * D, l, LORA_Q, grads, M, s))) return rc;
             rc = lora_grads(t, S.y1, D, t->dqkv + 2 * D, 3 * D, l, LORA_V, grads, M, s);
         } else {
-            rc = grad_weight(t, t->dqkv, S.y1, G(t, grads, VN_W_QKV, l), M, 3 * D, D, s, &dy16);
+            rc = grad_weight(t, t->dqkv, S.y1, G(t, grads, VN_W_QKV, l), M, 3 * D, D, s, &dy16, S.y1_16);
         }
         if (rc) return rc;
         if ((rc = gemm(t, t->dqkv, wTl, nullptr, t->dy, M, D, 3 * D, VN_EPI_STORE, s, dy16 && x3_shape(t, D, 3 * D)))) return rc;

@@ -45,8 +45,9 @@ int vn_launch_resid_dropout(vn_ctx* ctx, const float* x_in, const float* y, floa
 
 // dy_out = dy_in * keep * scale   (backward of the residual-branch dropout)
 __global__ __launch_bounds__(256) void vn_dropout_bwd_kernel(const float* __restrict__ dy, float* __restrict__ out, int M,
-                                                             int N4, vn_drop d) {
+                                                             int N4, vn_drop d, uint16_t* __restrict__ out16) {
     const long total = (long)M * N4;
+    bool bad = false;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
         const int row = (int)(i / N4), c4 = (int)(i - (long)row * N4);
         f32x4 a = ((const f32x4*)dy)[i];
@@ -57,18 +58,20 @@ __global__ __launch_bounds__(256) void vn_dropout_bwd_kernel(const float* __rest
         a[2] *= vn_drop_mul(d, b1, 0);
         a[3] *= vn_drop_mul(d, b1, 1);
         ((f32x4*)out)[i] = a;
+        if (out16) vn_store_planes4(out16, VN_PLANES_TILED, row, 4 * c4, 4 * N4, a, bad);
     }
 }
 
-int vn_launch_dropout_bwd(vn_ctx* ctx, const float* dy, float* out, int M, int N, const vn_drop& d, hipStream_t s) {
+int vn_launch_dropout_bwd(vn_ctx* ctx, const float* dy, float* out, int M, int N, const vn_drop& d, hipStream_t s, uint16_t* out16) {
     if (M <= 0) return VN_OK;
+    if (out16 && (!d.thresh16 || (N & 31))) return vn_fail(ctx, VN_ERR_INVALID, "dropout_bwd: plane output needs the mask on and N %% 32 == 0 (N=%s%ld)", "", N);
     if (!d.thresh16) {
         if (dy != out) VN_HIP_CHECK(ctx, hipMemcpyAsync(out, dy, (size_t)M * N * sizeof(float), hipMemcpyDeviceToDevice, s));
         return VN_OK;
     }
     const long total = (long)M * (N / 4);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(vn_dropout_bwd_kernel, dim3(blocks), dim3(256), 0, s, dy, out, M, N / 4, d);
+    hipLaunchKernelGGL(vn_dropout_bwd_kernel, dim3(blocks), dim3(256), 0, s, dy, out, M, N / 4, d, out16);
     VN_LAUNCH_CHECK(ctx);
     return VN_OK;
 }

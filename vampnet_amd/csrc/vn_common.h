@@ -516,6 +516,10 @@ struct vn_gemm_args {
     int conv_taps, conv_cin, conv_tin, conv_trows, conv_in_stride, conv_dil, conv_pad;
     int conv_tout, conv_out_stride, conv_out_off, conv_act;
     const uint16_t* zeros16;
+    // gemm_x3.hip, STORE epilogue, bf16x3 planes: tn_blocks > 0 = the TN operand mode (X3_MODE_TN) — C[M][N] = A^T W, A [tokens][M] and W
+    // [tokens][N] token-major TILED planes, K = the token count rounded up to 32, tn_blocks = ceil(tokens / 16) 16-token blocks exist (rows
+    // past the last token inside the last block must be ZERO in at least one operand and finite in the other); M % 32 == 0
+    int tn_blocks;
     const float* resid;
     const float* alpha;
     float* Y2;

@@ -11,7 +11,8 @@ struct vn_adamw_args {
 
 int vn_launch_resid_dropout(vn_ctx* ctx, const float* x_in, const float* y, float* x_out, int M, int N, const vn_drop& d,
                             hipStream_t s);
-int vn_launch_dropout_bwd(vn_ctx* ctx, const float* dy, float* out, int M, int N, const vn_drop& d, hipStream_t s);
+// out16 (optional, needs the mask to be on and N % 32 == 0): the result once more as TILED bf16x3 planes — the A operand of the dW / dX GEMMs
+int vn_launch_dropout_bwd(vn_ctx* ctx, const float* dy, float* out, int M, int N, const vn_drop& d, hipStream_t s, uint16_t* out16 = nullptr);
 int vn_launch_dropout_mask(vn_ctx* ctx, uint8_t* out, long rows, int cols, const vn_drop& d, hipStream_t s);
 int vn_launch_geglu_train(vn_ctx* ctx, const float* u, const float* dg, float* out, int M, int D2, const vn_drop& d,
                           bool bwd, hipStream_t s, uint16_t* out16 = nullptr);     // out16: the result also as tiled bf16x3 planes

@@ -186,6 +186,15 @@ class Engine:
                                            self.stream()), "vn_gemm_bf16x3")
         return out
 
+    def gemm_bf16x3_tn(self, at_tiled, wt_tiled, M, N, tokens, out=None):
+        """out [M, N] = At^T Wt with both operands token-major: at_tiled / wt_tiled = tile3() images of the split planes of At [tokens, M] /
+        Wt [tokens, N] (the layout the activations of the model path already have) — the dW GEMM of training, no transposing pass."""
+        if out is None:
+            out = torch.empty(M, N, device=at_tiled.device, dtype=torch.float32)
+        self.check(self.lib.vn_gemm_bf16x3_tn(self.handle, at_tiled.data_ptr(), wt_tiled.data_ptr(), out.data_ptr(), M, N, tokens,
+                                              self.stream()), "vn_gemm_bf16x3_tn")
+        return out
+
     def split2h(self, x, tiled=False):
         """fp32 [R, K] -> the f16x2 operand format of gemm_f16x2: float16 [2, R, K] (h0 = fp16(x), h1 = fp16((x - h0) * 2048)), or with
         tiled=True the tiled image [ceil(R/16), K/32, 2, 16, 32] (rows zero-padded to 16)."""
