@@ -23,6 +23,22 @@ PY
 rocm-smi --showproductname 2>/dev/null | head -8 > $O/gpu_info.txt; lscpu | grep -E "Model name|^CPU\(s\)|Socket" >> $O/gpu_info.txt
 timeout 2400 python -m pytest tests -q -m gpu -s > $O/pytest_gpu.log 2>&1; echo "pytest -m gpu rc=$?"; tail -n 3 $O/pytest_gpu.log; grep -E "^(FAILED|ERROR)" $O/pytest_gpu.log | head
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 1 $O/smoke.log
+# ---- fabric-traffic counters FIRST (their own passes, no trace domains): the bench lines below quote them (bench.py reads
+# profiles/r06_traffic_*.json and checks the kernel source's hash), so the capture of THIS build is put in place before they run
+cd /tmp; rm -rf /tmp/pf /tmp/pw /tmp/pfh /tmp/pwh
+P="--steps 1 --warmup 0 --no-cpu-baseline --no-kernel-events --no-sharded-check"
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o fetch -- python $R/bench.py $P --no-alt > /dev/null 2> $R/$O/pmc_fetch.err
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o write -- python $R/bench.py $P --no-alt > /dev/null 2> $R/$O/pmc_write.err
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pfh -o fetch -- python $R/bench.py --dtype f16x2 $P > /dev/null 2> $R/$O/pmc_fetch_h2.err
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pwh -o write -- python $R/bench.py --dtype f16x2 $P > /dev/null 2> $R/$O/pmc_write_h2.err
+cd $R
+python scripts/pmc_summary.py /tmp/pf FETCH_SIZE > $O/pmc_fetch_size.txt 2>&1
+python scripts/pmc_summary.py /tmp/pw WRITE_SIZE > $O/pmc_write_size.txt 2>&1
+python scripts/traffic_from_pmc.py $O/pmc_fetch_size.txt $O/pmc_write_size.txt vn_gemm_x3 $O/traffic_x3.json > /dev/null 2>&1
+python scripts/pmc_summary.py /tmp/pfh FETCH_SIZE > $O/pmc_fetch_size_h2.txt 2>&1
+python scripts/pmc_summary.py /tmp/pwh WRITE_SIZE > $O/pmc_write_size_h2.txt 2>&1
+python scripts/traffic_from_pmc.py $O/pmc_fetch_size_h2.txt $O/pmc_write_size_h2.txt vn_gemm_x3 $O/traffic_h2.json > /dev/null 2>&1
+cp $O/traffic_x3.json profiles/r06_traffic_x3.json; cp $O/traffic_h2.json profiles/r06_traffic_h2.json; head -12 $O/traffic_x3.json
 timeout 900 python scripts/power_trace.py $O/power_bench -- python bench.py --steps 20 --warmup 5 > $O/bench_n1.out 2> $O/bench_n1.err; grep '^{' $O/bench_n1.out > $O/bench_n1.json; J $O/bench_n1.json; tail -6 $O/power_bench.txt
 timeout 400 python bench.py --config 1 --steps 10 --warmup 3 > $O/bench_n1_config1.json 2> $O/bench_n1_config1.err; J $O/bench_n1_config1.json
 for b in 1 2 4; do timeout 300 python bench.py --batch-per-gpu $b --steps 5 --warmup 2 --no-cpu-baseline --no-alt --no-sharded-check > $O/bench_vamp_b$b.json 2> $O/bench_vamp_b$b.err; J $O/bench_vamp_b$b.json; done
@@ -33,26 +49,14 @@ timeout 400 python bench.py --workload train --steps 4 --warmup 2 > $O/bench_tra
 VN_TRAIN_X3=0 timeout 400 python bench.py --workload train --steps 4 --warmup 2 --no-cpu-baseline > $O/bench_train_n1_f32_mfma.json 2> /dev/null; J $O/bench_train_n1_f32_mfma.json
 VN_BENCH_ONE_GPU=1 timeout 400 python bench.py --gpus 2 --steps 2 --warmup 1 --no-alt --no-cpu-baseline > $O/bench_gpus2_one_gpu.json 2> $O/bench_gpus2.err; J $O/bench_gpus2_one_gpu.json
 # ---- rocprofv3: kernel trace + stats of the headline command and of the training step
-cd /tmp; rm -rf /tmp/px3 /tmp/pt /tmp/pf /tmp/pw /tmp/psq /tmp/pfh /tmp/pwh
+cd /tmp; rm -rf /tmp/px3 /tmp/pt /tmp/psq
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/px3 -o vamp -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt --no-sharded-check > $R/$O/bench_under_rocprof.json 2> $R/$O/trace.err
 for f in $(find /tmp/px3 -name "*kernel_stats.csv"); do cp $f $R/$O/kernel_stats.csv; done
 for f in $(find /tmp/px3 -name "*kernel_trace.csv"); do python $R/scripts/kstats_last_step.py $f vn_embed_kernel 24 vamp > $R/$O/last_vamp_kernel_stats.txt 2>&1; done
 timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/pt -o train -- python $R/bench.py --workload train --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > /dev/null 2> $R/$O/trace_train.err
 for f in $(find /tmp/pt -name "*kernel_trace.csv"); do python $R/scripts/kstats_last_step.py $f vn_embed_kernel 30 > $R/$O/train_last_step_kernel_stats.txt 2>&1; done
-# ---- counters (their own passes, no trace domains): fabric traffic of both split-plane precisions, instruction mix per kernel
-P="--steps 1 --warmup 0 --no-cpu-baseline --no-kernel-events --no-sharded-check"
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o fetch -- python $R/bench.py $P --no-alt > /dev/null 2> $R/$O/pmc_fetch.err
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o write -- python $R/bench.py $P --no-alt > /dev/null 2> $R/$O/pmc_write.err
 timeout 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d /tmp/psq -o sq -- python $R/bench.py $P --no-alt > /dev/null 2> $R/$O/pmc_sq.err
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pfh -o fetch -- python $R/bench.py --dtype f16x2 $P > /dev/null 2> $R/$O/pmc_fetch_h2.err
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pwh -o write -- python $R/bench.py --dtype f16x2 $P > /dev/null 2> $R/$O/pmc_write_h2.err
 cd $R
-python scripts/pmc_summary.py /tmp/pf FETCH_SIZE > $O/pmc_fetch_size.txt 2>&1
-python scripts/pmc_summary.py /tmp/pw WRITE_SIZE > $O/pmc_write_size.txt 2>&1
-python scripts/traffic_from_pmc.py $O/pmc_fetch_size.txt $O/pmc_write_size.txt vn_gemm_x3 $O/traffic_x3.json > /dev/null 2>&1
-python scripts/pmc_summary.py /tmp/pfh FETCH_SIZE > $O/pmc_fetch_size_h2.txt 2>&1
-python scripts/pmc_summary.py /tmp/pwh WRITE_SIZE > $O/pmc_write_size_h2.txt 2>&1
-python scripts/traffic_from_pmc.py $O/pmc_fetch_size_h2.txt $O/pmc_write_size_h2.txt vn_gemm_x3 $O/traffic_h2.json > /dev/null 2>&1
 python scripts/pmc_per_kernel.py /tmp/psq > $O/pmc_lds_mfma_per_kernel.txt 2>&1
 head -12 $O/last_vamp_kernel_stats.txt | cut -c1-150; cat $O/traffic_x3.json | head -12; head -12 $O/pmc_lds_mfma_per_kernel.txt
 bash scripts/gpu_model_clock.sh $TAG/clock --no-alt --no-sharded-check > $O/clock.txt 2>&1; tail -10 $O/clock.txt
