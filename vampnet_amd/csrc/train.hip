@@ -680,7 +680,7 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
         else rc = grad_weight(t, dh, S.g, G(t, grads, VN_W_W2, l), M, D, 2 * D, s, &dy16, S.g_16, dh16);
         if (rc) return rc;
         if ((rc = gemm(t, dh, wTl + 8L * D * D, nullptr, t->dg, M, 2 * D, D, VN_EPI_STORE, s, dy16 && x3_shape(t, 2 * D, D)))) return rc;
-        const bool du16 = x3_shape(t, D, 4 * D);       // du's planes for the dX GEMM below (grad_weight in between uses at16 / bt16 only)
+        const bool du16 = x3_shape(t, D, 4 * D);       // du's planes (t->a16): the A operand of the dW GEMM (token-major form) and of the dX GEMM below; nothing in between writes t->a16
         if ((rc = vn_launch_geglu_train(ctx, S.u, t->dg, t->du, M, 2 * D, make_drop(p, l, SITE_FFN, r_tok), true, s, du16 ? t->a16 : nullptr))) return rc;
         if (lora) rc = lora_grads(t, S.y3, D, t->du, 4 * D, l, LORA_W1, grads, M, s);
         else rc = grad_weight(t, t->du, S.y3, G(t, grads, VN_W_W1, l), M, 4 * D, D, s, nullptr, S.y3_16, du16);
