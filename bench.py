@@ -301,6 +301,22 @@ def bench_train(args, rank, world, device, pg, barrier, result_out=sys.stdout):
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # The layers' weight-gradient GEMMs run on a side stream beside the caller's (csrc/train.hip, VN_TRAIN_OVERLAP): a bracket of the timed
+    # region then contains the time its kernel SHARED the chip — a lower bound of the kernel's own rate.  One extra, untimed step with the
+    # side stream off gives the brackets of the kernels alone (`roofline` is taken from it; the timed region's own brackets are reported
+    # next to it as `roofline.overlapped`).
+    prof_serial = None
+    if prof is not None and tr.set_overlap(None):
+        tr.set_overlap(False)
+        tr.step(z, r=rs[args.warmup], generator=gen)
+        barrier()
+        eng.profile_begin(1200, stride=args.event_stride)
+        t1 = time.perf_counter()
+        tr.step(z, r=rs[args.warmup], generator=gen)
+        barrier()
+        serial_s = time.perf_counter() - t1
+        prof_serial = eng.profile_end()
+        tr.set_overlap(None)
     eng.health_check()
     loss = float(out["loss"].item())
     assert loss == loss and loss < 20.0, loss
@@ -328,9 +344,20 @@ def bench_train(args, rank, world, device, pg, barrier, result_out=sys.stdout):
                       "step_tflop_per_gpu": step_tflop, "achieved_tflops_per_gpu": step_tflop / (elapsed / args.steps),
                       "final_loss": loss}}
     if prof is not None:
+        over = None
+        if prof_serial is not None:
+            on_, oms, ofl, _ = prof["gemm"]
+            over = {"note": "the timed region's own brackets: kernels of the caller's stream while the weight-gradient GEMMs run beside them on "
+                            "the side stream (a bracket includes the time its kernel shared the chip); `roofline` itself = one extra untimed "
+                            "step with the side stream off", "launches": int(on_), "avg_launch_us": 1e3 * oms / on_ if on_ else None,
+                    "achieved": ofl / (oms * 1e-3) / 1e12 if oms else None}
+            prof = prof_serial
         n, ms, fl, by = prof["gemm"]
         an, ams, afl, _ = prof["attention"]
         peak = PEAK_BF16_MFMA_TF / 6.0 if train_dtype == "bf16x3" else PEAK_F32_MFMA_TF
+        el_b = serial_s if over is not None else elapsed           # wall time of the steps the brackets cover
+        if over is not None:
+            over["serial_step_ms"] = 1e3 * serial_s
         res["roofline"] = {"bound": "mfma", "kernel": "vn_gemm_x3_kernel" if train_dtype == "bf16x3" else "vn_gemm_f32[_sk]_kernel",
                            "achieved": fl / (ms * 1e-3) / 1e12 if ms else None,
                            "peak": peak, "unit": "TFLOP/s",
@@ -339,10 +366,11 @@ def bench_train(args, rank, world, device, pg, barrier, result_out=sys.stdout):
                            "frac": fl / (ms * 1e-3) / 1e12 / peak if ms else None, "traffic": None,
                            "algorithmic_bytes_per_launch": by / n if n else None, "launches": int(n),
                            "avg_launch_us": 1e3 * ms / n if n else None, "event_stride": args.event_stride,
-                           "gemm_time_frac": args.event_stride * ms / (1e3 * elapsed) if elapsed else None,
+                           "gemm_time_frac": args.event_stride * ms / (1e3 * el_b) if el_b else None,
                            "attention": {"launches": int(an), "avg_launch_us": 1e3 * ams / an if an else None,
                                          "achieved": afl / (ams * 1e-3) / 1e12 if ams else None,
-                                         "time_frac": args.event_stride * ams / (1e3 * elapsed)}}
+                                         "time_frac": args.event_stride * ams / (1e3 * el_b)},
+                           **({"overlapped": over} if over is not None else {})}
     if args.lora_only:
         res["config"]["workload"] += "; LoRA-only (r=8 adapters on w_qs, w_vs, fc, w_1, w_2; everything else frozen)"
     if not args.no_cpu_baseline and not args.lora_only:

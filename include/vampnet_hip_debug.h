@@ -96,6 +96,11 @@ int  vn_guard_poke(void* p, int64_t offset_bytes, int write, void* sink, void* s
 void *vn_guard_torch_alloc(long size, int device, void* stream);
 void vn_guard_torch_free(void* p, long size, int device, void* stream);
 
+/* Training step: run the layers' weight-gradient GEMMs on the trainer's SIDE stream (1; the default when the trainer was created
+ * with VN_TRAIN_OVERLAP unset or 1) or in the caller's stream (0); -1 = back to the state at creation.  For A/B runs and for
+ * bracketing kernels without concurrency (bench.py's `roofline_serial`); call it between steps only.  Returns the state in effect. */
+int  vn_debug_train_overlap(vn_train* t, int on);
+
 #ifdef __cplusplus
 }
 #endif

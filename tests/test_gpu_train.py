@@ -597,6 +597,36 @@ def test_weight_gradients_without_transposes_equal_the_transposed_form(engine, m
         assert not torch.equal(out["1"][0][1], out["1"][1][1])          # (the shorter batch is a different problem, not a cached result)
 
 
+@pytest.mark.parametrize("B,T,dims_name", [(2, 32, "tiny"), (3, 29, "tiny"), (2, 575, "coarse")])
+def test_weight_gradient_gemms_on_the_side_stream_change_nothing(engine, B, T, dims_name):
+    """Round 6: the layers' dW GEMMs run on the trainer's side stream (a second context, rotating plane buffers, ready / done / join
+    events) beside the chain dY -> dX -> ... of the caller's stream.  Same kernels on the same operands: loss and EVERY gradient bitwise
+    equal to the single-stream order, five steps in a row on one trainer (buffers rotate 4-deep, so slots are reused and waited for),
+    dropout on, a ragged token count; the hook reports the state in effect."""
+    dims = W.TINY_COARSE_DIMS if dims_name == "tiny" else W.COARSE_DIMS
+    sd, cb = W.synth_state_dict(dims, 0), W.synth_codebooks()
+    tr = _trainer(engine, dims, sd, cb, max_batch=B, max_T=T, dropout=0.1, seed=11)
+    if not tr.set_overlap(None):
+        pytest.skip("the trainer was created without the side stream (VN_TRAIN_OVERLAP=0 / VN_TRAIN_TN=0 / VN_TRAIN_X3=0)")
+    z = W.synth_codes(B, 4, T, seed=3)
+    mask = TO.make_training_mask(z, torch.linspace(0.3, 0.9, B), 0, generator=torch.Generator().manual_seed(2))
+    z_mask, target = tr.make_batch(z, mask=mask)
+    res = {}
+    for on in (True, False, True):
+        assert tr.set_overlap(on) == on
+        out = []
+        for _ in range(5 if dims_name == "tiny" else 2):
+            loss = tr.forward_backward(z_mask, target).clone()
+            out.append((loss, tr.grads.clone()))
+        res.setdefault(on, []).append(out)
+    tr.set_overlap(None)
+    ref = res[False][0]
+    for run in res[True]:
+        for (la, ga), (lb, gb) in zip(run, ref):
+            assert torch.equal(la, lb) and torch.equal(ga, gb)
+    assert torch.isfinite(ref[0][1]).all() and ref[0][1].abs().max() > 0
+
+
 @pytest.mark.skipif(os.environ.get("VN_TRAIN_X3") == "0", reason="this IS the child process")
 def test_training_step_on_the_fp32_input_mfma():
     """Since round 5 every training GEMM (forward, dX, dW) runs on the split-plane pipe by default (gemm_x3.hip, bf16x3: weights and

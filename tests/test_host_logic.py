@@ -19,15 +19,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # ------------------------------------------------------------------------------------------ C ABI
 def test_library_exports_every_declared_symbol():
     """The shared library loads on a GPU-less host and exports exactly what include/vampnet_hip.h (the boundary) and
-    include/vampnet_hip_debug.h (tuning / test hooks, every vn_debug_* of them per vn_ctx or per vn_model; the vn_guard_* allocator
-    harness is per PROCESS, as an allocator is) declare."""
+    include/vampnet_hip_debug.h (tuning / test hooks, every vn_debug_* of them per OBJECT — a vn_ctx, a vn_model or a vn_train; the
+    vn_guard_* allocator harness is per PROCESS, as an allocator is) declare."""
     hdr = open(os.path.join(ROOT, "include", "vampnet_hip.h")).read()
     dbg = open(os.path.join(ROOT, "include", "vampnet_hip_debug.h")).read()
     assert not re.search(r"\bvn_debug_\w+\s*\(", hdr), "debug hooks belong in vampnet_hip_debug.h"
     dbg_code = re.sub(r"/\*.*?\*/", "", dbg, flags=re.S)
     for name, args in re.findall(r"\bint\s+(vn_debug_\w+)\s*\(([^;{]*?)\)\s*;", dbg_code, flags=re.S):
         first = args.split(",")[0]
-        assert "vn_ctx*" in first.replace(" *", "*") or "vn_model*" in first.replace(" *", "*"), f"{name} must act on a context, not the process"
+        assert any(k in first.replace(" *", "*") for k in ("vn_ctx*", "vn_model*", "vn_train*")), f"{name} must act on an object, not the process"
     hdr = hdr + dbg
     declared = set(re.findall(r"\b(vn_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)

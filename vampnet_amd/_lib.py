@@ -93,6 +93,7 @@ SYMBOLS = {
     "vn_train_create": (C.c_int, [_P, _P, C.POINTER(_P)]),
     "vn_train_destroy": (None, [_P]),
     "vn_train_sync": (C.c_int, [_P, _P]),
+    "vn_debug_train_overlap": (C.c_int, [_P, C.c_int]),
     "vn_train_forward_backward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(vn_train_params), _P, _P, _P]),
     "vn_train_forward_loss": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(vn_train_params), _P, _P, _P]),
     "vn_train_backward": (C.c_int, [_P, C.POINTER(vn_train_params), _P, C.c_int, C.c_int, _P]),

@@ -69,6 +69,29 @@ struct vn_train {
     bool tn;
     uint16_t* yf16;
     int tn_rows;
+    // The layers' dW GEMMs on a SIDE stream (VN_TRAIN_OVERLAP, default on with tn): a weight gradient feeds nothing in the backward pass, so
+    // its GEMM need not sit in the chain dY -> dX -> norm backward -> ... of the caller's stream.  It runs from a second context (its own
+    // split-K workspace) on a low-priority stream, ordered by events: ready[i] (caller's stream: the planes of dY are in plane buffer i),
+    // done[i] (side stream: its GEMM has read buffer i — the caller's stream waits for it before that buffer is written again), join (end
+    // of every vn_train_backward call: the gradients are complete when the call's work on the caller's stream is).  The chain's small
+    // kernels and the half-empty last rounds of its GEMMs then share the chip with the weight-gradient GEMMs.  Same kernels, same
+    // operands: bitwise the same gradients.
+    enum { NB = 4 };
+    bool overlap;
+    vn_ctx* ctx2;
+    hipStream_t side;
+    hipEvent_t ev_ready[NB], ev_done[NB], ev_join;
+    // ... and the re-split of the weights after an update (vn_train_sync) runs there too, layer by layer: the NEXT forward waits for
+    // layer l's planes (ev_w[l]; ev_w[L] = the classifier's) just before its first GEMM of that layer, so the splitters of the deeper
+    // layers run beside the forward pass of the first ones.  Only the internal planes lag — the parameters themselves are final when
+    // vn_train_update returns on the caller's stream.
+    std::vector<hipEvent_t> ev_w;
+    hipEvent_t ev_upd;
+    bool w_pending;
+    bool buf_busy[NB];             // a side GEMM of the current backward call reads this buffer
+    bool side_used;
+    int buf_next;
+    uint16_t* a16r[NB];            // rotating plane buffers for the dY operands (a16r[0] == a16)
     // ... and the attention of the step as well (attention_x3.hip TRAIN forward, attention_train_x3.hip backward; VN_TRAIN_ATTN_X3, default
     // on with x3 when D % 128 == 0 and max_T fits the backward's LDS): the QKV GEMM writes the attention operands' planes (its
     // inference epilogue) into the layer's stash — no fp32 q / k / v exist; ax_ws = the backward's transposed / row-major plane images
@@ -154,6 +177,16 @@ static int talloc(vn_ctx* ctx, T** p, size_t n) {
 extern "C" void vn_train_destroy(vn_train* t) {
     if (!t) return;
     (void)vn_dev_free(t->yf16);
+    for (int i = 1; i < vn_train::NB; ++i) (void)vn_dev_free(t->a16r[i]);
+    if (t->side) {
+        (void)hipStreamSynchronize(t->side);
+        for (int i = 0; i < vn_train::NB; ++i) { (void)hipEventDestroy(t->ev_ready[i]); (void)hipEventDestroy(t->ev_done[i]); }
+        for (hipEvent_t e : t->ev_w) (void)hipEventDestroy(e);
+        (void)hipEventDestroy(t->ev_upd);
+        (void)hipEventDestroy(t->ev_join);
+        (void)hipStreamDestroy(t->side);
+    }
+    if (t->ctx2) vn_ctx_destroy(t->ctx2);
     for (auto& s : t->st) {
         (void)vn_dev_free(s.qk16); (void)vn_dev_free(s.vt16);
         (void)vn_dev_free(s.y1_16); (void)vn_dev_free(s.a_16); (void)vn_dev_free(s.y3_16); (void)vn_dev_free(s.g_16);
@@ -192,6 +225,8 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
     { const char* e = getenv("VN_TRAIN_X3"); t->x3 = !(e && e[0] == '0'); }
     { const char* e = getenv("VN_TRAIN_TN"); t->tn = t->x3 && !(e && e[0] == '0'); }
     t->yf16 = nullptr; t->tn_rows = 0;
+    t->overlap = false; t->ctx2 = nullptr; t->side = nullptr; t->buf_next = 0; t->side_used = false; t->w_pending = false;
+    for (int i = 0; i < vn_train::NB; ++i) { t->a16r[i] = nullptr; t->buf_busy[i] = false; }
     const vn_dims& d = m->d;
     const long D = m->D, L = m->L, rows = m->max_rows;
     t->ax_ws = nullptr; t->near_T = 0; t->near_r = 0;
@@ -260,6 +295,40 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
         if (rc == VN_OK && hipMemset(t->a16, 0, (size_t)3 * rows16 * (size_t)wide * 2) != hipSuccess) rc = VN_ERR_HIP;
         if (rc == VN_OK) rc = talloc(ctx, &t->at16, (size_t)3 * wide * t->Mp_max);
         if (rc == VN_OK) rc = talloc(ctx, &t->bt16, (size_t)3 * 2 * D * t->Mp_max);
+        t->a16r[0] = t->a16;
+        bool want = false;
+        { const char* e = getenv("VN_TRAIN_OVERLAP"); want = t->tn && rc == VN_OK && !(e && e[0] == '0'); }
+        if (want) {
+            for (int i = 1; i < vn_train::NB && rc == VN_OK; ++i) {
+                rc = talloc(ctx, &t->a16r[i], (size_t)3 * rows16 * (size_t)wide);
+                if (rc == VN_OK && hipMemset(t->a16r[i], 0, (size_t)3 * rows16 * (size_t)wide * 2) != hipSuccess) rc = VN_ERR_HIP;
+            }
+            // the side stream's context: its own split-K workspace and zero page, allocated here (nothing allocates inside a step)
+            if (rc == VN_OK) rc = vn_ctx_create(ctx->device, &t->ctx2);
+            if (rc == VN_OK) {
+                t->ctx2->tune = ctx->tune;
+                if (vn_dev_malloc((void**)&t->ctx2->zero_page, 1024) != hipSuccess || hipMemset(t->ctx2->zero_page, 0, 1024) != hipSuccess ||
+                    vn_dev_malloc((void**)&t->ctx2->x3_ws, (size_t)(32L << 20) * sizeof(float)) != hipSuccess)
+                    rc = VN_ERR_OOM;
+            }
+            if (rc == VN_OK) {
+                int lo = 0, hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);                   // lo = the LEAST urgent
+                bool ok = hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, lo) == hipSuccess;
+                for (int i = 0; i < vn_train::NB && ok; ++i)
+                    ok = hipEventCreateWithFlags(&t->ev_ready[i], hipEventDisableTiming) == hipSuccess &&
+                         hipEventCreateWithFlags(&t->ev_done[i], hipEventDisableTiming) == hipSuccess;
+                ok = ok && hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&t->ev_upd, hipEventDisableTiming) == hipSuccess;
+                for (int l = 0; l <= (int)L && ok; ++l) {
+                    hipEvent_t e;
+                    ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+                    if (ok) t->ev_w.push_back(e);
+                }
+                if (!ok) rc = VN_ERR_HIP;
+            }
+            t->overlap = rc == VN_OK;
+        }
         if (t->tn) {
             const size_t nd = (size_t)3 * rows16 * D;
             auto Z = [&](uint16_t** p, size_t cnt) {
@@ -284,6 +353,16 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
     return VN_OK;
 }
 
+// tuning / measurement hook: run the layers' weight-gradient GEMMs on the side stream (1) or in the caller's stream (0); -1 = as created
+// (VN_TRAIN_OVERLAP).  Only between steps; returns the state in effect.
+extern "C" int vn_debug_train_overlap(vn_train* t, int on) {
+    if (!t) return VN_ERR_INVALID;
+    const bool built = t->side != nullptr;
+    if (on < 0) { const char* e = getenv("VN_TRAIN_OVERLAP"); t->overlap = built && !(e && e[0] == '0'); }
+    else t->overlap = built && on != 0;
+    return t->overlap ? 1 : 0;
+}
+
 // re-derive everything that is a function of the parameters: folded classifier weight, W^T copies, bias table
 extern "C" int vn_train_sync(vn_train* t, void* stream) {
     if (!t) return VN_ERR_INVALID;
@@ -299,8 +378,17 @@ extern "C" int vn_train_sync(vn_train* t, void* stream) {
     const bool all_x3 = t->x3 && !(D & 63) && !(t->NV & 63);
     if (all_x3) {
         // planes of w [rows][K] (dst) and of w^T [K][rows] (dstT) in ONE pass over w (the transposing splitter writes both from its tile)
+        // vn_train::overlap: the splitters run on the side stream behind everything the caller's stream has done so far (the update, the
+        // classifier fold above); the next forward waits layer by layer (ev_w)
+        const bool aside = t->overlap && t->side;
+        vn_ctx* const cx = aside ? t->ctx2 : ctx;
+        if (aside) {
+            VN_HIP_CHECK(ctx, hipEventRecord(t->ev_upd, s));
+            VN_HIP_CHECK(ctx, hipStreamWaitEvent(t->side, t->ev_upd, 0));
+            s = t->side;
+        }
         auto both = [&](const float* w, uint16_t* dst, uint16_t* dstT, int rows, int K) {
-            return vn_launch_transpose_split3_tiled(ctx, w, dstT, rows, K, K, rows, s, dst);
+            return vn_launch_transpose_split3_tiled(cx, w, dstT, rows, K, K, rows, s, dst);
         };
         for (int l = 0; l < m->L; ++l) {
             uint16_t* b16 = t->wT16 + 3 * (t->wT_layer * l);
@@ -309,9 +397,12 @@ extern "C" int vn_train_sync(vn_train* t, void* stream) {
                 (rc = both(wo, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_WO, l), b16 + 3 * (3L * D * D), D, D)) ||
                 (rc = both(w1, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_W1, l), b16 + 3 * (4L * D * D), 4 * D, D)) ||
                 (rc = both(w2, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_W2, l), b16 + 3 * (8L * D * D), D, 2 * D)))
-                return rc;
+                return aside ? vn_fail(ctx, rc, "weight planes on the side stream: %s", cx->err) : rc;
+            if (aside) VN_HIP_CHECK(ctx, hipEventRecord(t->ev_w[l], s));
         }
-        if ((rc = both(clsW, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_CLS_W, 0), t->wT16 + 3 * t->wT_cls, t->NV, D))) return rc;
+        if ((rc = both(clsW, t->w16 + 3 * vn_tensor_offset(&m->d, VN_W_CLS_W, 0), t->wT16 + 3 * t->wT_cls, t->NV, D)))
+            return aside ? vn_fail(ctx, rc, "weight planes on the side stream: %s", cx->err) : rc;
+        if (aside) { VN_HIP_CHECK(ctx, hipEventRecord(t->ev_w[m->L], s)); t->w_pending = true; }
         m->bias_T = -1;
         return VN_OK;
     }
@@ -552,6 +643,7 @@ static int forward_train(vn_train* t, int B, int T, const vn_train_params* p, hi
         return rc;
     for (int l = 0; l < L; ++l) {
         vn_layer_stash& S = t->st[l];
+        if (t->w_pending) VN_HIP_CHECK(ctx, hipStreamWaitEvent(s, t->ev_w[l], 0));       // this layer's weight planes (vn_train_sync on the side stream)
         float* x_out = l + 1 < L ? t->st[l + 1].x_in : t->x_last;
         // where the planes of the four A operands go: the layer's stash (kept for the dW GEMMs) or the shared scratch
         uint16_t* const y1_16 = t->tn ? S.y1_16 : t->a16, * const a_16 = t->tn ? S.a_16 : t->a16, * const y3_16 = t->tn ? S.y3_16 : t->a16,
@@ -587,6 +679,7 @@ static int forward_train(vn_train* t, int B, int T, const vn_train_params* p, hi
         if ((rc = vn_launch_resid_dropout(ctx, S.x_mid, t->tmp, x_out, M, D, make_drop(p, l, SITE_RES2, r_tok), s))) return rc;
     }
     const bool f16 = (D == 256 || D == 1280) && x3_shape(t, t->NV, D);
+    if (t->w_pending) { VN_HIP_CHECK(ctx, hipStreamWaitEvent(s, t->ev_w[L], 0)); t->w_pending = false; }
     uint16_t* const yf16 = t->tn ? t->yf16 : t->a16;
     if ((rc = vn_launch_rmsnorm(ctx, t->x_last, P(t, VN_W_FINAL_NORM), t->y_f, M, D, m->d.eps, s, f16 ? yf16 : nullptr, VN_PLANES_TILED, true))) return rc;
     return gemm(t, t->y_f, P(t, VN_W_CLS_W), P(t, VN_W_CLS_B), m->logits, M, t->NV, D, VN_EPI_BIAS, s, f16, yf16);
@@ -598,25 +691,62 @@ static int forward_train(vn_train* t, int B, int T, const vn_train_params* p, hi
 // X16 (vn_train::tn): the tiled planes of X the forward GEMM read (the layer's stash); dy_ready: dY's tiled planes are in t->a16 already.
 // Then nothing is transposed: both operands go to the kernel token-major (gemm_x3.hip X3_MODE_TN), dY's planes — written here by one
 // split pass unless they exist — serve the dX GEMM that follows as before.
+// the plane buffer the NEXT dY operand goes into (vn_train::overlap: one of NB rotating buffers, waited free on the caller's stream if a
+// side GEMM of this backward call still reads it; otherwise always t->a16)
+static int plane_buf(vn_train* t, hipStream_t s, uint16_t** buf, int* slot) {
+    if (!t->overlap) { *buf = t->a16; *slot = 0; return VN_OK; }
+    const int i = t->buf_next;
+    t->buf_next = (i + 1) % vn_train::NB;
+    if (t->buf_busy[i]) {
+        VN_HIP_CHECK(t->m->ctx, hipStreamWaitEvent(s, t->ev_done[i], 0));
+        t->buf_busy[i] = false;
+    }
+    *buf = t->a16r[i]; *slot = i;
+    return VN_OK;
+}
+// end of a backward call: everything the side stream was given is complete when the caller's stream gets here
+static int side_join(vn_train* t, hipStream_t s) {
+    if (!t->overlap || !t->side_used) return VN_OK;
+    vn_ctx* ctx = t->m->ctx;
+    VN_HIP_CHECK(ctx, hipEventRecord(t->ev_join, t->side));
+    VN_HIP_CHECK(ctx, hipStreamWaitEvent(s, t->ev_join, 0));
+    for (int i = 0; i < vn_train::NB; ++i) t->buf_busy[i] = false;
+    t->side_used = false;
+    return VN_OK;
+}
+
+// dy16 / slot: the plane buffer of plane_buf() this dY uses (holds dY's planes already if dy_ready); side: this GEMM may run on the side
+// stream (its result is read by nothing before the end of the backward call)
 static int grad_weight(vn_train* t, const float* dY, const float* X, float* dW, int M, int N, int K, hipStream_t s, bool* dy_planes = nullptr,
-                       const uint16_t* X16 = nullptr, bool dy_ready = false) {
+                       const uint16_t* X16 = nullptr, bool dy_ready = false, uint16_t* dy16 = nullptr, int slot = 0, bool side = false) {
     vn_ctx* ctx = t->m->ctx;
     const int Mp = (M + 31) & ~31;
     int rc;
     if (dy_planes) *dy_planes = false;
+    if (!dy16) dy16 = t->a16;
     if (t->tn && X16 && x3_shape(t, N, K) && !(K & 63)) {      // x3_shape(N, K): the forward GEMM of this weight ran on the pipe and filled X16
-        if (!dy_ready && (rc = vn_launch_split3_tiled(ctx, dY, t->a16, M, N, N, s))) return rc;
+        if (!dy_ready && (rc = vn_launch_split3_tiled(ctx, dY, dy16, M, N, N, s))) return rc;
         if (dy_planes) *dy_planes = true;
         vn_gemm_args a{};
-        a.A = (const float*)t->a16; a.W = (const float*)X16; a.C = dW; a.M = N; a.N = K; a.K = Mp; a.ldc = K;
+        a.A = (const float*)dy16; a.W = (const float*)X16; a.C = dW; a.M = N; a.N = K; a.K = Mp; a.ldc = K;
         a.bf16 = 2; a.a_plane = VN_PLANES_TILED; a.w_plane = VN_PLANES_TILED; a.w_tiled = 1;
         a.tn_blocks = (M + 15) >> 4;
+        if (side && t->overlap && dy16 == t->a16r[slot]) {
+            VN_HIP_CHECK(ctx, hipEventRecord(t->ev_ready[slot], s));
+            VN_HIP_CHECK(ctx, hipStreamWaitEvent(t->side, t->ev_ready[slot], 0));
+            rc = vn_launch_gemm_x3(t->ctx2, a, VN_EPI_STORE, t->side);
+            if (rc) return vn_fail(ctx, rc, "weight-gradient GEMM on the side stream: %s", t->ctx2->err);
+            VN_HIP_CHECK(ctx, hipEventRecord(t->ev_done[slot], t->side));
+            t->buf_busy[slot] = true;
+            t->side_used = true;
+            return VN_OK;
+        }
         return vn_launch_gemm_x3(ctx, a, VN_EPI_STORE, s);
     }
     if (t->x3 && !(N & 15) && !(K & 63)) {
         // both operands as tiled planes straight out of the transposes: A = dY^T [N][Mp], W = X^T [K][Mp], contraction over the tokens
         const bool both = dy_planes && !(N & 31);
-        if ((rc = vn_launch_transpose_split3_tiled(ctx, dY, t->at16, M, N, N, Mp, s, both ? t->a16 : nullptr))) return rc;
+        if ((rc = vn_launch_transpose_split3_tiled(ctx, dY, t->at16, M, N, N, Mp, s, both ? dy16 : nullptr))) return rc;
         if (both) *dy_planes = true;
         if ((rc = vn_launch_transpose_split3_tiled(ctx, X, t->bt16, M, K, K, Mp, s))) return rc;
         vn_gemm_args a{};
@@ -634,7 +764,13 @@ static int grad_weight(vn_train* t, const float* dY, const float* X, float* dW, 
 // Backward over the stages hi >= ... >= lo of the stashed forward: stage L = classifier + final norm, stages L-1 .. 0 =
 // transformer layers, stage -1 = codebook embedding.  Between stages the running gradient lives in t->dxa, so a caller
 // may interleave its own work (e.g. the all-reduce of the gradient slices that are already final) between calls.
+static int backward_body(vn_train* t, const vn_train_params* p, float* grads, int hi, int lo, hipStream_t s);
 static int backward_range(vn_train* t, const vn_train_params* p, float* grads, int hi, int lo, hipStream_t s) {
+    const int rc = backward_body(t, p, grads, hi, lo, s);
+    const int rj = side_join(t, s);             // (also after an error: nothing of this call is left running on the side stream)
+    return rc ? rc : rj;
+}
+static int backward_body(vn_train* t, const vn_train_params* p, float* grads, int hi, int lo, hipStream_t s) {
     vn_model* m = t->m;
     vn_ctx* ctx = m->ctx;
     const int B = t->B, T = t->T;
@@ -671,21 +807,26 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
         const float* wTl = t->wT + t->wT_layer * l;
         // ---- feed-forward branch (transformer.py:72-85, :360-367)
         const vn_drop d2 = make_drop(p, l, SITE_RES2, r_tok);
-        bool dy16 = false;                             // grad_weight left dY's planes in t->a16 for the dX GEMM that follows it
+        bool dy16 = false;                             // grad_weight left dY's planes in the plane buffer for the dX GEMM that follows it
+        uint16_t* pb;                                  // the plane buffer of the current dY (plane_buf: t->a16, or one of the rotating ones)
+        int ps;
         const float* dh = dx;
-        // (vn_train::tn: the mask kernel writes dh's tiled planes into t->a16 as well — both GEMMs below read them, no split pass)
+        // (vn_train::tn: the mask kernel writes dh's tiled planes as well — both GEMMs below read them, no split pass)
         const bool dh16 = t->tn && d2.thresh16 && x3_shape(t, 2 * D, D);
-        if (d2.thresh16) { if ((rc = vn_launch_dropout_bwd(ctx, dx, t->dh, M, D, d2, s, dh16 ? t->a16 : nullptr))) return rc; dh = t->dh; }
+        if ((rc = plane_buf(t, s, &pb, &ps))) return rc;
+        if (d2.thresh16) { if ((rc = vn_launch_dropout_bwd(ctx, dx, t->dh, M, D, d2, s, dh16 ? pb : nullptr))) return rc; dh = t->dh; }
         if (lora) { rc = lora_grads(t, S.g, 2 * D, dh, D, l, LORA_W2, grads, M, s); dy16 = dh16; }
-        else rc = grad_weight(t, dh, S.g, G(t, grads, VN_W_W2, l), M, D, 2 * D, s, &dy16, S.g_16, dh16);
+        else rc = grad_weight(t, dh, S.g, G(t, grads, VN_W_W2, l), M, D, 2 * D, s, &dy16, S.g_16, dh16, pb, ps, true);
         if (rc) return rc;
-        if ((rc = gemm(t, dh, wTl + 8L * D * D, nullptr, t->dg, M, 2 * D, D, VN_EPI_STORE, s, dy16 && x3_shape(t, 2 * D, D)))) return rc;
-        const bool du16 = x3_shape(t, D, 4 * D);       // du's planes (t->a16): the A operand of the dW GEMM (token-major form) and of the dX GEMM below; nothing in between writes t->a16
-        if ((rc = vn_launch_geglu_train(ctx, S.u, t->dg, t->du, M, 2 * D, make_drop(p, l, SITE_FFN, r_tok), true, s, du16 ? t->a16 : nullptr))) return rc;
+        if ((rc = gemm(t, dh, wTl + 8L * D * D, nullptr, t->dg, M, 2 * D, D, VN_EPI_STORE, s, dy16 && x3_shape(t, 2 * D, D), pb))) return rc;
+        const bool du16 = x3_shape(t, D, 4 * D);       // du's planes: the A operand of the dW GEMM (token-major form) and of the dX GEMM below; nothing in between writes the buffer
+        if ((rc = plane_buf(t, s, &pb, &ps))) return rc;
+        if ((rc = vn_launch_geglu_train(ctx, S.u, t->dg, t->du, M, 2 * D, make_drop(p, l, SITE_FFN, r_tok), true, s, du16 ? pb : nullptr))) return rc;
+        bool du_p = false;
         if (lora) rc = lora_grads(t, S.y3, D, t->du, 4 * D, l, LORA_W1, grads, M, s);
-        else rc = grad_weight(t, t->du, S.y3, G(t, grads, VN_W_W1, l), M, 4 * D, D, s, nullptr, S.y3_16, du16);
+        else rc = grad_weight(t, t->du, S.y3, G(t, grads, VN_W_W1, l), M, 4 * D, D, s, &du_p, S.y3_16, du16, pb, ps, true);
         if (rc) return rc;
-        if ((rc = gemm(t, t->du, wTl + 4L * D * D, nullptr, t->dy, M, D, 4 * D, VN_EPI_STORE, s, du16))) return rc;
+        if ((rc = gemm(t, t->du, wTl + 4L * D * D, nullptr, t->dy, M, D, 4 * D, VN_EPI_STORE, s, du16 || (du_p && x3_shape(t, D, 4 * D)), pb))) return rc;
         if ((rc = vn_launch_rmsnorm_bwd(ctx, S.x_mid, P(t, VN_W_NORM3, l), t->dy, dx, dx2, lora ? junk : G(t, grads, VN_W_NORM3, l),
                                         t->partial, M, D, m->d.eps, s)))
             return rc;
@@ -693,12 +834,13 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
         const vn_drop d1 = make_drop(p, l, SITE_RES1, r_tok);
         const float* dh2 = dx2;
         const bool dh216 = t->tn && d1.thresh16 && x3_shape(t, D, D);
-        if (d1.thresh16) { if ((rc = vn_launch_dropout_bwd(ctx, dx2, t->dh, M, D, d1, s, dh216 ? t->a16 : nullptr))) return rc; dh2 = t->dh; }
+        if ((rc = plane_buf(t, s, &pb, &ps))) return rc;
+        if (d1.thresh16) { if ((rc = vn_launch_dropout_bwd(ctx, dx2, t->dh, M, D, d1, s, dh216 ? pb : nullptr))) return rc; dh2 = t->dh; }
         dy16 = false;
         if (lora) { rc = lora_grads(t, S.a, D, dh2, D, l, LORA_FC, grads, M, s); dy16 = dh216; }
-        else rc = grad_weight(t, dh2, S.a, G(t, grads, VN_W_WO, l), M, D, D, s, &dy16, S.a_16, dh216);
+        else rc = grad_weight(t, dh2, S.a, G(t, grads, VN_W_WO, l), M, D, D, s, &dy16, S.a_16, dh216, pb, ps, true);
         if (rc) return rc;
-        if ((rc = gemm(t, dh2, wTl + 3L * D * D, nullptr, t->da, M, D, D, VN_EPI_STORE, s, dy16 && x3_shape(t, D, D)))) return rc;
+        if ((rc = gemm(t, dh2, wTl + 3L * D * D, nullptr, t->da, M, D, D, VN_EPI_STORE, s, dy16 && x3_shape(t, D, D), pb))) return rc;
         if (t->ax3)
             rc = vn_launch_attention_x3_bwd(ctx, S.qk16, t->qk_plane, S.vt16, t->vt_plane, t->ax_ws, m->bias_full, m->lut, t->near_r, S.a, t->da,
                                             S.lse, t->delta, t->dqkv, lora ? nullptr : t->dbias_partial + t->dbias_slab * l, B, H, T,
@@ -713,10 +855,11 @@ static int backward_range(vn_train* t, const vn_train_params* p, float* grads, i
             if ((rc = lora_grads(t, S.y1, D, t->dqkv, 3 * D, l, LORA_Q, grads, M, s))) return rc;
             rc = lora_grads(t, S.y1, D, t->dqkv + 2 * D, 3 * D, l, LORA_V, grads, M, s);
         } else {
-            rc = grad_weight(t, t->dqkv, S.y1, G(t, grads, VN_W_QKV, l), M, 3 * D, D, s, &dy16, S.y1_16);
+            if ((rc = plane_buf(t, s, &pb, &ps))) return rc;
+            rc = grad_weight(t, t->dqkv, S.y1, G(t, grads, VN_W_QKV, l), M, 3 * D, D, s, &dy16, S.y1_16, false, pb, ps, true);
         }
         if (rc) return rc;
-        if ((rc = gemm(t, t->dqkv, wTl, nullptr, t->dy, M, D, 3 * D, VN_EPI_STORE, s, dy16 && x3_shape(t, D, 3 * D)))) return rc;
+        if ((rc = gemm(t, t->dqkv, wTl, nullptr, t->dy, M, D, 3 * D, VN_EPI_STORE, s, dy16 && x3_shape(t, D, 3 * D), lora ? nullptr : pb))) return rc;
         if ((rc = vn_launch_rmsnorm_bwd(ctx, S.x_in, P(t, VN_W_NORM1, l), t->dy, dx2, dx, lora ? junk : G(t, grads, VN_W_NORM1, l),
                                         t->partial, M, D, m->d.eps, s)))
             return rc;

@@ -291,6 +291,11 @@ class Trainer:
     def _sync_derived(self):
         self.engine.check(self.lib.vn_train_sync(self.handle, self.engine.stream()), "vn_train_sync")
 
+    def set_overlap(self, on):
+        """run the layers' weight-gradient GEMMs on the trainer's side stream (True; the default, VN_TRAIN_OVERLAP) or in the caller's
+        stream (False); None = as created.  Between steps only.  Returns the state in effect."""
+        return bool(self.lib.vn_debug_train_overlap(self.handle, -1 if on is None else int(bool(on))))
+
     def _update_zero1(self, step, lr):
         """reduce-scatter -> global norm from the slices' sums of squares -> clip + AdamW on the own slice -> all-gather."""
         import torch.distributed as dist
