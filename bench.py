@@ -807,7 +807,7 @@ def main():
                 # the codec's convolutions (both directions; hipEvents around EVERY launch of the timed region), booked by the roofline that
                 # BOUNDS each layer (csrc/vn_common.h vn_conv_class: arithmetic intensity of the layer's own operand bytes against the ridge
                 # of the pipe it runs on): the matrix-pipe-bound layers on the split-plane pipe (ceiling 2500 / 6 TF-eq), those on the
-                # fp32-input MFMA (157.3 TF), and the byte-bound layers (audio-rate 64 / 96-channel layers, k = 1 tails; ceiling 8 TB/s).
+                # fp32-input MFMA (157.3 TF), and the byte-bound layers (audio-rate 64-channel layers, 2-tap phases, k = 1 tails; ceiling 8 TB/s).
                 # Algorithmic flops = 2 x MACs of each convolution as launched; algorithmic bytes = every operand read once, every result
                 # written once.  Parity of every one of these kernels is unpinned (lac absent).
                 def grp(key, bound, peak, unit):
@@ -823,7 +823,7 @@ def main():
                     "groups": {"mfma_split_plane_pipe": grp("conv_x3", "mfma", PEAK_BF16_MFMA_TF / 6.0, "TFLOP/s"),
                                "mfma_fp32_input": grp("conv_f32", "mfma", PEAK_F32_MFMA_TF, "TFLOP/s"),
                                "hbm": grp("conv_hbm", "hbm", 8000.0, "GB/s")},
-                    "kernel": "vn_gemm_x3_kernel<CONV> + vn_conv1d_f32_kernel", "launches": int(cn), "ms_per_step": cms / args.steps,
+                    "kernel": "vn_gemm_x3_kernel<CONV / CONVT> + vn_conv1d_f32_kernel", "launches": int(cn), "ms_per_step": cms / args.steps,
                     "algorithmic_tflop_per_step": cfl / args.steps / 1e12, "algorithmic_gbytes_per_step": cby / args.steps / 1e9,
                     "codec_parity": "unpinned"}
         res["setup_s"] = setup_s
