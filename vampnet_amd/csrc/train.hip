@@ -314,7 +314,10 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
             if (rc == VN_OK) {
                 int lo = 0, hi = 0;
                 (void)hipDeviceGetStreamPriorityRange(&lo, &hi);                   // lo = the LEAST urgent
-                bool ok = hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, lo) == hipSuccess;
+                // (VN_TRAIN_SIDE_PRIO=high|normal for A/B runs: the chain of the caller's stream is the critical path, so the default is low)
+                const char* pe = getenv("VN_TRAIN_SIDE_PRIO");
+                const int prio = pe && pe[0] == 'h' ? hi : pe && pe[0] == 'n' ? 0 : lo;
+                bool ok = hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, prio) == hipSuccess;
                 for (int i = 0; i < vn_train::NB && ok; ++i)
                     ok = hipEventCreateWithFlags(&t->ev_ready[i], hipEventDisableTiming) == hipSuccess &&
                          hipEventCreateWithFlags(&t->ev_done[i], hipEventDisableTiming) == hipSuccess;
