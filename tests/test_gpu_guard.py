@@ -50,7 +50,10 @@ def test_harness_kills_a_process_that_reads_one_word_past_its_buffer():
 # generate, every attention decomposition, the 50-call training attention, ragged training steps) and EVERY single-op kernel test — 423
 # tests, ~80-90 s per mode.  The WHOLE suite under guard pages (710 tests per mode, 29 145 guard blocks, 11 minutes each) is
 # scripts/gpu_guard_full.sh; its logs are profiles/r06_guard_full_{end,start}.log.
-GUARDED = ["tests/test_gpu_guard_cases.py", "tests/test_gpu_kernels.py"]
+# (+ round 6's operand modes of the GEMM: the channels-on-rows convolutions with their per-tap gather; the token-major dW GEMMs are in
+# test_gpu_kernels.py, the training step with its side stream in the guard cases)
+GUARDED = ["tests/test_gpu_guard_cases.py", "tests/test_gpu_kernels.py",
+           "tests/test_gpu_codec.py::test_conv_channels_on_rows_equals_the_column_tile_form"]
 
 
 @pytest.mark.parametrize("mode", ["end", "start"])

@@ -91,9 +91,19 @@ hipError_t guard_alloc(void** out, size_t bytes, int mode) {
         const char* f = getenv("VN_GUARD_FILL");
         g_fill = f && *f ? (!strcmp(f, "none") ? 256 : (int)(strtol(f, nullptr, 0) & 0xff)) : 0xff;
     }
-    if (g_fill < 256 && (e = hipMemset(lo, g_fill, mapped)) != hipSuccess) {
-        (void)hipMemUnmap(lo, mapped); (void)hipMemRelease(b.handle); (void)hipMemAddressFree(b.base, b.reserved);
-        return e;
+    // The poison must be IN PLACE when the block is handed out.  hipMemset is asynchronous to the host and runs on the null stream: a
+    // copy through the DMA engines or a kernel on a non-blocking stream that writes the fresh block can overtake it — the poison then
+    // lands on top of real data (seen once in ~700 guarded tests: a mask tensor full of 0xff, a token -1 fetching row -1 of a table).  So
+    // the fill runs on a stream of its own and the allocator waits for THAT stream only (not for the device: other work stays in flight).
+    if (g_fill < 256) {
+        static hipStream_t fill_stream = nullptr;
+        if (!fill_stream && hipStreamCreateWithFlags(&fill_stream, hipStreamNonBlocking) != hipSuccess) fill_stream = nullptr;
+        e = hipMemsetAsync(lo, g_fill, mapped, fill_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(fill_stream);
+        if (e != hipSuccess) {
+            (void)hipMemUnmap(lo, mapped); (void)hipMemRelease(b.handle); (void)hipMemAddressFree(b.base, b.reserved);
+            return e;
+        }
     }
     if (sync_fill) (void)hipDeviceSynchronize();
     void* user = mode == 2 ? (void*)lo : (void*)(lo + (mapped - need));
