@@ -136,9 +136,15 @@ extern "C" int vn_ctx_create(int device, vn_ctx** out) {
     if (hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->cus <= 0) c->cus = 256;
     if (hipSetDevice(device) != hipSuccess) { delete c; return VN_ERR_HIP; }
     // the saturation ledger of the fp16 plane writers (vn_common.h): sticky words, read + cleared by vn_saturation_flags
+    // ... and the zero page (padding rows of the convolutions, token blocks past the end of a TN operand), here rather than at first use:
+    // a memset is asynchronous on the null stream, and a first launch on a NON-BLOCKING stream right behind a lazy one could read the
+    // page before it is cleared.  The synchronise makes both fills complete before the context exists.
     if (vn_dev_malloc((void**)&c->sat, VN_SAT_WORDS * sizeof(unsigned)) != hipSuccess ||
-        hipMemset(c->sat, 0, VN_SAT_WORDS * sizeof(unsigned)) != hipSuccess) {
+        hipMemset(c->sat, 0, VN_SAT_WORDS * sizeof(unsigned)) != hipSuccess ||
+        vn_dev_malloc((void**)&c->zero_page, 1024) != hipSuccess || hipMemset(c->zero_page, 0, 1024) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {
         (void)vn_dev_free(c->sat);
+        (void)vn_dev_free(c->zero_page);
         delete c;
         return VN_ERR_OOM;
     }

@@ -307,9 +307,7 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
             if (rc == VN_OK) rc = vn_ctx_create(ctx->device, &t->ctx2);
             if (rc == VN_OK) {
                 t->ctx2->tune = ctx->tune;
-                if (vn_dev_malloc((void**)&t->ctx2->zero_page, 1024) != hipSuccess || hipMemset(t->ctx2->zero_page, 0, 1024) != hipSuccess ||
-                    vn_dev_malloc((void**)&t->ctx2->x3_ws, (size_t)(32L << 20) * sizeof(float)) != hipSuccess)
-                    rc = VN_ERR_OOM;
+                if (vn_dev_malloc((void**)&t->ctx2->x3_ws, (size_t)(32L << 20) * sizeof(float)) != hipSuccess) rc = VN_ERR_OOM;
             }
             if (rc == VN_OK) {
                 int lo = 0, hi = 0;
@@ -351,6 +349,8 @@ extern "C" int vn_train_create(vn_model* m, float* params, vn_train** out) {
     if (rc == VN_OK) rc = talloc(ctx, &t->npartial, 1024);
     if (rc == VN_OK) rc = talloc(ctx, &t->t32, (size_t)rows * m->Cp);
     if (rc == VN_OK) rc = talloc(ctx, &t->n_valid, 4);
+    // (the zero fills above are asynchronous on the null stream; the trainer's own streams do not wait for that stream)
+    if (rc == VN_OK && hipDeviceSynchronize() != hipSuccess) rc = VN_ERR_HIP;
     if (rc != VN_OK) { vn_train_destroy(t); return rc; }
     *out = t;
     return VN_OK;
