@@ -611,6 +611,7 @@ static int plane_buffers(vn_model* m, bool attention_planes) {
             if ((rc = dev_alloc(m->ctx, &m->vt16, (size_t)3 * m->vt_plane))) return rc;
             // keys >= T of a head's last tile are multiplied by P = 0: they must be finite, so start from zeros
             VN_HIP_CHECK(m->ctx, hipMemset(m->vt16, 0, (size_t)3 * m->vt_plane * sizeof(uint16_t)));
+            VN_HIP_CHECK(m->ctx, hipDeviceSynchronize());   // (null-stream fills: complete before a launch on any other stream can follow)
         }
     }
     return VN_OK;

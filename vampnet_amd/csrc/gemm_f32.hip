@@ -475,6 +475,7 @@ static int sk_workspace(vn_ctx* ctx) {
     VN_HIP_CHECK(ctx, vn_dev_malloc((void**)&ctx->sk_slabs, (size_t)SK_MAX_BLOCKS * 128 * 128 * sizeof(float)));
     VN_HIP_CHECK(ctx, vn_dev_malloc((void**)&ctx->sk_flags, (SK_MAX_BLOCKS + 64) * sizeof(unsigned)));
     VN_HIP_CHECK(ctx, hipMemset(ctx->sk_flags, 0, (SK_MAX_BLOCKS + 64) * sizeof(unsigned)));
+    VN_HIP_CHECK(ctx, hipDeviceSynchronize());      // the fill runs on the null stream; the first launch may be on a stream that does not wait for it
     return VN_OK;
 }
 
